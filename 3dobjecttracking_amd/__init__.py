@@ -1,0 +1,29 @@
+"""MI355X-native implementation of M3T's per-frame pose-optimisation hot path.
+
+RegionModality correspondence lines + DepthModality ICP + the Gauss-Newton /
+Tikhonov solve behind Tracker::ExecuteTrackingStep, as hand-written HIP kernels
+for gfx950 behind a C-ABI (include/m3t_hip.h, csrc/libm3t_hip.so).  This Python
+package is only the thin host mirror used by tests and bench.py; a C++ host
+binds the same C-ABI directly.
+
+The directory name starts with a digit, so import it with
+    importlib.import_module("3dobjecttracking_amd")
+"""
+import os
+
+from . import host, synthetic  # noqa: F401
+from ._capi import CApi, M3TError  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "libm3t_hip.so")
+
+
+def open_context(device_id=0):
+    """Create one device context (one per GPU per host thread).
+
+    Fails loudly when the HIP extension has not been built or no GPU is
+    usable: there is no CPU fallback in the product path."""
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s missing: build it with `python __graft_entry__.py`" % LIB_PATH)
+    return CApi(LIB_PATH, "m3t_hip_", device_id)

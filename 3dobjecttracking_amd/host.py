@@ -1,0 +1,271 @@
+"""Host-side mirror of the reference's object graph for the hot path.
+
+Same class and method names as M3T (Body, ColorCamera, DepthCamera,
+RegionModel, DepthModel, RegionModality, DepthModality, Link, Optimizer,
+Constraint, Tracker with StartModalities / CalculateCorrespondences /
+CalculateGradientAndHessian / CalculateOptimization / CalculateResults /
+ExecuteTrackingStep; M3T/include/m3t/tracker.h:131-160), but every object is a
+handle into ONE batched device context behind the C-ABI: a Tracker call runs
+the step for all registered modalities in one launch sequence.
+
+Error behaviour follows the reference: steps return bool (False + message on
+stderr when something is not set up), constructors raise on invalid arguments.
+"""
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import _capi
+from ._capi import (DATA_LINE_DTYPE, DATA_POINT_DTYPE, DepthModalityParams, DepthModelDesc, Intrinsics, M3TError,
+                    RegionModalityParams, RegionModelDesc, fptr, iptr, pose_arg, pose_ret)
+
+
+class Tracker:
+    """m3t::Tracker restricted to the tracking step (tracker.cpp:344-364, 430-517)."""
+
+    def __init__(self, api, n_corr_iterations=5, n_update_iterations=2):
+        self.api = api
+        self.n_corr_iterations = n_corr_iterations
+        self.n_update_iterations = n_update_iterations
+        api.call("tracker_set_iterations", n_corr_iterations, n_update_iterations)
+
+    def _step(self, name, *args):
+        rc = self.api.raw(name, *args)
+        if rc < 0:
+            sys.stderr.write(self.api.last_error() + "\n")
+            return False
+        return True
+
+    def StartModalities(self, iteration):
+        return self._step("start_modalities", iteration)
+
+    def CalculateCorrespondences(self, iteration, corr_iteration):
+        return self._step("calculate_correspondences", iteration, corr_iteration)
+
+    def CalculateGradientAndHessian(self, iteration, corr_iteration, update_iteration):
+        return self._step("calculate_gradient_and_hessian", iteration, corr_iteration, update_iteration)
+
+    def CalculateOptimization(self, iteration, corr_iteration, update_iteration):
+        return self._step("calculate_optimization", iteration, corr_iteration, update_iteration)
+
+    def CalculateResults(self, iteration):
+        return self._step("calculate_results", iteration)
+
+    def ExecuteTrackingStep(self, iteration):
+        return self._step("execute_tracking_step", iteration)
+
+    def ExecuteTrackingCycle(self, iteration):  # ICG/RBGT/SRT3D name
+        return self._step("execute_tracking_cycle", iteration)
+
+    def Sync(self):
+        return self._step("sync")
+
+
+class Body:
+    def __init__(self, api, body2world_pose=np.eye(4)):
+        self.api = api
+        self.id = api.call("body_create", fptr(pose_arg(body2world_pose)))
+
+    def set_body2world_pose(self, pose):
+        self.api.call("body_set_body2world_pose", self.id, fptr(pose_arg(pose)))
+
+    def body2world_pose(self):
+        buf = np.zeros(16, np.float32)
+        self.api.call("body_get_body2world_pose", self.id, fptr(buf))
+        return pose_ret(buf)
+
+
+class _Camera:
+    def __init__(self, api, cam_id, width, height, bytes_per_pixel):
+        self.api = api
+        self.id = cam_id
+        self.width, self.height, self.bpp = width, height, bytes_per_pixel
+
+    def UpdateImage(self, image):
+        """image: (H, W, 3) uint8 BGR or (H, W) uint16; row stride taken from the array."""
+        a = np.asarray(image)
+        assert a.shape[0] == self.height and a.shape[1] == self.width, (a.shape, self.height, self.width)
+        assert a.itemsize * (a.shape[2] if a.ndim == 3 else 1) == self.bpp
+        if a.strides[1] != self.bpp or (a.ndim == 3 and a.strides[2] != 1):
+            a = np.ascontiguousarray(a)
+        self.api.call("camera_upload", self.id, a.ctypes.data_as(C.c_void_p), a.strides[0])
+        return True
+
+    def set_world2camera_pose(self, pose):
+        self.api.call("camera_set_world2camera_pose", self.id, fptr(pose_arg(pose)))
+
+
+def _intr(fu, fv, ppu, ppv, width, height):
+    return Intrinsics(fu, fv, ppu, ppv, width, height)
+
+
+class ColorCamera(_Camera):
+    def __init__(self, api, fu, fv, ppu, ppv, width, height, world2camera_pose=np.eye(4)):
+        i = _intr(fu, fv, ppu, ppv, width, height)
+        cid = api.call("color_camera_create", C.byref(i), fptr(pose_arg(world2camera_pose)))
+        super().__init__(api, cid, width, height, 3)
+
+
+class DepthCamera(_Camera):
+    def __init__(self, api, fu, fv, ppu, ppv, width, height, depth_scale, world2camera_pose=np.eye(4)):
+        i = _intr(fu, fv, ppu, ppv, width, height)
+        cid = api.call("depth_camera_create", C.byref(i), fptr(pose_arg(world2camera_pose)), depth_scale)
+        super().__init__(api, cid, width, height, 2)
+        self.depth_scale = depth_scale
+
+
+class RegionModel:
+    """Sparse viewpoint model for regions (runtime part of region_model.cpp)."""
+
+    def __init__(self, api, path=None, data_points=None, orientations=None, contour_lengths=None,
+                 stride_depth_offset=0.002, max_radius_depth_offset=0.05):
+        self.api = api
+        if path is not None:
+            self.id = api.call("region_model_load", str(path).encode())
+        else:
+            dp = np.ascontiguousarray(data_points, np.float32)
+            ori = np.ascontiguousarray(orientations, np.float32)
+            cl = np.ascontiguousarray(contour_lengths, np.float32)
+            assert dp.ndim == 3 and dp.shape[2] == _capi.M3T_REGION_POINT_FLOATS
+            d = RegionModelDesc(dp.shape[0], dp.shape[1], fptr(dp), fptr(ori), fptr(cl), stride_depth_offset,
+                                max_radius_depth_offset)
+            self.id = api.call("region_model_create", C.byref(d))
+        nv, npts, me = C.c_int(), C.c_int(), C.c_float()
+        api.call("region_model_info", self.id, C.byref(nv), C.byref(npts), C.byref(me))
+        self.n_views, self.n_points, self.max_contour_length = nv.value, npts.value, me.value
+
+    def GetClosestView(self, body2camera_pose):
+        v = C.c_int()
+        self.api.call("region_model_closest_view", self.id, fptr(pose_arg(body2camera_pose)), C.byref(v))
+        return v.value
+
+
+class DepthModel:
+    def __init__(self, api, path=None, data_points=None, orientations=None, surface_areas=None,
+                 stride_depth_offset=0.002, max_radius_depth_offset=0.05):
+        self.api = api
+        if path is not None:
+            self.id = api.call("depth_model_load", str(path).encode())
+        else:
+            dp = np.ascontiguousarray(data_points, np.float32)
+            ori = np.ascontiguousarray(orientations, np.float32)
+            sa = np.ascontiguousarray(surface_areas, np.float32)
+            assert dp.ndim == 3 and dp.shape[2] == _capi.M3T_DEPTH_POINT_FLOATS
+            d = DepthModelDesc(dp.shape[0], dp.shape[1], fptr(dp), fptr(ori), fptr(sa), stride_depth_offset,
+                               max_radius_depth_offset)
+            self.id = api.call("depth_model_create", C.byref(d))
+        nv, npts, me = C.c_int(), C.c_int(), C.c_float()
+        api.call("depth_model_info", self.id, C.byref(nv), C.byref(npts), C.byref(me))
+        self.n_views, self.n_points, self.max_surface_area = nv.value, npts.value, me.value
+
+    def GetClosestView(self, body2camera_pose):
+        v = C.c_int()
+        self.api.call("depth_model_closest_view", self.id, fptr(pose_arg(body2camera_pose)), C.byref(v))
+        return v.value
+
+
+class _Modality:
+    def gradient_hessian(self):
+        g = np.zeros(6, np.float32)
+        h = np.zeros(36, np.float32)
+        self.api.call("modality_get_gradient_hessian", self.id, fptr(g), fptr(h))
+        return g, h.reshape(6, 6).T.copy()
+
+    def gradient(self):
+        return self.gradient_hessian()[0]
+
+    def hessian(self):
+        return self.gradient_hessian()[1]
+
+    def set_gradient_hessian(self, g, h):
+        g = np.ascontiguousarray(g, np.float32).reshape(6)
+        h = np.ascontiguousarray(np.asarray(h, np.float32).reshape(6, 6).T).reshape(36)
+        self.api.call("modality_set_gradient_hessian", self.id, fptr(g), fptr(h))
+
+
+class RegionModality(_Modality):
+    def __init__(self, api, body, color_camera, region_model, depth_camera=None, params=None, **kw):
+        self.api = api
+        self.params = params if params is not None else RegionModalityParams(**kw)
+        self.id = api.call("region_modality_create", C.byref(self.params), body.id, color_camera.id,
+                           region_model.id, depth_camera.id if depth_camera is not None else -1)
+        self.n_bins = self.params.n_histogram_bins
+
+    def data_lines(self):
+        n = C.c_int()
+        cap = self.params.n_lines_max
+        out = np.zeros(cap, DATA_LINE_DTYPE)
+        self.api.call("region_modality_get_lines", self.id, out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        return out[:min(n.value, cap)]
+
+    def histograms(self):
+        n = self.n_bins ** 3
+        f = np.zeros(n, np.float32)
+        b = np.zeros(n, np.float32)
+        self.api.call("region_modality_get_histograms", self.id, fptr(f), fptr(b))
+        return f, b
+
+    def set_histograms(self, f, b):
+        f = np.ascontiguousarray(f, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        assert f.size == self.n_bins ** 3 and b.size == f.size
+        self.api.call("region_modality_set_histograms", self.id, fptr(f), fptr(b))
+
+
+class DepthModality(_Modality):
+    def __init__(self, api, body, depth_camera, depth_model, params=None, **kw):
+        self.api = api
+        self.params = params if params is not None else DepthModalityParams(**kw)
+        self.id = api.call("depth_modality_create", C.byref(self.params), body.id, depth_camera.id, depth_model.id)
+
+    def data_points(self):
+        n = C.c_int()
+        cap = self.params.n_points_max
+        out = np.zeros(cap, DATA_POINT_DTYPE)
+        self.api.call("depth_modality_get_points", self.id, out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        return out[:min(n.value, cap)]
+
+
+class Link:
+    def __init__(self, api, body=None, parent=None, body2joint_pose=np.eye(4), joint2parent_pose=np.eye(4),
+                 free_directions=(1, 1, 1, 1, 1, 1), fixed_body2joint_pose=True):
+        self.api = api
+        fd = np.asarray(free_directions, np.int32)
+        self.id = api.call("link_create", body.id if body is not None else -1,
+                           parent.id if parent is not None else -1, fptr(pose_arg(body2joint_pose)),
+                           fptr(pose_arg(joint2parent_pose)), iptr(fd), int(fixed_body2joint_pose))
+
+    def AddModality(self, modality):
+        self.api.call("link_add_modality", self.id, modality.id)
+
+    def link2world_pose(self):
+        buf = np.zeros(16, np.float32)
+        self.api.call("link_get_link2world_pose", self.id, fptr(buf))
+        return pose_ret(buf)
+
+
+class Optimizer:
+    def __init__(self, api, root_link=None, body=None, modalities=(), tikhonov_parameter_rotation=1000.0,
+                 tikhonov_parameter_translation=30000.0):
+        self.api = api
+        if root_link is not None:
+            self.id = api.call("optimizer_create", root_link.id, tikhonov_parameter_rotation,
+                               tikhonov_parameter_translation)
+        else:
+            ids = np.asarray([m.id for m in modalities], np.int32)
+            self.id = api.call("optimizer_create_rigid", body.id, len(ids), iptr(ids),
+                               tikhonov_parameter_rotation, tikhonov_parameter_translation)
+
+
+class Constraint:
+    def __init__(self, api, optimizer, link1, link2, body12joint1_pose=np.eye(4), body22joint2_pose=np.eye(4),
+                 constraint_directions=(0, 0, 0, 0, 0, 0)):
+        cd = np.asarray(constraint_directions, np.int32)
+        self.id = api.call("constraint_create", optimizer.id, link1.id, link2.id, fptr(pose_arg(body12joint1_pose)),
+                           fptr(pose_arg(body22joint2_pose)), iptr(cd))
+
+
+__all__ = ["Tracker", "Body", "ColorCamera", "DepthCamera", "RegionModel", "DepthModel", "RegionModality",
+           "DepthModality", "Link", "Optimizer", "Constraint", "M3TError", "RegionModalityParams",
+           "DepthModalityParams"]

@@ -1,0 +1,2074 @@
+// m3t_oracle.cpp — CPU restatement of M3T's per-frame pose-optimisation path.
+//
+// TEST INFRASTRUCTURE ONLY (see m3t_oracle.h).  Single-threaded scalar f32,
+// no Eigen / OpenCV.  Compile with -ffp-contract=off so every a*b+c rounds
+// twice like the expression trees written here (the reference's own binary
+// depends on its compiler's contraction choices).
+//
+// Conventions restated from the reference:
+//  * poses are Eigen::Transform<float,3,Affine>, column-major 4x4
+//    (M3T/include/m3t/common.h:19); T*v = t + L*v, T1*T2 = {L1*L2, L1*t2+t1}.
+//  * Transform::rotation() (polar factor via SVD) is replaced by linear();
+//    equal to ~1e-7 for rigid poses.
+//  * images: colour = BGR8 (cv::imread order), depth = u16.
+//
+// Citations are relative to /root/reference/M3T/.
+
+#include "m3t_oracle.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// small fixed-size math (column-major like Eigen)
+// ---------------------------------------------------------------------------
+struct Mat3 {
+  float m[9];  // (r,c) = m[c*3+r]
+  float& operator()(int r, int c) { return m[c * 3 + r]; }
+  float operator()(int r, int c) const { return m[c * 3 + r]; }
+};
+struct Mat4 {
+  float m[16];  // (r,c) = m[c*4+r]
+  float& operator()(int r, int c) { return m[c * 4 + r]; }
+  float operator()(int r, int c) const { return m[c * 4 + r]; }
+};
+
+Mat4 Identity4() {
+  Mat4 r;
+  for (int i = 0; i < 16; ++i) r.m[i] = 0.0f;
+  r(0, 0) = r(1, 1) = r(2, 2) = r(3, 3) = 1.0f;
+  return r;
+}
+Mat3 Identity3() {
+  Mat3 r;
+  for (int i = 0; i < 9; ++i) r.m[i] = 0.0f;
+  r(0, 0) = r(1, 1) = r(2, 2) = 1.0f;
+  return r;
+}
+Mat4 FromArray(const float* p) {
+  Mat4 r;
+  std::memcpy(r.m, p, sizeof(r.m));
+  return r;
+}
+Mat3 Linear(const Mat4& t) {
+  Mat3 r;
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < 3; ++k) r(k, c) = t(k, c);
+  return r;
+}
+// Eigen coefficient-based 3x3 products: ((a0*b0 + a1*b1) + a2*b2)
+Mat3 Mul3(const Mat3& a, const Mat3& b) {
+  Mat3 r;
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < 3; ++k)
+      r(k, c) = (a(k, 0) * b(0, c) + a(k, 1) * b(1, c)) + a(k, 2) * b(2, c);
+  return r;
+}
+void Mul3v(const Mat3& a, const float v[3], float out[3]) {
+  for (int k = 0; k < 3; ++k) out[k] = (a(k, 0) * v[0] + a(k, 1) * v[1]) + a(k, 2) * v[2];
+}
+// Transform * Vector3f  (Eigen: res = translation; res += linear * v)
+void Apply(const Mat4& t, const float v[3], float out[3]) {
+  for (int k = 0; k < 3; ++k)
+    out[k] = t(k, 3) + ((t(k, 0) * v[0] + t(k, 1) * v[1]) + t(k, 2) * v[2]);
+}
+// Transform * Transform (affine, non-projective)
+Mat4 Mul4(const Mat4& a, const Mat4& b) {
+  Mat4 r = Identity4();
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < 3; ++k)
+      r(k, c) = (a(k, 0) * b(0, c) + a(k, 1) * b(1, c)) + a(k, 2) * b(2, c);
+  for (int k = 0; k < 3; ++k)
+    r(k, 3) = ((a(k, 0) * b(0, 3) + a(k, 1) * b(1, 3)) + a(k, 2) * b(2, 3)) + a(k, 3);
+  return r;
+}
+// Eigen compute_inverse_size3: cofactors / determinant
+float Cofactor3(const Mat3& m, int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m(i1, j1) * m(i2, j2) - m(i1, j2) * m(i2, j1);
+}
+Mat3 Inverse3(const Mat3& m) {
+  float c00 = Cofactor3(m, 0, 0), c10 = Cofactor3(m, 1, 0), c20 = Cofactor3(m, 2, 0);
+  float det = (c00 * m(0, 0) + c10 * m(1, 0)) + c20 * m(2, 0);
+  float invdet = 1.0f / det;
+  Mat3 r;
+  for (int rr = 0; rr < 3; ++rr)
+    for (int cc = 0; cc < 3; ++cc) r(rr, cc) = Cofactor3(m, cc, rr) * invdet;
+  return r;
+}
+// Transform::inverse(Affine): linear().inverse(), translation = -(Linv * t)
+Mat4 InverseAffine(const Mat4& t) {
+  Mat3 li = Inverse3(Linear(t));
+  Mat4 r = Identity4();
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < 3; ++k) r(k, c) = li(k, c);
+  float tt[3] = {t(0, 3), t(1, 3), t(2, 3)}, o[3];
+  Mul3v(li, tt, o);
+  for (int k = 0; k < 3; ++k) r(k, 3) = -o[k];
+  return r;
+}
+inline float Dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+inline void Cross3(const float a[3], const float b[3], float o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline float sgnf(float v) { return v < 0.0f ? -1.0f : (v > 0.0f ? 1.0f : 0.0f); }  // common.h:46-54
+
+// M3T/include/m3t/common.h:62-68
+Mat3 Skew(const float v[3]) {
+  Mat3 s;
+  s(0, 0) = 0.0f;  s(0, 1) = -v[2]; s(0, 2) = v[1];
+  s(1, 0) = v[2];  s(1, 1) = 0.0f;  s(1, 2) = -v[0];
+  s(2, 0) = -v[1]; s(2, 1) = v[0];  s(2, 2) = 0.0f;
+  return s;
+}
+
+// 3x3 solve with partial pivoting (Eigen PartialPivLU semantics), X = A^-1 B
+Mat3 Solve3(Mat3 a, Mat3 b) {
+  int perm[3] = {0, 1, 2};
+  for (int k = 0; k < 3; ++k) {
+    int p = k;
+    float best = std::fabs(a(k, k));
+    for (int i = k + 1; i < 3; ++i)
+      if (std::fabs(a(i, k)) > best) { best = std::fabs(a(i, k)); p = i; }
+    if (p != k) {
+      for (int c = 0; c < 3; ++c) { std::swap(a(k, c), a(p, c)); std::swap(b(k, c), b(p, c)); }
+      std::swap(perm[k], perm[p]);
+    }
+    for (int i = k + 1; i < 3; ++i) {
+      float f = a(i, k) / a(k, k);
+      a(i, k) = f;
+      for (int c = k + 1; c < 3; ++c) a(i, c) -= f * a(k, c);
+      for (int c = 0; c < 3; ++c) b(i, c) -= f * b(k, c);
+    }
+  }
+  Mat3 x;
+  for (int c = 0; c < 3; ++c)
+    for (int i = 2; i >= 0; --i) {
+      float s = b(i, c);
+      for (int j = i + 1; j < 3; ++j) s -= a(i, j) * x(j, c);
+      x(i, c) = s / a(i, i);
+    }
+  return x;
+}
+
+// Matrix exponential of a 3x3 float matrix, Pade approximants with scaling and
+// squaring as in Eigen unsupported/MatrixFunctions (float thresholds), used by
+// Link::UpdatePoses (src/link.cpp:224: Vector2Skewsymmetric(theta).exp()).
+Mat3 AddScaled(const Mat3& a, float sa, const Mat3& b, float sb) {
+  Mat3 r;
+  for (int i = 0; i < 9; ++i) r.m[i] = sa * a.m[i] + sb * b.m[i];
+  return r;
+}
+Mat3 Expm3(const Mat3& a_in) {
+  float l1 = 0.0f;
+  for (int c = 0; c < 3; ++c) {
+    float s = 0.0f;
+    for (int r = 0; r < 3; ++r) s += std::fabs(a_in(r, c));
+    l1 = std::max(l1, s);
+  }
+  Mat3 I = Identity3();
+  Mat3 U, V;
+  int squarings = 0;
+  Mat3 a = a_in;
+  if (l1 < 4.258730016922831e-001f) {
+    const float b[] = {120.f, 60.f, 12.f, 1.f};
+    Mat3 a2 = Mul3(a, a);
+    Mat3 tmp = AddScaled(a2, b[3], I, b[1]);
+    U = Mul3(a, tmp);
+    V = AddScaled(a2, b[2], I, b[0]);
+  } else if (l1 < 1.880152677804762e+000f) {
+    const float b[] = {30240.f, 15120.f, 3360.f, 420.f, 30.f, 1.f};
+    Mat3 a2 = Mul3(a, a), a4 = Mul3(a2, a2);
+    Mat3 tmp = AddScaled(AddScaled(a4, b[5], a2, b[3]), 1.0f, I, b[1]);
+    U = Mul3(a, tmp);
+    V = AddScaled(AddScaled(a4, b[4], a2, b[2]), 1.0f, I, b[0]);
+  } else {
+    const float maxnorm = 3.925724783138660f;
+    int e;
+    std::frexp(l1 / maxnorm, &e);
+    squarings = std::max(0, e);
+    float sc = std::ldexp(1.0f, -squarings);
+    for (int i = 0; i < 9; ++i) a.m[i] *= sc;
+    const float b[] = {17297280.f, 8648640.f, 1995840.f, 277200.f, 25200.f, 1512.f, 56.f, 1.f};
+    Mat3 a2 = Mul3(a, a), a4 = Mul3(a2, a2), a6 = Mul3(a4, a2);
+    Mat3 tmp = AddScaled(AddScaled(AddScaled(a6, b[7], a4, b[5]), 1.0f, a2, b[3]), 1.0f, I, b[1]);
+    U = Mul3(a, tmp);
+    V = AddScaled(AddScaled(AddScaled(a6, b[6], a4, b[4]), 1.0f, a2, b[2]), 1.0f, I, b[0]);
+  }
+  Mat3 num = AddScaled(U, 1.0f, V, 1.0f);
+  Mat3 den = AddScaled(U, -1.0f, V, 1.0f);
+  Mat3 r = Solve3(den, num);
+  for (int i = 0; i < squarings; ++i) r = Mul3(r, r);
+  return r;
+}
+
+// Eigen::AngleAxisf(Matrix3f): quaternion from matrix, then angle/axis.
+void AngleAxisFromRotation(const Mat3& mat, float* angle, float axis[3]) {
+  float q[4];  // x y z w
+  float t = mat(0, 0) + mat(1, 1) + mat(2, 2);
+  if (t > 0.0f) {
+    t = std::sqrt(t + 1.0f);
+    q[3] = 0.5f * t;
+    t = 0.5f / t;
+    q[0] = (mat(2, 1) - mat(1, 2)) * t;
+    q[1] = (mat(0, 2) - mat(2, 0)) * t;
+    q[2] = (mat(1, 0) - mat(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (mat(1, 1) > mat(0, 0)) i = 1;
+    if (mat(2, 2) > mat(i, i)) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(mat(i, i) - mat(j, j) - mat(k, k) + 1.0f);
+    q[i] = 0.5f * t;
+    t = 0.5f / t;
+    q[3] = (mat(k, j) - mat(j, k)) * t;
+    q[j] = (mat(j, i) + mat(i, j)) * t;
+    q[k] = (mat(k, i) + mat(i, k)) * t;
+  }
+  float n = std::sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
+  if (n != 0.0f) {
+    *angle = 2.0f * std::atan2(n, std::fabs(q[3]));
+    if (q[3] < 0.0f) n = -n;
+    for (int c = 0; c < 3; ++c) axis[c] = q[c] / n;
+  } else {
+    *angle = 0.0f;
+    axis[0] = 1.0f; axis[1] = 0.0f; axis[2] = 0.0f;
+  }
+}
+
+// common.h:73-77
+float xcotx(float x) {
+  if (std::tan(x) <= std::numeric_limits<float>::min()) return 1.0f;
+  if (std::tan(x) >= std::numeric_limits<float>::max()) return 0.0f;
+  return float(double(x) / std::tan(double(x)));  // reference mixes float x with double tan()
+}
+
+// Eigen::LDLT<MatrixXf, Lower>: A = P^T L D L^T P with diagonal pivoting,
+// followed by solve() with the pseudo-inverse of D (optimizer.cpp:162-163).
+// `a` is n x n column-major; only the lower triangle is read.
+std::vector<float> LdltSolve(std::vector<float> a, const std::vector<float>& b_in, int n) {
+  auto A = [&](int r, int c) -> float& { return a[size_t(c) * n + r]; };
+  std::vector<int> trans(n);
+  std::vector<float> temp(n);
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    float best = std::fabs(A(k, k));
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(A(i, i)) > best) { best = std::fabs(A(i, i)); piv = i; }
+    trans[k] = piv;
+    if (piv != k) {
+      int s = n - piv - 1;
+      for (int c = 0; c < k; ++c) std::swap(A(k, c), A(piv, c));
+      for (int i = 0; i < s; ++i) std::swap(A(piv + 1 + i, k), A(piv + 1 + i, piv));
+      std::swap(A(k, k), A(piv, piv));
+      for (int i = k + 1; i < piv; ++i) std::swap(A(i, k), A(piv, i));
+    }
+    int rs = n - k - 1;
+    if (k > 0) {
+      for (int c = 0; c < k; ++c) temp[c] = A(c, c) * A(k, c);
+      float acc = 0.0f;
+      for (int c = 0; c < k; ++c) acc += A(k, c) * temp[c];
+      A(k, k) -= acc;
+      for (int i = 0; i < rs; ++i) {
+        float s = 0.0f;
+        for (int c = 0; c < k; ++c) s += A(k + 1 + i, c) * temp[c];
+        A(k + 1 + i, k) -= s;
+      }
+    }
+    float akk = A(k, k);
+    bool pivot_valid = std::fabs(akk) > 0.0f;
+    if (k == 0 && !pivot_valid) {
+      for (int j = 0; j < n; ++j) trans[j] = j;
+      break;
+    }
+    if (rs > 0 && pivot_valid)
+      for (int i = 0; i < rs; ++i) A(k + 1 + i, k) /= akk;
+  }
+  std::vector<float> x = b_in;
+  for (int k = 0; k < n; ++k) std::swap(x[k], x[trans[k]]);
+  for (int i = 0; i < n; ++i) {
+    float s = x[i];
+    for (int c = 0; c < i; ++c) s -= A(i, c) * x[c];
+    x[i] = s;
+  }
+  const float tolerance = std::numeric_limits<float>::min();
+  for (int i = 0; i < n; ++i) {
+    if (std::fabs(A(i, i)) > tolerance) x[i] /= A(i, i);
+    else x[i] = 0.0f;
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    float s = x[i];
+    for (int r = i + 1; r < n; ++r) s -= A(r, i) * x[r];
+    x[i] = s;
+  }
+  for (int k = n - 1; k >= 0; --k) std::swap(x[k], x[trans[k]]);
+  return x;
+}
+
+// ---------------------------------------------------------------------------
+// ColorHistograms  (src/color_histograms.cpp)
+// ---------------------------------------------------------------------------
+struct Histograms {
+  int n_bins = 16, bitshift = 4, n_bins_squared = 256, n_bins_cubed = 4096;
+  float learning_rate_f = 0.2f, learning_rate_b = 0.2f;
+  std::vector<float> memory_f, memory_b, histogram_f, histogram_b;
+
+  // PrecalculateVariables :131-158 + SetUpHistograms :160-172
+  bool SetUp(int bins, float lf, float lb) {
+    switch (bins) {
+      case 2: bitshift = 7; break;
+      case 4: bitshift = 6; break;
+      case 8: bitshift = 5; break;
+      case 16: bitshift = 4; break;
+      case 32: bitshift = 3; break;
+      case 64: bitshift = 2; break;
+      default: return false;
+    }
+    n_bins = bins;
+    n_bins_squared = bins * bins;
+    n_bins_cubed = bins * bins * bins;
+    learning_rate_f = lf;
+    learning_rate_b = lb;
+    memory_f.assign(n_bins_cubed, 0.0f);
+    memory_b.assign(n_bins_cubed, 0.0f);
+    float uniform_value = 1.0f / float(n_bins_cubed);
+    histogram_f.assign(n_bins_cubed, uniform_value);
+    histogram_b.assign(n_bins_cubed, uniform_value);
+    return true;
+  }
+  // :94-102 (index: channel 0 (B) most significant)
+  int Index(const uint8_t* c) const {
+    return (c[0] >> bitshift) * n_bins_squared + (c[1] >> bitshift) * n_bins + (c[2] >> bitshift);
+  }
+  void ClearMemory() {  // :50-58
+    std::fill(memory_f.begin(), memory_f.end(), 0.0f);
+    std::fill(memory_b.begin(), memory_b.end(), 0.0f);
+  }
+  void AddForegroundColor(const uint8_t* c) { memory_f[Index(c)] += 1.0f; }  // :60-64
+  void AddBackgroundColor(const uint8_t* c) { memory_b[Index(c)] += 1.0f; }  // :66-70
+  // :174-214
+  void CalculateHistogram(float learning_rate, const std::vector<float>& memory, std::vector<float>* histogram) {
+    float sum = 0.0f;
+    for (int i = 0; i < n_bins_cubed; i++) sum += memory[i];
+    if (!sum) {
+      if (learning_rate == 1.0f) {
+        float uniform_value = 1.0f / n_bins_cubed;
+        std::fill(histogram->begin(), histogram->end(), uniform_value);
+      }
+      return;
+    }
+    float complement_learning_rate = 1.0f - learning_rate;
+    float learning_rate_divide_sum = learning_rate / sum;
+    if (complement_learning_rate == 0.0f) {
+      for (int i = 0; i < n_bins_cubed; i++) (*histogram)[i] = memory[i] * learning_rate_divide_sum;
+    } else {
+      for (int i = 0; i < n_bins_cubed; i++) {
+        (*histogram)[i] *= complement_learning_rate;
+        (*histogram)[i] += memory[i] * learning_rate_divide_sum;
+      }
+    }
+  }
+  void InitializeHistograms() {  // :72-81
+    CalculateHistogram(1.0f, memory_f, &histogram_f);
+    CalculateHistogram(1.0f, memory_b, &histogram_b);
+    ClearMemory();
+  }
+  void UpdateHistograms() {  // :83-92
+    CalculateHistogram(learning_rate_f, memory_f, &histogram_f);
+    CalculateHistogram(learning_rate_b, memory_b, &histogram_b);
+    ClearMemory();
+  }
+  void GetProbabilities(const uint8_t* c, float* pf, float* pb) const {  // :94-102
+    int idx = Index(c);
+    *pf = histogram_f[idx];
+    *pb = histogram_b[idx];
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Sparse viewpoint models (runtime part)
+// ---------------------------------------------------------------------------
+struct SparseModel {
+  bool is_region = true;
+  int n_views = 0, n_points = 0, point_floats = 0;
+  std::vector<float> data_points;   // [n_views][n_points][point_floats]
+  std::vector<float> orientations;  // [n_views][3]
+  std::vector<float> extents;       // contour_length | surface_area
+  float stride_depth_offset = 0.002f, max_radius_depth_offset = 0.05f;
+  float max_extent = 0.0f;
+
+  const float* Point(int view, int i) const {
+    return &data_points[(size_t(view) * n_points + i) * point_floats];
+  }
+  // RegionModel::GetClosestView src/region_model.cpp:105-130 (== depth_model.cpp:81-106)
+  int GetClosestView(const Mat4& body2camera_pose) const {
+    float t[3] = {body2camera_pose(0, 3), body2camera_pose(1, 3), body2camera_pose(2, 3)};
+    float norm = std::sqrt(Dot3(t, t));
+    if (norm == 0.0f) return 0;
+    float tn[3] = {t[0] / norm, t[1] / norm, t[2] / norm};
+    Mat3 rinv = Inverse3(Linear(body2camera_pose));
+    float orientation[3];
+    Mul3v(rinv, tn, orientation);
+    float closest_dot = -1.0f;
+    int closest = 0;
+    for (int v = 0; v < n_views; ++v) {
+      float dot = Dot3(orientation, &orientations[size_t(v) * 3]);
+      if (dot > closest_dot) { closest = v; closest_dot = dot; }
+    }
+    return closest;
+  }
+};
+
+// .bin parser: src/model.cpp:218-284 (parameters + body data),
+// src/region_model.cpp:259-307,346-363, src/depth_model.cpp:215-283
+bool ReadBodyData(std::ifstream& ifs) {
+  uint64_t len = 0;
+  ifs.read((char*)&len, sizeof(len));
+  if (!ifs || len > (1u << 20)) return false;
+  ifs.seekg(std::streamoff(len), std::ios::cur);
+  ifs.seekg(4 + 1 + 1 + 4 + 64, std::ios::cur);
+  return bool(ifs);
+}
+bool LoadSparseModel(const char* path, bool region, SparseModel* m, std::string* err) {
+  std::ifstream ifs{path, std::ios::in | std::ios::binary};
+  if (!ifs.is_open()) { *err = std::string("Could not open model file ") + path; return false; }
+  char model_type; int32_t version_id;
+  float sphere_radius; int32_t n_divides, n_points; float max_radius, stride; uint8_t use_random_seed; int32_t image_size;
+  ifs.read(&model_type, 1);
+  ifs.read((char*)&version_id, 4);
+  ifs.read((char*)&sphere_radius, 4);
+  ifs.read((char*)&n_divides, 4);
+  ifs.read((char*)&n_points, 4);
+  ifs.read((char*)&max_radius, 4);
+  ifs.read((char*)&stride, 4);
+  ifs.read((char*)&use_random_seed, 1);
+  ifs.read((char*)&image_size, 4);
+  if (!ifs) { *err = "truncated model header"; return false; }
+  if (region ? (model_type != 'r') : (model_type != 'd')) { *err = "Wrong model type"; return false; }
+  if (!ReadBodyData(ifs)) { *err = "bad body data"; return false; }
+  uint64_t n_assoc = 0;
+  ifs.read((char*)&n_assoc, 8);
+  if (region) {
+    for (int g = 0; g < 4; ++g) {
+      uint64_t n = 0;
+      ifs.read((char*)&n, 8);
+      for (uint64_t i = 0; i < n; ++i)
+        if (!ReadBodyData(ifs)) { *err = "bad associated body data"; return false; }
+    }
+  } else {
+    for (uint64_t i = 0; i < n_assoc; ++i)
+      if (!ReadBodyData(ifs)) { *err = "bad occlusion body data"; return false; }
+  }
+  uint64_t n_views = 0;
+  ifs.read((char*)&n_views, 8);
+  if (!ifs || n_views == 0 || n_views > (1u << 24) || n_points <= 0) { *err = "bad view count"; return false; }
+  m->is_region = region;
+  m->n_views = int(n_views);
+  m->n_points = n_points;
+  m->point_floats = region ? M3T_REGION_POINT_FLOATS : M3T_DEPTH_POINT_FLOATS;
+  m->stride_depth_offset = stride;
+  m->max_radius_depth_offset = max_radius;
+  m->data_points.resize(size_t(n_views) * n_points * m->point_floats);
+  m->orientations.resize(size_t(n_views) * 3);
+  m->extents.resize(n_views);
+  for (uint64_t v = 0; v < n_views; ++v) {
+    ifs.read((char*)&m->data_points[v * n_points * m->point_floats], size_t(n_points) * m->point_floats * 4);
+    ifs.read((char*)&m->orientations[v * 3], 12);
+    ifs.read((char*)&m->extents[v], 4);
+  }
+  if (!ifs) { *err = "truncated view data"; return false; }
+  m->max_extent = 0.0f;
+  for (float e : m->extents) m->max_extent = std::max(m->max_extent, e);
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// data holders
+// ---------------------------------------------------------------------------
+struct Camera {
+  bool is_depth = false;
+  m3t_intrinsics intr{};
+  Mat4 world2camera = Identity4();
+  float depth_scale = 0.001f;
+  std::vector<uint8_t> image;  // tightly packed rows
+  bool has_image = false;
+  const uint8_t* Pixel(int row, int col) const { return &image[(size_t(row) * intr.width + col) * 3]; }
+  uint16_t Depth(int row, int col) const {
+    uint16_t v;
+    std::memcpy(&v, &image[(size_t(row) * intr.width + col) * 2], 2);
+    return v;
+  }
+};
+struct Body {
+  Mat4 body2world = Identity4();
+};
+
+template <typename T>
+T LastValidValue(const T* values, int n, int idx) {  // common.h:171-176
+  return idx < n ? values[idx] : values[n - 1];
+}
+
+struct Modality {
+  bool is_region = true;
+  int body = -1;
+  float gradient[6] = {0, 0, 0, 0, 0, 0};
+  float hessian[36] = {0};  // column-major symmetric
+  virtual ~Modality() {}
+  virtual bool StartModality(int iteration, int corr_iteration) = 0;
+  virtual bool CalculateCorrespondences(int iteration, int corr_iteration) = 0;
+  virtual bool CalculateGradientAndHessian(int iteration, int corr_iteration, int opt_iteration) = 0;
+  virtual bool CalculateResults(int iteration) = 0;
+};
+
+struct Context;
+
+// ---------------------------------------------------------------------------
+// RegionModality  (src/region_modality.cpp)
+// ---------------------------------------------------------------------------
+struct DataLine {  // region_modality.h:108-124
+  float center_f_body[3];
+  float center_f_camera[3];
+  float center_u, center_v, normal_u, normal_v;
+  float measured_depth_offset;
+  float continuous_distance;
+  float delta_r, normal_component_to_scale;
+  float distribution[M3T_MAX_DISTRIBUTION_LENGTH];
+  float mean, measured_variance;
+  int model_point_index;
+};
+
+struct RegionModality : Modality {
+  m3t_region_modality_params p{};
+  Context* ctx = nullptr;
+  int color_camera = -1, depth_camera = -1, model = -1;
+  Histograms hist;
+  // PrecalculateFunctionLookup / DistributionVariables
+  float function_lookup_f[M3T_MAX_FUNCTION_LENGTH], function_lookup_b[M3T_MAX_FUNCTION_LENGTH];
+  int line_length_in_segments = 0;
+  float distribution_length_minus_1_half = 0, distribution_length_plus_1_half = 0, min_expected_variance = 0;
+  // camera variables
+  float fu, fv, ppu, ppv;
+  int image_width_minus_1, image_height_minus_1, image_width_minus_2, image_height_minus_2;
+  float depth_fu, depth_fv, depth_ppu, depth_ppv, depth_scale;
+  int depth_image_width_minus_1, depth_image_height_minus_1;
+  int measured_depth_offset_id = 0;
+  // pose variables
+  Mat4 body2camera_pose, body2depth_camera_pose;
+  Mat3 body2camera_rotation;
+  // iteration dependent
+  int scale = 1;
+  float fscale = 1;
+  int line_length = 0, line_length_minus_1 = 0;
+  float line_length_minus_1_half = 0, line_length_half_minus_1 = 0, variance = 0;
+  int first_iteration = 0;
+  std::vector<DataLine> data_lines;
+
+  bool SetUp();
+  void PrecalculatePoseVariables();
+  void PrecalculateIterationDependentVariables(int corr_iteration);
+  int NumberOfLines(int view) const;
+  void AddLinePixelColorsToTempHistograms(bool handle_occlusions);
+  void CalculateBasicLineData(const float* data_point, DataLine* data_line) const;
+  bool IsLineValid(const DataLine& data_line, bool measure_occlusions) const;
+  bool IsLineUnoccludedMeasured(const float center_f_body[3], float depth_offset) const;
+  bool CalculateSegmentProbabilities(float center_u, float center_v, float normal_u, float normal_v,
+                                     float* segment_probabilities_f, float* segment_probabilities_b,
+                                     float* normal_component_to_scale, float* delta_r) const;
+  void MultiplyPixelColorProbability(const uint8_t* pixel_color, float* probability_f,
+                                     float* probability_b) const;
+  void CalculateDistribution(const float* sf, const float* sb, float* distribution) const;
+  void CalculateDistributionMoments(const float* distribution, float* mean, float* variance) const;
+
+  bool StartModality(int iteration, int corr_iteration) override;
+  bool CalculateCorrespondences(int iteration, int corr_iteration) override;
+  bool CalculateGradientAndHessian(int iteration, int corr_iteration, int opt_iteration) override;
+  bool CalculateResults(int iteration) override;
+};
+
+// ---------------------------------------------------------------------------
+// DepthModality  (src/depth_modality.cpp)
+// ---------------------------------------------------------------------------
+struct DepthDataPoint {  // depth_modality.h:96-108
+  float center_f_body[3], center_f_camera[3], normal_f_body[3];
+  float center_u, center_v, depth;
+  float measured_depth_offset;
+  float correspondence_center_f_camera[3];
+  int model_point_index;
+};
+
+struct DepthModality : Modality {
+  m3t_depth_modality_params p{};
+  Context* ctx = nullptr;
+  int depth_camera = -1, model = -1;
+  float fu, fv, ppu, ppv, depth_scale;
+  int image_width_minus_1, image_height_minus_1;
+  Mat4 body2camera_pose, camera2body_pose;
+  float considered_distance = 0, standard_deviation = 0;
+  int max_n_strides = 0;
+  int first_iteration = 0;
+  std::vector<DepthDataPoint> data_points;
+
+  bool SetUp();
+  void PrecalculatePoseVariables();
+  void PrecalculateIterationDependentVariables(int corr_iteration);
+  void CalculateBasicPointData(const float* model_point, DepthDataPoint* dp) const;
+  bool IsPointValid(const DepthDataPoint& dp, bool measure_occlusions) const;
+  bool IsPointUnoccludedMeasured(const DepthDataPoint& dp) const;
+  bool FindCorrespondence(const DepthDataPoint& dp, float* correspondence) const;
+
+  bool StartModality(int, int) override { return true; }  // depth_modality.cpp:248-250
+  bool CalculateCorrespondences(int iteration, int corr_iteration) override;
+  bool CalculateGradientAndHessian(int iteration, int corr_iteration, int opt_iteration) override;
+  bool CalculateResults(int) override { return true; }  // depth_modality.cpp:397
+};
+
+// ---------------------------------------------------------------------------
+// Link / Constraint / Optimizer
+// ---------------------------------------------------------------------------
+struct Link {
+  int body = -1, parent = -1;
+  std::vector<int> children, modalities;
+  Mat4 body2joint = Identity4(), joint2parent = Identity4(), link2world = Identity4();
+  bool free_directions[6] = {true, true, true, true, true, true};
+  bool fixed_body2joint_pose = true;
+  int first_jacobian_index = 0;
+  int jacobian_size = 0;
+  std::vector<float> jacobian;  // 6 x dof, column-major
+  float gradient[6] = {0}, hessian[36] = {0};
+  int DegreesOfFreedom() const {
+    int n = 0;
+    for (bool f : free_directions) n += f;
+    return n;
+  }
+};
+struct Constraint {
+  int link1 = -1, link2 = -1;
+  Mat4 body12joint1 = Identity4(), body22joint2 = Identity4();
+  bool constraint_directions[6] = {false, false, false, false, false, false};
+  std::vector<float> residual;             // n_c
+  std::vector<float> constraint_jacobian;  // n_c x dof column-major
+  int NumberOfConstraints() const {
+    int n = 0;
+    for (bool c : constraint_directions) n += c;
+    return n;
+  }
+};
+struct Optimizer {
+  int root_link = -1;
+  float tikhonov_parameter_rotation = 1000.0f, tikhonov_parameter_translation = 30000.0f;
+  int degrees_of_freedom = 0;
+  std::vector<float> tikhonov_vector;
+  std::vector<int> constraints;
+};
+
+struct Context {
+  std::string error;
+  std::vector<std::unique_ptr<SparseModel>> region_models, depth_models;
+  std::vector<std::unique_ptr<Camera>> cameras;
+  std::vector<Body> bodies;
+  std::vector<std::unique_ptr<Modality>> modalities;
+  std::vector<Link> links;
+  std::vector<Constraint> constraints;
+  std::vector<Optimizer> optimizers;
+  int n_corr_iterations = 5, n_update_iterations = 2;  // tracker.h:231-232
+
+  const Mat4& LinkPose(const Link& l) const {  // Link::link2world_pose() link.cpp:296-301
+    return l.body >= 0 ? bodies[l.body].body2world : l.link2world;
+  }
+};
+
+// ===========================================================================
+// RegionModality implementation
+// ===========================================================================
+bool RegionModality::SetUp() {
+  // PrecalculateFunctionLookup :910-923
+  for (int i = 0; i < p.function_length; ++i) {
+    float x = float(i) - float(p.function_length - 1) / 2.0f;
+    if (p.function_slope == 0.0f)
+      function_lookup_f[i] = 0.5f - p.function_amplitude * ((0.0f < x) - (x < 0.0f));
+    else
+      function_lookup_f[i] = 0.5f - p.function_amplitude * std::tanh(x / (2.0f * p.function_slope));
+    function_lookup_b[i] = 1.0f - function_lookup_f[i];
+  }
+  // PrecalculateDistributionVariables :925-936
+  line_length_in_segments = p.function_length + p.distribution_length - 1;
+  distribution_length_minus_1_half = (float(p.distribution_length) - 1.0f) / 2.0f;
+  distribution_length_plus_1_half = (float(p.distribution_length) + 1.0f) / 2.0f;
+  float min_expected_variance_laplace = 1.0f / (2.0f * powf(atanhf(2.0f * p.function_amplitude), 2.0f));
+  float min_expected_variance_gaussian = p.function_slope;
+  min_expected_variance = std::max(min_expected_variance_laplace, min_expected_variance_gaussian);
+  // SetUpInternalColorHistograms :938-943
+  if (!hist.SetUp(p.n_histogram_bins, p.learning_rate_f, p.learning_rate_b)) return false;
+  // PrecalculateCameraVariables :945-964
+  const Camera& cam = *ctx->cameras[color_camera];
+  fu = cam.intr.fu; fv = cam.intr.fv; ppu = cam.intr.ppu; ppv = cam.intr.ppv;
+  image_width_minus_1 = cam.intr.width - 1;
+  image_height_minus_1 = cam.intr.height - 1;
+  image_width_minus_2 = cam.intr.width - 2;
+  image_height_minus_2 = cam.intr.height - 2;
+  if (p.measure_occlusions) {
+    const Camera& dc = *ctx->cameras[depth_camera];
+    depth_fu = dc.intr.fu; depth_fv = dc.intr.fv; depth_ppu = dc.intr.ppu; depth_ppv = dc.intr.ppv;
+    depth_scale = dc.depth_scale;
+    depth_image_width_minus_1 = dc.intr.width - 1;
+    depth_image_height_minus_1 = dc.intr.height - 1;
+    // PrecalculateModelVariables :966-991
+    const SparseModel& m = *ctx->region_models[model];
+    if (p.measured_depth_offset_radius > m.max_radius_depth_offset) return false;
+    measured_depth_offset_id = int(p.measured_depth_offset_radius / m.stride_depth_offset + 0.5f);
+  }
+  return true;
+}
+
+// :1000-1009
+void RegionModality::PrecalculatePoseVariables() {
+  body2camera_pose = Mul4(ctx->cameras[color_camera]->world2camera, ctx->bodies[body].body2world);
+  if (p.measure_occlusions)
+    body2depth_camera_pose = Mul4(ctx->cameras[depth_camera]->world2camera, ctx->bodies[body].body2world);
+  body2camera_rotation = Linear(body2camera_pose);
+}
+
+// :1011-1023
+void RegionModality::PrecalculateIterationDependentVariables(int corr_iteration) {
+  scale = LastValidValue(p.scales, p.n_scales, corr_iteration);
+  fscale = float(scale);
+  line_length = line_length_in_segments * scale;
+  line_length_minus_1 = line_length - 1;
+  line_length_minus_1_half = float(line_length - 1) * 0.5f;
+  line_length_half_minus_1 = float(line_length) * 0.5f - 1.0f;
+  float standard_deviation = LastValidValue(p.standard_deviations, p.n_standard_deviations, corr_iteration);
+  variance = standard_deviation * standard_deviation;  // powf(x, 2.0f)
+}
+
+// :417-430 / :1045-1059
+int RegionModality::NumberOfLines(int view) const {
+  const SparseModel& m = *ctx->region_models[model];
+  int n_lines = p.n_lines_max;
+  if (p.use_adaptive_coverage) {
+    if (p.reference_contour_length > 0.0f)
+      n_lines = p.n_lines_max * std::min(1.0f, m.extents[view] / p.reference_contour_length);
+    else
+      n_lines = p.n_lines_max * m.extents[view] / m.max_extent;
+  }
+  if (n_lines > m.n_points) n_lines = m.n_points;
+  return n_lines;
+}
+
+// :1025-1155
+void RegionModality::AddLinePixelColorsToTempHistograms(bool handle_occlusions) {
+  const Camera& image = *ctx->cameras[color_camera];
+  const SparseModel& m = *ctx->region_models[model];
+  int view = m.GetClosestView(body2camera_pose);
+  int n_lines = NumberOfLines(view);
+  for (int i = 0; i < n_lines; ++i) {
+    const float* data_point = m.Point(view, i);
+    const float* center_f_body = data_point;
+    const float* normal_f_body = data_point + 3;
+    float foreground_distance = data_point[6], background_distance = data_point[7];
+    const float* depth_offsets = data_point + 8;
+
+    float center_f_camera[3];
+    Apply(body2camera_pose, center_f_body, center_f_camera);
+    if (center_f_camera[2] <= 0.0f) continue;
+    float center_u = center_f_camera[0] * fu / center_f_camera[2] + ppu;
+    float center_v = center_f_camera[1] * fv / center_f_camera[2] + ppv;
+    int i_center_u = int(center_u + 0.5f);
+    int i_center_v = int(center_v + 0.5f);
+    if (i_center_u < 0.0f || i_center_u > image_width_minus_1 || i_center_v < 0 ||
+        i_center_v > image_height_minus_1)
+      continue;
+
+    if (handle_occlusions) {
+      if (p.measure_occlusions &&
+          !IsLineUnoccludedMeasured(center_f_body, depth_offsets[measured_depth_offset_id]))
+        continue;
+    }
+
+    float length_f = p.max_considered_line_length;
+    float length_b = p.max_considered_line_length;
+
+    float l_f = foreground_distance * fu / center_f_camera[2];
+    float l_b = background_distance * fu / center_f_camera[2];
+    length_f = std::fmin(length_f, l_f - 2.0f * p.unconsidered_line_length);
+    length_b = std::fmin(length_b, l_b - 2.0f * p.unconsidered_line_length);
+
+    // (body2camera_rotation_xy_ * normal_f_body).normalized()
+    float nx = (body2camera_rotation(0, 0) * normal_f_body[0] + body2camera_rotation(0, 1) * normal_f_body[1]) +
+               body2camera_rotation(0, 2) * normal_f_body[2];
+    float ny = (body2camera_rotation(1, 0) * normal_f_body[0] + body2camera_rotation(1, 1) * normal_f_body[1]) +
+               body2camera_rotation(1, 2) * normal_f_body[2];
+    float nn = std::sqrt(nx * nx + ny * ny);
+    float normal[2] = {nx, ny};
+    if (nn > 0.0f) { normal[0] = nx / nn; normal[1] = ny / nn; }
+    float u_step, v_step;
+    int projected_length_f, projected_length_b;
+    float abs_normal_u = std::fabs(normal[0]);
+    float abs_normal_v = std::fabs(normal[1]);
+    if (abs_normal_u > abs_normal_v) {
+      u_step = sgnf(normal[0]);
+      v_step = normal[1] / abs_normal_u;
+      projected_length_f = int(length_f * abs_normal_u + 0.5f);
+      projected_length_b = int(length_b * abs_normal_u + 0.5f);
+    } else {
+      u_step = normal[0] / abs_normal_v;
+      v_step = sgnf(normal[1]);
+      projected_length_f = int(length_f * abs_normal_v + 0.5f);
+      projected_length_b = int(length_b * abs_normal_v + 0.5f);
+    }
+
+    float u = center_u - normal[0] * p.unconsidered_line_length + 0.5f;
+    float v = center_v - normal[1] * p.unconsidered_line_length + 0.5f;
+    int i_u, i_v;
+    for (int k = 0; k < projected_length_f; ++k) {
+      i_u = int(u);
+      i_v = int(v);
+      if (i_u < 0 || i_u > image_width_minus_1 || i_v < 0 || i_v > image_height_minus_1) break;
+      hist.AddForegroundColor(image.Pixel(i_v, i_u));
+      u -= u_step;
+      v -= v_step;
+    }
+    u = center_u + normal[0] * p.unconsidered_line_length + 0.5f;
+    v = center_v + normal[1] * p.unconsidered_line_length + 0.5f;
+    for (int k = 0; k < projected_length_b; ++k) {
+      i_u = int(u);
+      i_v = int(v);
+      if (i_u < 0 || i_u > image_width_minus_1 || i_v < 0 || i_v > image_height_minus_1) break;
+      hist.AddBackgroundColor(image.Pixel(i_v, i_u));
+      u += u_step;
+      v += v_step;
+    }
+  }
+}
+
+// :1231-1250
+void RegionModality::CalculateBasicLineData(const float* data_point, DataLine* data_line) const {
+  const float* center_f_body = data_point;
+  const float* normal_f_body = data_point + 3;
+  float foreground_distance = data_point[6], background_distance = data_point[7];
+  float center_f_camera[3];
+  Apply(body2camera_pose, center_f_body, center_f_camera);
+  float nx = (body2camera_rotation(0, 0) * normal_f_body[0] + body2camera_rotation(0, 1) * normal_f_body[1]) +
+             body2camera_rotation(0, 2) * normal_f_body[2];
+  float ny = (body2camera_rotation(1, 0) * normal_f_body[0] + body2camera_rotation(1, 1) * normal_f_body[1]) +
+             body2camera_rotation(1, 2) * normal_f_body[2];
+  float nn = std::sqrt(nx * nx + ny * ny);
+  if (nn > 0.0f) { nx = nx / nn; ny = ny / nn; }
+  for (int k = 0; k < 3; ++k) {
+    data_line->center_f_body[k] = center_f_body[k];
+    data_line->center_f_camera[k] = center_f_camera[k];
+  }
+  data_line->center_u = center_f_camera[0] * fu / center_f_camera[2] + ppu;
+  data_line->center_v = center_f_camera[1] * fv / center_f_camera[2] + ppv;
+  data_line->normal_u = nx;
+  data_line->normal_v = ny;
+  data_line->measured_depth_offset = data_point[8 + measured_depth_offset_id];
+  data_line->continuous_distance =
+      std::min(background_distance, foreground_distance) * fu / (center_f_camera[2] * fscale);
+}
+
+// :1252-1291 (region checking / modelled occlusions: renderer-fed, unsupported)
+bool RegionModality::IsLineValid(const DataLine& data_line, bool measure_occlusions) const {
+  if (data_line.continuous_distance < p.min_continuous_distance) return false;
+  if (data_line.center_f_camera[2] <= 0.0f) return false;
+  int i_center_u = int(data_line.center_u + 0.5f);
+  int i_center_v = int(data_line.center_v + 0.5f);
+  if (i_center_u < 0 || i_center_u > image_width_minus_1 || i_center_v < 0 ||
+      i_center_v > image_height_minus_1)
+    return false;
+  if (measure_occlusions) {
+    if (!IsLineUnoccludedMeasured(data_line.center_f_body, data_line.measured_depth_offset)) return false;
+  }
+  return true;
+}
+
+// :1343-1389
+bool RegionModality::IsLineUnoccludedMeasured(const float center_f_body[3], float depth_offset) const {
+  float center_f_depth_camera[3];
+  Apply(body2depth_camera_pose, center_f_body, center_f_depth_camera);
+  float center_u = center_f_depth_camera[0] * depth_fu / center_f_depth_camera[2] + depth_ppu;
+  float center_v = center_f_depth_camera[1] * depth_fv / center_f_depth_camera[2] + depth_ppv;
+
+  float meter_to_pixel = depth_fu / center_f_depth_camera[2];
+  float diameter = 2.0f * p.measured_occlusion_radius * meter_to_pixel;
+  int stride = int(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
+  int n_strides = int(diameter / stride + 0.5f);
+  int rounded_diameter = n_strides * stride;
+  float rounded_radius = 0.5f * float(rounded_diameter);
+
+  int u_min = int(center_u - rounded_radius + 0.5f);
+  int v_min = int(center_v - rounded_radius + 0.5f);
+  int u_max = u_min + rounded_diameter;
+  int v_max = v_min + rounded_diameter;
+  u_min = std::max(u_min, 0);
+  v_min = std::max(v_min, 0);
+  u_max = std::min(u_max, depth_image_width_minus_1);
+  v_max = std::min(v_max, depth_image_height_minus_1);
+
+  uint16_t depth;
+  // ushort(float): out-of-range conversions are UB in C++; x86 cvttss2si + truncation
+  // is what the reference binary does -> int conversion then wrap to 16 bit.
+  uint16_t min_depth =
+      uint16_t(int((center_f_depth_camera[2] - depth_offset - p.measured_occlusion_threshold) / depth_scale));
+  const Camera& image = *ctx->cameras[depth_camera];
+  for (int v = v_min; v <= v_max; v += stride) {
+    for (int u = u_min; u <= u_max; u += stride) {
+      depth = image.Depth(v, u);
+      if (depth > 0 && depth < min_depth) return false;
+    }
+  }
+  return true;
+}
+
+// :1575-1598
+void RegionModality::MultiplyPixelColorProbability(const uint8_t* pixel_color, float* probability_f,
+                                                   float* probability_b) const {
+  float pixel_color_probability_f, pixel_color_probability_b;
+  hist.GetProbabilities(pixel_color, &pixel_color_probability_f, &pixel_color_probability_b);
+  if (pixel_color_probability_f || pixel_color_probability_b) {
+    float sum = pixel_color_probability_f;
+    sum += pixel_color_probability_b;
+    pixel_color_probability_f /= sum;
+    pixel_color_probability_b /= sum;
+  } else {
+    pixel_color_probability_f = 0.5f;
+    pixel_color_probability_b = 0.5f;
+  }
+  *probability_f *= pixel_color_probability_f;
+  *probability_b *= pixel_color_probability_b;
+}
+
+// :1433-1573
+bool RegionModality::CalculateSegmentProbabilities(float center_u, float center_v, float normal_u,
+                                                   float normal_v, float* segment_probabilities_f,
+                                                   float* segment_probabilities_b,
+                                                   float* normal_component_to_scale, float* delta_r) const {
+  const Camera& image = *ctx->cameras[color_camera];
+  const int n_seg = line_length_in_segments;
+  if (std::fabs(normal_v) < std::fabs(normal_u)) {
+    float v_step = normal_v / normal_u;
+    int u = int(center_u - line_length_half_minus_1);
+    int u_end = u + line_length_minus_1;
+    float v_f = center_v + v_step * (float(u) - center_u) + 0.5f;
+    float v_f_end = v_f + v_step * float(line_length_minus_1);
+    if (u < 0 || u_end > image_width_minus_1 || int(v_f) < 0 || int(v_f) > image_height_minus_1 ||
+        int(v_f_end) < 1 || int(v_f_end) > image_height_minus_2)
+      return false;
+    if (normal_u > 0) {
+      float* sf = segment_probabilities_f;
+      float* sb = segment_probabilities_b;
+      *sf = 1.0f; *sb = 1.0f;
+      int segment_idx = 0;
+      for (; u <= u_end; ++u, v_f += v_step, segment_idx++) {
+        if (segment_idx == scale) { *(++sf) = 1.0f; *(++sb) = 1.0f; segment_idx = 0; }
+        MultiplyPixelColorProbability(image.Pixel(int(v_f), u), sf, sb);
+      }
+    } else {
+      float* sf = segment_probabilities_f + (n_seg - 1);
+      float* sb = segment_probabilities_b + (n_seg - 1);
+      *sf = 1.0f; *sb = 1.0f;
+      int segment_idx = 0;
+      for (; u <= u_end; ++u, v_f += v_step, ++segment_idx) {
+        if (segment_idx == scale) { *(--sf) = 1.0f; *(--sb) = 1.0f; segment_idx = 0; }
+        MultiplyPixelColorProbability(image.Pixel(int(v_f), u), sf, sb);
+      }
+    }
+    *normal_component_to_scale = std::fabs(normal_u) / fscale;
+    *delta_r = (std::round(center_u - line_length_minus_1_half) + line_length_minus_1_half - center_u) / normal_u;
+  } else {
+    float u_step = normal_u / normal_v;
+    int v = int(center_v - line_length_half_minus_1);
+    int v_end = v + line_length_minus_1;
+    float u_f = center_u + u_step * (float(v) - center_v) + 0.5f;
+    float u_f_end = u_f + u_step * float(line_length_minus_1);
+    if (v < 0 || v_end > image_height_minus_1 || int(u_f) < 0 || int(u_f) > image_width_minus_1 ||
+        int(u_f_end) < 1 || int(u_f_end) > image_width_minus_2)
+      return false;
+    if (normal_v > 0) {
+      float* sf = segment_probabilities_f;
+      float* sb = segment_probabilities_b;
+      *sf = 1.0f; *sb = 1.0f;
+      int segment_idx = 0;
+      for (; v <= v_end; ++v, u_f += u_step, ++segment_idx) {
+        if (segment_idx == scale) { *(++sf) = 1.0f; *(++sb) = 1.0f; segment_idx = 0; }
+        MultiplyPixelColorProbability(image.Pixel(v, int(u_f)), sf, sb);
+      }
+    } else {
+      float* sf = segment_probabilities_f + (n_seg - 1);
+      float* sb = segment_probabilities_b + (n_seg - 1);
+      *sf = 1.0f; *sb = 1.0f;
+      int segment_idx = 0;
+      for (; v <= v_end; ++v, u_f += u_step, ++segment_idx) {
+        if (segment_idx == scale) { *(--sf) = 1.0f; *(--sb) = 1.0f; segment_idx = 0; }
+        MultiplyPixelColorProbability(image.Pixel(v, int(u_f)), sf, sb);
+      }
+    }
+    *normal_component_to_scale = std::fabs(normal_v) / fscale;
+    *delta_r = (std::round(center_v - line_length_minus_1_half) + line_length_minus_1_half - center_v) / normal_v;
+  }
+  if (scale > 1) {
+    for (int s = 0; s < n_seg; ++s) {
+      if (segment_probabilities_f[s] || segment_probabilities_b[s]) {
+        float sum = segment_probabilities_f[s];
+        sum += segment_probabilities_b[s];
+        segment_probabilities_f[s] /= sum;
+        segment_probabilities_b[s] /= sum;
+      } else {
+        segment_probabilities_f[s] = 0.5f;
+        segment_probabilities_b[s] = 0.5f;
+      }
+    }
+  }
+  return true;
+}
+
+// :1600-1637
+void RegionModality::CalculateDistribution(const float* sf, const float* sb, float* distribution) const {
+  float distribution_area = 0.0f;
+  for (int d = 0; d < p.distribution_length; ++d) {
+    float value = 1.0f;
+    for (int k = 0; k < p.function_length; ++k)
+      value *= sf[d + k] * function_lookup_f[k] + sb[d + k] * function_lookup_b[k];
+    distribution[d] = value;
+    distribution_area += value;
+  }
+  for (int d = 0; d < p.distribution_length; ++d) distribution[d] /= distribution_area;
+}
+
+// :1639-1658
+void RegionModality::CalculateDistributionMoments(const float* distribution, float* mean,
+                                                  float* variance_out) const {
+  float mean_from_begin = 0.0f;
+  for (int i = 0; i < p.distribution_length; ++i) mean_from_begin += float(i) * distribution[i];
+  float distribution_variance = 0.0f;
+  for (int i = 0; i < p.distribution_length; ++i) {
+    float d = float(i) - mean_from_begin;
+    distribution_variance += (d * d) * distribution[i];  // powf(d, 2.0f) * dist
+  }
+  *mean = mean_from_begin - distribution_length_minus_1_half;
+  *variance_out = std::max(distribution_variance, min_expected_variance);
+}
+
+// :375-388
+bool RegionModality::StartModality(int iteration, int) {
+  first_iteration = iteration;
+  PrecalculatePoseVariables();
+  bool handle_occlusions = p.n_unoccluded_iterations == 0;
+  hist.ClearMemory();
+  AddLinePixelColorsToTempHistograms(handle_occlusions);
+  hist.InitializeHistograms();
+  return true;
+}
+
+// :390-465
+bool RegionModality::CalculateCorrespondences(int iteration, int corr_iteration) {
+  PrecalculatePoseVariables();
+  PrecalculateIterationDependentVariables(corr_iteration);
+  const SparseModel& m = *ctx->region_models[model];
+  int view = m.GetClosestView(body2camera_pose);
+  int n_lines = NumberOfLines(view);
+  float segment_probabilities_f[M3T_MAX_SEGMENTS], segment_probabilities_b[M3T_MAX_SEGMENTS];
+  for (int j = 0; j < 2; ++j) {
+    data_lines.clear();
+    bool handle_occlusions = j == 0 && (iteration - first_iteration) >= p.n_unoccluded_iterations;
+    for (int i = 0; i < n_lines; ++i) {
+      DataLine data_line;
+      data_line.model_point_index = i;
+      CalculateBasicLineData(m.Point(view, i), &data_line);
+      if (!IsLineValid(data_line, handle_occlusions && p.measure_occlusions)) continue;
+      if (!CalculateSegmentProbabilities(data_line.center_u, data_line.center_v, data_line.normal_u,
+                                         data_line.normal_v, segment_probabilities_f,
+                                         segment_probabilities_b, &data_line.normal_component_to_scale,
+                                         &data_line.delta_r))
+        continue;
+      CalculateDistribution(segment_probabilities_f, segment_probabilities_b, data_line.distribution);
+      CalculateDistributionMoments(data_line.distribution, &data_line.mean, &data_line.measured_variance);
+      data_lines.push_back(data_line);
+    }
+    if (int(data_lines.size()) >= p.min_n_unoccluded_lines) break;
+  }
+  return true;
+}
+
+// :485-558
+bool RegionModality::CalculateGradientAndHessian(int, int, int opt_iteration) {
+  PrecalculatePoseVariables();
+  for (float& g : gradient) g = 0.0f;
+  for (float& h : hessian) h = 0.0f;
+  for (auto& data_line : data_lines) {
+    Apply(body2camera_pose, data_line.center_f_body, data_line.center_f_camera);
+    float x = data_line.center_f_camera[0];
+    float y = data_line.center_f_camera[1];
+    float z = data_line.center_f_camera[2];
+
+    float fu_z = fu / z;
+    float fv_z = fv / z;
+    float xfu_z = x * fu_z;
+    float yfv_z = y * fv_z;
+    float delta_cs = (data_line.normal_u * (xfu_z + ppu - data_line.center_u) +
+                      data_line.normal_v * (yfv_z + ppv - data_line.center_v) - data_line.delta_r) *
+                     data_line.normal_component_to_scale;
+
+    float dloglikelihood_ddelta_cs;
+    if (opt_iteration < p.n_global_iterations) {
+      dloglikelihood_ddelta_cs = (data_line.mean - delta_cs) / data_line.measured_variance;
+    } else {
+      int dist_idx_upper = int(delta_cs + distribution_length_plus_1_half);
+      int dist_idx_lower = dist_idx_upper - 1;
+      if (dist_idx_upper <= 0 || dist_idx_upper >= p.distribution_length) continue;
+      dloglikelihood_ddelta_cs =
+          (std::log(data_line.distribution[dist_idx_upper]) - std::log(data_line.distribution[dist_idx_lower])) *
+          p.learning_rate / data_line.measured_variance;
+    }
+
+    float ddelta_cs_dcenter[3] = {
+        data_line.normal_component_to_scale * data_line.normal_u * fu_z,
+        data_line.normal_component_to_scale * data_line.normal_v * fv_z,
+        data_line.normal_component_to_scale * (-data_line.normal_u * xfu_z - data_line.normal_v * yfv_z) / z};
+    // RowVector3f * Matrix3f
+    float ddelta_cs_dtranslation[3];
+    for (int c = 0; c < 3; ++c)
+      ddelta_cs_dtranslation[c] = (ddelta_cs_dcenter[0] * body2camera_rotation(0, c) +
+                                   ddelta_cs_dcenter[1] * body2camera_rotation(1, c)) +
+                                  ddelta_cs_dcenter[2] * body2camera_rotation(2, c);
+    float ddelta_cs_dtheta[6];
+    Cross3(data_line.center_f_body, ddelta_cs_dtranslation, ddelta_cs_dtheta);
+    for (int c = 0; c < 3; ++c) ddelta_cs_dtheta[3 + c] = ddelta_cs_dtranslation[c];
+
+    float weight = min_expected_variance /
+                   (data_line.normal_component_to_scale * data_line.normal_component_to_scale * variance);
+
+    float wg = weight * dloglikelihood_ddelta_cs;
+    float wh = weight / data_line.measured_variance;
+    for (int r = 0; r < 6; ++r) gradient[r] += wg * ddelta_cs_dtheta[r];
+    for (int c = 0; c < 6; ++c)
+      for (int r = c; r < 6; ++r) hessian[c * 6 + r] -= (wh * ddelta_cs_dtheta[r]) * ddelta_cs_dtheta[c];
+  }
+  for (int c = 0; c < 6; ++c)
+    for (int r = c + 1; r < 6; ++r) hessian[r * 6 + c] = hessian[c * 6 + r];
+  return true;
+}
+
+// :572-583
+bool RegionModality::CalculateResults(int iteration) {
+  hist.ClearMemory();
+  PrecalculatePoseVariables();
+  bool handle_occlusions = (iteration - first_iteration) >= p.n_unoccluded_iterations;
+  AddLinePixelColorsToTempHistograms(handle_occlusions);
+  hist.UpdateHistograms();
+  return true;
+}
+
+// ===========================================================================
+// DepthModality implementation
+// ===========================================================================
+bool DepthModality::SetUp() {
+  const Camera& cam = *ctx->cameras[depth_camera];  // PrecalculateCameraVariables :626-634
+  fu = cam.intr.fu; fv = cam.intr.fv; ppu = cam.intr.ppu; ppv = cam.intr.ppv;
+  image_width_minus_1 = cam.intr.width - 1;
+  image_height_minus_1 = cam.intr.height - 1;
+  depth_scale = cam.depth_scale;
+  return true;
+}
+// :641-646
+void DepthModality::PrecalculatePoseVariables() {
+  body2camera_pose = Mul4(ctx->cameras[depth_camera]->world2camera, ctx->bodies[body].body2world);
+  camera2body_pose = InverseAffine(body2camera_pose);
+}
+// :648-654
+void DepthModality::PrecalculateIterationDependentVariables(int corr_iteration) {
+  considered_distance = LastValidValue(p.considered_distances, p.n_considered_distances, corr_iteration);
+  max_n_strides = int(considered_distance / p.stride_length + 0.5f);
+  standard_deviation = LastValidValue(p.standard_deviations, p.n_standard_deviations, corr_iteration);
+}
+// :656-695
+void DepthModality::CalculateBasicPointData(const float* mp, DepthDataPoint* dp) const {
+  float center_f_camera[3];
+  Apply(body2camera_pose, mp, center_f_camera);
+  for (int k = 0; k < 3; ++k) {
+    dp->center_f_body[k] = mp[k];
+    dp->normal_f_body[k] = mp[3 + k];
+    dp->center_f_camera[k] = center_f_camera[k];
+  }
+  dp->center_u = center_f_camera[0] * fu / center_f_camera[2] + ppu;
+  dp->center_v = center_f_camera[1] * fv / center_f_camera[2] + ppv;
+  dp->depth = center_f_camera[2];
+  dp->measured_depth_offset = 0.0f;
+  if (p.measure_occlusions) {
+    const SparseModel& m = *ctx->depth_models[model];
+    float radius = p.measured_depth_offset_radius;
+    if (p.use_depth_scaling) radius *= dp->depth;
+    int id = int(radius / m.stride_depth_offset + 0.5f);
+    if (id >= M3T_N_DEPTH_OFFSETS) id = M3T_N_DEPTH_OFFSETS - 1;
+    dp->measured_depth_offset = mp[6 + id];
+  }
+}
+// :697-726
+bool DepthModality::IsPointValid(const DepthDataPoint& dp, bool measure_occlusions) const {
+  if (dp.depth <= 0.0f) return false;
+  int i_center_u = int(dp.center_u + 0.5f);
+  int i_center_v = int(dp.center_v + 0.5f);
+  if (i_center_u < 0 || i_center_u > image_width_minus_1 || i_center_v < 0 ||
+      i_center_v > image_height_minus_1)
+    return false;
+  if (measure_occlusions) {
+    if (!IsPointUnoccludedMeasured(dp)) return false;
+  }
+  return true;
+}
+// :736-776
+bool DepthModality::IsPointUnoccludedMeasured(const DepthDataPoint& dp) const {
+  float diameter = 2.0f * p.measured_occlusion_radius * fu;
+  if (!p.use_depth_scaling) diameter /= dp.depth;
+  int stride = int(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
+  int n_strides = int(diameter / stride + 0.5f);
+  int rounded_diameter = n_strides * stride;
+  float rounded_radius = 0.5f * float(rounded_diameter);
+  int u_min = int(dp.center_u - rounded_radius + 0.5f);
+  int v_min = int(dp.center_v - rounded_radius + 0.5f);
+  int u_max = u_min + rounded_diameter;
+  int v_max = v_min + rounded_diameter;
+  u_min = std::max(u_min, 0);
+  v_min = std::max(v_min, 0);
+  u_max = std::min(u_max, image_width_minus_1);
+  v_max = std::min(v_max, image_height_minus_1);
+  float threshold = p.measured_occlusion_threshold;
+  if (p.use_depth_scaling) threshold *= dp.depth;
+  uint16_t min_depth = uint16_t(int((dp.depth - dp.measured_depth_offset - threshold) / depth_scale));
+  const Camera& image = *ctx->cameras[depth_camera];
+  for (int v = v_min; v <= v_max; v += stride) {
+    for (int u = u_min; u <= u_max; u += stride) {
+      uint16_t depth = image.Depth(v, u);
+      if (depth > 0 && depth < min_depth) return false;
+    }
+  }
+  return true;
+}
+// :826-884
+bool DepthModality::FindCorrespondence(const DepthDataPoint& dp, float* correspondence) const {
+  float cd = considered_distance;
+  if (p.use_depth_scaling) cd *= dp.depth;
+  float meter_to_pixel = fu / dp.depth;
+  float diameter = 2.0f * cd * meter_to_pixel;
+  int stride = int(diameter / max_n_strides + 1.0f);
+  int n_strides = int(diameter / stride + 0.5f);
+  int rounded_diameter = n_strides * stride;
+  float rounded_radius = 0.5f * float(rounded_diameter);
+  int u_min = int(dp.center_u - rounded_radius + 0.5f);
+  int v_min = int(dp.center_v - rounded_radius + 0.5f);
+  int u_max = u_min + rounded_diameter;
+  int v_max = v_min + rounded_diameter;
+  u_min = std::max(u_min, 0);
+  v_min = std::max(v_min, 0);
+  u_max = std::min(u_max, image_width_minus_1);
+  v_max = std::min(v_max, image_height_minus_1);
+  float min_depth_value = std::min(0.0f, (dp.depth - cd) / depth_scale);
+  float max_depth_value = (dp.depth + cd) / depth_scale;
+  float min_considered_distance_square = cd * cd;
+  float min_measured_distance_square = min_considered_distance_square;
+  const Camera& image = *ctx->cameras[depth_camera];
+  for (int v = v_min; v <= v_max; v += stride) {
+    for (int u = u_min; u <= u_max; u += stride) {
+      float depth = float(image.Depth(v, u));
+      if (depth > min_depth_value && depth < max_depth_value) {
+        depth *= depth_scale;
+        float tp[3] = {(float(u) - ppu) * depth / fu, (float(v) - ppv) * depth / fv, depth};
+        float d0 = tp[0] - dp.center_f_camera[0], d1 = tp[1] - dp.center_f_camera[1],
+              d2 = tp[2] - dp.center_f_camera[2];
+        float measured_distance_square = (d0 * d0 + d1 * d1) + d2 * d2;
+        if (measured_distance_square < min_measured_distance_square) {
+          correspondence[0] = tp[0]; correspondence[1] = tp[1]; correspondence[2] = tp[2];
+          min_measured_distance_square = measured_distance_square;
+        }
+      }
+    }
+  }
+  return min_measured_distance_square != min_considered_distance_square;
+}
+// :252-315
+bool DepthModality::CalculateCorrespondences(int iteration, int corr_iteration) {
+  PrecalculatePoseVariables();
+  PrecalculateIterationDependentVariables(corr_iteration);
+  const SparseModel& m = *ctx->depth_models[model];
+  int view = m.GetClosestView(body2camera_pose);
+  int n_points = p.n_points_max;
+  if (p.use_adaptive_coverage) {
+    if (p.reference_surface_area > 0.0f)
+      n_points = p.n_points_max * std::min(1.0f, m.extents[view] / p.reference_surface_area);
+    else
+      n_points = p.n_points_max * m.extents[view] / m.max_extent;
+  }
+  if (n_points > m.n_points) n_points = m.n_points;
+  for (int j = 0; j < 2; ++j) {
+    data_points.clear();
+    bool handle_occlusions = j == 0 && (iteration - first_iteration) >= p.n_unoccluded_iterations;
+    for (int i = 0; i < n_points; ++i) {
+      DepthDataPoint dp;
+      dp.model_point_index = i;
+      CalculateBasicPointData(m.Point(view, i), &dp);
+      if (!IsPointValid(dp, handle_occlusions && p.measure_occlusions)) continue;
+      if (!FindCorrespondence(dp, dp.correspondence_center_f_camera)) continue;
+      data_points.push_back(dp);
+    }
+    if (int(data_points.size()) >= p.min_n_unoccluded_points) break;
+  }
+  return true;
+}
+// :333-381
+bool DepthModality::CalculateGradientAndHessian(int, int, int) {
+  PrecalculatePoseVariables();
+  for (float& g : gradient) g = 0.0f;
+  for (float& h : hessian) h = 0.0f;
+  for (auto& dp : data_points) {
+    float cb[3];
+    Apply(camera2body_pose, dp.correspondence_center_f_camera, cb);
+    float diff[3] = {dp.center_f_body[0] - cb[0], dp.center_f_body[1] - cb[1], dp.center_f_body[2] - cb[2]};
+    float epsilon = Dot3(dp.normal_f_body, diff);
+    float cxn[3];
+    Cross3(cb, dp.normal_f_body, cxn);
+    float correspondence_depth = dp.correspondence_center_f_camera[2];
+    float weight = 1.0f / (standard_deviation * correspondence_depth);
+    float squared_weight = weight * weight;
+    float wc[3] = {weight * cxn[0], weight * cxn[1], weight * cxn[2]};
+    float wn[3] = {weight * dp.normal_f_body[0], weight * dp.normal_f_body[1], weight * dp.normal_f_body[2]};
+    float se = squared_weight * epsilon;
+    for (int k = 0; k < 3; ++k) {
+      gradient[k] -= se * cxn[k];
+      gradient[3 + k] -= se * dp.normal_f_body[k];
+    }
+    // upper triangle (r <= c) of column-major 6x6
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r <= c; ++r) hessian[c * 6 + r] -= wc[r] * wc[c];
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) hessian[(3 + c) * 6 + r] -= wc[r] * wn[c];
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r <= c; ++r) hessian[(3 + c) * 6 + 3 + r] -= wn[r] * wn[c];
+  }
+  for (int c = 0; c < 6; ++c)
+    for (int r = 0; r < c; ++r) hessian[r * 6 + c] = hessian[c * 6 + r];
+  return true;
+}
+
+// ===========================================================================
+// Link / Constraint / Optimizer implementation
+// ===========================================================================
+// Link::Adjoint src/link.cpp:341-348
+void Adjoint(const Mat4& pose, float out[36]) {
+  Mat3 R = Linear(pose);
+  float t[3] = {pose(0, 3), pose(1, 3), pose(2, 3)};
+  Mat3 tr = Mul3(Skew(t), R);
+  for (int i = 0; i < 36; ++i) out[i] = 0.0f;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) {
+      out[c * 6 + r] = R(r, c);
+      out[c * 6 + 3 + r] = tr(r, c);
+      out[(3 + c) * 6 + 3 + r] = R(r, c);
+    }
+}
+
+// Link::CalculateJacobian src/link.cpp:159-182
+void LinkCalculateJacobian(Context* ctx, Link& link) {
+  int dof = link.jacobian_size;
+  link.jacobian.assign(size_t(6) * dof, 0.0f);
+  if (link.parent >= 0) {
+    const Link& parent = ctx->links[link.parent];
+    Mat4 parent2body = InverseAffine(Mul4(link.joint2parent, link.body2joint));
+    float ad[36];
+    Adjoint(parent2body, ad);
+    for (int c = 0; c < dof; ++c)
+      for (int r = 0; r < 6; ++r) {
+        float s = 0.0f;
+        for (int k = 0; k < 6; ++k) s += ad[k * 6 + r] * parent.jacobian[size_t(c) * 6 + k];
+        link.jacobian[size_t(c) * 6 + r] = s;
+      }
+  }
+  Mat4 joint2body = InverseAffine(link.body2joint);
+  float ad[36];
+  Adjoint(joint2body, ad);
+  int jacobian_idx = link.first_jacobian_index;
+  for (int direction = 0; direction < 6; ++direction) {
+    if (link.free_directions[direction]) {
+      for (int r = 0; r < 6; ++r) link.jacobian[size_t(jacobian_idx) * 6 + r] = ad[direction * 6 + r];
+      jacobian_idx++;
+    }
+  }
+}
+
+// Link::CalculateGradientAndHessian src/link.cpp:184-193
+void LinkCalculateGradientAndHessian(Context* ctx, Link& link) {
+  for (float& g : link.gradient) g = 0.0f;
+  for (float& h : link.hessian) h = 0.0f;
+  for (int mid : link.modalities) {
+    const Modality& m = *ctx->modalities[mid];
+    for (int i = 0; i < 6; ++i) link.gradient[i] += m.gradient[i];
+    for (int i = 0; i < 36; ++i) link.hessian[i] += m.hessian[i];
+  }
+}
+
+// Link::UpdatePoses src/link.cpp:205-241
+void LinkUpdatePoses(Context* ctx, Link& link, const std::vector<float>& theta) {
+  float theta_link[6];
+  int jacobian_idx = link.first_jacobian_index;
+  for (int direction = 0; direction < 6; ++direction) {
+    if (link.free_directions[direction]) theta_link[direction] = theta[jacobian_idx++];
+    else theta_link[direction] = 0.0f;
+  }
+  Mat4 pose_variation = Identity4();
+  Mat3 R = Expm3(Skew(theta_link));
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) pose_variation(r, c) = R(r, c);
+  for (int r = 0; r < 3; ++r) pose_variation(r, 3) = theta_link[3 + r];
+
+  if (link.parent >= 0) {
+    if (link.fixed_body2joint_pose) link.joint2parent = Mul4(link.joint2parent, pose_variation);
+    else link.body2joint = Mul4(pose_variation, link.body2joint);
+    const Link& parent = ctx->links[link.parent];
+    link.link2world = Mul4(Mul4(ctx->LinkPose(parent), link.joint2parent), link.body2joint);
+  } else {
+    link.link2world =
+        Mul4(Mul4(Mul4(ctx->LinkPose(link), InverseAffine(link.body2joint)), pose_variation), link.body2joint);
+  }
+  if (link.body >= 0) ctx->bodies[link.body].body2world = link.link2world;
+}
+
+void UpdatePosesRecursive(Context* ctx, int link_id, const std::vector<float>& theta) {
+  LinkUpdatePoses(ctx, ctx->links[link_id], theta);
+  for (int c : ctx->links[link_id].children) UpdatePosesRecursive(ctx, c, theta);
+}
+
+// Constraint::Residual / UnprojectedConstraintJacobian src/constraint.cpp:176-274
+void ConstraintUnprojectedJacobian(const Constraint& c, const Mat4& joint22joint1, const Mat4& body2joint1,
+                                   std::vector<float>* jac /* n_c x 6 col-major */) {
+  int n_c = c.NumberOfConstraints();
+  Mat4 body2joint2 = Mul4(InverseAffine(joint22joint1), body2joint1);
+  Mat4 inv = InverseAffine(body2joint2);
+  float joint22body_translation[3] = {inv(0, 3), inv(1, 3), inv(2, 3)};
+  Mat3 body2joint1_rotation = Linear(body2joint1);
+  float angle, axis[3];
+  AngleAxisFromRotation(Linear(joint22joint1), &angle, axis);
+  float angle_half = 0.5f * angle;
+  float xc = xcotx(angle_half);
+  Mat3 sk = Skew(axis);
+  Mat3 variation_matrix;
+  for (int cc = 0; cc < 3; ++cc)
+    for (int r = 0; r < 3; ++r)
+      variation_matrix(r, cc) =
+          (xc * (r == cc ? 1.0f : 0.0f) - angle_half * sk(r, cc)) + ((1.0f - xc) * axis[r]) * axis[cc];
+  jac->assign(size_t(n_c) * 6, 0.0f);
+  int idx = 0;
+  for (int direction = 0; direction < 6; ++direction) {
+    if (!c.constraint_directions[direction]) continue;
+    if (direction < 3) {
+      for (int col = 0; col < 3; ++col) {
+        float s = (variation_matrix(direction, 0) * body2joint1_rotation(0, col) +
+                   variation_matrix(direction, 1) * body2joint1_rotation(1, col)) +
+                  variation_matrix(direction, 2) * body2joint1_rotation(2, col);
+        (*jac)[size_t(col) * n_c + idx] = s;
+      }
+    } else {
+      float row[3] = {body2joint1_rotation(direction - 3, 0), body2joint1_rotation(direction - 3, 1),
+                      body2joint1_rotation(direction - 3, 2)};
+      float cr[3];
+      Cross3(joint22body_translation, row, cr);
+      for (int col = 0; col < 3; ++col) {
+        (*jac)[size_t(col) * n_c + idx] = cr[col];
+        (*jac)[size_t(3 + col) * n_c + idx] = row[col];
+      }
+    }
+    idx++;
+  }
+}
+
+// Constraint::CalculateResidualAndConstraintJacobian src/constraint.cpp:81-102
+void ConstraintCalculate(Context* ctx, Constraint& c, int dof) {
+  const Link& l1 = ctx->links[c.link1];
+  const Link& l2 = ctx->links[c.link2];
+  Mat4 body22joint1 = Mul4(Mul4(c.body12joint1, InverseAffine(ctx->LinkPose(l1))), ctx->LinkPose(l2));
+  Mat4 joint22joint1 = Mul4(body22joint1, InverseAffine(c.body22joint2));
+  int n_c = c.NumberOfConstraints();
+  float angle, axis[3];
+  AngleAxisFromRotation(Linear(joint22joint1), &angle, axis);
+  float rotation_vector[3] = {angle * axis[0], angle * axis[1], angle * axis[2]};
+  c.residual.assign(n_c, 0.0f);
+  int idx = 0;
+  for (int direction = 0; direction < 6; ++direction) {
+    if (!c.constraint_directions[direction]) continue;
+    c.residual[idx++] = direction < 3 ? rotation_vector[direction] : joint22joint1(direction - 3, 3);
+  }
+  std::vector<float> j2, j1;
+  ConstraintUnprojectedJacobian(c, joint22joint1, body22joint1, &j2);
+  ConstraintUnprojectedJacobian(c, joint22joint1, c.body12joint1, &j1);
+  c.constraint_jacobian.assign(size_t(n_c) * dof, 0.0f);
+  for (int col = 0; col < dof; ++col)
+    for (int r = 0; r < n_c; ++r) {
+      float s2 = 0.0f, s1 = 0.0f;
+      for (int k = 0; k < 6; ++k) {
+        s2 += j2[size_t(k) * n_c + r] * l2.jacobian[size_t(col) * 6 + k];
+        s1 += j1[size_t(k) * n_c + r] * l1.jacobian[size_t(col) * 6 + k];
+      }
+      c.constraint_jacobian[size_t(col) * n_c + r] = s2 - s1;
+    }
+}
+
+int LinkTreeDof(Context* ctx, int link_id) {  // optimizer.cpp:223-228
+  int dof = ctx->links[link_id].DegreesOfFreedom();
+  for (int c : ctx->links[link_id].children) dof += LinkTreeDof(ctx, c);
+  return dof;
+}
+void DefineJacobians(Context* ctx, int link_id, int dof, int* first) {  // optimizer.cpp:237-250
+  Link& l = ctx->links[link_id];
+  l.jacobian_size = dof;
+  l.first_jacobian_index = *first;
+  *first += l.DegreesOfFreedom();
+  for (int c : l.children) DefineJacobians(ctx, c, dof, first);
+}
+void DefineTikhonovVector(Context* ctx, Optimizer& o, int link_id) {  // optimizer.cpp:252-271
+  const Link& l = ctx->links[link_id];
+  int idx = l.first_jacobian_index;
+  for (int direction = 0; direction < 6; ++direction) {
+    if (l.free_directions[direction]) {
+      o.tikhonov_vector[idx] = direction < 3 ? o.tikhonov_parameter_rotation : o.tikhonov_parameter_translation;
+      idx++;
+    }
+  }
+  for (int c : l.children) DefineTikhonovVector(ctx, o, c);
+}
+void CalculateDataLinks(Context* ctx, int link_id) {  // optimizer.cpp:288-296
+  LinkCalculateJacobian(ctx, ctx->links[link_id]);
+  LinkCalculateGradientAndHessian(ctx, ctx->links[link_id]);
+  for (int c : ctx->links[link_id].children) CalculateDataLinks(ctx, c);
+}
+void AddProjected(Context* ctx, int link_id, int dof, int size, std::vector<float>* b,
+                  std::vector<float>* a) {  // optimizer.cpp:309-321
+  const Link& l = ctx->links[link_id];
+  // b += J^T g
+  for (int i = 0; i < dof; ++i) {
+    float s = 0.0f;
+    for (int k = 0; k < 6; ++k) s += l.jacobian[size_t(i) * 6 + k] * l.gradient[k];
+    (*b)[i] += s;
+  }
+  // a.lower -= J^T H J
+  std::vector<float> hj(size_t(6) * dof);
+  for (int c = 0; c < dof; ++c)
+    for (int r = 0; r < 6; ++r) {
+      float s = 0.0f;
+      for (int k = 0; k < 6; ++k) s += l.hessian[k * 6 + r] * l.jacobian[size_t(c) * 6 + k];
+      hj[size_t(c) * 6 + r] = s;
+    }
+  for (int c = 0; c < dof; ++c)
+    for (int r = c; r < dof; ++r) {
+      float s = 0.0f;
+      for (int k = 0; k < 6; ++k) s += l.jacobian[size_t(r) * 6 + k] * hj[size_t(c) * 6 + k];
+      (*a)[size_t(c) * size + r] -= s;
+    }
+  for (int c : l.children) AddProjected(ctx, c, dof, size, b, a);
+}
+
+// Optimizer::CalculateOptimization src/optimizer.cpp:144-167
+bool OptimizerCalculateOptimization(Context* ctx, Optimizer& o) {
+  int dof = o.degrees_of_freedom;
+  int n_constraints = 0;
+  for (int cid : o.constraints) n_constraints += ctx->constraints[cid].NumberOfConstraints();
+  int size = dof + n_constraints;
+  std::vector<float> b(size, 0.0f), a(size_t(size) * size, 0.0f);
+  CalculateDataLinks(ctx, o.root_link);
+  for (int cid : o.constraints) ConstraintCalculate(ctx, ctx->constraints[cid], dof);
+  AddProjected(ctx, o.root_link, dof, size, &b, &a);
+  int idx = dof;  // AddResidualsAndConstraintJacobians :323-333
+  for (int cid : o.constraints) {
+    const Constraint& c = ctx->constraints[cid];
+    int n_c = c.NumberOfConstraints();
+    for (int r = 0; r < n_c; ++r) {
+      b[idx + r] = c.residual[r];
+      for (int col = 0; col < dof; ++col) a[size_t(col) * size + idx + r] = -c.constraint_jacobian[size_t(col) * n_c + r];
+    }
+    idx += n_c;
+  }
+  for (int i = 0; i < dof; ++i) a[size_t(i) * size + i] += o.tikhonov_vector[i];
+  std::vector<float> theta = LdltSolve(a, b, size);
+  for (float t : theta)
+    if (std::isnan(t)) return true;  // theta.array().isNaN().isZero() guard
+  UpdatePosesRecursive(ctx, o.root_link, theta);
+  return true;
+}
+
+void SetError(Context* c, const std::string& e) { c->error = e; }
+
+}  // namespace
+
+// ===========================================================================
+// C API
+// ===========================================================================
+struct m3t_oracle_context {
+  Context c;
+};
+struct m3t_oracle_histograms {
+  Histograms h;
+};
+
+#define CTX (&ctx->c)
+#define CHECK_CTX() \
+  if (!ctx) return M3T_ERR_INVALID_ARGUMENT
+#define FAIL(code, msg)  \
+  do {                   \
+    SetError(CTX, msg);  \
+    return code;         \
+  } while (0)
+
+extern "C" {
+
+int m3t_oracle_create(m3t_oracle_context** out, int) {
+  if (!out) return M3T_ERR_INVALID_ARGUMENT;
+  *out = new m3t_oracle_context();
+  return M3T_OK;
+}
+void m3t_oracle_destroy(m3t_oracle_context* ctx) { delete ctx; }
+const char* m3t_oracle_last_error(m3t_oracle_context* ctx) { return ctx ? ctx->c.error.c_str() : "null context"; }
+
+static int CreateModel(m3t_oracle_context* ctx, bool region, int n_views, int n_points, const float* pts,
+                       const float* orient, const float* ext, float stride, float max_radius) {
+  if (n_views <= 0 || n_points <= 0 || !pts || !orient || !ext) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad model desc");
+  auto m = std::make_unique<SparseModel>();
+  m->is_region = region;
+  m->n_views = n_views;
+  m->n_points = n_points;
+  m->point_floats = region ? M3T_REGION_POINT_FLOATS : M3T_DEPTH_POINT_FLOATS;
+  m->data_points.assign(pts, pts + size_t(n_views) * n_points * m->point_floats);
+  m->orientations.assign(orient, orient + size_t(n_views) * 3);
+  m->extents.assign(ext, ext + n_views);
+  m->stride_depth_offset = stride;
+  m->max_radius_depth_offset = max_radius;
+  for (float e : m->extents) m->max_extent = std::max(m->max_extent, e);
+  auto& vec = region ? CTX->region_models : CTX->depth_models;
+  vec.push_back(std::move(m));
+  return int(vec.size()) - 1;
+}
+int m3t_oracle_region_model_create(m3t_oracle_context* ctx, const m3t_region_model_desc* d) {
+  CHECK_CTX();
+  if (!d) FAIL(M3T_ERR_INVALID_ARGUMENT, "null desc");
+  return CreateModel(ctx, true, d->n_views, d->n_points, d->data_points, d->orientations, d->contour_lengths,
+                     d->stride_depth_offset, d->max_radius_depth_offset);
+}
+int m3t_oracle_depth_model_create(m3t_oracle_context* ctx, const m3t_depth_model_desc* d) {
+  CHECK_CTX();
+  if (!d) FAIL(M3T_ERR_INVALID_ARGUMENT, "null desc");
+  return CreateModel(ctx, false, d->n_views, d->n_points, d->data_points, d->orientations, d->surface_areas,
+                     d->stride_depth_offset, d->max_radius_depth_offset);
+}
+static int LoadModel(m3t_oracle_context* ctx, const char* path, bool region) {
+  auto m = std::make_unique<SparseModel>();
+  std::string err;
+  if (!path || !LoadSparseModel(path, region, m.get(), &err)) FAIL(M3T_ERR_IO, err);
+  auto& vec = region ? CTX->region_models : CTX->depth_models;
+  vec.push_back(std::move(m));
+  return int(vec.size()) - 1;
+}
+int m3t_oracle_region_model_load(m3t_oracle_context* ctx, const char* path) {
+  CHECK_CTX();
+  return LoadModel(ctx, path, true);
+}
+int m3t_oracle_depth_model_load(m3t_oracle_context* ctx, const char* path) {
+  CHECK_CTX();
+  return LoadModel(ctx, path, false);
+}
+static int ModelInfo(m3t_oracle_context* ctx, bool region, int id, int* nv, int* np, float* me) {
+  auto& vec = region ? CTX->region_models : CTX->depth_models;
+  if (id < 0 || id >= int(vec.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad model id");
+  if (nv) *nv = vec[id]->n_views;
+  if (np) *np = vec[id]->n_points;
+  if (me) *me = vec[id]->max_extent;
+  return M3T_OK;
+}
+int m3t_oracle_region_model_info(m3t_oracle_context* ctx, int id, int* nv, int* np, float* me) {
+  CHECK_CTX();
+  return ModelInfo(ctx, true, id, nv, np, me);
+}
+int m3t_oracle_depth_model_info(m3t_oracle_context* ctx, int id, int* nv, int* np, float* me) {
+  CHECK_CTX();
+  return ModelInfo(ctx, false, id, nv, np, me);
+}
+int m3t_oracle_region_model_closest_view(m3t_oracle_context* ctx, int id, const float pose[16], int* view) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->region_models.size()) || !pose || !view) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad args");
+  *view = CTX->region_models[id]->GetClosestView(FromArray(pose));
+  return M3T_OK;
+}
+int m3t_oracle_depth_model_closest_view(m3t_oracle_context* ctx, int id, const float pose[16], int* view) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->depth_models.size()) || !pose || !view) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad args");
+  *view = CTX->depth_models[id]->GetClosestView(FromArray(pose));
+  return M3T_OK;
+}
+
+static int CreateCamera(m3t_oracle_context* ctx, const m3t_intrinsics* intr, const float* w2c, bool depth,
+                        float depth_scale) {
+  if (!intr || !w2c || intr->width <= 0 || intr->height <= 0) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad camera");
+  auto c = std::make_unique<Camera>();
+  c->is_depth = depth;
+  c->intr = *intr;
+  c->world2camera = FromArray(w2c);
+  c->depth_scale = depth_scale;
+  c->image.assign(size_t(intr->width) * intr->height * (depth ? 2 : 3), 0);
+  CTX->cameras.push_back(std::move(c));
+  return int(CTX->cameras.size()) - 1;
+}
+int m3t_oracle_color_camera_create(m3t_oracle_context* ctx, const m3t_intrinsics* i, const float w2c[16]) {
+  CHECK_CTX();
+  return CreateCamera(ctx, i, w2c, false, 0.0f);
+}
+int m3t_oracle_depth_camera_create(m3t_oracle_context* ctx, const m3t_intrinsics* i, const float w2c[16],
+                                   float depth_scale) {
+  CHECK_CTX();
+  return CreateCamera(ctx, i, w2c, true, depth_scale);
+}
+int m3t_oracle_camera_upload(m3t_oracle_context* ctx, int id, const void* pixels, size_t row_step) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->cameras.size()) || !pixels) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+  Camera& c = *CTX->cameras[id];
+  size_t row_bytes = size_t(c.intr.width) * (c.is_depth ? 2 : 3);
+  if (row_step < row_bytes) FAIL(M3T_ERR_INVALID_ARGUMENT, "row_step too small");
+  for (int r = 0; r < c.intr.height; ++r)
+    std::memcpy(&c.image[size_t(r) * row_bytes], (const uint8_t*)pixels + size_t(r) * row_step, row_bytes);
+  c.has_image = true;
+  return M3T_OK;
+}
+int m3t_oracle_camera_set_world2camera_pose(m3t_oracle_context* ctx, int id, const float w2c[16]) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->cameras.size()) || !w2c) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+  CTX->cameras[id]->world2camera = FromArray(w2c);
+  return M3T_OK;
+}
+
+int m3t_oracle_body_create(m3t_oracle_context* ctx, const float pose[16]) {
+  CHECK_CTX();
+  Body b;
+  if (pose) b.body2world = FromArray(pose);
+  CTX->bodies.push_back(b);
+  return int(CTX->bodies.size()) - 1;
+}
+int m3t_oracle_body_set_body2world_pose(m3t_oracle_context* ctx, int id, const float pose[16]) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->bodies.size()) || !pose) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad body id");
+  CTX->bodies[id].body2world = FromArray(pose);
+  return M3T_OK;
+}
+int m3t_oracle_body_get_body2world_pose(m3t_oracle_context* ctx, int id, float pose[16]) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->bodies.size()) || !pose) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad body id");
+  std::memcpy(pose, CTX->bodies[id].body2world.m, 64);
+  return M3T_OK;
+}
+
+int m3t_oracle_region_modality_create(m3t_oracle_context* ctx, const m3t_region_modality_params* p, int body,
+                                      int color_camera, int model, int depth_camera) {
+  CHECK_CTX();
+  if (!p) FAIL(M3T_ERR_INVALID_ARGUMENT, "null params");
+  if (body < 0 || body >= int(CTX->bodies.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad body id");
+  if (color_camera < 0 || color_camera >= int(CTX->cameras.size()) || CTX->cameras[color_camera]->is_depth)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad color camera id");
+  if (model < 0 || model >= int(CTX->region_models.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad region model id");
+  if (p->use_region_checking || p->model_occlusions) FAIL(M3T_ERR_UNSUPPORTED, "renderer-fed branches unsupported");
+  if (p->measure_occlusions &&
+      (depth_camera < 0 || depth_camera >= int(CTX->cameras.size()) || !CTX->cameras[depth_camera]->is_depth))
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "measure_occlusions needs a depth camera");
+  if (p->function_length < 1 || p->function_length > M3T_MAX_FUNCTION_LENGTH || p->distribution_length < 2 ||
+      p->distribution_length > M3T_MAX_DISTRIBUTION_LENGTH || p->n_scales < 1 || p->n_scales > M3T_MAX_SCALES ||
+      p->n_standard_deviations < 1 || p->n_standard_deviations > M3T_MAX_SCALES || p->n_lines_max < 1)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad region modality parameters");
+  auto m = std::make_unique<RegionModality>();
+  m->is_region = true;
+  m->p = *p;
+  m->ctx = CTX;
+  m->body = body;
+  m->color_camera = color_camera;
+  m->depth_camera = depth_camera;
+  m->model = model;
+  if (!m->SetUp()) FAIL(M3T_ERR_INVALID_ARGUMENT, "region modality set up failed");
+  CTX->modalities.push_back(std::move(m));
+  return int(CTX->modalities.size()) - 1;
+}
+int m3t_oracle_depth_modality_create(m3t_oracle_context* ctx, const m3t_depth_modality_params* p, int body,
+                                     int depth_camera, int model) {
+  CHECK_CTX();
+  if (!p) FAIL(M3T_ERR_INVALID_ARGUMENT, "null params");
+  if (body < 0 || body >= int(CTX->bodies.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad body id");
+  if (depth_camera < 0 || depth_camera >= int(CTX->cameras.size()) || !CTX->cameras[depth_camera]->is_depth)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad depth camera id");
+  if (model < 0 || model >= int(CTX->depth_models.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad depth model id");
+  if (p->use_silhouette_checking || p->model_occlusions) FAIL(M3T_ERR_UNSUPPORTED, "renderer-fed branches unsupported");
+  if (p->n_considered_distances < 1 || p->n_considered_distances > M3T_MAX_SCALES || p->n_standard_deviations < 1 ||
+      p->n_standard_deviations > M3T_MAX_SCALES || p->n_points_max < 1)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad depth modality parameters");
+  auto m = std::make_unique<DepthModality>();
+  m->is_region = false;
+  m->p = *p;
+  m->ctx = CTX;
+  m->body = body;
+  m->depth_camera = depth_camera;
+  m->model = model;
+  m->SetUp();
+  CTX->modalities.push_back(std::move(m));
+  return int(CTX->modalities.size()) - 1;
+}
+
+int m3t_oracle_link_create(m3t_oracle_context* ctx, int body, int parent, const float body2joint[16],
+                           const float joint2parent[16], const int free_directions[6], int fixed_body2joint) {
+  CHECK_CTX();
+  if (body >= int(CTX->bodies.size()) || parent >= int(CTX->links.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad link args");
+  Link l;
+  l.body = body;
+  l.parent = parent;
+  if (body2joint) l.body2joint = FromArray(body2joint);
+  if (joint2parent) l.joint2parent = FromArray(joint2parent);
+  if (free_directions)
+    for (int i = 0; i < 6; ++i) l.free_directions[i] = free_directions[i] != 0;
+  l.fixed_body2joint_pose = fixed_body2joint != 0;
+  if (body >= 0) l.link2world = CTX->bodies[body].body2world;
+  CTX->links.push_back(l);
+  int id = int(CTX->links.size()) - 1;
+  if (parent >= 0) CTX->links[parent].children.push_back(id);
+  return id;
+}
+int m3t_oracle_link_add_modality(m3t_oracle_context* ctx, int link, int modality) {
+  CHECK_CTX();
+  if (link < 0 || link >= int(CTX->links.size()) || modality < 0 || modality >= int(CTX->modalities.size()))
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad ids");
+  CTX->links[link].modalities.push_back(modality);
+  return M3T_OK;
+}
+int m3t_oracle_optimizer_create(m3t_oracle_context* ctx, int root_link, float tr, float tt) {
+  CHECK_CTX();
+  if (root_link < 0 || root_link >= int(CTX->links.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad root link");
+  Optimizer o;
+  o.root_link = root_link;
+  o.tikhonov_parameter_rotation = tr;
+  o.tikhonov_parameter_translation = tt;
+  o.degrees_of_freedom = LinkTreeDof(CTX, root_link);
+  int first = 0;
+  DefineJacobians(CTX, root_link, o.degrees_of_freedom, &first);
+  o.tikhonov_vector.assign(o.degrees_of_freedom, 0.0f);
+  DefineTikhonovVector(CTX, o, root_link);
+  CTX->optimizers.push_back(o);
+  return int(CTX->optimizers.size()) - 1;
+}
+int m3t_oracle_optimizer_create_rigid(m3t_oracle_context* ctx, int body, int n, const int* mids, float tr, float tt) {
+  CHECK_CTX();
+  int link = m3t_oracle_link_create(ctx, body, -1, nullptr, nullptr, nullptr, 1);
+  if (link < 0) return link;
+  for (int i = 0; i < n; ++i) {
+    int r = m3t_oracle_link_add_modality(ctx, link, mids[i]);
+    if (r < 0) return r;
+  }
+  return m3t_oracle_optimizer_create(ctx, link, tr, tt);
+}
+int m3t_oracle_constraint_create(m3t_oracle_context* ctx, int optimizer, int link1, int link2, const float b1[16],
+                                 const float b2[16], const int dirs[6]) {
+  CHECK_CTX();
+  if (optimizer < 0 || optimizer >= int(CTX->optimizers.size()) || link1 < 0 || link2 < 0 ||
+      link1 >= int(CTX->links.size()) || link2 >= int(CTX->links.size()) || !dirs)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad constraint args");
+  Constraint c;
+  c.link1 = link1;
+  c.link2 = link2;
+  if (b1) c.body12joint1 = FromArray(b1);
+  if (b2) c.body22joint2 = FromArray(b2);
+  for (int i = 0; i < 6; ++i) c.constraint_directions[i] = dirs[i] != 0;
+  CTX->constraints.push_back(c);
+  CTX->optimizers[optimizer].constraints.push_back(int(CTX->constraints.size()) - 1);
+  return int(CTX->constraints.size()) - 1;
+}
+int m3t_oracle_link_get_link2world_pose(m3t_oracle_context* ctx, int link, float pose[16]) {
+  CHECK_CTX();
+  if (link < 0 || link >= int(CTX->links.size()) || !pose) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad link id");
+  std::memcpy(pose, CTX->LinkPose(CTX->links[link]).m, 64);
+  return M3T_OK;
+}
+
+int m3t_oracle_tracker_set_iterations(m3t_oracle_context* ctx, int n_corr, int n_update) {
+  CHECK_CTX();
+  if (n_corr < 0 || n_update < 0) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad iteration counts");
+  CTX->n_corr_iterations = n_corr;
+  CTX->n_update_iterations = n_update;
+  return M3T_OK;
+}
+static int CheckImages(m3t_oracle_context* ctx) {
+  for (auto& m : CTX->modalities) {
+    if (m->is_region) {
+      auto* r = static_cast<RegionModality*>(m.get());
+      if (!CTX->cameras[r->color_camera]->has_image) FAIL(M3T_ERR_NOT_SET_UP, "Set up color camera first (no image)");
+      if (r->p.measure_occlusions && !CTX->cameras[r->depth_camera]->has_image)
+        FAIL(M3T_ERR_NOT_SET_UP, "Set up depth camera first (no image)");
+    } else {
+      auto* d = static_cast<DepthModality*>(m.get());
+      if (!CTX->cameras[d->depth_camera]->has_image) FAIL(M3T_ERR_NOT_SET_UP, "Set up depth camera first (no image)");
+    }
+  }
+  return M3T_OK;
+}
+// Tracker::StartModalities src/tracker.cpp:430-445
+int m3t_oracle_start_modalities(m3t_oracle_context* ctx, int iteration) {
+  CHECK_CTX();
+  int r = CheckImages(ctx);
+  if (r) return r;
+  for (auto& m : CTX->modalities) m->StartModality(iteration, 0);
+  return M3T_OK;
+}
+// Tracker::CalculateCorrespondences src/tracker.cpp:447-457
+int m3t_oracle_calculate_correspondences(m3t_oracle_context* ctx, int iteration, int corr_iteration) {
+  CHECK_CTX();
+  int r = CheckImages(ctx);
+  if (r) return r;
+  for (auto& m : CTX->modalities) m->CalculateCorrespondences(iteration, corr_iteration);
+  return M3T_OK;
+}
+// Tracker::CalculateGradientAndHessian src/tracker.cpp:471-479
+int m3t_oracle_calculate_gradient_and_hessian(m3t_oracle_context* ctx, int iteration, int corr_iteration,
+                                              int opt_iteration) {
+  CHECK_CTX();
+  for (auto& m : CTX->modalities) m->CalculateGradientAndHessian(iteration, corr_iteration, opt_iteration);
+  return M3T_OK;
+}
+// Tracker::CalculateOptimization src/tracker.cpp:481-489
+int m3t_oracle_calculate_optimization(m3t_oracle_context* ctx, int, int, int) {
+  CHECK_CTX();
+  for (auto& o : CTX->optimizers) OptimizerCalculateOptimization(CTX, o);
+  return M3T_OK;
+}
+// Tracker::CalculateResults src/tracker.cpp:503-517
+int m3t_oracle_calculate_results(m3t_oracle_context* ctx, int iteration) {
+  CHECK_CTX();
+  int r = CheckImages(ctx);
+  if (r) return r;
+  for (auto& m : CTX->modalities) m->CalculateResults(iteration);
+  return M3T_OK;
+}
+// Tracker::ExecuteTrackingStep src/tracker.cpp:344-364
+int m3t_oracle_execute_tracking_step(m3t_oracle_context* ctx, int iteration) {
+  CHECK_CTX();
+  for (int corr_iteration = 0; corr_iteration < CTX->n_corr_iterations; ++corr_iteration) {
+    int r = m3t_oracle_calculate_correspondences(ctx, iteration, corr_iteration);
+    if (r) return r;
+    for (int update_iteration = 0; update_iteration < CTX->n_update_iterations; ++update_iteration) {
+      r = m3t_oracle_calculate_gradient_and_hessian(ctx, iteration, corr_iteration, update_iteration);
+      if (r) return r;
+      r = m3t_oracle_calculate_optimization(ctx, iteration, corr_iteration, update_iteration);
+      if (r) return r;
+    }
+  }
+  return m3t_oracle_calculate_results(ctx, iteration);
+}
+int m3t_oracle_execute_tracking_cycle(m3t_oracle_context* ctx, int iteration) {
+  return m3t_oracle_execute_tracking_step(ctx, iteration);
+}
+int m3t_oracle_sync(m3t_oracle_context* ctx) {
+  CHECK_CTX();
+  return M3T_OK;
+}
+
+int m3t_oracle_modality_get_gradient_hessian(m3t_oracle_context* ctx, int id, float g[6], float h[36]) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->modalities.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad modality id");
+  if (g) std::memcpy(g, CTX->modalities[id]->gradient, 24);
+  if (h) std::memcpy(h, CTX->modalities[id]->hessian, 144);
+  return M3T_OK;
+}
+int m3t_oracle_modality_set_gradient_hessian(m3t_oracle_context* ctx, int id, const float g[6], const float h[36]) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->modalities.size()) || !g || !h) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad modality id");
+  std::memcpy(CTX->modalities[id]->gradient, g, 24);
+  std::memcpy(CTX->modalities[id]->hessian, h, 144);
+  return M3T_OK;
+}
+int m3t_oracle_region_modality_get_lines(m3t_oracle_context* ctx, int id, m3t_data_line* out, int capacity, int* n) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->modalities.size()) || !CTX->modalities[id]->is_region)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
+  auto* r = static_cast<RegionModality*>(CTX->modalities[id].get());
+  int count = int(r->data_lines.size());
+  if (n) *n = count;
+  for (int i = 0; i < count && i < capacity && out; ++i) {
+    const DataLine& l = r->data_lines[i];
+    m3t_data_line& o = out[i];
+    std::memset(&o, 0, sizeof(o));
+    for (int k = 0; k < 3; ++k) o.center_f_body[k] = l.center_f_body[k];
+    o.center_u = l.center_u; o.center_v = l.center_v;
+    o.normal_u = l.normal_u; o.normal_v = l.normal_v;
+    o.delta_r = l.delta_r;
+    o.normal_component_to_scale = l.normal_component_to_scale;
+    o.continuous_distance = l.continuous_distance;
+    o.mean = l.mean;
+    o.measured_variance = l.measured_variance;
+    for (int k = 0; k < r->p.distribution_length; ++k) o.distribution[k] = l.distribution[k];
+    o.valid = 1;
+    o.model_point_index = l.model_point_index;
+  }
+  return M3T_OK;
+}
+int m3t_oracle_depth_modality_get_points(m3t_oracle_context* ctx, int id, m3t_data_point* out, int capacity, int* n) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->modalities.size()) || CTX->modalities[id]->is_region)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad depth modality id");
+  auto* d = static_cast<DepthModality*>(CTX->modalities[id].get());
+  int count = int(d->data_points.size());
+  if (n) *n = count;
+  for (int i = 0; i < count && i < capacity && out; ++i) {
+    const DepthDataPoint& p = d->data_points[i];
+    m3t_data_point& o = out[i];
+    std::memset(&o, 0, sizeof(o));
+    for (int k = 0; k < 3; ++k) {
+      o.center_f_body[k] = p.center_f_body[k];
+      o.normal_f_body[k] = p.normal_f_body[k];
+      o.correspondence_center_f_camera[k] = p.correspondence_center_f_camera[k];
+    }
+    o.center_u = p.center_u; o.center_v = p.center_v; o.depth = p.depth;
+    o.valid = 1;
+    o.model_point_index = p.model_point_index;
+  }
+  return M3T_OK;
+}
+int m3t_oracle_region_modality_get_histograms(m3t_oracle_context* ctx, int id, float* f, float* b) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->modalities.size()) || !CTX->modalities[id]->is_region)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
+  auto* r = static_cast<RegionModality*>(CTX->modalities[id].get());
+  if (f) std::memcpy(f, r->hist.histogram_f.data(), size_t(r->hist.n_bins_cubed) * 4);
+  if (b) std::memcpy(b, r->hist.histogram_b.data(), size_t(r->hist.n_bins_cubed) * 4);
+  return M3T_OK;
+}
+int m3t_oracle_region_modality_set_histograms(m3t_oracle_context* ctx, int id, const float* f, const float* b) {
+  CHECK_CTX();
+  if (id < 0 || id >= int(CTX->modalities.size()) || !CTX->modalities[id]->is_region || !f || !b)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
+  auto* r = static_cast<RegionModality*>(CTX->modalities[id].get());
+  std::memcpy(r->hist.histogram_f.data(), f, size_t(r->hist.n_bins_cubed) * 4);
+  std::memcpy(r->hist.histogram_b.data(), b, size_t(r->hist.n_bins_cubed) * 4);
+  return M3T_OK;
+}
+
+m3t_oracle_histograms* m3t_oracle_histograms_create(int n_bins, float lf, float lb) {
+  auto* h = new m3t_oracle_histograms();
+  if (!h->h.SetUp(n_bins, lf, lb)) { delete h; return nullptr; }
+  return h;
+}
+void m3t_oracle_histograms_destroy(m3t_oracle_histograms* h) { delete h; }
+void m3t_oracle_histograms_clear_memory(m3t_oracle_histograms* h) { h->h.ClearMemory(); }
+void m3t_oracle_histograms_add_foreground(m3t_oracle_histograms* h, const uint8_t bgr[3]) { h->h.AddForegroundColor(bgr); }
+void m3t_oracle_histograms_add_background(m3t_oracle_histograms* h, const uint8_t bgr[3]) { h->h.AddBackgroundColor(bgr); }
+void m3t_oracle_histograms_initialize(m3t_oracle_histograms* h) { h->h.InitializeHistograms(); }
+void m3t_oracle_histograms_update(m3t_oracle_histograms* h) { h->h.UpdateHistograms(); }
+void m3t_oracle_histograms_get_probabilities(m3t_oracle_histograms* h, const uint8_t bgr[3], float* pf, float* pb) {
+  h->h.GetProbabilities(bgr, pf, pb);
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+/* m3t_oracle.h — CPU restatement of M3T's per-frame pose-optimisation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is the parity checker and the CPU
+ * baseline ("port") for the HIP product in 3dobjecttracking_amd/.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product (libm3t_hip.so) never links, loads or calls anything in oracle/.
+ *
+ * It is a from-scratch single-threaded scalar restatement (no Eigen, no
+ * OpenCV) of the reference functions listed in SURVEY.md §8(a); every function
+ * in m3t_oracle.cpp cites the reference file:line it follows.  The reference
+ * itself cannot be compiled in this image (needs Eigen/OpenCV/GLEW/GLFW), so
+ * there is no oracle/_ref binary.  Parity pinning status:
+ *   pinned   : ColorHistograms (closed-form KAT of color_histograms_test.cpp),
+ *              .bin model loader + GetClosestView (data/model_test goldens),
+ *              Optimizer/Link solve + pose update (optimizer_test golden pose).
+ *   unpinned : RegionModality / DepthModality per-line arithmetic (their
+ *              goldens need the OpenGL-generated triangle model).
+ *
+ * The function set mirrors include/m3t_hip.h one to one (prefix m3t_oracle_
+ * instead of m3t_hip_) so the parity tests drive both through the same code.
+ */
+#ifndef M3T_ORACLE_H_
+#define M3T_ORACLE_H_
+
+#include "../include/m3t_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct m3t_oracle_context m3t_oracle_context;
+
+int m3t_oracle_create(m3t_oracle_context** out, int device_id /* ignored */);
+void m3t_oracle_destroy(m3t_oracle_context* ctx);
+const char* m3t_oracle_last_error(m3t_oracle_context* ctx);
+
+/* models (region_model.cpp:259-307, depth_model.cpp:215-283, model.cpp:218-284) */
+int m3t_oracle_region_model_create(m3t_oracle_context*, const m3t_region_model_desc*);
+int m3t_oracle_region_model_load(m3t_oracle_context*, const char* path);
+int m3t_oracle_depth_model_create(m3t_oracle_context*, const m3t_depth_model_desc*);
+int m3t_oracle_depth_model_load(m3t_oracle_context*, const char* path);
+int m3t_oracle_region_model_info(m3t_oracle_context*, int model_id, int* n_views, int* n_points,
+                                 float* max_contour_length);
+int m3t_oracle_depth_model_info(m3t_oracle_context*, int model_id, int* n_views, int* n_points,
+                                float* max_surface_area);
+/* GetClosestView (region_model.cpp:105-130 / depth_model.cpp:81-106) */
+int m3t_oracle_region_model_closest_view(m3t_oracle_context*, int model_id,
+                                         const float body2camera[16], int* view_index);
+int m3t_oracle_depth_model_closest_view(m3t_oracle_context*, int model_id,
+                                        const float body2camera[16], int* view_index);
+
+/* cameras (camera.h:32-88): image = BGR8 (color) or u16 (depth), row_step in bytes */
+int m3t_oracle_color_camera_create(m3t_oracle_context*, const m3t_intrinsics*, const float world2camera[16]);
+int m3t_oracle_depth_camera_create(m3t_oracle_context*, const m3t_intrinsics*, const float world2camera[16],
+                                   float depth_scale);
+int m3t_oracle_camera_upload(m3t_oracle_context*, int camera_id, const void* pixels, size_t row_step);
+int m3t_oracle_camera_set_world2camera_pose(m3t_oracle_context*, int camera_id, const float world2camera[16]);
+
+/* bodies (body.h: body2world_pose) */
+int m3t_oracle_body_create(m3t_oracle_context*, const float body2world[16]);
+int m3t_oracle_body_set_body2world_pose(m3t_oracle_context*, int body_id, const float body2world[16]);
+int m3t_oracle_body_get_body2world_pose(m3t_oracle_context*, int body_id, float body2world[16]);
+
+/* modalities (modality.h:56-155) */
+int m3t_oracle_region_modality_create(m3t_oracle_context*, const m3t_region_modality_params*, int body_id,
+                                      int color_camera_id, int region_model_id, int depth_camera_id);
+int m3t_oracle_depth_modality_create(m3t_oracle_context*, const m3t_depth_modality_params*, int body_id,
+                                     int depth_camera_id, int depth_model_id);
+
+/* links / optimizers (link.h:67, optimizer.h:48) */
+int m3t_oracle_link_create(m3t_oracle_context*, int body_id, int parent_link_id, const float body2joint[16],
+                           const float joint2parent[16], const int free_directions[6],
+                           int fixed_body2joint_pose);
+int m3t_oracle_link_add_modality(m3t_oracle_context*, int link_id, int modality_id);
+int m3t_oracle_optimizer_create(m3t_oracle_context*, int root_link_id, float tikhonov_parameter_rotation,
+                                float tikhonov_parameter_translation);
+/* convenience: one free 6-dof root link holding `n` modalities of one body */
+int m3t_oracle_optimizer_create_rigid(m3t_oracle_context*, int body_id, int n_modalities,
+                                      const int* modality_ids, float tikhonov_parameter_rotation,
+                                      float tikhonov_parameter_translation);
+/* hard constraint between two links (constraint.h) */
+int m3t_oracle_constraint_create(m3t_oracle_context*, int optimizer_id, int link1_id, int link2_id,
+                                 const float body12joint1[16], const float body22joint2[16],
+                                 const int constraint_directions[6]);
+int m3t_oracle_link_get_link2world_pose(m3t_oracle_context*, int link_id, float pose[16]);
+
+/* tracker (tracker.h:131-160, tracker.cpp:344-517) */
+int m3t_oracle_tracker_set_iterations(m3t_oracle_context*, int n_corr_iterations, int n_update_iterations);
+int m3t_oracle_start_modalities(m3t_oracle_context*, int iteration);
+int m3t_oracle_calculate_correspondences(m3t_oracle_context*, int iteration, int corr_iteration);
+int m3t_oracle_calculate_gradient_and_hessian(m3t_oracle_context*, int iteration, int corr_iteration,
+                                              int opt_iteration);
+int m3t_oracle_calculate_optimization(m3t_oracle_context*, int iteration, int corr_iteration,
+                                      int opt_iteration);
+int m3t_oracle_calculate_results(m3t_oracle_context*, int iteration);
+int m3t_oracle_execute_tracking_step(m3t_oracle_context*, int iteration);
+int m3t_oracle_execute_tracking_cycle(m3t_oracle_context*, int iteration); /* ICG name */
+int m3t_oracle_sync(m3t_oracle_context*);
+
+/* accessors */
+int m3t_oracle_modality_get_gradient_hessian(m3t_oracle_context*, int modality_id, float gradient[6],
+                                             float hessian[36]);
+int m3t_oracle_modality_set_gradient_hessian(m3t_oracle_context*, int modality_id, const float gradient[6],
+                                             const float hessian[36]);
+int m3t_oracle_region_modality_get_lines(m3t_oracle_context*, int modality_id, m3t_data_line* out,
+                                         int capacity, int* n_lines);
+int m3t_oracle_depth_modality_get_points(m3t_oracle_context*, int modality_id, m3t_data_point* out,
+                                         int capacity, int* n_points);
+int m3t_oracle_region_modality_get_histograms(m3t_oracle_context*, int modality_id, float* histogram_f,
+                                              float* histogram_b);
+int m3t_oracle_region_modality_set_histograms(m3t_oracle_context*, int modality_id, const float* histogram_f,
+                                              const float* histogram_b);
+
+/* stand-alone ColorHistograms object for the closed-form KAT
+ * (color_histograms.cpp:50-102,174-214; color_histograms_test.cpp:71-103) */
+typedef struct m3t_oracle_histograms m3t_oracle_histograms;
+m3t_oracle_histograms* m3t_oracle_histograms_create(int n_bins, float learning_rate_f, float learning_rate_b);
+void m3t_oracle_histograms_destroy(m3t_oracle_histograms*);
+void m3t_oracle_histograms_clear_memory(m3t_oracle_histograms*);
+void m3t_oracle_histograms_add_foreground(m3t_oracle_histograms*, const uint8_t bgr[3]);
+void m3t_oracle_histograms_add_background(m3t_oracle_histograms*, const uint8_t bgr[3]);
+void m3t_oracle_histograms_initialize(m3t_oracle_histograms*);
+void m3t_oracle_histograms_update(m3t_oracle_histograms*);
+void m3t_oracle_histograms_get_probabilities(m3t_oracle_histograms*, const uint8_t bgr[3], float* pf, float* pb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3T_ORACLE_H_ */
