@@ -235,9 +235,12 @@ _HIP_ONLY = {
     "get_stream": [C.POINTER(C.c_void_p)],
     "device_info": [C.c_char_p, C.c_size_t, c_int_p, C.POINTER(C.c_size_t)],
     "set_fused_step": [C.c_int],
-    "last_step_kernel_ms": [c_float_p],
     "bodies_get_poses": [c_float_p, C.c_int],
     "bodies_set_poses": [c_float_p, C.c_int],
+    "camera_set_ring": [C.c_int, C.c_int],
+    "camera_upload_slot": [C.c_int, C.c_int, C.c_void_p, C.c_size_t],
+    "camera_select_slot": [C.c_int, C.c_int],
+    "cameras_select_slot": [C.c_int],
 }
 
 

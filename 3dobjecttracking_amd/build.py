@@ -1,0 +1,36 @@
+"""Builds csrc/libm3t_hip.so for gfx950 with hipcc (in-tree, no JIT cache)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libm3t_hip.so")
+SOURCES = ["m3t_hip_api.hip", "m3t_kernels.hip", "m3t_device.h"]
+HEADERS = [os.path.join(HERE, "..", "include", "m3t_hip.h"), os.path.join(HERE, "..", "include", "m3t_types.h")]
+# -ffp-contract=off: the kernels follow the reference's f32 expression trees op by op
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", LIB, os.path.join(CSRC, "m3t_hip_api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

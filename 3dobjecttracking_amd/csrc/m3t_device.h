@@ -1,0 +1,131 @@
+// m3t_device.h — device-resident layouts shared by the host-side C-ABI
+// implementation (m3t_hip_api.hip) and the gfx950 kernels (m3t_kernels.hip).
+//
+// Data layout in HBM:
+//   * one CameraDev row per camera (intrinsics, world2camera, current frame ptr)
+//   * one float[16] column-major body2world pose per body
+//   * one RegionModDev / DepthModDev row per modality: parameters, pointers to
+//     the (shared) sparse viewpoint model, the per-object histogram tables and
+//     the per-object line / point state (structure-of-arrays, field-major)
+//   * one RigidOptDev row per rigid-body optimizer
+#ifndef M3T_DEVICE_H_
+#define M3T_DEVICE_H_
+
+#include <stdint.h>
+
+#include "../../include/m3t_types.h"
+
+// ---- per-line state, field-major: state[field * n_lines_max + line] ----------
+enum {
+  LS_CX = 0, LS_CY, LS_CZ,          // center_f_body
+  LS_CENTER_U, LS_CENTER_V, LS_NORMAL_U, LS_NORMAL_V,
+  LS_DELTA_R, LS_NCTS,              // normal_component_to_scale
+  LS_MEAN, LS_VAR,                  // measured_variance
+  LS_CONT,                          // continuous_distance
+  LS_VALID,                         // int bits: bit0 valid, bit1 valid w/o occlusion handling, bit2 horizontal walk, bit3 reversed fill
+  LS_WALK_START,                    // int bits: first major-axis pixel coordinate
+  LS_WALK_STEP,                     // minor-axis increment per pixel
+  LS_DIST0,                         // distribution[M3T_MAX_DISTRIBUTION_LENGTH]
+  LS_FIELDS = LS_DIST0 + M3T_MAX_DISTRIBUTION_LENGTH
+};
+// ---- per-point state (depth modality), field-major -------------------------
+enum {
+  PS_CX = 0, PS_CY, PS_CZ, PS_NX, PS_NY, PS_NZ,
+  PS_CENTER_U, PS_CENTER_V, PS_DEPTH,
+  PS_CORR_X, PS_CORR_Y, PS_CORR_Z,
+  PS_VALID,
+  PS_FIELDS
+};
+
+struct CameraDev {
+  const uint8_t* image;  // current frame (BGR8 or u16), pitch-linear
+  uint32_t pitch;        // bytes per row
+  int width, height;
+  float fu, fv, ppu, ppv;
+  float depth_scale;
+  float world2camera[16];  // column-major
+};
+
+struct RegionModDev {
+  int body, camera, depth_camera;
+  // sparse viewpoint model (shared between objects using the same model)
+  const float* points;        // [n_views][n_points][38]
+  const float* orientations;  // [n_views][3]
+  const float* extents;       // contour_length [n_views]
+  int n_views, n_points;
+  float max_extent;
+  // parameters (m3t_region_modality_params, precalculated)
+  int n_lines_max, use_adaptive_coverage;
+  float reference_contour_length, min_continuous_distance;
+  int function_length, distribution_length, n_seg;
+  float function_lookup_f[M3T_MAX_FUNCTION_LENGTH], function_lookup_b[M3T_MAX_FUNCTION_LENGTH];
+  float learning_rate;
+  int n_global_iterations;
+  int n_scales, scales[M3T_MAX_SCALES];
+  int n_standard_deviations;
+  float standard_deviations[M3T_MAX_SCALES];
+  int n_bins, bitshift;
+  float learning_rate_f, learning_rate_b, unconsidered_line_length, max_considered_line_length;
+  int measure_occlusions, measured_depth_offset_id;
+  float measured_occlusion_radius, measured_occlusion_threshold;
+  int n_unoccluded_iterations, min_n_unoccluded_lines;
+  float min_expected_variance, distribution_length_minus_1_half, distribution_length_plus_1_half;
+  int first_iteration;
+  // per-object state
+  float* histogram_f;     // [n_bins^3]
+  float* histogram_b;     // [n_bins^3]
+  float2* histogram_norm; // [n_bins^3] (pf/(pf+pb), pb/(pf+pb)) or (0.5,0.5): MultiplyPixelColorProbability hoisted per bin
+  uint32_t* count_scratch; // [n_bins^3] packed counts, only when they do not fit in LDS (n_bins = 64)
+  float* line_state;      // [LS_FIELDS][n_lines_max]
+  float* gradient_hessian;  // [6 + 36] gradient, column-major hessian
+};
+
+struct DepthModDev {
+  int body, camera;
+  const float* points;        // [n_views][n_points][36]
+  const float* orientations;
+  const float* extents;       // surface_area
+  int n_views, n_points;
+  float max_extent;
+  float stride_depth_offset;
+  int n_points_max, use_adaptive_coverage, use_depth_scaling;
+  float reference_surface_area, stride_length;
+  int n_considered_distances;
+  float considered_distances[M3T_MAX_SCALES];
+  int n_standard_deviations;
+  float standard_deviations[M3T_MAX_SCALES];
+  int measure_occlusions;
+  float measured_depth_offset_radius, measured_occlusion_radius, measured_occlusion_threshold;
+  int n_unoccluded_iterations, min_n_unoccluded_points;
+  int first_iteration;
+  float* point_state;       // [PS_FIELDS][n_points_max]
+  float* gradient_hessian;  // [6 + 36]
+};
+
+// One rigid body with an unconstrained 6-dof root link (body2joint = I):
+// Optimizer::CalculateOptimization specialised to dof = 6, J = I.
+struct RigidOptDev {
+  int body;
+  int region_modality;  // index into RegionModDev table or -1
+  int depth_modality;   // index into DepthModDev table or -1
+  float tikhonov_rotation, tikhonov_translation;
+};
+
+// LDS carve-up of the tracking kernels, computed on the host from the maxima
+// over all objects of one launch.
+struct TrackLdsLayout {
+  int nl;        // max n_lines_max / n_points_max
+  int ns;        // max n_seg
+  int off_state;   // float offset: LS_FIELDS * nl
+  int off_chain;   // nl * ns  (aliased by the raw distribution nl * M3T_MAX_DISTRIBUTION_LENGTH)
+  int off_seg_f;   // nl * ns
+  int off_seg_b;   // nl * ns
+  int off_misc;    // reduction scratch
+  int off_hist;    // optional LDS-staged histogram_norm (float2[n_bins^3]) or -1
+  int total_floats;
+};
+
+#define M3T_BLOCK_THREADS 512
+#define M3T_MISC_FLOATS 1024
+
+#endif  // M3T_DEVICE_H_

@@ -1,0 +1,1250 @@
+// m3t_hip_api.hip — host side of libm3t_hip.so: context, device-resident tables,
+// .bin model parser and kernel launches behind the C-ABI of include/m3t_hip.h.
+// Single translation unit together with the kernels (one hipcc invocation).
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/m3t_hip.h"
+#include "m3t_device.h"
+#include "m3t_kernels.hip"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevMem {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevMem() = default;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
+  ~DevMem() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+struct Model {
+  bool region = true;
+  int n_views = 0, n_points = 0, point_floats = 0;
+  float stride_depth_offset = 0.002f, max_radius_depth_offset = 0.05f, max_extent = 0.0f;
+  DevMem points, orientations, extents;
+};
+
+struct Camera {
+  bool is_depth = false;
+  m3t_intrinsics intr{};
+  float world2camera[16];
+  float depth_scale = 0.0f;
+  uint32_t pitch = 0;
+  size_t frame_bytes = 0;
+  int n_slots = 1, current = 0;
+  std::vector<bool> has_image;
+  DevMem ring;
+};
+
+struct RegionMod {
+  m3t_region_modality_params p{};
+  int body, camera, depth_camera, model;
+  DevMem hist_f, hist_b, hist_norm, count_scratch, line_state, gh;
+  RegionModDev dev{};
+};
+struct DepthMod {
+  m3t_depth_modality_params p{};
+  int body, camera, model;
+  DevMem point_state, gh;
+  DepthModDev dev{};
+};
+struct ModalityRef {
+  bool region;
+  int index;
+};
+struct Link {
+  int body;
+  std::vector<int> modalities;
+};
+struct Optimizer {
+  int link;
+  float tr, tt;
+};
+
+}  // namespace
+
+struct m3t_hip_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop{};
+  std::string error;
+  std::vector<std::unique_ptr<Model>> region_models, depth_models;
+  std::vector<std::unique_ptr<Camera>> cameras;
+  std::vector<float> body_poses;  // host mirror [n][16] (valid when !poses_on_device_newer)
+  std::vector<std::unique_ptr<RegionMod>> region_mods;
+  std::vector<std::unique_ptr<DepthMod>> depth_mods;
+  std::vector<ModalityRef> modalities;
+  std::vector<Link> links;
+  std::vector<Optimizer> optimizers;
+  int n_corr_iterations = 5, n_update_iterations = 2;
+  int fused_mode = 1;
+  // device tables
+  DevMem d_cams, d_region, d_depth, d_opts, d_poses, d_scratch_view;
+  bool tables_dirty = true, cams_dirty = true, poses_dirty_host = true;
+  size_t pose_capacity = 0;
+  std::vector<RigidOptDev> opt_table;
+  bool fused_possible = false;
+  bool state_valid = false;  // line/point state + g/H on the device reflect the last step
+  TrackLdsLayout layout{};
+  int np_max = 0, off_points = 0;
+  size_t lds_track = 0, lds_corr = 0, lds_hist = 0, lds_depth = 0;
+  bool hist_counts_in_lds = true;
+};
+
+namespace {
+
+using Ctx = m3t_hip_context;
+
+int Fail(Ctx* c, int code, const std::string& msg) {
+  if (c) c->error = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return Fail(ctx, M3T_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+  } while (0)
+#define REQUIRE(cond, code, msg) \
+  do {                           \
+    if (!(cond)) return Fail(ctx, code, msg); \
+  } while (0)
+
+// ---- .bin parser: model.cpp:218-284 + region_model.cpp:259-307,346-363 + depth_model.cpp:215-283
+bool SkipBodyData(std::ifstream& ifs) {
+  uint64_t len = 0;
+  ifs.read(reinterpret_cast<char*>(&len), 8);
+  if (!ifs || len > (1u << 20)) return false;
+  ifs.seekg(std::streamoff(len + 4 + 1 + 1 + 4 + 64), std::ios::cur);
+  return bool(ifs);
+}
+struct HostModel {
+  int n_views = 0, n_points = 0;
+  float stride = 0, max_radius = 0;
+  std::vector<float> points, orientations, extents;
+};
+bool ParseModelFile(const char* path, bool region, HostModel* m, std::string* err) {
+  std::ifstream ifs{path, std::ios::in | std::ios::binary};
+  if (!ifs.is_open()) { *err = std::string("Could not open model file ") + path; return false; }
+  char type = 0;
+  int32_t version = 0, n_divides = 0, n_points = 0, image_size = 0;
+  float sphere_radius = 0, max_radius = 0, stride = 0;
+  uint8_t use_random_seed = 0;
+  ifs.read(&type, 1);
+  ifs.read(reinterpret_cast<char*>(&version), 4);
+  ifs.read(reinterpret_cast<char*>(&sphere_radius), 4);
+  ifs.read(reinterpret_cast<char*>(&n_divides), 4);
+  ifs.read(reinterpret_cast<char*>(&n_points), 4);
+  ifs.read(reinterpret_cast<char*>(&max_radius), 4);
+  ifs.read(reinterpret_cast<char*>(&stride), 4);
+  ifs.read(reinterpret_cast<char*>(&use_random_seed), 1);
+  ifs.read(reinterpret_cast<char*>(&image_size), 4);
+  if (!ifs) { *err = "truncated model header"; return false; }
+  if (type != (region ? 'r' : 'd')) { *err = "Wrong model type"; return false; }
+  if (version != (region ? 10 : 9)) { *err = "Wrong version id"; return false; }
+  if (!SkipBodyData(ifs)) { *err = "bad body data"; return false; }
+  uint64_t n_assoc = 0;
+  ifs.read(reinterpret_cast<char*>(&n_assoc), 8);
+  if (region) {
+    for (int g = 0; g < 4; ++g) {
+      uint64_t n = 0;
+      ifs.read(reinterpret_cast<char*>(&n), 8);
+      for (uint64_t i = 0; i < n && ifs; ++i)
+        if (!SkipBodyData(ifs)) { *err = "bad associated body data"; return false; }
+    }
+  } else {
+    for (uint64_t i = 0; i < n_assoc && ifs; ++i)
+      if (!SkipBodyData(ifs)) { *err = "bad occlusion body data"; return false; }
+  }
+  uint64_t n_views = 0;
+  ifs.read(reinterpret_cast<char*>(&n_views), 8);
+  if (!ifs || n_views == 0 || n_views > (1u << 24) || n_points <= 0 || n_points > (1 << 20)) {
+    *err = "bad view table";
+    return false;
+  }
+  const int pf = region ? M3T_REGION_POINT_FLOATS : M3T_DEPTH_POINT_FLOATS;
+  m->n_views = int(n_views);
+  m->n_points = n_points;
+  m->stride = stride;
+  m->max_radius = max_radius;
+  m->points.resize(size_t(n_views) * n_points * pf);
+  m->orientations.resize(size_t(n_views) * 3);
+  m->extents.resize(n_views);
+  for (uint64_t v = 0; v < n_views; ++v) {
+    ifs.read(reinterpret_cast<char*>(&m->points[v * n_points * pf]), std::streamsize(size_t(n_points) * pf * 4));
+    ifs.read(reinterpret_cast<char*>(&m->orientations[v * 3]), 12);
+    ifs.read(reinterpret_cast<char*>(&m->extents[v]), 4);
+  }
+  if (!ifs) { *err = "truncated view data"; return false; }
+  return true;
+}
+
+int CreateModel(Ctx* ctx, bool region, int n_views, int n_points, const float* pts, const float* ori,
+                const float* ext, float stride, float max_radius) {
+  REQUIRE(n_views > 0 && n_points > 0 && pts && ori && ext, M3T_ERR_INVALID_ARGUMENT, "bad model description");
+  auto m = std::make_unique<Model>();
+  m->region = region;
+  m->n_views = n_views;
+  m->n_points = n_points;
+  m->point_floats = region ? M3T_REGION_POINT_FLOATS : M3T_DEPTH_POINT_FLOATS;
+  m->stride_depth_offset = stride;
+  m->max_radius_depth_offset = max_radius;
+  for (int v = 0; v < n_views; ++v) m->max_extent = std::max(m->max_extent, ext[v]);
+  size_t pb = size_t(n_views) * n_points * m->point_floats * 4;
+  HIPCHK(m->points.alloc(pb));
+  HIPCHK(m->orientations.alloc(size_t(n_views) * 12));
+  HIPCHK(m->extents.alloc(size_t(n_views) * 4));
+  HIPCHK(hipMemcpy(m->points.p, pts, pb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->orientations.p, ori, size_t(n_views) * 12, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->extents.p, ext, size_t(n_views) * 4, hipMemcpyHostToDevice));
+  auto& vec = region ? ctx->region_models : ctx->depth_models;
+  vec.push_back(std::move(m));
+  return int(vec.size()) - 1;
+}
+
+int LoadModel(Ctx* ctx, const char* path, bool region) {
+  REQUIRE(path, M3T_ERR_INVALID_ARGUMENT, "null path");
+  HostModel h;
+  std::string err;
+  if (!ParseModelFile(path, region, &h, &err)) return Fail(ctx, M3T_ERR_IO, err);
+  return CreateModel(ctx, region, h.n_views, h.n_points, h.points.data(), h.orientations.data(), h.extents.data(),
+                     h.stride, h.max_radius);
+}
+
+int CreateCamera(Ctx* ctx, const m3t_intrinsics* intr, const float* w2c, bool depth, float depth_scale) {
+  REQUIRE(intr && w2c && intr->width > 0 && intr->height > 0, M3T_ERR_INVALID_ARGUMENT, "bad camera description");
+  auto c = std::make_unique<Camera>();
+  c->is_depth = depth;
+  c->intr = *intr;
+  std::memcpy(c->world2camera, w2c, 64);
+  c->depth_scale = depth_scale;
+  size_t row = size_t(intr->width) * (depth ? 2 : 3);
+  c->pitch = uint32_t((row + 63) / 64 * 64);
+  c->frame_bytes = size_t(c->pitch) * intr->height;
+  c->n_slots = 1;
+  c->has_image.assign(1, false);
+  HIPCHK(c->ring.alloc(c->frame_bytes));
+  ctx->cameras.push_back(std::move(c));
+  ctx->cams_dirty = true;
+  return int(ctx->cameras.size()) - 1;
+}
+
+int UploadFrame(Ctx* ctx, int id, int slot, const void* pixels, size_t row_step) {
+  REQUIRE(id >= 0 && id < int(ctx->cameras.size()) && pixels, M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+  Camera& c = *ctx->cameras[id];
+  REQUIRE(slot >= 0 && slot < c.n_slots, M3T_ERR_INVALID_ARGUMENT, "bad frame slot");
+  size_t row = size_t(c.intr.width) * (c.is_depth ? 2 : 3);
+  REQUIRE(row_step >= row, M3T_ERR_INVALID_ARGUMENT, "row_step smaller than one image row");
+  uint8_t* dst = c.ring.as<uint8_t>() + size_t(slot) * c.frame_bytes;
+  HIPCHK(hipMemcpy2DAsync(dst, c.pitch, pixels, row_step, row, c.intr.height, hipMemcpyHostToDevice, ctx->stream));
+  // the host buffer is only borrowed for the duration of the call
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  c.has_image[slot] = true;
+  return M3T_OK;
+}
+
+// ---- device tables -----------------------------------------------------------
+int SyncPosesToHost(Ctx* ctx) {
+  // device is authoritative after any device-side optimisation
+  size_t n = ctx->body_poses.size() / 16;
+  if (n == 0 || ctx->poses_dirty_host) return M3T_OK;
+  HIPCHK(hipMemcpyAsync(ctx->body_poses.data(), ctx->d_poses.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return M3T_OK;
+}
+
+void ComputeLayout(Ctx* ctx) {
+  int nl = 1, ns = 1, bins3 = 0, np = 1;
+  bool hist_lds = !ctx->region_mods.empty();
+  for (auto& m : ctx->region_mods) {
+    nl = std::max(nl, m->p.n_lines_max);
+    ns = std::max(ns, m->dev.n_seg);
+    int b = m->p.n_histogram_bins;
+    bins3 = std::max(bins3, b * b * b);
+  }
+  for (auto& m : ctx->depth_mods) np = std::max(np, m->p.n_points_max);
+  // the LDS-staged pair table must fit next to the line buffers (<= 16 bins: 32 KB)
+  if (bins3 * 8 > 32 * 1024) hist_lds = false;
+  TrackLdsLayout L{};
+  L.nl = nl;
+  L.ns = ns;
+  int off = 0;
+  L.off_misc = off; off += M3T_MISC_FLOATS;
+  L.off_state = off; off += LS_FIELDS * nl;
+  L.off_chain = off; off += nl * ns;
+  L.off_seg_f = off; off += nl * ns;
+  L.off_seg_b = off; off += nl * ns;
+  ctx->off_points = off;
+  ctx->np_max = np;
+  int off_with_points = off + (ctx->depth_mods.empty() ? 0 : PS_FIELDS * np);
+  if (hist_lds) {
+    L.off_hist = (off_with_points + 3) / 4 * 4;
+    L.total_floats = L.off_hist + bins3 * 2;
+  } else {
+    L.off_hist = -1;
+    L.total_floats = off_with_points;
+  }
+  ctx->layout = L;
+  ctx->lds_track = size_t(L.total_floats) * 4;
+  // the correspondence-only kernel does not need the depth point block
+  ctx->lds_corr = ctx->lds_track;
+  ctx->lds_depth = size_t(M3T_MISC_FLOATS + PS_FIELDS * np) * 4;
+  size_t counts = size_t(bins3) * 4;
+  ctx->hist_counts_in_lds = (M3T_MISC_FLOATS * 4 + counts) <= 160 * 1024;
+  ctx->lds_hist = M3T_MISC_FLOATS * 4 + (ctx->hist_counts_in_lds ? counts : 0);
+}
+
+int UploadTables(Ctx* ctx) {
+  if (ctx->cams_dirty || ctx->tables_dirty) {
+    std::vector<CameraDev> cams(ctx->cameras.size());
+    for (size_t i = 0; i < cams.size(); ++i) {
+      const Camera& c = *ctx->cameras[i];
+      CameraDev& d = cams[i];
+      d.image = c.ring.as<uint8_t>() + size_t(c.current) * c.frame_bytes;
+      d.pitch = c.pitch;
+      d.width = c.intr.width;
+      d.height = c.intr.height;
+      d.fu = c.intr.fu; d.fv = c.intr.fv; d.ppu = c.intr.ppu; d.ppv = c.intr.ppv;
+      d.depth_scale = c.depth_scale;
+      std::memcpy(d.world2camera, c.world2camera, 64);
+    }
+    if (ctx->d_cams.bytes < cams.size() * sizeof(CameraDev)) HIPCHK(ctx->d_cams.alloc(cams.size() * sizeof(CameraDev) * 2));
+    if (!cams.empty())
+      HIPCHK(hipMemcpyAsync(ctx->d_cams.p, cams.data(), cams.size() * sizeof(CameraDev), hipMemcpyHostToDevice,
+                            ctx->stream));
+    // pageable source: the runtime stages it before returning, but be explicit about lifetime
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->cams_dirty = false;
+  }
+  if (ctx->tables_dirty) {
+    std::vector<RegionModDev> r(ctx->region_mods.size());
+    for (size_t i = 0; i < r.size(); ++i) r[i] = ctx->region_mods[i]->dev;
+    std::vector<DepthModDev> d(ctx->depth_mods.size());
+    for (size_t i = 0; i < d.size(); ++i) d[i] = ctx->depth_mods[i]->dev;
+    HIPCHK(ctx->d_region.alloc(std::max<size_t>(1, r.size()) * sizeof(RegionModDev)));
+    HIPCHK(ctx->d_depth.alloc(std::max<size_t>(1, d.size()) * sizeof(DepthModDev)));
+    if (!r.empty()) HIPCHK(hipMemcpy(ctx->d_region.p, r.data(), r.size() * sizeof(RegionModDev), hipMemcpyHostToDevice));
+    if (!d.empty()) HIPCHK(hipMemcpy(ctx->d_depth.p, d.data(), d.size() * sizeof(DepthModDev), hipMemcpyHostToDevice));
+    // optimizer table
+    ctx->opt_table.clear();
+    ctx->fused_possible = !ctx->optimizers.empty();
+    std::vector<char> body_used(ctx->body_poses.size() / 16, 0);
+    for (auto& o : ctx->optimizers) {
+      const Link& l = ctx->links[o.link];
+      RigidOptDev od{};
+      od.body = l.body;
+      od.region_modality = -1;
+      od.depth_modality = -1;
+      od.tikhonov_rotation = o.tr;
+      od.tikhonov_translation = o.tt;
+      for (int mid : l.modalities) {
+        const ModalityRef& ref = ctx->modalities[mid];
+        if (ref.region) od.region_modality = ref.index;
+        else od.depth_modality = ref.index;
+      }
+      if (body_used[l.body]) ctx->fused_possible = false;
+      body_used[l.body] = 1;
+      ctx->opt_table.push_back(od);
+    }
+    // the fused kernel iterates optimizers; every modality must hang on exactly one of them
+    size_t attached = 0;
+    for (auto& o : ctx->optimizers) attached += ctx->links[o.link].modalities.size();
+    if (attached != ctx->modalities.size()) ctx->fused_possible = false;
+    HIPCHK(ctx->d_opts.alloc(std::max<size_t>(1, ctx->opt_table.size()) * sizeof(RigidOptDev)));
+    if (!ctx->opt_table.empty())
+      HIPCHK(hipMemcpy(ctx->d_opts.p, ctx->opt_table.data(), ctx->opt_table.size() * sizeof(RigidOptDev),
+                       hipMemcpyHostToDevice));
+    ComputeLayout(ctx);
+    size_t max_lds = std::max(std::max(ctx->lds_track, ctx->lds_hist), ctx->lds_depth);
+    REQUIRE(max_lds <= 160 * 1024, M3T_ERR_UNSUPPORTED,
+            "per-object working set exceeds the 160 KB LDS of a CU");
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_correspondence_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_corr)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_gradient_hessian_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_corr)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_histogram_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_hist)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(depth_correspondence_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_depth)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(depth_gradient_hessian_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_depth)));
+    ctx->tables_dirty = false;
+  }
+  size_t n_bodies = ctx->body_poses.size() / 16;
+  if (ctx->pose_capacity < n_bodies) {
+    // keep device poses if they are newer than the host mirror
+    if (!ctx->poses_dirty_host && ctx->pose_capacity > 0) {
+      std::vector<float> tmp(ctx->pose_capacity * 16);
+      HIPCHK(hipMemcpy(tmp.data(), ctx->d_poses.p, tmp.size() * 4, hipMemcpyDeviceToHost));
+      std::memcpy(ctx->body_poses.data(), tmp.data(), tmp.size() * 4);
+    }
+    HIPCHK(ctx->d_poses.alloc(std::max<size_t>(1, n_bodies) * 64 * 2));
+    ctx->pose_capacity = ctx->d_poses.bytes / 64;
+    ctx->poses_dirty_host = true;
+  }
+  if (ctx->poses_dirty_host && n_bodies) {
+    HIPCHK(hipMemcpyAsync(ctx->d_poses.p, ctx->body_poses.data(), n_bodies * 64, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->poses_dirty_host = false;
+  }
+  return M3T_OK;
+}
+
+int CheckImages(Ctx* ctx) {
+  for (auto& m : ctx->region_mods) {
+    const Camera& c = *ctx->cameras[m->camera];
+    REQUIRE(c.has_image[c.current], M3T_ERR_NOT_SET_UP, "Set up color camera first (no image uploaded)");
+    if (m->p.measure_occlusions) {
+      const Camera& d = *ctx->cameras[m->depth_camera];
+      REQUIRE(d.has_image[d.current], M3T_ERR_NOT_SET_UP, "Set up depth camera first (no image uploaded)");
+    }
+  }
+  for (auto& m : ctx->depth_mods) {
+    const Camera& d = *ctx->cameras[m->camera];
+    REQUIRE(d.has_image[d.current], M3T_ERR_NOT_SET_UP, "Set up depth camera first (no image uploaded)");
+  }
+  return M3T_OK;
+}
+
+int LaunchHistogram(Ctx* ctx, int iteration, bool initialize) {
+  int n = int(ctx->region_mods.size());
+  if (n == 0) return M3T_OK;
+  hipLaunchKernelGGL(region_histogram_kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_hist, ctx->stream,
+                     ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(), iteration,
+                     initialize ? 1 : 0, ctx->hist_counts_in_lds ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  return M3T_OK;
+}
+
+int LaunchCorrespondences(Ctx* ctx, int iteration, int corr_iteration) {
+  int nr = int(ctx->region_mods.size()), nd = int(ctx->depth_mods.size());
+  if (nr) {
+    hipLaunchKernelGGL(region_correspondence_kernel, dim3(nr), dim3(M3T_BLOCK_THREADS), ctx->lds_corr, ctx->stream,
+                       ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->layout, iteration, corr_iteration);
+    HIPCHK(hipGetLastError());
+  }
+  if (nd) {
+    hipLaunchKernelGGL(depth_correspondence_kernel, dim3(nd), dim3(M3T_BLOCK_THREADS), ctx->lds_depth, ctx->stream,
+                       ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->np_max, iteration, corr_iteration);
+    HIPCHK(hipGetLastError());
+  }
+  return M3T_OK;
+}
+
+int LaunchGradientHessian(Ctx* ctx, int corr_iteration, int opt_iteration) {
+  int nr = int(ctx->region_mods.size()), nd = int(ctx->depth_mods.size());
+  if (nr) {
+    hipLaunchKernelGGL(region_gradient_hessian_kernel, dim3(nr), dim3(M3T_BLOCK_THREADS), ctx->lds_corr, ctx->stream,
+                       ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->layout, corr_iteration, opt_iteration);
+    HIPCHK(hipGetLastError());
+  }
+  if (nd) {
+    hipLaunchKernelGGL(depth_gradient_hessian_kernel, dim3(nd), dim3(M3T_BLOCK_THREADS), ctx->lds_depth, ctx->stream,
+                       ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->np_max, corr_iteration);
+    HIPCHK(hipGetLastError());
+  }
+  return M3T_OK;
+}
+
+int LaunchOptimization(Ctx* ctx) {
+  int n = int(ctx->opt_table.size());
+  if (n == 0) return M3T_OK;
+  hipLaunchKernelGGL(rigid_optimize_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
+                     ctx->d_opts.as<RigidOptDev>(), n, ctx->d_region.as<RegionModDev>(),
+                     ctx->d_depth.as<DepthModDev>(), ctx->d_poses.as<float>());
+  HIPCHK(hipGetLastError());
+  return M3T_OK;
+}
+
+int Prepare(Ctx* ctx, bool need_images) {
+  if (need_images) {
+    int r = CheckImages(ctx);
+    if (r) return r;
+  }
+  return UploadTables(ctx);
+}
+
+RegionMod* GetRegion(Ctx* ctx, int id) {
+  if (id < 0 || id >= int(ctx->modalities.size()) || !ctx->modalities[id].region) return nullptr;
+  return ctx->region_mods[ctx->modalities[id].index].get();
+}
+DepthMod* GetDepth(Ctx* ctx, int id) {
+  if (id < 0 || id >= int(ctx->modalities.size()) || ctx->modalities[id].region) return nullptr;
+  return ctx->depth_mods[ctx->modalities[id].index].get();
+}
+
+}  // namespace
+
+#define CHECK_CTX() \
+  if (!ctx) return M3T_ERR_INVALID_ARGUMENT
+
+extern "C" {
+
+int m3t_hip_create(m3t_hip_context** out, int device_id) {
+  if (!out) return M3T_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = std::string("no usable HIP device: ") + (e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return M3T_ERR_DEVICE;
+  }
+  if (device_id < 0 || device_id >= n) {
+    g_create_error = "device id out of range";
+    return M3T_ERR_INVALID_ARGUMENT;
+  }
+  auto ctx = std::make_unique<m3t_hip_context>();
+  ctx->device = device_id;
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device_id)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_create_error = std::string("device initialisation failed: ") + hipGetErrorString(e);
+    return M3T_ERR_DEVICE;
+  }
+  *out = ctx.release();
+  return M3T_OK;
+}
+
+void m3t_hip_destroy(m3t_hip_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+}
+
+const char* m3t_hip_last_error(m3t_hip_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int m3t_hip_device_info(m3t_hip_context* ctx, char* name, size_t cap, int* cus, size_t* mem) {
+  CHECK_CTX();
+  if (name && cap) {
+    std::snprintf(name, cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  }
+  if (cus) *cus = ctx->prop.multiProcessorCount;
+  if (mem) *mem = ctx->prop.totalGlobalMem;
+  return M3T_OK;
+}
+int m3t_hip_get_stream(m3t_hip_context* ctx, void** s) {
+  CHECK_CTX();
+  REQUIRE(s, M3T_ERR_INVALID_ARGUMENT, "null out pointer");
+  *s = ctx->stream;
+  return M3T_OK;
+}
+
+// ---- models -------------------------------------------------------------------
+int m3t_hip_region_model_create(m3t_hip_context* ctx, const m3t_region_model_desc* d) {
+  CHECK_CTX();
+  REQUIRE(d, M3T_ERR_INVALID_ARGUMENT, "null desc");
+  HIPCHK(hipSetDevice(ctx->device));
+  return CreateModel(ctx, true, d->n_views, d->n_points, d->data_points, d->orientations, d->contour_lengths,
+                     d->stride_depth_offset, d->max_radius_depth_offset);
+}
+int m3t_hip_depth_model_create(m3t_hip_context* ctx, const m3t_depth_model_desc* d) {
+  CHECK_CTX();
+  REQUIRE(d, M3T_ERR_INVALID_ARGUMENT, "null desc");
+  HIPCHK(hipSetDevice(ctx->device));
+  return CreateModel(ctx, false, d->n_views, d->n_points, d->data_points, d->orientations, d->surface_areas,
+                     d->stride_depth_offset, d->max_radius_depth_offset);
+}
+int m3t_hip_region_model_load(m3t_hip_context* ctx, const char* path) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  return LoadModel(ctx, path, true);
+}
+int m3t_hip_depth_model_load(m3t_hip_context* ctx, const char* path) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  return LoadModel(ctx, path, false);
+}
+static int ModelInfo(m3t_hip_context* ctx, bool region, int id, int* nv, int* np, float* me) {
+  auto& vec = region ? ctx->region_models : ctx->depth_models;
+  REQUIRE(id >= 0 && id < int(vec.size()), M3T_ERR_INVALID_ARGUMENT, "bad model id");
+  if (nv) *nv = vec[id]->n_views;
+  if (np) *np = vec[id]->n_points;
+  if (me) *me = vec[id]->max_extent;
+  return M3T_OK;
+}
+int m3t_hip_region_model_info(m3t_hip_context* ctx, int id, int* nv, int* np, float* me) {
+  CHECK_CTX();
+  return ModelInfo(ctx, true, id, nv, np, me);
+}
+int m3t_hip_depth_model_info(m3t_hip_context* ctx, int id, int* nv, int* np, float* me) {
+  CHECK_CTX();
+  return ModelInfo(ctx, false, id, nv, np, me);
+}
+
+}  // extern "C"
+
+// single-block helper kernel for the stand-alone GetClosestView entry point
+extern "C" __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+closest_view_kernel(const float* orientations, int n_views, const float* body2camera, int* out) {
+  __shared__ float misc[256];
+  const Affine b2c = load_pose(body2camera);
+  int v = closest_view(orientations, n_views, b2c, misc);
+  if (threadIdx.x == 0) *out = v;
+}
+
+extern "C" {
+
+static int ClosestView(m3t_hip_context* ctx, bool region, int id, const float* pose, int* view) {
+  auto& vec = region ? ctx->region_models : ctx->depth_models;
+  REQUIRE(id >= 0 && id < int(vec.size()) && pose && view, M3T_ERR_INVALID_ARGUMENT, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->d_scratch_view.bytes < 128) HIPCHK(ctx->d_scratch_view.alloc(128));
+  float* d_pose = ctx->d_scratch_view.as<float>();
+  int* d_out = reinterpret_cast<int*>(d_pose + 16);
+  HIPCHK(hipMemcpyAsync(d_pose, pose, 64, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(closest_view_kernel, dim3(1), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                     vec[id]->orientations.as<float>(), vec[id]->n_views, d_pose, d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(view, d_out, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return M3T_OK;
+}
+int m3t_hip_region_model_closest_view(m3t_hip_context* ctx, int id, const float pose[16], int* view) {
+  CHECK_CTX();
+  return ClosestView(ctx, true, id, pose, view);
+}
+int m3t_hip_depth_model_closest_view(m3t_hip_context* ctx, int id, const float pose[16], int* view) {
+  CHECK_CTX();
+  return ClosestView(ctx, false, id, pose, view);
+}
+
+// ---- cameras --------------------------------------------------------------------
+int m3t_hip_color_camera_create(m3t_hip_context* ctx, const m3t_intrinsics* i, const float w2c[16]) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  return CreateCamera(ctx, i, w2c, false, 0.0f);
+}
+int m3t_hip_depth_camera_create(m3t_hip_context* ctx, const m3t_intrinsics* i, const float w2c[16], float depth_scale) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  return CreateCamera(ctx, i, w2c, true, depth_scale);
+}
+int m3t_hip_camera_upload(m3t_hip_context* ctx, int id, const void* pixels, size_t row_step) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  REQUIRE(id >= 0 && id < int(ctx->cameras.size()), M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+  return UploadFrame(ctx, id, ctx->cameras[id]->current, pixels, row_step);
+}
+int m3t_hip_camera_set_world2camera_pose(m3t_hip_context* ctx, int id, const float w2c[16]) {
+  CHECK_CTX();
+  REQUIRE(id >= 0 && id < int(ctx->cameras.size()) && w2c, M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+  std::memcpy(ctx->cameras[id]->world2camera, w2c, 64);
+  ctx->cams_dirty = true;
+  return M3T_OK;
+}
+int m3t_hip_camera_set_ring(m3t_hip_context* ctx, int id, int n_slots) {
+  CHECK_CTX();
+  REQUIRE(id >= 0 && id < int(ctx->cameras.size()) && n_slots >= 1, M3T_ERR_INVALID_ARGUMENT, "bad arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  Camera& c = *ctx->cameras[id];
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(c.ring.alloc(c.frame_bytes * size_t(n_slots)));
+  c.n_slots = n_slots;
+  c.current = 0;
+  c.has_image.assign(n_slots, false);
+  ctx->cams_dirty = true;
+  return M3T_OK;
+}
+int m3t_hip_camera_upload_slot(m3t_hip_context* ctx, int id, int slot, const void* pixels, size_t row_step) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  return UploadFrame(ctx, id, slot, pixels, row_step);
+}
+int m3t_hip_camera_select_slot(m3t_hip_context* ctx, int id, int slot) {
+  CHECK_CTX();
+  REQUIRE(id >= 0 && id < int(ctx->cameras.size()), M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+  Camera& c = *ctx->cameras[id];
+  REQUIRE(slot >= 0 && slot < c.n_slots, M3T_ERR_INVALID_ARGUMENT, "bad frame slot");
+  if (c.current != slot) {
+    c.current = slot;
+    ctx->cams_dirty = true;
+  }
+  return M3T_OK;
+}
+int m3t_hip_cameras_select_slot(m3t_hip_context* ctx, int slot) {
+  CHECK_CTX();
+  for (size_t i = 0; i < ctx->cameras.size(); ++i) {
+    int r = m3t_hip_camera_select_slot(ctx, int(i), slot);
+    if (r) return r;
+  }
+  return M3T_OK;
+}
+
+// ---- bodies ---------------------------------------------------------------------
+int m3t_hip_body_create(m3t_hip_context* ctx, const float pose[16]) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = SyncPosesToHost(ctx);
+  if (r) return r;
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float* src = pose ? pose : ident;
+  ctx->body_poses.insert(ctx->body_poses.end(), src, src + 16);
+  ctx->poses_dirty_host = true;
+  ctx->tables_dirty = true;
+  return int(ctx->body_poses.size() / 16) - 1;
+}
+int m3t_hip_body_set_body2world_pose(m3t_hip_context* ctx, int id, const float pose[16]) {
+  CHECK_CTX();
+  REQUIRE(id >= 0 && id < int(ctx->body_poses.size() / 16) && pose, M3T_ERR_INVALID_ARGUMENT, "bad body id");
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = SyncPosesToHost(ctx);
+  if (r) return r;
+  std::memcpy(&ctx->body_poses[size_t(id) * 16], pose, 64);
+  ctx->poses_dirty_host = true;
+  return M3T_OK;
+}
+int m3t_hip_body_get_body2world_pose(m3t_hip_context* ctx, int id, float pose[16]) {
+  CHECK_CTX();
+  REQUIRE(id >= 0 && id < int(ctx->body_poses.size() / 16) && pose, M3T_ERR_INVALID_ARGUMENT, "bad body id");
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = SyncPosesToHost(ctx);
+  if (r) return r;
+  std::memcpy(pose, &ctx->body_poses[size_t(id) * 16], 64);
+  return M3T_OK;
+}
+int m3t_hip_bodies_set_poses(m3t_hip_context* ctx, const float* poses, int n) {
+  CHECK_CTX();
+  REQUIRE(poses && n >= 0 && n <= int(ctx->body_poses.size() / 16), M3T_ERR_INVALID_ARGUMENT, "bad pose count");
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = SyncPosesToHost(ctx);
+  if (r) return r;
+  std::memcpy(ctx->body_poses.data(), poses, size_t(n) * 64);
+  ctx->poses_dirty_host = true;
+  return M3T_OK;
+}
+int m3t_hip_bodies_get_poses(m3t_hip_context* ctx, float* poses, int n) {
+  CHECK_CTX();
+  REQUIRE(poses && n >= 0 && n <= int(ctx->body_poses.size() / 16), M3T_ERR_INVALID_ARGUMENT, "bad pose count");
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = SyncPosesToHost(ctx);
+  if (r) return r;
+  std::memcpy(poses, ctx->body_poses.data(), size_t(n) * 64);
+  return M3T_OK;
+}
+
+// ---- modalities -------------------------------------------------------------------
+int m3t_hip_region_modality_create(m3t_hip_context* ctx, const m3t_region_modality_params* p, int body,
+                                   int color_camera, int model, int depth_camera) {
+  CHECK_CTX();
+  REQUIRE(p, M3T_ERR_INVALID_ARGUMENT, "null params");
+  REQUIRE(body >= 0 && body < int(ctx->body_poses.size() / 16), M3T_ERR_INVALID_ARGUMENT, "bad body id");
+  REQUIRE(color_camera >= 0 && color_camera < int(ctx->cameras.size()) && !ctx->cameras[color_camera]->is_depth,
+          M3T_ERR_INVALID_ARGUMENT, "bad color camera id");
+  REQUIRE(model >= 0 && model < int(ctx->region_models.size()), M3T_ERR_INVALID_ARGUMENT, "bad region model id");
+  REQUIRE(!p->use_region_checking && !p->model_occlusions, M3T_ERR_UNSUPPORTED,
+          "renderer-fed branches (region checking / modelled occlusions) are not supported");
+  if (p->measure_occlusions)
+    REQUIRE(depth_camera >= 0 && depth_camera < int(ctx->cameras.size()) && ctx->cameras[depth_camera]->is_depth,
+            M3T_ERR_INVALID_ARGUMENT, "measure_occlusions needs a depth camera");
+  REQUIRE(p->function_length >= 1 && p->function_length <= M3T_MAX_FUNCTION_LENGTH && p->distribution_length >= 2 &&
+              p->distribution_length <= M3T_MAX_DISTRIBUTION_LENGTH && p->n_scales >= 1 &&
+              p->n_scales <= M3T_MAX_SCALES && p->n_standard_deviations >= 1 &&
+              p->n_standard_deviations <= M3T_MAX_SCALES && p->n_lines_max >= 1,
+          M3T_ERR_INVALID_ARGUMENT, "bad region modality parameters");
+  int bitshift;
+  switch (p->n_histogram_bins) {  // color_histograms.cpp:131-158
+    case 2: bitshift = 7; break;
+    case 4: bitshift = 6; break;
+    case 8: bitshift = 5; break;
+    case 16: bitshift = 4; break;
+    case 32: bitshift = 3; break;
+    case 64: bitshift = 2; break;
+    default:
+      return Fail(ctx, M3T_ERR_INVALID_ARGUMENT, "n_bins has to be of value 2, 4, 8, 16, 32, or 64");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const Model& mdl = *ctx->region_models[model];
+  auto m = std::make_unique<RegionMod>();
+  m->p = *p;
+  m->body = body;
+  m->camera = color_camera;
+  m->depth_camera = p->measure_occlusions ? depth_camera : -1;
+  m->model = model;
+  RegionModDev& d = m->dev;
+  d.body = body;
+  d.camera = color_camera;
+  d.depth_camera = m->depth_camera;
+  d.points = mdl.points.as<float>();
+  d.orientations = mdl.orientations.as<float>();
+  d.extents = mdl.extents.as<float>();
+  d.n_views = mdl.n_views;
+  d.n_points = mdl.n_points;
+  d.max_extent = mdl.max_extent;
+  d.n_lines_max = p->n_lines_max;
+  d.use_adaptive_coverage = p->use_adaptive_coverage;
+  d.reference_contour_length = p->reference_contour_length;
+  d.min_continuous_distance = p->min_continuous_distance;
+  d.function_length = p->function_length;
+  d.distribution_length = p->distribution_length;
+  d.n_seg = p->function_length + p->distribution_length - 1;
+  // PrecalculateFunctionLookup region_modality.cpp:910-923
+  for (int i = 0; i < p->function_length; ++i) {
+    float x = float(i) - float(p->function_length - 1) / 2.0f;
+    if (p->function_slope == 0.0f)
+      d.function_lookup_f[i] = 0.5f - p->function_amplitude * ((0.0f < x) - (x < 0.0f));
+    else
+      d.function_lookup_f[i] = 0.5f - p->function_amplitude * std::tanh(x / (2.0f * p->function_slope));
+    d.function_lookup_b[i] = 1.0f - d.function_lookup_f[i];
+  }
+  // PrecalculateDistributionVariables region_modality.cpp:925-936
+  d.distribution_length_minus_1_half = (float(p->distribution_length) - 1.0f) / 2.0f;
+  d.distribution_length_plus_1_half = (float(p->distribution_length) + 1.0f) / 2.0f;
+  float mev_laplace = 1.0f / (2.0f * powf(atanhf(2.0f * p->function_amplitude), 2.0f));
+  d.min_expected_variance = std::max(mev_laplace, p->function_slope);
+  d.learning_rate = p->learning_rate;
+  d.n_global_iterations = p->n_global_iterations;
+  d.n_scales = p->n_scales;
+  d.n_standard_deviations = p->n_standard_deviations;
+  for (int i = 0; i < M3T_MAX_SCALES; ++i) {
+    d.scales[i] = p->scales[i];
+    d.standard_deviations[i] = p->standard_deviations[i];
+  }
+  for (int i = 0; i < p->n_scales; ++i)
+    REQUIRE(p->scales[i] >= 1, M3T_ERR_INVALID_ARGUMENT, "scales must be >= 1");
+  d.n_bins = p->n_histogram_bins;
+  d.bitshift = bitshift;
+  d.learning_rate_f = p->learning_rate_f;
+  d.learning_rate_b = p->learning_rate_b;
+  d.unconsidered_line_length = p->unconsidered_line_length;
+  d.max_considered_line_length = p->max_considered_line_length;
+  d.measure_occlusions = p->measure_occlusions;
+  d.measured_depth_offset_id = 0;
+  if (p->measure_occlusions) {  // PrecalculateModelVariables region_modality.cpp:966-991
+    REQUIRE(p->measured_depth_offset_radius <= mdl.max_radius_depth_offset, M3T_ERR_INVALID_ARGUMENT,
+            "Measured depth offset radius too large");
+    d.measured_depth_offset_id = int(p->measured_depth_offset_radius / mdl.stride_depth_offset + 0.5f);
+    REQUIRE(d.measured_depth_offset_id < M3T_N_DEPTH_OFFSETS, M3T_ERR_INVALID_ARGUMENT, "depth offset id out of range");
+  }
+  d.measured_occlusion_radius = p->measured_occlusion_radius;
+  d.measured_occlusion_threshold = p->measured_occlusion_threshold;
+  d.n_unoccluded_iterations = p->n_unoccluded_iterations;
+  d.min_n_unoccluded_lines = p->min_n_unoccluded_lines;
+  d.first_iteration = 0;
+  size_t bins3 = size_t(d.n_bins) * d.n_bins * d.n_bins;
+  HIPCHK(m->hist_f.alloc(bins3 * 4));
+  HIPCHK(m->hist_b.alloc(bins3 * 4));
+  HIPCHK(m->hist_norm.alloc(bins3 * 8));
+  if (bins3 * 4 + M3T_MISC_FLOATS * 4 > 160 * 1024) HIPCHK(m->count_scratch.alloc(bins3 * 4));
+  HIPCHK(m->line_state.alloc(size_t(LS_FIELDS) * d.n_lines_max * 4));
+  HIPCHK(m->gh.alloc(42 * 4));
+  HIPCHK(hipMemset(m->line_state.p, 0, m->line_state.bytes));
+  HIPCHK(hipMemset(m->gh.p, 0, m->gh.bytes));
+  {  // SetUpHistograms color_histograms.cpp:160-172: uniform 1/n^3
+    std::vector<float> u(bins3, 1.0f / float(bins3));
+    std::vector<float> nrm(bins3 * 2, 0.5f);
+    HIPCHK(hipMemcpy(m->hist_f.p, u.data(), bins3 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->hist_b.p, u.data(), bins3 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->hist_norm.p, nrm.data(), bins3 * 8, hipMemcpyHostToDevice));
+  }
+  d.histogram_f = m->hist_f.as<float>();
+  d.histogram_b = m->hist_b.as<float>();
+  d.histogram_norm = m->hist_norm.as<float2>();
+  d.count_scratch = m->count_scratch.as<uint32_t>();
+  d.line_state = m->line_state.as<float>();
+  d.gradient_hessian = m->gh.as<float>();
+  ctx->region_mods.push_back(std::move(m));
+  ctx->modalities.push_back({true, int(ctx->region_mods.size()) - 1});
+  ctx->tables_dirty = true;
+  return int(ctx->modalities.size()) - 1;
+}
+
+int m3t_hip_depth_modality_create(m3t_hip_context* ctx, const m3t_depth_modality_params* p, int body, int depth_camera,
+                                  int model) {
+  CHECK_CTX();
+  REQUIRE(p, M3T_ERR_INVALID_ARGUMENT, "null params");
+  REQUIRE(body >= 0 && body < int(ctx->body_poses.size() / 16), M3T_ERR_INVALID_ARGUMENT, "bad body id");
+  REQUIRE(depth_camera >= 0 && depth_camera < int(ctx->cameras.size()) && ctx->cameras[depth_camera]->is_depth,
+          M3T_ERR_INVALID_ARGUMENT, "bad depth camera id");
+  REQUIRE(model >= 0 && model < int(ctx->depth_models.size()), M3T_ERR_INVALID_ARGUMENT, "bad depth model id");
+  REQUIRE(!p->use_silhouette_checking && !p->model_occlusions, M3T_ERR_UNSUPPORTED,
+          "renderer-fed branches (silhouette checking / modelled occlusions) are not supported");
+  REQUIRE(p->n_considered_distances >= 1 && p->n_considered_distances <= M3T_MAX_SCALES &&
+              p->n_standard_deviations >= 1 && p->n_standard_deviations <= M3T_MAX_SCALES && p->n_points_max >= 1,
+          M3T_ERR_INVALID_ARGUMENT, "bad depth modality parameters");
+  HIPCHK(hipSetDevice(ctx->device));
+  const Model& mdl = *ctx->depth_models[model];
+  auto m = std::make_unique<DepthMod>();
+  m->p = *p;
+  m->body = body;
+  m->camera = depth_camera;
+  m->model = model;
+  DepthModDev& d = m->dev;
+  d.body = body;
+  d.camera = depth_camera;
+  d.points = mdl.points.as<float>();
+  d.orientations = mdl.orientations.as<float>();
+  d.extents = mdl.extents.as<float>();
+  d.n_views = mdl.n_views;
+  d.n_points = mdl.n_points;
+  d.max_extent = mdl.max_extent;
+  d.stride_depth_offset = mdl.stride_depth_offset;
+  d.n_points_max = p->n_points_max;
+  d.use_adaptive_coverage = p->use_adaptive_coverage;
+  d.use_depth_scaling = p->use_depth_scaling;
+  d.reference_surface_area = p->reference_surface_area;
+  d.stride_length = p->stride_length;
+  d.n_considered_distances = p->n_considered_distances;
+  d.n_standard_deviations = p->n_standard_deviations;
+  for (int i = 0; i < M3T_MAX_SCALES; ++i) {
+    d.considered_distances[i] = p->considered_distances[i];
+    d.standard_deviations[i] = p->standard_deviations[i];
+  }
+  d.measure_occlusions = p->measure_occlusions;
+  d.measured_depth_offset_radius = p->measured_depth_offset_radius;
+  d.measured_occlusion_radius = p->measured_occlusion_radius;
+  d.measured_occlusion_threshold = p->measured_occlusion_threshold;
+  d.n_unoccluded_iterations = p->n_unoccluded_iterations;
+  d.min_n_unoccluded_points = p->min_n_unoccluded_points;
+  d.first_iteration = 0;  // DepthModality never sets first_iteration_ (depth_modality.h:358)
+  HIPCHK(m->point_state.alloc(size_t(PS_FIELDS) * d.n_points_max * 4));
+  HIPCHK(m->gh.alloc(42 * 4));
+  HIPCHK(hipMemset(m->point_state.p, 0, m->point_state.bytes));
+  HIPCHK(hipMemset(m->gh.p, 0, m->gh.bytes));
+  d.point_state = m->point_state.as<float>();
+  d.gradient_hessian = m->gh.as<float>();
+  ctx->depth_mods.push_back(std::move(m));
+  ctx->modalities.push_back({false, int(ctx->depth_mods.size()) - 1});
+  ctx->tables_dirty = true;
+  return int(ctx->modalities.size()) - 1;
+}
+
+static float* ModalityGh(m3t_hip_context* ctx, int id) {
+  if (id < 0 || id >= int(ctx->modalities.size())) return nullptr;
+  const ModalityRef& r = ctx->modalities[id];
+  return r.region ? ctx->region_mods[r.index]->gh.as<float>() : ctx->depth_mods[r.index]->gh.as<float>();
+}
+int m3t_hip_modality_get_gradient_hessian(m3t_hip_context* ctx, int id, float g[6], float h[36]) {
+  CHECK_CTX();
+  float* d = ModalityGh(ctx, id);
+  REQUIRE(d, M3T_ERR_INVALID_ARGUMENT, "bad modality id");
+  REQUIRE(ctx->state_valid, M3T_ERR_NOT_SET_UP,
+          "gradient/hessian are not written back in fused mode 1 (use m3t_hip_set_fused_step(ctx, 0 or 2))");
+  HIPCHK(hipSetDevice(ctx->device));
+  float buf[42];
+  HIPCHK(hipMemcpyAsync(buf, d, sizeof(buf), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (g) std::memcpy(g, buf, 24);
+  if (h) std::memcpy(h, buf + 6, 144);
+  return M3T_OK;
+}
+int m3t_hip_modality_set_gradient_hessian(m3t_hip_context* ctx, int id, const float g[6], const float h[36]) {
+  CHECK_CTX();
+  float* d = ModalityGh(ctx, id);
+  REQUIRE(d && g && h, M3T_ERR_INVALID_ARGUMENT, "bad modality id");
+  HIPCHK(hipSetDevice(ctx->device));
+  float buf[42];
+  std::memcpy(buf, g, 24);
+  std::memcpy(buf + 6, h, 144);
+  HIPCHK(hipMemcpyAsync(d, buf, sizeof(buf), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->state_valid = true;
+  return M3T_OK;
+}
+
+int m3t_hip_region_modality_get_lines(m3t_hip_context* ctx, int id, m3t_data_line* out, int capacity, int* n) {
+  CHECK_CTX();
+  RegionMod* m = GetRegion(ctx, id);
+  REQUIRE(m, M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
+  REQUIRE(ctx->state_valid, M3T_ERR_NOT_SET_UP,
+          "line state is not written back in fused mode 1 (use m3t_hip_set_fused_step(ctx, 0 or 2))");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nl = m->p.n_lines_max;
+  std::vector<float> st(size_t(LS_FIELDS) * nl);
+  HIPCHK(hipMemcpyAsync(st.data(), m->line_state.p, st.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int count = 0;
+  for (int l = 0; l < nl; ++l) {
+    int flags;
+    std::memcpy(&flags, &st[size_t(LS_VALID) * nl + l], 4);
+    if (!(flags & 1)) continue;
+    if (out && count < capacity) {
+      m3t_data_line& o = out[count];
+      std::memset(&o, 0, sizeof(o));
+      o.center_f_body[0] = st[size_t(LS_CX) * nl + l];
+      o.center_f_body[1] = st[size_t(LS_CY) * nl + l];
+      o.center_f_body[2] = st[size_t(LS_CZ) * nl + l];
+      o.center_u = st[size_t(LS_CENTER_U) * nl + l];
+      o.center_v = st[size_t(LS_CENTER_V) * nl + l];
+      o.normal_u = st[size_t(LS_NORMAL_U) * nl + l];
+      o.normal_v = st[size_t(LS_NORMAL_V) * nl + l];
+      o.delta_r = st[size_t(LS_DELTA_R) * nl + l];
+      o.normal_component_to_scale = st[size_t(LS_NCTS) * nl + l];
+      o.continuous_distance = st[size_t(LS_CONT) * nl + l];
+      o.mean = st[size_t(LS_MEAN) * nl + l];
+      o.measured_variance = st[size_t(LS_VAR) * nl + l];
+      for (int d = 0; d < m->p.distribution_length; ++d) o.distribution[d] = st[size_t(LS_DIST0 + d) * nl + l];
+      o.valid = 1;
+      o.model_point_index = l;
+    }
+    ++count;
+  }
+  if (n) *n = count;
+  return M3T_OK;
+}
+
+int m3t_hip_depth_modality_get_points(m3t_hip_context* ctx, int id, m3t_data_point* out, int capacity, int* n) {
+  CHECK_CTX();
+  DepthMod* m = GetDepth(ctx, id);
+  REQUIRE(m, M3T_ERR_INVALID_ARGUMENT, "bad depth modality id");
+  REQUIRE(ctx->state_valid, M3T_ERR_NOT_SET_UP,
+          "point state is not written back in fused mode 1 (use m3t_hip_set_fused_step(ctx, 0 or 2))");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int np = m->p.n_points_max;
+  std::vector<float> st(size_t(PS_FIELDS) * np);
+  HIPCHK(hipMemcpyAsync(st.data(), m->point_state.p, st.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int count = 0;
+  for (int i = 0; i < np; ++i) {
+    int flags;
+    std::memcpy(&flags, &st[size_t(PS_VALID) * np + i], 4);
+    if (!(flags & 1)) continue;
+    if (out && count < capacity) {
+      m3t_data_point& o = out[count];
+      std::memset(&o, 0, sizeof(o));
+      for (int k = 0; k < 3; ++k) {
+        o.center_f_body[k] = st[size_t(PS_CX + k) * np + i];
+        o.normal_f_body[k] = st[size_t(PS_NX + k) * np + i];
+        o.correspondence_center_f_camera[k] = st[size_t(PS_CORR_X + k) * np + i];
+      }
+      o.center_u = st[size_t(PS_CENTER_U) * np + i];
+      o.center_v = st[size_t(PS_CENTER_V) * np + i];
+      o.depth = st[size_t(PS_DEPTH) * np + i];
+      o.valid = 1;
+      o.model_point_index = i;
+    }
+    ++count;
+  }
+  if (n) *n = count;
+  return M3T_OK;
+}
+
+int m3t_hip_region_modality_get_histograms(m3t_hip_context* ctx, int id, float* f, float* b) {
+  CHECK_CTX();
+  RegionMod* m = GetRegion(ctx, id);
+  REQUIRE(m, M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (f) HIPCHK(hipMemcpy(f, m->hist_f.p, m->hist_f.bytes, hipMemcpyDeviceToHost));
+  if (b) HIPCHK(hipMemcpy(b, m->hist_b.p, m->hist_b.bytes, hipMemcpyDeviceToHost));
+  return M3T_OK;
+}
+int m3t_hip_region_modality_set_histograms(m3t_hip_context* ctx, int id, const float* f, const float* b) {
+  CHECK_CTX();
+  RegionMod* m = GetRegion(ctx, id);
+  REQUIRE(m && f && b, M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  size_t bins3 = m->hist_f.bytes / 4;
+  std::vector<float> nrm(bins3 * 2);
+  for (size_t i = 0; i < bins3; ++i) {  // MultiplyPixelColorProbability :1585-1593 per bin
+    float pf = f[i], pb = b[i];
+    if (pf || pb) {
+      float sum = pf;
+      sum += pb;
+      nrm[2 * i] = pf / sum;
+      nrm[2 * i + 1] = pb / sum;
+    } else {
+      nrm[2 * i] = 0.5f;
+      nrm[2 * i + 1] = 0.5f;
+    }
+  }
+  HIPCHK(hipMemcpy(m->hist_f.p, f, bins3 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->hist_b.p, b, bins3 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->hist_norm.p, nrm.data(), bins3 * 8, hipMemcpyHostToDevice));
+  return M3T_OK;
+}
+
+// ---- links / optimizers ---------------------------------------------------------------
+static bool IsIdentity(const float* p) {
+  if (!p) return true;
+  static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  return std::memcmp(p, ident, 64) == 0;
+}
+int m3t_hip_link_create(m3t_hip_context* ctx, int body, int parent, const float body2joint[16],
+                        const float joint2parent[16], const int free_directions[6], int) {
+  CHECK_CTX();
+  REQUIRE(body >= 0 && body < int(ctx->body_poses.size() / 16), M3T_ERR_UNSUPPORTED,
+          "links without a body are part of the multi-body row (not supported yet)");
+  bool all_free = true;
+  if (free_directions)
+    for (int i = 0; i < 6; ++i) all_free &= free_directions[i] != 0;
+  REQUIRE(parent < 0 && IsIdentity(body2joint) && IsIdentity(joint2parent) && all_free, M3T_ERR_UNSUPPORTED,
+          "kinematic trees (child links, partial joints, body2joint != I) are not supported yet");
+  ctx->links.push_back(Link{body, {}});
+  ctx->tables_dirty = true;
+  return int(ctx->links.size()) - 1;
+}
+int m3t_hip_link_add_modality(m3t_hip_context* ctx, int link, int modality) {
+  CHECK_CTX();
+  REQUIRE(link >= 0 && link < int(ctx->links.size()) && modality >= 0 && modality < int(ctx->modalities.size()),
+          M3T_ERR_INVALID_ARGUMENT, "bad ids");
+  const ModalityRef& ref = ctx->modalities[modality];
+  int mbody = ref.region ? ctx->region_mods[ref.index]->body : ctx->depth_mods[ref.index]->body;
+  REQUIRE(mbody == ctx->links[link].body, M3T_ERR_INVALID_ARGUMENT, "modality and link refer to different bodies");
+  for (int mid : ctx->links[link].modalities)
+    REQUIRE(ctx->modalities[mid].region != ref.region, M3T_ERR_UNSUPPORTED,
+            "at most one region and one depth modality per link");
+  ctx->links[link].modalities.push_back(modality);
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
+int m3t_hip_optimizer_create(m3t_hip_context* ctx, int root_link, float tr, float tt) {
+  CHECK_CTX();
+  REQUIRE(root_link >= 0 && root_link < int(ctx->links.size()), M3T_ERR_INVALID_ARGUMENT, "bad root link");
+  ctx->optimizers.push_back(Optimizer{root_link, tr, tt});
+  ctx->tables_dirty = true;
+  return int(ctx->optimizers.size()) - 1;
+}
+int m3t_hip_optimizer_create_rigid(m3t_hip_context* ctx, int body, int n, const int* mids, float tr, float tt) {
+  CHECK_CTX();
+  int link = m3t_hip_link_create(ctx, body, -1, nullptr, nullptr, nullptr, 1);
+  if (link < 0) return link;
+  for (int i = 0; i < n; ++i) {
+    int r = m3t_hip_link_add_modality(ctx, link, mids[i]);
+    if (r < 0) return r;
+  }
+  return m3t_hip_optimizer_create(ctx, link, tr, tt);
+}
+int m3t_hip_constraint_create(m3t_hip_context* ctx, int, int, int, const float*, const float*, const int*) {
+  CHECK_CTX();
+  return Fail(ctx, M3T_ERR_UNSUPPORTED, "constraints are part of the multi-body row (not supported yet)");
+}
+int m3t_hip_link_get_link2world_pose(m3t_hip_context* ctx, int link, float pose[16]) {
+  CHECK_CTX();
+  REQUIRE(link >= 0 && link < int(ctx->links.size()), M3T_ERR_INVALID_ARGUMENT, "bad link id");
+  return m3t_hip_body_get_body2world_pose(ctx, ctx->links[link].body, pose);
+}
+
+// ---- tracker sub-steps -------------------------------------------------------------------
+int m3t_hip_tracker_set_iterations(m3t_hip_context* ctx, int n_corr, int n_update) {
+  CHECK_CTX();
+  REQUIRE(n_corr >= 0 && n_update >= 0, M3T_ERR_INVALID_ARGUMENT, "bad iteration counts");
+  ctx->n_corr_iterations = n_corr;
+  ctx->n_update_iterations = n_update;
+  return M3T_OK;
+}
+int m3t_hip_set_fused_step(m3t_hip_context* ctx, int mode) {
+  CHECK_CTX();
+  REQUIRE(mode >= 0 && mode <= 2, M3T_ERR_INVALID_ARGUMENT, "mode must be 0, 1 or 2");
+  ctx->fused_mode = mode;
+  return M3T_OK;
+}
+
+int m3t_hip_start_modalities(m3t_hip_context* ctx, int iteration) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  for (auto& m : ctx->region_mods) {  // RegionModality::StartModality :378
+    if (m->dev.first_iteration != iteration) {
+      m->dev.first_iteration = iteration;
+      ctx->tables_dirty = true;
+    }
+  }
+  int r = Prepare(ctx, true);
+  if (r) return r;
+  return LaunchHistogram(ctx, iteration, true);
+}
+int m3t_hip_calculate_correspondences(m3t_hip_context* ctx, int iteration, int corr_iteration) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = Prepare(ctx, true);
+  if (r) return r;
+  ctx->state_valid = true;
+  return LaunchCorrespondences(ctx, iteration, corr_iteration);
+}
+int m3t_hip_calculate_gradient_and_hessian(m3t_hip_context* ctx, int, int corr_iteration, int opt_iteration) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = Prepare(ctx, false);
+  if (r) return r;
+  REQUIRE(ctx->state_valid, M3T_ERR_NOT_SET_UP, "CalculateCorrespondences has to be called first");
+  return LaunchGradientHessian(ctx, corr_iteration, opt_iteration);
+}
+int m3t_hip_calculate_optimization(m3t_hip_context* ctx, int, int, int) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = Prepare(ctx, false);
+  if (r) return r;
+  return LaunchOptimization(ctx);
+}
+int m3t_hip_calculate_results(m3t_hip_context* ctx, int iteration) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = Prepare(ctx, true);
+  if (r) return r;
+  return LaunchHistogram(ctx, iteration, false);
+}
+
+int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = Prepare(ctx, true);
+  if (r) return r;
+  if (ctx->fused_mode >= 1 && ctx->fused_possible) {
+    int n = int(ctx->opt_table.size());
+    hipLaunchKernelGGL(tracking_step_kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
+                       ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                       ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
+                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    ctx->state_valid = ctx->fused_mode == 2;
+  } else {
+    // Tracker::ExecuteTrackingStep tracker.cpp:344-364, one launch per sub-step
+    for (int c = 0; c < ctx->n_corr_iterations; ++c) {
+      if ((r = LaunchCorrespondences(ctx, iteration, c))) return r;
+      for (int u = 0; u < ctx->n_update_iterations; ++u) {
+        if ((r = LaunchGradientHessian(ctx, c, u))) return r;
+        if ((r = LaunchOptimization(ctx))) return r;
+      }
+    }
+    ctx->state_valid = true;
+  }
+  return LaunchHistogram(ctx, iteration, false);
+}
+int m3t_hip_execute_tracking_cycle(m3t_hip_context* ctx, int iteration) {
+  return m3t_hip_execute_tracking_step(ctx, iteration);
+}
+int m3t_hip_sync(m3t_hip_context* ctx) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return M3T_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1184 @@
+// m3t_kernels.hip — gfx950 (CDNA4, wave64) kernels for M3T's per-frame pose
+// optimisation hot path.  Hand-written HIP, no MFMA (gather + reduce work),
+// one workgroup per tracked object, all per-object intermediates in LDS.
+//
+// Kernel inventory:
+//   region_histogram_kernel   StartModality / CalculateResults: contour-line colour
+//                             sampling into an LDS count table + histogram blend
+//   region_correspondence_kernel  RegionModality::CalculateCorrespondences
+//   region_gradient_hessian_kernel RegionModality::CalculateGradientAndHessian
+//   depth_correspondence_kernel / depth_gradient_hessian_kernel  DepthModality
+//   rigid_optimize_kernel     Optimizer::CalculateOptimization (dof 6) + Link::UpdatePoses
+//   tracking_step_kernel      the whole ExecuteTrackingStep loop nest fused on device
+//
+// Arithmetic follows the reference expression by expression in IEEE f32
+// (compile with -ffp-contract=off; hipcc's f32 divide / sqrt are correctly
+// rounded by default), so every discrete decision (pixel truncation, validity
+// tests, distribution index) matches the CPU restatement bit for bit; only
+// the order of the g/H sums over lines differs (tree instead of sequential).
+// Reference citations are relative to M3T/src/.
+
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include "m3t_device.h"
+
+namespace {
+
+constexpr int kWave = 64;
+// misc LDS scratch layout (floats): [0,128) view search / counters, [128,160) reduced sums,
+// [160,640) per-wave partials (16 waves x 27), [640,656) pose, [704,746) region g/H, [768,810) depth g/H
+constexpr int kMiscRed = 128, kMiscPartials = 160, kMiscPose = 640, kMiscGhRegion = 704, kMiscGhDepth = 768;
+
+// ---------------------------------------------------------------------------
+// pose math (column-major like Eigen; same expression trees as the reference)
+// ---------------------------------------------------------------------------
+struct Affine {
+  float l[9];  // linear, (r,c) = l[c*3+r]
+  float t[3];
+};
+
+__device__ __forceinline__ Affine load_pose(const float* p /*16, column-major 4x4*/) {
+  Affine a;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) a.l[c * 3 + r] = p[c * 4 + r];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) a.t[r] = p[12 + r];
+  return a;
+}
+
+// Transform * Transform: L = La*Lb, t = La*tb + ta
+__device__ __forceinline__ Affine mul_pose(const Affine& a, const Affine& b) {
+  Affine r;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      r.l[c * 3 + k] = (a.l[k] * b.l[c * 3] + a.l[3 + k] * b.l[c * 3 + 1]) + a.l[6 + k] * b.l[c * 3 + 2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r.t[k] = ((a.l[k] * b.t[0] + a.l[3 + k] * b.t[1]) + a.l[6 + k] * b.t[2]) + a.t[k];
+  return r;
+}
+
+// Transform * Vector3f: t + L*v
+__device__ __forceinline__ void apply_pose(const Affine& a, float x, float y, float z, float& ox, float& oy,
+                                           float& oz) {
+  ox = a.t[0] + ((a.l[0] * x + a.l[3] * y) + a.l[6] * z);
+  oy = a.t[1] + ((a.l[1] * x + a.l[4] * y) + a.l[7] * z);
+  oz = a.t[2] + ((a.l[2] * x + a.l[5] * y) + a.l[8] * z);
+}
+
+// Eigen compute_inverse_size3: cofactors / determinant
+__device__ __forceinline__ float cofactor3(const float* m, int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[j1 * 3 + i1] * m[j2 * 3 + i2] - m[j2 * 3 + i1] * m[j1 * 3 + i2];
+}
+__device__ __forceinline__ void inverse3(const float* m, float* r) {
+  float c00 = cofactor3(m, 0, 0), c10 = cofactor3(m, 1, 0), c20 = cofactor3(m, 2, 0);
+  float det = (c00 * m[0] + c10 * m[1]) + c20 * m[2];
+  float invdet = 1.0f / det;
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) r[cc * 3 + rr] = cofactor3(m, cc, rr) * invdet;
+}
+__device__ __forceinline__ Affine inverse_pose(const Affine& a) {
+  Affine r;
+  inverse3(a.l, r.l);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r.t[k] = -((r.l[k] * a.t[0] + r.l[3 + k] * a.t[1]) + r.l[6 + k] * a.t[2]);
+  return r;
+}
+
+__device__ __forceinline__ int f2i(float v) { return (int)v; }  // truncation like C int(float)
+__device__ __forceinline__ float i2f_bits(int v) { return __int_as_float(v); }
+__device__ __forceinline__ int f2i_bits(float v) { return __float_as_int(v); }
+
+template <typename T>
+__device__ __forceinline__ T last_valid(const T* values, int n, int idx) {  // common.h:171-176
+  return idx < n ? values[idx] : values[n - 1];
+}
+
+// ---------------------------------------------------------------------------
+// RegionModel::GetClosestView (region_model.cpp:105-130), whole block.
+// First maximum wins == (max dot, lowest index); result broadcast to all threads.
+// misc: >= 128 floats of LDS scratch.  Contains two __syncthreads().
+// ---------------------------------------------------------------------------
+__device__ int closest_view(const float* __restrict__ orientations, int n_views, const Affine& b2c, float* misc) {
+  float tn = sqrtf((b2c.t[0] * b2c.t[0] + b2c.t[1] * b2c.t[1]) + b2c.t[2] * b2c.t[2]);
+  if (tn == 0.0f) return 0;  // block-uniform
+  float tx = b2c.t[0] / tn, ty = b2c.t[1] / tn, tz = b2c.t[2] / tn;
+  float ri[9];
+  inverse3(b2c.l, ri);
+  float o0 = (ri[0] * tx + ri[3] * ty) + ri[6] * tz;
+  float o1 = (ri[1] * tx + ri[4] * ty) + ri[7] * tz;
+  float o2 = (ri[2] * tx + ri[5] * ty) + ri[8] * tz;
+  float best = -1.0f;
+  int bi = INT_MAX;
+  for (int v = threadIdx.x; v < n_views; v += blockDim.x) {
+    const float* p = orientations + 3 * (size_t)v;
+    float d = (o0 * p[0] + o1 * p[1]) + o2 * p[2];
+    if (d > best) { best = d; bi = v; }
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    float ob = __shfl_down(best, off);
+    int oi = __shfl_down(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, n_waves = blockDim.x / kWave;
+  int* imisc = reinterpret_cast<int*>(misc);
+  if (lane == 0) { misc[wave] = best; imisc[32 + wave] = bi; }
+  __syncthreads();
+  best = misc[0];
+  bi = imisc[32];
+  for (int w = 1; w < n_waves; ++w) {
+    float ob = misc[w];
+    int oi = imisc[32 + w];
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  __syncthreads();
+  return bi == INT_MAX ? 0 : bi;
+}
+
+// RegionModality::CalculateCorrespondences :417-430 (adaptive coverage)
+__device__ __forceinline__ int number_of_lines(int n_max, int adaptive, float reference, float extent, float max_extent,
+                                               int n_points) {
+  int n = n_max;
+  if (adaptive) {
+    if (reference > 0.0f) n = (int)((float)n_max * fminf(1.0f, extent / reference));
+    else n = (int)((float)n_max * extent / max_extent);
+  }
+  if (n > n_points) n = n_points;
+  return n;
+}
+
+// IsLineUnoccludedMeasured :1343-1389 / IsPointUnoccludedMeasured depth_modality.cpp:736-776
+// (window of <= (kMaxNOcclusionStrides+1)^2 u16 samples around (center_u, center_v))
+__device__ bool occlusion_window_clear(const CameraDev& dc, float center_u, float center_v, float diameter,
+                                       float depth, float depth_offset, float threshold) {
+  int stride = f2i(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
+  int n_strides = f2i(diameter / stride + 0.5f);
+  int rounded_diameter = n_strides * stride;
+  float rounded_radius = 0.5f * (float)rounded_diameter;
+  int u_min = f2i(center_u - rounded_radius + 0.5f);
+  int v_min = f2i(center_v - rounded_radius + 0.5f);
+  int u_max = u_min + rounded_diameter;
+  int v_max = v_min + rounded_diameter;
+  u_min = max(u_min, 0);
+  v_min = max(v_min, 0);
+  u_max = min(u_max, dc.width - 1);
+  v_max = min(v_max, dc.height - 1);
+  unsigned short min_depth = (unsigned short)f2i((depth - depth_offset - threshold) / dc.depth_scale);
+  for (int v = v_min; v <= v_max; v += stride) {
+    const unsigned short* row = reinterpret_cast<const unsigned short*>(dc.image + (size_t)v * dc.pitch);
+    for (int u = u_min; u <= u_max; u += stride) {
+      unsigned short d = row[u];
+      if (d > 0 && d < min_depth) return false;
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// iteration-dependent scalars (PrecalculateIterationDependentVariables :1011-1023)
+// ---------------------------------------------------------------------------
+struct RegionIter {
+  int scale;
+  float fscale;
+  int line_length, line_length_minus_1;
+  float line_length_minus_1_half, line_length_half_minus_1, variance;
+};
+__device__ __forceinline__ RegionIter region_iter(const RegionModDev& m, int corr_iteration) {
+  RegionIter it;
+  it.scale = last_valid(m.scales, m.n_scales, corr_iteration);
+  it.fscale = (float)it.scale;
+  it.line_length = m.n_seg * it.scale;
+  it.line_length_minus_1 = it.line_length - 1;
+  it.line_length_minus_1_half = (float)(it.line_length - 1) * 0.5f;
+  it.line_length_half_minus_1 = (float)(it.line_length) * 0.5f - 1.0f;
+  float sd = last_valid(m.standard_deviations, m.n_standard_deviations, corr_iteration);
+  it.variance = sd * sd;
+  return it;
+}
+
+// LDS views of one tracked object
+struct Lds {
+  float* state;  // [LS_FIELDS][nl]
+  float* chain;  // [nl][ns]   minor-axis coordinate at every segment start; later raw distribution [nl][DL]
+  float* seg_f;  // [nl][ns]
+  float* seg_b;  // [nl][ns]
+  float* misc;   // M3T_MISC_FLOATS
+  const float2* hist;  // LDS-staged histogram_norm or nullptr
+  int nl, ns;
+};
+__device__ __forceinline__ Lds carve(float* base, const TrackLdsLayout& L) {
+  Lds s;
+  s.state = base + L.off_state;
+  s.chain = base + L.off_chain;
+  s.seg_f = base + L.off_seg_f;
+  s.seg_b = base + L.off_seg_b;
+  s.misc = base + L.off_misc;
+  s.hist = L.off_hist >= 0 ? reinterpret_cast<const float2*>(base + L.off_hist) : nullptr;
+  s.nl = L.nl;
+  s.ns = L.ns;
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// RegionModality::CalculateCorrespondences (:390-465) for one object, whole block.
+// Phase A  one thread per line: CalculateBasicLineData :1231, IsLineValid :1252,
+//          the geometric part of CalculateSegmentProbabilities :1441-1455,:1494-1496
+//          and the sequential minor-axis chain (v_f += v_step) sampled at segment starts.
+// Phase B  one thread per (line, segment): MultiplyPixelColorProbability :1575 over
+//          `scale` pixels in walk order + per-segment renormalisation :1556-1571.
+// Phase C  one thread per (line, d): CalculateDistribution :1600 products; then one
+//          thread per line: normalisation + CalculateDistributionMoments :1639.
+// ---------------------------------------------------------------------------
+__device__ void region_correspondences(const RegionModDev& m, const CameraDev& cam, const CameraDev* dcam,
+                                       const Affine& b2c, const Affine& b2dc, int iteration, int corr_iteration,
+                                       const Lds& s) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const RegionIter it = region_iter(m, corr_iteration);
+  const int nl = s.nl;
+  const int view = closest_view(m.orientations, m.n_views, b2c, s.misc);
+  const int n_lines =
+      number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length, m.extents[view],
+                      m.max_extent, m.n_points);
+  const bool occlusion_pass =
+      m.measure_occlusions && (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
+  const int n_seg = m.n_seg;
+  const uint8_t* __restrict__ image = cam.image;
+  const uint32_t pitch = cam.pitch;
+
+  // ---- phase A ----
+  int my_valid_occ = 0;
+  for (int line = tid; line < nl; line += nt) {
+    int flags = 0;
+    if (line < n_lines) {
+      const float* p = m.points + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
+      float cx = p[0], cy = p[1], cz = p[2];
+      float nx = p[3], ny = p[4], nz = p[5];
+      float fg = p[6], bg = p[7];
+      float X, Y, Z;
+      apply_pose(b2c, cx, cy, cz, X, Y, Z);
+      float nu = (b2c.l[0] * nx + b2c.l[3] * ny) + b2c.l[6] * nz;
+      float nv = (b2c.l[1] * nx + b2c.l[4] * ny) + b2c.l[7] * nz;
+      float nn = sqrtf(nu * nu + nv * nv);
+      if (nn > 0.0f) { nu = nu / nn; nv = nv / nn; }
+      float center_u = X * cam.fu / Z + cam.ppu;
+      float center_v = Y * cam.fv / Z + cam.ppv;
+      float cont = ((fg < bg) ? fg : bg) * cam.fu / (Z * it.fscale);
+      bool valid = !(cont < m.min_continuous_distance) && !(Z <= 0.0f);
+      if (valid) {
+        int icu = f2i(center_u + 0.5f), icv = f2i(center_v + 0.5f);
+        valid = !(icu < 0 || icu > cam.width - 1 || icv < 0 || icv > cam.height - 1);
+      }
+      // geometric part of CalculateSegmentProbabilities
+      bool horiz = fabsf(nv) < fabsf(nu);
+      float step, cmaj, cmin, ndom;
+      int maj_lim, min_lim1, min_lim2;
+      if (horiz) {
+        step = nv / nu; cmaj = center_u; cmin = center_v; ndom = nu;
+        maj_lim = cam.width - 1; min_lim1 = cam.height - 1; min_lim2 = cam.height - 2;
+      } else {
+        step = nu / nv; cmaj = center_v; cmin = center_u; ndom = nv;
+        maj_lim = cam.height - 1; min_lim1 = cam.width - 1; min_lim2 = cam.width - 2;
+      }
+      int start = f2i(cmaj - it.line_length_half_minus_1);
+      int end = start + it.line_length_minus_1;
+      float x0 = cmin + step * ((float)start - cmaj) + 0.5f;
+      float xend = x0 + step * (float)it.line_length_minus_1;
+      if (valid)
+        valid = !(start < 0 || end > maj_lim || f2i(x0) < 0 || f2i(x0) > min_lim1 || f2i(xend) < 1 ||
+                  f2i(xend) > min_lim2);
+      bool valid_occ = valid;
+      if (valid && occlusion_pass) {
+        float dx, dy, dz;
+        apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
+        float du = dx * dcam->fu / dz + dcam->ppu;
+        float dv = dy * dcam->fv / dz + dcam->ppv;
+        float meter_to_pixel = dcam->fu / dz;
+        float diameter = 2.0f * m.measured_occlusion_radius * meter_to_pixel;
+        valid_occ = occlusion_window_clear(*dcam, du, dv, diameter, dz, p[8 + m.measured_depth_offset_id],
+                                           m.measured_occlusion_threshold);
+      }
+      if (valid) {
+        flags = (valid_occ ? 1 : 0) | 2 | (horiz ? 4 : 0) | ((ndom > 0.0f) ? 0 : 8);
+        my_valid_occ += valid_occ ? 1 : 0;
+        s.state[LS_CX * nl + line] = cx;
+        s.state[LS_CY * nl + line] = cy;
+        s.state[LS_CZ * nl + line] = cz;
+        s.state[LS_CENTER_U * nl + line] = center_u;
+        s.state[LS_CENTER_V * nl + line] = center_v;
+        s.state[LS_NORMAL_U * nl + line] = nu;
+        s.state[LS_NORMAL_V * nl + line] = nv;
+        s.state[LS_CONT * nl + line] = cont;
+        s.state[LS_NCTS * nl + line] = fabsf(ndom) / it.fscale;
+        s.state[LS_DELTA_R * nl + line] =
+            (roundf(cmaj - it.line_length_minus_1_half) + it.line_length_minus_1_half - cmaj) / ndom;
+        s.state[LS_WALK_START * nl + line] = i2f_bits(start);
+        s.state[LS_WALK_STEP * nl + line] = step;
+        // sequential chain: x_{k+1} = x_k + step, recorded at every segment start
+        float x = x0;
+        float* chain = s.chain + line * s.ns;
+        int seg = 0, in_seg = 0;
+        for (int k = 0; k < it.line_length; ++k) {
+          if (in_seg == 0) chain[seg] = x;
+          x += step;
+          if (++in_seg == it.scale) { in_seg = 0; ++seg; }
+        }
+      }
+    }
+    s.state[LS_VALID * nl + line] = i2f_bits(flags);
+  }
+  // two-pass fallback :435-463: use the occlusion-handled set only if it has enough lines
+  bool use_occ = false;
+  if (occlusion_pass) {
+    int cnt = my_valid_occ;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    int* imisc = reinterpret_cast<int*>(s.misc);
+    if (tid % kWave == 0) imisc[64 + tid / kWave] = cnt;
+    __syncthreads();
+    int total = 0;
+    for (int w = 0; w < nt / kWave; ++w) total += imisc[64 + w];
+    use_occ = total >= m.min_n_unoccluded_lines;
+  }
+  __syncthreads();
+  const int valid_mask = use_occ ? 1 : 2;
+
+  // ---- phase B ----
+  const float2* __restrict__ hist = s.hist ? s.hist : m.histogram_norm;
+  const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = m.n_bins * m.n_bins;
+  const int n_items = n_lines * n_seg;
+  for (int item = tid; item < n_items; item += nt) {
+    int line = item / n_seg;
+    int sw = item - line * n_seg;  // segment index in walk order
+    int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+    if (!(flags & valid_mask)) continue;
+    int start = f2i_bits(s.state[LS_WALK_START * nl + line]);
+    float step = s.state[LS_WALK_STEP * nl + line];
+    float x = s.chain[line * s.ns + sw];
+    int major = start + sw * it.scale;
+    const bool horiz = flags & 4;
+    float pf = 1.0f, pb = 1.0f;
+    for (int j = 0; j < it.scale; ++j, ++major, x += step) {
+      int minor = f2i(x);
+      const uint8_t* px = horiz ? image + (size_t)minor * pitch + major * 3 : image + (size_t)major * pitch + minor * 3;
+      int idx = (px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift);
+      float2 h = hist[idx];
+      pf *= h.x;
+      pb *= h.y;
+    }
+    if (it.scale > 1) {
+      if (pf || pb) {
+        float sum = pf;
+        sum += pb;
+        pf /= sum;
+        pb /= sum;
+      } else {
+        pf = 0.5f;
+        pb = 0.5f;
+      }
+    }
+    int seg = (flags & 8) ? (n_seg - 1 - sw) : sw;
+    s.seg_f[line * s.ns + seg] = pf;
+    s.seg_b[line * s.ns + seg] = pb;
+  }
+  __syncthreads();
+
+  // ---- phase C1: raw distribution products (aliases the chain buffer) ----
+  const int dl = m.distribution_length, fl = m.function_length;
+  float* raw = s.chain;  // [nl][M3T_MAX_DISTRIBUTION_LENGTH] needs ns >= dl (n_seg = fl + dl - 1 >= dl)
+  for (int item = tid; item < n_lines * dl; item += nt) {
+    int line = item / dl;
+    int d = item - line * dl;
+    int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+    if (!(flags & valid_mask)) continue;
+    const float* sf = s.seg_f + line * s.ns + d;
+    const float* sb = s.seg_b + line * s.ns + d;
+    float value = 1.0f;
+    for (int k = 0; k < fl; ++k) value *= sf[k] * m.function_lookup_f[k] + sb[k] * m.function_lookup_b[k];
+    raw[line * s.ns + d] = value;
+  }
+  __syncthreads();
+  // ---- phase C2: normalisation + moments, one thread per line ----
+  for (int line = tid; line < nl; line += nt) {
+    int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+    bool valid = (flags & valid_mask) != 0;
+    if (valid) {
+      const float* r = raw + line * s.ns;
+      float area = 0.0f;
+      for (int d = 0; d < dl; ++d) area += r[d];
+      float mean_from_begin = 0.0f;
+      float dist[M3T_MAX_DISTRIBUTION_LENGTH];
+#pragma unroll
+      for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d) {
+        if (d < dl) {
+          dist[d] = r[d] / area;
+          mean_from_begin += (float)d * dist[d];
+        }
+      }
+      float var = 0.0f;
+#pragma unroll
+      for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d) {
+        if (d < dl) {
+          float dd = (float)d - mean_from_begin;
+          var += (dd * dd) * dist[d];
+          s.state[(LS_DIST0 + d) * nl + line] = dist[d];
+        }
+      }
+      s.state[LS_MEAN * nl + line] = mean_from_begin - m.distribution_length_minus_1_half;
+      s.state[LS_VAR * nl + line] = fmaxf(var, m.min_expected_variance);
+    }
+    // final flag: bit0 = line is in data_lines_
+    s.state[LS_VALID * nl + line] = i2f_bits((flags & ~1) | (valid ? 1 : 0));
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// Block reduction of N per-thread partial sums: wave shuffle tree, then the
+// per-wave partials are added in wave order.  out[] valid for threads < N.
+// scratch: n_waves * N floats.  Two __syncthreads().
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ void block_reduce(float (&v)[N], float* scratch, float* out /*LDS, N floats*/) {
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave, n_waves = blockDim.x / kWave;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float x = v[i];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if (lane == 0) scratch[wave * N + i] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    float x = 0.0f;
+    for (int w = 0; w < n_waves; ++w) x += scratch[w * N + threadIdx.x];
+    out[threadIdx.x] = x;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// RegionModality::CalculateGradientAndHessian (:485-558), whole block.
+// Result: gh[0..5] gradient, gh[6..41] column-major symmetric hessian (LDS or global).
+// ---------------------------------------------------------------------------
+__device__ void region_gradient_hessian(const RegionModDev& m, const CameraDev& cam, const Affine& b2c,
+                                        int corr_iteration, int opt_iteration, const Lds& s, float* gh_out) {
+  const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
+  const RegionIter it = region_iter(m, corr_iteration);
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+  for (int line = tid; line < nl; line += nt) {
+    int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+    if (!(flags & 1)) continue;
+    float cx = s.state[LS_CX * nl + line], cy = s.state[LS_CY * nl + line], cz = s.state[LS_CZ * nl + line];
+    float x, y, z;
+    apply_pose(b2c, cx, cy, cz, x, y, z);
+    float normal_u = s.state[LS_NORMAL_U * nl + line], normal_v = s.state[LS_NORMAL_V * nl + line];
+    float center_u = s.state[LS_CENTER_U * nl + line], center_v = s.state[LS_CENTER_V * nl + line];
+    float ncts = s.state[LS_NCTS * nl + line];
+    float measured_variance = s.state[LS_VAR * nl + line];
+    float fu_z = cam.fu / z;
+    float fv_z = cam.fv / z;
+    float xfu_z = x * fu_z;
+    float yfv_z = y * fv_z;
+    float delta_cs = (normal_u * (xfu_z + cam.ppu - center_u) + normal_v * (yfv_z + cam.ppv - center_v) -
+                      s.state[LS_DELTA_R * nl + line]) *
+                     ncts;
+    float dll;
+    if (opt_iteration < m.n_global_iterations) {
+      dll = (s.state[LS_MEAN * nl + line] - delta_cs) / measured_variance;
+    } else {
+      int upper = f2i(delta_cs + m.distribution_length_plus_1_half);
+      int lower = upper - 1;
+      if (upper <= 0 || upper >= m.distribution_length) continue;
+      dll = (logf(s.state[(LS_DIST0 + upper) * nl + line]) - logf(s.state[(LS_DIST0 + lower) * nl + line])) *
+            m.learning_rate / measured_variance;
+    }
+    float dc0 = ncts * normal_u * fu_z;
+    float dc1 = ncts * normal_v * fv_z;
+    float dc2 = ncts * (-normal_u * xfu_z - normal_v * yfv_z) / z;
+    float J[6];
+    // RowVector3f * Matrix3f (body2camera_rotation_)
+    float t0 = (dc0 * b2c.l[0] + dc1 * b2c.l[1]) + dc2 * b2c.l[2];
+    float t1 = (dc0 * b2c.l[3] + dc1 * b2c.l[4]) + dc2 * b2c.l[5];
+    float t2 = (dc0 * b2c.l[6] + dc1 * b2c.l[7]) + dc2 * b2c.l[8];
+    J[0] = cy * t2 - cz * t1;
+    J[1] = cz * t0 - cx * t2;
+    J[2] = cx * t1 - cy * t0;
+    J[3] = t0;
+    J[4] = t1;
+    J[5] = t2;
+    float weight = m.min_expected_variance / (ncts * ncts * it.variance);
+    float wg = weight * dll;
+    float wh = weight / measured_variance;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[r] += wg * J[r];
+    int k = 6;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int r = c; r < 6; ++r) acc[k++] -= (wh * J[r]) * J[c];
+  }
+  float* red = s.misc + kMiscRed;
+  block_reduce<27>(acc, s.misc + kMiscPartials, red);
+  if (tid < 6) gh_out[tid] = red[tid];
+  if (tid < 36) {
+    int c = tid / 6, r = tid % 6;
+    int lo = r >= c ? r : c, hi = r >= c ? c : r;  // lower triangle (row lo, col hi)
+    int k = 6 + hi * 6 - hi * (hi - 1) / 2 + (lo - hi);
+    gh_out[6 + c * 6 + r] = red[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Optimizer::CalculateOptimization (optimizer.cpp:144-167) for dof = 6, J = I, plus
+// Link::UpdatePoses (link.cpp:205-241) with body2joint = I: one thread.
+// A = -H + diag(lambda) (lower), Eigen-style LDLT with diagonal pivoting, NaN guard,
+// dT = [exp(skew(theta_r)) | theta_t], pose <- pose * dT.
+// ---------------------------------------------------------------------------
+__device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-major 6x6*/, float lambda_rot,
+                                   float lambda_trans, float* pose /*16 col-major, in/out*/) {
+  float a[36], b[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) a[i] = 0.0f;
+  for (int c = 0; c < 6; ++c)
+    for (int r = c; r < 6; ++r) a[c * 6 + r] = 0.0f - h_sum[c * 6 + r];
+  for (int i = 0; i < 6; ++i) {
+    b[i] = 0.0f + g_sum[i];
+    a[i * 6 + i] += i < 3 ? lambda_rot : lambda_trans;
+  }
+  int trans[6];
+  float temp[6];
+  bool degenerate = false;
+  for (int k = 0; k < 6 && !degenerate; ++k) {
+    int piv = k;
+    float best = fabsf(a[k * 6 + k]);
+    for (int i = k + 1; i < 6; ++i) {
+      float v = fabsf(a[i * 6 + i]);
+      if (v > best) { best = v; piv = i; }
+    }
+    trans[k] = piv;
+    if (piv != k) {
+      int sr = 6 - piv - 1;
+      for (int c = 0; c < k; ++c) { float t = a[c * 6 + k]; a[c * 6 + k] = a[c * 6 + piv]; a[c * 6 + piv] = t; }
+      for (int i = 0; i < sr; ++i) {
+        float t = a[k * 6 + piv + 1 + i];
+        a[k * 6 + piv + 1 + i] = a[piv * 6 + piv + 1 + i];
+        a[piv * 6 + piv + 1 + i] = t;
+      }
+      { float t = a[k * 6 + k]; a[k * 6 + k] = a[piv * 6 + piv]; a[piv * 6 + piv] = t; }
+      for (int i = k + 1; i < piv; ++i) { float t = a[k * 6 + i]; a[k * 6 + i] = a[i * 6 + piv]; a[i * 6 + piv] = t; }
+    }
+    int rs = 6 - k - 1;
+    if (k > 0) {
+      for (int c = 0; c < k; ++c) temp[c] = a[c * 6 + c] * a[c * 6 + k];
+      float acc = 0.0f;
+      for (int c = 0; c < k; ++c) acc += a[c * 6 + k] * temp[c];
+      a[k * 6 + k] -= acc;
+      for (int i = 0; i < rs; ++i) {
+        float sacc = 0.0f;
+        for (int c = 0; c < k; ++c) sacc += a[c * 6 + k + 1 + i] * temp[c];
+        a[k * 6 + k + 1 + i] -= sacc;
+      }
+    }
+    float akk = a[k * 6 + k];
+    bool pivot_valid = fabsf(akk) > 0.0f;
+    if (k == 0 && !pivot_valid) {
+      for (int j = 0; j < 6; ++j) trans[j] = j;
+      degenerate = true;
+    } else if (rs > 0 && pivot_valid) {
+      for (int i = 0; i < rs; ++i) a[k * 6 + k + 1 + i] /= akk;
+    }
+  }
+  float x[6];
+  for (int i = 0; i < 6; ++i) x[i] = b[i];
+  for (int k = 0; k < 6; ++k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
+  for (int i = 0; i < 6; ++i) {
+    float sacc = x[i];
+    for (int c = 0; c < i; ++c) sacc -= a[c * 6 + i] * x[c];
+    x[i] = sacc;
+  }
+  for (int i = 0; i < 6; ++i) {
+    if (fabsf(a[i * 6 + i]) > 1.17549435e-38f) x[i] /= a[i * 6 + i];
+    else x[i] = 0.0f;
+  }
+  for (int i = 5; i >= 0; --i) {
+    float sacc = x[i];
+    for (int r = i + 1; r < 6; ++r) sacc -= a[i * 6 + r] * x[r];
+    x[i] = sacc;
+  }
+  for (int k = 5; k >= 0; --k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
+  // NaN guard (optimizer.cpp:165): skip the update, still success
+  bool has_nan = false;
+  for (int i = 0; i < 6; ++i) has_nan |= (x[i] != x[i]);
+  if (has_nan) return;
+  // exp(skew(theta_r)) by Rodrigues (Eigen uses a Pade approximant; equal to ~1e-7)
+  float wx = x[0], wy = x[1], wz = x[2];
+  float th2 = (wx * wx + wy * wy) + wz * wz;
+  float A, B;  // R = I + A K + B K^2
+  if (th2 < 1e-8f) {
+    A = 1.0f - th2 / 6.0f;
+    B = 0.5f - th2 / 24.0f;
+  } else {
+    float th = sqrtf(th2);
+    A = sinf(th) / th;
+    B = (1.0f - cosf(th)) / th2;
+  }
+  float R[9];  // column-major
+  R[0] = 1.0f - B * (wy * wy + wz * wz);
+  R[4] = 1.0f - B * (wx * wx + wz * wz);
+  R[8] = 1.0f - B * (wx * wx + wy * wy);
+  R[3] = B * wx * wy - A * wz;  // (0,1)
+  R[1] = B * wx * wy + A * wz;  // (1,0)
+  R[6] = B * wx * wz + A * wy;  // (0,2)
+  R[2] = B * wx * wz - A * wy;  // (2,0)
+  R[7] = B * wy * wz - A * wx;  // (1,2)
+  R[5] = B * wy * wz + A * wx;  // (2,1)
+  Affine T = load_pose(pose), D;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) D.l[i] = R[i];
+  D.t[0] = x[3]; D.t[1] = x[4]; D.t[2] = x[5];
+  Affine N = mul_pose(T, D);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pose[c * 4 + r] = N.l[c * 3 + r];
+    pose[c * 4 + 3] = 0.0f;
+  }
+  pose[12] = N.t[0]; pose[13] = N.t[1]; pose[14] = N.t[2]; pose[15] = 1.0f;
+}
+
+// ---------------------------------------------------------------------------
+// DepthModality::CalculateCorrespondences (depth_modality.cpp:252-315), whole block.
+// One thread per point: CalculateBasicPointData :656, IsPointValid :697,
+// IsPointUnoccludedMeasured :736, FindCorrespondence :826 (strided window scan,
+// first strictly smaller distance wins in (v outer, u inner) order).
+// Point state lives in `ps` (LDS, [PS_FIELDS][np]).
+// ---------------------------------------------------------------------------
+__device__ void depth_correspondences(const DepthModDev& m, const CameraDev& cam, const Affine& b2c, int iteration,
+                                      int corr_iteration, float* ps, int np, float* misc) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int view = closest_view(m.orientations, m.n_views, b2c, misc);
+  int n_points = number_of_lines(m.n_points_max, m.use_adaptive_coverage, m.reference_surface_area, m.extents[view],
+                                 m.max_extent, m.n_points);
+  const float considered_distance0 = last_valid(m.considered_distances, m.n_considered_distances, corr_iteration);
+  const int max_n_strides = f2i(considered_distance0 / m.stride_length + 0.5f);
+  const bool occlusion_pass = m.measure_occlusions && (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
+  int my_valid_occ = 0;
+  for (int i = tid; i < np; i += nt) {
+    int flags = 0;
+    if (i < n_points) {
+      const float* p = m.points + ((size_t)view * m.n_points + i) * M3T_DEPTH_POINT_FLOATS;
+      float cx = p[0], cy = p[1], cz = p[2];
+      float X, Y, Z;
+      apply_pose(b2c, cx, cy, cz, X, Y, Z);
+      float center_u = X * cam.fu / Z + cam.ppu;
+      float center_v = Y * cam.fv / Z + cam.ppv;
+      float depth = Z;
+      bool valid = !(depth <= 0.0f);
+      if (valid) {
+        int icu = f2i(center_u + 0.5f), icv = f2i(center_v + 0.5f);
+        valid = !(icu < 0 || icu > cam.width - 1 || icv < 0 || icv > cam.height - 1);
+      }
+      // FindCorrespondence
+      float corr[3] = {0.0f, 0.0f, 0.0f};
+      if (valid) {
+        float cd = considered_distance0;
+        if (m.use_depth_scaling) cd *= depth;
+        float meter_to_pixel = cam.fu / depth;
+        float diameter = 2.0f * cd * meter_to_pixel;
+        int stride = f2i(diameter / max_n_strides + 1.0f);
+        int n_strides = f2i(diameter / stride + 0.5f);
+        int rounded_diameter = n_strides * stride;
+        float rounded_radius = 0.5f * (float)rounded_diameter;
+        int u_min = f2i(center_u - rounded_radius + 0.5f);
+        int v_min = f2i(center_v - rounded_radius + 0.5f);
+        int u_max = u_min + rounded_diameter;
+        int v_max = v_min + rounded_diameter;
+        u_min = max(u_min, 0);
+        v_min = max(v_min, 0);
+        u_max = min(u_max, cam.width - 1);
+        v_max = min(v_max, cam.height - 1);
+        float min_depth_value = fminf(0.0f, (depth - cd) / cam.depth_scale);
+        float max_depth_value = (depth + cd) / cam.depth_scale;
+        float min_considered = cd * cd;
+        float best = min_considered;
+        for (int v = v_min; v <= v_max; v += stride) {
+          const unsigned short* row = reinterpret_cast<const unsigned short*>(cam.image + (size_t)v * cam.pitch);
+          for (int u = u_min; u <= u_max; u += stride) {
+            float d = (float)row[u];
+            if (d > min_depth_value && d < max_depth_value) {
+              d *= cam.depth_scale;
+              float t0 = ((float)u - cam.ppu) * d / cam.fu;
+              float t1 = ((float)v - cam.ppv) * d / cam.fv;
+              float e0 = t0 - X, e1 = t1 - Y, e2 = d - Z;
+              float dist2 = (e0 * e0 + e1 * e1) + e2 * e2;
+              if (dist2 < best) {
+                corr[0] = t0; corr[1] = t1; corr[2] = d;
+                best = dist2;
+              }
+            }
+          }
+        }
+        valid = best != min_considered;
+      }
+      bool valid_occ = valid;
+      if (valid && occlusion_pass) {
+        float radius = m.measured_depth_offset_radius;
+        if (m.use_depth_scaling) radius *= depth;
+        int id = f2i(radius / m.stride_depth_offset + 0.5f);
+        if (id >= M3T_N_DEPTH_OFFSETS) id = M3T_N_DEPTH_OFFSETS - 1;
+        float diameter = 2.0f * m.measured_occlusion_radius * cam.fu;
+        if (!m.use_depth_scaling) diameter /= depth;
+        float threshold = m.measured_occlusion_threshold;
+        if (m.use_depth_scaling) threshold *= depth;
+        valid_occ = occlusion_window_clear(cam, center_u, center_v, diameter, depth, p[6 + id], threshold);
+      }
+      if (valid) {
+        flags = (valid_occ ? 1 : 0) | 2;
+        my_valid_occ += valid_occ ? 1 : 0;
+        ps[PS_CX * np + i] = cx; ps[PS_CY * np + i] = cy; ps[PS_CZ * np + i] = cz;
+        ps[PS_NX * np + i] = p[3]; ps[PS_NY * np + i] = p[4]; ps[PS_NZ * np + i] = p[5];
+        ps[PS_CENTER_U * np + i] = center_u;
+        ps[PS_CENTER_V * np + i] = center_v;
+        ps[PS_DEPTH * np + i] = depth;
+        ps[PS_CORR_X * np + i] = corr[0]; ps[PS_CORR_Y * np + i] = corr[1]; ps[PS_CORR_Z * np + i] = corr[2];
+      }
+    }
+    ps[PS_VALID * np + i] = i2f_bits(flags);
+  }
+  bool use_occ = false;
+  if (occlusion_pass) {
+    int cnt = my_valid_occ;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    int* imisc = reinterpret_cast<int*>(misc);
+    if (tid % kWave == 0) imisc[64 + tid / kWave] = cnt;
+    __syncthreads();
+    int total = 0;
+    for (int w = 0; w < nt / kWave; ++w) total += imisc[64 + w];
+    use_occ = total >= m.min_n_unoccluded_points;
+  }
+  __syncthreads();
+  const int valid_mask = use_occ ? 1 : 2;
+  for (int i = tid; i < np; i += nt) {
+    int flags = f2i_bits(ps[PS_VALID * np + i]);
+    ps[PS_VALID * np + i] = i2f_bits((flags & ~1) | ((flags & valid_mask) ? 1 : 0));
+  }
+  __syncthreads();
+}
+
+// DepthModality::CalculateGradientAndHessian (depth_modality.cpp:333-381), whole block.
+__device__ void depth_gradient_hessian(const DepthModDev& m, const Affine& b2c, int corr_iteration, const float* ps,
+                                       int np, float* misc, float* gh_out) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const Affine c2b = inverse_pose(b2c);
+  const float standard_deviation = last_valid(m.standard_deviations, m.n_standard_deviations, corr_iteration);
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+  for (int i = tid; i < np; i += nt) {
+    if (!(f2i_bits(ps[PS_VALID * np + i]) & 1)) continue;
+    float qx, qy, qz;
+    apply_pose(c2b, ps[PS_CORR_X * np + i], ps[PS_CORR_Y * np + i], ps[PS_CORR_Z * np + i], qx, qy, qz);
+    float nx = ps[PS_NX * np + i], ny = ps[PS_NY * np + i], nz = ps[PS_NZ * np + i];
+    float d0 = ps[PS_CX * np + i] - qx, d1 = ps[PS_CY * np + i] - qy, d2 = ps[PS_CZ * np + i] - qz;
+    float epsilon = (nx * d0 + ny * d1) + nz * d2;
+    float c0 = qy * nz - qz * ny, c1 = qz * nx - qx * nz, c2 = qx * ny - qy * nx;
+    float weight = 1.0f / (standard_deviation * ps[PS_CORR_Z * np + i]);
+    float se = (weight * weight) * epsilon;
+    float w[6] = {weight * c0, weight * c1, weight * c2, weight * nx, weight * ny, weight * nz};
+    acc[0] -= se * c0; acc[1] -= se * c1; acc[2] -= se * c2;
+    acc[3] -= se * nx; acc[4] -= se * ny; acc[5] -= se * nz;
+    // upper triangle, column by column (r <= c)
+    int k = 6;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int r = 0; r <= c; ++r) acc[k++] -= w[r] * w[c];
+  }
+  float* red = misc + kMiscRed;
+  block_reduce<27>(acc, misc + kMiscPartials, red);
+  if (tid < 6) gh_out[tid] = red[tid];
+  if (tid < 36) {
+    int c = tid / 6, r = tid % 6;
+    int hi = r <= c ? c : r, lo = r <= c ? r : c;  // upper triangle entry (row lo, col hi)
+    gh_out[6 + c * 6 + r] = red[6 + hi * (hi + 1) / 2 + lo];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// AddLinePixelColorsToTempHistograms (:1025-1155) + ColorHistograms::CalculateHistogram
+// (color_histograms.cpp:174-214) for one object.  counts: packed u32 per bin
+// (foreground count in the low 16 bits, background in the high 16 bits; each is
+// <= n_lines * max_considered_line_length < 65536), in LDS when it fits.
+// ---------------------------------------------------------------------------
+__device__ void region_histogram_update(const RegionModDev& m, const CameraDev& cam, const CameraDev* dcam,
+                                        const Affine& b2c, const Affine& b2dc, bool handle_occlusions, bool initialize,
+                                        uint32_t* counts, float* misc) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n_bins3 = m.n_bins * m.n_bins * m.n_bins;
+  for (int i = tid; i < n_bins3; i += nt) counts[i] = 0;
+  const int view = closest_view(m.orientations, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
+  const int n_lines = number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length,
+                                      m.extents[view], m.max_extent, m.n_points);
+  const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = n_bins * n_bins;
+  const int w1 = cam.width - 1, h1 = cam.height - 1;
+  for (int line = tid; line < n_lines; line += nt) {
+    const float* p = m.points + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
+    float cx = p[0], cy = p[1], cz = p[2];
+    float X, Y, Z;
+    apply_pose(b2c, cx, cy, cz, X, Y, Z);
+    if (Z <= 0.0f) continue;
+    float center_u = X * cam.fu / Z + cam.ppu;
+    float center_v = Y * cam.fv / Z + cam.ppv;
+    int icu = f2i(center_u + 0.5f), icv = f2i(center_v + 0.5f);
+    if ((float)icu < 0.0f || icu > w1 || icv < 0 || icv > h1) continue;
+    if (handle_occlusions && m.measure_occlusions) {
+      float dx, dy, dz;
+      apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
+      float du = dx * dcam->fu / dz + dcam->ppu;
+      float dv = dy * dcam->fv / dz + dcam->ppv;
+      float diameter = 2.0f * m.measured_occlusion_radius * (dcam->fu / dz);
+      if (!occlusion_window_clear(*dcam, du, dv, diameter, dz, p[8 + m.measured_depth_offset_id],
+                                  m.measured_occlusion_threshold))
+        continue;
+    }
+    float length_f = m.max_considered_line_length, length_b = m.max_considered_line_length;
+    float l_f = p[6] * cam.fu / Z;
+    float l_b = p[7] * cam.fu / Z;
+    length_f = fminf(length_f, l_f - 2.0f * m.unconsidered_line_length);
+    length_b = fminf(length_b, l_b - 2.0f * m.unconsidered_line_length);
+    float nu = (b2c.l[0] * p[3] + b2c.l[3] * p[4]) + b2c.l[6] * p[5];
+    float nv = (b2c.l[1] * p[3] + b2c.l[4] * p[4]) + b2c.l[7] * p[5];
+    float nn = sqrtf(nu * nu + nv * nv);
+    if (nn > 0.0f) { nu = nu / nn; nv = nv / nn; }
+    float u_step, v_step;
+    int projected_length_f, projected_length_b;
+    float abs_nu = fabsf(nu), abs_nv = fabsf(nv);
+    if (abs_nu > abs_nv) {
+      u_step = nu < 0.0f ? -1.0f : (nu > 0.0f ? 1.0f : 0.0f);
+      v_step = nv / abs_nu;
+      projected_length_f = f2i(length_f * abs_nu + 0.5f);
+      projected_length_b = f2i(length_b * abs_nu + 0.5f);
+    } else {
+      u_step = nu / abs_nv;
+      v_step = nv < 0.0f ? -1.0f : (nv > 0.0f ? 1.0f : 0.0f);
+      projected_length_f = f2i(length_f * abs_nv + 0.5f);
+      projected_length_b = f2i(length_b * abs_nv + 0.5f);
+    }
+    float u = center_u - nu * m.unconsidered_line_length + 0.5f;
+    float v = center_v - nv * m.unconsidered_line_length + 0.5f;
+    for (int k = 0; k < projected_length_f; ++k) {
+      int iu = f2i(u), iv = f2i(v);
+      if (iu < 0 || iu > w1 || iv < 0 || iv > h1) break;
+      const uint8_t* px = cam.image + (size_t)iv * cam.pitch + iu * 3;
+      atomicAdd(&counts[(px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift)], 1u);
+      u -= u_step;
+      v -= v_step;
+    }
+    u = center_u + nu * m.unconsidered_line_length + 0.5f;
+    v = center_v + nv * m.unconsidered_line_length + 0.5f;
+    for (int k = 0; k < projected_length_b; ++k) {
+      int iu = f2i(u), iv = f2i(v);
+      if (iu < 0 || iu > w1 || iv < 0 || iv > h1) break;
+      const uint8_t* px = cam.image + (size_t)iv * cam.pitch + iu * 3;
+      atomicAdd(&counts[(px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift)],
+                65536u);
+      u += u_step;
+      v += v_step;
+    }
+  }
+  __syncthreads();
+  // sums (exact: integer counts)
+  unsigned sf = 0, sb = 0;
+  for (int i = tid; i < n_bins3; i += nt) {
+    uint32_t c = counts[i];
+    sf += c & 0xffffu;
+    sb += c >> 16;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    sf += __shfl_down(sf, off);
+    sb += __shfl_down(sb, off);
+  }
+  unsigned* umisc = reinterpret_cast<unsigned*>(misc);
+  if (tid % kWave == 0) { umisc[2 * (tid / kWave)] = sf; umisc[2 * (tid / kWave) + 1] = sb; }
+  __syncthreads();
+  sf = 0; sb = 0;
+  for (int w = 0; w < nt / kWave; ++w) { sf += umisc[2 * w]; sb += umisc[2 * w + 1]; }
+  const float sum_f = (float)sf, sum_b = (float)sb;
+  const float lr_f = initialize ? 1.0f : m.learning_rate_f, lr_b = initialize ? 1.0f : m.learning_rate_b;
+  const float comp_f = 1.0f - lr_f, comp_b = 1.0f - lr_b;
+  const float scale_f = lr_f / sum_f, scale_b = lr_b / sum_b;
+  const float uniform_value = 1.0f / (float)n_bins3;
+  for (int i = tid; i < n_bins3; i += nt) {
+    uint32_t c = counts[i];
+    float hf = m.histogram_f[i], hb = m.histogram_b[i];
+    if (sf == 0) {
+      if (lr_f == 1.0f) hf = uniform_value;
+    } else if (comp_f == 0.0f) {
+      hf = (float)(c & 0xffffu) * scale_f;
+    } else {
+      hf *= comp_f;
+      hf += (float)(c & 0xffffu) * scale_f;
+    }
+    if (sb == 0) {
+      if (lr_b == 1.0f) hb = uniform_value;
+    } else if (comp_b == 0.0f) {
+      hb = (float)(c >> 16) * scale_b;
+    } else {
+      hb *= comp_b;
+      hb += (float)(c >> 16) * scale_b;
+    }
+    m.histogram_f[i] = hf;
+    m.histogram_b[i] = hb;
+    // MultiplyPixelColorProbability :1585-1593 hoisted from per pixel to per bin
+    float2 n;
+    if (hf || hb) {
+      float sum = hf;
+      sum += hb;
+      n.x = hf / sum;
+      n.y = hb / sum;
+    } else {
+      n.x = 0.5f;
+      n.y = 0.5f;
+    }
+    m.histogram_norm[i] = n;
+  }
+}
+
+__device__ __forceinline__ void stage_histogram(const RegionModDev& m, float* lds_hist) {
+  const int n2 = m.n_bins * m.n_bins * m.n_bins * 2;
+  const float* src = reinterpret_cast<const float*>(m.histogram_norm);
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) lds_hist[i] = src[i];
+}
+
+__device__ __forceinline__ void copy_state(float* dst, const float* src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace
+
+// ===========================================================================
+// kernels
+// ===========================================================================
+extern "C" {
+
+// One block per region modality.  initialize != 0: StartModality (:375-388), else CalculateResults (:572-583).
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+region_histogram_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses, int iteration,
+                        int initialize, int counts_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const RegionModDev& m = mods[blockIdx.x];
+  const CameraDev& cam = cams[m.camera];
+  const CameraDev* dcam = m.measure_occlusions ? &cams[m.depth_camera] : nullptr;
+  const Affine b2w = load_pose(body_poses + 16 * m.body);
+  const Affine b2c = mul_pose(load_pose(cam.world2camera), b2w);
+  Affine b2dc = b2c;
+  if (dcam) b2dc = mul_pose(load_pose(dcam->world2camera), b2w);
+  // first_iteration is maintained by the host table (StartModality :378)
+  bool handle_occlusions = initialize ? (m.n_unoccluded_iterations == 0)
+                                      : ((iteration - m.first_iteration) >= m.n_unoccluded_iterations);
+  float* misc = lds;
+  uint32_t* counts = counts_in_lds ? reinterpret_cast<uint32_t*>(lds + M3T_MISC_FLOATS) : m.count_scratch;
+  region_histogram_update(m, cam, dcam, b2c, b2dc, handle_occlusions, initialize != 0, counts, misc);
+}
+
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+region_correspondence_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses,
+                             TrackLdsLayout layout, int iteration, int corr_iteration) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const RegionModDev& m = mods[blockIdx.x];
+  const CameraDev& cam = cams[m.camera];
+  const CameraDev* dcam = m.measure_occlusions ? &cams[m.depth_camera] : nullptr;
+  Lds s = carve(lds, layout);
+  if (layout.off_hist >= 0) {
+    stage_histogram(m, lds + layout.off_hist);
+    __syncthreads();
+  }
+  const Affine b2w = load_pose(body_poses + 16 * m.body);
+  const Affine b2c = mul_pose(load_pose(cam.world2camera), b2w);
+  Affine b2dc = b2c;
+  if (dcam) b2dc = mul_pose(load_pose(dcam->world2camera), b2w);
+  region_correspondences(m, cam, dcam, b2c, b2dc, iteration, corr_iteration, s);
+  // LDS -> global line state (compact stride n_lines_max)
+  for (int i = threadIdx.x; i < LS_FIELDS * m.n_lines_max; i += blockDim.x) {
+    int f = i / m.n_lines_max, l = i - f * m.n_lines_max;
+    m.line_state[i] = s.state[f * s.nl + l];
+  }
+}
+
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+region_gradient_hessian_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses,
+                               TrackLdsLayout layout, int corr_iteration, int opt_iteration) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const RegionModDev& m = mods[blockIdx.x];
+  const CameraDev& cam = cams[m.camera];
+  Lds s = carve(lds, layout);
+  for (int i = threadIdx.x; i < LS_FIELDS * m.n_lines_max; i += blockDim.x) {
+    int f = i / m.n_lines_max, l = i - f * m.n_lines_max;
+    s.state[f * s.nl + l] = m.line_state[i];
+  }
+  for (int l = m.n_lines_max + threadIdx.x; l < s.nl; l += blockDim.x) s.state[LS_VALID * s.nl + l] = i2f_bits(0);
+  __syncthreads();
+  const Affine b2c = mul_pose(load_pose(cam.world2camera), load_pose(body_poses + 16 * m.body));
+  region_gradient_hessian(m, cam, b2c, corr_iteration, opt_iteration, s, m.gradient_hessian);
+}
+
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+depth_correspondence_kernel(const DepthModDev* mods, const CameraDev* cams, const float* body_poses, int np,
+                            int iteration, int corr_iteration) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DepthModDev& m = mods[blockIdx.x];
+  const CameraDev& cam = cams[m.camera];
+  float* misc = lds;
+  float* ps = lds + M3T_MISC_FLOATS;
+  const Affine b2c = mul_pose(load_pose(cam.world2camera), load_pose(body_poses + 16 * m.body));
+  depth_correspondences(m, cam, b2c, iteration, corr_iteration, ps, np, misc);
+  for (int i = threadIdx.x; i < PS_FIELDS * m.n_points_max; i += blockDim.x) {
+    int f = i / m.n_points_max, l = i - f * m.n_points_max;
+    m.point_state[i] = ps[f * np + l];
+  }
+}
+
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+depth_gradient_hessian_kernel(const DepthModDev* mods, const CameraDev* cams, const float* body_poses, int np,
+                              int corr_iteration) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DepthModDev& m = mods[blockIdx.x];
+  const CameraDev& cam = cams[m.camera];
+  float* misc = lds;
+  float* ps = lds + M3T_MISC_FLOATS;
+  for (int i = threadIdx.x; i < PS_FIELDS * m.n_points_max; i += blockDim.x) {
+    int f = i / m.n_points_max, l = i - f * m.n_points_max;
+    ps[f * np + l] = m.point_state[i];
+  }
+  for (int l = m.n_points_max + threadIdx.x; l < np; l += blockDim.x) ps[PS_VALID * np + l] = i2f_bits(0);
+  __syncthreads();
+  const Affine b2c = mul_pose(load_pose(cam.world2camera), load_pose(body_poses + 16 * m.body));
+  depth_gradient_hessian(m, b2c, corr_iteration, ps, np, misc, m.gradient_hessian);
+}
+
+// One thread per rigid optimizer (Link::CalculateGradientAndHessian link.cpp:184-193 + solve + update).
+__global__ void rigid_optimize_kernel(const RigidOptDev* opts, int n_opts, const RegionModDev* rmods,
+                                      const DepthModDev* dmods, float* body_poses) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_opts) return;
+  const RigidOptDev& o = opts[i];
+  float g[6], h[36];
+  for (int k = 0; k < 6; ++k) g[k] = 0.0f;
+  for (int k = 0; k < 36; ++k) h[k] = 0.0f;
+  if (o.region_modality >= 0) {
+    const float* gh = rmods[o.region_modality].gradient_hessian;
+    for (int k = 0; k < 6; ++k) g[k] += gh[k];
+    for (int k = 0; k < 36; ++k) h[k] += gh[6 + k];
+  }
+  if (o.depth_modality >= 0) {
+    const float* gh = dmods[o.depth_modality].gradient_hessian;
+    for (int k = 0; k < 6; ++k) g[k] += gh[k];
+    for (int k = 0; k < 36; ++k) h[k] += gh[6 + k];
+  }
+  float pose[16];
+  for (int k = 0; k < 16; ++k) pose[k] = body_poses[16 * o.body + k];
+  rigid_solve_update(g, h, o.tikhonov_rotation, o.tikhonov_translation, pose);
+  for (int k = 0; k < 16; ++k) body_poses[16 * o.body + k] = pose[k];
+}
+
+// ---------------------------------------------------------------------------
+// Fused Tracker::ExecuteTrackingStep (tracker.cpp:344-364) minus CalculateResults:
+// one block per rigid optimizer; n_corr x (correspondences + n_update x (g/H + solve)).
+// Everything between the image/model gathers and the final pose stays in LDS.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const RigidOptDev& o = opts[blockIdx.x];
+  const RegionModDev* rm = o.region_modality >= 0 ? &rmods[o.region_modality] : nullptr;
+  const DepthModDev* dm = o.depth_modality >= 0 ? &dmods[o.depth_modality] : nullptr;
+  Lds s = carve(lds, layout);
+  float* ps = lds + off_points;
+  float* pose = s.misc + kMiscPose;           // 16 floats
+  float* gh_region = s.misc + kMiscGhRegion;  // 42
+  float* gh_depth = s.misc + kMiscGhDepth;    // 42
+  if (threadIdx.x < 16) pose[threadIdx.x] = body_poses[16 * o.body + threadIdx.x];
+  if (rm && layout.off_hist >= 0) stage_histogram(*rm, lds + layout.off_hist);
+  __syncthreads();
+  const CameraDev* cam = rm ? &cams[rm->camera] : nullptr;
+  const CameraDev* rdcam = (rm && rm->measure_occlusions) ? &cams[rm->depth_camera] : nullptr;
+  const CameraDev* dcam = dm ? &cams[dm->camera] : nullptr;
+  for (int c = 0; c < n_corr_iterations; ++c) {
+    {
+      const Affine b2w = load_pose(pose);
+      if (rm) {
+        const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+        Affine b2dc = b2c;
+        if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
+        region_correspondences(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s);
+      }
+      if (dm) {
+        const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
+        depth_correspondences(*dm, *dcam, b2c, iteration, c, ps, np, s.misc);
+      }
+    }
+    for (int u = 0; u < n_update_iterations; ++u) {
+      const Affine b2w = load_pose(pose);
+      if (rm) {
+        const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+        region_gradient_hessian(*rm, *cam, b2c, c, u, s, gh_region);
+      }
+      if (dm) {
+        const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
+        depth_gradient_hessian(*dm, b2c, c, ps, np, s.misc, gh_depth);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float g[6], h[36];
+        for (int k = 0; k < 6; ++k) g[k] = 0.0f;
+        for (int k = 0; k < 36; ++k) h[k] = 0.0f;
+        if (rm) {
+          for (int k = 0; k < 6; ++k) g[k] += gh_region[k];
+          for (int k = 0; k < 36; ++k) h[k] += gh_region[6 + k];
+        }
+        if (dm) {
+          for (int k = 0; k < 6; ++k) g[k] += gh_depth[k];
+          for (int k = 0; k < 36; ++k) h[k] += gh_depth[6 + k];
+        }
+        float p[16];
+        for (int k = 0; k < 16; ++k) p[k] = pose[k];
+        rigid_solve_update(g, h, o.tikhonov_rotation, o.tikhonov_translation, p);
+        for (int k = 0; k < 16; ++k) pose[k] = p[k];
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x < 16) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
+  if (write_state) {
+    if (rm) {
+      for (int i = threadIdx.x; i < LS_FIELDS * rm->n_lines_max; i += blockDim.x) {
+        int f = i / rm->n_lines_max, l = i - f * rm->n_lines_max;
+        rm->line_state[i] = s.state[f * s.nl + l];
+      }
+      if (threadIdx.x < 42) rm->gradient_hessian[threadIdx.x] = gh_region[threadIdx.x];
+    }
+    if (dm) {
+      for (int i = threadIdx.x; i < PS_FIELDS * dm->n_points_max; i += blockDim.x) {
+        int f = i / dm->n_points_max, l = i - f * dm->n_points_max;
+        dm->point_state[i] = ps[f * np + l];
+      }
+      if (threadIdx.x < 42) dm->gradient_hessian[threadIdx.x] = gh_depth[threadIdx.x];
+    }
+  }
+}
+
+}  // extern "C"

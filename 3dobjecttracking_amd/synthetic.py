@@ -223,7 +223,8 @@ class Scene:
         rng = self.rng
         self.intr = dict(intr)
         if semi_axes is None:
-            semi_axes = np.sort(rng.uniform(0.03, 0.08, 3))[::-1] * np.array([1.0, 0.85, 0.7])
+            # clearly tri-axial so that all three rotations are observable from the silhouette
+            semi_axes = rng.uniform(0.06, 0.09) * np.array([1.0, rng.uniform(0.45, 0.65), rng.uniform(0.25, 0.4)])
         self.body = Ellipsoid(semi_axes)
         W, H = intr["width"], intr["height"]
         mu_b = rng.uniform(40, 215, 3)

@@ -1,0 +1,154 @@
+/* m3t_hip.h — C-ABI of libm3t_hip.so: the MI355X (gfx950) implementation of M3T's
+ * per-frame pose-optimisation hot path.
+ *
+ * This is the drop-in boundary.  The reference keeps
+ * m3t::Tracker / m3t::Optimizer / m3t::Link concrete and m3t::Modality abstract
+ * (M3T/include/m3t/modality.h:56-155); a C++ host binds these entry points from
+ * Modality subclasses or directly from its tracking loop (INTEGRATION.md shows
+ * the adapter).  Plain C: opaque context, int handles, borrowed host pointers
+ * that only have to stay valid for the duration of a call, no exceptions, no
+ * torch types.
+ *
+ * Conventions
+ *  - every function returns M3T_OK (0) / a non-negative handle on success and a
+ *    negative M3T_ERR_* code on failure; m3t_hip_last_error() gives the message
+ *    (reference: `bool` + std::cerr, e.g. region_modality.cpp:1813-1819).
+ *  - poses: float[16], column-major 4x4 (Eigen::Transform<float,3,Affine>::data()).
+ *  - a context is bound to one GPU and one host thread (the reference holds
+ *    tracking_mutex_ for a whole step, tracker.cpp:251-255); calls are
+ *    asynchronous on the context's HIP stream unless they return data.
+ *  - batching: one call of a tracking sub-step processes ALL modalities /
+ *    optimizers registered in the context in one launch, the way
+ *    Tracker::CalculateCorrespondences loops over tracking_modality_ptrs_
+ *    (tracker.cpp:452-455), only in parallel.
+ *  - there is no CPU fallback: without a usable gfx950 device m3t_hip_create
+ *    fails with M3T_ERR_DEVICE.
+ */
+#ifndef M3T_HIP_H_
+#define M3T_HIP_H_
+
+#include "m3t_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct m3t_hip_context m3t_hip_context;
+
+/* ---- context ------------------------------------------------------------- */
+int m3t_hip_create(m3t_hip_context** out, int device_id);
+void m3t_hip_destroy(m3t_hip_context* ctx);
+const char* m3t_hip_last_error(m3t_hip_context* ctx); /* ctx may be NULL: last create() error */
+/* device name / CU count / total HBM bytes of the bound GPU */
+int m3t_hip_device_info(m3t_hip_context*, char* name, size_t name_capacity, int* compute_units,
+                        size_t* total_memory_bytes);
+/* the hipStream_t all work of this context is enqueued on (for events / interop) */
+int m3t_hip_get_stream(m3t_hip_context*, void** hip_stream);
+
+/* ---- Sparse Viewpoint Models ---------------------------------------------
+ * replaces RegionModel::LoadModel (region_model.cpp:259-307) / DepthModel::LoadModel
+ * (depth_model.cpp:215-283): parses the reference's .bin (model.cpp:218-284) or takes
+ * the view table from memory, and keeps it resident in HBM.  Returns a model id. */
+int m3t_hip_region_model_create(m3t_hip_context*, const m3t_region_model_desc*);
+int m3t_hip_region_model_load(m3t_hip_context*, const char* path);
+int m3t_hip_depth_model_create(m3t_hip_context*, const m3t_depth_model_desc*);
+int m3t_hip_depth_model_load(m3t_hip_context*, const char* path);
+int m3t_hip_region_model_info(m3t_hip_context*, int model_id, int* n_views, int* n_points,
+                              float* max_contour_length);
+int m3t_hip_depth_model_info(m3t_hip_context*, int model_id, int* n_views, int* n_points,
+                             float* max_surface_area);
+/* RegionModel::GetClosestView (region_model.cpp:105-130) / DepthModel (depth_model.cpp:81-106),
+ * evaluated on the device; returns the view index */
+int m3t_hip_region_model_closest_view(m3t_hip_context*, int model_id, const float body2camera[16],
+                                      int* view_index);
+int m3t_hip_depth_model_closest_view(m3t_hip_context*, int model_id, const float body2camera[16],
+                                     int* view_index);
+
+/* ---- Cameras (camera.h:32-88) ----------------------------------------------
+ * camera_upload == Camera::UpdateImage: copies the host frame (BGR8, as cv::imread
+ * delivers it, loader_camera.cpp:76-98; or u16 depth) into HBM. */
+int m3t_hip_color_camera_create(m3t_hip_context*, const m3t_intrinsics*, const float world2camera[16]);
+int m3t_hip_depth_camera_create(m3t_hip_context*, const m3t_intrinsics*, const float world2camera[16],
+                                float depth_scale);
+int m3t_hip_camera_upload(m3t_hip_context*, int camera_id, const void* pixels, size_t row_step);
+int m3t_hip_camera_set_world2camera_pose(m3t_hip_context*, int camera_id, const float world2camera[16]);
+/* device-side frame ring: pre-stage n_slots frames, then switch the current frame
+ * without a host copy (double-buffered ingest; slot 0 is what camera_upload writes) */
+int m3t_hip_camera_set_ring(m3t_hip_context*, int camera_id, int n_slots);
+int m3t_hip_camera_upload_slot(m3t_hip_context*, int camera_id, int slot, const void* pixels, size_t row_step);
+int m3t_hip_camera_select_slot(m3t_hip_context*, int camera_id, int slot);
+int m3t_hip_cameras_select_slot(m3t_hip_context*, int slot); /* all cameras */
+
+/* ---- Bodies (body.h:46: only body2world_pose crosses the boundary) ------------ */
+int m3t_hip_body_create(m3t_hip_context*, const float body2world[16]);
+int m3t_hip_body_set_body2world_pose(m3t_hip_context*, int body_id, const float body2world[16]);
+int m3t_hip_body_get_body2world_pose(m3t_hip_context*, int body_id, float body2world[16]);
+/* bulk variants: poses[n][16] for body ids 0..n-1 */
+int m3t_hip_bodies_set_poses(m3t_hip_context*, const float* poses, int n);
+int m3t_hip_bodies_get_poses(m3t_hip_context*, float* poses, int n);
+
+/* ---- Modalities (modality.h:56-155) -------------------------------------------
+ * RegionModality ctor + SetUp (region_modality.h:169-176, region_modality.cpp:25-99);
+ * depth_camera_id = -1 unless measure_occlusions.  Renderer-fed options
+ * (use_region_checking / model_occlusions / use_silhouette_checking) -> M3T_ERR_UNSUPPORTED. */
+int m3t_hip_region_modality_create(m3t_hip_context*, const m3t_region_modality_params*, int body_id,
+                                   int color_camera_id, int region_model_id, int depth_camera_id);
+int m3t_hip_depth_modality_create(m3t_hip_context*, const m3t_depth_modality_params*, int body_id,
+                                  int depth_camera_id, int depth_model_id);
+/* Modality::gradient() / hessian() (modality.h:89-90): 6 floats + column-major 6x6 */
+int m3t_hip_modality_get_gradient_hessian(m3t_hip_context*, int modality_id, float gradient[6],
+                                          float hessian[36]);
+int m3t_hip_modality_set_gradient_hessian(m3t_hip_context*, int modality_id, const float gradient[6],
+                                          const float hessian[36]);
+/* data_lines_ / data_points_ of the last CalculateCorrespondences (for visualisation / parity) */
+int m3t_hip_region_modality_get_lines(m3t_hip_context*, int modality_id, m3t_data_line* out, int capacity,
+                                      int* n_lines);
+int m3t_hip_depth_modality_get_points(m3t_hip_context*, int modality_id, m3t_data_point* out, int capacity,
+                                      int* n_points);
+/* ColorHistograms state (color_histograms.h): n_bins^3 floats each */
+int m3t_hip_region_modality_get_histograms(m3t_hip_context*, int modality_id, float* histogram_f,
+                                           float* histogram_b);
+int m3t_hip_region_modality_set_histograms(m3t_hip_context*, int modality_id, const float* histogram_f,
+                                           const float* histogram_b);
+
+/* ---- Links / Optimizers (link.h:67, optimizer.h:48, constraint.h) -----------------
+ * Round 1: the device solve covers one free 6-dof root link per optimizer (every
+ * RBOT / YCB configuration).  Kinematic trees and constraints return
+ * M3T_ERR_UNSUPPORTED until the multi-body row lands. */
+int m3t_hip_link_create(m3t_hip_context*, int body_id, int parent_link_id, const float body2joint[16],
+                        const float joint2parent[16], const int free_directions[6],
+                        int fixed_body2joint_pose);
+int m3t_hip_link_add_modality(m3t_hip_context*, int link_id, int modality_id);
+int m3t_hip_optimizer_create(m3t_hip_context*, int root_link_id, float tikhonov_parameter_rotation,
+                             float tikhonov_parameter_translation);
+int m3t_hip_optimizer_create_rigid(m3t_hip_context*, int body_id, int n_modalities, const int* modality_ids,
+                                   float tikhonov_parameter_rotation, float tikhonov_parameter_translation);
+int m3t_hip_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, int link2_id,
+                              const float body12joint1[16], const float body22joint2[16],
+                              const int constraint_directions[6]);
+int m3t_hip_link_get_link2world_pose(m3t_hip_context*, int link_id, float pose[16]);
+
+/* ---- Tracker sub-steps (tracker.h:131-160; tracker.cpp:344-364, 430-517) -----------
+ * Same names, arguments and order as the reference's public Tracker methods. */
+int m3t_hip_tracker_set_iterations(m3t_hip_context*, int n_corr_iterations, int n_update_iterations);
+int m3t_hip_start_modalities(m3t_hip_context*, int iteration);                     /* tracker.cpp:430 */
+int m3t_hip_calculate_correspondences(m3t_hip_context*, int iteration, int corr_iteration); /* :447 */
+int m3t_hip_calculate_gradient_and_hessian(m3t_hip_context*, int iteration, int corr_iteration,
+                                           int opt_iteration);                    /* :471 */
+int m3t_hip_calculate_optimization(m3t_hip_context*, int iteration, int corr_iteration,
+                                   int opt_iteration);                            /* :481 */
+int m3t_hip_calculate_results(m3t_hip_context*, int iteration);                    /* :503 */
+/* Tracker::ExecuteTrackingStep (M3T tracker.cpp:344) == Tracker::ExecuteTrackingCycle
+ * (ICG tracker.cpp:247): the whole loop nest on the device, two launches per frame. */
+int m3t_hip_execute_tracking_step(m3t_hip_context*, int iteration);
+int m3t_hip_execute_tracking_cycle(m3t_hip_context*, int iteration);
+/* 0: execute_tracking_step issues the sub-step kernels one by one (line state and
+ *    g/H of every iteration observable); 1 (default): fused device loop;
+ * 2: fused + line/point state and g/H of the last iteration written back. */
+int m3t_hip_set_fused_step(m3t_hip_context*, int mode);
+int m3t_hip_sync(m3t_hip_context*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3T_HIP_H_ */
