@@ -116,6 +116,13 @@ struct m3t_hip_context {
   int np_max = 0, off_points = 0;
   size_t lds_track = 0, lds_corr = 0, lds_hist = 0, lds_depth = 0;
   bool hist_counts_in_lds = true;
+  // optional HIP-event timing of the two per-frame kernels (bench.py roofline leg)
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  struct Pending { hipEvent_t a, b; int which; };
+  std::vector<Pending> pending;
+  double kernel_ms[2] = {0.0, 0.0};
+  int kernel_launches[2] = {0, 0};
 };
 
 namespace {
@@ -435,9 +442,26 @@ int CheckImages(Ctx* ctx) {
   return M3T_OK;
 }
 
+struct ScopedKernelTimer {
+  Ctx* ctx;
+  int which;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedKernelTimer(Ctx* c, int w) : ctx(c), which(w) {
+    if (!ctx->timing) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  ~ScopedKernelTimer() {
+    if (!a) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->pending.push_back({a, b, which});
+  }
+};
+
 int LaunchHistogram(Ctx* ctx, int iteration, bool initialize) {
   int n = int(ctx->region_mods.size());
   if (n == 0) return M3T_OK;
+  ScopedKernelTimer timer(ctx, 1);
   hipLaunchKernelGGL(region_histogram_kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_hist, ctx->stream,
                      ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(), iteration,
                      initialize ? 1 : 0, ctx->hist_counts_in_lds ? 1 : 0);
@@ -1217,6 +1241,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   if (r) return r;
   if (ctx->fused_mode >= 1 && ctx->fused_possible) {
     int n = int(ctx->opt_table.size());
+    ScopedKernelTimer timer(ctx, 0);
     hipLaunchKernelGGL(tracking_step_kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                        ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
@@ -1239,6 +1264,38 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
 }
 int m3t_hip_execute_tracking_cycle(m3t_hip_context* ctx, int iteration) {
   return m3t_hip_execute_tracking_step(ctx, iteration);
+}
+int m3t_hip_set_kernel_timing(m3t_hip_context* ctx, int enable) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& p : ctx->pending) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  ctx->pending.clear();
+  ctx->timing = enable != 0;
+  ctx->kernel_ms[0] = ctx->kernel_ms[1] = 0.0;
+  ctx->kernel_launches[0] = ctx->kernel_launches[1] = 0;
+  return M3T_OK;
+}
+int m3t_hip_get_kernel_timing(m3t_hip_context* ctx, float total_ms[2], int launches[2]) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& p : ctx->pending) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ctx->kernel_ms[p.which] += ms;
+      ctx->kernel_launches[p.which] += 1;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  ctx->pending.clear();
+  if (total_ms) { total_ms[0] = float(ctx->kernel_ms[0]); total_ms[1] = float(ctx->kernel_ms[1]); }
+  if (launches) { launches[0] = ctx->kernel_launches[0]; launches[1] = ctx->kernel_launches[1]; }
+  return M3T_OK;
 }
 int m3t_hip_sync(m3t_hip_context* ctx) {
   CHECK_CTX();

@@ -365,13 +365,32 @@ __device__ void region_correspondences(const RegionModDev& m, const CameraDev& c
     int major = start + sw * it.scale;
     const bool horiz = flags & 4;
     float pf = 1.0f, pb = 1.0f;
-    for (int j = 0; j < it.scale; ++j, ++major, x += step) {
-      int minor = f2i(x);
-      const uint8_t* px = horiz ? image + (size_t)minor * pitch + major * 3 : image + (size_t)major * pitch + minor * 3;
-      int idx = (px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift);
-      float2 h = hist[idx];
-      pf *= h.x;
-      pb *= h.y;
+    // up to 8 pixels in flight: all pixel loads, then all histogram gathers, then the
+    // ordered product (the multiplication order is the walk order, like the reference)
+    for (int j0 = 0; j0 < it.scale; j0 += 8) {
+      int idx[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        idx[j] = -1;
+        if (j0 + j < it.scale) {
+          int minor = f2i(x);
+          const uint8_t* px =
+              horiz ? image + (size_t)minor * pitch + major * 3 : image + (size_t)major * pitch + minor * 3;
+          idx[j] = (px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift);
+          ++major;
+          x += step;
+        }
+      }
+      float2 h[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (idx[j] >= 0) h[j] = hist[idx[j]];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (idx[j] >= 0) {
+          pf *= h[j].x;
+          pb *= h[j].y;
+        }
     }
     if (it.scale > 1) {
       if (pf || pb) {
@@ -546,78 +565,107 @@ __device__ void region_gradient_hessian(const RegionModDev& m, const CameraDev& 
 // ---------------------------------------------------------------------------
 __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-major 6x6*/, float lambda_rot,
                                    float lambda_trans, float* pose /*16 col-major, in/out*/) {
-  float a[36], b[6];
+  // Every index below is a compile-time constant after unrolling, so a/x stay in VGPRs
+  // (a dynamically indexed local array would live in scratch memory: ~100x slower).
+  float a[36], x[6];
 #pragma unroll
   for (int i = 0; i < 36; ++i) a[i] = 0.0f;
+#pragma unroll
   for (int c = 0; c < 6; ++c)
+#pragma unroll
     for (int r = c; r < 6; ++r) a[c * 6 + r] = 0.0f - h_sum[c * 6 + r];
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
-    b[i] = 0.0f + g_sum[i];
+    x[i] = 0.0f + g_sum[i];
     a[i * 6 + i] += i < 3 ? lambda_rot : lambda_trans;
   }
-  int trans[6];
-  float temp[6];
+  int trans[6] = {0, 1, 2, 3, 4, 5};
   bool degenerate = false;
-  for (int k = 0; k < 6 && !degenerate; ++k) {
-    int piv = k;
-    float best = fabsf(a[k * 6 + k]);
-    for (int i = k + 1; i < 6; ++i) {
-      float v = fabsf(a[i * 6 + i]);
-      if (v > best) { best = v; piv = i; }
-    }
-    trans[k] = piv;
-    if (piv != k) {
-      int sr = 6 - piv - 1;
-      for (int c = 0; c < k; ++c) { float t = a[c * 6 + k]; a[c * 6 + k] = a[c * 6 + piv]; a[c * 6 + piv] = t; }
-      for (int i = 0; i < sr; ++i) {
-        float t = a[k * 6 + piv + 1 + i];
-        a[k * 6 + piv + 1 + i] = a[piv * 6 + piv + 1 + i];
-        a[piv * 6 + piv + 1 + i] = t;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (!degenerate) {
+      int piv = k;
+      float best = fabsf(a[k * 6 + k]);
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) {
+        float v = fabsf(a[i * 6 + i]);
+        if (v > best) { best = v; piv = i; }
       }
-      { float t = a[k * 6 + k]; a[k * 6 + k] = a[piv * 6 + piv]; a[piv * 6 + piv] = t; }
-      for (int i = k + 1; i < piv; ++i) { float t = a[k * 6 + i]; a[k * 6 + i] = a[i * 6 + piv]; a[i * 6 + piv] = t; }
-    }
-    int rs = 6 - k - 1;
-    if (k > 0) {
-      for (int c = 0; c < k; ++c) temp[c] = a[c * 6 + c] * a[c * 6 + k];
-      float acc = 0.0f;
-      for (int c = 0; c < k; ++c) acc += a[c * 6 + k] * temp[c];
-      a[k * 6 + k] -= acc;
-      for (int i = 0; i < rs; ++i) {
-        float sacc = 0.0f;
-        for (int c = 0; c < k; ++c) sacc += a[c * 6 + k + 1 + i] * temp[c];
-        a[k * 6 + k + 1 + i] -= sacc;
+      trans[k] = piv;
+#pragma unroll
+      for (int j = k + 1; j < 6; ++j) {
+        if (piv == j) {  // symmetric swap of k and j inside the lower triangle (Eigen ldlt_inplace)
+#pragma unroll
+          for (int c = 0; c < k; ++c) { float t = a[c * 6 + k]; a[c * 6 + k] = a[c * 6 + j]; a[c * 6 + j] = t; }
+#pragma unroll
+          for (int i = j + 1; i < 6; ++i) { float t = a[k * 6 + i]; a[k * 6 + i] = a[j * 6 + i]; a[j * 6 + i] = t; }
+          { float t = a[k * 6 + k]; a[k * 6 + k] = a[j * 6 + j]; a[j * 6 + j] = t; }
+#pragma unroll
+          for (int i = k + 1; i < j; ++i) { float t = a[k * 6 + i]; a[k * 6 + i] = a[i * 6 + j]; a[i * 6 + j] = t; }
+        }
       }
-    }
-    float akk = a[k * 6 + k];
-    bool pivot_valid = fabsf(akk) > 0.0f;
-    if (k == 0 && !pivot_valid) {
-      for (int j = 0; j < 6; ++j) trans[j] = j;
-      degenerate = true;
-    } else if (rs > 0 && pivot_valid) {
-      for (int i = 0; i < rs; ++i) a[k * 6 + k + 1 + i] /= akk;
+      if (k > 0) {
+        float temp[5];
+#pragma unroll
+        for (int c = 0; c < k; ++c) temp[c] = a[c * 6 + c] * a[c * 6 + k];
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < k; ++c) acc += a[c * 6 + k] * temp[c];
+        a[k * 6 + k] -= acc;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+          float sacc = 0.0f;
+#pragma unroll
+          for (int c = 0; c < k; ++c) sacc += a[c * 6 + i] * temp[c];
+          a[k * 6 + i] -= sacc;
+        }
+      }
+      float akk = a[k * 6 + k];
+      bool pivot_valid = fabsf(akk) > 0.0f;
+      if (k == 0 && !pivot_valid) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) trans[j] = j;
+        degenerate = true;
+      } else if (pivot_valid) {
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) a[k * 6 + i] /= akk;
+      }
     }
   }
-  float x[6];
-  for (int i = 0; i < 6; ++i) x[i] = b[i];
-  for (int k = 0; k < 6; ++k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j)
+      if (trans[k] == j) { float t = x[k]; x[k] = x[j]; x[j] = t; }
+  }
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     float sacc = x[i];
+#pragma unroll
     for (int c = 0; c < i; ++c) sacc -= a[c * 6 + i] * x[c];
     x[i] = sacc;
   }
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     if (fabsf(a[i * 6 + i]) > 1.17549435e-38f) x[i] /= a[i * 6 + i];
     else x[i] = 0.0f;
   }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
     float sacc = x[i];
+#pragma unroll
     for (int r = i + 1; r < 6; ++r) sacc -= a[i * 6 + r] * x[r];
     x[i] = sacc;
   }
-  for (int k = 5; k >= 0; --k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j)
+      if (trans[k] == j) { float t = x[k]; x[k] = x[j]; x[j] = t; }
+  }
   // NaN guard (optimizer.cpp:165): skip the update, still success
   bool has_nan = false;
+#pragma unroll
   for (int i = 0; i < 6; ++i) has_nan |= (x[i] != x[i]);
   if (has_nan) return;
   // exp(skew(theta_r)) by Rodrigues (Eigen uses a Pade approximant; equal to ~1e-7)

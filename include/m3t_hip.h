@@ -147,6 +147,10 @@ int m3t_hip_execute_tracking_cycle(m3t_hip_context*, int iteration);
  * 2: fused + line/point state and g/H of the last iteration written back. */
 int m3t_hip_set_fused_step(m3t_hip_context*, int mode);
 int m3t_hip_sync(m3t_hip_context*);
+/* measurement aid (bench.py roofline leg): HIP events on the context stream around
+ * [0] the fused tracking kernel and [1] the histogram kernel; totals since enable */
+int m3t_hip_set_kernel_timing(m3t_hip_context*, int enable);
+int m3t_hip_get_kernel_timing(m3t_hip_context*, float total_ms[2], int launches[2]);
 
 #ifdef __cplusplus
 }
