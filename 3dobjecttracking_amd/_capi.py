@@ -241,6 +241,7 @@ _HIP_ONLY = {
     "camera_upload_slot": [C.c_int, C.c_int, C.c_void_p, C.c_size_t],
     "camera_select_slot": [C.c_int, C.c_int],
     "cameras_select_slot": [C.c_int],
+    "set_summation_mode": [C.c_int],
     "set_kernel_timing": [C.c_int],
     "get_kernel_timing": [c_float_p, c_int_p],
 }

@@ -49,8 +49,9 @@ struct CameraDev {
 struct RegionModDev {
   int body, camera, depth_camera;
   // sparse viewpoint model (shared between objects using the same model)
-  const float* points;        // [n_views][n_points][38]
-  const float* orientations;  // [n_views][3]
+  const float* points;        // [n_views][n_points][38]  the .bin layout (depth_offsets are read from here)
+  const float4* points8;      // [n_views][n_points][2]: {cx,cy,cz,nx},{ny,nz,foreground_distance,background_distance}
+  const float4* orientations4;  // [n_views] xyz + pad
   const float* extents;       // contour_length [n_views]
   int n_views, n_points;
   float max_extent;
@@ -82,8 +83,9 @@ struct RegionModDev {
 
 struct DepthModDev {
   int body, camera;
-  const float* points;        // [n_views][n_points][36]
-  const float* orientations;
+  const float* points;        // [n_views][n_points][36]  the .bin layout (depth_offsets are read from here)
+  const float4* points8;      // [n_views][n_points][2]: {cx,cy,cz,nx},{ny,nz,0,0}
+  const float4* orientations4;
   const float* extents;       // surface_area
   int n_views, n_points;
   float max_extent;

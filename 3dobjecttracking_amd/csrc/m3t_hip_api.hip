@@ -49,6 +49,7 @@ struct Model {
   int n_views = 0, n_points = 0, point_floats = 0;
   float stride_depth_offset = 0.002f, max_radius_depth_offset = 0.05f, max_extent = 0.0f;
   DevMem points, orientations, extents;
+  DevMem points8, orientations4;  // device-only compact copies of the hot fields
 };
 
 struct Camera {
@@ -105,6 +106,7 @@ struct m3t_hip_context {
   std::vector<Optimizer> optimizers;
   int n_corr_iterations = 5, n_update_iterations = 2;
   int fused_mode = 1;
+  int sequential_sum = 0;
   // device tables
   DevMem d_cams, d_region, d_depth, d_opts, d_poses, d_scratch_view;
   bool tables_dirty = true, cams_dirty = true, poses_dirty_host = true;
@@ -231,6 +233,18 @@ int CreateModel(Ctx* ctx, bool region, int n_views, int n_points, const float* p
   HIPCHK(hipMemcpy(m->points.p, pts, pb, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->orientations.p, ori, size_t(n_views) * 12, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->extents.p, ext, size_t(n_views) * 4, hipMemcpyHostToDevice));
+  {  // compact, 16-byte aligned copies: 32 B per point instead of 152/144 B, float4 per orientation
+    const int pf = m->point_floats;
+    std::vector<float> p8(size_t(n_views) * n_points * 8, 0.0f), o4(size_t(n_views) * 4, 0.0f);
+    for (size_t i = 0; i < size_t(n_views) * n_points; ++i)
+      for (int k = 0; k < (region ? 8 : 6); ++k) p8[i * 8 + k] = pts[i * pf + k];
+    for (int v = 0; v < n_views; ++v)
+      for (int k = 0; k < 3; ++k) o4[size_t(v) * 4 + k] = ori[size_t(v) * 3 + k];
+    HIPCHK(m->points8.alloc(p8.size() * 4));
+    HIPCHK(m->orientations4.alloc(o4.size() * 4));
+    HIPCHK(hipMemcpy(m->points8.p, p8.data(), p8.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->orientations4.p, o4.data(), o4.size() * 4, hipMemcpyHostToDevice));
+  }
   auto& vec = region ? ctx->region_models : ctx->depth_models;
   vec.push_back(std::move(m));
   return int(vec.size()) - 1;
@@ -292,7 +306,7 @@ void ComputeLayout(Ctx* ctx) {
   bool hist_lds = !ctx->region_mods.empty();
   for (auto& m : ctx->region_mods) {
     nl = std::max(nl, m->p.n_lines_max);
-    ns = std::max(ns, m->dev.n_seg);
+    ns = std::max(ns, std::max(9, m->dev.n_seg));
     int b = m->p.n_histogram_bins;
     bins3 = std::max(bins3, b * b * b);
   }
@@ -310,7 +324,7 @@ void ComputeLayout(Ctx* ctx) {
   L.off_seg_b = off; off += nl * ns;
   ctx->off_points = off;
   ctx->np_max = np;
-  int off_with_points = off + (ctx->depth_mods.empty() ? 0 : PS_FIELDS * np);
+  int off_with_points = off + (ctx->depth_mods.empty() ? 0 : (PS_FIELDS + 14) * np);  // + parity-mode staging
   if (hist_lds) {
     L.off_hist = (off_with_points + 3) / 4 * 4;
     L.total_floats = L.off_hist + bins3 * 2;
@@ -322,7 +336,7 @@ void ComputeLayout(Ctx* ctx) {
   ctx->lds_track = size_t(L.total_floats) * 4;
   // the correspondence-only kernel does not need the depth point block
   ctx->lds_corr = ctx->lds_track;
-  ctx->lds_depth = size_t(M3T_MISC_FLOATS + PS_FIELDS * np) * 4;
+  ctx->lds_depth = size_t(M3T_MISC_FLOATS + (PS_FIELDS + 14) * np) * 4;
   size_t counts = size_t(bins3) * 4;
   ctx->hist_counts_in_lds = (M3T_MISC_FLOATS * 4 + counts) <= 160 * 1024;
   ctx->lds_hist = M3T_MISC_FLOATS * 4 + (ctx->hist_counts_in_lds ? counts : 0);
@@ -491,13 +505,13 @@ int LaunchGradientHessian(Ctx* ctx, int corr_iteration, int opt_iteration) {
   if (nr) {
     hipLaunchKernelGGL(region_gradient_hessian_kernel, dim3(nr), dim3(M3T_BLOCK_THREADS), ctx->lds_corr, ctx->stream,
                        ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
-                       ctx->layout, corr_iteration, opt_iteration);
+                       ctx->layout, corr_iteration, opt_iteration, ctx->sequential_sum);
     HIPCHK(hipGetLastError());
   }
   if (nd) {
     hipLaunchKernelGGL(depth_gradient_hessian_kernel, dim3(nd), dim3(M3T_BLOCK_THREADS), ctx->lds_depth, ctx->stream,
                        ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
-                       ctx->np_max, corr_iteration);
+                       ctx->np_max, corr_iteration, ctx->sequential_sum);
     HIPCHK(hipGetLastError());
   }
   return M3T_OK;
@@ -635,7 +649,7 @@ int m3t_hip_depth_model_info(m3t_hip_context* ctx, int id, int* nv, int* np, flo
 
 // single-block helper kernel for the stand-alone GetClosestView entry point
 extern "C" __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
-closest_view_kernel(const float* orientations, int n_views, const float* body2camera, int* out) {
+closest_view_kernel(const float4* orientations, int n_views, const float* body2camera, int* out) {
   __shared__ float misc[256];
   const Affine b2c = load_pose(body2camera);
   int v = closest_view(orientations, n_views, b2c, misc);
@@ -653,7 +667,7 @@ static int ClosestView(m3t_hip_context* ctx, bool region, int id, const float* p
   int* d_out = reinterpret_cast<int*>(d_pose + 16);
   HIPCHK(hipMemcpyAsync(d_pose, pose, 64, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(closest_view_kernel, dim3(1), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
-                     vec[id]->orientations.as<float>(), vec[id]->n_views, d_pose, d_out);
+                     vec[id]->orientations4.as<float4>(), vec[id]->n_views, d_pose, d_out);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(view, d_out, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -825,7 +839,8 @@ int m3t_hip_region_modality_create(m3t_hip_context* ctx, const m3t_region_modali
   d.camera = color_camera;
   d.depth_camera = m->depth_camera;
   d.points = mdl.points.as<float>();
-  d.orientations = mdl.orientations.as<float>();
+  d.points8 = mdl.points8.as<float4>();
+  d.orientations4 = mdl.orientations4.as<float4>();
   d.extents = mdl.extents.as<float>();
   d.n_views = mdl.n_views;
   d.n_points = mdl.n_points;
@@ -932,7 +947,8 @@ int m3t_hip_depth_modality_create(m3t_hip_context* ctx, const m3t_depth_modality
   d.body = body;
   d.camera = depth_camera;
   d.points = mdl.points.as<float>();
-  d.orientations = mdl.orientations.as<float>();
+  d.points8 = mdl.points8.as<float4>();
+  d.orientations4 = mdl.orientations4.as<float4>();
   d.extents = mdl.extents.as<float>();
   d.n_views = mdl.n_views;
   d.n_points = mdl.n_points;
@@ -1246,7 +1262,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                        ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
                        ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
-                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0);
+                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, ctx->sequential_sum);
     HIPCHK(hipGetLastError());
     ctx->state_valid = ctx->fused_mode == 2;
   } else {
@@ -1264,6 +1280,12 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
 }
 int m3t_hip_execute_tracking_cycle(m3t_hip_context* ctx, int iteration) {
   return m3t_hip_execute_tracking_step(ctx, iteration);
+}
+int m3t_hip_set_summation_mode(m3t_hip_context* ctx, int mode) {
+  CHECK_CTX();
+  REQUIRE(mode == 0 || mode == 1, M3T_ERR_INVALID_ARGUMENT, "mode must be 0 (tree) or 1 (reference order)");
+  ctx->sequential_sum = mode;
+  return M3T_OK;
 }
 int m3t_hip_set_kernel_timing(m3t_hip_context* ctx, int enable) {
   CHECK_CTX();
@@ -1297,6 +1319,18 @@ int m3t_hip_get_kernel_timing(m3t_hip_context* ctx, float total_ms[2], int launc
   if (launches) { launches[0] = ctx->kernel_launches[0]; launches[1] = ctx->kernel_launches[1]; }
   return M3T_OK;
 }
+#ifdef M3T_PHASE_TIMING
+int m3t_hip_debug_phase_cycles(m3t_hip_context* ctx, unsigned long long* out16, int reset) {
+  CHECK_CTX();
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
+  }
+  return M3T_OK;
+}
+#endif
 int m3t_hip_sync(m3t_hip_context* ctx) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));

@@ -23,12 +23,36 @@
 
 #include "m3t_device.h"
 
+#ifdef M3T_PHASE_TIMING
+// developer instrumentation: accumulated s_memtime cycles per phase, block 0 thread 0
+__device__ unsigned long long g_phase_cycles[16];
+#define PHASE_T0() unsigned long long _pt = clock64()
+#define PHASE_MARK(i)                                                         \
+  do {                                                                        \
+    unsigned long long _n = clock64();                                        \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_cycles[i] += _n - _pt;   \
+    _pt = _n;                                                                 \
+  } while (0)
+#else
+#define PHASE_T0() do {} while (0)
+#define PHASE_MARK(i) do {} while (0)
+#endif
+
 namespace {
+
+// The per-object parameter tables are read-only while a kernel runs: address them through
+// the constant address space so that uniform field reads become scalar loads (s_load -> SGPR)
+// instead of per-lane global loads in the middle of every dependency chain.
+typedef const __attribute__((address_space(4))) RegionModDev CRegion;
+typedef const __attribute__((address_space(4))) DepthModDev CDepth;
+typedef const __attribute__((address_space(4))) CameraDev CCam;
+typedef const __attribute__((address_space(4))) RigidOptDev COpt;
 
 constexpr int kWave = 64;
 // misc LDS scratch layout (floats): [0,128) view search / counters, [128,160) reduced sums,
 // [160,640) per-wave partials (16 waves x 27), [640,656) pose, [704,746) region g/H, [768,810) depth g/H
-constexpr int kMiscRed = 128, kMiscPartials = 160, kMiscPose = 640, kMiscGhRegion = 704, kMiscGhDepth = 768;
+constexpr int kMiscRed = 128, kMiscPartials = 160, kMiscPose = 640, kMiscGhRegion = 704, kMiscGhDepth = 768,
+              kMiscLookup = 832;  // function_lookup_f[16], function_lookup_b[16]
 
 // ---------------------------------------------------------------------------
 // pose math (column-major like Eigen; same expression trees as the reference)
@@ -38,7 +62,8 @@ struct Affine {
   float t[3];
 };
 
-__device__ __forceinline__ Affine load_pose(const float* p /*16, column-major 4x4*/) {
+template <typename P>
+__device__ __forceinline__ Affine load_pose(P p /*16 floats, column-major 4x4*/) {
   Affine a;
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -96,17 +121,75 @@ __device__ __forceinline__ int f2i(float v) { return (int)v; }  // truncation li
 __device__ __forceinline__ float i2f_bits(int v) { return __int_as_float(v); }
 __device__ __forceinline__ int f2i_bits(float v) { return __float_as_int(v); }
 
-template <typename T>
-__device__ __forceinline__ T last_valid(const T* values, int n, int idx) {  // common.h:171-176
+template <typename P>
+__device__ __forceinline__ auto last_valid(P values, int n, int idx) {  // common.h:171-176
   return idx < n ? values[idx] : values[n - 1];
+}
+
+// ---------------------------------------------------------------------------
+// wave64 primitives on DPP (no LDS traffic): row_shr 1/2/4/8 inside each 16-lane row,
+// then row_bcast:15 / row_bcast:31 across rows; the full-wave result lands in lane 63.
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_zero(float v) {  // lanes without a source read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_zero_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_self(float v) {  // lanes without a source read themselves
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_self_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += dpp_zero<0x111, 0xf>(v);
+  v += dpp_zero<0x112, 0xf>(v);
+  v += dpp_zero<0x114, 0xf>(v);
+  v += dpp_zero<0x118, 0xf>(v);
+  v += dpp_zero<0x142, 0xa>(v);
+  v += dpp_zero<0x143, 0xc>(v);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {  // broadcast result
+  v += dpp_zero_i<0x111, 0xf>(v);
+  v += dpp_zero_i<0x112, 0xf>(v);
+  v += dpp_zero_i<0x114, 0xf>(v);
+  v += dpp_zero_i<0x118, 0xf>(v);
+  v += dpp_zero_i<0x142, 0xa>(v);
+  v += dpp_zero_i<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max(float v) {  // broadcast result
+  v = fmaxf(v, dpp_self<0x111, 0xf>(v));
+  v = fmaxf(v, dpp_self<0x112, 0xf>(v));
+  v = fmaxf(v, dpp_self<0x114, 0xf>(v));
+  v = fmaxf(v, dpp_self<0x118, 0xf>(v));
+  v = fmaxf(v, dpp_self<0x142, 0xa>(v));
+  v = fmaxf(v, dpp_self<0x143, 0xc>(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_i(int v) {  // broadcast result
+  v = min(v, dpp_self_i<0x111, 0xf>(v));
+  v = min(v, dpp_self_i<0x112, 0xf>(v));
+  v = min(v, dpp_self_i<0x114, 0xf>(v));
+  v = min(v, dpp_self_i<0x118, 0xf>(v));
+  v = min(v, dpp_self_i<0x142, 0xa>(v));
+  v = min(v, dpp_self_i<0x143, 0xc>(v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // ---------------------------------------------------------------------------
 // RegionModel::GetClosestView (region_model.cpp:105-130), whole block.
 // First maximum wins == (max dot, lowest index); result broadcast to all threads.
-// misc: >= 128 floats of LDS scratch.  Contains two __syncthreads().
+// orientations4: one float4 per view (xyz + pad).  misc: >= 128 floats of LDS scratch.
+// Contains two __syncthreads().
 // ---------------------------------------------------------------------------
-__device__ int closest_view(const float* __restrict__ orientations, int n_views, const Affine& b2c, float* misc) {
+__device__ int closest_view(const float4* __restrict__ orientations4, int n_views, const Affine& b2c, float* misc) {
   float tn = sqrtf((b2c.t[0] * b2c.t[0] + b2c.t[1] * b2c.t[1]) + b2c.t[2] * b2c.t[2]);
   if (tn == 0.0f) return 0;  // block-uniform
   float tx = b2c.t[0] / tn, ty = b2c.t[1] / tn, tz = b2c.t[2] / tn;
@@ -117,20 +200,26 @@ __device__ int closest_view(const float* __restrict__ orientations, int n_views,
   float o2 = (ri[2] * tx + ri[5] * ty) + ri[8] * tz;
   float best = -1.0f;
   int bi = INT_MAX;
-  for (int v = threadIdx.x; v < n_views; v += blockDim.x) {
-    const float* p = orientations + 3 * (size_t)v;
-    float d = (o0 * p[0] + o1 * p[1]) + o2 * p[2];
-    if (d > best) { best = d; bi = v; }
-  }
+  const int nt = blockDim.x;
+  for (int v0 = threadIdx.x; v0 < n_views; v0 += 4 * nt) {
+    float4 p[4];
 #pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) {
-    float ob = __shfl_down(best, off);
-    int oi = __shfl_down(bi, off);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    for (int j = 0; j < 4; ++j) {
+      int v = v0 + j * nt;
+      p[j] = orientations4[v < n_views ? v : v0];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int v = v0 + j * nt;
+      float d = (o0 * p[j].x + o1 * p[j].y) + o2 * p[j].z;
+      if (v < n_views && d > best) { best = d; bi = v; }
+    }
   }
+  float wbest = wave_max(best);
+  int wbi = wave_min_i(best == wbest ? bi : INT_MAX);
   int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, n_waves = blockDim.x / kWave;
   int* imisc = reinterpret_cast<int*>(misc);
-  if (lane == 0) { misc[wave] = best; imisc[32 + wave] = bi; }
+  if (lane == 0) { misc[wave] = wbest; imisc[32 + wave] = wbi; }
   __syncthreads();
   best = misc[0];
   bi = imisc[32];
@@ -157,7 +246,7 @@ __device__ __forceinline__ int number_of_lines(int n_max, int adaptive, float re
 
 // IsLineUnoccludedMeasured :1343-1389 / IsPointUnoccludedMeasured depth_modality.cpp:736-776
 // (window of <= (kMaxNOcclusionStrides+1)^2 u16 samples around (center_u, center_v))
-__device__ bool occlusion_window_clear(const CameraDev& dc, float center_u, float center_v, float diameter,
+__device__ bool occlusion_window_clear(CCam& dc, float center_u, float center_v, float diameter,
                                        float depth, float depth_offset, float threshold) {
   int stride = f2i(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
   int n_strides = f2i(diameter / stride + 0.5f);
@@ -191,7 +280,7 @@ struct RegionIter {
   int line_length, line_length_minus_1;
   float line_length_minus_1_half, line_length_half_minus_1, variance;
 };
-__device__ __forceinline__ RegionIter region_iter(const RegionModDev& m, int corr_iteration) {
+__device__ __forceinline__ RegionIter region_iter(CRegion& m, int corr_iteration) {
   RegionIter it;
   it.scale = last_valid(m.scales, m.n_scales, corr_iteration);
   it.fscale = (float)it.scale;
@@ -228,6 +317,135 @@ __device__ __forceinline__ Lds carve(float* base, const TrackLdsLayout& L) {
 }
 
 // ---------------------------------------------------------------------------
+// Phase B of the correspondence search: one thread per (line, segment).
+// MultiplyPixelColorProbability (:1575-1598) over SCALE pixels in walk order, then the
+// per-segment renormalisation (:1556-1571).  B segments per thread are processed together
+// so that ~10 independent pixel loads, then ~10 independent histogram gathers are in
+// flight per lane (the walk is latency bound); the products keep the reference's order.
+// A pixel is one unaligned 4-byte load (B,G,R + one byte of the next pixel).
+// ---------------------------------------------------------------------------
+struct __attribute__((packed)) PackedU32 { uint32_t v; };
+
+template <int SCALE>
+__device__ __forceinline__ void region_segments(CRegion& m, const uint8_t* __restrict__ image,
+                                                uint32_t pitch, const float2* __restrict__ hist, int n_lines,
+                                                int valid_mask, const Lds& s) {
+  constexpr int B = SCALE >= 6 ? 1 : (SCALE >= 4 ? 2 : (SCALE == 3 ? 3 : (SCALE == 2 ? 5 : 10)));
+  const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
+  const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = m.n_bins * m.n_bins;
+  const int n_items = n_lines * n_seg;
+  for (int base = tid; base < n_items; base += nt * B) {
+    uint32_t px[B][SCALE];
+    int out_index[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      int item = base + b * nt;
+      out_index[b] = -1;
+#pragma unroll
+      for (int j = 0; j < SCALE; ++j) px[b][j] = 0;
+      if (item < n_items) {
+        int line = item / n_seg;
+        int sw = item - line * n_seg;  // segment index in walk order
+        int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+        if (flags & valid_mask) {
+          int start = f2i_bits(s.state[LS_WALK_START * nl + line]);
+          float step = s.state[LS_WALK_STEP * nl + line];
+          float x = s.chain[line * s.ns + sw];
+          int major = start + sw * SCALE;
+          const bool horiz = flags & 4;
+#pragma unroll
+          for (int j = 0; j < SCALE; ++j) {
+            int minor = f2i(x);
+            const uint8_t* p = horiz ? image + (size_t)minor * pitch + (major + j) * 3
+                                     : image + (size_t)(major + j) * pitch + minor * 3;
+            px[b][j] = reinterpret_cast<const PackedU32*>(p)->v;
+            x += step;
+          }
+          int seg = (flags & 8) ? (n_seg - 1 - sw) : sw;
+          out_index[b] = line * s.ns + seg;
+        }
+      }
+    }
+    float2 h[B][SCALE];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int j = 0; j < SCALE; ++j) {
+        uint32_t v = px[b][j];
+        int idx = ((v & 0xffu) >> bitshift) * n_bins2 + (((v >> 8) & 0xffu) >> bitshift) * n_bins +
+                  (((v >> 16) & 0xffu) >> bitshift);
+        h[b][j] = hist[idx];
+      }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      if (out_index[b] < 0) continue;
+      float pf = 1.0f, pb = 1.0f;
+#pragma unroll
+      for (int j = 0; j < SCALE; ++j) {
+        pf *= h[b][j].x;
+        pb *= h[b][j].y;
+      }
+      if (SCALE > 1) {
+        if (pf || pb) {
+          float sum = pf;
+          sum += pb;
+          pf /= sum;
+          pb /= sum;
+        } else {
+          pf = 0.5f;
+          pb = 0.5f;
+        }
+      }
+      s.seg_f[out_index[b]] = pf;
+      s.seg_b[out_index[b]] = pb;
+    }
+  }
+}
+
+// any scale (not unrolled); same arithmetic
+__device__ void region_segments_generic(CRegion& m, const uint8_t* __restrict__ image, uint32_t pitch,
+                                        const float2* __restrict__ hist, int n_lines, int valid_mask, int scale,
+                                        const Lds& s) {
+  const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
+  const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = m.n_bins * m.n_bins;
+  const int n_items = n_lines * n_seg;
+  for (int item = tid; item < n_items; item += nt) {
+    int line = item / n_seg;
+    int sw = item - line * n_seg;
+    int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+    if (!(flags & valid_mask)) continue;
+    int start = f2i_bits(s.state[LS_WALK_START * nl + line]);
+    float step = s.state[LS_WALK_STEP * nl + line];
+    float x = s.chain[line * s.ns + sw];
+    int major = start + sw * scale;
+    const bool horiz = flags & 4;
+    float pf = 1.0f, pb = 1.0f;
+    for (int j = 0; j < scale; ++j, ++major, x += step) {
+      int minor = f2i(x);
+      const uint8_t* p = horiz ? image + (size_t)minor * pitch + major * 3 : image + (size_t)major * pitch + minor * 3;
+      int idx = (p[0] >> bitshift) * n_bins2 + (p[1] >> bitshift) * n_bins + (p[2] >> bitshift);
+      float2 h = hist[idx];
+      pf *= h.x;
+      pb *= h.y;
+    }
+    if (scale > 1) {
+      if (pf || pb) {
+        float sum = pf;
+        sum += pb;
+        pf /= sum;
+        pb /= sum;
+      } else {
+        pf = 0.5f;
+        pb = 0.5f;
+      }
+    }
+    int seg = (flags & 8) ? (n_seg - 1 - sw) : sw;
+    s.seg_f[line * s.ns + seg] = pf;
+    s.seg_b[line * s.ns + seg] = pb;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // RegionModality::CalculateCorrespondences (:390-465) for one object, whole block.
 // Phase A  one thread per line: CalculateBasicLineData :1231, IsLineValid :1252,
 //          the geometric part of CalculateSegmentProbabilities :1441-1455,:1494-1496
@@ -237,13 +455,19 @@ __device__ __forceinline__ Lds carve(float* base, const TrackLdsLayout& L) {
 // Phase C  one thread per (line, d): CalculateDistribution :1600 products; then one
 //          thread per line: normalisation + CalculateDistributionMoments :1639.
 // ---------------------------------------------------------------------------
-__device__ void region_correspondences(const RegionModDev& m, const CameraDev& cam, const CameraDev* dcam,
+__device__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam,
                                        const Affine& b2c, const Affine& b2dc, int iteration, int corr_iteration,
                                        const Lds& s) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const RegionIter it = region_iter(m, corr_iteration);
   const int nl = s.nl;
-  const int view = closest_view(m.orientations, m.n_views, b2c, s.misc);
+  PHASE_T0();
+  if (tid < M3T_MAX_FUNCTION_LENGTH) {
+    s.misc[kMiscLookup + tid] = m.function_lookup_f[tid];
+    s.misc[kMiscLookup + M3T_MAX_FUNCTION_LENGTH + tid] = m.function_lookup_b[tid];
+  }
+  const int view = closest_view(m.orientations4, m.n_views, b2c, s.misc);  // (syncs publish the lookups)
+  PHASE_MARK(0);
   const int n_lines =
       number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length, m.extents[view],
                       m.max_extent, m.n_points);
@@ -258,10 +482,11 @@ __device__ void region_correspondences(const RegionModDev& m, const CameraDev& c
   for (int line = tid; line < nl; line += nt) {
     int flags = 0;
     if (line < n_lines) {
-      const float* p = m.points + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
-      float cx = p[0], cy = p[1], cz = p[2];
-      float nx = p[3], ny = p[4], nz = p[5];
-      float fg = p[6], bg = p[7];
+      const float4* p8 = m.points8 + ((size_t)view * m.n_points + line) * 2;
+      const float4 pa = p8[0], pb4 = p8[1];
+      float cx = pa.x, cy = pa.y, cz = pa.z;
+      float nx = pa.w, ny = pb4.x, nz = pb4.y;
+      float fg = pb4.z, bg = pb4.w;
       float X, Y, Z;
       apply_pose(b2c, cx, cy, cz, X, Y, Z);
       float nu = (b2c.l[0] * nx + b2c.l[3] * ny) + b2c.l[6] * nz;
@@ -302,6 +527,7 @@ __device__ void region_correspondences(const RegionModDev& m, const CameraDev& c
         float dv = dy * dcam->fv / dz + dcam->ppv;
         float meter_to_pixel = dcam->fu / dz;
         float diameter = 2.0f * m.measured_occlusion_radius * meter_to_pixel;
+        const float* p = m.points + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
         valid_occ = occlusion_window_clear(*dcam, du, dv, diameter, dz, p[8 + m.measured_depth_offset_id],
                                            m.measured_occlusion_threshold);
       }
@@ -337,9 +563,7 @@ __device__ void region_correspondences(const RegionModDev& m, const CameraDev& c
   // two-pass fallback :435-463: use the occlusion-handled set only if it has enough lines
   bool use_occ = false;
   if (occlusion_pass) {
-    int cnt = my_valid_occ;
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    int cnt = wave_sum_i(my_valid_occ);
     int* imisc = reinterpret_cast<int*>(s.misc);
     if (tid % kWave == 0) imisc[64 + tid / kWave] = cnt;
     __syncthreads();
@@ -348,66 +572,25 @@ __device__ void region_correspondences(const RegionModDev& m, const CameraDev& c
     use_occ = total >= m.min_n_unoccluded_lines;
   }
   __syncthreads();
+  PHASE_MARK(1);
   const int valid_mask = use_occ ? 1 : 2;
 
   // ---- phase B ----
   const float2* __restrict__ hist = s.hist ? s.hist : m.histogram_norm;
-  const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = m.n_bins * m.n_bins;
-  const int n_items = n_lines * n_seg;
-  for (int item = tid; item < n_items; item += nt) {
-    int line = item / n_seg;
-    int sw = item - line * n_seg;  // segment index in walk order
-    int flags = f2i_bits(s.state[LS_VALID * nl + line]);
-    if (!(flags & valid_mask)) continue;
-    int start = f2i_bits(s.state[LS_WALK_START * nl + line]);
-    float step = s.state[LS_WALK_STEP * nl + line];
-    float x = s.chain[line * s.ns + sw];
-    int major = start + sw * it.scale;
-    const bool horiz = flags & 4;
-    float pf = 1.0f, pb = 1.0f;
-    // up to 8 pixels in flight: all pixel loads, then all histogram gathers, then the
-    // ordered product (the multiplication order is the walk order, like the reference)
-    for (int j0 = 0; j0 < it.scale; j0 += 8) {
-      int idx[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        idx[j] = -1;
-        if (j0 + j < it.scale) {
-          int minor = f2i(x);
-          const uint8_t* px =
-              horiz ? image + (size_t)minor * pitch + major * 3 : image + (size_t)major * pitch + minor * 3;
-          idx[j] = (px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift);
-          ++major;
-          x += step;
-        }
-      }
-      float2 h[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (idx[j] >= 0) h[j] = hist[idx[j]];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (idx[j] >= 0) {
-          pf *= h[j].x;
-          pb *= h[j].y;
-        }
-    }
-    if (it.scale > 1) {
-      if (pf || pb) {
-        float sum = pf;
-        sum += pb;
-        pf /= sum;
-        pb /= sum;
-      } else {
-        pf = 0.5f;
-        pb = 0.5f;
-      }
-    }
-    int seg = (flags & 8) ? (n_seg - 1 - sw) : sw;
-    s.seg_f[line * s.ns + seg] = pf;
-    s.seg_b[line * s.ns + seg] = pb;
+  switch (it.scale) {
+    case 1: region_segments<1>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 2: region_segments<2>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 3: region_segments<3>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 4: region_segments<4>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 5: region_segments<5>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 6: region_segments<6>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 7: region_segments<7>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 8: region_segments<8>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 9: region_segments<9>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    default: region_segments_generic(m, image, pitch, hist, n_lines, valid_mask, it.scale, s); break;
   }
   __syncthreads();
+  PHASE_MARK(2);
 
   // ---- phase C1: raw distribution products (aliases the chain buffer) ----
   const int dl = m.distribution_length, fl = m.function_length;
@@ -420,10 +603,13 @@ __device__ void region_correspondences(const RegionModDev& m, const CameraDev& c
     const float* sf = s.seg_f + line * s.ns + d;
     const float* sb = s.seg_b + line * s.ns + d;
     float value = 1.0f;
-    for (int k = 0; k < fl; ++k) value *= sf[k] * m.function_lookup_f[k] + sb[k] * m.function_lookup_b[k];
+    const float* lf = s.misc + kMiscLookup;
+    const float* lb = s.misc + kMiscLookup + M3T_MAX_FUNCTION_LENGTH;
+    for (int k = 0; k < fl; ++k) value *= sf[k] * lf[k] + sb[k] * lb[k];
     raw[line * s.ns + d] = value;
   }
   __syncthreads();
+  PHASE_MARK(3);
   // ---- phase C2: normalisation + moments, one thread per line ----
   for (int line = tid; line < nl; line += nt) {
     int flags = f2i_bits(s.state[LS_VALID * nl + line]);
@@ -457,6 +643,7 @@ __device__ void region_correspondences(const RegionModDev& m, const CameraDev& c
     s.state[LS_VALID * nl + line] = i2f_bits((flags & ~1) | (valid ? 1 : 0));
   }
   __syncthreads();
+  PHASE_MARK(4);
 }
 
 // ---------------------------------------------------------------------------
@@ -465,19 +652,19 @@ __device__ void region_correspondences(const RegionModDev& m, const CameraDev& c
 // scratch: n_waves * N floats.  Two __syncthreads().
 // ---------------------------------------------------------------------------
 template <int N>
-__device__ void block_reduce(float (&v)[N], float* scratch, float* out /*LDS, N floats*/) {
-  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave, n_waves = blockDim.x / kWave;
+__device__ void block_reduce(float (&v)[N], int n_active_waves, float* scratch, float* out /*LDS, N floats*/) {
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  if (wave < n_active_waves) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    float x = v[i];
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_down(x, off);
-    if (lane == 0) scratch[wave * N + i] = x;
+    for (int i = 0; i < N; ++i) {
+      float x = wave_sum_lane63(v[i]);
+      if (lane == kWave - 1) scratch[wave * N + i] = x;
+    }
   }
   __syncthreads();
   if (threadIdx.x < N) {
     float x = 0.0f;
-    for (int w = 0; w < n_waves; ++w) x += scratch[w * N + threadIdx.x];
+    for (int w = 0; w < n_active_waves; ++w) x += scratch[w * N + threadIdx.x];
     out[threadIdx.x] = x;
   }
   __syncthreads();
@@ -487,14 +674,16 @@ __device__ void block_reduce(float (&v)[N], float* scratch, float* out /*LDS, N 
 // RegionModality::CalculateGradientAndHessian (:485-558), whole block.
 // Result: gh[0..5] gradient, gh[6..41] column-major symmetric hessian (LDS or global).
 // ---------------------------------------------------------------------------
-__device__ void region_gradient_hessian(const RegionModDev& m, const CameraDev& cam, const Affine& b2c,
-                                        int corr_iteration, int opt_iteration, const Lds& s, float* gh_out) {
+__device__ void region_gradient_hessian(CRegion& m, CCam& cam, const Affine& b2c,
+                                        int corr_iteration, int opt_iteration, const Lds& s, float* gh_out,
+                                        bool sequential_sum) {
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
   const RegionIter it = region_iter(m, corr_iteration);
   float acc[27];
 #pragma unroll
   for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
   for (int line = tid; line < nl; line += nt) {
+    if (sequential_sum) s.chain[line * 9 + 8] = 0.0f;
     int flags = f2i_bits(s.state[LS_VALID * nl + line]);
     if (!(flags & 1)) continue;
     float cx = s.state[LS_CX * nl + line], cy = s.state[LS_CY * nl + line], cz = s.state[LS_CZ * nl + line];
@@ -518,7 +707,9 @@ __device__ void region_gradient_hessian(const RegionModDev& m, const CameraDev& 
       int upper = f2i(delta_cs + m.distribution_length_plus_1_half);
       int lower = upper - 1;
       if (upper <= 0 || upper >= m.distribution_length) continue;
-      dll = (logf(s.state[(LS_DIST0 + upper) * nl + line]) - logf(s.state[(LS_DIST0 + lower) * nl + line])) *
+      // std::log(float): correctly rounded through f64 on both sides of the parity check
+      dll = ((float)log((double)s.state[(LS_DIST0 + upper) * nl + line]) -
+             (float)log((double)s.state[(LS_DIST0 + lower) * nl + line])) *
             m.learning_rate / measured_variance;
     }
     float dc0 = ncts * normal_u * fu_z;
@@ -538,6 +729,15 @@ __device__ void region_gradient_hessian(const RegionModDev& m, const CameraDev& 
     float weight = m.min_expected_variance / (ncts * ncts * it.variance);
     float wg = weight * dll;
     float wh = weight / measured_variance;
+    if (sequential_sum) {  // stage the per-line terms; summed below in line order
+      float* st = s.chain + line * 9;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) st[r] = J[r];
+      st[6] = wg;
+      st[7] = wh;
+      st[8] = 1.0f;
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 6; ++r) acc[r] += wg * J[r];
     int k = 6;
@@ -547,13 +747,151 @@ __device__ void region_gradient_hessian(const RegionModDev& m, const CameraDev& 
       for (int r = c; r < 6; ++r) acc[k++] -= (wh * J[r]) * J[c];
   }
   float* red = s.misc + kMiscRed;
-  block_reduce<27>(acc, s.misc + kMiscPartials, red);
+  if (sequential_sum) {
+    // parity mode: the reference's summation order (line by line, f32), 27 lanes in one wave.
+    // s.chain must hold 9 * nl floats (nl * ns >= 9 * nl since ns >= 9 is enforced on the host).
+    __syncthreads();
+    if (tid < 27) {
+      int r, c;
+      if (tid < 6) { r = tid; c = 0; }
+      else {
+        int k = tid - 6;
+        c = 0;
+        while (k >= 6 - c) { k -= 6 - c; ++c; }
+        r = c + k;
+      }
+      float sum = 0.0f;
+      for (int line = 0; line < nl; ++line) {
+        const float* st = s.chain + line * 9;
+        if (st[8] == 0.0f) continue;
+        if (tid < 6) sum += st[6] * st[r];
+        else sum -= (st[7] * st[r]) * st[c];
+      }
+      red[tid] = sum;
+    }
+    __syncthreads();
+  } else {
+    block_reduce<27>(acc, (nl + kWave - 1) / kWave, s.misc + kMiscPartials, red);
+  }
   if (tid < 6) gh_out[tid] = red[tid];
   if (tid < 36) {
     int c = tid / 6, r = tid % 6;
     int lo = r >= c ? r : c, hi = r >= c ? c : r;  // lower triangle (row lo, col hi)
     int k = 6 + hi * 6 - hi * (hi - 1) / 2 + (lo - hi);
     gh_out[6 + c * 6 + r] = red[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 helpers for the pose update (column-major, Eigen coefficient order)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void mul3(const float* a, const float* b, float* r) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[c * 3 + k] = (a[k] * b[c * 3] + a[3 + k] * b[c * 3 + 1]) + a[6 + k] * b[c * 3 + 2];
+}
+__device__ __forceinline__ void add_scaled3(const float* a, float sa, const float* b, float sb, float* r) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r[i] = sa * a[i] + sb * b[i];
+}
+// X = A^-1 B, Gaussian elimination with partial pivoting (first largest |a(i,k)| wins)
+__device__ void solve3(float* a, float* b, float* x) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int p = k;
+    float best = fabsf(a[k * 3 + k]);
+#pragma unroll
+    for (int i = k + 1; i < 3; ++i) {
+      float v = fabsf(a[k * 3 + i]);
+      if (v > best) { best = v; p = i; }
+    }
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j) {
+      if (p == j) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float t = a[c * 3 + k]; a[c * 3 + k] = a[c * 3 + j]; a[c * 3 + j] = t;
+          t = b[c * 3 + k]; b[c * 3 + k] = b[c * 3 + j]; b[c * 3 + j] = t;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = k + 1; i < 3; ++i) {
+      float f = a[k * 3 + i] / a[k * 3 + k];
+      a[k * 3 + i] = f;
+#pragma unroll
+      for (int c = k + 1; c < 3; ++c) a[c * 3 + i] -= f * a[c * 3 + k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) b[c * 3 + i] -= f * b[c * 3 + k];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 2; i >= 0; --i) {
+      float sacc = b[c * 3 + i];
+#pragma unroll
+      for (int j = i + 1; j < 3; ++j) sacc -= a[j * 3 + i] * x[c * 3 + j];
+      x[c * 3 + i] = sacc / a[i * 3 + i];
+    }
+}
+__device__ void expm3(const float* a_in, float* r) {
+  float l1 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float sacc = 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) sacc += fabsf(a_in[c * 3 + rr]);
+    l1 = fmaxf(l1, sacc);
+  }
+  const float I[9] = {1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+  float U[9], V[9], a[9], a2[9], tmp[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a[i] = a_in[i];
+  int squarings = 0;
+  if (l1 < 4.258730016922831e-001f) {
+    mul3(a, a, a2);
+    add_scaled3(a2, 1.0f, I, 60.0f, tmp);
+    mul3(a, tmp, U);
+    add_scaled3(a2, 12.0f, I, 120.0f, V);
+  } else if (l1 < 1.880152677804762e+000f) {
+    float a4[9], t2[9];
+    mul3(a, a, a2);
+    mul3(a2, a2, a4);
+    add_scaled3(a4, 1.0f, a2, 420.0f, t2);
+    add_scaled3(t2, 1.0f, I, 15120.0f, tmp);
+    mul3(a, tmp, U);
+    add_scaled3(a4, 30.0f, a2, 3360.0f, t2);
+    add_scaled3(t2, 1.0f, I, 30240.0f, V);
+  } else {
+    int e;
+    (void)frexpf(l1 / 3.925724783138660f, &e);
+    squarings = e > 0 ? e : 0;
+    float sc = ldexpf(1.0f, -squarings);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] *= sc;
+    float a4[9], a6[9], t2[9], t3[9];
+    mul3(a, a, a2);
+    mul3(a2, a2, a4);
+    mul3(a4, a2, a6);
+    add_scaled3(a6, 1.0f, a4, 1512.0f, t2);
+    add_scaled3(t2, 1.0f, a2, 277200.0f, t3);
+    add_scaled3(t3, 1.0f, I, 8648640.0f, tmp);
+    mul3(a, tmp, U);
+    add_scaled3(a6, 56.0f, a4, 25200.0f, t2);
+    add_scaled3(t2, 1.0f, a2, 1995840.0f, t3);
+    add_scaled3(t3, 1.0f, I, 17297280.0f, V);
+  }
+  float num[9], den[9];
+  add_scaled3(U, 1.0f, V, 1.0f, num);
+  add_scaled3(U, -1.0f, V, 1.0f, den);
+  solve3(den, num, r);
+  for (int i = 0; i < squarings; ++i) {
+    float t[9];
+    mul3(r, r, t);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) r[j] = t[j];
   }
 }
 
@@ -668,28 +1006,14 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
 #pragma unroll
   for (int i = 0; i < 6; ++i) has_nan |= (x[i] != x[i]);
   if (has_nan) return;
-  // exp(skew(theta_r)) by Rodrigues (Eigen uses a Pade approximant; equal to ~1e-7)
-  float wx = x[0], wy = x[1], wz = x[2];
-  float th2 = (wx * wx + wy * wy) + wz * wz;
-  float A, B;  // R = I + A K + B K^2
-  if (th2 < 1e-8f) {
-    A = 1.0f - th2 / 6.0f;
-    B = 0.5f - th2 / 24.0f;
-  } else {
-    float th = sqrtf(th2);
-    A = sinf(th) / th;
-    B = (1.0f - cosf(th)) / th2;
-  }
-  float R[9];  // column-major
-  R[0] = 1.0f - B * (wy * wy + wz * wz);
-  R[4] = 1.0f - B * (wx * wx + wz * wz);
-  R[8] = 1.0f - B * (wx * wx + wy * wy);
-  R[3] = B * wx * wy - A * wz;  // (0,1)
-  R[1] = B * wx * wy + A * wz;  // (1,0)
-  R[6] = B * wx * wz + A * wy;  // (0,2)
-  R[2] = B * wx * wz - A * wy;  // (2,0)
-  R[7] = B * wy * wz - A * wx;  // (1,2)
-  R[5] = B * wy * wz + A * wx;  // (2,1)
+  // exp(skew(theta_r)): Pade approximant with scaling and squaring like Eigen's
+  // MatrixFunctions (link.cpp:224), operation for operation the oracle's Expm3.
+  float K[9];  // column-major skew(theta_r), common.h:62-68
+  K[0] = 0.0f;  K[3] = -x[2]; K[6] = x[1];
+  K[1] = x[2];  K[4] = 0.0f;  K[7] = -x[0];
+  K[2] = -x[1]; K[5] = x[0];  K[8] = 0.0f;
+  float R[9];
+  expm3(K, R);
   Affine T = load_pose(pose), D;
 #pragma unroll
   for (int i = 0; i < 9; ++i) D.l[i] = R[i];
@@ -711,10 +1035,10 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
 // first strictly smaller distance wins in (v outer, u inner) order).
 // Point state lives in `ps` (LDS, [PS_FIELDS][np]).
 // ---------------------------------------------------------------------------
-__device__ void depth_correspondences(const DepthModDev& m, const CameraDev& cam, const Affine& b2c, int iteration,
+__device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, int iteration,
                                       int corr_iteration, float* ps, int np, float* misc) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int view = closest_view(m.orientations, m.n_views, b2c, misc);
+  const int view = closest_view(m.orientations4, m.n_views, b2c, misc);
   int n_points = number_of_lines(m.n_points_max, m.use_adaptive_coverage, m.reference_surface_area, m.extents[view],
                                  m.max_extent, m.n_points);
   const float considered_distance0 = last_valid(m.considered_distances, m.n_considered_distances, corr_iteration);
@@ -725,7 +1049,9 @@ __device__ void depth_correspondences(const DepthModDev& m, const CameraDev& cam
     int flags = 0;
     if (i < n_points) {
       const float* p = m.points + ((size_t)view * m.n_points + i) * M3T_DEPTH_POINT_FLOATS;
-      float cx = p[0], cy = p[1], cz = p[2];
+      const float4* p8 = m.points8 + ((size_t)view * m.n_points + i) * 2;
+      const float4 pa = p8[0], pb4 = p8[1];
+      float cx = pa.x, cy = pa.y, cz = pa.z;
       float X, Y, Z;
       apply_pose(b2c, cx, cy, cz, X, Y, Z);
       float center_u = X * cam.fu / Z + cam.ppu;
@@ -794,7 +1120,7 @@ __device__ void depth_correspondences(const DepthModDev& m, const CameraDev& cam
         flags = (valid_occ ? 1 : 0) | 2;
         my_valid_occ += valid_occ ? 1 : 0;
         ps[PS_CX * np + i] = cx; ps[PS_CY * np + i] = cy; ps[PS_CZ * np + i] = cz;
-        ps[PS_NX * np + i] = p[3]; ps[PS_NY * np + i] = p[4]; ps[PS_NZ * np + i] = p[5];
+        ps[PS_NX * np + i] = pa.w; ps[PS_NY * np + i] = pb4.x; ps[PS_NZ * np + i] = pb4.y;
         ps[PS_CENTER_U * np + i] = center_u;
         ps[PS_CENTER_V * np + i] = center_v;
         ps[PS_DEPTH * np + i] = depth;
@@ -805,9 +1131,7 @@ __device__ void depth_correspondences(const DepthModDev& m, const CameraDev& cam
   }
   bool use_occ = false;
   if (occlusion_pass) {
-    int cnt = my_valid_occ;
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    int cnt = wave_sum_i(my_valid_occ);
     int* imisc = reinterpret_cast<int*>(misc);
     if (tid % kWave == 0) imisc[64 + tid / kWave] = cnt;
     __syncthreads();
@@ -825,8 +1149,8 @@ __device__ void depth_correspondences(const DepthModDev& m, const CameraDev& cam
 }
 
 // DepthModality::CalculateGradientAndHessian (depth_modality.cpp:333-381), whole block.
-__device__ void depth_gradient_hessian(const DepthModDev& m, const Affine& b2c, int corr_iteration, const float* ps,
-                                       int np, float* misc, float* gh_out) {
+__device__ void depth_gradient_hessian(CDepth& m, const Affine& b2c, int corr_iteration, const float* ps,
+                                       int np, float* misc, float* gh_out, bool sequential_sum, float* stage) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const Affine c2b = inverse_pose(b2c);
   const float standard_deviation = last_valid(m.standard_deviations, m.n_standard_deviations, corr_iteration);
@@ -834,6 +1158,7 @@ __device__ void depth_gradient_hessian(const DepthModDev& m, const Affine& b2c, 
 #pragma unroll
   for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
   for (int i = tid; i < np; i += nt) {
+    if (sequential_sum) stage[i * 14 + 13] = 0.0f;
     if (!(f2i_bits(ps[PS_VALID * np + i]) & 1)) continue;
     float qx, qy, qz;
     apply_pose(c2b, ps[PS_CORR_X * np + i], ps[PS_CORR_Y * np + i], ps[PS_CORR_Z * np + i], qx, qy, qz);
@@ -844,6 +1169,15 @@ __device__ void depth_gradient_hessian(const DepthModDev& m, const Affine& b2c, 
     float weight = 1.0f / (standard_deviation * ps[PS_CORR_Z * np + i]);
     float se = (weight * weight) * epsilon;
     float w[6] = {weight * c0, weight * c1, weight * c2, weight * nx, weight * ny, weight * nz};
+    if (sequential_sum) {
+      float* st = stage + i * 14;
+      st[0] = c0; st[1] = c1; st[2] = c2; st[3] = nx; st[4] = ny; st[5] = nz;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) st[6 + r] = w[r];
+      st[12] = se;
+      st[13] = 1.0f;
+      continue;
+    }
     acc[0] -= se * c0; acc[1] -= se * c1; acc[2] -= se * c2;
     acc[3] -= se * nx; acc[4] -= se * ny; acc[5] -= se * nz;
     // upper triangle, column by column (r <= c)
@@ -854,7 +1188,29 @@ __device__ void depth_gradient_hessian(const DepthModDev& m, const Affine& b2c, 
       for (int r = 0; r <= c; ++r) acc[k++] -= w[r] * w[c];
   }
   float* red = misc + kMiscRed;
-  block_reduce<27>(acc, misc + kMiscPartials, red);
+  if (sequential_sum) {
+    __syncthreads();
+    if (tid < 27) {
+      int r = tid, c = 0;
+      if (tid >= 6) {
+        int k = tid - 6;
+        c = 0;
+        while (k > c) { k -= c + 1; ++c; }
+        r = k;
+      }
+      float sum = 0.0f;
+      for (int i = 0; i < np; ++i) {
+        const float* st = stage + i * 14;
+        if (st[13] == 0.0f) continue;
+        if (tid < 6) sum -= st[12] * st[r];
+        else sum -= st[6 + r] * st[6 + c];
+      }
+      red[tid] = sum;
+    }
+    __syncthreads();
+  } else {
+    block_reduce<27>(acc, (np + kWave - 1) / kWave, misc + kMiscPartials, red);
+  }
   if (tid < 6) gh_out[tid] = red[tid];
   if (tid < 36) {
     int c = tid / 6, r = tid % 6;
@@ -869,20 +1225,22 @@ __device__ void depth_gradient_hessian(const DepthModDev& m, const Affine& b2c, 
 // (foreground count in the low 16 bits, background in the high 16 bits; each is
 // <= n_lines * max_considered_line_length < 65536), in LDS when it fits.
 // ---------------------------------------------------------------------------
-__device__ void region_histogram_update(const RegionModDev& m, const CameraDev& cam, const CameraDev* dcam,
+__device__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam,
                                         const Affine& b2c, const Affine& b2dc, bool handle_occlusions, bool initialize,
                                         uint32_t* counts, float* misc) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n_bins3 = m.n_bins * m.n_bins * m.n_bins;
   for (int i = tid; i < n_bins3; i += nt) counts[i] = 0;
-  const int view = closest_view(m.orientations, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
+  const int view = closest_view(m.orientations4, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
   const int n_lines = number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length,
                                       m.extents[view], m.max_extent, m.n_points);
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = n_bins * n_bins;
   const int w1 = cam.width - 1, h1 = cam.height - 1;
   for (int line = tid; line < n_lines; line += nt) {
     const float* p = m.points + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
-    float cx = p[0], cy = p[1], cz = p[2];
+    const float4* p8 = m.points8 + ((size_t)view * m.n_points + line) * 2;
+    const float4 pa = p8[0], pb4 = p8[1];
+    float cx = pa.x, cy = pa.y, cz = pa.z;
     float X, Y, Z;
     apply_pose(b2c, cx, cy, cz, X, Y, Z);
     if (Z <= 0.0f) continue;
@@ -901,12 +1259,12 @@ __device__ void region_histogram_update(const RegionModDev& m, const CameraDev& 
         continue;
     }
     float length_f = m.max_considered_line_length, length_b = m.max_considered_line_length;
-    float l_f = p[6] * cam.fu / Z;
-    float l_b = p[7] * cam.fu / Z;
+    float l_f = pb4.z * cam.fu / Z;
+    float l_b = pb4.w * cam.fu / Z;
     length_f = fminf(length_f, l_f - 2.0f * m.unconsidered_line_length);
     length_b = fminf(length_b, l_b - 2.0f * m.unconsidered_line_length);
-    float nu = (b2c.l[0] * p[3] + b2c.l[3] * p[4]) + b2c.l[6] * p[5];
-    float nv = (b2c.l[1] * p[3] + b2c.l[4] * p[4]) + b2c.l[7] * p[5];
+    float nu = (b2c.l[0] * pa.w + b2c.l[3] * pb4.x) + b2c.l[6] * pb4.y;
+    float nv = (b2c.l[1] * pa.w + b2c.l[4] * pb4.x) + b2c.l[7] * pb4.y;
     float nn = sqrtf(nu * nu + nv * nv);
     if (nn > 0.0f) { nu = nu / nn; nv = nv / nn; }
     float u_step, v_step;
@@ -1004,7 +1362,7 @@ __device__ void region_histogram_update(const RegionModDev& m, const CameraDev& 
   }
 }
 
-__device__ __forceinline__ void stage_histogram(const RegionModDev& m, float* lds_hist) {
+__device__ __forceinline__ void stage_histogram(CRegion& m, float* lds_hist) {
   const int n2 = m.n_bins * m.n_bins * m.n_bins * 2;
   const float* src = reinterpret_cast<const float*>(m.histogram_norm);
   for (int i = threadIdx.x; i < n2; i += blockDim.x) lds_hist[i] = src[i];
@@ -1026,9 +1384,9 @@ __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 region_histogram_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses, int iteration,
                         int initialize, int counts_in_lds) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const RegionModDev& m = mods[blockIdx.x];
-  const CameraDev& cam = cams[m.camera];
-  const CameraDev* dcam = m.measure_occlusions ? &cams[m.depth_camera] : nullptr;
+  CRegion& m = *(CRegion*)(mods + blockIdx.x);
+  CCam& cam = *(CCam*)(cams + m.camera);
+  CCam* dcam = m.measure_occlusions ? (CCam*)(cams + m.depth_camera) : nullptr;
   const Affine b2w = load_pose(body_poses + 16 * m.body);
   const Affine b2c = mul_pose(load_pose(cam.world2camera), b2w);
   Affine b2dc = b2c;
@@ -1045,9 +1403,9 @@ __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 region_correspondence_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses,
                              TrackLdsLayout layout, int iteration, int corr_iteration) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const RegionModDev& m = mods[blockIdx.x];
-  const CameraDev& cam = cams[m.camera];
-  const CameraDev* dcam = m.measure_occlusions ? &cams[m.depth_camera] : nullptr;
+  CRegion& m = *(CRegion*)(mods + blockIdx.x);
+  CCam& cam = *(CCam*)(cams + m.camera);
+  CCam* dcam = m.measure_occlusions ? (CCam*)(cams + m.depth_camera) : nullptr;
   Lds s = carve(lds, layout);
   if (layout.off_hist >= 0) {
     stage_histogram(m, lds + layout.off_hist);
@@ -1067,10 +1425,10 @@ region_correspondence_kernel(const RegionModDev* mods, const CameraDev* cams, co
 
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 region_gradient_hessian_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses,
-                               TrackLdsLayout layout, int corr_iteration, int opt_iteration) {
+                               TrackLdsLayout layout, int corr_iteration, int opt_iteration, int sequential_sum) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const RegionModDev& m = mods[blockIdx.x];
-  const CameraDev& cam = cams[m.camera];
+  CRegion& m = *(CRegion*)(mods + blockIdx.x);
+  CCam& cam = *(CCam*)(cams + m.camera);
   Lds s = carve(lds, layout);
   for (int i = threadIdx.x; i < LS_FIELDS * m.n_lines_max; i += blockDim.x) {
     int f = i / m.n_lines_max, l = i - f * m.n_lines_max;
@@ -1079,15 +1437,15 @@ region_gradient_hessian_kernel(const RegionModDev* mods, const CameraDev* cams, 
   for (int l = m.n_lines_max + threadIdx.x; l < s.nl; l += blockDim.x) s.state[LS_VALID * s.nl + l] = i2f_bits(0);
   __syncthreads();
   const Affine b2c = mul_pose(load_pose(cam.world2camera), load_pose(body_poses + 16 * m.body));
-  region_gradient_hessian(m, cam, b2c, corr_iteration, opt_iteration, s, m.gradient_hessian);
+  region_gradient_hessian(m, cam, b2c, corr_iteration, opt_iteration, s, m.gradient_hessian, sequential_sum != 0);
 }
 
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 depth_correspondence_kernel(const DepthModDev* mods, const CameraDev* cams, const float* body_poses, int np,
                             int iteration, int corr_iteration) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const DepthModDev& m = mods[blockIdx.x];
-  const CameraDev& cam = cams[m.camera];
+  CDepth& m = *(CDepth*)(mods + blockIdx.x);
+  CCam& cam = *(CCam*)(cams + m.camera);
   float* misc = lds;
   float* ps = lds + M3T_MISC_FLOATS;
   const Affine b2c = mul_pose(load_pose(cam.world2camera), load_pose(body_poses + 16 * m.body));
@@ -1100,10 +1458,10 @@ depth_correspondence_kernel(const DepthModDev* mods, const CameraDev* cams, cons
 
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 depth_gradient_hessian_kernel(const DepthModDev* mods, const CameraDev* cams, const float* body_poses, int np,
-                              int corr_iteration) {
+                              int corr_iteration, int sequential_sum) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const DepthModDev& m = mods[blockIdx.x];
-  const CameraDev& cam = cams[m.camera];
+  CDepth& m = *(CDepth*)(mods + blockIdx.x);
+  CCam& cam = *(CCam*)(cams + m.camera);
   float* misc = lds;
   float* ps = lds + M3T_MISC_FLOATS;
   for (int i = threadIdx.x; i < PS_FIELDS * m.n_points_max; i += blockDim.x) {
@@ -1113,7 +1471,8 @@ depth_gradient_hessian_kernel(const DepthModDev* mods, const CameraDev* cams, co
   for (int l = m.n_points_max + threadIdx.x; l < np; l += blockDim.x) ps[PS_VALID * np + l] = i2f_bits(0);
   __syncthreads();
   const Affine b2c = mul_pose(load_pose(cam.world2camera), load_pose(body_poses + 16 * m.body));
-  depth_gradient_hessian(m, b2c, corr_iteration, ps, np, misc, m.gradient_hessian);
+  depth_gradient_hessian(m, b2c, corr_iteration, ps, np, misc, m.gradient_hessian, sequential_sum != 0,
+                         ps + PS_FIELDS * np);
 }
 
 // One thread per rigid optimizer (Link::CalculateGradientAndHessian link.cpp:184-193 + solve + update).
@@ -1121,7 +1480,7 @@ __global__ void rigid_optimize_kernel(const RigidOptDev* opts, int n_opts, const
                                       const DepthModDev* dmods, float* body_poses) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_opts) return;
-  const RigidOptDev& o = opts[i];
+  COpt& o = *(COpt*)(opts + i);
   float g[6], h[36];
   for (int k = 0; k < 6; ++k) g[k] = 0.0f;
   for (int k = 0; k < 36; ++k) h[k] = 0.0f;
@@ -1149,11 +1508,12 @@ __global__ void rigid_optimize_kernel(const RigidOptDev* opts, int n_opts, const
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
-                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state) {
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int sequential_sum) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const RigidOptDev& o = opts[blockIdx.x];
-  const RegionModDev* rm = o.region_modality >= 0 ? &rmods[o.region_modality] : nullptr;
-  const DepthModDev* dm = o.depth_modality >= 0 ? &dmods[o.depth_modality] : nullptr;
+  COpt& o = *(COpt*)(opts + blockIdx.x);
+  CRegion* rm = o.region_modality >= 0 ? (CRegion*)(rmods + o.region_modality) : nullptr;
+  CDepth* dm = o.depth_modality >= 0 ? (CDepth*)(dmods + o.depth_modality) : nullptr;
   Lds s = carve(lds, layout);
   float* ps = lds + off_points;
   float* pose = s.misc + kMiscPose;           // 16 floats
@@ -1162,9 +1522,9 @@ tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const D
   if (threadIdx.x < 16) pose[threadIdx.x] = body_poses[16 * o.body + threadIdx.x];
   if (rm && layout.off_hist >= 0) stage_histogram(*rm, lds + layout.off_hist);
   __syncthreads();
-  const CameraDev* cam = rm ? &cams[rm->camera] : nullptr;
-  const CameraDev* rdcam = (rm && rm->measure_occlusions) ? &cams[rm->depth_camera] : nullptr;
-  const CameraDev* dcam = dm ? &cams[dm->camera] : nullptr;
+  CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
+  CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
+  CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
   for (int c = 0; c < n_corr_iterations; ++c) {
     {
       const Affine b2w = load_pose(pose);
@@ -1180,16 +1540,18 @@ tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const D
       }
     }
     for (int u = 0; u < n_update_iterations; ++u) {
+      PHASE_T0();
       const Affine b2w = load_pose(pose);
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
-        region_gradient_hessian(*rm, *cam, b2c, c, u, s, gh_region);
+        region_gradient_hessian(*rm, *cam, b2c, c, u, s, gh_region, sequential_sum != 0);
       }
       if (dm) {
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
-        depth_gradient_hessian(*dm, b2c, c, ps, np, s.misc, gh_depth);
+        depth_gradient_hessian(*dm, b2c, c, ps, np, s.misc, gh_depth, sequential_sum != 0, ps + PS_FIELDS * np);
       }
       __syncthreads();
+      PHASE_MARK(5);
       if (threadIdx.x == 0) {
         float g[6], h[36];
         for (int k = 0; k < 6; ++k) g[k] = 0.0f;
@@ -1208,6 +1570,7 @@ tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const D
         for (int k = 0; k < 16; ++k) pose[k] = p[k];
       }
       __syncthreads();
+      PHASE_MARK(6);
     }
   }
   if (threadIdx.x < 16) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];

@@ -147,6 +147,11 @@ int m3t_hip_execute_tracking_cycle(m3t_hip_context*, int iteration);
  * 2: fused + line/point state and g/H of the last iteration written back. */
 int m3t_hip_set_fused_step(m3t_hip_context*, int mode);
 int m3t_hip_sync(m3t_hip_context*);
+/* order of the gradient/Hessian sums over lines/points.  0 (default): wavefront DPP tree +
+ * LDS across waves.  1: the reference's sequential f32 order (region_modality.cpp:550-554,
+ * depth_modality.cpp:361-377) on 27 lanes -- ~10x slower per call, for bit-level parity
+ * checks of whole tracking sequences against the CPU restatement. */
+int m3t_hip_set_summation_mode(m3t_hip_context*, int mode);
 /* measurement aid (bench.py roofline leg): HIP events on the context stream around
  * [0] the fused tracking kernel and [1] the histogram kernel; totals since enable */
 int m3t_hip_set_kernel_timing(m3t_hip_context*, int enable);

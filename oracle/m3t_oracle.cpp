@@ -1127,9 +1127,11 @@ bool RegionModality::CalculateGradientAndHessian(int, int, int opt_iteration) {
       int dist_idx_upper = int(delta_cs + distribution_length_plus_1_half);
       int dist_idx_lower = dist_idx_upper - 1;
       if (dist_idx_upper <= 0 || dist_idx_upper >= p.distribution_length) continue;
-      dloglikelihood_ddelta_cs =
-          (std::log(data_line.distribution[dist_idx_upper]) - std::log(data_line.distribution[dist_idx_lower])) *
-          p.learning_rate / data_line.measured_variance;
+      // std::log(float) of the reference, taken correctly rounded (through f64) so that the
+      // value does not depend on the libm in use (glibc logf is within 1 ulp of this)
+      dloglikelihood_ddelta_cs = (float(std::log(double(data_line.distribution[dist_idx_upper]))) -
+                                  float(std::log(double(data_line.distribution[dist_idx_lower])))) *
+                                 p.learning_rate / data_line.measured_variance;
     }
 
     float ddelta_cs_dcenter[3] = {

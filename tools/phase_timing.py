@@ -1,0 +1,30 @@
+"""Developer tool: per-phase s_memtime cycles of the fused tracking kernel (block 0),
+using a -DM3T_PHASE_TIMING build of the library (gpurun_out/libm3t_hip_timing.so)."""
+import ctypes as C, importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+pkg = importlib.import_module("3dobjecttracking_amd")
+import scenes
+lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "libm3t_hip_timing.so")
+n_obj = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+hip = pkg.CApi(lib, "m3t_hip_")
+f = hip.lib.m3t_hip_debug_phase_cycles
+f.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+inputs = scenes.Inputs(n_obj, 8, n_divides=4, n_models=8)
+inst = scenes.Instance(hip, inputs)
+inst.upload_frame(0)
+inst.tracker.StartModalities(0)
+buf = (C.c_ulonglong * 16)()
+for k in range(1, 4):
+    inst.upload_frame(k); inst.tracker.ExecuteTrackingStep(k)
+f(hip.ctx, buf, 1)
+n = 4
+for k in range(4, 8):
+    inst.upload_frame(k); inst.tracker.ExecuteTrackingStep(k)
+f(hip.ctx, buf, 1)
+names = ["view search", "phase A (lines)", "phase B (pixels)", "phase C1 (dist)", "phase C2 (moments)", "g/H", "solve"]
+tot = sum(buf[i] for i in range(7))
+for i, nme in enumerate(names):
+    print("%-20s %10.0f cycles/frame  %5.1f%%" % (nme, buf[i] / n, 100.0 * buf[i] / tot))
+print("total %.0f cycles/frame" % (tot / n))
