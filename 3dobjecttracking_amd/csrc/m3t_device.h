@@ -127,7 +127,9 @@ struct TrackLdsLayout {
   int total_floats;
 };
 
+#ifndef M3T_BLOCK_THREADS
 #define M3T_BLOCK_THREADS 512
+#endif
 #define M3T_MISC_FLOATS 1024
 
 #endif  // M3T_DEVICE_H_

@@ -408,7 +408,11 @@ int UploadTables(Ctx* ctx) {
             "per-object working set exceeds the 160 KB LDS of a CU");
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_lds_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_correspondence_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_corr)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_correspondence_lds_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_corr)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_gradient_hessian_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_corr)));
@@ -486,7 +490,8 @@ int LaunchHistogram(Ctx* ctx, int iteration, bool initialize) {
 int LaunchCorrespondences(Ctx* ctx, int iteration, int corr_iteration) {
   int nr = int(ctx->region_mods.size()), nd = int(ctx->depth_mods.size());
   if (nr) {
-    hipLaunchKernelGGL(region_correspondence_kernel, dim3(nr), dim3(M3T_BLOCK_THREADS), ctx->lds_corr, ctx->stream,
+    hipLaunchKernelGGL(ctx->layout.off_hist >= 0 ? region_correspondence_lds_kernel : region_correspondence_kernel,
+                       dim3(nr), dim3(M3T_BLOCK_THREADS), ctx->lds_corr, ctx->stream,
                        ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
                        ctx->layout, iteration, corr_iteration);
     HIPCHK(hipGetLastError());
@@ -652,7 +657,7 @@ extern "C" __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 closest_view_kernel(const float4* orientations, int n_views, const float* body2camera, int* out) {
   __shared__ float misc[256];
   const Affine b2c = load_pose(body2camera);
-  int v = closest_view(orientations, n_views, b2c, misc);
+  int v = closest_view((G<v4f>)orientations, n_views, b2c, misc);
   if (threadIdx.x == 0) *out = v;
 }
 
@@ -1258,7 +1263,8 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   if (ctx->fused_mode >= 1 && ctx->fused_possible) {
     int n = int(ctx->opt_table.size());
     ScopedKernelTimer timer(ctx, 0);
-    hipLaunchKernelGGL(tracking_step_kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
+    hipLaunchKernelGGL(ctx->layout.off_hist >= 0 ? tracking_step_lds_kernel : tracking_step_kernel, dim3(n),
+                       dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                        ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
                        ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,

@@ -48,6 +48,21 @@ typedef const __attribute__((address_space(4))) DepthModDev CDepth;
 typedef const __attribute__((address_space(4))) CameraDev CCam;
 typedef const __attribute__((address_space(4))) RigidOptDev COpt;
 
+// Pointers stored inside the parameter tables are generic; loads through them would be FLAT
+// instructions with 64-bit per-lane addresses.  Re-type them as global (address space 1) so the
+// compiler emits global_load with a scalar base + 32-bit lane offset.
+// plain clang vectors: HIP's float4/float2 classes cannot be copied out of a non-generic address space
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <typename T>
+using G = const __attribute__((address_space(1))) T*;
+template <typename T>
+using GW = __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ G<T> as_global(const T* p) { return (G<T>)p; }
+template <typename T>
+__device__ __forceinline__ GW<T> as_global_w(T* p) { return (GW<T>)p; }
+
 constexpr int kWave = 64;
 // misc LDS scratch layout (floats): [0,128) view search / counters, [128,160) reduced sums,
 // [160,640) per-wave partials (16 waves x 27), [640,656) pose, [704,746) region g/H, [768,810) depth g/H
@@ -189,7 +204,7 @@ __device__ __forceinline__ int wave_min_i(int v) {  // broadcast result
 // orientations4: one float4 per view (xyz + pad).  misc: >= 128 floats of LDS scratch.
 // Contains two __syncthreads().
 // ---------------------------------------------------------------------------
-__device__ int closest_view(const float4* __restrict__ orientations4, int n_views, const Affine& b2c, float* misc) {
+__device__ int closest_view(G<v4f> orientations4, int n_views, const Affine& b2c, float* misc) {
   float tn = sqrtf((b2c.t[0] * b2c.t[0] + b2c.t[1] * b2c.t[1]) + b2c.t[2] * b2c.t[2]);
   if (tn == 0.0f) return 0;  // block-uniform
   float tx = b2c.t[0] / tn, ty = b2c.t[1] / tn, tz = b2c.t[2] / tn;
@@ -202,7 +217,7 @@ __device__ int closest_view(const float4* __restrict__ orientations4, int n_view
   int bi = INT_MAX;
   const int nt = blockDim.x;
   for (int v0 = threadIdx.x; v0 < n_views; v0 += 4 * nt) {
-    float4 p[4];
+    v4f p[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int v = v0 + j * nt;
@@ -262,7 +277,7 @@ __device__ bool occlusion_window_clear(CCam& dc, float center_u, float center_v,
   v_max = min(v_max, dc.height - 1);
   unsigned short min_depth = (unsigned short)f2i((depth - depth_offset - threshold) / dc.depth_scale);
   for (int v = v_min; v <= v_max; v += stride) {
-    const unsigned short* row = reinterpret_cast<const unsigned short*>(dc.image + (size_t)v * dc.pitch);
+    G<unsigned short> row = (G<unsigned short>)(as_global(dc.image) + (uint32_t)v * dc.pitch);
     for (int u = u_min; u <= u_max; u += stride) {
       unsigned short d = row[u];
       if (d > 0 && d < min_depth) return false;
@@ -326,59 +341,107 @@ __device__ __forceinline__ Lds carve(float* base, const TrackLdsLayout& L) {
 // ---------------------------------------------------------------------------
 struct __attribute__((packed)) PackedU32 { uint32_t v; };
 
+typedef const __attribute__((address_space(3))) float* LdsF;
+__device__ __forceinline__ v2f load_pair(G<v2f> hist, uint32_t idx) { return hist[idx]; }
+__device__ __forceinline__ v2f load_pair(LdsF hist, uint32_t idx) {
+  v2f r;
+  r.x = hist[2 * idx];
+  r.y = hist[2 * idx + 1];
+  return r;
+}
+
+// the reference's v_f += v_step chain (region_modality.cpp:1464-1473), sampled at segment starts
 template <int SCALE>
-__device__ __forceinline__ void region_segments(CRegion& m, const uint8_t* __restrict__ image,
-                                                uint32_t pitch, const float2* __restrict__ hist, int n_lines,
-                                                int valid_mask, const Lds& s) {
-  constexpr int B = SCALE >= 6 ? 1 : (SCALE >= 4 ? 2 : (SCALE == 3 ? 3 : (SCALE == 2 ? 5 : 10)));
+__device__ __forceinline__ void chain_fill(float* chain, float x, float step, int n_seg) {
+  for (int seg = 0; seg < n_seg; ++seg) {
+    chain[seg] = x;
+#pragma unroll
+    for (int j = 0; j < SCALE; ++j) x += step;
+  }
+}
+
+template <int SCALE, typename HistPtr>
+__device__ __forceinline__ void region_segments(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist,
+                                                int n_lines, int valid_mask, const Lds& s) {
+  constexpr int B = SCALE >= 8 ? 2 : (SCALE >= 6 ? 3 : (SCALE >= 4 ? 4 : (SCALE == 3 ? 6 : 8)));  // <= 20 pixels in flight
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
-  const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = m.n_bins * m.n_bins;
+  const int bin_bits = 8 - m.bitshift;  // n_bins == 1 << bin_bits
+  const int bitshift = m.bitshift;
   const int n_items = n_lines * n_seg;
+  // (line, segment) of item = tid, advanced by nt per step without divisions
+  const int q = nt / n_seg, r = nt - q * n_seg;
+  int line0 = tid / n_seg, sw0 = tid - line0 * n_seg;
   for (int base = tid; base < n_items; base += nt * B) {
+    PHASE_T0();
     uint32_t px[B][SCALE];
     int out_index[B];
+    // all LDS reads of the batch first (independent), then the address arithmetic
+    int flags_b[B], start_b[B], sw_b[B], line_b[B];
+    float step_b[B], x_b[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       int item = base + b * nt;
+      int line = line0, sw = sw0;  // segment index in walk order
+      line0 += q;
+      sw0 += r;
+      if (sw0 >= n_seg) { sw0 -= n_seg; ++line0; }
+      if (item >= n_items) { line = 0; sw = 0; }
+      line_b[b] = line;
+      sw_b[b] = sw;
+      flags_b[b] = item < n_items ? f2i_bits(s.state[LS_VALID * nl + line]) : 0;
+      start_b[b] = f2i_bits(s.state[LS_WALK_START * nl + line]);
+      step_b[b] = s.state[LS_WALK_STEP * nl + line];
+      x_b[b] = s.chain[line * s.ns + sw];
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int flags = flags_b[b], sw = sw_b[b];
       out_index[b] = -1;
 #pragma unroll
       for (int j = 0; j < SCALE; ++j) px[b][j] = 0;
-      if (item < n_items) {
-        int line = item / n_seg;
-        int sw = item - line * n_seg;  // segment index in walk order
-        int flags = f2i_bits(s.state[LS_VALID * nl + line]);
-        if (flags & valid_mask) {
-          int start = f2i_bits(s.state[LS_WALK_START * nl + line]);
-          float step = s.state[LS_WALK_STEP * nl + line];
-          float x = s.chain[line * s.ns + sw];
-          int major = start + sw * SCALE;
-          const bool horiz = flags & 4;
+      if (flags & valid_mask) {
+        float x = x_b[b];
+        const float step = step_b[b];
+        const int major = start_b[b] + sw * SCALE;
+        const bool horiz = flags & 4;
+        // byte offset = minor * stride_minor + (major + j) * stride_major; minor < 2^16 and the
+        // strides < 2^24, so the 24-bit multiply (full rate) is exact in its low 32 bits
+        const uint32_t stride_minor = horiz ? pitch : 3u, stride_major = horiz ? 3u : pitch;
+        uint32_t off_major = (uint32_t)major * stride_major;
 #pragma unroll
-          for (int j = 0; j < SCALE; ++j) {
-            int minor = f2i(x);
-            const uint8_t* p = horiz ? image + (size_t)minor * pitch + (major + j) * 3
-                                     : image + (size_t)(major + j) * pitch + minor * 3;
-            px[b][j] = reinterpret_cast<const PackedU32*>(p)->v;
-            x += step;
-          }
-          int seg = (flags & 8) ? (n_seg - 1 - sw) : sw;
-          out_index[b] = line * s.ns + seg;
+        for (int j = 0; j < SCALE; ++j) {
+          uint32_t off = __umul24((uint32_t)f2i(x), stride_minor) + off_major;
+          px[b][j] = reinterpret_cast<G<PackedU32>>(image + off)->v;
+          off_major += stride_major;
+          x += step;
         }
+        int seg = (flags & 8) ? (n_seg - 1 - sw) : sw;
+        out_index[b] = line_b[b] * s.ns + seg;
       }
     }
-    float2 h[B][SCALE];
+    PHASE_MARK(7);  // LDS reads + address arithmetic + pixel load issue
+    v2f h[B][SCALE];
+#ifdef M3T_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_MARK(8);  // pixel load latency
+#endif
 #pragma unroll
     for (int b = 0; b < B; ++b)
 #pragma unroll
       for (int j = 0; j < SCALE; ++j) {
         uint32_t v = px[b][j];
-        int idx = ((v & 0xffu) >> bitshift) * n_bins2 + (((v >> 8) & 0xffu) >> bitshift) * n_bins +
-                  (((v >> 16) & 0xffu) >> bitshift);
-        h[b][j] = hist[idx];
+        // (B >> s) * n^2 + (G >> s) * n + (R >> s) with n = 2^bin_bits (color_histograms.cpp:97-99)
+        uint32_t idx = ((((v & 0xffu) >> bitshift) << bin_bits | ((v >> 8) & 0xffu) >> bitshift) << bin_bits) |
+                       (((v >> 16) & 0xffu) >> bitshift);
+        h[b][j] = load_pair(hist, idx);
       }
+#ifdef M3T_PHASE_TIMING
+    PHASE_MARK(9);  // histogram gather issue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_MARK(10);  // histogram gather latency
+#endif
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-      if (out_index[b] < 0) continue;
       float pf = 1.0f, pb = 1.0f;
 #pragma unroll
       for (int j = 0; j < SCALE; ++j) {
@@ -396,16 +459,19 @@ __device__ __forceinline__ void region_segments(CRegion& m, const uint8_t* __res
           pb = 0.5f;
         }
       }
-      s.seg_f[out_index[b]] = pf;
-      s.seg_b[out_index[b]] = pb;
+      if (out_index[b] >= 0) {
+        s.seg_f[out_index[b]] = pf;
+        s.seg_b[out_index[b]] = pb;
+      }
     }
+    PHASE_MARK(11);  // products, normalisation, LDS stores
   }
 }
 
 // any scale (not unrolled); same arithmetic
-__device__ void region_segments_generic(CRegion& m, const uint8_t* __restrict__ image, uint32_t pitch,
-                                        const float2* __restrict__ hist, int n_lines, int valid_mask, int scale,
-                                        const Lds& s) {
+template <typename HistPtr>
+__device__ void region_segments_generic(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist, int n_lines,
+                                        int valid_mask, int scale, const Lds& s) {
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = m.n_bins * m.n_bins;
   const int n_items = n_lines * n_seg;
@@ -422,9 +488,9 @@ __device__ void region_segments_generic(CRegion& m, const uint8_t* __restrict__ 
     float pf = 1.0f, pb = 1.0f;
     for (int j = 0; j < scale; ++j, ++major, x += step) {
       int minor = f2i(x);
-      const uint8_t* p = horiz ? image + (size_t)minor * pitch + major * 3 : image + (size_t)major * pitch + minor * 3;
+      G<uint8_t> p = horiz ? image + (uint32_t)minor * pitch + major * 3 : image + (uint32_t)major * pitch + minor * 3;
       int idx = (p[0] >> bitshift) * n_bins2 + (p[1] >> bitshift) * n_bins + (p[2] >> bitshift);
-      float2 h = hist[idx];
+      v2f h = load_pair(hist, idx);
       pf *= h.x;
       pb *= h.y;
     }
@@ -445,6 +511,23 @@ __device__ void region_segments_generic(CRegion& m, const uint8_t* __restrict__ 
   }
 }
 
+template <typename HistPtr>
+__device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist,
+                                                         int scale, int n_lines, int valid_mask, const Lds& s) {
+  switch (scale) {
+    case 1: region_segments<1>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 2: region_segments<2>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 3: region_segments<3>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 4: region_segments<4>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 5: region_segments<5>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 6: region_segments<6>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 7: region_segments<7>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 8: region_segments<8>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    case 9: region_segments<9>(m, image, pitch, hist, n_lines, valid_mask, s); break;
+    default: region_segments_generic(m, image, pitch, hist, n_lines, valid_mask, scale, s); break;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // RegionModality::CalculateCorrespondences (:390-465) for one object, whole block.
 // Phase A  one thread per line: CalculateBasicLineData :1231, IsLineValid :1252,
@@ -455,9 +538,10 @@ __device__ void region_segments_generic(CRegion& m, const uint8_t* __restrict__ 
 // Phase C  one thread per (line, d): CalculateDistribution :1600 products; then one
 //          thread per line: normalisation + CalculateDistributionMoments :1639.
 // ---------------------------------------------------------------------------
-__device__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam,
-                                       const Affine& b2c, const Affine& b2dc, int iteration, int corr_iteration,
-                                       const Lds& s) {
+template <bool HIST_LDS>
+__device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
+                                                       const Affine& b2dc, int iteration, int corr_iteration,
+                                                       const Lds& s) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const RegionIter it = region_iter(m, corr_iteration);
   const int nl = s.nl;
@@ -466,7 +550,7 @@ __device__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam,
     s.misc[kMiscLookup + tid] = m.function_lookup_f[tid];
     s.misc[kMiscLookup + M3T_MAX_FUNCTION_LENGTH + tid] = m.function_lookup_b[tid];
   }
-  const int view = closest_view(m.orientations4, m.n_views, b2c, s.misc);  // (syncs publish the lookups)
+  const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, s.misc);  // (syncs publish the lookups)
   PHASE_MARK(0);
   const int n_lines =
       number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length, m.extents[view],
@@ -474,7 +558,7 @@ __device__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam,
   const bool occlusion_pass =
       m.measure_occlusions && (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
   const int n_seg = m.n_seg;
-  const uint8_t* __restrict__ image = cam.image;
+  G<uint8_t> image = as_global(cam.image);
   const uint32_t pitch = cam.pitch;
 
   // ---- phase A ----
@@ -482,8 +566,8 @@ __device__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam,
   for (int line = tid; line < nl; line += nt) {
     int flags = 0;
     if (line < n_lines) {
-      const float4* p8 = m.points8 + ((size_t)view * m.n_points + line) * 2;
-      const float4 pa = p8[0], pb4 = p8[1];
+      G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
+      const v4f pa = p8[0], pb4 = p8[1];
       float cx = pa.x, cy = pa.y, cz = pa.z;
       float nx = pa.w, ny = pb4.x, nz = pb4.y;
       float fg = pb4.z, bg = pb4.w;
@@ -527,7 +611,7 @@ __device__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam,
         float dv = dy * dcam->fv / dz + dcam->ppv;
         float meter_to_pixel = dcam->fu / dz;
         float diameter = 2.0f * m.measured_occlusion_radius * meter_to_pixel;
-        const float* p = m.points + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
+        G<float> p = as_global(m.points) + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
         valid_occ = occlusion_window_clear(*dcam, du, dv, diameter, dz, p[8 + m.measured_depth_offset_id],
                                            m.measured_occlusion_threshold);
       }
@@ -548,13 +632,22 @@ __device__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam,
         s.state[LS_WALK_START * nl + line] = i2f_bits(start);
         s.state[LS_WALK_STEP * nl + line] = step;
         // sequential chain: x_{k+1} = x_k + step, recorded at every segment start
-        float x = x0;
         float* chain = s.chain + line * s.ns;
-        int seg = 0, in_seg = 0;
-        for (int k = 0; k < it.line_length; ++k) {
-          if (in_seg == 0) chain[seg] = x;
-          x += step;
-          if (++in_seg == it.scale) { in_seg = 0; ++seg; }
+        switch (it.scale) {
+          case 1: chain_fill<1>(chain, x0, step, n_seg); break;
+          case 2: chain_fill<2>(chain, x0, step, n_seg); break;
+          case 3: chain_fill<3>(chain, x0, step, n_seg); break;
+          case 4: chain_fill<4>(chain, x0, step, n_seg); break;
+          case 5: chain_fill<5>(chain, x0, step, n_seg); break;
+          case 6: chain_fill<6>(chain, x0, step, n_seg); break;
+          case 7: chain_fill<7>(chain, x0, step, n_seg); break;
+          default: {
+            float x = x0;
+            for (int seg = 0; seg < n_seg; ++seg) {
+              chain[seg] = x;
+              for (int j = 0; j < it.scale; ++j) x += step;
+            }
+          }
         }
       }
     }
@@ -576,18 +669,10 @@ __device__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam,
   const int valid_mask = use_occ ? 1 : 2;
 
   // ---- phase B ----
-  const float2* __restrict__ hist = s.hist ? s.hist : m.histogram_norm;
-  switch (it.scale) {
-    case 1: region_segments<1>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 2: region_segments<2>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 3: region_segments<3>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 4: region_segments<4>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 5: region_segments<5>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 6: region_segments<6>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 7: region_segments<7>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 8: region_segments<8>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 9: region_segments<9>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    default: region_segments_generic(m, image, pitch, hist, n_lines, valid_mask, it.scale, s); break;
+  if (HIST_LDS) {  // pair table staged in LDS (n_bins <= 16)
+    region_segments_dispatch(m, image, pitch, (LdsF)s.hist, it.scale, n_lines, valid_mask, s);
+  } else {         // pair table gathered from L2 / HBM
+    region_segments_dispatch(m, image, pitch, (G<v2f>)m.histogram_norm, it.scale, n_lines, valid_mask, s);
   }
   __syncthreads();
   PHASE_MARK(2);
@@ -605,7 +690,15 @@ __device__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam,
     float value = 1.0f;
     const float* lf = s.misc + kMiscLookup;
     const float* lb = s.misc + kMiscLookup + M3T_MAX_FUNCTION_LENGTH;
-    for (int k = 0; k < fl; ++k) value *= sf[k] * lf[k] + sb[k] * lb[k];
+    if (fl == 8) {  // default function_length: independent LDS reads, ordered product
+      float f[8], b[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { f[k] = sf[k]; b[k] = sb[k]; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) value *= f[k] * lf[k] + b[k] * lb[k];
+    } else {
+      for (int k = 0; k < fl; ++k) value *= sf[k] * lf[k] + sb[k] * lb[k];
+    }
     raw[line * s.ns + d] = value;
   }
   __syncthreads();
@@ -1038,7 +1131,7 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
 __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, int iteration,
                                       int corr_iteration, float* ps, int np, float* misc) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int view = closest_view(m.orientations4, m.n_views, b2c, misc);
+  const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);
   int n_points = number_of_lines(m.n_points_max, m.use_adaptive_coverage, m.reference_surface_area, m.extents[view],
                                  m.max_extent, m.n_points);
   const float considered_distance0 = last_valid(m.considered_distances, m.n_considered_distances, corr_iteration);
@@ -1049,8 +1142,8 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
     int flags = 0;
     if (i < n_points) {
       const float* p = m.points + ((size_t)view * m.n_points + i) * M3T_DEPTH_POINT_FLOATS;
-      const float4* p8 = m.points8 + ((size_t)view * m.n_points + i) * 2;
-      const float4 pa = p8[0], pb4 = p8[1];
+      G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + i) * 2;
+      const v4f pa = p8[0], pb4 = p8[1];
       float cx = pa.x, cy = pa.y, cz = pa.z;
       float X, Y, Z;
       apply_pose(b2c, cx, cy, cz, X, Y, Z);
@@ -1086,7 +1179,7 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
         float min_considered = cd * cd;
         float best = min_considered;
         for (int v = v_min; v <= v_max; v += stride) {
-          const unsigned short* row = reinterpret_cast<const unsigned short*>(cam.image + (size_t)v * cam.pitch);
+          G<unsigned short> row = (G<unsigned short>)(as_global(cam.image) + (uint32_t)v * cam.pitch);
           for (int u = u_min; u <= u_max; u += stride) {
             float d = (float)row[u];
             if (d > min_depth_value && d < max_depth_value) {
@@ -1231,15 +1324,15 @@ __device__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam,
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n_bins3 = m.n_bins * m.n_bins * m.n_bins;
   for (int i = tid; i < n_bins3; i += nt) counts[i] = 0;
-  const int view = closest_view(m.orientations4, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
+  const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
   const int n_lines = number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length,
                                       m.extents[view], m.max_extent, m.n_points);
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = n_bins * n_bins;
   const int w1 = cam.width - 1, h1 = cam.height - 1;
   for (int line = tid; line < n_lines; line += nt) {
     const float* p = m.points + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
-    const float4* p8 = m.points8 + ((size_t)view * m.n_points + line) * 2;
-    const float4 pa = p8[0], pb4 = p8[1];
+    G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
+    const v4f pa = p8[0], pb4 = p8[1];
     float cx = pa.x, cy = pa.y, cz = pa.z;
     float X, Y, Z;
     apply_pose(b2c, cx, cy, cz, X, Y, Z);
@@ -1286,7 +1379,7 @@ __device__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam,
     for (int k = 0; k < projected_length_f; ++k) {
       int iu = f2i(u), iv = f2i(v);
       if (iu < 0 || iu > w1 || iv < 0 || iv > h1) break;
-      const uint8_t* px = cam.image + (size_t)iv * cam.pitch + iu * 3;
+      G<uint8_t> px = as_global(cam.image) + (uint32_t)iv * cam.pitch + iu * 3;
       atomicAdd(&counts[(px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift)], 1u);
       u -= u_step;
       v -= v_step;
@@ -1296,7 +1389,7 @@ __device__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam,
     for (int k = 0; k < projected_length_b; ++k) {
       int iu = f2i(u), iv = f2i(v);
       if (iu < 0 || iu > w1 || iv < 0 || iv > h1) break;
-      const uint8_t* px = cam.image + (size_t)iv * cam.pitch + iu * 3;
+      G<uint8_t> px = as_global(cam.image) + (uint32_t)iv * cam.pitch + iu * 3;
       atomicAdd(&counts[(px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift)],
                 65536u);
       u += u_step;
@@ -1399,28 +1492,41 @@ region_histogram_kernel(const RegionModDev* mods, const CameraDev* cams, const f
   region_histogram_update(m, cam, dcam, b2c, b2dc, handle_occlusions, initialize != 0, counts, misc);
 }
 
-__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
-region_correspondence_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses,
+extern "C++" {
+template <bool HIST_LDS>
+__device__ __forceinline__ void region_correspondence_body(const RegionModDev* mods, const CameraDev* cams, const float* body_poses,
                              TrackLdsLayout layout, int iteration, int corr_iteration) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds_t[];
   CRegion& m = *(CRegion*)(mods + blockIdx.x);
   CCam& cam = *(CCam*)(cams + m.camera);
   CCam* dcam = m.measure_occlusions ? (CCam*)(cams + m.depth_camera) : nullptr;
-  Lds s = carve(lds, layout);
-  if (layout.off_hist >= 0) {
-    stage_histogram(m, lds + layout.off_hist);
+  Lds s = carve(lds_t, layout);
+  if (HIST_LDS) {
+    stage_histogram(m, lds_t + layout.off_hist);
     __syncthreads();
   }
   const Affine b2w = load_pose(body_poses + 16 * m.body);
   const Affine b2c = mul_pose(load_pose(cam.world2camera), b2w);
   Affine b2dc = b2c;
   if (dcam) b2dc = mul_pose(load_pose(dcam->world2camera), b2w);
-  region_correspondences(m, cam, dcam, b2c, b2dc, iteration, corr_iteration, s);
+  region_correspondences<HIST_LDS>(m, cam, dcam, b2c, b2dc, iteration, corr_iteration, s);
   // LDS -> global line state (compact stride n_lines_max)
   for (int i = threadIdx.x; i < LS_FIELDS * m.n_lines_max; i += blockDim.x) {
     int f = i / m.n_lines_max, l = i - f * m.n_lines_max;
     m.line_state[i] = s.state[f * s.nl + l];
   }
+}
+
+}  // extern "C++"
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+region_correspondence_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses,
+                             TrackLdsLayout layout, int iteration, int corr_iteration) {
+  region_correspondence_body<false>(mods, cams, body_poses, layout, iteration, corr_iteration);
+}
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+region_correspondence_lds_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses,
+                                 TrackLdsLayout layout, int iteration, int corr_iteration) {
+  region_correspondence_body<true>(mods, cams, body_poses, layout, iteration, corr_iteration);
 }
 
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
@@ -1505,22 +1611,23 @@ __global__ void rigid_optimize_kernel(const RigidOptDev* opts, int n_opts, const
 // one block per rigid optimizer; n_corr x (correspondences + n_update x (g/H + solve)).
 // Everything between the image/model gathers and the final pose stays in LDS.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
-tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+extern "C++" {
+template <bool HIST_LDS>
+__device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
                      int sequential_sum) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds_t[];
   COpt& o = *(COpt*)(opts + blockIdx.x);
   CRegion* rm = o.region_modality >= 0 ? (CRegion*)(rmods + o.region_modality) : nullptr;
   CDepth* dm = o.depth_modality >= 0 ? (CDepth*)(dmods + o.depth_modality) : nullptr;
-  Lds s = carve(lds, layout);
-  float* ps = lds + off_points;
+  Lds s = carve(lds_t, layout);
+  float* ps = lds_t + off_points;
   float* pose = s.misc + kMiscPose;           // 16 floats
   float* gh_region = s.misc + kMiscGhRegion;  // 42
   float* gh_depth = s.misc + kMiscGhDepth;    // 42
   if (threadIdx.x < 16) pose[threadIdx.x] = body_poses[16 * o.body + threadIdx.x];
-  if (rm && layout.off_hist >= 0) stage_histogram(*rm, lds + layout.off_hist);
+  if (HIST_LDS && rm) stage_histogram(*rm, lds_t + layout.off_hist);
   __syncthreads();
   CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
   CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
@@ -1532,7 +1639,7 @@ tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const D
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_correspondences(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s);
+        region_correspondences<HIST_LDS>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s);
       }
       if (dm) {
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
@@ -1590,6 +1697,24 @@ tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const D
       if (threadIdx.x < 42) dm->gradient_hessian[threadIdx.x] = gh_depth[threadIdx.x];
     }
   }
+}
+
+}  // extern "C++"
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int sequential_sum) {
+  tracking_step_body<false>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
+                            n_update_iterations, write_state, sequential_sum);
+}
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_lds_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int sequential_sum) {
+  tracking_step_body<true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
+                            n_update_iterations, write_state, sequential_sum);
 }
 
 }  // extern "C"
