@@ -1,0 +1,226 @@
+// m3t_hip.hpp — header-only C++ host mirror of the reference's object graph for the hot
+// path, on top of the C-ABI (m3t_hip.h).  Class and method names follow M3T
+// (Body, ColorCamera, DepthCamera, RegionModel, DepthModel, RegionModality, DepthModality,
+// Optimizer, Tracker::StartModalities / CalculateCorrespondences / CalculateGradientAndHessian /
+// CalculateOptimization / CalculateResults / ExecuteTrackingStep; M3T/include/m3t/tracker.h:131-160),
+// steps return bool and report on std::cerr like the reference.  No Eigen / OpenCV types:
+// poses are std::array<float,16> column-major (== Eigen::Transform<float,3,Affine>::data()),
+// images are raw pointers + row step (== cv::Mat::data / cv::Mat::step).
+// INTEGRATION.md shows the m3t::Modality adapter built with the user's Eigen / OpenCV.
+#ifndef M3T_HIP_HPP_
+#define M3T_HIP_HPP_
+
+#include <array>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "m3t_hip.h"
+
+namespace m3t_hip {
+
+using Pose = std::array<float, 16>;  // column-major 4x4
+
+inline Pose IdentityPose() { return Pose{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; }
+
+class Context {
+ public:
+  explicit Context(int device_id = 0) {
+    int rc = m3t_hip_create(&ctx_, device_id);
+    if (rc != M3T_OK) throw std::runtime_error(std::string("m3t_hip_create: ") + m3t_hip_last_error(nullptr));
+  }
+  ~Context() { m3t_hip_destroy(ctx_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  m3t_hip_context* get() const { return ctx_; }
+  // constructors throw on invalid arguments (the reference's SetUp() would return false)
+  int Check(int rc, const char* what) const {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + m3t_hip_last_error(ctx_));
+    return rc;
+  }
+  // steps return bool + message on std::cerr, like every Tracker / Modality step of the reference
+  bool Step(int rc) const {
+    if (rc < 0) {
+      std::cerr << m3t_hip_last_error(ctx_) << std::endl;
+      return false;
+    }
+    return true;
+  }
+
+ private:
+  m3t_hip_context* ctx_ = nullptr;
+};
+using ContextPtr = std::shared_ptr<Context>;
+
+class Body {
+ public:
+  Body(ContextPtr c, const Pose& body2world_pose) : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_body_create(c_->get(), body2world_pose.data()), "Body");
+  }
+  void set_body2world_pose(const Pose& p) { c_->Check(m3t_hip_body_set_body2world_pose(c_->get(), id_, p.data()), "Body"); }
+  Pose body2world_pose() const {
+    Pose p;
+    c_->Check(m3t_hip_body_get_body2world_pose(c_->get(), id_, p.data()), "Body");
+    return p;
+  }
+  int id() const { return id_; }
+
+ private:
+  ContextPtr c_;
+  int id_;
+};
+
+class Camera {
+ public:
+  // Camera::UpdateImage: pixels = BGR8 (color) or u16 (depth), row_step in bytes
+  bool UpdateImage(const void* pixels, size_t row_step) {
+    return c_->Step(m3t_hip_camera_upload(c_->get(), id_, pixels, row_step));
+  }
+  void set_world2camera_pose(const Pose& p) {
+    c_->Check(m3t_hip_camera_set_world2camera_pose(c_->get(), id_, p.data()), "Camera");
+  }
+  int id() const { return id_; }
+
+ protected:
+  ContextPtr c_;
+  int id_ = -1;
+};
+class ColorCamera : public Camera {
+ public:
+  ColorCamera(ContextPtr c, const m3t_intrinsics& intrinsics, const Pose& world2camera_pose = IdentityPose()) {
+    c_ = std::move(c);
+    id_ = c_->Check(m3t_hip_color_camera_create(c_->get(), &intrinsics, world2camera_pose.data()), "ColorCamera");
+  }
+};
+class DepthCamera : public Camera {
+ public:
+  DepthCamera(ContextPtr c, const m3t_intrinsics& intrinsics, float depth_scale,
+              const Pose& world2camera_pose = IdentityPose()) {
+    c_ = std::move(c);
+    id_ = c_->Check(m3t_hip_depth_camera_create(c_->get(), &intrinsics, world2camera_pose.data(), depth_scale),
+                    "DepthCamera");
+  }
+};
+
+class RegionModel {
+ public:
+  RegionModel(ContextPtr c, const std::string& model_path) : c_(std::move(c)) {  // RegionModel::LoadModel
+    id_ = c_->Check(m3t_hip_region_model_load(c_->get(), model_path.c_str()), "RegionModel");
+  }
+  RegionModel(ContextPtr c, const m3t_region_model_desc& desc) : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_region_model_create(c_->get(), &desc), "RegionModel");
+  }
+  int GetClosestView(const Pose& body2camera_pose) const {
+    int v = 0;
+    c_->Check(m3t_hip_region_model_closest_view(c_->get(), id_, body2camera_pose.data(), &v), "GetClosestView");
+    return v;
+  }
+  int id() const { return id_; }
+
+ private:
+  ContextPtr c_;
+  int id_;
+};
+class DepthModel {
+ public:
+  DepthModel(ContextPtr c, const std::string& model_path) : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_depth_model_load(c_->get(), model_path.c_str()), "DepthModel");
+  }
+  DepthModel(ContextPtr c, const m3t_depth_model_desc& desc) : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_depth_model_create(c_->get(), &desc), "DepthModel");
+  }
+  int id() const { return id_; }
+
+ private:
+  ContextPtr c_;
+  int id_;
+};
+
+class Modality {
+ public:
+  virtual ~Modality() = default;
+  // Modality::gradient() / hessian(): 6 floats, column-major 6x6
+  void gradient_hessian(float gradient[6], float hessian[36]) const {
+    c_->Check(m3t_hip_modality_get_gradient_hessian(c_->get(), id_, gradient, hessian), "Modality");
+  }
+  int id() const { return id_; }
+
+ protected:
+  ContextPtr c_;
+  int id_ = -1;
+};
+class RegionModality : public Modality {
+ public:
+  RegionModality(ContextPtr c, const Body& body, const ColorCamera& color_camera, const RegionModel& region_model,
+                 const m3t_region_modality_params& params, const DepthCamera* depth_camera = nullptr) {
+    c_ = std::move(c);
+    id_ = c_->Check(m3t_hip_region_modality_create(c_->get(), &params, body.id(), color_camera.id(), region_model.id(),
+                                                   depth_camera ? depth_camera->id() : -1),
+                    "RegionModality");
+  }
+  std::vector<m3t_data_line> data_lines(int capacity = 1024) const {
+    std::vector<m3t_data_line> out(capacity);
+    int n = 0;
+    c_->Check(m3t_hip_region_modality_get_lines(c_->get(), id_, out.data(), capacity, &n), "data_lines");
+    out.resize(n < capacity ? n : capacity);
+    return out;
+  }
+};
+class DepthModality : public Modality {
+ public:
+  DepthModality(ContextPtr c, const Body& body, const DepthCamera& depth_camera, const DepthModel& depth_model,
+                const m3t_depth_modality_params& params) {
+    c_ = std::move(c);
+    id_ = c_->Check(m3t_hip_depth_modality_create(c_->get(), &params, body.id(), depth_camera.id(), depth_model.id()),
+                    "DepthModality");
+  }
+};
+
+// m3t::Optimizer with one free 6-dof root Link holding the modalities of one body
+class Optimizer {
+ public:
+  Optimizer(ContextPtr c, const Body& body, const std::vector<const Modality*>& modalities,
+            float tikhonov_parameter_rotation = 1000.0f, float tikhonov_parameter_translation = 30000.0f)
+      : c_(std::move(c)) {
+    std::vector<int> ids;
+    for (auto* m : modalities) ids.push_back(m->id());
+    id_ = c_->Check(m3t_hip_optimizer_create_rigid(c_->get(), body.id(), int(ids.size()), ids.data(),
+                                                   tikhonov_parameter_rotation, tikhonov_parameter_translation),
+                    "Optimizer");
+  }
+  int id() const { return id_; }
+
+ private:
+  ContextPtr c_;
+  int id_;
+};
+
+// m3t::Tracker restricted to the tracking step (tracker.cpp:344-364, 430-517)
+class Tracker {
+ public:
+  Tracker(ContextPtr c, int n_corr_iterations = 5, int n_update_iterations = 2) : c_(std::move(c)) {
+    c_->Check(m3t_hip_tracker_set_iterations(c_->get(), n_corr_iterations, n_update_iterations), "Tracker");
+  }
+  bool StartModalities(int iteration) { return c_->Step(m3t_hip_start_modalities(c_->get(), iteration)); }
+  bool CalculateCorrespondences(int iteration, int corr_iteration) {
+    return c_->Step(m3t_hip_calculate_correspondences(c_->get(), iteration, corr_iteration));
+  }
+  bool CalculateGradientAndHessian(int iteration, int corr_iteration, int update_iteration) {
+    return c_->Step(m3t_hip_calculate_gradient_and_hessian(c_->get(), iteration, corr_iteration, update_iteration));
+  }
+  bool CalculateOptimization(int iteration, int corr_iteration, int update_iteration) {
+    return c_->Step(m3t_hip_calculate_optimization(c_->get(), iteration, corr_iteration, update_iteration));
+  }
+  bool CalculateResults(int iteration) { return c_->Step(m3t_hip_calculate_results(c_->get(), iteration)); }
+  bool ExecuteTrackingStep(int iteration) { return c_->Step(m3t_hip_execute_tracking_step(c_->get(), iteration)); }
+  bool ExecuteTrackingCycle(int iteration) { return c_->Step(m3t_hip_execute_tracking_cycle(c_->get(), iteration)); }
+  bool Sync() { return c_->Step(m3t_hip_sync(c_->get())); }
+
+ private:
+  ContextPtr c_;
+};
+
+}  // namespace m3t_hip
+#endif  // M3T_HIP_HPP_
