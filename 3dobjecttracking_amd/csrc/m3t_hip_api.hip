@@ -410,6 +410,10 @@ int UploadTables(Ctx* ctx) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_lds_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_occ2_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_lds_occ2_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_correspondence_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_corr)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_correspondence_lds_kernel),
@@ -1263,8 +1267,11 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   if (ctx->fused_mode >= 1 && ctx->fused_possible) {
     int n = int(ctx->opt_table.size());
     ScopedKernelTimer timer(ctx, 0);
-    hipLaunchKernelGGL(ctx->layout.off_hist >= 0 ? tracking_step_lds_kernel : tracking_step_kernel, dim3(n),
-                       dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
+    // more objects than CUs and two workgroups fit the LDS of a CU: use the 128-VGPR variants
+    const bool occ2 = n > ctx->prop.multiProcessorCount && ctx->lds_track * 2 <= 160 * 1024;
+    auto kernel = ctx->layout.off_hist >= 0 ? (occ2 ? tracking_step_lds_occ2_kernel : tracking_step_lds_kernel)
+                                            : (occ2 ? tracking_step_occ2_kernel : tracking_step_kernel);
+    hipLaunchKernelGGL(kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                        ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
                        ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,

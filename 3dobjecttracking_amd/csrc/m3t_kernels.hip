@@ -748,10 +748,22 @@ template <int N>
 __device__ void block_reduce(float (&v)[N], int n_active_waves, float* scratch, float* out /*LDS, N floats*/) {
   const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
   if (wave < n_active_waves) {
+    // level by level over all N values: N independent DPP adds per level fill the DPP wait states
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      float x = wave_sum_lane63(v[i]);
-      if (lane == kWave - 1) scratch[wave * N + i] = x;
+    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x111, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x112, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x114, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x118, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x142, 0xa>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x143, 0xc>(v[i]);
+    if (lane == kWave - 1) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) scratch[wave * N + i] = v[i];
     }
   }
   __syncthreads();
@@ -998,6 +1010,7 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
                                    float lambda_trans, float* pose /*16 col-major, in/out*/) {
   // Every index below is a compile-time constant after unrolling, so a/x stay in VGPRs
   // (a dynamically indexed local array would live in scratch memory: ~100x slower).
+  PHASE_T0();
   float a[36], x[6];
 #pragma unroll
   for (int i = 0; i < 36; ++i) a[i] = 0.0f;
@@ -1010,6 +1023,7 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
     x[i] = 0.0f + g_sum[i];
     a[i * 6 + i] += i < 3 ? lambda_rot : lambda_trans;
   }
+  PHASE_MARK(12);  // build A, b
   int trans[6] = {0, 1, 2, 3, 4, 5};
   bool degenerate = false;
 #pragma unroll
@@ -1063,6 +1077,7 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
       }
     }
   }
+  PHASE_MARK(13);  // LDLT factorisation
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
 #pragma unroll
@@ -1099,6 +1114,7 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
 #pragma unroll
   for (int i = 0; i < 6; ++i) has_nan |= (x[i] != x[i]);
   if (has_nan) return;
+  PHASE_MARK(14);  // triangular solves
   // exp(skew(theta_r)): Pade approximant with scaling and squaring like Eigen's
   // MatrixFunctions (link.cpp:224), operation for operation the oracle's Expm3.
   float K[9];  // column-major skew(theta_r), common.h:62-68
@@ -1107,6 +1123,7 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
   K[2] = -x[1]; K[5] = x[0];  K[8] = 0.0f;
   float R[9];
   expm3(K, R);
+  PHASE_MARK(15);  // expm
   Affine T = load_pose(pose), D;
 #pragma unroll
   for (int i = 0; i < 9; ++i) D.l[i] = R[i];
@@ -1710,6 +1727,25 @@ tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const D
 }
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_lds_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int sequential_sum) {
+  tracking_step_body<true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
+                            n_update_iterations, write_state, sequential_sum);
+}
+
+// throughput variants for batches larger than the CU count: registers capped at 128 so that two
+// workgroups share a CU and hide each other's dependent phases (some spilling in the solve)
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS, 4)
+tracking_step_occ2_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int sequential_sum) {
+  tracking_step_body<false>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
+                            n_update_iterations, write_state, sequential_sum);
+}
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS, 4)
+tracking_step_lds_occ2_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
                      int sequential_sum) {

@@ -218,7 +218,7 @@ class Scene:
     """One object with its own camera stream: background texture, colour means and GT trajectory."""
 
     def __init__(self, object_index, intr=RBOT_INTRINSICS, semi_axes=None, with_depth=False, depth_scale=1e-4,
-                 distance=(0.45, 0.75)):
+                 distance=(0.7, 0.9)):
         self.rng = np.random.default_rng(1000 + object_index)
         rng = self.rng
         self.intr = dict(intr)

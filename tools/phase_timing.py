@@ -24,7 +24,8 @@ for k in range(4, 8):
     inst.upload_frame(k); inst.tracker.ExecuteTrackingStep(k)
 f(hip.ctx, buf, 1)
 names = ["view search", "phase A (lines)", "phase B (pixels)", "phase C1 (dist)", "phase C2 (moments)", "g/H", "solve",
-         "  B: addr+issue", "  B: pixel wait", "  B: gather issue", "  B: gather wait", "  B: products"]
+         "  B: addr+issue", "  B: pixel wait", "  B: gather issue", "  B: gather wait", "  B: products",
+         "  solve: build", "  solve: LDLT", "  solve: trisolve", "  solve: expm"]
 tot = sum(buf[i] for i in range(7))
 for i, nme in enumerate(names):
     print("%-20s %10.0f cycles/frame  %5.1f%%" % (nme, buf[i] / n, 100.0 * buf[i] / tot))
