@@ -214,6 +214,11 @@ _SIGNATURES = {
     "optimizer_create_rigid": [C.c_int, C.c_int, c_int_p, C.c_float, C.c_float],
     "constraint_create": [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p],
     "link_get_link2world_pose": [C.c_int, c_float_p],
+    "link_set_joint_poses": [C.c_int, c_float_p, c_float_p],
+    "link_get_joint_poses": [C.c_int, c_float_p, c_float_p],
+    "calculate_consistent_poses": [],
+    "calculate_optimization_begin": [C.POINTER(c_float_p), C.POINTER(C.c_size_t)],
+    "calculate_optimization_end": [],
     "tracker_set_iterations": [C.c_int, C.c_int],
     "start_modalities": [C.c_int],
     "calculate_correspondences": [C.c_int, C.c_int],

@@ -16,6 +16,7 @@
 #include "../../include/m3t_hip.h"
 #include "m3t_device.h"
 #include "m3t_kernels.hip"
+#include "m3t_links.hip"
 
 namespace {
 
@@ -81,12 +82,26 @@ struct ModalityRef {
   int index;
 };
 struct Link {
-  int body;
-  std::vector<int> modalities;
+  int body = -1, parent = -1;
+  std::vector<int> children, modalities;
+  float body2joint[16], joint2parent[16], link2world[16];
+  int free_directions[6] = {1, 1, 1, 1, 1, 1};
+  int fixed_body2joint_pose = 1;
+  bool simple = true;  // free 6-dof root link with identity joint poses and a body
+  int optimizer = -1, local_index = -1;
+};
+struct ConstraintH {
+  int link1, link2;
+  float body12joint1[16], body22joint2[16];
+  int directions[6];
 };
 struct Optimizer {
   int link;
   float tr, tt;
+  std::vector<int> constraints;
+  std::vector<int> order;  // global link ids, depth first (parents before children)
+  int dof = 0, n_rows = 0;
+  size_t partial_offset = 0;
 };
 
 }  // namespace
@@ -103,7 +118,13 @@ struct m3t_hip_context {
   std::vector<std::unique_ptr<DepthMod>> depth_mods;
   std::vector<ModalityRef> modalities;
   std::vector<Link> links;
+  std::vector<ConstraintH> constraints;
   std::vector<Optimizer> optimizers;
+  bool tree_mode = false;          // any kinematic tree / constraint -> links_* kernels
+  bool links_device_newer = false;  // joint poses on the device are ahead of the host mirror
+  DevMem d_links, d_constraints, d_treeopts, d_work, d_partial;
+  size_t partial_count = 0;
+  bool partial_ready = false;
   int n_corr_iterations = 5, n_update_iterations = 2;
   int fused_mode = 1;
   int sequential_sum = 0;
@@ -342,6 +363,122 @@ void ComputeLayout(Ctx* ctx) {
   ctx->lds_hist = M3T_MISC_FLOATS * 4 + (ctx->hist_counts_in_lds ? counts : 0);
 }
 
+void DfsOrder(Ctx* ctx, int link, std::vector<int>* order) {
+  order->push_back(link);
+  for (int c : ctx->links[link].children) DfsOrder(ctx, c, order);
+}
+
+// device -> host mirror of the joint poses (after device-side UpdatePoses)
+int PullLinks(Ctx* ctx) {
+  if (!ctx->links_device_newer || !ctx->tree_mode) return M3T_OK;
+  size_t n = 0;
+  for (auto& o : ctx->optimizers) n += o.order.size();
+  std::vector<LinkDev> dev(n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n) HIPCHK(hipMemcpy(dev.data(), ctx->d_links.p, n * sizeof(LinkDev), hipMemcpyDeviceToHost));
+  size_t off = 0;
+  for (auto& o : ctx->optimizers)
+    for (int lid : o.order) {
+      Link& l = ctx->links[lid];
+      std::memcpy(l.body2joint, dev[off].body2joint, 64);
+      std::memcpy(l.joint2parent, dev[off].joint2parent, 64);
+      std::memcpy(l.link2world, dev[off].link2world, 64);
+      ++off;
+    }
+  ctx->links_device_newer = false;
+  return M3T_OK;
+}
+
+int UploadTreeTables(Ctx* ctx) {
+  int r = PullLinks(ctx);
+  if (r) return r;
+  std::vector<LinkDev> links;
+  std::vector<ConstraintDev> cons;
+  std::vector<TreeOptDev> opts(ctx->optimizers.size());
+  std::vector<size_t> link_off(ctx->optimizers.size()), con_off(ctx->optimizers.size()), work_off(ctx->optimizers.size());
+  size_t work_total = 0, partial_total = 0;
+  for (auto& l : ctx->links) { l.optimizer = -1; l.local_index = -1; }
+  for (size_t oi = 0; oi < ctx->optimizers.size(); ++oi) {
+    Optimizer& o = ctx->optimizers[oi];
+    o.order.clear();
+    DfsOrder(ctx, o.link, &o.order);
+    int dof = 0;
+    for (size_t k = 0; k < o.order.size(); ++k) {
+      Link& l = ctx->links[o.order[k]];
+      REQUIRE(l.optimizer < 0, M3T_ERR_INVALID_ARGUMENT, "a link belongs to two optimizers");
+      l.optimizer = int(oi);
+      l.local_index = int(k);
+    }
+    link_off[oi] = links.size();
+    for (int lid : o.order) {
+      const Link& l = ctx->links[lid];
+      LinkDev d{};
+      d.body = l.body;
+      d.parent = l.parent >= 0 ? ctx->links[l.parent].local_index : -1;
+      std::memcpy(d.body2joint, l.body2joint, 64);
+      std::memcpy(d.joint2parent, l.joint2parent, 64);
+      std::memcpy(d.link2world, l.link2world, 64);
+      for (int i = 0; i < 6; ++i) d.free_directions[i] = l.free_directions[i];
+      d.fixed_body2joint_pose = l.fixed_body2joint_pose;
+      d.first_jacobian_index = dof;  // optimizer.cpp:237-250
+      for (int i = 0; i < 6; ++i) dof += l.free_directions[i] ? 1 : 0;
+      REQUIRE(int(l.modalities.size()) <= M3T_MAX_LINK_MODALITIES, M3T_ERR_UNSUPPORTED, "too many modalities per link");
+      d.n_gh = int(l.modalities.size());
+      for (int k = 0; k < d.n_gh; ++k) {
+        const ModalityRef& ref = ctx->modalities[l.modalities[k]];
+        d.gh[k] = ref.region ? ctx->region_mods[ref.index]->gh.as<float>() : ctx->depth_mods[ref.index]->gh.as<float>();
+      }
+      links.push_back(d);
+    }
+    o.dof = dof;
+    con_off[oi] = cons.size();
+    o.n_rows = 0;
+    for (int cid : o.constraints) {
+      const ConstraintH& c = ctx->constraints[cid];
+      REQUIRE(ctx->links[c.link1].optimizer == int(oi) && ctx->links[c.link2].optimizer == int(oi),
+              M3T_ERR_INVALID_ARGUMENT, "constraint links must belong to the optimizer's structure");
+      ConstraintDev d{};
+      d.link1 = ctx->links[c.link1].local_index;
+      d.link2 = ctx->links[c.link2].local_index;
+      std::memcpy(d.body12joint1, c.body12joint1, 64);
+      std::memcpy(d.body22joint2, c.body22joint2, 64);
+      d.n = 0;
+      for (int i = 0; i < 6; ++i) { d.directions[i] = c.directions[i]; d.n += c.directions[i] ? 1 : 0; }
+      o.n_rows += d.n;
+      cons.push_back(d);
+    }
+    work_off[oi] = work_total;
+    work_total += tree_work_floats(int(o.order.size()), dof, o.n_rows);
+    o.partial_offset = partial_total;
+    partial_total += size_t(dof) * dof + dof;
+  }
+  HIPCHK(ctx->d_links.alloc(std::max<size_t>(1, links.size()) * sizeof(LinkDev)));
+  HIPCHK(ctx->d_constraints.alloc(std::max<size_t>(1, cons.size()) * sizeof(ConstraintDev)));
+  HIPCHK(ctx->d_treeopts.alloc(std::max<size_t>(1, opts.size()) * sizeof(TreeOptDev)));
+  HIPCHK(ctx->d_work.alloc(std::max<size_t>(1, work_total) * 4));
+  HIPCHK(ctx->d_partial.alloc(std::max<size_t>(1, partial_total) * 4));
+  HIPCHK(hipMemset(ctx->d_partial.p, 0, ctx->d_partial.bytes));
+  ctx->partial_count = partial_total;
+  for (size_t oi = 0; oi < opts.size(); ++oi) {
+    const Optimizer& o = ctx->optimizers[oi];
+    TreeOptDev& d = opts[oi];
+    d.n_links = int(o.order.size());
+    d.links = ctx->d_links.as<LinkDev>() + link_off[oi];
+    d.dof = o.dof;
+    d.n_constraints = int(o.constraints.size());
+    d.constraints = ctx->d_constraints.as<ConstraintDev>() + con_off[oi];
+    d.n_rows = o.n_rows;
+    d.tikhonov_rotation = o.tr;
+    d.tikhonov_translation = o.tt;
+    d.work = ctx->d_work.as<float>() + work_off[oi];
+    d.partial = ctx->d_partial.as<float>() + o.partial_offset;
+  }
+  if (!links.empty()) HIPCHK(hipMemcpy(ctx->d_links.p, links.data(), links.size() * sizeof(LinkDev), hipMemcpyHostToDevice));
+  if (!cons.empty()) HIPCHK(hipMemcpy(ctx->d_constraints.p, cons.data(), cons.size() * sizeof(ConstraintDev), hipMemcpyHostToDevice));
+  if (!opts.empty()) HIPCHK(hipMemcpy(ctx->d_treeopts.p, opts.data(), opts.size() * sizeof(TreeOptDev), hipMemcpyHostToDevice));
+  return M3T_OK;
+}
+
 int UploadTables(Ctx* ctx) {
   if (ctx->cams_dirty || ctx->tables_dirty) {
     std::vector<CameraDev> cams(ctx->cameras.size());
@@ -373,11 +510,21 @@ int UploadTables(Ctx* ctx) {
     HIPCHK(ctx->d_depth.alloc(std::max<size_t>(1, d.size()) * sizeof(DepthModDev)));
     if (!r.empty()) HIPCHK(hipMemcpy(ctx->d_region.p, r.data(), r.size() * sizeof(RegionModDev), hipMemcpyHostToDevice));
     if (!d.empty()) HIPCHK(hipMemcpy(ctx->d_depth.p, d.data(), d.size() * sizeof(DepthModDev), hipMemcpyHostToDevice));
+    // kinematic structures (m3t_links.hip) as soon as one optimizer is more than a free rigid body
+    ctx->tree_mode = false;
+    for (auto& o : ctx->optimizers)
+      if (!ctx->links[o.link].simple || !ctx->links[o.link].children.empty() || !o.constraints.empty())
+        ctx->tree_mode = true;
+    if (ctx->tree_mode) {
+      int r = UploadTreeTables(ctx);
+      if (r) return r;
+    }
     // optimizer table
     ctx->opt_table.clear();
-    ctx->fused_possible = !ctx->optimizers.empty();
+    ctx->fused_possible = !ctx->optimizers.empty() && !ctx->tree_mode;
     std::vector<char> body_used(ctx->body_poses.size() / 16, 0);
     for (auto& o : ctx->optimizers) {
+      if (ctx->tree_mode) break;
       const Link& l = ctx->links[o.link];
       RigidOptDev od{};
       od.body = l.body;
@@ -526,7 +673,32 @@ int LaunchGradientHessian(Ctx* ctx, int corr_iteration, int opt_iteration) {
   return M3T_OK;
 }
 
+int LaunchProject(Ctx* ctx) {
+  int n = int(ctx->optimizers.size());
+  if (n == 0) return M3T_OK;
+  hipLaunchKernelGGL(links_project_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
+                     ctx->d_treeopts.as<TreeOptDev>(), n, ctx->d_poses.as<float>());
+  HIPCHK(hipGetLastError());
+  ctx->partial_ready = true;
+  return M3T_OK;
+}
+int LaunchSolve(Ctx* ctx, bool zero_theta) {
+  int n = int(ctx->optimizers.size());
+  if (n == 0) return M3T_OK;
+  hipLaunchKernelGGL(links_solve_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
+                     ctx->d_treeopts.as<TreeOptDev>(), n, ctx->d_poses.as<float>(), zero_theta ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  ctx->links_device_newer = true;
+  ctx->partial_ready = false;
+  return M3T_OK;
+}
+
 int LaunchOptimization(Ctx* ctx) {
+  if (ctx->tree_mode) {
+    int r = LaunchProject(ctx);
+    if (r) return r;
+    return LaunchSolve(ctx, false);
+  }
   int n = int(ctx->opt_table.size());
   if (n == 0) return M3T_OK;
   hipLaunchKernelGGL(rigid_optimize_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
@@ -1145,19 +1317,42 @@ static bool IsIdentity(const float* p) {
   static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   return std::memcmp(p, ident, 64) == 0;
 }
+static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+
+// m3t::Link (link.h:67): body may be -1 (pure joint), parent -1 = root
 int m3t_hip_link_create(m3t_hip_context* ctx, int body, int parent, const float body2joint[16],
-                        const float joint2parent[16], const int free_directions[6], int) {
+                        const float joint2parent[16], const int free_directions[6], int fixed_body2joint_pose) {
   CHECK_CTX();
-  REQUIRE(body >= 0 && body < int(ctx->body_poses.size() / 16), M3T_ERR_UNSUPPORTED,
-          "links without a body are part of the multi-body row (not supported yet)");
+  REQUIRE(body >= -1 && body < int(ctx->body_poses.size() / 16), M3T_ERR_INVALID_ARGUMENT, "bad body id");
+  REQUIRE(parent >= -1 && parent < int(ctx->links.size()), M3T_ERR_INVALID_ARGUMENT, "bad parent link id");
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = PullLinks(ctx);
+  if (r) return r;
+  Link l;
+  l.body = body;
+  l.parent = parent;
+  std::memcpy(l.body2joint, body2joint ? body2joint : kIdentity, 64);
+  std::memcpy(l.joint2parent, joint2parent ? joint2parent : kIdentity, 64);
+  if (body >= 0) {
+    r = SyncPosesToHost(ctx);
+    if (r) return r;
+    std::memcpy(l.link2world, &ctx->body_poses[size_t(body) * 16], 64);
+  } else {
+    std::memcpy(l.link2world, kIdentity, 64);
+  }
   bool all_free = true;
   if (free_directions)
-    for (int i = 0; i < 6; ++i) all_free &= free_directions[i] != 0;
-  REQUIRE(parent < 0 && IsIdentity(body2joint) && IsIdentity(joint2parent) && all_free, M3T_ERR_UNSUPPORTED,
-          "kinematic trees (child links, partial joints, body2joint != I) are not supported yet");
-  ctx->links.push_back(Link{body, {}});
+    for (int i = 0; i < 6; ++i) {
+      l.free_directions[i] = free_directions[i] != 0;
+      all_free &= free_directions[i] != 0;
+    }
+  l.fixed_body2joint_pose = fixed_body2joint_pose != 0;
+  l.simple = body >= 0 && parent < 0 && IsIdentity(body2joint) && IsIdentity(joint2parent) && all_free;
+  ctx->links.push_back(l);
+  int id = int(ctx->links.size()) - 1;
+  if (parent >= 0) ctx->links[parent].children.push_back(id);
   ctx->tables_dirty = true;
-  return int(ctx->links.size()) - 1;
+  return id;
 }
 int m3t_hip_link_add_modality(m3t_hip_context* ctx, int link, int modality) {
   CHECK_CTX();
@@ -1166,9 +1361,6 @@ int m3t_hip_link_add_modality(m3t_hip_context* ctx, int link, int modality) {
   const ModalityRef& ref = ctx->modalities[modality];
   int mbody = ref.region ? ctx->region_mods[ref.index]->body : ctx->depth_mods[ref.index]->body;
   REQUIRE(mbody == ctx->links[link].body, M3T_ERR_INVALID_ARGUMENT, "modality and link refer to different bodies");
-  for (int mid : ctx->links[link].modalities)
-    REQUIRE(ctx->modalities[mid].region != ref.region, M3T_ERR_UNSUPPORTED,
-            "at most one region and one depth modality per link");
   ctx->links[link].modalities.push_back(modality);
   ctx->tables_dirty = true;
   return M3T_OK;
@@ -1176,12 +1368,17 @@ int m3t_hip_link_add_modality(m3t_hip_context* ctx, int link, int modality) {
 int m3t_hip_optimizer_create(m3t_hip_context* ctx, int root_link, float tr, float tt) {
   CHECK_CTX();
   REQUIRE(root_link >= 0 && root_link < int(ctx->links.size()), M3T_ERR_INVALID_ARGUMENT, "bad root link");
-  ctx->optimizers.push_back(Optimizer{root_link, tr, tt});
+  Optimizer o;
+  o.link = root_link;
+  o.tr = tr;
+  o.tt = tt;
+  ctx->optimizers.push_back(o);
   ctx->tables_dirty = true;
   return int(ctx->optimizers.size()) - 1;
 }
 int m3t_hip_optimizer_create_rigid(m3t_hip_context* ctx, int body, int n, const int* mids, float tr, float tt) {
   CHECK_CTX();
+  REQUIRE(body >= 0, M3T_ERR_INVALID_ARGUMENT, "bad body id");
   int link = m3t_hip_link_create(ctx, body, -1, nullptr, nullptr, nullptr, 1);
   if (link < 0) return link;
   for (int i = 0; i < n; ++i) {
@@ -1190,14 +1387,57 @@ int m3t_hip_optimizer_create_rigid(m3t_hip_context* ctx, int body, int n, const 
   }
   return m3t_hip_optimizer_create(ctx, link, tr, tt);
 }
-int m3t_hip_constraint_create(m3t_hip_context* ctx, int, int, int, const float*, const float*, const int*) {
+// m3t::Constraint (constraint.h): hard constraint between two links of one structure
+int m3t_hip_constraint_create(m3t_hip_context* ctx, int optimizer, int link1, int link2, const float b1[16],
+                              const float b2[16], const int dirs[6]) {
   CHECK_CTX();
-  return Fail(ctx, M3T_ERR_UNSUPPORTED, "constraints are part of the multi-body row (not supported yet)");
+  REQUIRE(optimizer >= 0 && optimizer < int(ctx->optimizers.size()) && link1 >= 0 && link2 >= 0 &&
+              link1 < int(ctx->links.size()) && link2 < int(ctx->links.size()) && dirs,
+          M3T_ERR_INVALID_ARGUMENT, "bad constraint arguments");
+  ConstraintH c;
+  c.link1 = link1;
+  c.link2 = link2;
+  std::memcpy(c.body12joint1, b1 ? b1 : kIdentity, 64);
+  std::memcpy(c.body22joint2, b2 ? b2 : kIdentity, 64);
+  for (int i = 0; i < 6; ++i) c.directions[i] = dirs[i] != 0;
+  ctx->constraints.push_back(c);
+  ctx->optimizers[optimizer].constraints.push_back(int(ctx->constraints.size()) - 1);
+  ctx->tables_dirty = true;
+  return int(ctx->constraints.size()) - 1;
 }
 int m3t_hip_link_get_link2world_pose(m3t_hip_context* ctx, int link, float pose[16]) {
   CHECK_CTX();
+  REQUIRE(link >= 0 && link < int(ctx->links.size()) && pose, M3T_ERR_INVALID_ARGUMENT, "bad link id");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->links[link].body >= 0) return m3t_hip_body_get_body2world_pose(ctx, ctx->links[link].body, pose);
+  int r = PullLinks(ctx);
+  if (r) return r;
+  std::memcpy(pose, ctx->links[link].link2world, 64);
+  return M3T_OK;
+}
+int m3t_hip_link_set_joint_poses(m3t_hip_context* ctx, int link, const float body2joint[16],
+                                 const float joint2parent[16]) {
+  CHECK_CTX();
   REQUIRE(link >= 0 && link < int(ctx->links.size()), M3T_ERR_INVALID_ARGUMENT, "bad link id");
-  return m3t_hip_body_get_body2world_pose(ctx, ctx->links[link].body, pose);
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = PullLinks(ctx);
+  if (r) return r;
+  Link& l = ctx->links[link];
+  if (body2joint) std::memcpy(l.body2joint, body2joint, 64);
+  if (joint2parent) std::memcpy(l.joint2parent, joint2parent, 64);
+  if (!IsIdentity(l.body2joint) || !IsIdentity(l.joint2parent)) l.simple = false;
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
+int m3t_hip_link_get_joint_poses(m3t_hip_context* ctx, int link, float body2joint[16], float joint2parent[16]) {
+  CHECK_CTX();
+  REQUIRE(link >= 0 && link < int(ctx->links.size()), M3T_ERR_INVALID_ARGUMENT, "bad link id");
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = PullLinks(ctx);
+  if (r) return r;
+  if (body2joint) std::memcpy(body2joint, ctx->links[link].body2joint, 64);
+  if (joint2parent) std::memcpy(joint2parent, ctx->links[link].joint2parent, 64);
+  return M3T_OK;
 }
 
 // ---- tracker sub-steps -------------------------------------------------------------------
@@ -1250,6 +1490,41 @@ int m3t_hip_calculate_optimization(m3t_hip_context* ctx, int, int, int) {
   int r = Prepare(ctx, false);
   if (r) return r;
   return LaunchOptimization(ctx);
+}
+// Optimizer::CalculateOptimization split at the multi-GPU exchange point: *partial is a
+// DEVICE pointer to `count` floats (the stacked [dof*dof | dof] sums of every structure); sum it over the
+// ranks that hold bodies of the structures (one RCCL all-reduce on the context stream), then call _end.
+int m3t_hip_calculate_optimization_begin(m3t_hip_context* ctx, float** partial, size_t* count) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = Prepare(ctx, false);
+  if (r) return r;
+  if (!ctx->tree_mode) {  // rigid bodies only: force the general path so that the sums exist
+    ctx->tree_mode = true;
+    ctx->fused_possible = false;
+    r = UploadTreeTables(ctx);
+    if (r) return r;
+  }
+  r = LaunchProject(ctx);
+  if (r) return r;
+  if (partial) *partial = ctx->d_partial.as<float>();
+  if (count) *count = ctx->partial_count;
+  return M3T_OK;
+}
+int m3t_hip_calculate_optimization_end(m3t_hip_context* ctx) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  REQUIRE(ctx->partial_ready, M3T_ERR_NOT_SET_UP, "calculate_optimization_begin has to be called first");
+  return LaunchSolve(ctx, false);
+}
+// Tracker::CalculateConsistentPoses tracker.cpp:423 -> Optimizer::CalculateConsistentPoses optimizer.cpp:135
+int m3t_hip_calculate_consistent_poses(m3t_hip_context* ctx) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = Prepare(ctx, false);
+  if (r) return r;
+  if (!ctx->tree_mode) return M3T_OK;  // T * [I | 0] == T exactly for a free rigid body
+  return LaunchSolve(ctx, true);
 }
 int m3t_hip_calculate_results(m3t_hip_context* ctx, int iteration) {
   CHECK_CTX();

@@ -52,6 +52,20 @@ class Tracker:
     def CalculateResults(self, iteration):
         return self._step("calculate_results", iteration)
 
+    def CalculateConsistentPoses(self):
+        return self._step("calculate_consistent_poses")
+
+    def CalculateOptimizationBegin(self):
+        """first half of CalculateOptimization: this process's stacked [dof*dof | dof] sums.
+        Returns (pointer, count); device pointer for the HIP library, host pointer for the oracle."""
+        ptr = _capi.c_float_p()
+        n = C.c_size_t()
+        self.api.call("calculate_optimization_begin", C.byref(ptr), C.byref(n))
+        return ptr, n.value
+
+    def CalculateOptimizationEnd(self):
+        return self._step("calculate_optimization_end")
+
     def ExecuteTrackingStep(self, iteration):
         return self._step("execute_tracking_step", iteration)
 
@@ -242,6 +256,22 @@ class Link:
     def link2world_pose(self):
         buf = np.zeros(16, np.float32)
         self.api.call("link_get_link2world_pose", self.id, fptr(buf))
+        return pose_ret(buf)
+
+    def set_body2joint_pose(self, pose):
+        self.api.call("link_set_joint_poses", self.id, fptr(pose_arg(pose)), None)
+
+    def set_joint2parent_pose(self, pose):
+        self.api.call("link_set_joint_poses", self.id, None, fptr(pose_arg(pose)))
+
+    def body2joint_pose(self):
+        buf = np.zeros(16, np.float32)
+        self.api.call("link_get_joint_poses", self.id, fptr(buf), None)
+        return pose_ret(buf)
+
+    def joint2parent_pose(self):
+        buf = np.zeros(16, np.float32)
+        self.api.call("link_get_joint_poses", self.id, None, fptr(buf))
         return pose_ret(buf)
 
 

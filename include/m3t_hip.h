@@ -111,10 +111,10 @@ int m3t_hip_region_modality_get_histograms(m3t_hip_context*, int modality_id, fl
 int m3t_hip_region_modality_set_histograms(m3t_hip_context*, int modality_id, const float* histogram_f,
                                            const float* histogram_b);
 
-/* ---- Links / Optimizers (link.h:67, optimizer.h:48, constraint.h) -----------------
- * Round 1: the device solve covers one free 6-dof root link per optimizer (every
- * RBOT / YCB configuration).  Kinematic trees and constraints return
- * M3T_ERR_UNSUPPORTED until the multi-body row lands. */
+/* ---- Links / Optimizers / Constraints (link.h:67, optimizer.h:48, constraint.h) -----
+ * A free 6-dof root link per body (every RBOT / YCB configuration) takes the fused
+ * rigid path; kinematic trees (child links, partial joints, links without body) and hard
+ * constraints run through the general device path (m3t_links.hip).  body_id / parent may be -1. */
 int m3t_hip_link_create(m3t_hip_context*, int body_id, int parent_link_id, const float body2joint[16],
                         const float joint2parent[16], const int free_directions[6],
                         int fixed_body2joint_pose);
@@ -127,6 +127,10 @@ int m3t_hip_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, 
                               const float body12joint1[16], const float body22joint2[16],
                               const int constraint_directions[6]);
 int m3t_hip_link_get_link2world_pose(m3t_hip_context*, int link_id, float pose[16]);
+/* Link::set_body2joint_pose / set_joint2parent_pose (either may be NULL) and the getters */
+int m3t_hip_link_set_joint_poses(m3t_hip_context*, int link_id, const float body2joint[16],
+                                 const float joint2parent[16]);
+int m3t_hip_link_get_joint_poses(m3t_hip_context*, int link_id, float body2joint[16], float joint2parent[16]);
 
 /* ---- Tracker sub-steps (tracker.h:131-160; tracker.cpp:344-364, 430-517) -----------
  * Same names, arguments and order as the reference's public Tracker methods. */
@@ -137,6 +141,15 @@ int m3t_hip_calculate_gradient_and_hessian(m3t_hip_context*, int iteration, int 
                                            int opt_iteration);                    /* :471 */
 int m3t_hip_calculate_optimization(m3t_hip_context*, int iteration, int corr_iteration,
                                    int opt_iteration);                            /* :481 */
+/* Optimizer::CalculateOptimization split where a kinematic structure spread over several GPUs
+ * exchanges data: begin() leaves this process's stacked sums  [J^T H J (dof x dof) | J^T g (dof)]
+ * of every structure in ONE contiguous device buffer (*partial, `count` floats); the host sums that
+ * buffer over the participating ranks with a single all-reduce (ncclAllReduce / torch.distributed
+ * on RCCL, on the stream of m3t_hip_get_stream) and calls end(), which adds constraint rows and the
+ * Tikhonov diagonal, solves and updates the poses identically on every rank. */
+int m3t_hip_calculate_optimization_begin(m3t_hip_context*, float** partial, size_t* count);
+int m3t_hip_calculate_optimization_end(m3t_hip_context*);
+int m3t_hip_calculate_consistent_poses(m3t_hip_context*); /* tracker.cpp:423, optimizer.cpp:135 */
 int m3t_hip_calculate_results(m3t_hip_context*, int iteration);                    /* :503 */
 /* Tracker::ExecuteTrackingStep (M3T tracker.cpp:344) == Tracker::ExecuteTrackingCycle
  * (ICG tracker.cpp:247): the whole loop nest on the device, two launches per frame. */

@@ -671,6 +671,7 @@ struct Optimizer {
   int degrees_of_freedom = 0;
   std::vector<float> tikhonov_vector;
   std::vector<int> constraints;
+  std::vector<float> partial;  // [dof*dof | dof] of the last Begin
 };
 
 struct Context {
@@ -682,6 +683,7 @@ struct Context {
   std::vector<Link> links;
   std::vector<Constraint> constraints;
   std::vector<Optimizer> optimizers;
+  std::vector<float> partial_all;  // concatenated partial sums of all optimizers
   int n_corr_iterations = 5, n_update_iterations = 2;  // tracker.h:231-232
 
   const Mat4& LinkPose(const Link& l) const {  // Link::link2world_pose() link.cpp:296-301
@@ -1577,16 +1579,30 @@ void AddProjected(Context* ctx, int link_id, int dof, int size, std::vector<floa
   for (int c : l.children) AddProjected(ctx, c, dof, size, b, a);
 }
 
-// Optimizer::CalculateOptimization src/optimizer.cpp:144-167
-bool OptimizerCalculateOptimization(Context* ctx, Optimizer& o) {
+// Optimizer::CalculateOptimization src/optimizer.cpp:144-167, split at the point where a
+// kinematic structure spread over several GPUs exchanges data: Begin computes
+// this process's projected sums  A_p = sum J^T H J (dof x dof, lower), b_p = sum J^T g;
+// End adds the constraint rows and the Tikhonov diagonal, solves and updates the poses.
+// Single process: Begin + End == the reference function, operation for operation.
+void OptimizerBegin(Context* ctx, Optimizer& o) {
+  int dof = o.degrees_of_freedom;
+  o.partial.assign(size_t(dof) * dof + dof, 0.0f);
+  std::vector<float> b(dof, 0.0f), a(size_t(dof) * dof, 0.0f);
+  CalculateDataLinks(ctx, o.root_link);
+  AddProjected(ctx, o.root_link, dof, dof, &b, &a);
+  std::copy(a.begin(), a.end(), o.partial.begin());
+  std::copy(b.begin(), b.end(), o.partial.begin() + size_t(dof) * dof);
+}
+bool OptimizerEnd(Context* ctx, Optimizer& o) {
   int dof = o.degrees_of_freedom;
   int n_constraints = 0;
   for (int cid : o.constraints) n_constraints += ctx->constraints[cid].NumberOfConstraints();
   int size = dof + n_constraints;
   std::vector<float> b(size, 0.0f), a(size_t(size) * size, 0.0f);
-  CalculateDataLinks(ctx, o.root_link);
+  for (int c = 0; c < dof; ++c)
+    for (int r = 0; r < dof; ++r) a[size_t(c) * size + r] = o.partial[size_t(c) * dof + r];
+  for (int i = 0; i < dof; ++i) b[i] = o.partial[size_t(dof) * dof + i];
   for (int cid : o.constraints) ConstraintCalculate(ctx, ctx->constraints[cid], dof);
-  AddProjected(ctx, o.root_link, dof, size, &b, &a);
   int idx = dof;  // AddResidualsAndConstraintJacobians :323-333
   for (int cid : o.constraints) {
     const Constraint& c = ctx->constraints[cid];
@@ -1603,6 +1619,10 @@ bool OptimizerCalculateOptimization(Context* ctx, Optimizer& o) {
     if (std::isnan(t)) return true;  // theta.array().isNaN().isZero() guard
   UpdatePosesRecursive(ctx, o.root_link, theta);
   return true;
+}
+bool OptimizerCalculateOptimization(Context* ctx, Optimizer& o) {
+  OptimizerBegin(ctx, o);
+  return OptimizerEnd(ctx, o);
 }
 
 void SetError(Context* c, const std::string& e) { c->error = e; }
@@ -1897,6 +1917,30 @@ int m3t_oracle_link_get_link2world_pose(m3t_oracle_context* ctx, int link, float
   return M3T_OK;
 }
 
+int m3t_oracle_link_set_joint_poses(m3t_oracle_context* ctx, int link, const float body2joint[16],
+                                    const float joint2parent[16]) {
+  CHECK_CTX();
+  if (link < 0 || link >= int(CTX->links.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad link id");
+  if (body2joint) CTX->links[link].body2joint = FromArray(body2joint);
+  if (joint2parent) CTX->links[link].joint2parent = FromArray(joint2parent);
+  return M3T_OK;
+}
+int m3t_oracle_link_get_joint_poses(m3t_oracle_context* ctx, int link, float body2joint[16], float joint2parent[16]) {
+  CHECK_CTX();
+  if (link < 0 || link >= int(CTX->links.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad link id");
+  if (body2joint) std::memcpy(body2joint, CTX->links[link].body2joint.m, 64);
+  if (joint2parent) std::memcpy(joint2parent, CTX->links[link].joint2parent.m, 64);
+  return M3T_OK;
+}
+// Tracker::CalculateConsistentPoses tracker.cpp:423 -> Optimizer::CalculateConsistentPoses optimizer.cpp:135
+int m3t_oracle_calculate_consistent_poses(m3t_oracle_context* ctx) {
+  CHECK_CTX();
+  for (auto& o : CTX->optimizers) {
+    std::vector<float> theta(o.degrees_of_freedom, 0.0f);
+    UpdatePosesRecursive(CTX, o.root_link, theta);
+  }
+  return M3T_OK;
+}
 int m3t_oracle_tracker_set_iterations(m3t_oracle_context* ctx, int n_corr, int n_update) {
   CHECK_CTX();
   if (n_corr < 0 || n_update < 0) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad iteration counts");
@@ -1945,6 +1989,28 @@ int m3t_oracle_calculate_gradient_and_hessian(m3t_oracle_context* ctx, int itera
 int m3t_oracle_calculate_optimization(m3t_oracle_context* ctx, int, int, int) {
   CHECK_CTX();
   for (auto& o : CTX->optimizers) OptimizerCalculateOptimization(CTX, o);
+  return M3T_OK;
+}
+int m3t_oracle_calculate_optimization_begin(m3t_oracle_context* ctx, float** partial, size_t* count) {
+  CHECK_CTX();
+  CTX->partial_all.clear();
+  for (auto& o : CTX->optimizers) {
+    OptimizerBegin(CTX, o);
+    CTX->partial_all.insert(CTX->partial_all.end(), o.partial.begin(), o.partial.end());
+  }
+  if (partial) *partial = CTX->partial_all.data();
+  if (count) *count = CTX->partial_all.size();
+  return M3T_OK;
+}
+int m3t_oracle_calculate_optimization_end(m3t_oracle_context* ctx) {
+  CHECK_CTX();
+  size_t off = 0;
+  for (auto& o : CTX->optimizers) {
+    if (off + o.partial.size() > CTX->partial_all.size()) FAIL(M3T_ERR_NOT_SET_UP, "calculate_optimization_begin first");
+    std::copy(CTX->partial_all.begin() + off, CTX->partial_all.begin() + off + o.partial.size(), o.partial.begin());
+    off += o.partial.size();
+    OptimizerEnd(CTX, o);
+  }
   return M3T_OK;
 }
 // Tracker::CalculateResults src/tracker.cpp:503-517

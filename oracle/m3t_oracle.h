@@ -83,6 +83,10 @@ int m3t_oracle_constraint_create(m3t_oracle_context*, int optimizer_id, int link
                                  const float body12joint1[16], const float body22joint2[16],
                                  const int constraint_directions[6]);
 int m3t_oracle_link_get_link2world_pose(m3t_oracle_context*, int link_id, float pose[16]);
+int m3t_oracle_link_set_joint_poses(m3t_oracle_context*, int link_id, const float body2joint[16],
+                                    const float joint2parent[16]); /* either may be NULL */
+int m3t_oracle_link_get_joint_poses(m3t_oracle_context*, int link_id, float body2joint[16], float joint2parent[16]);
+int m3t_oracle_calculate_consistent_poses(m3t_oracle_context*); /* tracker.cpp:423, optimizer.cpp:135 */
 
 /* tracker (tracker.h:131-160, tracker.cpp:344-517) */
 int m3t_oracle_tracker_set_iterations(m3t_oracle_context*, int n_corr_iterations, int n_update_iterations);
@@ -92,6 +96,10 @@ int m3t_oracle_calculate_gradient_and_hessian(m3t_oracle_context*, int iteration
                                               int opt_iteration);
 int m3t_oracle_calculate_optimization(m3t_oracle_context*, int iteration, int corr_iteration,
                                       int opt_iteration);
+/* the same optimisation split where a kinematic structure spread over GPUs all-reduces its
+ * stacked [dof*dof | dof] sums: begin -> (sum `partial` over ranks) -> end */
+int m3t_oracle_calculate_optimization_begin(m3t_oracle_context*, float** partial, size_t* count);
+int m3t_oracle_calculate_optimization_end(m3t_oracle_context*);
 int m3t_oracle_calculate_results(m3t_oracle_context*, int iteration);
 int m3t_oracle_execute_tracking_step(m3t_oracle_context*, int iteration);
 int m3t_oracle_execute_tracking_cycle(m3t_oracle_context*, int iteration); /* ICG name */

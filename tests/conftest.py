@@ -16,3 +16,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def pkg():
     return importlib.import_module("3dobjecttracking_amd")
+
+
+def pytest_sessionstart(session):
+    """On a GPU box initialise torch's HIP runtime BEFORE libm3t_hip.so loads /opt/rocm's: torch
+    bundles its own libamdhip64 and reports "no GPUs" if it comes second (the RCCL test needs it)."""
+    if os.path.exists("/dev/kfd"):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass

@@ -1,0 +1,166 @@
+"""Kinematic structures on the device (m3t_links.hip) against the oracle: Link tree with a 1-dof
+joint tracked by two RegionModalities, hard constraints (constraint_convergence.cpp), and the
+begin -> all-reduce -> end split of Optimizer::CalculateOptimization with RCCL (world size 1)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+import util
+from test_multibody_oracle import build, random_pose, run_convergence
+from util import host, syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_constraint_convergence_on_device(seed):
+    errs_h, poses_h = run_convergence(util.open_hip(), seed)
+    errs_o, poses_o = run_convergence(util.open_oracle(), seed)
+    assert errs_h[-1][0] < 2e-5 and errs_h[-1][1] < 2e-5
+    for ph, po in zip(poses_h, poses_o):  # atan2f / tan differ in the last bit between libm and ocml
+        for a, b in zip(ph, po):
+            assert np.max(np.abs(a - b)) < 2e-5
+
+
+class Chain:
+    """body A (free root) -- revolute joint about the joint z axis -- body B, one camera each"""
+
+    def __init__(self, api, inputs, joint2parent, start_a, start_angle):
+        rp = dict(syn.RBOT_REGION_PARAMS)
+        self.api = api
+        self.models = [host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
+                       for m in inputs.region_models]
+        self.bodies = [host.Body(api, np.eye(4)), host.Body(api, np.eye(4))]
+        self.cams = [host.ColorCamera(api, **inputs.intr) for _ in range(2)]
+        self.mods = [host.RegionModality(api, self.bodies[i], self.cams[i], self.models[i], **rp) for i in range(2)]
+        self.link_a = host.Link(api, body=self.bodies[0])
+        self.link_b = host.Link(api, body=self.bodies[1], parent=self.link_a,
+                                joint2parent_pose=joint2parent @ syn.make_pose(syn.rot_vec([0, 0, start_angle]), [0, 0, 0]),
+                                free_directions=(0, 0, 1, 0, 0, 0))
+        self.link_a.AddModality(self.mods[0])
+        self.link_b.AddModality(self.mods[1])
+        self.opt = host.Optimizer(api, root_link=self.link_a)
+        self.tracker = host.Tracker(api, 7, 2)
+        self.bodies[0].set_body2world_pose(start_a)
+        assert self.tracker.CalculateConsistentPoses()  # body B follows from the joint
+
+    def upload(self, inputs, k):
+        for i in range(2):
+            self.cams[i].UpdateImage(inputs.color[i][k])
+
+    def state(self):
+        return [b.body2world_pose() for b in self.bodies] + [self.link_b.joint2parent_pose()]
+
+
+def chain_inputs(n_frames=4):
+    inputs = scenes.Inputs(2, 1, n_divides=2)
+    rng = np.random.default_rng(11)
+    joint2parent = syn.make_pose(syn.rot_vec([0.3, -0.2, 0.1]), [0.16, 0.02, 0.0])
+    pose_a = inputs.gt[0][0].copy()
+    gt, angle = [], 0.2
+    inputs.color = [[], []]
+    for k in range(n_frames):
+        pose_a = syn.perturb_pose(pose_a, rng, rot_deg=0.7, trans=0.002)
+        angle += rng.uniform(-0.03, 0.03)
+        pose_b = pose_a @ joint2parent @ syn.make_pose(syn.rot_vec([0, 0, angle]), [0, 0, 0])
+        gt.append((pose_a.copy(), pose_b.copy(), angle))
+        inputs.color[0].append(inputs.scenes[0].render(pose_a))
+        inputs.color[1].append(inputs.scenes[1].render(pose_b))
+    return inputs, joint2parent, gt
+
+
+def test_kinematic_chain_tracking_matches_oracle():
+    inputs, joint2parent, gt = chain_inputs()
+    start_a = syn.perturb_pose(gt[0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
+    results = {}
+    for name, api in (("hip", util.open_hip()), ("oracle", util.open_oracle())):
+        if name == "hip":
+            api.call("set_summation_mode", 1)
+        ch = Chain(api, inputs, joint2parent, start_a, gt[0][2] + 0.01)
+        ch.upload(inputs, 0)
+        assert ch.tracker.StartModalities(0)
+        states = []
+        for k in range(len(gt)):
+            ch.upload(inputs, k)
+            assert ch.tracker.ExecuteTrackingStep(k)
+            states.append(ch.state())
+        results[name] = states
+        # the joint keeps the structure consistent: B == A * joint2parent (body2joint = I)
+        a, b, j = states[-1]
+        assert np.max(np.abs(a.astype(np.float64) @ j.astype(np.float64) - b)) < 1e-5
+        # and the tracker follows the ground truth of both bodies
+        assert syn.pose_errors(b, gt[-1][1])[1] < 0.05
+    # a pure tree uses + - * / only: with the reference's summation order the device is bit-exact
+    for sh, so in zip(results["hip"], results["oracle"]):
+        for x, y in zip(sh, so):
+            assert np.array_equal(x, y)
+
+
+def test_begin_allreduce_end_with_rccl_world1():
+    """the multi-GPU split: begin() exposes one device buffer, torch.distributed (RCCL) sums it,
+    end() solves; with world size 1 the result equals the single call bit for bit"""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        out = []
+        for split in (False, True):
+            rng = np.random.default_rng(3)
+            api = util.open_hip()
+            b1, b2 = random_pose(rng), random_pose(rng)
+            link1, link2, opt = build(api, b1, b2, directions=(1, 1, 0, 1, 1, 1))
+            d = random_pose(rng)
+            d[:3, :3] = syn.rot_vec(rng.normal(size=3) * 0.3)
+            link2.set_joint2parent_pose(np.linalg.inv(b1) @ d)
+            tracker = host.Tracker(api, 1, 1)
+            assert tracker.CalculateConsistentPoses()
+            stream_ptr = C.c_void_p()
+            api.call("get_stream", C.byref(stream_ptr))
+            ext = torch.cuda.ExternalStream(stream_ptr.value)
+            for it in range(3):
+                if split:
+                    ptr, n = tracker.CalculateOptimizationBegin()
+                    assert n == 12 * 12 + 12
+                    addr = C.cast(ptr, C.c_void_p).value
+
+                    class _Buf:  # zero-copy view of the library's device buffer
+                        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (addr, False),
+                                                    "version": 2}
+                    with torch.cuda.stream(ext):
+                        t = torch.as_tensor(_Buf(), device="cuda")
+                        dist.all_reduce(t)  # one RCCL all-reduce over the stacked sums
+                    assert tracker.CalculateOptimizationEnd()
+                else:
+                    assert tracker.CalculateOptimization(0, 0, 0)
+            out.append((link1.link2world_pose(), link2.link2world_pose(), link2.joint2parent_pose()))
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rigid_context_switches_to_general_path_for_begin_end():
+    """begin/end on a rigid-only context == the rigid fast path within one Newton-step tolerance"""
+    inputs = scenes.Inputs(2, 2, n_divides=2)
+    poses = []
+    for split in (False, True):
+        hip = util.open_hip()
+        hip.call("set_fused_step", 0)
+        a = scenes.Instance(hip, inputs)
+        a.upload_frame(0)
+        assert a.tracker.StartModalities(0)
+        assert a.tracker.CalculateCorrespondences(0, 0)
+        assert a.tracker.CalculateGradientAndHessian(0, 0, 0)
+        if split:
+            ptr, n = a.tracker.CalculateOptimizationBegin()
+            assert n == 2 * 42
+            assert a.tracker.CalculateOptimizationEnd()
+        else:
+            assert a.tracker.CalculateOptimization(0, 0, 0)
+        poses.append(np.stack(a.poses()))
+    assert np.array_equal(poses[0], poses[1])
