@@ -197,6 +197,70 @@ class Optimizer {
   int id_;
 };
 
+// m3t::Link (link.h:67): body and parent are optional (pure joints / root links)
+class Link {
+ public:
+  Link(ContextPtr c, const Body* body = nullptr, const Link* parent = nullptr,
+       const Pose& body2joint_pose = IdentityPose(), const Pose& joint2parent_pose = IdentityPose(),
+       const std::array<bool, 6>& free_directions = {true, true, true, true, true, true},
+       bool fixed_body2joint_pose = true)
+      : c_(std::move(c)) {
+    int fd[6];
+    for (int i = 0; i < 6; ++i) fd[i] = free_directions[i] ? 1 : 0;
+    id_ = c_->Check(m3t_hip_link_create(c_->get(), body ? body->id() : -1, parent ? parent->id() : -1,
+                                        body2joint_pose.data(), joint2parent_pose.data(), fd,
+                                        fixed_body2joint_pose ? 1 : 0),
+                    "Link");
+  }
+  void AddModality(const Modality& m) { c_->Check(m3t_hip_link_add_modality(c_->get(), id_, m.id()), "Link"); }
+  void set_joint2parent_pose(const Pose& p) {
+    c_->Check(m3t_hip_link_set_joint_poses(c_->get(), id_, nullptr, p.data()), "Link");
+  }
+  void set_body2joint_pose(const Pose& p) {
+    c_->Check(m3t_hip_link_set_joint_poses(c_->get(), id_, p.data(), nullptr), "Link");
+  }
+  Pose joint2parent_pose() const {
+    Pose p;
+    c_->Check(m3t_hip_link_get_joint_poses(c_->get(), id_, nullptr, p.data()), "Link");
+    return p;
+  }
+  Pose link2world_pose() const {
+    Pose p;
+    c_->Check(m3t_hip_link_get_link2world_pose(c_->get(), id_, p.data()), "Link");
+    return p;
+  }
+  int id() const { return id_; }
+
+ private:
+  ContextPtr c_;
+  int id_;
+};
+
+// m3t::Optimizer over a kinematic tree + m3t::Constraint (constraint.h)
+class TreeOptimizer {
+ public:
+  TreeOptimizer(ContextPtr c, const Link& root_link, float tikhonov_parameter_rotation = 1000.0f,
+                float tikhonov_parameter_translation = 30000.0f)
+      : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_optimizer_create(c_->get(), root_link.id(), tikhonov_parameter_rotation,
+                                             tikhonov_parameter_translation),
+                    "Optimizer");
+  }
+  int AddConstraint(const Link& link1, const Link& link2, const Pose& body12joint1_pose, const Pose& body22joint2_pose,
+                    const std::array<bool, 6>& constraint_directions) {
+    int cd[6];
+    for (int i = 0; i < 6; ++i) cd[i] = constraint_directions[i] ? 1 : 0;
+    return c_->Check(m3t_hip_constraint_create(c_->get(), id_, link1.id(), link2.id(), body12joint1_pose.data(),
+                                               body22joint2_pose.data(), cd),
+                     "Constraint");
+  }
+  int id() const { return id_; }
+
+ private:
+  ContextPtr c_;
+  int id_;
+};
+
 // m3t::Tracker restricted to the tracking step (tracker.cpp:344-364, 430-517)
 class Tracker {
  public:
@@ -214,6 +278,7 @@ class Tracker {
     return c_->Step(m3t_hip_calculate_optimization(c_->get(), iteration, corr_iteration, update_iteration));
   }
   bool CalculateResults(int iteration) { return c_->Step(m3t_hip_calculate_results(c_->get(), iteration)); }
+  bool CalculateConsistentPoses() { return c_->Step(m3t_hip_calculate_consistent_poses(c_->get())); }
   bool ExecuteTrackingStep(int iteration) { return c_->Step(m3t_hip_execute_tracking_step(c_->get(), iteration)); }
   bool ExecuteTrackingCycle(int iteration) { return c_->Step(m3t_hip_execute_tracking_cycle(c_->get(), iteration)); }
   bool Sync() { return c_->Step(m3t_hip_sync(c_->get())); }

@@ -12,9 +12,10 @@ import util
 from test_multibody_oracle import build, random_pose, run_convergence
 from util import host, syn
 
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 
 
+@gpu
 @pytest.mark.parametrize("seed", range(4))
 def test_constraint_convergence_on_device(seed):
     errs_h, poses_h = run_convergence(util.open_hip(), seed)
@@ -28,20 +29,22 @@ def test_constraint_convergence_on_device(seed):
 class Chain:
     """body A (free root) -- revolute joint about the joint z axis -- body B, one camera each"""
 
-    def __init__(self, api, inputs, joint2parent, start_a, start_angle):
+    def __init__(self, api, inputs, joint2parent, start_a, start_angle, owned=(0, 1)):
         rp = dict(syn.RBOT_REGION_PARAMS)
         self.api = api
         self.models = [host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
                        for m in inputs.region_models]
         self.bodies = [host.Body(api, np.eye(4)), host.Body(api, np.eye(4))]
         self.cams = [host.ColorCamera(api, **inputs.intr) for _ in range(2)]
-        self.mods = [host.RegionModality(api, self.bodies[i], self.cams[i], self.models[i], **rp) for i in range(2)]
+        self.mods = {i: host.RegionModality(api, self.bodies[i], self.cams[i], self.models[i], **rp) for i in owned}
         self.link_a = host.Link(api, body=self.bodies[0])
         self.link_b = host.Link(api, body=self.bodies[1], parent=self.link_a,
                                 joint2parent_pose=joint2parent @ syn.make_pose(syn.rot_vec([0, 0, start_angle]), [0, 0, 0]),
                                 free_directions=(0, 0, 1, 0, 0, 0))
-        self.link_a.AddModality(self.mods[0])
-        self.link_b.AddModality(self.mods[1])
+        if 0 in self.mods:
+            self.link_a.AddModality(self.mods[0])
+        if 1 in self.mods:
+            self.link_b.AddModality(self.mods[1])
         self.opt = host.Optimizer(api, root_link=self.link_a)
         self.tracker = host.Tracker(api, 7, 2)
         self.bodies[0].set_body2world_pose(start_a)
@@ -72,6 +75,7 @@ def chain_inputs(n_frames=4):
     return inputs, joint2parent, gt
 
 
+@gpu
 def test_kinematic_chain_tracking_matches_oracle():
     inputs, joint2parent, gt = chain_inputs()
     start_a = syn.perturb_pose(gt[0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
@@ -99,6 +103,7 @@ def test_kinematic_chain_tracking_matches_oracle():
             assert np.array_equal(x, y)
 
 
+@gpu
 def test_begin_allreduce_end_with_rccl_world1():
     """the multi-GPU split: begin() exposes one device buffer, torch.distributed (RCCL) sums it,
     end() solves; with world size 1 the result equals the single call bit for bit"""
@@ -144,6 +149,7 @@ def test_begin_allreduce_end_with_rccl_world1():
         dist.destroy_process_group()
 
 
+@gpu
 def test_rigid_context_switches_to_general_path_for_begin_end():
     """begin/end on a rigid-only context == the rigid fast path within one Newton-step tolerance"""
     inputs = scenes.Inputs(2, 2, n_divides=2)

@@ -69,3 +69,57 @@ def test_single_process_gather_is_identity():
     out = sh.gather_poses([3, 1, 0, 2], poses, 4)
     assert np.array_equal(out[[3, 1, 0, 2]], poses)
     assert sh.max_over_ranks(2.5) == 2.5
+
+
+# ---- one kinematic structure spread over two ranks: the single all-reduce of SURVEY §8e ----
+def _chain_worker(rank, world, port, out_dir):
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    from test_gpu_multibody import Chain, chain_inputs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    inputs, joint2parent, gt = chain_inputs(n_frames=3)
+    start_a = util.syn.perturb_pose(gt[0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
+    api = util.open_oracle()
+    owned = [0, 1] if world == 1 else [rank]  # body r's modality lives on rank r
+    ch = Chain(api, inputs, joint2parent, start_a, gt[0][2] + 0.01, owned=owned)
+    for i in owned:
+        ch.cams[i].UpdateImage(inputs.color[i][0])
+    assert ch.tracker.StartModalities(0)
+    for k in range(len(gt)):
+        for i in owned:
+            ch.cams[i].UpdateImage(inputs.color[i][k])
+        for c in range(7):
+            assert ch.tracker.CalculateCorrespondences(k, c)
+            for u in range(2):
+                assert ch.tracker.CalculateGradientAndHessian(k, c, u)
+                ptr, n = ch.tracker.CalculateOptimizationBegin()
+                if world > 1:
+                    buf = np.ctypeslib.as_array(ptr, shape=(n,))
+                    t = torch.from_numpy(buf)  # shares memory with the library's buffer
+                    dist.all_reduce(t)
+                assert ch.tracker.CalculateOptimizationEnd()
+        assert ch.tracker.CalculateResults(k)
+    np.save(os.path.join(out_dir, "chain_%d_%d.npy" % (world, rank)), np.stack(ch.state()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_kinematic_structure_over_two_ranks(tmp_path):
+    """every rank keeps the whole link tree but only its own bodies' modalities; one all-reduce of
+    the stacked [dof*dof | dof] sums per Newton step keeps all replicas identical and equal to the
+    single-process result"""
+    import torch.multiprocessing as mp
+    port = 29700 + os.getpid() % 200
+    mp.spawn(_chain_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _chain_worker(0, 1, port + 1, str(tmp_path))
+    ref = np.load(os.path.join(str(tmp_path), "chain_1_0.npy"))
+    r0 = np.load(os.path.join(str(tmp_path), "chain_2_0.npy"))
+    r1 = np.load(os.path.join(str(tmp_path), "chain_2_1.npy"))
+    assert np.array_equal(r0, r1)       # replicas stay bit-identical
+    assert np.array_equal(r0, ref)      # and equal the single-process run
