@@ -133,8 +133,147 @@ class Ellipsoid:
         return x, nrm
 
 
+def _ray_hits(part_s, o, d):
+    """does the ray o + s d (s > 0) hit the ellipsoid with semi axes part_s (arrays (...,3))"""
+    ob, db = o / part_s, d / part_s
+    a = np.sum(db * db, -1)
+    b = 2 * np.sum(db * ob, -1)
+    c = np.sum(ob * ob, -1) - 1.0
+    disc = b * b - 4 * a * c
+    s1 = (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a)
+    return (disc > 0) & (s1 > 0), s1
+
+
+class Composite:
+    """Union of ellipsoids (each with its own pose in the body frame): a non-convex, non-symmetric
+    body whose silhouette constrains all six degrees of freedom (a single ellipsoid does not)."""
+
+    def __init__(self, parts):
+        self.parts = [(Ellipsoid(s), np.asarray(R, np.float64), np.asarray(t, np.float64)) for s, R, t in parts]
+        self.s = np.array([max(np.linalg.norm(t) + np.max(e.s) for e, R, t in self.parts)] * 3)  # bounding radius
+
+    def vertices(self, n=400, seed=0):
+        out = []
+        for k, (e, R, t) in enumerate(self.parts):
+            v = e.vertices(n // len(self.parts), seed + k).astype(np.float64)
+            out.append(v @ R.T + t)
+        return np.concatenate(out).astype(np.float32)
+
+    def hits(self, o, d, skip=None):
+        """ray o + s d against all parts (body frame, arrays (...,3)): (hit mask, nearest s)"""
+        hit = np.zeros(o.shape[:-1], bool)
+        smin = np.full(o.shape[:-1], np.inf)
+        for k, (e, R, t) in enumerate(self.parts):
+            if k == skip:
+                continue
+            h, s1 = _ray_hits(e.s, (o - t) @ R, d @ R)
+            smin = np.where(h & (s1 < smin), s1, smin)
+            hit |= h
+        return hit, smin
+
+    def rim_candidates(self, cam, phi):
+        """per part exact rims seen from cam (V,3): points, normals (V, K*P, 3), own chord (V, K*P), valid mask"""
+        xs, ns, chords, valid = [], [], [], []
+        for k, (e, R, t) in enumerate(self.parts):
+            cp = (cam - t) @ R
+            x, n = e.rim(cp, phi)
+            chords.append(_ellipse_chord(e, cp, x, n))
+            xb = x @ R.T + t
+            nb = n @ R.T
+            d = xb - cam[:, None, :]
+            h, _ = self.hits(np.broadcast_to(cam[:, None, :], xb.shape), d, skip=k)
+            xs.append(xb)
+            ns.append(nb)
+            valid.append(~h)
+        return np.concatenate(xs, 1), np.concatenate(ns, 1), np.concatenate(chords, 1), np.concatenate(valid, 1)
+
+
+def _ellipse_chord(e, cam_p, x, nrm):
+    """length of the chord of the rim ellipse of `e` (seen from cam_p, part frame) from the rim
+    point x along the inward normal, in metres (orthographic footprint of the rim)"""
+    V = cam_p.shape[0]
+    ori = -cam_p / np.linalg.norm(cam_p, axis=1, keepdims=True)
+    e1, e2 = _basis(ori)
+    xc, _ = e.rim(cam_p, np.zeros((V, 1)))
+    xs, _ = e.rim(cam_p, np.full((V, 1), np.pi / 2))
+    xo, _ = e.rim(cam_p, np.full((V, 1), np.pi))
+    centre3 = 0.5 * (xc[:, 0] + xo[:, 0])
+    m1 = xc[:, 0] - centre3
+    m2 = xs[:, 0] - centre3
+    M = np.stack([np.stack([np.sum(m1 * e1, 1), np.sum(m2 * e1, 1)], 1),
+                  np.stack([np.sum(m1 * e2, 1), np.sum(m2 * e2, 1)], 1)], 1)
+    Minv = np.linalg.inv(M)
+    p0 = np.stack([np.sum((x - centre3[:, None]) * e1[:, None], 2), np.sum((x - centre3[:, None]) * e2[:, None], 2)], 2)
+    n2 = np.stack([np.sum(nrm * e1[:, None], 2), np.sum(nrm * e2[:, None], 2)], 2)
+    n2 /= np.linalg.norm(n2, axis=2, keepdims=True)
+    q0 = np.einsum("vij,vpj->vpi", Minv, p0)
+    w = np.einsum("vij,vpj->vpi", Minv, n2)
+    return np.maximum(2.0 * np.sum(q0 * w, 2) / np.sum(w * w, 2), 0.0)
+
+
+def make_composite_region_model(body, n_divides=4, n_points=200, sphere_radius=0.8, seed=7):
+    """Sparse viewpoint model of a Composite: rim points of every part that lie on the union's
+    silhouette, sampled at random (like the reference's mt19937 sampling of the contour)."""
+    rng = np.random.default_rng(seed)
+    ori = geodesic_points(n_divides)
+    V = ori.shape[0]
+    cam = -sphere_radius * ori
+    P = 2 * n_points
+    phi = (np.arange(P)[None, :] + rng.random((V, 1))) * (2 * np.pi / P)
+    x, nrm, chord, valid = body.rim_candidates(cam, phi)
+    # random choice of n_points valid candidates per view
+    score = rng.random(valid.shape) + (~valid) * 10.0
+    pick = np.argsort(score, axis=1)[:, :n_points]
+    n_valid = valid.sum(1)
+    assert n_valid.min() >= 8, "degenerate view"
+    # views with fewer valid candidates than n_points: wrap around the valid ones
+    wrap = np.arange(n_points)[None, :] % np.maximum(n_valid, 1)[:, None]
+    pick = np.take_along_axis(pick, wrap, axis=1)
+    take = lambda a: np.take_along_axis(a, pick[..., None] if a.ndim == 3 else pick, axis=1)
+    x, nrm, chord = take(x), take(nrm), take(chord)
+    # background distance: first re-entry into the body along the outward normal (view ray through x + t n)
+    bg = np.full(x.shape[:2], np.float64(FLT_MAX))
+    camb = np.broadcast_to(cam[:, None, :], x.shape)
+    for tstep in np.arange(0.006, 0.10, 0.008)[::-1]:
+        h, _ = body.hits(camb, x + tstep * nrm - camb)
+        bg = np.where(h, tstep, bg)
+    take = lambda a: a
+    dp = np.zeros((V, n_points, M3T_REGION_POINT_FLOATS), np.float32)
+    dp[:, :, 0:3] = take(x)
+    dp[:, :, 3:6] = take(nrm)
+    dp[:, :, 6] = take(chord)
+    dp[:, :, 7] = np.minimum(take(bg), FLT_MAX).astype(np.float32)
+    contour = (2 * np.pi * np.mean(body.s) * n_valid / valid.shape[1]).astype(np.float32)
+    return dp, ori.astype(np.float32), contour
+
+
+def make_composite_depth_model(body, n_divides=4, n_points=200, sphere_radius=0.8, seed=7):
+    rng = np.random.default_rng(seed + 1)
+    ori = geodesic_points(n_divides)
+    V = ori.shape[0]
+    cam = -sphere_radius * ori
+    xs, ns, valid = [], [], []
+    for k, (e, R, t) in enumerate(body.parts):
+        x, n = e.visible_points((cam - t) @ R, rng, 2 * n_points)
+        xb, nb = x @ R.T + t, n @ R.T
+        camb = np.broadcast_to(cam[:, None, :], xb.shape)
+        h, s1 = body.hits(camb, xb - camb, skip=k)
+        xs.append(xb)
+        ns.append(nb)
+        valid.append(~(h & (s1 < 1.0)))
+    x, nrm, valid = np.concatenate(xs, 1), np.concatenate(ns, 1), np.concatenate(valid, 1)
+    score = rng.random(valid.shape) + (~valid) * 10.0
+    pick = np.argsort(score, axis=1)[:, :n_points]
+    dp = np.zeros((V, n_points, M3T_DEPTH_POINT_FLOATS), np.float32)
+    dp[:, :, 0:3] = np.take_along_axis(x, pick[..., None], axis=1)
+    dp[:, :, 3:6] = np.take_along_axis(nrm, pick[..., None], axis=1)
+    return dp, ori.astype(np.float32), np.full(V, np.pi * np.mean(body.s) ** 2, np.float32)
+
+
 def make_region_model(body, n_divides=4, n_points=200, sphere_radius=0.8, seed=7):
     """Sparse viewpoint model arrays: data_points (V,P,38), orientations (V,3), contour_lengths (V)."""
+    if isinstance(body, Composite):
+        return make_composite_region_model(body, n_divides, n_points, sphere_radius, seed)
     rng = np.random.default_rng(seed)
     ori = geodesic_points(n_divides)  # camera -> body direction, body frame
     V = ori.shape[0]
@@ -175,6 +314,8 @@ def make_region_model(body, n_divides=4, n_points=200, sphere_radius=0.8, seed=7
 
 
 def make_depth_model(body, n_divides=4, n_points=200, sphere_radius=0.8, seed=7):
+    if isinstance(body, Composite):
+        return make_composite_depth_model(body, n_divides, n_points, sphere_radius, seed)
     rng = np.random.default_rng(seed + 1)
     ori = geodesic_points(n_divides)
     V = ori.shape[0]
@@ -218,14 +359,20 @@ class Scene:
     """One object with its own camera stream: background texture, colour means and GT trajectory."""
 
     def __init__(self, object_index, intr=RBOT_INTRINSICS, semi_axes=None, with_depth=False, depth_scale=1e-4,
-                 distance=(0.7, 0.9)):
+                 distance=(0.5, 0.8)):
         self.rng = np.random.default_rng(1000 + object_index)
         rng = self.rng
         self.intr = dict(intr)
         if semi_axes is None:
-            # clearly tri-axial so that all three rotations are observable from the silhouette
-            semi_axes = rng.uniform(0.06, 0.09) * np.array([1.0, rng.uniform(0.45, 0.65), rng.uniform(0.25, 0.4)])
-        self.body = Ellipsoid(semi_axes)
+            # two ellipsoidal lobes at an angle: all six degrees of freedom show in the silhouette
+            a = rng.uniform(0.06, 0.085)
+            main = a * np.array([1.0, rng.uniform(0.4, 0.55), rng.uniform(0.28, 0.4)])
+            lobe = a * np.array([rng.uniform(0.6, 0.8), rng.uniform(0.28, 0.4), rng.uniform(0.22, 0.32)])
+            R_l = rot_vec(rng.uniform(0.6, 1.2) * np.array([0.3, 0.4, 1.0]) * rng.choice([-1, 1]))
+            t_l = a * np.array([rng.uniform(0.45, 0.7), rng.uniform(0.25, 0.45) * rng.choice([-1, 1]), rng.uniform(-0.15, 0.15)])
+            self.body = Composite([(main, np.eye(3), np.zeros(3)), (lobe, R_l, t_l)])
+        else:
+            self.body = Ellipsoid(semi_axes)
         W, H = intr["width"], intr["height"]
         mu_b = rng.uniform(40, 215, 3)
         mu_f = (mu_b + rng.choice([-1, 1], 3) * rng.uniform(60, 110, 3)) % 256
@@ -270,22 +417,20 @@ class Scene:
         if u1 > u0 and v1 > v0:
             uu, vv = np.meshgrid(np.arange(u0, u1), np.arange(v0, v1))
             d = np.stack([(uu - intr["ppu"]) / intr["fu"], (vv - intr["ppv"]) / intr["fv"], np.ones_like(uu, float)], -1)
-            # ray o + s d in the body frame, sphere space
-            db = (d @ R) / self.body.s
-            ob = (-(R.T @ t)) / self.body.s
-            a = np.sum(db * db, -1)
-            b = 2 * np.sum(db * ob, -1)
-            c = np.sum(ob * ob) - 1.0
-            disc = b * b - 4 * a * c
-            hit = disc > 0
+            # ray o + s d in the body frame (d has z = 1 in the camera frame -> s is the depth)
+            db = d @ R
+            ob = np.broadcast_to(-(R.T @ t), db.shape)
+            if isinstance(self.body, Composite):
+                hit, s_hit = self.body.hits(ob, db)
+            else:
+                hit, s_hit = _ray_hits(self.body.s, ob, db)
             nh = int(hit.sum())
             if nh:
                 sub = img[v0:v1, u0:u1]
                 sub[hit] = np.clip(self.mu_f + self.rng.normal(0, 20, (nh, 3)), 0, 255).astype(np.uint8)
                 if depth is not None:
-                    s = (-b[hit] - np.sqrt(disc[hit])) / (2 * a[hit])
                     dsub = depth[v0:v1, u0:u1]
-                    dsub[hit] = s  # d has z = 1 -> s is the camera-frame depth
+                    dsub[hit] = s_hit[hit]
         if depth is not None:
             noisy = depth + self.rng.normal(0, 0.001, depth.shape)
             d16 = np.clip(noisy / self.depth_scale, 0, 65535).astype(np.uint16)

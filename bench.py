@@ -44,7 +44,7 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--objects", type=int, default=64, help="objects per GPU")
-    p.add_argument("--models", type=int, default=16, help="distinct sparse viewpoint models per GPU")
+    p.add_argument("--models", type=int, default=8, help="distinct sparse viewpoint models per GPU")
     p.add_argument("--n-divides", type=int, default=4, help="geodesic subdivisions (4 -> 2562 views)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget")
     p.add_argument("--no-cpu-baseline", action="store_true")
