@@ -140,6 +140,12 @@ struct m3t_hip_context {
   size_t lds_track = 0, lds_corr = 0, lds_hist = 0, lds_depth = 0;
   bool hist_counts_in_lds = true;
   // optional HIP-event timing of the two per-frame kernels (bench.py roofline leg)
+  // pinned staging ring for the camera table: a frame switch is an async 1-2 KB copy, no host sync
+  static constexpr int kStage = 8;
+  void* cam_stage[kStage] = {nullptr};
+  size_t cam_stage_bytes = 0;
+  hipEvent_t cam_stage_done[kStage] = {nullptr};
+  int cam_stage_next = 0;
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   struct Pending { hipEvent_t a, b; int which; };
@@ -292,7 +298,7 @@ int CreateCamera(Ctx* ctx, const m3t_intrinsics* intr, const float* w2c, bool de
   c->frame_bytes = size_t(c->pitch) * intr->height;
   c->n_slots = 1;
   c->has_image.assign(1, false);
-  HIPCHK(c->ring.alloc(c->frame_bytes));
+  HIPCHK(c->ring.alloc(c->frame_bytes + 64));  // +64: pixels are fetched as one 4-byte load (B,G,R,+1)
   ctx->cameras.push_back(std::move(c));
   ctx->cams_dirty = true;
   return int(ctx->cameras.size()) - 1;
@@ -493,12 +499,28 @@ int UploadTables(Ctx* ctx) {
       d.depth_scale = c.depth_scale;
       std::memcpy(d.world2camera, c.world2camera, 64);
     }
-    if (ctx->d_cams.bytes < cams.size() * sizeof(CameraDev)) HIPCHK(ctx->d_cams.alloc(cams.size() * sizeof(CameraDev) * 2));
-    if (!cams.empty())
-      HIPCHK(hipMemcpyAsync(ctx->d_cams.p, cams.data(), cams.size() * sizeof(CameraDev), hipMemcpyHostToDevice,
-                            ctx->stream));
-    // pageable source: the runtime stages it before returning, but be explicit about lifetime
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const size_t bytes = cams.size() * sizeof(CameraDev);
+    if (ctx->d_cams.bytes < bytes) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx->d_cams.alloc(bytes * 2));
+    }
+    if (ctx->cam_stage_bytes < bytes) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      for (int i = 0; i < Ctx::kStage; ++i) {
+        if (ctx->cam_stage[i]) (void)hipHostFree(ctx->cam_stage[i]);
+        HIPCHK(hipHostMalloc(&ctx->cam_stage[i], bytes * 2, hipHostMallocDefault));
+        if (!ctx->cam_stage_done[i]) HIPCHK(hipEventCreateWithFlags(&ctx->cam_stage_done[i], hipEventDisableTiming));
+      }
+      ctx->cam_stage_bytes = bytes * 2;
+    }
+    if (!cams.empty()) {
+      const int slot = ctx->cam_stage_next;
+      ctx->cam_stage_next = (slot + 1) % Ctx::kStage;
+      HIPCHK(hipEventSynchronize(ctx->cam_stage_done[slot]));  // normally long complete
+      std::memcpy(ctx->cam_stage[slot], cams.data(), bytes);
+      HIPCHK(hipMemcpyAsync(ctx->d_cams.p, ctx->cam_stage[slot], bytes, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipEventRecord(ctx->cam_stage_done[slot], ctx->stream));
+    }
     ctx->cams_dirty = false;
   }
   if (ctx->tables_dirty) {
@@ -763,6 +785,10 @@ void m3t_hip_destroy(m3t_hip_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
+  for (int i = 0; i < m3t_hip_context::kStage; ++i) {
+    if (ctx->cam_stage[i]) (void)hipHostFree(ctx->cam_stage[i]);
+    if (ctx->cam_stage_done[i]) (void)hipEventDestroy(ctx->cam_stage_done[i]);
+  }
   delete ctx;
 }
 
@@ -893,7 +919,7 @@ int m3t_hip_camera_set_ring(m3t_hip_context* ctx, int id, int n_slots) {
   HIPCHK(hipSetDevice(ctx->device));
   Camera& c = *ctx->cameras[id];
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(c.ring.alloc(c.frame_bytes * size_t(n_slots)));
+  HIPCHK(c.ring.alloc(c.frame_bytes * size_t(n_slots) + 64));
   c.n_slots = n_slots;
   c.current = 0;
   c.has_image.assign(n_slots, false);

@@ -680,26 +680,48 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   // ---- phase C1: raw distribution products (aliases the chain buffer) ----
   const int dl = m.distribution_length, fl = m.function_length;
   float* raw = s.chain;  // [nl][M3T_MAX_DISTRIBUTION_LENGTH] needs ns >= dl (n_seg = fl + dl - 1 >= dl)
-  for (int item = tid; item < n_lines * dl; item += nt) {
-    int line = item / dl;
-    int d = item - line * dl;
-    int flags = f2i_bits(s.state[LS_VALID * nl + line]);
-    if (!(flags & valid_mask)) continue;
-    const float* sf = s.seg_f + line * s.ns + d;
-    const float* sb = s.seg_b + line * s.ns + d;
-    float value = 1.0f;
+  {
     const float* lf = s.misc + kMiscLookup;
     const float* lb = s.misc + kMiscLookup + M3T_MAX_FUNCTION_LENGTH;
-    if (fl == 8) {  // default function_length: independent LDS reads, ordered product
-      float f[8], b[8];
+    // (line, d) of item = tid, advanced by nt per step without divisions
+    const int q = nt / dl, r = nt - q * dl;
+    int line = tid / dl, d = tid - line * dl;
+    if (fl == 8) {  // default function_length: lookups as uniform scalars, independent LDS reads, ordered product
+      float lfr[8], lbr[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { f[k] = sf[k]; b[k] = sb[k]; }
+      for (int k = 0; k < 8; ++k) { lfr[k] = m.function_lookup_f[k]; lbr[k] = m.function_lookup_b[k]; }
+      for (int item = tid; item < n_lines * dl; item += nt) {
+        int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+        if (flags & valid_mask) {
+          const float* sf = s.seg_f + line * s.ns + d;
+          const float* sb = s.seg_b + line * s.ns + d;
+          float f[8], b[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) value *= f[k] * lf[k] + b[k] * lb[k];
+          for (int k = 0; k < 8; ++k) { f[k] = sf[k]; b[k] = sb[k]; }
+          float value = 1.0f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) value *= f[k] * lfr[k] + b[k] * lbr[k];
+          raw[line * s.ns + d] = value;
+        }
+        line += q;
+        d += r;
+        if (d >= dl) { d -= dl; ++line; }
+      }
     } else {
-      for (int k = 0; k < fl; ++k) value *= sf[k] * lf[k] + sb[k] * lb[k];
+      for (int item = tid; item < n_lines * dl; item += nt) {
+        int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+        if (flags & valid_mask) {
+          const float* sf = s.seg_f + line * s.ns + d;
+          const float* sb = s.seg_b + line * s.ns + d;
+          float value = 1.0f;
+          for (int k = 0; k < fl; ++k) value *= sf[k] * lf[k] + sb[k] * lb[k];
+          raw[line * s.ns + d] = value;
+        }
+        line += q;
+        d += r;
+        if (d >= dl) { d -= dl; ++line; }
+      }
     }
-    raw[line * s.ns + d] = value;
   }
   __syncthreads();
   PHASE_MARK(3);
@@ -1335,9 +1357,17 @@ __device__ void depth_gradient_hessian(CDepth& m, const Affine& b2c, int corr_it
 // (foreground count in the low 16 bits, background in the high 16 bits; each is
 // <= n_lines * max_considered_line_length < 65536), in LDS when it fits.
 // ---------------------------------------------------------------------------
-__device__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam,
-                                        const Affine& b2c, const Affine& b2dc, bool handle_occlusions, bool initialize,
-                                        uint32_t* counts, float* misc) {
+__device__ __forceinline__ void count_add(__attribute__((address_space(3))) uint32_t* p, uint32_t v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u32
+}
+__device__ __forceinline__ void count_add(__attribute__((address_space(1))) uint32_t* p, uint32_t v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename CountPtr>
+__device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
+                                                        const Affine& b2dc, bool handle_occlusions, bool initialize,
+                                                        CountPtr counts, float* misc) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n_bins3 = m.n_bins * m.n_bins * m.n_bins;
   for (int i = tid; i < n_bins3; i += nt) counts[i] = 0;
@@ -1346,7 +1376,10 @@ __device__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam,
                                       m.extents[view], m.max_extent, m.n_points);
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = n_bins * n_bins;
   const int w1 = cam.width - 1, h1 = cam.height - 1;
-  for (int line = tid; line < n_lines; line += nt) {
+  // two lanes per line: even lane = foreground walk (inwards), odd lane = background walk
+  for (int item = tid; item < 2 * n_lines; item += nt) {
+    const int line = item >> 1;
+    const bool background = item & 1;
     const float* p = m.points + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
     G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
     const v4f pa = p8[0], pb4 = p8[1];
@@ -1391,26 +1424,37 @@ __device__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam,
       projected_length_f = f2i(length_f * abs_nv + 0.5f);
       projected_length_b = f2i(length_b * abs_nv + 0.5f);
     }
-    float u = center_u - nu * m.unconsidered_line_length + 0.5f;
-    float v = center_v - nv * m.unconsidered_line_length + 0.5f;
-    for (int k = 0; k < projected_length_f; ++k) {
-      int iu = f2i(u), iv = f2i(v);
-      if (iu < 0 || iu > w1 || iv < 0 || iv > h1) break;
-      G<uint8_t> px = as_global(cam.image) + (uint32_t)iv * cam.pitch + iu * 3;
-      atomicAdd(&counts[(px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift)], 1u);
-      u -= u_step;
-      v -= v_step;
+    // one walk per lane; first count the steps that stay on the image (the reference breaks at the
+    // first step off the image), then replay the same float chain with independent loads + LDS atomics
+    const float sgn = background ? 1.0f : -1.0f;
+    const int projected_length = background ? projected_length_b : projected_length_f;
+    const float u0 = background ? center_u + nu * m.unconsidered_line_length + 0.5f
+                                : center_u - nu * m.unconsidered_line_length + 0.5f;
+    const float v0 = background ? center_v + nv * m.unconsidered_line_length + 0.5f
+                                : center_v - nv * m.unconsidered_line_length + 0.5f;
+    const float du = sgn * u_step, dv = sgn * v_step;  // u -= u_step == u += (-u_step), exactly
+    int n_valid = 0;
+    {
+      float u = u0, v = v0;
+      for (int k = 0; k < projected_length; ++k) {
+        int iu = f2i(u), iv = f2i(v);
+        if (iu < 0 || iu > w1 || iv < 0 || iv > h1) break;
+        ++n_valid;
+        u += du;
+        v += dv;
+      }
     }
-    u = center_u + nu * m.unconsidered_line_length + 0.5f;
-    v = center_v + nv * m.unconsidered_line_length + 0.5f;
-    for (int k = 0; k < projected_length_b; ++k) {
-      int iu = f2i(u), iv = f2i(v);
-      if (iu < 0 || iu > w1 || iv < 0 || iv > h1) break;
-      G<uint8_t> px = as_global(cam.image) + (uint32_t)iv * cam.pitch + iu * 3;
-      atomicAdd(&counts[(px[0] >> bitshift) * n_bins2 + (px[1] >> bitshift) * n_bins + (px[2] >> bitshift)],
-                65536u);
-      u += u_step;
-      v += v_step;
+    const uint32_t inc = background ? 65536u : 1u;
+    float u = u0, v = v0;
+    G<uint8_t> image = as_global(cam.image);
+    for (int k = 0; k < n_valid; ++k) {
+      uint32_t off = __umul24((uint32_t)f2i(v), cam.pitch) + (uint32_t)f2i(u) * 3u;
+      uint32_t px = reinterpret_cast<G<PackedU32>>(image + off)->v;
+      count_add(&counts[((px & 0xffu) >> bitshift) * n_bins2 + (((px >> 8) & 0xffu) >> bitshift) * n_bins +
+                        (((px >> 16) & 0xffu) >> bitshift)],
+                inc);
+      u += du;
+      v += dv;
     }
   }
   __syncthreads();
@@ -1421,11 +1465,8 @@ __device__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam,
     sf += c & 0xffffu;
     sb += c >> 16;
   }
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) {
-    sf += __shfl_down(sf, off);
-    sb += __shfl_down(sb, off);
-  }
+  sf = (unsigned)wave_sum_i((int)sf);
+  sb = (unsigned)wave_sum_i((int)sb);
   unsigned* umisc = reinterpret_cast<unsigned*>(misc);
   if (tid % kWave == 0) { umisc[2 * (tid / kWave)] = sf; umisc[2 * (tid / kWave) + 1] = sb; }
   __syncthreads();
@@ -1436,39 +1477,52 @@ __device__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam,
   const float comp_f = 1.0f - lr_f, comp_b = 1.0f - lr_b;
   const float scale_f = lr_f / sum_f, scale_b = lr_b / sum_b;
   const float uniform_value = 1.0f / (float)n_bins3;
-  for (int i = tid; i < n_bins3; i += nt) {
-    uint32_t c = counts[i];
-    float hf = m.histogram_f[i], hb = m.histogram_b[i];
-    if (sf == 0) {
-      if (lr_f == 1.0f) hf = uniform_value;
-    } else if (comp_f == 0.0f) {
-      hf = (float)(c & 0xffffu) * scale_f;
-    } else {
-      hf *= comp_f;
-      hf += (float)(c & 0xffffu) * scale_f;
+  // blend (color_histograms.cpp:174-214) + per-bin normalisation, 4 bins per lane: 16-byte global
+  // loads / stores through global-address-space pointers (n_bins^3 is a multiple of 8)
+  GW<v4f> hist_f4 = (GW<v4f>)m.histogram_f;
+  GW<v4f> hist_b4 = (GW<v4f>)m.histogram_b;
+  GW<v4f> norm4 = (GW<v4f>)m.histogram_norm;
+  for (int i4 = tid; i4 < n_bins3 / 4; i4 += nt) {
+    v4f hf4 = hist_f4[i4], hb4 = hist_b4[i4];
+    uint32_t c4[4] = {counts[4 * i4], counts[4 * i4 + 1], counts[4 * i4 + 2], counts[4 * i4 + 3]};
+    v4f n0, n1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float hf = hf4[k], hb = hb4[k];
+      uint32_t c = c4[k];
+      if (sf == 0) {
+        if (lr_f == 1.0f) hf = uniform_value;
+      } else if (comp_f == 0.0f) {
+        hf = (float)(c & 0xffffu) * scale_f;
+      } else {
+        hf *= comp_f;
+        hf += (float)(c & 0xffffu) * scale_f;
+      }
+      if (sb == 0) {
+        if (lr_b == 1.0f) hb = uniform_value;
+      } else if (comp_b == 0.0f) {
+        hb = (float)(c >> 16) * scale_b;
+      } else {
+        hb *= comp_b;
+        hb += (float)(c >> 16) * scale_b;
+      }
+      hf4[k] = hf;
+      hb4[k] = hb;
+      // MultiplyPixelColorProbability :1585-1593 hoisted from per pixel to per bin
+      float nx = 0.5f, ny = 0.5f;
+      if (hf || hb) {
+        float sum = hf;
+        sum += hb;
+        nx = hf / sum;
+        ny = hb / sum;
+      }
+      if (k < 2) { n0[2 * k] = nx; n0[2 * k + 1] = ny; }
+      else { n1[2 * (k - 2)] = nx; n1[2 * (k - 2) + 1] = ny; }
     }
-    if (sb == 0) {
-      if (lr_b == 1.0f) hb = uniform_value;
-    } else if (comp_b == 0.0f) {
-      hb = (float)(c >> 16) * scale_b;
-    } else {
-      hb *= comp_b;
-      hb += (float)(c >> 16) * scale_b;
-    }
-    m.histogram_f[i] = hf;
-    m.histogram_b[i] = hb;
-    // MultiplyPixelColorProbability :1585-1593 hoisted from per pixel to per bin
-    float2 n;
-    if (hf || hb) {
-      float sum = hf;
-      sum += hb;
-      n.x = hf / sum;
-      n.y = hb / sum;
-    } else {
-      n.x = 0.5f;
-      n.y = 0.5f;
-    }
-    m.histogram_norm[i] = n;
+    hist_f4[i4] = hf4;
+    hist_b4[i4] = hb4;
+    norm4[2 * i4] = n0;
+    norm4[2 * i4 + 1] = n1;
   }
 }
 
@@ -1505,8 +1559,13 @@ region_histogram_kernel(const RegionModDev* mods, const CameraDev* cams, const f
   bool handle_occlusions = initialize ? (m.n_unoccluded_iterations == 0)
                                       : ((iteration - m.first_iteration) >= m.n_unoccluded_iterations);
   float* misc = lds;
-  uint32_t* counts = counts_in_lds ? reinterpret_cast<uint32_t*>(lds + M3T_MISC_FLOATS) : m.count_scratch;
-  region_histogram_update(m, cam, dcam, b2c, b2dc, handle_occlusions, initialize != 0, counts, misc);
+  if (counts_in_lds) {  // ds_add_u32 on the LDS count table
+    region_histogram_update(m, cam, dcam, b2c, b2dc, handle_occlusions, initialize != 0,
+                            (__attribute__((address_space(3))) uint32_t*)(lds + M3T_MISC_FLOATS), misc);
+  } else {              // 64 bins: 1 MB table in HBM, global atomics
+    region_histogram_update(m, cam, dcam, b2c, b2dc, handle_occlusions, initialize != 0,
+                            (__attribute__((address_space(1))) uint32_t*)m.count_scratch, misc);
+  }
 }
 
 extern "C++" {

@@ -138,6 +138,26 @@ def main():
                     "histogram_kernel_GBs": round((B_HIST_RMW + B_HIST_PIXELS + B_VIEW_SCAN // 7 + B_VIEW_POINTS // 7) *
                                                   n_obj / (hist_ms * 1e-3) / 1e9, 2)}
 
+    # ---- host-buffer (PCIe-inclusive) rate: every step first uploads its 64 frames from host memory
+    # through m3t_hip_camera_upload (the boundary's Camera::UpdateImage); never the headline value ----
+    pcie = None
+    if rank == 0:
+        n_up = min(5, K)
+        hip.call("cameras_select_slot", 0)
+        hip.call("sync")
+        tu = time.perf_counter()
+        for k in range(1 + W, 1 + W + n_up):
+            for i, cam in enumerate(inst.color_cams):
+                f = inputs.color[i][k]
+                hip.call("camera_upload", cam.id, f.ctypes.data_as(C.c_void_p), f.strides[0])
+            hip.call("execute_tracking_step", k)
+        hip.call("sync")
+        el = time.perf_counter() - tu
+        frame_bytes = sum(inputs.color[i][0].nbytes for i in range(n_obj))
+        pcie = {"pose_updates_per_s": round(n_obj * n_up / el, 1), "ms_per_step": round(el / n_up * 1e3, 3),
+                "host_bytes_per_step": frame_bytes, "upload_GBs": round(frame_bytes * n_up / el / 1e9, 2),
+                "note": "pageable host frames, synchronous m3t_hip_camera_upload per camera, then the step"}
+
     # ---- optional batch sweep (extra lines on stderr, not the headline) ----
     sweep = []
     if rank == 0 and args.sweep:
@@ -184,7 +204,7 @@ def main():
                                    (n_obj, inputs.region_models[0][1].shape[0], len(inputs.region_models)),
                        "objects_per_gpu": n_obj, "parallelism": "objects sharded over %d GPU(s), no collective" % n_gpus,
                        "tracked_within_5cm_5deg": "%d/%d" % (tracked, n_obj), "setup_s": round(setup_s, 1)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "frac_of_hbm_roofline_whole_step": round(total / elapsed * B_ALG / (HBM_PEAK_GBS * 1e9 * n_gpus), 5),
         }
         if sweep:
