@@ -1,0 +1,178 @@
+"""Edge cases of the path, HIP vs oracle (bit-exact per-line state / histograms unless noted):
+ragged and empty line sets, objects leaving the image or behind the camera, adaptive coverage,
+non-default distribution / function lengths, every template and the generic pixel-walk path,
+heterogeneous parameters inside one batch, several bodies sharing one camera (YCB shape)."""
+import numpy as np
+import pytest
+
+import scenes
+import util
+from test_gpu_parity import _assert_lines_equal, rel_fro
+from util import host, syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(inputs, **kw):
+    hip, ora = util.open_hip(), util.open_oracle()
+    hip.call("set_fused_step", 0)
+    a = scenes.Instance(hip, inputs, **kw)
+    b = scenes.Instance(ora, inputs, **kw)
+    for inst in (a, b):
+        inst.upload_frame(0)
+        assert inst.tracker.StartModalities(0)
+    return a, b
+
+
+def _compare_step(a, b, it=0, n_corr=None):
+    n_corr = n_corr or a.tracker.n_corr_iterations
+    for c in range(n_corr):
+        a.set_poses(b.poses())
+        assert a.tracker.CalculateCorrespondences(it, c) and b.tracker.CalculateCorrespondences(it, c)
+        for ra, rb in zip(a.region, b.region):
+            _assert_lines_equal(ra.data_lines(), rb.data_lines())
+        for u in range(2):
+            a.set_poses(b.poses())
+            assert a.tracker.CalculateGradientAndHessian(it, c, u) and b.tracker.CalculateGradientAndHessian(it, c, u)
+            for ra, rb in zip(a.region, b.region):
+                ga, ha = ra.gradient_hessian()
+                gb, hb = rb.gradient_hessian()
+                if np.any(hb):
+                    assert rel_fro(ga, gb) < 1e-4 and rel_fro(ha, hb) < 1e-4
+                else:
+                    assert not np.any(ha) and not np.any(ga)
+            assert a.tracker.CalculateOptimization(it, c, u) and b.tracker.CalculateOptimization(it, c, u)
+    assert a.tracker.CalculateResults(it) and b.tracker.CalculateResults(it)
+
+
+@pytest.mark.parametrize("scales", [[1], [3, 2], [4, 3], [6, 1], [7, 4, 2], [8, 5], [9, 7, 5, 2], [10, 3], [12]])
+def test_every_scale_variant(scales):
+    """region_segments<1..9> and the generic path (scale >= 10): lines bit-exact"""
+    inputs = scenes.Inputs(2, 1, n_divides=2)
+    rp = dict(syn.RBOT_REGION_PARAMS, scales=scales, standard_deviations=[15.0] * len(scales))
+    a, b = _both(inputs, region_params=rp)
+    _compare_step(a, b, n_corr=len(scales))
+
+
+@pytest.mark.parametrize("fl,dl", [(8, 12), (6, 10), (4, 16), (10, 8), (16, 16), (1, 2)])
+def test_function_and_distribution_lengths(fl, dl):
+    inputs = scenes.Inputs(2, 1, n_divides=2)
+    rp = dict(syn.RBOT_REGION_PARAMS, function_length=fl, distribution_length=dl, scales=[2, 1],
+              standard_deviations=[7.0, 1.5])
+    a, b = _both(inputs, region_params=rp)
+    _compare_step(a, b, n_corr=2)
+
+
+def test_ragged_and_empty_line_sets():
+    """object half outside the image, fully outside, and behind the camera: fewer / zero valid lines,
+    zero g/H leaves the pose untouched, histograms stay uniform when nothing is sampled"""
+    inputs = scenes.Inputs(3, 1, n_divides=2)
+    W = inputs.intr["width"]
+    z = inputs.gt[0][0][2, 3]
+    # object 0: centre on the right image border; object 1: far outside; object 2: behind the camera
+    inputs.start[0] = inputs.gt[0][0].copy()
+    inputs.start[0][0, 3] = (W - 1 - inputs.intr["ppu"]) * z / inputs.intr["fu"]
+    inputs.start[1] = inputs.gt[1][0].copy()
+    inputs.start[1][0, 3] += 3.0
+    inputs.start[2] = inputs.gt[2][0].copy()
+    inputs.start[2][2, 3] = -0.5
+    a, b = _both(inputs)
+    fa, ba = a.region[1].histograms()
+    assert np.all(fa == np.float32(1.0) / np.float32(32 ** 3)) and np.array_equal(fa, b.region[1].histograms()[0])
+    before = b.poses()
+    _compare_step(a, b, n_corr=3)
+    counts = [len(r.data_lines()) for r in b.region]
+    assert 0 < counts[0] < 150 and counts[1] == 0 and counts[2] == 0
+    after_h, after_o = a.poses(), b.poses()
+    for i in (1, 2):
+        assert np.array_equal(after_o[i], before[i]) and np.array_equal(after_h[i], before[i])
+
+
+def test_fewer_model_points_than_lines_and_adaptive_coverage():
+    """n_lines_max larger than the model's points (clamped with a warning in the reference,
+    region_modality.cpp:426-430) and use_adaptive_coverage with both reference settings"""
+    inputs = scenes.Inputs(2, 1, n_divides=2, n_points=120)
+    for extra in (dict(n_lines_max=200), dict(n_lines_max=100, use_adaptive_coverage=1),
+                  dict(n_lines_max=100, use_adaptive_coverage=1, reference_contour_length=0.35)):
+        rp = dict(syn.RBOT_REGION_PARAMS, **extra)
+        a, b = _both(inputs, region_params=rp)
+        _compare_step(a, b, n_corr=2)
+        assert len(b.region[0].data_lines()) <= 120
+
+
+def test_heterogeneous_batch():
+    """objects with different parameters (lines, bins, scales, image sizes) in ONE context / launch"""
+    hip, ora = util.open_hip(), util.open_oracle()
+    hip.call("set_fused_step", 0)
+    inputs_a = scenes.Inputs(2, 2, n_divides=2)
+    inputs_b = scenes.Inputs(2, 2, n_divides=1, intr=dict(syn.RBOT_INTRINSICS, width=480, height=360, ppu=240, ppv=180),
+                             first_object=7)
+    out = []
+    for api in (hip, ora):
+        i1 = scenes.Instance(api, inputs_a)
+        i2 = scenes.Instance(api, inputs_b, region_params=dict(
+            syn.RBOT_REGION_PARAMS, n_lines_max=90, n_histogram_bins=8, scales=[4, 2, 1],
+            standard_deviations=[15.0, 5.0, 1.5], function_slope=0.5, function_amplitude=0.43))
+        for inst in (i1, i2):
+            inst.upload_frame(0)
+        assert i1.tracker.StartModalities(0)
+        out.append((i1, i2))
+    (a1, a2), (b1, b2) = out
+    for c in range(3):
+        for x, y in ((a1, b1), (a2, b2)):
+            x.set_poses(y.poses())
+        assert a1.tracker.CalculateCorrespondences(0, c) and b1.tracker.CalculateCorrespondences(0, c)
+        for x, y in ((a1, b1), (a2, b2)):
+            for ra, rb in zip(x.region, y.region):
+                _assert_lines_equal(ra.data_lines(), rb.data_lines())
+    # fused step over the mixed batch stays within one-step tolerance
+    hip.call("set_fused_step", 1)
+    for x, y in ((a1, b1), (a2, b2)):
+        x.set_poses(y.poses())
+    assert a1.tracker.ExecuteTrackingStep(0) and b1.tracker.ExecuteTrackingStep(0)
+    st = [syn.pose_errors(p, q) for x, y in ((a1, b1), (a2, b2)) for p, q in zip(x.poses(), y.poses())]
+    assert np.median([e[0] for e in st]) < 1e-5 and np.median([e[1] for e in st]) < 1e-6
+
+
+def test_bodies_sharing_one_camera():
+    """YCB shape: one colour + one depth camera, several bodies / modalities referencing them"""
+    inputs = scenes.Inputs(3, 2, n_divides=2, with_depth=True)
+    # one common frame: paste every object into the image / depth of object 0
+    for k in range(inputs.n_frames):
+        img, dep = inputs.color[0][k].copy(), inputs.depth[0][k].copy()
+        for i in range(1, inputs.n_objects):
+            mask = inputs.depth[i][k] < np.uint16(0.95 / inputs.depth_scale)
+            img[mask] = inputs.color[i][k][mask]
+            dep[mask] = np.minimum(dep[mask], inputs.depth[i][k][mask])
+        for i in range(inputs.n_objects):
+            inputs.color[i][k], inputs.depth[i][k] = img, dep
+    results = []
+    for api in (util.open_hip(), util.open_oracle()):
+        if api.is_hip:
+            api.call("set_summation_mode", 1)
+        cam = host.ColorCamera(api, **inputs.intr)
+        dcam = host.DepthCamera(api, depth_scale=inputs.depth_scale, **inputs.intr)
+        bodies, mods = [], []
+        for i in range(inputs.n_objects):
+            rm = host.RegionModel(api, data_points=inputs.region_models[i][0], orientations=inputs.region_models[i][1],
+                                  contour_lengths=inputs.region_models[i][2])
+            dm = host.DepthModel(api, data_points=inputs.depth_models[i][0], orientations=inputs.depth_models[i][1],
+                                 surface_areas=inputs.depth_models[i][2])
+            body = host.Body(api, inputs.start[i])
+            r = host.RegionModality(api, body, cam, rm, depth_camera=dcam, **syn.YCB_REGION_PARAMS)
+            d = host.DepthModality(api, body, dcam, dm, **syn.YCB_DEPTH_PARAMS)
+            host.Optimizer(api, body=body, modalities=[r, d])
+            bodies.append(body)
+            mods.append((r, d))
+        tr = host.Tracker(api, 4, 2)
+        cam.UpdateImage(inputs.color[0][0])
+        dcam.UpdateImage(inputs.depth[0][0])
+        assert tr.StartModalities(0)
+        for k in range(inputs.n_frames):
+            cam.UpdateImage(inputs.color[0][k])
+            dcam.UpdateImage(inputs.depth[0][k])
+            assert tr.ExecuteTrackingStep(k)
+        results.append(np.stack([b.body2world_pose() for b in bodies]))
+    assert np.array_equal(results[0], results[1])  # reference summation order: bit-exact
+    for i in range(inputs.n_objects):
+        assert syn.pose_errors(results[0][i], inputs.gt[i][inputs.n_frames - 1])[1] < 0.03
