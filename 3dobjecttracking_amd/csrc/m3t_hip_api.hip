@@ -1634,12 +1634,12 @@ int m3t_hip_get_kernel_timing(m3t_hip_context* ctx, float total_ms[2], int launc
   return M3T_OK;
 }
 #ifdef M3T_PHASE_TIMING
-int m3t_hip_debug_phase_cycles(m3t_hip_context* ctx, unsigned long long* out16, int reset) {
+int m3t_hip_debug_phase_cycles(m3t_hip_context* ctx, unsigned long long* out24, int reset) {
   CHECK_CTX();
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)));
+  HIPCHK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_phase_cycles), 24 * sizeof(unsigned long long)));
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[24] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
   }
   return M3T_OK;

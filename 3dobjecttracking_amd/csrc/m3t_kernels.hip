@@ -5,18 +5,22 @@
 // Kernel inventory:
 //   region_histogram_kernel   StartModality / CalculateResults: contour-line colour
 //                             sampling into an LDS count table + histogram blend
-//   region_correspondence_kernel  RegionModality::CalculateCorrespondences
+//   region_correspondence_kernel (+ _lds_: pair table staged in LDS for <= 16 bins)
+//                             RegionModality::CalculateCorrespondences
 //   region_gradient_hessian_kernel RegionModality::CalculateGradientAndHessian
 //   depth_correspondence_kernel / depth_gradient_hessian_kernel  DepthModality
 //   rigid_optimize_kernel     Optimizer::CalculateOptimization (dof 6) + Link::UpdatePoses
-//   tracking_step_kernel      the whole ExecuteTrackingStep loop nest fused on device
+//   tracking_step_kernel (+ _lds_, + _occ2_ 128-VGPR variants for batches > #CUs)
+//                             the whole ExecuteTrackingStep loop nest fused on device
+//   (kinematic structures: m3t_links.hip)
 //
 // Arithmetic follows the reference expression by expression in IEEE f32
 // (compile with -ffp-contract=off; hipcc's f32 divide / sqrt are correctly
 // rounded by default), so every discrete decision (pixel truncation, validity
 // tests, distribution index) matches the CPU restatement bit for bit; only
-// the order of the g/H sums over lines differs (tree instead of sequential).
-// Reference citations are relative to M3T/src/.
+// the order of the g/H sums over lines differs in the default mode (wave DPP
+// tree instead of sequential; m3t_hip_set_summation_mode(1) restores the
+// reference order).  Reference citations are relative to M3T/src/.
 
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -25,7 +29,7 @@
 
 #ifdef M3T_PHASE_TIMING
 // developer instrumentation: accumulated s_memtime cycles per phase, block 0 thread 0
-__device__ unsigned long long g_phase_cycles[16];
+__device__ unsigned long long g_phase_cycles[24];
 #define PHASE_T0() unsigned long long _pt = clock64()
 #define PHASE_MARK(i)                                                         \
   do {                                                                        \
@@ -161,15 +165,6 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_self_i(int v) {
   return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-  v += dpp_zero<0x111, 0xf>(v);
-  v += dpp_zero<0x112, 0xf>(v);
-  v += dpp_zero<0x114, 0xf>(v);
-  v += dpp_zero<0x118, 0xf>(v);
-  v += dpp_zero<0x142, 0xa>(v);
-  v += dpp_zero<0x143, 0xc>(v);
-  return v;
-}
 __device__ __forceinline__ int wave_sum_i(int v) {  // broadcast result
   v += dpp_zero_i<0x111, 0xf>(v);
   v += dpp_zero_i<0x112, 0xf>(v);
@@ -276,12 +271,27 @@ __device__ bool occlusion_window_clear(CCam& dc, float center_u, float center_v,
   u_max = min(u_max, dc.width - 1);
   v_max = min(v_max, dc.height - 1);
   unsigned short min_depth = (unsigned short)f2i((depth - depth_offset - threshold) / dc.depth_scale);
-  for (int v = v_min; v <= v_max; v += stride) {
-    G<unsigned short> row = (G<unsigned short>)(as_global(dc.image) + (uint32_t)v * dc.pitch);
-    for (int u = u_min; u <= u_max; u += stride) {
-      unsigned short d = row[u];
-      if (d > 0 && d < min_depth) return false;
+  // <= 6 x 6 samples; the result is an OR over all of them, so they are fetched in independent
+  // batches of 12 (no early exit inside a batch) instead of one dependent load per sample
+  G<uint8_t> image = as_global(dc.image);
+  const int n_u = u_max >= u_min ? (u_max - u_min) / stride + 1 : 0;
+  const int n_v = v_max >= v_min ? (v_max - v_min) / stride + 1 : 0;
+  const int total = n_u * n_v;
+  for (int base = 0; base < total; base += 12) {
+    unsigned short d[12];
+    int ui = base % n_u, vi = base / n_u;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      d[k] = 0;
+      if (base + k < total)
+        d[k] = *reinterpret_cast<G<unsigned short>>(image + (uint32_t)(v_min + vi * stride) * dc.pitch +
+                                                    (uint32_t)(u_min + ui * stride) * 2u);
+      if (++ui == n_u) { ui = 0; ++vi; }
     }
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) hit |= (d[k] > 0 && d[k] < min_depth);
+    if (hit) return false;
   }
   return true;
 }
@@ -1169,86 +1179,171 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
 // ---------------------------------------------------------------------------
 __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, int iteration,
                                       int corr_iteration, float* ps, int np, float* misc) {
+  // 16 lanes (one DPP row) per model point: the strided search window of FindCorrespondence
+  // (<= 15x15 depth samples) and the occlusion window (<= 6x6) are scanned by the row in
+  // parallel; the winner is the smallest distance, ties to the lowest scan index == the
+  // reference's "first strictly smaller in (v outer, u inner) order".
+  constexpr int kGroup = 16;
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int gl = tid % kGroup;
+  PHASE_T0();
   const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);
+  PHASE_MARK(17);
   int n_points = number_of_lines(m.n_points_max, m.use_adaptive_coverage, m.reference_surface_area, m.extents[view],
                                  m.max_extent, m.n_points);
   const float considered_distance0 = last_valid(m.considered_distances, m.n_considered_distances, corr_iteration);
   const int max_n_strides = f2i(considered_distance0 / m.stride_length + 0.5f);
   const bool occlusion_pass = m.measure_occlusions && (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
+  G<uint8_t> image = as_global(cam.image);
   int my_valid_occ = 0;
-  for (int i = tid; i < np; i += nt) {
+  const int np_round = (np + nt / kGroup - 1) / (nt / kGroup) * (nt / kGroup);
+  for (int i = tid / kGroup; i < np_round; i += nt / kGroup) {
     int flags = 0;
-    if (i < n_points) {
-      const float* p = m.points + ((size_t)view * m.n_points + i) * M3T_DEPTH_POINT_FLOATS;
-      G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + i) * 2;
-      const v4f pa = p8[0], pb4 = p8[1];
-      float cx = pa.x, cy = pa.y, cz = pa.z;
-      float X, Y, Z;
-      apply_pose(b2c, cx, cy, cz, X, Y, Z);
-      float center_u = X * cam.fu / Z + cam.ppu;
-      float center_v = Y * cam.fv / Z + cam.ppv;
-      float depth = Z;
-      bool valid = !(depth <= 0.0f);
-      if (valid) {
-        int icu = f2i(center_u + 0.5f), icv = f2i(center_v + 0.5f);
-        valid = !(icu < 0 || icu > cam.width - 1 || icv < 0 || icv > cam.height - 1);
-      }
-      // FindCorrespondence
-      float corr[3] = {0.0f, 0.0f, 0.0f};
-      if (valid) {
-        float cd = considered_distance0;
-        if (m.use_depth_scaling) cd *= depth;
-        float meter_to_pixel = cam.fu / depth;
-        float diameter = 2.0f * cd * meter_to_pixel;
-        int stride = f2i(diameter / max_n_strides + 1.0f);
-        int n_strides = f2i(diameter / stride + 0.5f);
-        int rounded_diameter = n_strides * stride;
-        float rounded_radius = 0.5f * (float)rounded_diameter;
-        int u_min = f2i(center_u - rounded_radius + 0.5f);
-        int v_min = f2i(center_v - rounded_radius + 0.5f);
-        int u_max = u_min + rounded_diameter;
-        int v_max = v_min + rounded_diameter;
-        u_min = max(u_min, 0);
-        v_min = max(v_min, 0);
-        u_max = min(u_max, cam.width - 1);
-        v_max = min(v_max, cam.height - 1);
-        float min_depth_value = fminf(0.0f, (depth - cd) / cam.depth_scale);
-        float max_depth_value = (depth + cd) / cam.depth_scale;
-        float min_considered = cd * cd;
-        float best = min_considered;
-        for (int v = v_min; v <= v_max; v += stride) {
-          G<unsigned short> row = (G<unsigned short>)(as_global(cam.image) + (uint32_t)v * cam.pitch);
-          for (int u = u_min; u <= u_max; u += stride) {
-            float d = (float)row[u];
-            if (d > min_depth_value && d < max_depth_value) {
-              d *= cam.depth_scale;
-              float t0 = ((float)u - cam.ppu) * d / cam.fu;
-              float t1 = ((float)v - cam.ppv) * d / cam.fv;
-              float e0 = t0 - X, e1 = t1 - Y, e2 = d - Z;
-              float dist2 = (e0 * e0 + e1 * e1) + e2 * e2;
-              if (dist2 < best) {
-                corr[0] = t0; corr[1] = t1; corr[2] = d;
-                best = dist2;
-              }
+    const bool in_model = i < n_points;
+    const int ip = in_model ? i : 0;
+    G<float> p = as_global(m.points) + ((size_t)view * m.n_points + ip) * M3T_DEPTH_POINT_FLOATS;
+    G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + ip) * 2;
+    const v4f pa = p8[0], pb4 = p8[1];
+    float cx = pa.x, cy = pa.y, cz = pa.z;
+    float X, Y, Z;
+    apply_pose(b2c, cx, cy, cz, X, Y, Z);
+    float center_u = X * cam.fu / Z + cam.ppu;
+    float center_v = Y * cam.fv / Z + cam.ppv;
+    float depth = Z;
+    bool valid = in_model && !(depth <= 0.0f);
+    if (valid) {
+      int icu = f2i(center_u + 0.5f), icv = f2i(center_v + 0.5f);
+      valid = !(icu < 0 || icu > cam.width - 1 || icv < 0 || icv > cam.height - 1);
+    }
+    // FindCorrespondence: window limits (uniform inside the row)
+    float cd = considered_distance0;
+    if (m.use_depth_scaling) cd *= depth;
+    int stride = 1, u_min = 0, v_min = 0, n_u = 0, n_v = 0;
+    if (valid) {
+      float meter_to_pixel = cam.fu / depth;
+      float diameter = 2.0f * cd * meter_to_pixel;
+      stride = f2i(diameter / max_n_strides + 1.0f);
+      int n_strides = f2i(diameter / stride + 0.5f);
+      int rounded_diameter = n_strides * stride;
+      float rounded_radius = 0.5f * (float)rounded_diameter;
+      u_min = f2i(center_u - rounded_radius + 0.5f);
+      v_min = f2i(center_v - rounded_radius + 0.5f);
+      int u_max = u_min + rounded_diameter;
+      int v_max = v_min + rounded_diameter;
+      u_min = max(u_min, 0);
+      v_min = max(v_min, 0);
+      u_max = min(u_max, cam.width - 1);
+      v_max = min(v_max, cam.height - 1);
+      if (stride < 1) stride = 1;
+      n_u = u_max >= u_min ? (u_max - u_min) / stride + 1 : 0;
+      n_v = v_max >= v_min ? (v_max - v_min) / stride + 1 : 0;
+    }
+    PHASE_MARK(18);
+    const float min_depth_value = fminf(0.0f, (depth - cd) / cam.depth_scale);
+    const float max_depth_value = (depth + cd) / cam.depth_scale;
+    const float min_considered = cd * cd;
+    float best = min_considered;
+    int best_pos = INT_MAX;
+    const int total = n_u * n_v;
+    {
+      // this lane's samples: pos = gl, gl + 16, ... in scan order; 8 loads in flight
+      int ui = 0, vi = 0;
+      if (n_u > 0) { vi = gl / n_u; ui = gl - vi * n_u; }
+      const int du = kGroup % (n_u > 0 ? n_u : 1), dvq = kGroup / (n_u > 0 ? n_u : 1);
+      for (int pos0 = gl; pos0 < total; pos0 += 8 * kGroup) {
+        unsigned short raw[8];
+        int us[8], vs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          us[k] = u_min + ui * stride;
+          vs[k] = v_min + vi * stride;
+          raw[k] = 0;
+          if (pos0 + k * kGroup < total)
+            raw[k] = *reinterpret_cast<G<unsigned short>>(image + (uint32_t)vs[k] * cam.pitch + (uint32_t)us[k] * 2u);
+          ui += du;
+          vi += dvq;
+          if (ui >= n_u) { ui -= n_u; ++vi; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (pos0 + k * kGroup >= total) continue;
+          float d = (float)raw[k];
+          if (d > min_depth_value && d < max_depth_value) {
+            d *= cam.depth_scale;
+            float t0 = ((float)us[k] - cam.ppu) * d / cam.fu;
+            float t1 = ((float)vs[k] - cam.ppv) * d / cam.fv;
+            float e0 = t0 - X, e1 = t1 - Y, e2 = d - Z;
+            float dist2 = (e0 * e0 + e1 * e1) + e2 * e2;
+            if (dist2 < best) {  // positions of one lane are visited in increasing scan order
+              best = dist2;
+              best_pos = pos0 + k * kGroup;
             }
           }
         }
-        valid = best != min_considered;
       }
-      bool valid_occ = valid;
-      if (valid && occlusion_pass) {
-        float radius = m.measured_depth_offset_radius;
-        if (m.use_depth_scaling) radius *= depth;
-        int id = f2i(radius / m.stride_depth_offset + 0.5f);
-        if (id >= M3T_N_DEPTH_OFFSETS) id = M3T_N_DEPTH_OFFSETS - 1;
-        float diameter = 2.0f * m.measured_occlusion_radius * cam.fu;
-        if (!m.use_depth_scaling) diameter /= depth;
-        float threshold = m.measured_occlusion_threshold;
-        if (m.use_depth_scaling) threshold *= depth;
-        valid_occ = occlusion_window_clear(cam, center_u, center_v, diameter, depth, p[6 + id], threshold);
+    }
+    PHASE_MARK(19);
+    // row reduction (min distance, lowest scan index); the result lands in lane 15 of the row
+#define M3T_ROW_MIN_STEP(CTRL)                                                  \
+    {                                                                         \
+      float ob = dpp_self<CTRL, 0xf>(best);                                   \
+      int op = dpp_self_i<CTRL, 0xf>(best_pos);                               \
+      if (ob < best || (ob == best && op < best_pos)) { best = ob; best_pos = op; } \
+    }
+    M3T_ROW_MIN_STEP(0x111)
+    M3T_ROW_MIN_STEP(0x112)
+    M3T_ROW_MIN_STEP(0x114)
+    M3T_ROW_MIN_STEP(0x118)
+#undef M3T_ROW_MIN_STEP
+    // measured occlusion (IsPointUnoccludedMeasured :736-776), the row ORs its samples
+    int occluded = 0;
+    if (occlusion_pass && valid) {
+      float radius = m.measured_depth_offset_radius;
+      if (m.use_depth_scaling) radius *= depth;
+      int id = f2i(radius / m.stride_depth_offset + 0.5f);
+      if (id >= M3T_N_DEPTH_OFFSETS) id = M3T_N_DEPTH_OFFSETS - 1;
+      float diameter = 2.0f * m.measured_occlusion_radius * cam.fu;
+      if (!m.use_depth_scaling) diameter /= depth;
+      float threshold = m.measured_occlusion_threshold;
+      if (m.use_depth_scaling) threshold *= depth;
+      int ostride = f2i(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
+      int n_strides = f2i(diameter / ostride + 0.5f);
+      int rounded_diameter = n_strides * ostride;
+      float rounded_radius = 0.5f * (float)rounded_diameter;
+      int ou_min = f2i(center_u - rounded_radius + 0.5f);
+      int ov_min = f2i(center_v - rounded_radius + 0.5f);
+      int ou_max = ou_min + rounded_diameter;
+      int ov_max = ov_min + rounded_diameter;
+      ou_min = max(ou_min, 0);
+      ov_min = max(ov_min, 0);
+      ou_max = min(ou_max, cam.width - 1);
+      ov_max = min(ov_max, cam.height - 1);
+      unsigned short min_depth = (unsigned short)f2i((depth - p[6 + id] - threshold) / cam.depth_scale);
+      int on_u = ou_max >= ou_min ? (ou_max - ou_min) / ostride + 1 : 0;
+      int on_v = ov_max >= ov_min ? (ov_max - ov_min) / ostride + 1 : 0;
+      for (int pos = gl; pos < on_u * on_v; pos += kGroup) {
+        int vi = pos / on_u, ui = pos - vi * on_u;
+        unsigned short d = *reinterpret_cast<G<unsigned short>>(
+            image + (uint32_t)(ov_min + vi * ostride) * cam.pitch + (uint32_t)(ou_min + ui * ostride) * 2u);
+        if (d > 0 && d < min_depth) occluded = 1;
       }
+    }
+    occluded |= dpp_self_i<0x111, 0xf>(occluded);
+    occluded |= dpp_self_i<0x112, 0xf>(occluded);
+    occluded |= dpp_self_i<0x114, 0xf>(occluded);
+    occluded |= dpp_self_i<0x118, 0xf>(occluded);
+    PHASE_MARK(20);
+    if (gl == kGroup - 1 && i < np) {  // lane 15 of the row owns the reduced result
+      valid = valid && best != min_considered;
       if (valid) {
+        // recompute the winning sample (same operations as in the scan)
+        int vi = best_pos / n_u, ui = best_pos - vi * n_u;
+        int u = u_min + ui * stride, v = v_min + vi * stride;
+        float d = (float)(*reinterpret_cast<G<unsigned short>>(image + (uint32_t)v * cam.pitch + (uint32_t)u * 2u));
+        d *= cam.depth_scale;
+        float t0 = ((float)u - cam.ppu) * d / cam.fu;
+        float t1 = ((float)v - cam.ppv) * d / cam.fv;
+        bool valid_occ = !occluded;
         flags = (valid_occ ? 1 : 0) | 2;
         my_valid_occ += valid_occ ? 1 : 0;
         ps[PS_CX * np + i] = cx; ps[PS_CY * np + i] = cy; ps[PS_CZ * np + i] = cz;
@@ -1256,10 +1351,11 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
         ps[PS_CENTER_U * np + i] = center_u;
         ps[PS_CENTER_V * np + i] = center_v;
         ps[PS_DEPTH * np + i] = depth;
-        ps[PS_CORR_X * np + i] = corr[0]; ps[PS_CORR_Y * np + i] = corr[1]; ps[PS_CORR_Z * np + i] = corr[2];
+        ps[PS_CORR_X * np + i] = t0; ps[PS_CORR_Y * np + i] = t1; ps[PS_CORR_Z * np + i] = d;
       }
+      ps[PS_VALID * np + i] = i2f_bits(flags);
     }
-    ps[PS_VALID * np + i] = i2f_bits(flags);
+    PHASE_MARK(21);
   }
   bool use_occ = false;
   if (occlusion_pass) {
@@ -1532,10 +1628,6 @@ __device__ __forceinline__ void stage_histogram(CRegion& m, float* lds_hist) {
   for (int i = threadIdx.x; i < n2; i += blockDim.x) lds_hist[i] = src[i];
 }
 
-__device__ __forceinline__ void copy_state(float* dst, const float* src, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-}
-
 }  // namespace
 
 // ===========================================================================
@@ -1718,8 +1810,10 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         region_correspondences<HIST_LDS>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s);
       }
       if (dm) {
+        PHASE_T0();
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
         depth_correspondences(*dm, *dcam, b2c, iteration, c, ps, np, s.misc);
+        PHASE_MARK(16);
       }
     }
     for (int u = 0; u < n_update_iterations; ++u) {

@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--sweep", type=str, default="", help="comma separated object counts for a batch sweep (extra)")
+    p.add_argument("--ycb", type=int, default=0,
+                   help="extra leg: N objects with Region+Depth fused modalities, YCB parameters (BASELINE configs[2])")
     return p.parse_args()
 
 
@@ -164,6 +166,10 @@ def main():
         for n in [int(x) for x in args.sweep.split(",") if x]:
             sweep.append(batch_point(pkg, scenes, n, args))
 
+    ycb = None
+    if rank == 0 and args.ycb:
+        ycb = ycb_point(pkg, scenes, args.ycb, args)
+
     # ---- CPU baseline: the oracle restatement, 1 thread, bounded sample (rank 0) ----
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -209,6 +215,8 @@ def main():
         }
         if sweep:
             out["batch_sweep"] = sweep
+        if ycb:
+            out["ycb_region_depth"] = ycb
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
@@ -231,6 +239,56 @@ def measured_traffic(kernel, n_obj):
         return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+B_ALG_YCB = 1094456  # Region + Depth with measured occlusions, YCB parameters
+
+
+def ycb_point(pkg, scenes, n_obj, args):
+    """BASELINE configs[2]-shaped leg: n_obj objects, Region + Depth (ICG), YCB parameters, 640x480"""
+    import util
+    hip = pkg.open_context(0)
+    K, W = 10, 3
+    n_frames = K + W + 1
+    inputs = scenes.Inputs(n_obj, n_frames, n_divides=args.n_divides, n_models=min(8, n_obj), with_depth=True)
+    inst = scenes.Instance(hip, inputs, use_depth=True)
+    for cams, frames in ((inst.color_cams, inputs.color), (inst.depth_cams, inputs.depth)):
+        for i, cam in enumerate(cams):
+            hip.call("camera_set_ring", cam.id, n_frames)
+            for k in range(n_frames):
+                f = frames[i][k]
+                hip.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+    hip.call("cameras_select_slot", 0)
+    hip.call("start_modalities", 0)
+    for k in range(1, 1 + W):
+        hip.call("cameras_select_slot", k)
+        hip.call("execute_tracking_step", k)
+    hip.call("sync")
+    t = time.perf_counter()
+    for k in range(1 + W, 1 + W + K):
+        hip.call("cameras_select_slot", k)
+        hip.call("execute_tracking_step", k)
+    hip.call("sync")
+    el = time.perf_counter() - t
+    poses = np.zeros((n_obj, 16), np.float32)
+    hip.call("bodies_get_poses", poses.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+    adds = [pkg.synthetic.add_s(inputs.vertices[i], poses[i].reshape(4, 4).T, inputs.gt[i][W + K]) for i in range(n_obj)]
+    # CPU restatement on the same objects / frames (1 thread)
+    ora = util.open_oracle()
+    oinst = scenes.Instance(ora, inputs, use_depth=True)
+    oinst.upload_frame(0)
+    oinst.tracker.StartModalities(0)
+    tc = 0.0
+    for k in range(1, 1 + W + K):
+        oinst.upload_frame(k)
+        t0 = time.perf_counter()
+        oinst.tracker.ExecuteTrackingStep(k)
+        tc += time.perf_counter() - t0
+    rate = n_obj * K / el
+    return {"objects": n_obj, "pose_updates_per_s": round(rate, 1), "ms_per_step": round(el / K * 1e3, 4),
+            "frac_of_hbm_roofline": round(rate * B_ALG_YCB / (HBM_PEAK_GBS * 1e9), 5),
+            "mean_add_s_vs_gt_m": round(float(np.mean(adds)), 5),
+            "cpu_port_pose_updates_per_s": round(n_obj * (W + K) / tc, 1)}
 
 
 def batch_point(pkg, scenes, n_obj, args):

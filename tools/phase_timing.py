@@ -8,14 +8,15 @@ pkg = importlib.import_module("3dobjecttracking_amd")
 import scenes
 lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "libm3t_hip_timing.so")
 n_obj = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+ycb = len(sys.argv) > 3 and sys.argv[3] == "ycb"
 hip = pkg.CApi(lib, "m3t_hip_")
 f = hip.lib.m3t_hip_debug_phase_cycles
 f.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-inputs = scenes.Inputs(n_obj, 8, n_divides=4, n_models=8)
-inst = scenes.Instance(hip, inputs)
+inputs = scenes.Inputs(n_obj, 8, n_divides=4, n_models=8, with_depth=ycb)
+inst = scenes.Instance(hip, inputs, use_depth=ycb)
 inst.upload_frame(0)
 inst.tracker.StartModalities(0)
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 24)()
 for k in range(1, 4):
     inst.upload_frame(k); inst.tracker.ExecuteTrackingStep(k)
 f(hip.ctx, buf, 1)
@@ -25,8 +26,8 @@ for k in range(4, 8):
 f(hip.ctx, buf, 1)
 names = ["view search", "phase A (lines)", "phase B (pixels)", "phase C1 (dist)", "phase C2 (moments)", "g/H", "solve",
          "  B: addr+issue", "  B: pixel wait", "  B: gather issue", "  B: gather wait", "  B: products",
-         "  solve: build", "  solve: LDLT", "  solve: trisolve", "  solve: expm"]
-tot = sum(buf[i] for i in range(7))
+         "  solve: build", "  solve: LDLT", "  solve: trisolve", "  solve: expm", "depth correspondences", "  d: view search", "  d: point setup", "  d: window scan", "  d: reduce+occlusion", "  d: write"]
+tot = sum(buf[i] for i in range(7)) + buf[16]
 for i, nme in enumerate(names):
     print("%-20s %10.0f cycles/frame  %5.1f%%" % (nme, buf[i] / n, 100.0 * buf[i] / tot))
 print("total %.0f cycles/frame" % (tot / n))
