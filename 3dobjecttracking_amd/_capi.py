@@ -244,6 +244,10 @@ _HIP_ONLY = {
     "bodies_set_poses": [c_float_p, C.c_int],
     "camera_set_ring": [C.c_int, C.c_int],
     "camera_upload_slot": [C.c_int, C.c_int, C.c_void_p, C.c_size_t],
+    "camera_upload_slot_async": [C.c_int, C.c_int, C.c_void_p, C.c_size_t],
+    "host_register": [C.c_void_p, C.c_size_t],
+    "host_unregister": [C.c_void_p],
+    "ingest_sync": [],
     "camera_select_slot": [C.c_int, C.c_int],
     "cameras_select_slot": [C.c_int],
     "set_summation_mode": [C.c_int],

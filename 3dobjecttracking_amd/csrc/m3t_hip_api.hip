@@ -62,6 +62,7 @@ struct Camera {
   size_t frame_bytes = 0;
   int n_slots = 1, current = 0;
   std::vector<bool> has_image;
+  std::vector<long> last_read_step;  // per slot: the last streaming step that read it (-1: none)
   DevMem ring;
 };
 
@@ -146,6 +147,16 @@ struct m3t_hip_context {
   size_t cam_stage_bytes = 0;
   hipEvent_t cam_stage_done[kStage] = {nullptr};
   int cam_stage_next = 0;
+  // asynchronous ingest: frame copies run on their own stream beside the tracking kernels
+  static constexpr int kStepEvents = 16;
+  static constexpr int kCopyStreams = 4;  // cameras are spread round-robin: per-copy DMA latencies overlap
+  hipStream_t copy_stream[kCopyStreams] = {nullptr};
+  hipEvent_t copies_done[kCopyStreams] = {nullptr};
+  hipEvent_t step_done[kStepEvents] = {nullptr};
+  bool async_ingest = false, untracked_launches = false;
+  unsigned copies_pending = 0;  // bit s: copy stream s has frames not yet ordered before the compute stream
+  long step_counter = 0, copy_waited_step[kCopyStreams] = {-1, -1, -1, -1};
+  std::vector<void*> registered;
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   struct Pending { hipEvent_t a, b; int which; };
@@ -298,6 +309,7 @@ int CreateCamera(Ctx* ctx, const m3t_intrinsics* intr, const float* w2c, bool de
   c->frame_bytes = size_t(c->pitch) * intr->height;
   c->n_slots = 1;
   c->has_image.assign(1, false);
+  c->last_read_step.assign(1, -1);
   HIPCHK(c->ring.alloc(c->frame_bytes + 64));  // +64: pixels are fetched as one 4-byte load (B,G,R,+1)
   ctx->cameras.push_back(std::move(c));
   ctx->cams_dirty = true;
@@ -486,6 +498,15 @@ int UploadTreeTables(Ctx* ctx) {
 }
 
 int UploadTables(Ctx* ctx) {
+  if (ctx->copies_pending) {
+    // frames enqueued on the copy stream so far become visible to everything launched from here on
+    for (int k = 0; k < Ctx::kCopyStreams; ++k) {
+      if (!(ctx->copies_pending >> k & 1u)) continue;
+      HIPCHK(hipEventRecord(ctx->copies_done[k], ctx->copy_stream[k]));
+      HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->copies_done[k], 0));
+    }
+    ctx->copies_pending = 0;
+  }
   if (ctx->cams_dirty || ctx->tables_dirty) {
     std::vector<CameraDev> cams(ctx->cameras.size());
     for (size_t i = 0; i < cams.size(); ++i) {
@@ -731,6 +752,7 @@ int LaunchOptimization(Ctx* ctx) {
 }
 
 int Prepare(Ctx* ctx, bool need_images) {
+  if (ctx->async_ingest) ctx->untracked_launches = true;  // execute_tracking_step undoes this for itself
   if (need_images) {
     int r = CheckImages(ctx);
     if (r) return r;
@@ -785,6 +807,16 @@ void m3t_hip_destroy(m3t_hip_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
+  for (auto& cs : ctx->copy_stream) {
+    if (!cs) continue;
+    (void)hipStreamSynchronize(cs);
+    (void)hipStreamDestroy(cs);
+  }
+  for (void* p : ctx->registered) (void)hipHostUnregister(p);
+  for (auto& e : ctx->copies_done)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->step_done)
+    if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < m3t_hip_context::kStage; ++i) {
     if (ctx->cam_stage[i]) (void)hipHostFree(ctx->cam_stage[i]);
     if (ctx->cam_stage_done[i]) (void)hipEventDestroy(ctx->cam_stage_done[i]);
@@ -923,6 +955,7 @@ int m3t_hip_camera_set_ring(m3t_hip_context* ctx, int id, int n_slots) {
   c.n_slots = n_slots;
   c.current = 0;
   c.has_image.assign(n_slots, false);
+  c.last_read_step.assign(n_slots, -1);
   ctx->cams_dirty = true;
   return M3T_OK;
 }
@@ -930,6 +963,68 @@ int m3t_hip_camera_upload_slot(m3t_hip_context* ctx, int id, int slot, const voi
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));
   return UploadFrame(ctx, id, slot, pixels, row_step);
+}
+int m3t_hip_host_register(m3t_hip_context* ctx, void* ptr, size_t bytes) {
+  CHECK_CTX();
+  REQUIRE(ptr && bytes, M3T_ERR_INVALID_ARGUMENT, "null buffer");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  ctx->registered.push_back(ptr);
+  return M3T_OK;
+}
+int m3t_hip_host_unregister(m3t_hip_context* ctx, void* ptr) {
+  CHECK_CTX();
+  auto it = std::find(ctx->registered.begin(), ctx->registered.end(), ptr);
+  REQUIRE(it != ctx->registered.end(), M3T_ERR_INVALID_ARGUMENT, "buffer was not registered with this context");
+  HIPCHK(hipSetDevice(ctx->device));
+  for (auto& cs : ctx->copy_stream)
+    if (cs) HIPCHK(hipStreamSynchronize(cs));
+  HIPCHK(hipHostUnregister(ptr));
+  ctx->registered.erase(it);
+  return M3T_OK;
+}
+int m3t_hip_camera_upload_slot_async(m3t_hip_context* ctx, int id, int slot, const void* pixels, size_t row_step) {
+  CHECK_CTX();
+  REQUIRE(id >= 0 && id < int(ctx->cameras.size()) && pixels, M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+  Camera& c = *ctx->cameras[id];
+  REQUIRE(slot >= 0 && slot < c.n_slots, M3T_ERR_INVALID_ARGUMENT, "bad frame slot");
+  size_t row = size_t(c.intr.width) * (c.is_depth ? 2 : 3);
+  REQUIRE(row_step >= row, M3T_ERR_INVALID_ARGUMENT, "row_step smaller than one image row");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->async_ingest) {
+    for (auto& cs : ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    for (auto& e : ctx->copies_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : ctx->step_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->async_ingest = true;
+    ctx->untracked_launches = true;  // whatever ran before was not tracked by step events
+  }
+  const int cs = id % Ctx::kCopyStreams;
+  if (ctx->untracked_launches) {
+    // sub-step launches (or anything before the first asynchronous upload) carry no step event
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->untracked_launches = false;
+  } else if (c.last_read_step[slot] > ctx->copy_waited_step[cs]) {
+    // overwrite only after the last step that read this slot (a recycled event is a later step: still
+    // safe); a copy stream is in order, so one wait per step covers all of its cameras
+    HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->step_done[c.last_read_step[slot] % Ctx::kStepEvents], 0));
+    ctx->copy_waited_step[cs] = c.last_read_step[slot];
+  }
+  uint8_t* dst = c.ring.as<uint8_t>() + size_t(slot) * c.frame_bytes;
+  if (row_step == c.pitch)  // contiguous on both sides: one linear DMA transfer
+    HIPCHK(hipMemcpyAsync(dst, pixels, c.frame_bytes - (c.pitch - row), hipMemcpyHostToDevice, ctx->copy_stream[cs]));
+  else
+    HIPCHK(hipMemcpy2DAsync(dst, c.pitch, pixels, row_step, row, c.intr.height, hipMemcpyHostToDevice,
+                            ctx->copy_stream[cs]));
+  c.has_image[slot] = true;
+  ctx->copies_pending |= 1u << cs;
+  return M3T_OK;
+}
+int m3t_hip_ingest_sync(m3t_hip_context* ctx) {
+  CHECK_CTX();
+  HIPCHK(hipSetDevice(ctx->device));
+  for (auto& cs : ctx->copy_stream)
+    if (cs) HIPCHK(hipStreamSynchronize(cs));
+  return M3T_OK;
 }
 int m3t_hip_camera_select_slot(m3t_hip_context* ctx, int id, int slot) {
   CHECK_CTX();
@@ -1563,8 +1658,10 @@ int m3t_hip_calculate_results(m3t_hip_context* ctx, int iteration) {
 int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));
+  const bool untracked_before = ctx->untracked_launches;
   int r = Prepare(ctx, true);
   if (r) return r;
+  ctx->untracked_launches = untracked_before;  // a whole step is tracked by its step_done event below
   if (ctx->fused_mode >= 1 && ctx->fused_possible) {
     int n = int(ctx->opt_table.size());
     ScopedKernelTimer timer(ctx, 0);
@@ -1590,7 +1687,15 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     }
     ctx->state_valid = true;
   }
-  return LaunchHistogram(ctx, iteration, false);
+  if ((r = LaunchHistogram(ctx, iteration, false))) return r;
+  if (ctx->async_ingest) {
+    // remember which frame slots this step reads, so that a later asynchronous upload into one of
+    // them waits for exactly this step and not for the ones enqueued after it
+    HIPCHK(hipEventRecord(ctx->step_done[ctx->step_counter % Ctx::kStepEvents], ctx->stream));
+    for (auto& cam : ctx->cameras) cam->last_read_step[cam->current] = ctx->step_counter;
+    ++ctx->step_counter;
+  }
+  return M3T_OK;
 }
 int m3t_hip_execute_tracking_cycle(m3t_hip_context* ctx, int iteration) {
   return m3t_hip_execute_tracking_step(ctx, iteration);

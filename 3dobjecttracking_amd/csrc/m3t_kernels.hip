@@ -243,10 +243,12 @@ __device__ int closest_view(G<v4f> orientations4, int n_views, const Affine& b2c
 }
 
 // RegionModality::CalculateCorrespondences :417-430 (adaptive coverage)
-__device__ __forceinline__ int number_of_lines(int n_max, int adaptive, float reference, float extent, float max_extent,
-                                               int n_points) {
+template <typename ExtentPtr>
+__device__ __forceinline__ int number_of_lines(int n_max, int adaptive, float reference, ExtentPtr extents, int view,
+                                               float max_extent, int n_points) {
   int n = n_max;
-  if (adaptive) {
+  if (adaptive) {  // only then the view's contour length / surface area is fetched
+    const float extent = extents[view];
     if (reference > 0.0f) n = (int)((float)n_max * fminf(1.0f, extent / reference));
     else n = (int)((float)n_max * extent / max_extent);
   }
@@ -563,7 +565,7 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, s.misc);  // (syncs publish the lookups)
   PHASE_MARK(0);
   const int n_lines =
-      number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length, m.extents[view],
+      number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length, as_global(m.extents), view,
                       m.max_extent, m.n_points);
   const bool occlusion_pass =
       m.measure_occlusions && (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
@@ -1189,7 +1191,7 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
   PHASE_T0();
   const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);
   PHASE_MARK(17);
-  int n_points = number_of_lines(m.n_points_max, m.use_adaptive_coverage, m.reference_surface_area, m.extents[view],
+  int n_points = number_of_lines(m.n_points_max, m.use_adaptive_coverage, m.reference_surface_area, as_global(m.extents), view,
                                  m.max_extent, m.n_points);
   const float considered_distance0 = last_valid(m.considered_distances, m.n_considered_distances, corr_iteration);
   const int max_n_strides = f2i(considered_distance0 / m.stride_length + 0.5f);
@@ -1469,7 +1471,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
   for (int i = tid; i < n_bins3; i += nt) counts[i] = 0;
   const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
   const int n_lines = number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length,
-                                      m.extents[view], m.max_extent, m.n_points);
+                                      as_global(m.extents), view, m.max_extent, m.n_points);
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = n_bins * n_bins;
   const int w1 = cam.width - 1, h1 = cam.height - 1;
   // two lanes per line: even lane = foreground walk (inwards), odd lane = background walk

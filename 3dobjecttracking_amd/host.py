@@ -69,6 +69,20 @@ class Tracker:
     def ExecuteTrackingStep(self, iteration):
         return self._step("execute_tracking_step", iteration)
 
+    # asynchronous ingest (HIP library only)
+    def register_host_buffer(self, array):
+        """page-lock a caller-owned frame buffer so that asynchronous uploads overlap the tracking kernels"""
+        self.api.call("host_register", array.ctypes.data_as(C.c_void_p), array.nbytes)
+
+    def unregister_host_buffer(self, array):
+        self.api.call("host_unregister", array.ctypes.data_as(C.c_void_p))
+
+    def select_slot(self, slot):
+        self.api.call("cameras_select_slot", slot)
+
+    def ingest_sync(self):
+        self.api.call("ingest_sync")
+
     def ExecuteTrackingCycle(self, iteration):  # ICG/RBGT/SRT3D name
         return self._step("execute_tracking_cycle", iteration)
 
@@ -105,6 +119,23 @@ class _Camera:
             a = np.ascontiguousarray(a)
         self.api.call("camera_upload", self.id, a.ctypes.data_as(C.c_void_p), a.strides[0])
         return True
+
+    # device-side frame ring + asynchronous ingest (HIP library only)
+    def set_ring(self, n_slots):
+        self.api.call("camera_set_ring", self.id, n_slots)
+
+    def upload_slot(self, slot, image, asynchronous=False):
+        """Stage `image` into ring slot `slot`.  With asynchronous=True the call returns at once and
+        the array must stay alive and unchanged until Tracker.ingest_sync() (page-lock it once with
+        Tracker.register_host_buffer for a true overlapped copy)."""
+        a = np.asarray(image)
+        assert a.shape[0] == self.height and a.shape[1] == self.width
+        assert a.strides[1] == self.bpp, "asynchronous uploads borrow the buffer: it must be pixel-contiguous"
+        self.api.call("camera_upload_slot_async" if asynchronous else "camera_upload_slot", self.id, slot,
+                      a.ctypes.data_as(C.c_void_p), a.strides[0])
+
+    def select_slot(self, slot):
+        self.api.call("camera_select_slot", self.id, slot)
 
     def set_world2camera_pose(self, pose):
         self.api.call("camera_set_world2camera_pose", self.id, fptr(pose_arg(pose)))

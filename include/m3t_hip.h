@@ -78,6 +78,18 @@ int m3t_hip_camera_set_ring(m3t_hip_context*, int camera_id, int n_slots);
 int m3t_hip_camera_upload_slot(m3t_hip_context*, int camera_id, int slot, const void* pixels, size_t row_step);
 int m3t_hip_camera_select_slot(m3t_hip_context*, int camera_id, int slot);
 int m3t_hip_cameras_select_slot(m3t_hip_context*, int slot); /* all cameras */
+/* asynchronous ingest (replaces the blocking cv::Mat hand-over of Camera::UpdateImage,
+ * camera.h:32-88, for callers that keep their frames in page-locked memory).  upload_slot_async enqueues
+ * the copy on the context's copy stream and returns; `pixels` must stay valid until ingest_sync() or
+ * the next sync() after a step that used the slot.  Copies already enqueued are visible to every step
+ * launched after them; a slot is overwritten only after the last execute_tracking_step that read it.
+ * The natural double-buffer loop is: select_slot(k%2); execute_tracking_step(k); upload_slot_async((k+1)%2).
+ * Buffers that are not page-locked still work but the copy is then staged synchronously by the runtime;
+ * host_register page-locks a caller-owned buffer once (e.g. the capture ring). */
+int m3t_hip_host_register(m3t_hip_context*, void* ptr, size_t bytes);
+int m3t_hip_host_unregister(m3t_hip_context*, void* ptr);
+int m3t_hip_camera_upload_slot_async(m3t_hip_context*, int camera_id, int slot, const void* pixels, size_t row_step);
+int m3t_hip_ingest_sync(m3t_hip_context*); /* wait until all enqueued frame copies have landed */
 
 /* ---- Bodies (body.h:46: only body2world_pose crosses the boundary) ------------ */
 int m3t_hip_body_create(m3t_hip_context*, const float body2world[16]);

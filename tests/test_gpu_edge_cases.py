@@ -176,3 +176,44 @@ def test_bodies_sharing_one_camera():
     assert np.array_equal(results[0], results[1])  # reference summation order: bit-exact
     for i in range(inputs.n_objects):
         assert syn.pose_errors(results[0][i], inputs.gt[i][inputs.n_frames - 1])[1] < 0.03
+
+
+def test_async_ingest_matches_blocking_upload():
+    """double-buffered asynchronous ingest (page-locked frames, copy stream, slot recycling) gives
+    the bit-identical pose sequence of the blocking Camera::UpdateImage hand-over"""
+    n_frames = 7
+    inputs = scenes.Inputs(3, n_frames, n_divides=2)
+    poses = []
+    for asynchronous in (False, True):
+        hip = util.open_hip()
+        inst = scenes.Instance(hip, inputs)
+        inst.upload_frame(0)
+        assert inst.tracker.StartModalities(0)
+        seq = []
+        if not asynchronous:
+            for k in range(1, n_frames):
+                inst.upload_frame(k)
+                assert inst.tracker.ExecuteTrackingStep(k)
+                seq.append(inst.poses())
+        else:
+            # one page-locked block per frame index, all cameras
+            blocks = [np.stack([inputs.color[i][k] for i in range(inputs.n_objects)]) for k in range(n_frames)]
+            for b in blocks:
+                inst.tracker.register_host_buffer(b)
+            for cam in inst.color_cams:
+                cam.set_ring(2)
+            for i, cam in enumerate(inst.color_cams):
+                cam.upload_slot(1, blocks[1][i], asynchronous=True)
+            for k in range(1, n_frames):
+                inst.tracker.select_slot(k % 2)
+                assert inst.tracker.ExecuteTrackingStep(k)
+                if k + 1 < n_frames:  # overlaps step k; recycles the slot step k-1 read
+                    for i, cam in enumerate(inst.color_cams):
+                        cam.upload_slot((k + 1) % 2, blocks[k + 1][i], asynchronous=True)
+                seq.append(None)  # poses fetched at the end: no host sync inside the loop
+            inst.tracker.ingest_sync()
+            seq[-1] = inst.poses()
+            for b in blocks:
+                inst.tracker.unregister_host_buffer(b)
+        poses.append(seq)
+    assert np.array_equal(poses[0][-1], poses[1][-1])
