@@ -81,6 +81,13 @@ class Camera {
   void set_world2camera_pose(const Pose& p) {
     c_->Check(m3t_hip_camera_set_world2camera_pose(c_->get(), id_, p.data()), "Camera");
   }
+  // device-side frame ring and asynchronous ingest (m3t_hip.h: camera_set_ring ... ingest_sync)
+  void SetRing(int n_slots) { c_->Check(m3t_hip_camera_set_ring(c_->get(), id_, n_slots), "Camera"); }
+  bool UploadSlot(int slot, const void* pixels, size_t row_step, bool asynchronous = false) {
+    return c_->Step(asynchronous ? m3t_hip_camera_upload_slot_async(c_->get(), id_, slot, pixels, row_step)
+                                 : m3t_hip_camera_upload_slot(c_->get(), id_, slot, pixels, row_step));
+  }
+  bool SelectSlot(int slot) { return c_->Step(m3t_hip_camera_select_slot(c_->get(), id_, slot)); }
   int id() const { return id_; }
 
  protected:
