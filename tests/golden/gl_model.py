@@ -1,0 +1,488 @@
+"""Sparse-viewpoint-model generation without OpenGL, for closed CONVEX meshes.
+
+TEST INFRASTRUCTURE.  The reference generates its region / depth models by rendering the body
+with OpenGL from 2562 geodesic viewpoints and sampling the rendered images
+(region_model.cpp:187-258,457-555, depth_model.cpp:144-212,302-351, model.cpp:338-410).
+The goldens of its modality tests (data/modality_test/*_{gradient,hessian}.txt) were produced
+with models of data/_body/triangle.obj that are NOT shipped, so pinning the oracle's modality
+arithmetic against those goldens needs the models to be regenerated.  This module restates the
+generation with a software rasteriser that follows the OpenGL rules the reference relies on
+(pixel centres at integer image coordinates, renderer.cpp:257-264; 1/256 sub-pixel snapping,
+top-left fill rule, 16-bit depth, RGBA8 flat normals, normal_renderer.cpp:11-31,148-153) and
+OpenCV's border following (cv::findContours, RETR_LIST / CHAIN_APPROX_NONE) for the contour
+order, so that the same mt19937{7} draws select the same pixels.  It is validated against the
+reference's own generated models data/model_test/{region,depth}_model.bin (n_divides 2,
+10 points, 162 views) in tests/test_model_generation.py.
+"""
+import struct
+
+import numpy as np
+
+F = np.float32
+K_MAIN_BODY_ID = 255
+REGION_POINT_FLOATS = 38
+DEPTH_POINT_FLOATS = 36
+N_DEPTH_OFFSETS = 30
+K_CONTOUR_NORMAL_APPROX_RADIUS = 3  # region_model.h:62
+K_MIN_CONTOUR_LENGTH = 15           # region_model.h:63
+K_MAX_POINT_SAMPLING_TRIES = 100    # region_model.h:64
+K_IMAGE_SIZE_SAFETY_BOUNDARY = 20   # model.h:57
+FLT_MAX = np.finfo(np.float32).max
+
+
+# ---- files ------------------------------------------------------------------------------------
+def load_obj(path):
+    """'v x y z' and 'f a//n b//n c//n' records (body.cpp:196-240, tiny_obj_loader)"""
+    verts, faces = [], []
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "v":
+            verts.append([float(x) for x in t[1:4]])
+        elif t[0] == "f":
+            faces.append([int(x.split("/")[0]) - 1 for x in t[1:4]])
+    return np.asarray(verts, F), np.asarray(faces, np.int64)
+
+
+def read_model_bin(path, region):
+    """model.cpp:218-284, region_model.cpp:259-307, depth_model.cpp:215-283"""
+    b = open(path, "rb").read()
+    off = 0
+
+    def rd(fmt):
+        nonlocal off
+        v = struct.unpack_from("<" + fmt, b, off)
+        off += struct.calcsize("<" + fmt)
+        return v if len(v) > 1 else v[0]
+
+    def skip_body():
+        nonlocal off
+        n = rd("Q")
+        off += n + 4 + 1 + 1 + 4 + 64
+
+    hdr = dict(type=rd("c"), version=rd("i"), sphere_radius=rd("f"), n_divides=rd("i"), n_points=rd("i"),
+               max_radius_depth_offset=rd("f"), stride_depth_offset=rd("f"), use_random_seed=rd("B"),
+               image_size=rd("i"))
+    skip_body()
+    n_assoc = rd("Q")
+    if region:
+        for _ in range(4):
+            for _ in range(rd("Q")):
+                skip_body()
+    else:
+        for _ in range(n_assoc):
+            skip_body()
+    n_views = rd("Q")
+    pf = REGION_POINT_FLOATS if region else DEPTH_POINT_FLOATS
+    n = hdr["n_points"]
+    pts = np.zeros((n_views, n, pf), F)
+    ori = np.zeros((n_views, 3), F)
+    ext = np.zeros(n_views, F)
+    for v in range(n_views):
+        pts[v] = np.frombuffer(b, F, n * pf, off).reshape(n, pf)
+        off += n * pf * 4
+        ori[v] = np.frombuffer(b, F, 3, off)
+        off += 12
+        ext[v] = np.frombuffer(b, F, 1, off)[0]
+        off += 4
+    assert off == len(b), (off, len(b))
+    return dict(hdr, points=pts, orientations=ori, extents=ext)
+
+
+# ---- geodesic viewpoints (model.cpp:386-454) -----------------------------------------------------
+def _normalized(v):
+    v = np.asarray(v, F)
+    # Eigen's unrolled reduction splits in halves: x^2 + (y^2 + z^2)  (bit-exact against the
+    # orientations stored in the reference's model files)
+    n = F(np.sqrt(F(F(v[0] * v[0]) + F(F(v[1] * v[1]) + F(v[2] * v[2])))))
+    return (v / n).astype(F)
+
+
+def geodesic_points(n_divides):
+    x, z = F(0.525731112119133606), F(0.850650808352039932)
+    o = F(0.0)
+    ico = [(-x, o, z), (x, o, z), (-x, o, -z), (x, o, -z), (o, z, x), (o, z, -x), (o, -z, x), (o, -z, -x),
+           (z, x, o), (-z, x, o), (z, -x, o), (-z, -x, o)]
+    ico = [np.asarray(p, F) for p in ico]
+    ids = [(0, 4, 1), (0, 9, 4), (9, 5, 4), (4, 5, 8), (4, 8, 1), (8, 10, 1), (8, 3, 10), (5, 3, 8), (5, 2, 3),
+           (2, 7, 3), (7, 10, 3), (7, 6, 10), (7, 11, 6), (11, 0, 6), (0, 1, 6), (6, 1, 10), (9, 0, 11),
+           (9, 11, 2), (9, 2, 5), (7, 2, 11)]
+    pts = {}
+
+    def subdivide(v1, v2, v3, n):
+        if n == 0:
+            for v in (v1, v2, v3):
+                pts[(float(v[0]), float(v[1]), float(v[2]))] = v
+            return
+        v12, v13, v23 = _normalized(v1 + v2), _normalized(v1 + v3), _normalized(v2 + v3)
+        subdivide(v1, v12, v13, n - 1)
+        subdivide(v2, v12, v23, n - 1)
+        subdivide(v3, v13, v23, n - 1)
+        subdivide(v12, v13, v23, n - 1)
+
+    for a, b, c in ids:
+        subdivide(ico[a], ico[b], ico[c], n_divides)
+    # std::set with CompareSmallerVector3f: lexicographic order, exact duplicates collapse
+    return [pts[k] for k in sorted(pts)]
+
+
+def geodesic_poses(n_divides, sphere_radius):
+    """camera2body poses, 4x4 float32"""
+    poses = []
+    for p in geodesic_points(n_divides):
+        R = np.zeros((3, 3), F)
+        m = (-p).astype(F)
+        R[:, 2] = m
+        if p[0] == 0.0 and p[2] == 0.0:
+            R[:, 0] = (1, 0, 0)
+        else:
+            R[:, 0] = _normalized(np.asarray([m[2], F(0.0), -m[0]], F))  # (0,1,0) x m
+        R[:, 1] = np.cross(R[:, 2], R[:, 0]).astype(F)
+        T = np.eye(4, dtype=F)
+        T[:3, :3] = R
+        T[:3, 3] = (p * F(sphere_radius)).astype(F)
+        poses.append(T)
+    return poses
+
+
+# ---- the renderer -----------------------------------------------------------------------------
+class ConvexBody:
+    def __init__(self, obj_path, geometry2body):
+        self.vertices, self.faces = load_obj(obj_path)
+        self.geometry2body = np.asarray(geometry2body, F)
+        v = (self.vertices @ self.geometry2body[:3, :3].T + self.geometry2body[:3, 3]).astype(F)
+        self.maximum_body_diameter = F(2.0) * F(np.max(np.sqrt(np.sum(v.astype(F) ** 2, axis=1, dtype=F))))
+        # flat normal of every triangle, RendererGeometry::AssembleVertexData renderer_geometry.cpp:193-207
+        p = self.vertices[self.faces]
+        n = np.cross(p[:, 2] - p[:, 1], p[:, 0] - p[:, 1]).astype(F)
+        self.normals = (n / np.sqrt(np.sum(n * n, axis=1, dtype=F))[:, None]).astype(F)
+
+
+class Render:
+    """One view: silhouette mask, 16-bit depth image, RGBA8 flat-normal image"""
+
+    def __init__(self, body, camera2body, sphere_radius, image_size, subpixel_bits=8, quant_bias=0.04):
+        S = image_size
+        d = body.maximum_body_diameter
+        # Model::SetUpRenderer model.cpp:120-153
+        self.fu = F(0.5) * F(S - K_IMAGE_SIZE_SAFETY_BOUNDARY) / F(np.tan(np.arcsin(F(0.5) * d / F(sphere_radius))))
+        self.pp = F(S) / F(2.0)
+        self.size = S
+        z_min = F(sphere_radius) - d * F(0.5)
+        z_max = F(sphere_radius) + d * F(0.5)
+        self.term_a = z_max * z_min * F(65535.0) / (z_max - z_min)  # renderer.cpp:475-478
+        self.term_b = z_max * F(65535.0) / (z_max - z_min)
+        fu, pp = self.fu, self.pp
+        P = np.array([[F(2.0) * fu / F(S), 0, F(2.0) * (pp + F(0.5)) / F(S) - F(1.0), 0],
+                      [0, F(2.0) * fu / F(S), F(2.0) * (pp + F(0.5)) / F(S) - F(1.0), 0],
+                      [0, 0, (z_max + z_min) / (z_max - z_min), F(-2.0) * z_max * z_min / (z_max - z_min)],
+                      [0, 0, 1, 0]], F)
+        c2b = np.asarray(camera2body, F)
+        w2c = np.eye(4, dtype=F)
+        w2c[:3, :3] = np.linalg.inv(c2b[:3, :3].astype(np.float64)).astype(F)
+        w2c[:3, 3] = -(w2c[:3, :3] @ c2b[:3, 3]).astype(F)
+        twp = (w2c @ body.geometry2body).astype(F)
+        trans = (P @ twp).astype(F)
+        rot = twp[:3, :3]
+        vh = np.concatenate([body.vertices, np.ones((len(body.vertices), 1), F)], axis=1)
+        clip = (vh @ trans.T).astype(F)
+        ndc = (clip[:, :3] / clip[:, 3:4]).astype(F)
+        win = np.empty_like(ndc)
+        win[:, 0] = (ndc[:, 0] + F(1.0)) * F(0.5 * S)
+        win[:, 1] = (ndc[:, 1] + F(1.0)) * F(0.5 * S)
+        win[:, 2] = (ndc[:, 2] + F(1.0)) * F(0.5)
+        sub = 1 << subpixel_bits
+        snapped = np.floor(win[:, :2].astype(np.float64) * sub + 0.5).astype(np.int64)
+        self.mask = np.zeros((S, S), np.uint8)
+        self.depth = np.full((S, S), 65535, np.uint16)
+        self.normal = np.zeros((S, S, 4), np.uint8)
+        zbuf = np.full((S, S), np.inf)
+        half = sub // 2
+        for f, (a, b, c) in enumerate(body.faces):
+            xa, ya = snapped[a]
+            xb, yb = snapped[b]
+            xc, yc = snapped[c]
+            area = (xb - xa) * (yc - ya) - (yb - ya) * (xc - xa)
+            if area == 0:
+                continue
+            # the mesh is counter-clockwise seen from outside; the image's y axis points down, so faces
+            # turned towards the camera have negative area here (glFrontFace(CCW) + glCullFace(FRONT))
+            if area > 0:
+                continue
+            tri = [(xa, ya), (xc, yc), (xb, yb)]  # re-ordered to positive area
+            zs = [win[a, 2], win[c, 2], win[b, 2]]
+            x0 = max(int(min(xa, xb, xc) // sub) - 1, 0)
+            x1 = min(int(max(xa, xb, xc) // sub) + 1, S - 1)
+            y0 = max(int(min(ya, yb, yc) // sub) - 1, 0)
+            y1 = min(int(max(ya, yb, yc) // sub) + 1, S - 1)
+            if x1 < x0 or y1 < y0:
+                continue
+            px = (np.arange(x0, x1 + 1, dtype=np.int64) * sub + half)[None, :]
+            py = (np.arange(y0, y1 + 1, dtype=np.int64) * sub + half)[:, None]
+            inside = np.ones((y1 - y0 + 1, x1 - x0 + 1), bool)
+            es = []
+            for k in range(3):
+                (ax, ay), (bx, by) = tri[k], tri[(k + 1) % 3]
+                e = (bx - ax) * (py - ay) - (by - ay) * (px - ax)
+                # top-left rule (y down): an edge owns its pixels if it is a top edge (horizontal, interior
+                # below) or a left edge (going up)
+                dx, dy = bx - ax, by - ay
+                owns = (dy < 0) or (dy == 0 and dx > 0)
+                inside &= (e > 0) | ((e == 0) & owns)
+                es.append(e)
+            if not inside.any():
+                continue
+            a2 = float(-area)
+            # barycentric weights of vertex k are the edge functions of the opposite edge
+            w0 = es[1] / a2
+            w1 = es[2] / a2
+            w2 = es[0] / a2
+            z = w0 * float(zs[0]) + w1 * float(zs[1]) + w2 * float(zs[2])
+            sl = (slice(y0, y1 + 1), slice(x0, x1 + 1))
+            closer = inside & (z < zbuf[sl])
+            zbuf[sl][closer] = z[closer]
+            self.mask[sl][closer] = K_MAIN_BODY_ID
+            n_cam = (rot @ body.normals[f]).astype(F)
+            col = np.float64(0.5) - np.float64(0.5) * n_cam.astype(np.float64)
+            rgba = np.floor(np.clip(col, 0, 1) * 255.0 + 0.5 - quant_bias).astype(np.uint8)
+            self.normal[sl][closer] = (rgba[0], rgba[1], rgba[2], 255)
+        cov = self.mask > 0
+        zq = zbuf[cov] * 65535.0
+        self.depth[cov] = np.floor(zq + 0.5 - quant_bias).astype(np.uint16)
+
+    def depth_of_value(self, value):
+        return self.term_a / (self.term_b - F(value))
+
+    def depth_at(self, x, y):
+        return self.depth_of_value(self.depth[y, x])
+
+    def point_vector(self, x, y):  # FullDepthRenderer::PointVector renderer.cpp:445-452
+        d = self.depth_at(x, y)
+        return np.asarray([d * (F(x) - self.pp) / self.fu, d * (F(y) - self.pp) / self.fu, d], F)
+
+    def normal_vector(self, x, y):  # FullNormalRenderer::NormalVector normal_renderer.cpp:264-270
+        v = self.normal[y, x]
+        return np.asarray([F(1.0) - F(v[0]) / F(127.5), F(1.0) - F(v[1]) / F(127.5), F(1.0) - F(v[2]) / F(127.5)], F)
+
+
+# ---- cv::findContours for one 8-connected outer border ---------------------------------------------
+_DELTAS = [(1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1)]  # chain codes 0..7, y down
+
+
+def find_contours(mask):
+    """cv::findContours(RETR_LIST, CHAIN_APPROX_NONE): Suzuki-Abe border following as OpenCV
+    implements it (icvFindNextContour / icvFetchContour): raster scan, an outer border starts at an
+    unvisited 1-pixel whose left neighbour is 0, a hole border at a 0-pixel whose left neighbour is a
+    positive pixel.  Returned in OpenCV's order (RETR_LIST links every new contour at the head of
+    the list: last found first)."""
+    h, w = mask.shape
+    img = np.zeros((h + 2, w + 2), np.int32)
+    img[1:-1, 1:-1] = (mask != 0)
+    contours = []
+    nbd = 1
+    # only columns where the value changes along a row can start a border
+    ys, xs = np.nonzero(img[:, 1:] != img[:, :-1])
+    xs = xs + 1
+    order = np.lexsort((xs, ys))
+    for y, x in zip(ys[order].tolist(), xs[order].tolist()):
+        p, prev = img[y, x], img[y, x - 1]
+        if prev == 0 and p == 1:
+            is_hole = False
+        elif p == 0 and prev >= 1:
+            is_hole = True
+        else:
+            continue
+        nbd += 1
+        pts = _fetch_contour(img, x - (1 if is_hole else 0), y, is_hole, nbd)
+        contours.append([(px - 1, py - 1) for px, py in pts])
+    return contours[::-1]
+
+
+def _fetch_contour(img, x0, y0, is_hole, nbd):
+    s_end = s = 0 if is_hole else 4
+    while True:
+        s = (s - 1) & 7
+        dx, dy = _DELTAS[s]
+        if img[y0 + dy, x0 + dx] != 0 or s == s_end:
+            break
+    pts = []
+    if s == s_end and img[y0 + _DELTAS[s][1], x0 + _DELTAS[s][0]] == 0:
+        img[y0, x0] = -nbd
+        return [(x0, y0)]
+    x1, y1 = x0 + _DELTAS[s][0], y0 + _DELTAS[s][1]
+    x3, y3 = x0, y0
+    while True:
+        s_end = s
+        while True:
+            s += 1
+            dx, dy = _DELTAS[s & 7]
+            if img[y3 + dy, x3 + dx] != 0:
+                break
+        s &= 7
+        # mark: right neighbour background examined -> negative mark
+        if (s - 1) & 0xFFFFFFFF < (s_end & 0xFFFFFFFF):  # unsigned compare as in OpenCV
+            img[y3, x3] = -nbd
+        elif img[y3, x3] == 1:
+            img[y3, x3] = nbd
+        pts.append((x3, y3))
+        x4, y4 = x3 + _DELTAS[s][0], y3 + _DELTAS[s][1]
+        if (x4, y4) == (x0, y0) and (x3, y3) == (x1, y1):
+            break
+        x3, y3 = x4, y4
+        s = (s + 4) & 7
+    return pts
+
+
+# ---- model generation ---------------------------------------------------------------------------
+def mt19937(seed):
+    """std::mt19937{seed}: raw 32-bit outputs"""
+    bg = np.random.RandomState(seed)._bit_generator
+    while True:
+        for v in bg.random_raw(4096):
+            yield int(v)
+
+
+def _transform(c2b, p):
+    """Eigen's Transform3fA * Vector3f in float32: ((R_i0 x + R_i1 y) + R_i2 z) + t_i"""
+    out = np.empty(3, F)
+    for i in range(3):
+        out[i] = F(F(F(c2b[i, 0] * p[0]) + F(c2b[i, 1] * p[1])) + F(c2b[i, 2] * p[2])) + c2b[i, 3]
+    return out
+
+
+def depth_offsets(r, x, y, pixel_to_meter, max_radius_depth_offset, stride_depth_offset):
+    """Model::CalculateDepthOffsets model.cpp:338-384"""
+    n_values = int(F(max_radius_depth_offset) / F(stride_depth_offset) + F(1.0))
+    stride = F(stride_depth_offset) / F(pixel_to_meter)
+    max_diameter = F(2.0) * F(n_values) * stride
+    image_stride = int(stride + F(1.0))
+    n_image_strides = int(max_diameter / F(image_stride) + F(1.0))
+    image_diameter = n_image_strides * image_stride
+    rm = image_diameter // 2
+    rp = image_diameter - rm
+    v_min, v_max = max(y - rm, 0), min(y + rp, r.size - 1)
+    u_min, u_max = max(x - rm, 0), min(x + rp, r.size - 1)
+    vs = np.arange(v_min, v_max + 1, image_stride)
+    us = np.arange(u_min, u_max + 1, image_stride)
+    sub = r.depth[np.ix_(vs, us)]
+    dist = np.sqrt(((us[None, :] - x) ** 2 + (vs[:, None] - y) ** 2).astype(F)).astype(F)
+    idx = (dist / stride).astype(F).astype(np.int64)
+    mins = np.full(N_DEPTH_OFFSETS, 65535, np.int64)
+    mins[0] = r.depth[y, x]
+    ok = idx < n_values
+    np.minimum.at(mins, idx[ok], sub[ok].astype(np.int64))
+    mins = np.minimum.accumulate(mins)
+    dc = r.depth_at(x, y)
+    return np.asarray([dc - r.depth_of_value(m) for m in mins], F)
+
+
+def depth_view(body, camera2body, sphere_radius, n_points, image_size, max_radius_depth_offset=0.05,
+               stride_depth_offset=0.002, **render_kw):
+    """DepthModel::GeneratePointData depth_model.cpp:302-351"""
+    r = Render(body, camera2body, sphere_radius, image_size, **render_kw)
+    c2b = np.asarray(camera2body, F)
+    n_pix = int(np.count_nonzero(r.mask))
+    area = F(n_pix) * F(F(sphere_radius) / r.fu) ** 2
+    pts = np.zeros((n_points, DEPTH_POINT_FLOATS), F)
+    if n_pix == 0:
+        return pts, (-c2b[:3, 2] * 0 + c2b[:3, 2]), F(0.0), r
+    gen = mt19937(7)
+    total = image_size * image_size
+    for i in range(n_points):
+        while True:
+            idx = next(gen) % total
+            x, y = idx // image_size, idx % image_size
+            if r.mask[y, x]:
+                break
+        pc = r.point_vector(x, y)
+        nc = r.normal_vector(x, y)
+        pts[i, 0:3] = _transform(c2b, pc)
+        pts[i, 3:6] = (c2b[:3, :3] @ nc).astype(F)
+        pts[i, 6:] = depth_offsets(r, x, y, pc[2] / r.fu, max_radius_depth_offset, stride_depth_offset)
+    return pts, c2b[:3, 2].copy(), area, r
+
+
+def _closest_contour_point(cont_xy, u, v):
+    d = np.hypot(cont_xy[:, 0].astype(F) - F(u), cont_xy[:, 1].astype(F) - F(v)).astype(F)
+    k = int(np.argmin(d))  # first minimum wins, as the strict '<' of FindClosestContourPoint
+    return cont_xy[k]
+
+
+def region_view(body, camera2body, sphere_radius, n_points, image_size, max_radius_depth_offset=0.05,
+                stride_depth_offset=0.002, **render_kw):
+    """RegionModel::GeneratePointData region_model.cpp:457-555 (single body: no associated renderers)"""
+    r = Render(body, camera2body, sphere_radius, image_size, **render_kw)
+    c2b = np.asarray(camera2body, F)
+    pts = np.zeros((n_points, REGION_POINT_FLOATS), F)
+    contours = [c for c in find_contours(r.mask) if len(c) >= K_MIN_CONTOUR_LENGTH]
+    valid = [p for c in contours for p in c]  # IsContourPointValid is always true for a single body
+    pixel_to_meter = F(sphere_radius) / r.fu
+    contour_length = F(len(valid)) * pixel_to_meter
+    if not valid:
+        return pts, c2b[:3, 2].copy(), F(0.0), r
+    all_xy = np.asarray([p for c in contours for p in c], np.int64)
+    gen = mt19937(7)
+    i = 0
+    n_tries = 0
+    while i < n_points:
+        n_tries += 1
+        if n_tries - 1 > K_MAX_POINT_SAMPLING_TRIES:
+            return pts, c2b[:3, 2].copy(), F(0.0), r
+        cx, cy = valid[next(gen) % len(valid)]
+        pc = r.point_vector(cx, cy)
+        # CalculateContourSegment region_model.cpp:649-685
+        seg = None
+        for c in contours:
+            try:
+                k = c.index((cx, cy))
+            except ValueError:
+                continue
+            s, e = k - K_CONTOUR_NORMAL_APPROX_RADIUS, k + K_CONTOUR_NORMAL_APPROX_RADIUS
+            seg = []
+            if s < 0:
+                seg += c[len(c) + s:]
+                s = 0
+            if e >= len(c):
+                seg += c[s:]
+                s = 0
+                e -= len(c)
+            seg += c[s:e + 1]
+            break
+        if seg is None:
+            continue
+        if not (np.hypot(F(seg[-1][0] - seg[0][0]), F(seg[-1][1] - seg[0][1])) > F(K_CONTOUR_NORMAL_APPROX_RADIUS)):
+            continue
+        nrm = np.asarray([-F(seg[-1][1] - seg[0][1]), F(seg[-1][0] - seg[0][0])], F)
+        nrm = (nrm / F(np.sqrt(F(nrm[0] * nrm[0]) + F(nrm[1] * nrm[1])))).astype(F)
+        pts[i, 0:3] = _transform(c2b, pc)
+        pts[i, 3:6] = (c2b[:3, :3] @ np.asarray([nrm[0], nrm[1], 0], F)).astype(F)
+        p2m = pc[2] / r.fu
+        # CalculateLineDistances region_model.cpp:695-770
+        if abs(nrm[1]) < abs(nrm[0]):
+            u_step, v_step = F(np.sign(nrm[0])), nrm[1] / abs(nrm[0])
+        else:
+            u_step, v_step = nrm[0] / abs(nrm[1]), F(np.sign(nrm[1]))
+        u_in = u_out = F(cx) + F(0.5)
+        v_in = v_out = F(cy) + F(0.5)
+        while True:
+            u_in = F(u_in - u_step)
+            v_in = F(v_in - v_step)
+            if r.mask[int(v_in), int(u_in)] != K_MAIN_BODY_ID:
+                q = _closest_contour_point(all_xy, u_in + u_step - F(0.5), v_in + v_step - F(0.5))
+                pts[i, 6] = p2m * F(np.hypot(F(q[0] - cx), F(q[1] - cy)))
+                break
+        while True:
+            u_out = F(u_out + u_step)
+            v_out = F(v_out + v_step)
+            if int(u_out) < 0 or int(u_out) >= image_size or int(v_out) < 0 or int(v_out) >= image_size:
+                pts[i, 7] = FLT_MAX
+                break
+            if r.mask[int(v_out), int(u_out)] == K_MAIN_BODY_ID:
+                q = _closest_contour_point(all_xy, u_out - F(0.5), v_out - F(0.5))
+                pts[i, 7] = p2m * F(np.hypot(F(q[0] - cx), F(q[1] - cy)))
+                break
+        pts[i, 8:] = depth_offsets(r, cx, cy, p2m, max_radius_depth_offset, stride_depth_offset)
+        i += 1
+        n_tries = 0
+    return pts, c2b[:3, 2].copy(), contour_length, r

@@ -1,0 +1,90 @@
+"""tests/golden/gl_model.py (OpenGL-free sparse-viewpoint-model generation) against
+the reference's own generated models data/model_test/{region,depth}_model.bin (schauma bottle,
+n_divides 2, 10 points per view, image_size 500; RegionModelTest / DepthModelTest
+GenerateAndLoadModel, test/model_test.cpp:165-184): view orientations bit-exact, silhouette pixel
+counts and contour lengths exact, every sampled point the same pixel (centres equal to the last
+16-bit depth step), normals and line distances equal."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+sys.path.insert(0, os.path.join(util.ROOT, "tests", "golden"))
+import gl_model as g  # noqa: E402
+import make_triangle_views as mtv  # noqa: E402
+
+SCHAUMA_GEOMETRY2BODY = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, -0.097], [0, 0, 0, 1]]  # data/_body/schauma.yaml
+DEPTH_LSB = 4.5e-6   # one 16-bit depth step at these distances, metres
+NORMAL_LSB = 1.0 / 127.5
+VIEWS = list(range(0, 162, 18)) + [161]
+
+
+@pytest.fixture(scope="module")
+def schauma():
+    return g.ConvexBody(os.path.join(util.GOLDEN, "_body/schauma.obj"), SCHAUMA_GEOMETRY2BODY)
+
+
+@pytest.mark.parametrize("region", [True, False])
+def test_geodesic_orientations_bit_exact(region):
+    m = g.read_model_bin(os.path.join(util.GOLDEN, "model_test", "region_model.bin" if region else "depth_model.bin"),
+                         region)
+    poses = g.geodesic_poses(m["n_divides"], m["sphere_radius"])
+    assert len(poses) == 162 == len(m["orientations"])
+    assert np.array_equal(np.asarray([p[:3, 2] for p in poses]), m["orientations"])
+
+
+def test_region_views_match_reference_model(schauma):
+    m = g.read_model_bin(os.path.join(util.GOLDEN, "model_test/region_model.bin"), True)
+    poses = g.geodesic_poses(m["n_divides"], m["sphere_radius"])
+    n_exact = n_total = 0
+    for v in VIEWS:
+        pts, ori, length, r = g.region_view(schauma, poses[v], m["sphere_radius"], m["n_points"], m["image_size"],
+                                            m["max_radius_depth_offset"], m["stride_depth_offset"])
+        ref = m["points"][v]
+        p2m = m["sphere_radius"] / r.fu
+        assert round(float(length / p2m)) == round(float(m["extents"][v] / p2m))  # contour pixel count
+        dc = np.abs(pts[:, :3] - ref[:, :3]).max(axis=1)
+        assert dc.max() < DEPTH_LSB
+        n_exact += int((dc < 5e-8).sum())
+        n_total += len(dc)
+        assert np.abs(pts[:, 3:6] - ref[:, 3:6]).max() < 3e-7        # contour normals
+        assert np.abs(pts[:, 6] - ref[:, 6]).max() < 2e-6            # foreground distance
+        assert np.array_equal(pts[:, 7] == g.FLT_MAX, ref[:, 7] == g.FLT_MAX)
+        fin = ref[:, 7] != g.FLT_MAX
+        assert np.abs(pts[fin, 7] - ref[fin, 7]).max(initial=0) < 2e-6
+        assert np.abs(pts[:, 8:] - ref[:, 8:]).max() < 2 * DEPTH_LSB  # depth offsets: a difference of two depths
+    assert n_exact >= 0.9 * n_total  # the rest sits one depth step away
+
+
+def test_depth_views_match_reference_model(schauma):
+    m = g.read_model_bin(os.path.join(util.GOLDEN, "model_test/depth_model.bin"), False)
+    poses = g.geodesic_poses(m["n_divides"], m["sphere_radius"])
+    n_exact = n_normal_exact = n_total = n_mask_exact = 0
+    for v in VIEWS:
+        pts, ori, area, r = g.depth_view(schauma, poses[v], m["sphere_radius"], m["n_points"], m["image_size"],
+                                         m["max_radius_depth_offset"], m["stride_depth_offset"])
+        ref = m["points"][v]
+        p2m2 = (m["sphere_radius"] / r.fu) ** 2
+        d_pix = abs(round(float(area / p2m2)) - round(float(m["extents"][v] / p2m2)))  # silhouette pixel count
+        assert d_pix <= 1  # of 30 000 - 70 000; an edge through a pixel centre to within the 1/256 snapping
+        n_mask_exact += int(d_pix == 0)
+        dc = np.abs(pts[:, :3] - ref[:, :3]).max(axis=1)
+        dn = np.abs(pts[:, 3:6] - ref[:, 3:6]).max(axis=1)
+        assert dc.max() < DEPTH_LSB and dn.max() < 1.01 * NORMAL_LSB
+        n_exact += int((dc < 5e-8).sum())
+        n_normal_exact += int((dn < 1e-6).sum())
+        n_total += len(dc)
+        assert np.abs(pts[:, 6:] - ref[:, 6:]).max() < 2 * DEPTH_LSB
+    assert n_exact >= 0.9 * n_total and n_normal_exact >= 0.9 * n_total
+    assert n_mask_exact >= len(VIEWS) - 1
+
+
+def test_triangle_views_fixture_is_reproducible():
+    out = mtv.generate()
+    ref = np.load(os.path.join(util.ROOT, "tests", "golden", "triangle_views.npz"))
+    for k in ("region_views", "region_points", "region_orientations", "region_contour_lengths", "depth_views",
+              "depth_points", "depth_orientations", "depth_surface_areas"):
+        assert np.array_equal(out[k], ref[k]), k
