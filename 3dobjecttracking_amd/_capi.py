@@ -213,6 +213,9 @@ _SIGNATURES = {
     "optimizer_create": [C.c_int, C.c_float, C.c_float],
     "optimizer_create_rigid": [C.c_int, C.c_int, c_int_p, C.c_float, C.c_float],
     "constraint_create": [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p],
+    "soft_constraint_create": [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, C.c_float, C.c_float,
+                               C.c_float, C.c_float],
+    "set_soft_constraints_active": [C.c_int],
     "link_get_link2world_pose": [C.c_int, c_float_p],
     "link_set_joint_poses": [C.c_int, c_float_p, c_float_p],
     "link_get_joint_poses": [C.c_int, c_float_p, c_float_p],

@@ -96,10 +96,14 @@ struct ConstraintH {
   float body12joint1[16], body22joint2[16];
   int directions[6];
 };
+struct SoftConstraintH {
+  ConstraintH joint;
+  float max_distance_rotation, max_distance_translation, standard_deviation_rotation, standard_deviation_translation;
+};
 struct Optimizer {
   int link;
   float tr, tt;
-  std::vector<int> constraints;
+  std::vector<int> constraints, soft_constraints;
   std::vector<int> order;  // global link ids, depth first (parents before children)
   int dof = 0, n_rows = 0;
   size_t partial_offset = 0;
@@ -120,10 +124,12 @@ struct m3t_hip_context {
   std::vector<ModalityRef> modalities;
   std::vector<Link> links;
   std::vector<ConstraintH> constraints;
+  std::vector<SoftConstraintH> soft_constraints;
+  bool soft_constraints_active = true;
   std::vector<Optimizer> optimizers;
   bool tree_mode = false;          // any kinematic tree / constraint -> links_* kernels
   bool links_device_newer = false;  // joint poses on the device are ahead of the host mirror
-  DevMem d_links, d_constraints, d_treeopts, d_work, d_partial;
+  DevMem d_links, d_constraints, d_soft, d_treeopts, d_work, d_partial;
   size_t partial_count = 0;
   bool partial_ready = false;
   int n_corr_iterations = 5, n_update_iterations = 2;
@@ -412,8 +418,10 @@ int UploadTreeTables(Ctx* ctx) {
   if (r) return r;
   std::vector<LinkDev> links;
   std::vector<ConstraintDev> cons;
+  std::vector<SoftConstraintDev> soft;
   std::vector<TreeOptDev> opts(ctx->optimizers.size());
-  std::vector<size_t> link_off(ctx->optimizers.size()), con_off(ctx->optimizers.size()), work_off(ctx->optimizers.size());
+  std::vector<size_t> link_off(ctx->optimizers.size()), con_off(ctx->optimizers.size()), work_off(ctx->optimizers.size()),
+      soft_off(ctx->optimizers.size());
   size_t work_total = 0, partial_total = 0;
   for (auto& l : ctx->links) { l.optimizer = -1; l.local_index = -1; }
   for (size_t oi = 0; oi < ctx->optimizers.size(); ++oi) {
@@ -465,6 +473,23 @@ int UploadTreeTables(Ctx* ctx) {
       o.n_rows += d.n;
       cons.push_back(d);
     }
+    soft_off[oi] = soft.size();
+    for (int sid : o.soft_constraints) {
+      const SoftConstraintH& c = ctx->soft_constraints[sid];
+      REQUIRE(ctx->links[c.joint.link1].optimizer == int(oi) && ctx->links[c.joint.link2].optimizer == int(oi),
+              M3T_ERR_INVALID_ARGUMENT, "soft constraint links must belong to the optimizer's structure");
+      SoftConstraintDev d{};
+      d.joint.link1 = ctx->links[c.joint.link1].local_index;
+      d.joint.link2 = ctx->links[c.joint.link2].local_index;
+      std::memcpy(d.joint.body12joint1, c.joint.body12joint1, 64);
+      std::memcpy(d.joint.body22joint2, c.joint.body22joint2, 64);
+      for (int i = 0; i < 6; ++i) { d.joint.directions[i] = c.joint.directions[i]; d.joint.n += c.joint.directions[i] ? 1 : 0; }
+      d.max_distance_rotation = c.max_distance_rotation;
+      d.max_distance_translation = c.max_distance_translation;
+      d.standard_deviation_rotation = c.standard_deviation_rotation;
+      d.standard_deviation_translation = c.standard_deviation_translation;
+      soft.push_back(d);
+    }
     work_off[oi] = work_total;
     work_total += tree_work_floats(int(o.order.size()), dof, o.n_rows);
     o.partial_offset = partial_total;
@@ -472,6 +497,7 @@ int UploadTreeTables(Ctx* ctx) {
   }
   HIPCHK(ctx->d_links.alloc(std::max<size_t>(1, links.size()) * sizeof(LinkDev)));
   HIPCHK(ctx->d_constraints.alloc(std::max<size_t>(1, cons.size()) * sizeof(ConstraintDev)));
+  HIPCHK(ctx->d_soft.alloc(std::max<size_t>(1, soft.size()) * sizeof(SoftConstraintDev)));
   HIPCHK(ctx->d_treeopts.alloc(std::max<size_t>(1, opts.size()) * sizeof(TreeOptDev)));
   HIPCHK(ctx->d_work.alloc(std::max<size_t>(1, work_total) * 4));
   HIPCHK(ctx->d_partial.alloc(std::max<size_t>(1, partial_total) * 4));
@@ -486,6 +512,8 @@ int UploadTreeTables(Ctx* ctx) {
     d.n_constraints = int(o.constraints.size());
     d.constraints = ctx->d_constraints.as<ConstraintDev>() + con_off[oi];
     d.n_rows = o.n_rows;
+    d.n_soft = ctx->soft_constraints_active ? int(o.soft_constraints.size()) : 0;
+    d.soft = ctx->d_soft.as<SoftConstraintDev>() + soft_off[oi];
     d.tikhonov_rotation = o.tr;
     d.tikhonov_translation = o.tt;
     d.work = ctx->d_work.as<float>() + work_off[oi];
@@ -493,6 +521,7 @@ int UploadTreeTables(Ctx* ctx) {
   }
   if (!links.empty()) HIPCHK(hipMemcpy(ctx->d_links.p, links.data(), links.size() * sizeof(LinkDev), hipMemcpyHostToDevice));
   if (!cons.empty()) HIPCHK(hipMemcpy(ctx->d_constraints.p, cons.data(), cons.size() * sizeof(ConstraintDev), hipMemcpyHostToDevice));
+  if (!soft.empty()) HIPCHK(hipMemcpy(ctx->d_soft.p, soft.data(), soft.size() * sizeof(SoftConstraintDev), hipMemcpyHostToDevice));
   if (!opts.empty()) HIPCHK(hipMemcpy(ctx->d_treeopts.p, opts.data(), opts.size() * sizeof(TreeOptDev), hipMemcpyHostToDevice));
   return M3T_OK;
 }
@@ -556,7 +585,8 @@ int UploadTables(Ctx* ctx) {
     // kinematic structures (m3t_links.hip) as soon as one optimizer is more than a free rigid body
     ctx->tree_mode = false;
     for (auto& o : ctx->optimizers)
-      if (!ctx->links[o.link].simple || !ctx->links[o.link].children.empty() || !o.constraints.empty())
+      if (!ctx->links[o.link].simple || !ctx->links[o.link].children.empty() || !o.constraints.empty() ||
+          !o.soft_constraints.empty())
         ctx->tree_mode = true;
     if (ctx->tree_mode) {
       int r = UploadTreeTables(ctx);
@@ -1525,6 +1555,39 @@ int m3t_hip_constraint_create(m3t_hip_context* ctx, int optimizer, int link1, in
   ctx->optimizers[optimizer].constraints.push_back(int(ctx->constraints.size()) - 1);
   ctx->tables_dirty = true;
   return int(ctx->constraints.size()) - 1;
+}
+int m3t_hip_soft_constraint_create(m3t_hip_context* ctx, int optimizer, int link1, int link2, const float b1[16],
+                                   const float b2[16], const int dirs[6], float max_distance_rotation,
+                                   float max_distance_translation, float standard_deviation_rotation,
+                                   float standard_deviation_translation) {
+  CHECK_CTX();
+  REQUIRE(optimizer >= 0 && optimizer < int(ctx->optimizers.size()) && link1 >= 0 && link2 >= 0 &&
+              link1 < int(ctx->links.size()) && link2 < int(ctx->links.size()) && dirs,
+          M3T_ERR_INVALID_ARGUMENT, "bad soft constraint arguments");
+  REQUIRE(standard_deviation_rotation > 0.0f && standard_deviation_translation > 0.0f, M3T_ERR_INVALID_ARGUMENT,
+          "standard deviations must be positive");
+  SoftConstraintH c{};
+  c.joint.link1 = link1;
+  c.joint.link2 = link2;
+  std::memcpy(c.joint.body12joint1, b1 ? b1 : kIdentity, 64);
+  std::memcpy(c.joint.body22joint2, b2 ? b2 : kIdentity, 64);
+  for (int i = 0; i < 6; ++i) c.joint.directions[i] = dirs[i] != 0;
+  c.max_distance_rotation = max_distance_rotation;
+  c.max_distance_translation = max_distance_translation;
+  c.standard_deviation_rotation = standard_deviation_rotation;
+  c.standard_deviation_translation = standard_deviation_translation;
+  ctx->soft_constraints.push_back(c);
+  ctx->optimizers[optimizer].soft_constraints.push_back(int(ctx->soft_constraints.size()) - 1);
+  ctx->tables_dirty = true;
+  return int(ctx->soft_constraints.size()) - 1;
+}
+int m3t_hip_set_soft_constraints_active(m3t_hip_context* ctx, int active) {
+  CHECK_CTX();
+  if (ctx->soft_constraints_active != (active != 0)) {
+    ctx->soft_constraints_active = active != 0;
+    ctx->tables_dirty = true;
+  }
+  return M3T_OK;
 }
 int m3t_hip_link_get_link2world_pose(m3t_hip_context* ctx, int link, float pose[16]) {
   CHECK_CTX();

@@ -31,6 +31,11 @@ struct ConstraintDev {
   int directions[6];
   int n;  // number of constrained directions
 };
+struct SoftConstraintDev {  // soft_constraint.h
+  ConstraintDev joint;
+  float max_distance_rotation, max_distance_translation;
+  float standard_deviation_rotation, standard_deviation_translation;
+};
 struct TreeOptDev {
   int n_links;
   LinkDev* links;
@@ -38,6 +43,8 @@ struct TreeOptDev {
   int n_constraints;
   ConstraintDev* constraints;
   int n_rows;  // sum of constraint rows
+  int n_soft;  // soft constraints (0 while they are switched off for this process)
+  SoftConstraintDev* soft;
   float tikhonov_rotation, tikhonov_translation;
   float* work;     // scratch, layout in tree_work_floats()
   float* partial;  // [dof*dof | dof]
@@ -217,6 +224,68 @@ __device__ void ldlt_solve_dynamic(float* a, float* x, int n, float* temp, int* 
 
 }  // namespace
 
+// SoftConstraint::AddGradientsAndHessiansToLink soft_constraint.cpp:220-272, one residual group
+// (rotation: directions 0-2, translation: 3-5); gh = link gradient[6] | hessian[36]
+__device__ void soft_constraint_add_group(const SoftConstraintDev& sc, bool rotation, const Affine& joint22joint1,
+                                          const Affine& body2joint1, float sign, float* g, float* h) {
+  ConstraintDev group = sc.joint;
+  group.n = 0;
+  for (int d = 0; d < 6; ++d) {
+    group.directions[d] = sc.joint.directions[d] && ((d < 3) == rotation);
+    group.n += group.directions[d] ? 1 : 0;
+  }
+  const int n = group.n;
+  if (n == 0) return;
+  float full[3];
+  if (rotation) {
+    float angle, axis[3];
+    angle_axis(joint22joint1.l, &angle, axis);
+    for (int k = 0; k < 3; ++k) full[k] = angle * axis[k];
+  } else {
+    for (int k = 0; k < 3; ++k) full[k] = joint22joint1.t[k];
+  }
+  float v[3] = {0.0f, 0.0f, 0.0f};
+  for (int d = 0, idx = 0; d < 3; ++d)
+    if (group.directions[d + (rotation ? 0 : 3)]) v[idx++] = full[d];
+  const float squared = n == 1 ? v[0] * v[0] : (n == 2 ? v[0] * v[0] + v[1] * v[1] : v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]));
+  const float distance = sqrtf(squared);
+  const float max_distance = rotation ? sc.max_distance_rotation : sc.max_distance_translation;
+  const float sd = rotation ? sc.standard_deviation_rotation : sc.standard_deviation_translation;
+  if (!(distance > max_distance)) return;
+  float jac[18];
+  constraint_unprojected_jacobian(group, joint22joint1, body2joint1, jac);
+  float vn[3], r[3];
+  for (int k = 0; k < n; ++k) {
+    vn[k] = v[k] / distance;
+    r[k] = v[k] - vn[k] * max_distance;
+  }
+  const float cg = sign / (sd * sd), ch = 1.0f / (sd * sd), ratio = max_distance / distance;
+  float mm[9];
+  for (int c = 0; c < n; ++c)
+    for (int k = 0; k < n; ++k) {
+      float id = k == c ? 1.0f : 0.0f;
+      mm[c * 3 + k] = id - ratio * (id - vn[k] * vn[c]);
+    }
+  for (int i = 0; i < 6; ++i) {
+    float s = 0.0f;
+    for (int k = 0; k < n; ++k) s += (cg * jac[i * n + k]) * r[k];
+    g[i] -= s;
+  }
+  float jm[18];
+  for (int c = 0; c < n; ++c)
+    for (int i = 0; i < 6; ++i) {
+      float s = 0.0f;
+      for (int k = 0; k < n; ++k) s += (ch * jac[i * n + k]) * mm[c * 3 + k];
+      jm[c * 6 + i] = s;
+    }
+  for (int c = 0; c < 6; ++c)
+    for (int i = 0; i < 6; ++i) {
+      float s = 0.0f;
+      for (int k = 0; k < n; ++k) s += jm[k * 6 + i] * jac[c * n + k];
+      h[c * 6 + i] -= s;
+    }
+}
+
 extern "C" {
 
 // Optimizer::CalculateDataLinks (:281-296) + AddProjectedGradientsAndHessians (:309-321)
@@ -256,6 +325,26 @@ __global__ void links_project_kernel(const TreeOptDev* opts, int n_opts, const f
     for (int i = 0; i < 42; ++i) gh[i] = 0.0f;
     for (int m = 0; m < l.n_gh; ++m)
       for (int i = 0; i < 42; ++i) gh[i] += l.gh[m][i];
+  }
+  // SoftConstraint::AddGradientsAndHessiansToLinks soft_constraint.cpp:113-131 (optimizer.cpp:283-284)
+  for (int si = 0; si < o.n_soft; ++si) {
+    const SoftConstraintDev& sc = o.soft[si];
+    Affine b12j1 = load_pose(sc.joint.body12joint1);
+    Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(link_pose(o.links[sc.joint.link1], body_poses))),
+                                   link_pose(o.links[sc.joint.link2], body_poses));
+    Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(sc.joint.body22joint2)));
+    for (int which = 0; which < 2; ++which) {
+      float g[6], h[36];
+      for (int i = 0; i < 6; ++i) g[i] = 0.0f;
+      for (int i = 0; i < 36; ++i) h[i] = 0.0f;
+      const Affine& body2joint1 = which == 0 ? b12j1 : body22joint1;
+      const float sign = which == 0 ? -1.0f : 1.0f;
+      soft_constraint_add_group(sc, true, joint22joint1, body2joint1, sign, g, h);
+      soft_constraint_add_group(sc, false, joint22joint1, body2joint1, sign, g, h);
+      float* gh = gh_all + (size_t)(which == 0 ? sc.joint.link1 : sc.joint.link2) * 42;
+      for (int i = 0; i < 6; ++i) gh[i] += g[i];
+      for (int i = 0; i < 36; ++i) gh[6 + i] += h[i];
+    }
   }
   float* A = o.partial;
   float* b = o.partial + (size_t)dof * dof;

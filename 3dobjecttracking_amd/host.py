@@ -327,6 +327,19 @@ class Constraint:
                            fptr(pose_arg(body22joint2_pose)), iptr(cd))
 
 
+class SoftConstraint:
+    """include/m3t/soft_constraint.h:52-62 (same defaults)"""
+
+    def __init__(self, api, optimizer, link1, link2, body12joint1_pose=np.eye(4), body22joint2_pose=np.eye(4),
+                 constraint_directions=(0, 0, 0, 0, 0, 0), max_distance_rotation=0.0, max_distance_translation=0.0,
+                 standard_deviation_rotation=0.01, standard_deviation_translation=0.001):
+        cd = np.asarray(constraint_directions, np.int32)
+        self.id = api.call("soft_constraint_create", optimizer.id, link1.id, link2.id,
+                           fptr(pose_arg(body12joint1_pose)), fptr(pose_arg(body22joint2_pose)), iptr(cd),
+                           max_distance_rotation, max_distance_translation, standard_deviation_rotation,
+                           standard_deviation_translation)
+
+
 __all__ = ["Tracker", "Body", "ColorCamera", "DepthCamera", "RegionModel", "DepthModel", "RegionModality",
-           "DepthModality", "Link", "Optimizer", "Constraint", "M3TError", "RegionModalityParams",
+           "DepthModality", "Link", "Optimizer", "Constraint", "SoftConstraint", "M3TError", "RegionModalityParams",
            "DepthModalityParams"]

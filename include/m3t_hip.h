@@ -138,6 +138,16 @@ int m3t_hip_optimizer_create_rigid(m3t_hip_context*, int body_id, int n_modaliti
 int m3t_hip_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, int link2_id,
                               const float body12joint1[16], const float body22joint2[16],
                               const int constraint_directions[6]);
+/* SoftConstraint (include/m3t/soft_constraint.h:52-62; soft_constraint.cpp:113-131,220-272): a joint that only
+ * pulls once its rotation / translation error exceeds max_distance_*, weighted with 1/standard_deviation^2;
+ * it adds to the g/H of both links before the projection.  A structure spread over several processes
+ * (begin -> all-reduce -> end) keeps them active on one rank only: set_soft_constraints_active(0) elsewhere. */
+int m3t_hip_soft_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, int link2_id,
+                                   const float body12joint1[16], const float body22joint2[16],
+                                   const int constraint_directions[6], float max_distance_rotation,
+                                   float max_distance_translation, float standard_deviation_rotation,
+                                   float standard_deviation_translation);
+int m3t_hip_set_soft_constraints_active(m3t_hip_context*, int active);
 int m3t_hip_link_get_link2world_pose(m3t_hip_context*, int link_id, float pose[16]);
 /* Link::set_body2joint_pose / set_joint2parent_pose (either may be NULL) and the getters */
 int m3t_hip_link_set_joint_poses(m3t_hip_context*, int link_id, const float body2joint[16],

@@ -261,6 +261,19 @@ class TreeOptimizer {
                                                body22joint2_pose.data(), cd),
                      "Constraint");
   }
+  // m3t::SoftConstraint (soft_constraint.h:52-62, same defaults)
+  int AddSoftConstraint(const Link& link1, const Link& link2, const Pose& body12joint1_pose,
+                        const Pose& body22joint2_pose, const std::array<bool, 6>& constraint_directions,
+                        float max_distance_rotation = 0.0f, float max_distance_translation = 0.0f,
+                        float standard_deviation_rotation = 0.01f, float standard_deviation_translation = 0.001f) {
+    int cd[6];
+    for (int i = 0; i < 6; ++i) cd[i] = constraint_directions[i] ? 1 : 0;
+    return c_->Check(m3t_hip_soft_constraint_create(c_->get(), id_, link1.id(), link2.id(), body12joint1_pose.data(),
+                                                    body22joint2_pose.data(), cd, max_distance_rotation,
+                                                    max_distance_translation, standard_deviation_rotation,
+                                                    standard_deviation_translation),
+                     "SoftConstraint");
+  }
   int id() const { return id_; }
 
  private:

@@ -665,12 +665,17 @@ struct Constraint {
     return n;
   }
 };
+struct SoftConstraint {  // soft_constraint.h: same joint description as Constraint + tolerances
+  Constraint joint;
+  float max_distance_rotation = 0.0f, max_distance_translation = 0.0f;
+  float standard_deviation_rotation = 0.1f, standard_deviation_translation = 0.01f;
+};
 struct Optimizer {
   int root_link = -1;
   float tikhonov_parameter_rotation = 1000.0f, tikhonov_parameter_translation = 30000.0f;
   int degrees_of_freedom = 0;
   std::vector<float> tikhonov_vector;
-  std::vector<int> constraints;
+  std::vector<int> constraints, soft_constraints;
   std::vector<float> partial;  // [dof*dof | dof] of the last Begin
 };
 
@@ -682,6 +687,8 @@ struct Context {
   std::vector<std::unique_ptr<Modality>> modalities;
   std::vector<Link> links;
   std::vector<Constraint> constraints;
+  std::vector<SoftConstraint> soft_constraints;
+  bool soft_constraints_active = true;  // a structure spread over processes adds them on one rank only
   std::vector<Optimizer> optimizers;
   std::vector<float> partial_all;  // concatenated partial sums of all optimizers
   int n_corr_iterations = 5, n_update_iterations = 2;  // tracker.h:231-232
@@ -1525,6 +1532,81 @@ void ConstraintCalculate(Context* ctx, Constraint& c, int dof) {
     }
 }
 
+// SoftConstraint::AddGradientsAndHessiansToLink src/soft_constraint.cpp:220-272 for one of the two
+// residual groups (rotation: directions 0-2, translation: 3-5)
+void SoftConstraintAddGroup(const SoftConstraint& sc, bool rotation, const Mat4& joint22joint1,
+                            const Mat4& body2joint1, float sign, float gradient[6], float hessian[36]) {
+  Constraint group = sc.joint;  // the unprojected Jacobian rows of this group only
+  for (int d = 0; d < 6; ++d) group.constraint_directions[d] = sc.joint.constraint_directions[d] && ((d < 3) == rotation);
+  const int n = group.NumberOfConstraints();
+  if (n == 0) return;
+  float full[3];
+  if (rotation) {  // ConsideredRotationVector :274-288
+    float angle, axis[3];
+    AngleAxisFromRotation(Linear(joint22joint1), &angle, axis);
+    for (int k = 0; k < 3; ++k) full[k] = angle * axis[k];
+  } else {         // ConsideredTranslationVector :290-303
+    for (int k = 0; k < 3; ++k) full[k] = joint22joint1(k, 3);
+  }
+  float v[3] = {0.0f, 0.0f, 0.0f};
+  for (int d = 0, idx = 0; d < 3; ++d)
+    if (group.constraint_directions[d + (rotation ? 0 : 3)]) v[idx++] = full[d];
+  const float squared = n == 1 ? v[0] * v[0] : (n == 2 ? v[0] * v[0] + v[1] * v[1] : v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]));
+  const float distance = std::sqrt(squared);
+  const float max_distance = rotation ? sc.max_distance_rotation : sc.max_distance_translation;
+  const float sd = rotation ? sc.standard_deviation_rotation : sc.standard_deviation_translation;
+  if (!(distance > max_distance)) return;
+  std::vector<float> jac;  // n x 6, column-major
+  ConstraintUnprojectedJacobian(group, joint22joint1, body2joint1, &jac);
+  float vn[3], r[3];
+  for (int k = 0; k < n; ++k) {
+    vn[k] = v[k] / distance;
+    r[k] = v[k] - vn[k] * max_distance;
+  }
+  const float cg = sign / (sd * sd), ch = 1.0f / (sd * sd), ratio = max_distance / distance;
+  float mm[9];  // identity - ratio * (identity - vn vn^T), n x n
+  for (int c = 0; c < n; ++c)
+    for (int k = 0; k < n; ++k) {
+      float id = k == c ? 1.0f : 0.0f;
+      mm[c * 3 + k] = id - ratio * (id - vn[k] * vn[c]);
+    }
+  for (int i = 0; i < 6; ++i) {  // gradient -= (cg * J^T) * r
+    float s = 0.0f;
+    for (int k = 0; k < n; ++k) s += (cg * jac[size_t(i) * n + k]) * r[k];
+    gradient[i] -= s;
+  }
+  float jm[18];  // (ch * J^T) * M: 6 x n
+  for (int c = 0; c < n; ++c)
+    for (int i = 0; i < 6; ++i) {
+      float s = 0.0f;
+      for (int k = 0; k < n; ++k) s += (ch * jac[size_t(i) * n + k]) * mm[c * 3 + k];
+      jm[c * 6 + i] = s;
+    }
+  for (int c = 0; c < 6; ++c)
+    for (int i = 0; i < 6; ++i) {
+      float s = 0.0f;
+      for (int k = 0; k < n; ++k) s += jm[k * 6 + i] * jac[size_t(c) * n + k];
+      hessian[c * 6 + i] -= s;
+    }
+}
+// SoftConstraint::AddGradientsAndHessiansToLinks src/soft_constraint.cpp:113-131
+void SoftConstraintAdd(Context* ctx, const SoftConstraint& sc) {
+  Link& l1 = ctx->links[sc.joint.link1];
+  Link& l2 = ctx->links[sc.joint.link2];
+  Mat4 body22joint1 = Mul4(Mul4(sc.joint.body12joint1, InverseAffine(ctx->LinkPose(l1))), ctx->LinkPose(l2));
+  Mat4 joint22joint1 = Mul4(body22joint1, InverseAffine(sc.joint.body22joint2));
+  for (int which = 0; which < 2; ++which) {
+    Link& link = which == 0 ? l1 : l2;
+    const Mat4& body2joint1 = which == 0 ? sc.joint.body12joint1 : body22joint1;
+    const float sign = which == 0 ? -1.0f : 1.0f;
+    float g[6] = {0}, h[36] = {0};
+    SoftConstraintAddGroup(sc, true, joint22joint1, body2joint1, sign, g, h);
+    SoftConstraintAddGroup(sc, false, joint22joint1, body2joint1, sign, g, h);
+    for (int i = 0; i < 6; ++i) link.gradient[i] += g[i];  // Link::AddToGradientAndHessian link.cpp:195-203
+    for (int i = 0; i < 36; ++i) link.hessian[i] += h[i];
+  }
+}
+
 int LinkTreeDof(Context* ctx, int link_id) {  // optimizer.cpp:223-228
   int dof = ctx->links[link_id].DegreesOfFreedom();
   for (int c : ctx->links[link_id].children) dof += LinkTreeDof(ctx, c);
@@ -1589,6 +1671,8 @@ void OptimizerBegin(Context* ctx, Optimizer& o) {
   o.partial.assign(size_t(dof) * dof + dof, 0.0f);
   std::vector<float> b(dof, 0.0f), a(size_t(dof) * dof, 0.0f);
   CalculateDataLinks(ctx, o.root_link);
+  if (ctx->soft_constraints_active)  // Optimizer::CalculateDataLinks optimizer.cpp:281-286
+    for (int sid : o.soft_constraints) SoftConstraintAdd(ctx, ctx->soft_constraints[sid]);
   AddProjected(ctx, o.root_link, dof, dof, &b, &a);
   std::copy(a.begin(), a.end(), o.partial.begin());
   std::copy(b.begin(), b.end(), o.partial.begin() + size_t(dof) * dof);
@@ -1909,6 +1993,35 @@ int m3t_oracle_constraint_create(m3t_oracle_context* ctx, int optimizer, int lin
   CTX->constraints.push_back(c);
   CTX->optimizers[optimizer].constraints.push_back(int(CTX->constraints.size()) - 1);
   return int(CTX->constraints.size()) - 1;
+}
+int m3t_oracle_soft_constraint_create(m3t_oracle_context* ctx, int optimizer, int link1, int link2,
+                                      const float b1[16], const float b2[16], const int dirs[6],
+                                      float max_distance_rotation, float max_distance_translation,
+                                      float standard_deviation_rotation, float standard_deviation_translation) {
+  CHECK_CTX();
+  if (optimizer < 0 || optimizer >= int(CTX->optimizers.size()) || link1 < 0 || link2 < 0 ||
+      link1 >= int(CTX->links.size()) || link2 >= int(CTX->links.size()) || !dirs)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad soft constraint args");
+  if (!(standard_deviation_rotation > 0.0f) || !(standard_deviation_translation > 0.0f))
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "standard deviations must be positive");
+  SoftConstraint sc;
+  sc.joint.link1 = link1;
+  sc.joint.link2 = link2;
+  if (b1) sc.joint.body12joint1 = FromArray(b1);
+  if (b2) sc.joint.body22joint2 = FromArray(b2);
+  for (int i = 0; i < 6; ++i) sc.joint.constraint_directions[i] = dirs[i] != 0;
+  sc.max_distance_rotation = max_distance_rotation;
+  sc.max_distance_translation = max_distance_translation;
+  sc.standard_deviation_rotation = standard_deviation_rotation;
+  sc.standard_deviation_translation = standard_deviation_translation;
+  CTX->soft_constraints.push_back(sc);
+  CTX->optimizers[optimizer].soft_constraints.push_back(int(CTX->soft_constraints.size()) - 1);
+  return int(CTX->soft_constraints.size()) - 1;
+}
+int m3t_oracle_set_soft_constraints_active(m3t_oracle_context* ctx, int active) {
+  CHECK_CTX();
+  CTX->soft_constraints_active = active != 0;
+  return M3T_OK;
 }
 int m3t_oracle_link_get_link2world_pose(m3t_oracle_context* ctx, int link, float pose[16]) {
   CHECK_CTX();

@@ -91,6 +91,13 @@ int m3t_oracle_optimizer_create_rigid(m3t_oracle_context*, int body_id, int n_mo
 int m3t_oracle_constraint_create(m3t_oracle_context*, int optimizer_id, int link1_id, int link2_id,
                                  const float body12joint1[16], const float body22joint2[16],
                                  const int constraint_directions[6]);
+/* soft constraint between two links (soft_constraint.h; added to the links' g/H, soft_constraint.cpp:113-131) */
+int m3t_oracle_soft_constraint_create(m3t_oracle_context*, int optimizer_id, int link1_id, int link2_id,
+                                      const float body12joint1[16], const float body22joint2[16],
+                                      const int constraint_directions[6], float max_distance_rotation,
+                                      float max_distance_translation, float standard_deviation_rotation,
+                                      float standard_deviation_translation);
+int m3t_oracle_set_soft_constraints_active(m3t_oracle_context*, int active);
 int m3t_oracle_link_get_link2world_pose(m3t_oracle_context*, int link_id, float pose[16]);
 int m3t_oracle_link_set_joint_poses(m3t_oracle_context*, int link_id, const float body2joint[16],
                                     const float joint2parent[16]); /* either may be NULL */

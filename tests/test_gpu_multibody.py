@@ -9,7 +9,7 @@ import pytest
 
 import scenes
 import util
-from test_multibody_oracle import build, random_pose, run_convergence
+from test_multibody_oracle import build, random_pose, run_convergence, run_soft
 from util import host, syn
 
 gpu = pytest.mark.gpu
@@ -22,6 +22,20 @@ def test_constraint_convergence_on_device(seed):
     errs_o, poses_o = run_convergence(util.open_oracle(), seed)
     assert errs_h[-1][0] < 2e-5 and errs_h[-1][1] < 2e-5
     for ph, po in zip(poses_h, poses_o):  # atan2f / tan differ in the last bit between libm and ocml
+        for a, b in zip(ph, po):
+            assert np.max(np.abs(a - b)) < 2e-5
+
+
+@gpu
+@pytest.mark.parametrize("kw", [dict(), dict(max_distance_rotation=0.1, max_distance_translation=0.005),
+                                dict(directions=(1, 0, 1, 0, 1, 1), standard_deviation_rotation=0.05),
+                                dict(directions=(1, 1, 1, 0, 0, 0), max_distance_rotation=0.2, root_free=False)])
+def test_soft_constraints_on_device(kw):
+    """SoftConstraint::AddGradientsAndHessiansToLinks in links_project_kernel against the oracle"""
+    errs_h, poses_h = run_soft(util.open_hip(), 2, 25, **kw)
+    errs_o, poses_o = run_soft(util.open_oracle(), 2, 25, **kw)
+    assert errs_h[-1][0] < errs_h[0][0]
+    for ph, po in zip(poses_h, poses_o):
         for a, b in zip(ph, po):
             assert np.max(np.abs(a - b)) < 2e-5
 
