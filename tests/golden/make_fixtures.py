@@ -6,6 +6,8 @@ Provenance (all under /root/reference/M3T/data/):
   model_test/{region,depth}_model.bin      RegionModelTest/DepthModelTest goldens (test/model_test.cpp:165-184)
   modality_test/*_{gradient,hessian}.txt   modality g/H goldens (test/modality_test.cpp:280-316,534-550)
   modality_test/region_modality.png        lines-correspondence visualisation golden (test/modality_test.cpp:180-193)
+  modality_test/*measured_occlusions.png, depth_modality.png   visualisation goldens with / without measured
+                                           occlusions (test/modality_test.cpp:222-248,433-456,486-502)
   optimizer_test/triangle_pose.txt         OptimizerTest.Optimize golden (test/optimizer_test.cpp:97-105)
   tracker_test/, refiner_test/ pose goldens (test/tracker_test.cpp:164-195)
   _sequence/{color,depth}_camera_image_20{0,1}.png + yaml   the fixture frames (test/common_test.cpp:96-118)
@@ -23,6 +25,8 @@ FILES = [
     "modality_test/region_modality_local_gradient.txt", "modality_test/region_modality_local_hessian.txt",
     "modality_test/depth_modality_gradient.txt", "modality_test/depth_modality_hessian.txt",
     "modality_test/region_modality.yaml", "modality_test/depth_modality.yaml", "modality_test/region_modality.png",
+    "modality_test/region_modality_measured_occlusions.png", "modality_test/region_modality_depth_measured_occlusions.png",
+    "modality_test/depth_modality.png", "modality_test/depth_modality_measured_occlusions.png",
     "optimizer_test/triangle_pose.txt", "optimizer_test/optimizer.yaml",
     "tracker_test/triangle_pose.txt", "tracker_test/tracker.yaml", "refiner_test/triangle_pose.txt",
     "_sequence/color_camera_image_200.png", "_sequence/color_camera_image_201.png",

@@ -25,7 +25,7 @@ def views():
 
 
 class RegionFixture:
-    def __init__(self, api):
+    def __init__(self, api, measure_occlusions=False):
         v = views()
         self.api = api
         self.image = load_png("_sequence/color_camera_image_200.png")
@@ -33,14 +33,23 @@ class RegionFixture:
                                       contour_lengths=v["region_contour_lengths"])
         self.body = host.Body(api, mtv.body2world())
         self.camera = host.ColorCamera(api, **mtv.COLOR_INTRINSICS)
-        self.modality = host.RegionModality(api, self.body, self.camera, self.model)  # default parameters
+        if measure_occlusions:  # RegionModalityTest.CalculateCorrespondencesMeasuredOcclusions
+            w2c = np.linalg.inv(mtv.DEPTH_CAMERA2WORLD).astype(np.float32)
+            self.depth_camera = host.DepthCamera(api, depth_scale=mtv.DEPTH_SCALE, world2camera_pose=w2c,
+                                                 **mtv.DEPTH_INTRINSICS)
+            self.depth_camera.UpdateImage(load_png("_sequence/depth_camera_image_200.png"))
+            self.modality = host.RegionModality(api, self.body, self.camera, self.model,
+                                                depth_camera=self.depth_camera, measure_occlusions=1,
+                                                n_unoccluded_iterations=0)
+        else:
+            self.modality = host.RegionModality(api, self.body, self.camera, self.model)  # default parameters
         self.optimizer = host.Optimizer(api, body=self.body, modalities=[self.modality])
         self.camera.UpdateImage(self.image)
         self.tracker = host.Tracker(api)
 
 
 class DepthFixture:
-    def __init__(self, api):
+    def __init__(self, api, measure_occlusions=False):
         v = views()
         self.api = api
         self.image = load_png("_sequence/depth_camera_image_200.png")
@@ -50,7 +59,9 @@ class DepthFixture:
         w2c = np.linalg.inv(mtv.DEPTH_CAMERA2WORLD).astype(np.float32)
         self.camera = host.DepthCamera(api, depth_scale=mtv.DEPTH_SCALE, world2camera_pose=w2c,
                                        **mtv.DEPTH_INTRINSICS)
-        self.modality = host.DepthModality(api, self.body, self.camera, self.model)  # default parameters
+        kw = dict(measure_occlusions=1, n_unoccluded_iterations=0) if measure_occlusions else {}
+        self.body2camera = (w2c @ mtv.body2world()).astype(np.float32)
+        self.modality = host.DepthModality(api, self.body, self.camera, self.model, **kw)  # else defaults
         self.optimizer = host.Optimizer(api, body=self.body, modalities=[self.modality])
         self.camera.UpdateImage(self.image)
         self.tracker = host.Tracker(api)
@@ -131,3 +142,22 @@ class TrackerFixture:
         self.color_camera.UpdateImage(load_png("_sequence/color_camera_image_200.png"))
         self.depth_camera.UpdateImage(load_png("_sequence/depth_camera_image_200.png"))
         self.tracker = host.Tracker(api, n_corr_iterations, n_update_iterations)
+
+
+def point_mask(shape, points_f_body, body2camera, intrinsics):
+    """DrawPointInImage common.cpp:268-276 for every point: cv::circle(radius 1, FILLED) = the pixel and
+    its four neighbours"""
+    f32 = np.float32
+    mask = np.zeros(shape, bool)
+    for p in points_f_body:
+        c = (body2camera[:3, :3] @ p + body2camera[:3, 3]).astype(f32)
+        u = int(c[0] * f32(intrinsics["fu"]) / c[2] + f32(intrinsics["ppu"]) + 0.5)
+        v = int(c[1] * f32(intrinsics["fv"]) / c[2] + f32(intrinsics["ppv"]) + 0.5)
+        for du, dv in ((0, 0), (1, 0), (-1, 0), (0, 1), (0, -1)):
+            if 0 <= v + dv < shape[0] and 0 <= u + du < shape[1]:
+                mask[v + dv, u + du] = True
+    return mask
+
+
+def golden_point_mask(rel, bgr):
+    return (load_png(rel).astype(np.int32) == np.asarray(bgr)).all(axis=2)

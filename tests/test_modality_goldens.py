@@ -57,6 +57,38 @@ def check_region_visualisation(api):
     assert int((diff > 0).sum()) <= 3
 
 
+def check_measured_occlusion_goldens(api):
+    """RegionModalityTest / DepthModalityTest CalculateCorrespondences[MeasuredOcclusions]
+    (test/modality_test.cpp:222-248,433-456,486-502): which lines / points survive the measured
+    occlusion test on depth frame 200, read off the visualisation goldens (the grey level of the
+    depth background in those files follows 255/999 per raw unit instead of the shipped
+    NormalizedDepthImage's 255/1000, camera.cpp:108-115, so only the drawn marks are compared)"""
+    f = gs.RegionFixture(api, measure_occlusions=True)
+    assert f.tracker.StartModalities(0) and f.tracker.CalculateCorrespondences(0, 0)
+    lines = f.modality.data_lines()
+    lines = lines[lines["valid"] != 0]
+    assert len(lines) == 83  # of 179 without occlusion handling
+    hf, hb = f.modality.histograms()
+    vis = gs.render_lines_visualisation(f.image, hf, hb, lines, n_bins=16, scale=6, distribution_length=12)
+    gold = gs.load_png("modality_test/region_modality_measured_occlusions.png").astype(np.int32)
+    assert int((np.abs(vis - gold).max(axis=2) > 0).sum()) <= 3
+    w2c = np.linalg.inv(gs.mtv.DEPTH_CAMERA2WORLD).astype(np.float32)
+    b2dc = (w2c @ gs.mtv.body2world()).astype(np.float32)
+    mine = gs.point_mask((480, 848), lines["center_f_body"], b2dc,
+                         gs.mtv.DEPTH_INTRINSICS)
+    assert np.array_equal(mine, gs.golden_point_mask("modality_test/region_modality_depth_measured_occlusions.png",
+                                                     (24, 184, 234)))
+    for occlusions, name, n_valid in ((False, "depth_modality.png", 182),
+                                      (True, "depth_modality_measured_occlusions.png", 110)):
+        d = gs.DepthFixture(api, measure_occlusions=occlusions)
+        assert d.tracker.CalculateCorrespondences(0, 0)
+        pts = d.modality.data_points()
+        pts = pts[pts["valid"] != 0]
+        assert len(pts) == n_valid
+        mine = gs.point_mask((480, 848), pts["center_f_body"], d.body2camera, gs.mtv.DEPTH_INTRINSICS)
+        assert np.array_equal(mine, gs.golden_point_mask("modality_test/" + name, (187, 117, 0)))
+
+
 def check_depth_goldens(api):
     """DepthModalityTest.CalculateGradientAndHessian, with the reference's own 1e-3 criterion"""
     f = gs.DepthFixture(api)
@@ -118,6 +150,15 @@ def test_oracle_region_visualisation_golden():
 
 def test_oracle_depth_goldens():
     check_depth_goldens(util.open_oracle())
+
+
+def test_oracle_measured_occlusion_goldens():
+    check_measured_occlusion_goldens(util.open_oracle())
+
+
+@pytest.mark.gpu
+def test_hip_measured_occlusion_goldens():
+    check_measured_occlusion_goldens(util.open_hip())
 
 
 def test_oracle_optimizer_golden_full_chain():
