@@ -44,6 +44,12 @@ class DepthModelDesc(C.Structure):
                 ("stride_depth_offset", C.c_float), ("max_radius_depth_offset", C.c_float)]
 
 
+class BodyGeometry(C.Structure):
+    _fields_ = [("vertices", c_float_p), ("n_vertices", C.c_int), ("triangles", c_int_p), ("n_triangles", C.c_int),
+                ("geometry2body", C.c_float * 16), ("geometry_counterclockwise", C.c_int),
+                ("geometry_enable_culling", C.c_int), ("body_id", C.c_int), ("region_id", C.c_int)]
+
+
 class RegionModalityParams(C.Structure):
     """m3t_region_modality_params; defaults = M3T/include/m3t/region_modality.h:411-443."""
     _fields_ = [
@@ -60,6 +66,8 @@ class RegionModalityParams(C.Structure):
         ("measured_depth_offset_radius", C.c_float), ("measured_occlusion_radius", C.c_float),
         ("measured_occlusion_threshold", C.c_float), ("model_occlusions", C.c_int),
         ("n_unoccluded_iterations", C.c_int), ("min_n_unoccluded_lines", C.c_int),
+        ("modeled_depth_offset_radius", C.c_float), ("modeled_occlusion_radius", C.c_float),
+        ("modeled_occlusion_threshold", C.c_float),
     ]
 
     def __init__(self, **kw):
@@ -84,6 +92,9 @@ class RegionModalityParams(C.Structure):
         self.measured_occlusion_threshold = 0.03
         self.n_unoccluded_iterations = 10
         self.min_n_unoccluded_lines = 0
+        self.modeled_depth_offset_radius = 0.01
+        self.modeled_occlusion_radius = 0.01
+        self.modeled_occlusion_threshold = 0.03
         for k, v in kw.items():
             if k == "scales":
                 self.set_scales(v)
@@ -116,6 +127,8 @@ class DepthModalityParams(C.Structure):
         ("measured_depth_offset_radius", C.c_float), ("measured_occlusion_radius", C.c_float),
         ("measured_occlusion_threshold", C.c_float), ("model_occlusions", C.c_int),
         ("n_unoccluded_iterations", C.c_int), ("min_n_unoccluded_points", C.c_int),
+        ("modeled_depth_offset_radius", C.c_float), ("modeled_occlusion_radius", C.c_float),
+        ("modeled_occlusion_threshold", C.c_float),
     ]
 
     def __init__(self, **kw):
@@ -128,6 +141,9 @@ class DepthModalityParams(C.Structure):
         self.measured_occlusion_radius = 0.01
         self.measured_occlusion_threshold = 0.03
         self.n_unoccluded_iterations = 10
+        self.modeled_depth_offset_radius = 0.01
+        self.modeled_occlusion_radius = 0.01
+        self.modeled_occlusion_threshold = 0.03
         for k, v in kw.items():
             if k == "considered_distances":
                 self.set_considered_distances(v)
@@ -213,6 +229,18 @@ _SIGNATURES = {
     "optimizer_create": [C.c_int, C.c_float, C.c_float],
     "optimizer_create_rigid": [C.c_int, C.c_int, c_int_p, C.c_float, C.c_float],
     "constraint_create": [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p],
+    "body_set_geometry": [C.c_int, C.POINTER(BodyGeometry)],
+    "renderer_geometry_create": [],
+    "renderer_geometry_add_body": [C.c_int, C.c_int],
+    "focused_depth_renderer_create": [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float],
+    "focused_silhouette_renderer_create": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float],
+    "renderer_add_referenced_body": [C.c_int, C.c_int],
+    "renderer_start_rendering": [C.c_int],
+    "renderer_get_images": [C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint8), c_float_p, c_int_p],
+    "region_modality_model_occlusions": [C.c_int, C.c_int],
+    "region_modality_use_region_checking": [C.c_int, C.c_int],
+    "depth_modality_model_occlusions": [C.c_int, C.c_int],
+    "depth_modality_use_silhouette_checking": [C.c_int, C.c_int],
     "soft_constraint_create": [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, C.c_float, C.c_float,
                                C.c_float, C.c_float],
     "set_soft_constraints_active": [C.c_int],

@@ -46,6 +46,30 @@ struct CameraDev {
   float world2camera[16];  // column-major
 };
 
+// FocusedBasicDepthRenderer / FocusedSilhouetteRenderer (renderer.h:180-330) on the device
+enum { RS_CORNER_U = 0, RS_CORNER_V, RS_SCALE, RS_TERM_A, RS_TERM_B, RS_N_VISIBLE, RS_VISIBLE0 = 8,
+       RS_FLOATS = 8 + M3T_MAX_RENDERER_BODIES };
+struct RendererDev {
+  int camera, silhouette, id_type, image_size;
+  float z_min, z_max;
+  int n_bodies;                                 // RendererGeometry, draw order
+  int body[M3T_MAX_RENDERER_BODIES];
+  const float* vertices[M3T_MAX_RENDERER_BODIES];
+  const int* triangles[M3T_MAX_RENDERER_BODIES];
+  int n_triangles[M3T_MAX_RENDERER_BODIES];
+  float geometry2body[M3T_MAX_RENDERER_BODIES][16];
+  int culling[M3T_MAX_RENDERER_BODIES];
+  int id[M3T_MAX_RENDERER_BODIES];              // value written by the silhouette pass
+  int n_referenced;
+  int referenced[M3T_MAX_RENDERER_BODIES];
+  float referenced_diameter[M3T_MAX_RENDERER_BODIES];
+  // results of the last rendering
+  uint16_t* depth_image;        // [image_size^2], 65535 = nothing
+  uint8_t* silhouette_image;    // [image_size^2] ids (0 = nothing)
+  uint32_t* packed;             // z-buffer scratch when image_size^2 words do not fit in LDS
+  float* state;                 // [RS_FLOATS]
+};
+
 struct RegionModDev {
   int body, camera, depth_camera;
   // sparse viewpoint model (shared between objects using the same model)
@@ -72,6 +96,12 @@ struct RegionModDev {
   int n_unoccluded_iterations, min_n_unoccluded_lines;
   float min_expected_variance, distribution_length_minus_1_half, distribution_length_plus_1_half;
   int first_iteration;
+  // renderer-fed branches (region_modality.cpp:1157-1229,1293-1341,1391-1431)
+  int use_region_checking, model_occlusions, modeled_depth_offset_id, region_id;
+  float modeled_occlusion_radius, modeled_occlusion_threshold;
+  const RendererDev* depth_renderer;
+  const RendererDev* silhouette_renderer;
+  int depth_renderer_slot, silhouette_renderer_slot;  // index of the body among the referenced bodies
   // per-object state
   float* histogram_f;     // [n_bins^3]
   float* histogram_b;     // [n_bins^3]
@@ -100,6 +130,12 @@ struct DepthModDev {
   float measured_depth_offset_radius, measured_occlusion_radius, measured_occlusion_threshold;
   int n_unoccluded_iterations, min_n_unoccluded_points;
   int first_iteration;
+  // renderer-fed branches (depth_modality.cpp:728-734,778-824)
+  int use_silhouette_checking, model_occlusions, body_id;
+  float modeled_depth_offset_radius, modeled_occlusion_radius, modeled_occlusion_threshold;
+  const RendererDev* depth_renderer;
+  const RendererDev* silhouette_renderer;
+  int depth_renderer_slot, silhouette_renderer_slot;
   float* point_state;       // [PS_FIELDS][n_points_max]
   float* gradient_hessian;  // [6 + 36]
 };

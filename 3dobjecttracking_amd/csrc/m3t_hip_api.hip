@@ -16,6 +16,7 @@
 #include "../../include/m3t_hip.h"
 #include "m3t_device.h"
 #include "m3t_kernels.hip"
+#include "m3t_render.hip"
 #include "m3t_links.hip"
 
 namespace {
@@ -66,14 +67,32 @@ struct Camera {
   DevMem ring;
 };
 
+struct BodyGeometryH {  // body.h:46-60 on the device
+  bool set = false;
+  DevMem vertices, triangles;
+  int n_triangles = 0;
+  float geometry2body[16];
+  int culling = 1, body_id = 0, region_id = 0;
+  float maximum_body_diameter = 0.0f;
+};
+struct RendererH {  // FocusedBasicDepthRenderer / FocusedSilhouetteRenderer
+  bool silhouette = false;
+  int geometry = -1, camera = -1, id_type = M3T_ID_TYPE_BODY, image_size = 200;
+  float z_min = 0.02f, z_max = 10.0f;
+  std::vector<int> referenced;
+  DevMem depth, sil, packed, state;
+  bool rendered = false;
+};
 struct RegionMod {
   m3t_region_modality_params p{};
+  int depth_renderer = -1, silhouette_renderer = -1;
   int body, camera, depth_camera, model;
   DevMem hist_f, hist_b, hist_norm, count_scratch, line_state, gh;
   RegionModDev dev{};
 };
 struct DepthMod {
   m3t_depth_modality_params p{};
+  int depth_renderer = -1, silhouette_renderer = -1;
   int body, camera, model;
   DevMem point_state, gh;
   DepthModDev dev{};
@@ -122,6 +141,11 @@ struct m3t_hip_context {
   std::vector<std::unique_ptr<RegionMod>> region_mods;
   std::vector<std::unique_ptr<DepthMod>> depth_mods;
   std::vector<ModalityRef> modalities;
+  std::vector<std::unique_ptr<BodyGeometryH>> body_geometries;  // parallel to the bodies (may be shorter)
+  std::vector<std::vector<int>> renderer_geometries;
+  std::vector<std::unique_ptr<RendererH>> renderers;
+  DevMem d_renderers, d_render_region, d_render_all;  // RendererDev table; which renderers to run when
+  int n_render_region = 0, n_render_all = 0;
   std::vector<Link> links;
   std::vector<ConstraintH> constraints;
   std::vector<SoftConstraintH> soft_constraints;
@@ -526,6 +550,118 @@ int UploadTreeTables(Ctx* ctx) {
   return M3T_OK;
 }
 
+// RendererDev table + the renderer fields of the modality tables + the two "which renderers" lists
+// (region modalities' renderers for start / results, all referenced ones for correspondences)
+int UploadRendererTables(Ctx* ctx) {
+  const size_t n = ctx->renderers.size();
+  std::vector<RendererDev> table(n);
+  for (size_t i = 0; i < n; ++i) {
+    RendererH& h = *ctx->renderers[i];
+    RendererDev& d = table[i];
+    std::memset(&d, 0, sizeof(d));
+    d.camera = h.camera;
+    d.silhouette = h.silhouette ? 1 : 0;
+    d.id_type = h.id_type;
+    d.image_size = h.image_size;
+    d.z_min = h.z_min;
+    d.z_max = h.z_max;
+    const std::vector<int>& bodies = ctx->renderer_geometries[h.geometry];
+    d.n_bodies = int(bodies.size());
+    for (int k = 0; k < d.n_bodies; ++k) {
+      const BodyGeometryH& g = *ctx->body_geometries[bodies[k]];
+      d.body[k] = bodies[k];
+      d.vertices[k] = g.vertices.as<float>();
+      d.triangles[k] = g.triangles.as<int>();
+      d.n_triangles[k] = g.n_triangles;
+      std::memcpy(d.geometry2body[k], g.geometry2body, 64);
+      d.culling[k] = g.culling;
+      d.id[k] = h.id_type == M3T_ID_TYPE_REGION ? g.region_id : g.body_id;
+    }
+    d.n_referenced = int(h.referenced.size());
+    for (int k = 0; k < d.n_referenced; ++k) {
+      d.referenced[k] = h.referenced[k];
+      d.referenced_diameter[k] = ctx->body_geometries[h.referenced[k]]->maximum_body_diameter;
+    }
+    d.depth_image = h.depth.as<uint16_t>();
+    d.silhouette_image = h.sil.as<uint8_t>();
+    d.packed = h.packed.as<uint32_t>();
+    d.state = h.state.as<float>();
+  }
+  HIPCHK(ctx->d_renderers.alloc(std::max<size_t>(1, n) * sizeof(RendererDev)));
+  if (n) HIPCHK(hipMemcpy(ctx->d_renderers.p, table.data(), n * sizeof(RendererDev), hipMemcpyHostToDevice));
+  auto slot_of = [&](int renderer, int body) {
+    const std::vector<int>& ref = ctx->renderers[renderer]->referenced;
+    for (size_t k = 0; k < ref.size(); ++k)
+      if (ref[k] == body) return int(k);
+    return -1;
+  };
+  std::vector<char> for_region(n, 0), for_all(n, 0);
+  for (auto& m : ctx->region_mods) {
+    RegionModDev& d = m->dev;
+    d.depth_renderer = d.model_occlusions ? ctx->d_renderers.as<RendererDev>() + m->depth_renderer : nullptr;
+    d.silhouette_renderer = d.use_region_checking ? ctx->d_renderers.as<RendererDev>() + m->silhouette_renderer : nullptr;
+    d.depth_renderer_slot = d.model_occlusions ? slot_of(m->depth_renderer, m->body) : -1;
+    d.silhouette_renderer_slot = d.use_region_checking ? slot_of(m->silhouette_renderer, m->body) : -1;
+    if (d.model_occlusions) for_region[m->depth_renderer] = for_all[m->depth_renderer] = 1;
+    if (d.use_region_checking) for_region[m->silhouette_renderer] = for_all[m->silhouette_renderer] = 1;
+  }
+  for (auto& m : ctx->depth_mods) {
+    DepthModDev& d = m->dev;
+    d.depth_renderer = d.model_occlusions ? ctx->d_renderers.as<RendererDev>() + m->depth_renderer : nullptr;
+    d.silhouette_renderer =
+        d.use_silhouette_checking ? ctx->d_renderers.as<RendererDev>() + m->silhouette_renderer : nullptr;
+    d.depth_renderer_slot = d.model_occlusions ? slot_of(m->depth_renderer, m->body) : -1;
+    d.silhouette_renderer_slot = d.use_silhouette_checking ? slot_of(m->silhouette_renderer, m->body) : -1;
+    if (d.model_occlusions) for_all[m->depth_renderer] = 1;
+    if (d.use_silhouette_checking) for_all[m->silhouette_renderer] = 1;
+  }
+  std::vector<int> list_region, list_all;
+  for (size_t i = 0; i < n; ++i) {
+    if (for_region[i]) list_region.push_back(int(i));
+    if (for_all[i]) list_all.push_back(int(i));
+  }
+  ctx->n_render_region = int(list_region.size());
+  ctx->n_render_all = int(list_all.size());
+  HIPCHK(ctx->d_render_region.alloc(std::max<size_t>(1, list_region.size()) * 4));
+  HIPCHK(ctx->d_render_all.alloc(std::max<size_t>(1, list_all.size()) * 4));
+  if (!list_region.empty())
+    HIPCHK(hipMemcpy(ctx->d_render_region.p, list_region.data(), list_region.size() * 4, hipMemcpyHostToDevice));
+  if (!list_all.empty())
+    HIPCHK(hipMemcpy(ctx->d_render_all.p, list_all.data(), list_all.size() * 4, hipMemcpyHostToDevice));
+  return M3T_OK;
+}
+
+// one workgroup per renderer; the packed z-buffer lives in LDS when image_size^2 words fit
+int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int largest_image_size) {
+  if (n_which == 0) return M3T_OK;
+  const size_t words = size_t(largest_image_size) * largest_image_size;
+  const bool in_lds = words * 4 <= 160 * 1024 - 1024;
+  const size_t lds = in_lds ? words * 4 : 0;
+  if (lds > 64 * 1024) {
+    static bool attribute_set = false;
+    if (!attribute_set) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(focused_render_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+      attribute_set = true;
+    }
+  }
+  hipLaunchKernelGGL(focused_render_kernel, dim3(n_which), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
+                     ctx->d_renderers.as<RendererDev>(), which, ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                     in_lds ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  return M3T_OK;
+}
+int LargestRendererImage(Ctx* ctx) {
+  int s = 0;
+  for (auto& r : ctx->renderers) s = std::max(s, r->image_size);
+  return s;
+}
+int RenderForModalities(Ctx* ctx, bool region_only) {
+  for (auto& r : ctx->renderers) r->rendered = true;
+  return LaunchRenderers(ctx, region_only ? ctx->d_render_region.as<int>() : ctx->d_render_all.as<int>(),
+                         region_only ? ctx->n_render_region : ctx->n_render_all, LargestRendererImage(ctx));
+}
+
 int UploadTables(Ctx* ctx) {
   if (ctx->copies_pending) {
     // frames enqueued on the copy stream so far become visible to everything launched from here on
@@ -574,6 +710,8 @@ int UploadTables(Ctx* ctx) {
     ctx->cams_dirty = false;
   }
   if (ctx->tables_dirty) {
+    int rr = UploadRendererTables(ctx);
+    if (rr) return rr;
     std::vector<RegionModDev> r(ctx->region_mods.size());
     for (size_t i = 0; i < r.size(); ++i) r[i] = ctx->region_mods[i]->dev;
     std::vector<DepthModDev> d(ctx->depth_mods.size());
@@ -618,6 +756,8 @@ int UploadTables(Ctx* ctx) {
     size_t attached = 0;
     for (auto& o : ctx->optimizers) attached += ctx->links[o.link].modalities.size();
     if (attached != ctx->modalities.size()) ctx->fused_possible = false;
+    // renderer-fed branches read other bodies' poses between the sub-steps: one launch per sub-step
+    if (ctx->n_render_all > 0) ctx->fused_possible = false;
     HIPCHK(ctx->d_opts.alloc(std::max<size_t>(1, ctx->opt_table.size()) * sizeof(RigidOptDev)));
     if (!ctx->opt_table.empty())
       HIPCHK(hipMemcpy(ctx->d_opts.p, ctx->opt_table.data(), ctx->opt_table.size() * sizeof(RigidOptDev),
@@ -1137,8 +1277,8 @@ int m3t_hip_region_modality_create(m3t_hip_context* ctx, const m3t_region_modali
   REQUIRE(color_camera >= 0 && color_camera < int(ctx->cameras.size()) && !ctx->cameras[color_camera]->is_depth,
           M3T_ERR_INVALID_ARGUMENT, "bad color camera id");
   REQUIRE(model >= 0 && model < int(ctx->region_models.size()), M3T_ERR_INVALID_ARGUMENT, "bad region model id");
-  REQUIRE(!p->use_region_checking && !p->model_occlusions, M3T_ERR_UNSUPPORTED,
-          "renderer-fed branches (region checking / modelled occlusions) are not supported");
+  REQUIRE(!p->use_region_checking && !p->model_occlusions, M3T_ERR_INVALID_ARGUMENT,
+          "switch region checking / modelled occlusions on with their renderer afterwards");
   if (p->measure_occlusions)
     REQUIRE(depth_camera >= 0 && depth_camera < int(ctx->cameras.size()) && ctx->cameras[depth_camera]->is_depth,
             M3T_ERR_INVALID_ARGUMENT, "measure_occlusions needs a depth camera");
@@ -1263,8 +1403,8 @@ int m3t_hip_depth_modality_create(m3t_hip_context* ctx, const m3t_depth_modality
   REQUIRE(depth_camera >= 0 && depth_camera < int(ctx->cameras.size()) && ctx->cameras[depth_camera]->is_depth,
           M3T_ERR_INVALID_ARGUMENT, "bad depth camera id");
   REQUIRE(model >= 0 && model < int(ctx->depth_models.size()), M3T_ERR_INVALID_ARGUMENT, "bad depth model id");
-  REQUIRE(!p->use_silhouette_checking && !p->model_occlusions, M3T_ERR_UNSUPPORTED,
-          "renderer-fed branches (silhouette checking / modelled occlusions) are not supported");
+  REQUIRE(!p->use_silhouette_checking && !p->model_occlusions, M3T_ERR_INVALID_ARGUMENT,
+          "switch silhouette checking / modelled occlusions on with their renderer afterwards");
   REQUIRE(p->n_considered_distances >= 1 && p->n_considered_distances <= M3T_MAX_SCALES &&
               p->n_standard_deviations >= 1 && p->n_standard_deviations <= M3T_MAX_SCALES && p->n_points_max >= 1,
           M3T_ERR_INVALID_ARGUMENT, "bad depth modality parameters");
@@ -1471,6 +1611,217 @@ static bool IsIdentity(const float* p) {
 static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
 // m3t::Link (link.h:67): body may be -1 (pure joint), parent -1 = root
+// ---- renderer-fed branches (a14 / f-3) ---------------------------------------------------------------
+int m3t_hip_body_set_geometry(m3t_hip_context* ctx, int body, const m3t_body_geometry* g) {
+  CHECK_CTX();
+  REQUIRE(body >= 0 && body < int(ctx->body_poses.size() / 16) && g && g->vertices && g->triangles &&
+              g->n_vertices >= 3 && g->n_triangles >= 1 && g->body_id >= 0 && g->body_id <= 255 &&
+              g->region_id >= 0 && g->region_id <= 255,
+          M3T_ERR_INVALID_ARGUMENT, "bad body geometry");
+  for (int i = 0; i < g->n_triangles * 3; ++i)
+    REQUIRE(g->triangles[i] >= 0 && g->triangles[i] < g->n_vertices, M3T_ERR_INVALID_ARGUMENT,
+            "triangle index out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->body_geometries.size() <= size_t(body)) ctx->body_geometries.resize(size_t(body) + 1);
+  auto bg = std::make_unique<BodyGeometryH>();
+  std::vector<int> tri(size_t(g->n_triangles) * 3);
+  for (int t = 0; t < g->n_triangles; ++t)  // body.cpp:227-236
+    for (int k = 0; k < 3; ++k)
+      tri[size_t(t) * 3 + k] = g->triangles[size_t(t) * 3 + (g->geometry_counterclockwise ? k : 2 - k)];
+  HIPCHK(bg->vertices.alloc(size_t(g->n_vertices) * 12));
+  HIPCHK(bg->triangles.alloc(tri.size() * 4));
+  HIPCHK(hipMemcpy(bg->vertices.p, g->vertices, size_t(g->n_vertices) * 12, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(bg->triangles.p, tri.data(), tri.size() * 4, hipMemcpyHostToDevice));
+  bg->n_triangles = g->n_triangles;
+  std::memcpy(bg->geometry2body, g->geometry2body, 64);
+  bg->culling = g->geometry_enable_culling ? 1 : 0;
+  bg->body_id = g->body_id;
+  bg->region_id = g->region_id;
+  float max_radius = 0.0f;  // Body::CalculateMaximumBodyDiameter body.cpp:244-250
+  const float* m = g->geometry2body;
+  for (int i = 0; i < g->n_vertices; ++i) {
+    const float* v = g->vertices + size_t(i) * 3;
+    float q[3];
+    for (int k = 0; k < 3; ++k) q[k] = m[12 + k] + ((m[k] * v[0] + m[4 + k] * v[1]) + m[8 + k] * v[2]);
+    max_radius = std::max(max_radius, std::sqrt(q[0] * q[0] + (q[1] * q[1] + q[2] * q[2])));
+  }
+  bg->maximum_body_diameter = 2.0f * max_radius;
+  bg->set = true;
+  ctx->body_geometries[body] = std::move(bg);
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
+static bool HasGeometry(m3t_hip_context* ctx, int body) {
+  return body >= 0 && size_t(body) < ctx->body_geometries.size() && ctx->body_geometries[body] &&
+         ctx->body_geometries[body]->set;
+}
+int m3t_hip_renderer_geometry_create(m3t_hip_context* ctx) {
+  CHECK_CTX();
+  ctx->renderer_geometries.emplace_back();
+  return int(ctx->renderer_geometries.size()) - 1;
+}
+int m3t_hip_renderer_geometry_add_body(m3t_hip_context* ctx, int geometry, int body) {
+  CHECK_CTX();
+  REQUIRE(geometry >= 0 && geometry < int(ctx->renderer_geometries.size()) && body >= 0 &&
+              body < int(ctx->body_poses.size() / 16),
+          M3T_ERR_INVALID_ARGUMENT, "bad renderer geometry / body id");
+  REQUIRE(HasGeometry(ctx, body), M3T_ERR_NOT_SET_UP, "body has no geometry");
+  REQUIRE(ctx->renderer_geometries[geometry].size() < M3T_MAX_RENDERER_BODIES, M3T_ERR_UNSUPPORTED, "too many bodies");
+  ctx->renderer_geometries[geometry].push_back(body);
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
+static int CreateRenderer(m3t_hip_context* ctx, bool silhouette, int geometry, int camera, int id_type, int image_size,
+                          float z_min, float z_max) {
+  CHECK_CTX();
+  REQUIRE(geometry >= 0 && geometry < int(ctx->renderer_geometries.size()) && camera >= 0 &&
+              camera < int(ctx->cameras.size()) && image_size >= 8 && image_size <= 1024 && z_min > 0.0f &&
+              z_max > z_min && (id_type == M3T_ID_TYPE_BODY || id_type == M3T_ID_TYPE_REGION),
+          M3T_ERR_INVALID_ARGUMENT, "bad renderer arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  auto r = std::make_unique<RendererH>();
+  r->silhouette = silhouette;
+  r->geometry = geometry;
+  r->camera = camera;
+  r->id_type = id_type;
+  r->image_size = image_size;
+  r->z_min = z_min;
+  r->z_max = z_max;
+  const size_t px = size_t(image_size) * image_size;
+  HIPCHK(r->depth.alloc(px * 2));
+  HIPCHK(r->sil.alloc(px));
+  HIPCHK(r->packed.alloc(px * 4));
+  HIPCHK(r->state.alloc(RS_FLOATS * 4));
+  HIPCHK(hipMemset(r->state.p, 0, RS_FLOATS * 4));
+  ctx->renderers.push_back(std::move(r));
+  ctx->tables_dirty = true;
+  return int(ctx->renderers.size()) - 1;
+}
+int m3t_hip_focused_depth_renderer_create(m3t_hip_context* ctx, int geometry, int camera, int image_size, float z_min,
+                                          float z_max) {
+  return CreateRenderer(ctx, false, geometry, camera, M3T_ID_TYPE_BODY, image_size, z_min, z_max);
+}
+int m3t_hip_focused_silhouette_renderer_create(m3t_hip_context* ctx, int geometry, int camera, int id_type,
+                                               int image_size, float z_min, float z_max) {
+  return CreateRenderer(ctx, true, geometry, camera, id_type, image_size, z_min, z_max);
+}
+int m3t_hip_renderer_add_referenced_body(m3t_hip_context* ctx, int renderer, int body) {
+  CHECK_CTX();
+  REQUIRE(renderer >= 0 && renderer < int(ctx->renderers.size()) && body >= 0 && body < int(ctx->body_poses.size() / 16),
+          M3T_ERR_INVALID_ARGUMENT, "bad renderer / body id");
+  REQUIRE(HasGeometry(ctx, body), M3T_ERR_NOT_SET_UP, "body has no geometry");
+  RendererH& r = *ctx->renderers[renderer];
+  REQUIRE(r.referenced.size() < M3T_MAX_RENDERER_BODIES, M3T_ERR_UNSUPPORTED, "too many referenced bodies");
+  r.referenced.push_back(body);
+  r.rendered = false;
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
+int m3t_hip_renderer_start_rendering(m3t_hip_context* ctx, int renderer) {
+  CHECK_CTX();
+  REQUIRE(renderer >= 0 && renderer < int(ctx->renderers.size()), M3T_ERR_INVALID_ARGUMENT, "bad renderer id");
+  REQUIRE(!ctx->renderers[renderer]->referenced.empty(), M3T_ERR_NOT_SET_UP, "no referenced body");
+  HIPCHK(hipSetDevice(ctx->device));
+  int r = Prepare(ctx, false);
+  if (r) return r;
+  DevMem which;  // freed after the synchronisation below
+  HIPCHK(which.alloc(4));
+  HIPCHK(hipMemcpy(which.p, &renderer, 4, hipMemcpyHostToDevice));
+  if ((r = LaunchRenderers(ctx, which.as<int>(), 1, ctx->renderers[renderer]->image_size))) return r;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->renderers[renderer]->rendered = true;
+  return M3T_OK;
+}
+int m3t_hip_renderer_get_images(m3t_hip_context* ctx, int renderer, uint16_t* depth, uint8_t* silhouette,
+                                float info[3], int* n_visible) {
+  CHECK_CTX();
+  REQUIRE(renderer >= 0 && renderer < int(ctx->renderers.size()), M3T_ERR_INVALID_ARGUMENT, "bad renderer id");
+  RendererH& r = *ctx->renderers[renderer];
+  REQUIRE(r.rendered, M3T_ERR_NOT_SET_UP, "renderer has not rendered yet");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const size_t px = size_t(r.image_size) * r.image_size;
+  if (depth) HIPCHK(hipMemcpy(depth, r.depth.p, px * 2, hipMemcpyDeviceToHost));
+  if (silhouette) HIPCHK(hipMemcpy(silhouette, r.sil.p, px, hipMemcpyDeviceToHost));
+  float state[RS_FLOATS];
+  HIPCHK(hipMemcpy(state, r.state.p, sizeof(state), hipMemcpyDeviceToHost));
+  if (info) { info[0] = state[RS_CORNER_U]; info[1] = state[RS_CORNER_V]; info[2] = state[RS_SCALE]; }
+  if (n_visible) *n_visible = int(state[RS_N_VISIBLE]);
+  return M3T_OK;
+}
+static int CheckAttach(m3t_hip_context* ctx, int modality, int renderer, bool want_region, bool want_silhouette,
+                       int body) {
+  REQUIRE(renderer >= 0 && renderer < int(ctx->renderers.size()) &&
+              ctx->renderers[renderer]->silhouette == want_silhouette,
+          M3T_ERR_INVALID_ARGUMENT, "bad renderer id / kind");
+  bool referenced = false;
+  for (int b : ctx->renderers[renderer]->referenced) referenced |= b == body;
+  REQUIRE(referenced, M3T_ERR_INVALID_ARGUMENT, "the modality's body is not referenced by the renderer");
+  return M3T_OK;
+}
+int m3t_hip_region_modality_model_occlusions(m3t_hip_context* ctx, int modality, int renderer) {
+  CHECK_CTX();
+  RegionMod* m = GetRegion(ctx, modality);
+  REQUIRE(m, M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
+  int r = CheckAttach(ctx, modality, renderer, true, false, m->body);
+  if (r) return r;
+  const Model& mdl = *ctx->region_models[m->model];
+  REQUIRE(m->p.modeled_depth_offset_radius <= mdl.max_radius_depth_offset, M3T_ERR_INVALID_ARGUMENT,
+          "Modeled depth offset radius too large");
+  m->depth_renderer = renderer;
+  m->p.model_occlusions = 1;
+  m->dev.model_occlusions = 1;
+  m->dev.modeled_depth_offset_id = int(m->p.modeled_depth_offset_radius / mdl.stride_depth_offset + 0.5f);
+  m->dev.modeled_occlusion_radius = m->p.modeled_occlusion_radius;
+  m->dev.modeled_occlusion_threshold = m->p.modeled_occlusion_threshold;
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
+int m3t_hip_region_modality_use_region_checking(m3t_hip_context* ctx, int modality, int renderer) {
+  CHECK_CTX();
+  RegionMod* m = GetRegion(ctx, modality);
+  REQUIRE(m, M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
+  int r = CheckAttach(ctx, modality, renderer, true, true, m->body);
+  if (r) return r;
+  m->silhouette_renderer = renderer;
+  m->p.use_region_checking = 1;
+  m->dev.use_region_checking = 1;
+  m->dev.region_id = ctx->body_geometries[m->body]->region_id;
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
+int m3t_hip_depth_modality_model_occlusions(m3t_hip_context* ctx, int modality, int renderer) {
+  CHECK_CTX();
+  REQUIRE(modality >= 0 && modality < int(ctx->modalities.size()) && !ctx->modalities[modality].region,
+          M3T_ERR_INVALID_ARGUMENT, "bad depth modality id");
+  DepthMod* m = ctx->depth_mods[ctx->modalities[modality].index].get();
+  int r = CheckAttach(ctx, modality, renderer, false, false, m->body);
+  if (r) return r;
+  m->depth_renderer = renderer;
+  m->p.model_occlusions = 1;
+  m->dev.model_occlusions = 1;
+  m->dev.modeled_depth_offset_radius = m->p.modeled_depth_offset_radius;
+  m->dev.modeled_occlusion_radius = m->p.modeled_occlusion_radius;
+  m->dev.modeled_occlusion_threshold = m->p.modeled_occlusion_threshold;
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
+int m3t_hip_depth_modality_use_silhouette_checking(m3t_hip_context* ctx, int modality, int renderer) {
+  CHECK_CTX();
+  REQUIRE(modality >= 0 && modality < int(ctx->modalities.size()) && !ctx->modalities[modality].region,
+          M3T_ERR_INVALID_ARGUMENT, "bad depth modality id");
+  DepthMod* m = ctx->depth_mods[ctx->modalities[modality].index].get();
+  int r = CheckAttach(ctx, modality, renderer, false, true, m->body);
+  if (r) return r;
+  m->silhouette_renderer = renderer;
+  m->p.use_silhouette_checking = 1;
+  m->dev.use_silhouette_checking = 1;
+  m->dev.body_id = ctx->body_geometries[m->body]->body_id;
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
+
 int m3t_hip_link_create(m3t_hip_context* ctx, int body, int parent, const float body2joint[16],
                         const float joint2parent[16], const int free_directions[6], int fixed_body2joint_pose) {
   CHECK_CTX();
@@ -1650,6 +2001,7 @@ int m3t_hip_start_modalities(m3t_hip_context* ctx, int iteration) {
   }
   int r = Prepare(ctx, true);
   if (r) return r;
+  if ((r = RenderForModalities(ctx, true))) return r;  // start_modality_renderer_ptrs tracker.cpp:430-436
   return LaunchHistogram(ctx, iteration, true);
 }
 int m3t_hip_calculate_correspondences(m3t_hip_context* ctx, int iteration, int corr_iteration) {
@@ -1658,6 +2010,7 @@ int m3t_hip_calculate_correspondences(m3t_hip_context* ctx, int iteration, int c
   int r = Prepare(ctx, true);
   if (r) return r;
   ctx->state_valid = true;
+  if ((r = RenderForModalities(ctx, false))) return r;  // correspondence_renderer_ptrs tracker.cpp:447-452
   return LaunchCorrespondences(ctx, iteration, corr_iteration);
 }
 int m3t_hip_calculate_gradient_and_hessian(m3t_hip_context* ctx, int, int corr_iteration, int opt_iteration) {
@@ -1715,6 +2068,7 @@ int m3t_hip_calculate_results(m3t_hip_context* ctx, int iteration) {
   HIPCHK(hipSetDevice(ctx->device));
   int r = Prepare(ctx, true);
   if (r) return r;
+  if ((r = RenderForModalities(ctx, true))) return r;  // results_renderer_ptrs tracker.cpp:503-509
   return LaunchHistogram(ctx, iteration, false);
 }
 
@@ -1742,6 +2096,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   } else {
     // Tracker::ExecuteTrackingStep tracker.cpp:344-364, one launch per sub-step
     for (int c = 0; c < ctx->n_corr_iterations; ++c) {
+      if ((r = RenderForModalities(ctx, false))) return r;
       if ((r = LaunchCorrespondences(ctx, iteration, c))) return r;
       for (int u = 0; u < ctx->n_update_iterations; ++u) {
         if ((r = LaunchGradientHessian(ctx, c, u))) return r;
@@ -1750,6 +2105,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     }
     ctx->state_valid = true;
   }
+  if ((r = RenderForModalities(ctx, true))) return r;
   if ((r = LaunchHistogram(ctx, iteration, false))) return r;
   if (ctx->async_ingest) {
     // remember which frame slots this step reads, so that a later asynchronous upload into one of

@@ -299,6 +299,130 @@ __device__ bool occlusion_window_clear(CCam& dc, float center_u, float center_v,
 }
 
 // ---------------------------------------------------------------------------
+// renderer-fed branches: what the modalities read from a focused rendering (m3t_render.hip writes it)
+// ---------------------------------------------------------------------------
+// reading side (modalities)
+__device__ __forceinline__ bool renderer_body_visible(const RendererDev* r, int slot) {
+  return r != nullptr && slot >= 0 && r->state[RS_VISIBLE0 + slot] != 0.0f;
+}
+__device__ __forceinline__ float renderer_depth(const RendererDev& r, unsigned short value) {
+  return r.state[RS_TERM_A] / (r.state[RS_TERM_B] - (float)value);
+}
+// the minimum of the <= 6 x 6 strided samples of IsLineUnoccludedModeled :1391-1431 /
+// IsPointUnoccludedModeled depth_modality.cpp:778-824
+__device__ unsigned short modeled_window_min(const RendererDev& r, float center_u, float center_v, float diameter) {
+  const int size_minus_1 = r.image_size - 1;
+  int stride = f2i(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
+  int n_strides = f2i(diameter / stride + 0.5f);
+  int rounded_diameter = n_strides * stride;
+  float rounded_radius = 0.5f * (float)rounded_diameter;
+  float focused_center_u = (center_u - r.state[RS_CORNER_U]) * r.state[RS_SCALE];
+  float focused_center_v = (center_v - r.state[RS_CORNER_V]) * r.state[RS_SCALE];
+  int u_min = f2i(focused_center_u - rounded_radius + 0.5f);
+  int v_min = f2i(focused_center_v - rounded_radius + 0.5f);
+  int u_max = u_min + rounded_diameter;
+  int v_max = v_min + rounded_diameter;
+  u_min = max(u_min, 0);
+  v_min = max(v_min, 0);
+  u_max = min(u_max, size_minus_1);
+  v_max = min(v_max, size_minus_1);
+  unsigned short min_value = 65535;
+  for (int v = v_min; v <= v_max; v += stride)
+    for (int u = u_min; u <= u_max; u += stride) {
+      unsigned short d = r.depth_image[(size_t)v * r.image_size + u];
+      min_value = d < min_value ? d : min_value;
+    }
+  return min_value;
+}
+__device__ __forceinline__ int silhouette_at(const RendererDev& r, float u, float v) {  // -1: off the image
+  const float size = (float)r.image_size;
+  if (u >= size || u < 0.0f || v >= size || v < 0.0f) return -1;
+  return r.silhouette_image[(size_t)f2i(v) * r.image_size + f2i(u)];
+}
+// IsDynamicLineRegionSufficient :1293-1341 (an off-image coordinate in the foreground loop, which the
+// reference reads unchecked, counts as another region)
+__device__ bool dynamic_line_region_sufficient(const RendererDev& r, int region_id, float min_continuous_distance,
+                                               float fscale, float center_u, float center_v, float normal_u,
+                                               float normal_v) {
+  const float scale = r.state[RS_SCALE];
+  float focused_min_continuous_distance = min_continuous_distance * fscale * scale;
+  float focused_stride = fmaxf((focused_min_continuous_distance - M3T_REGION_OFFSET) / (float)M3T_N_REGION_STRIDE, 0.0f);
+  float stride_u = focused_stride * normal_u;
+  float stride_v = focused_stride * normal_v;
+  float offset_u = M3T_REGION_OFFSET * normal_u;
+  float offset_v = M3T_REGION_OFFSET * normal_v;
+  float focused_center_u = 0.5f + (center_u - r.state[RS_CORNER_U]) * scale;
+  float focused_center_v = 0.5f + (center_v - r.state[RS_CORNER_V]) * scale;
+  float u = focused_center_u - offset_u;
+  float v = focused_center_v - offset_v;
+  for (int i = 0; i <= M3T_N_REGION_STRIDE; ++i) {
+    if (silhouette_at(r, u, v) != region_id) return false;
+    u -= stride_u;
+    v -= stride_v;
+  }
+  u = focused_center_u + offset_u;
+  v = focused_center_v + offset_v;
+  for (int i = 0; i <= M3T_N_REGION_STRIDE; ++i) {
+    int id = silhouette_at(r, u, v);
+    if (id < 0) break;
+    if (id == region_id) return false;
+    u += stride_u;
+    v += stride_v;
+  }
+  return true;
+}
+// DynamicRegionDistance :1157-1229 (with the assignment to the *foreground* distance in the background loop)
+__device__ void dynamic_region_distance(const RendererDev& r, int region_id, float max_considered_line_length,
+                                        float unconsidered_line_length, float center_u, float center_v,
+                                        float normal_u, float normal_v, float* foreground, float* background) {
+  const float scale = r.state[RS_SCALE];
+  float stride = max_considered_line_length / (float)M3T_N_REGION_STRIDE;
+  float focused_stride = stride * scale;
+  float focused_stride_u = focused_stride * normal_u;
+  float focused_stride_v = focused_stride * normal_v;
+  float delta_start = M3T_REGION_OFFSET / scale - unconsidered_line_length;
+  int i_start = max(f2i(delta_start / stride + 1.0f), 0);
+  float offset = unconsidered_line_length + (float)i_start * stride;
+  float focused_offset = offset * scale;
+  float focused_offset_u = focused_offset * normal_u;
+  float focused_offset_v = focused_offset * normal_v;
+  float focused_center_u = 0.5f + (center_u - r.state[RS_CORNER_U]) * scale;
+  float focused_center_v = 0.5f + (center_v - r.state[RS_CORNER_V]) * scale;
+  float u = focused_center_u - focused_offset_u;
+  float v = focused_center_v - focused_offset_v;
+  for (int i = i_start; i <= M3T_N_REGION_STRIDE; ++i) {
+    int id = silhouette_at(r, u, v);
+    if (id < 0) {
+      *foreground = stride * (float)i;
+      break;
+    }
+    if (id != region_id) {
+      *foreground = i == i_start ? 0.0f : stride * (float)i;
+      break;
+    }
+    u -= focused_stride_u;
+    v -= focused_stride_v;
+  }
+  u = focused_center_u + focused_offset_u;
+  v = focused_center_v + focused_offset_v;
+  for (int i = i_start; i <= M3T_N_REGION_STRIDE; ++i) {
+    int id = silhouette_at(r, u, v);
+    if (id < 0) {
+      *background = max_considered_line_length;
+      break;
+    }
+    if (id == region_id) {
+      if (i == i_start) *background = 0.0f;
+      else *foreground = stride * (float)i;
+      break;
+    }
+    u += focused_stride_u;
+    v += focused_stride_v;
+  }
+}
+
+
+// ---------------------------------------------------------------------------
 // iteration-dependent scalars (PrecalculateIterationDependentVariables :1011-1023)
 // ---------------------------------------------------------------------------
 struct RegionIter {
@@ -567,8 +691,13 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   const int n_lines =
       number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length, as_global(m.extents), view,
                       m.max_extent, m.n_points);
-  const bool occlusion_pass =
-      m.measure_occlusions && (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
+  const bool handle_occlusions = (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
+  const bool measured_pass = m.measure_occlusions && handle_occlusions;
+  const bool modeled_pass = m.model_occlusions && handle_occlusions &&
+                            renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
+  const bool region_checking =
+      m.use_region_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
+  const bool occlusion_pass = measured_pass || modeled_pass;
   const int n_seg = m.n_seg;
   G<uint8_t> image = as_global(cam.image);
   const uint32_t pitch = cam.pitch;
@@ -615,8 +744,19 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
       if (valid)
         valid = !(start < 0 || end > maj_lim || f2i(x0) < 0 || f2i(x0) > min_lim1 || f2i(xend) < 1 ||
                   f2i(xend) > min_lim2);
+      // IsLineValid :1252-1291: region checking applies in both passes, the occlusion tests in the first
+      if (valid && region_checking)
+        valid = dynamic_line_region_sufficient(*m.silhouette_renderer, m.region_id, m.min_continuous_distance,
+                                               it.fscale, center_u, center_v, nu, nv);
       bool valid_occ = valid;
-      if (valid && occlusion_pass) {
+      if (valid && modeled_pass) {
+        G<float> p = as_global(m.points) + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
+        float diameter = 2.0f * m.modeled_occlusion_radius * ((cam.fu / Z) * m.depth_renderer->state[RS_SCALE]);
+        unsigned short min_value = modeled_window_min(*m.depth_renderer, center_u, center_v, diameter);
+        valid_occ = renderer_depth(*m.depth_renderer, min_value) >
+                    Z - p[8 + m.modeled_depth_offset_id] - m.modeled_occlusion_threshold;
+      }
+      if (valid_occ && measured_pass) {
         float dx, dy, dz;
         apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
         float du = dx * dcam->fu / dz + dcam->ppu;
@@ -1195,7 +1335,13 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
                                  m.max_extent, m.n_points);
   const float considered_distance0 = last_valid(m.considered_distances, m.n_considered_distances, corr_iteration);
   const int max_n_strides = f2i(considered_distance0 / m.stride_length + 0.5f);
-  const bool occlusion_pass = m.measure_occlusions && (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
+  const bool handle_occlusions = (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
+  const bool measured_pass = m.measure_occlusions && handle_occlusions;
+  const bool modeled_pass = m.model_occlusions && handle_occlusions &&
+                            renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
+  const bool silhouette_checking =
+      m.use_silhouette_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
+  const bool occlusion_pass = measured_pass || modeled_pass;
   G<uint8_t> image = as_global(cam.image);
   int my_valid_occ = 0;
   const int np_round = (np + nt / kGroup - 1) / (nt / kGroup) * (nt / kGroup);
@@ -1216,6 +1362,13 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
     if (valid) {
       int icu = f2i(center_u + 0.5f), icv = f2i(center_v + 0.5f);
       valid = !(icu < 0 || icu > cam.width - 1 || icv < 0 || icv > cam.height - 1);
+      if (valid && silhouette_checking) {  // IsPointOnValidSilhouette :728-734, SilhouetteValue silhouette_renderer.cpp:394-399
+        const RendererDev& sr = *m.silhouette_renderer;
+        int fu_ = f2i(((float)icu - sr.state[RS_CORNER_U]) * sr.state[RS_SCALE] + 0.5f);
+        int fv_ = f2i(((float)icv - sr.state[RS_CORNER_V]) * sr.state[RS_SCALE] + 0.5f);
+        valid = fu_ >= 0 && fu_ < sr.image_size && fv_ >= 0 && fv_ < sr.image_size &&
+                sr.silhouette_image[(size_t)fv_ * sr.image_size + fu_] == m.body_id;
+      }
     }
     // FindCorrespondence: window limits (uniform inside the row)
     float cd = considered_distance0;
@@ -1299,7 +1452,7 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
 #undef M3T_ROW_MIN_STEP
     // measured occlusion (IsPointUnoccludedMeasured :736-776), the row ORs its samples
     int occluded = 0;
-    if (occlusion_pass && valid) {
+    if (measured_pass && valid) {
       float radius = m.measured_depth_offset_radius;
       if (m.use_depth_scaling) radius *= depth;
       int id = f2i(radius / m.stride_depth_offset + 0.5f);
@@ -1346,6 +1499,20 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
         float t0 = ((float)u - cam.ppu) * d / cam.fu;
         float t1 = ((float)v - cam.ppv) * d / cam.fv;
         bool valid_occ = !occluded;
+        if (valid_occ && modeled_pass) {  // IsPointUnoccludedModeled :778-824
+          const RendererDev& dr = *m.depth_renderer;
+          float radius = m.modeled_depth_offset_radius;
+          if (m.use_depth_scaling) radius *= depth;
+          int id = f2i(radius / m.stride_depth_offset + 0.5f);
+          if (id >= M3T_N_DEPTH_OFFSETS) id = M3T_N_DEPTH_OFFSETS - 1;
+          float meter_to_pixel = cam.fu * dr.state[RS_SCALE];
+          if (!m.use_depth_scaling) meter_to_pixel /= depth;
+          float diameter = 2.0f * m.modeled_occlusion_radius * meter_to_pixel;
+          unsigned short min_value = modeled_window_min(dr, center_u, center_v, diameter);
+          float threshold = m.modeled_occlusion_threshold;
+          if (m.use_depth_scaling) threshold *= depth;
+          valid_occ = renderer_depth(dr, min_value) > depth - p[6 + id] - threshold;
+        }
         flags = (valid_occ ? 1 : 0) | 2;
         my_valid_occ += valid_occ ? 1 : 0;
         ps[PS_CX * np + i] = cx; ps[PS_CY * np + i] = cy; ps[PS_CZ * np + i] = cz;
@@ -1474,6 +1641,9 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
                                       as_global(m.extents), view, m.max_extent, m.n_points);
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = n_bins * n_bins;
   const int w1 = cam.width - 1, h1 = cam.height - 1;
+  const bool visible_depth = m.model_occlusions && renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
+  const bool visible_silhouette =
+      m.use_region_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
   // two lanes per line: even lane = foreground walk (inwards), odd lane = background walk
   for (int item = tid; item < 2 * n_lines; item += nt) {
     const int line = item >> 1;
@@ -1489,6 +1659,13 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     float center_v = Y * cam.fv / Z + cam.ppv;
     int icu = f2i(center_u + 0.5f), icv = f2i(center_v + 0.5f);
     if ((float)icu < 0.0f || icu > w1 || icv < 0 || icv > h1) continue;
+    if (handle_occlusions && m.model_occlusions && visible_depth) {  // :1079-1083
+      float diameter = 2.0f * m.modeled_occlusion_radius * ((cam.fu / Z) * m.depth_renderer->state[RS_SCALE]);
+      unsigned short min_value = modeled_window_min(*m.depth_renderer, center_u, center_v, diameter);
+      if (!(renderer_depth(*m.depth_renderer, min_value) >
+            Z - p[8 + m.modeled_depth_offset_id] - m.modeled_occlusion_threshold))
+        continue;
+    }
     if (handle_occlusions && m.measure_occlusions) {
       float dx, dy, dz;
       apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
@@ -1500,6 +1677,14 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
         continue;
     }
     float length_f = m.max_considered_line_length, length_b = m.max_considered_line_length;
+    if (m.use_region_checking && visible_silhouette) {  // :1094-1099
+      float ru = (b2c.l[0] * pa.w + b2c.l[3] * pb4.x) + b2c.l[6] * pb4.y;
+      float rv = (b2c.l[1] * pa.w + b2c.l[4] * pb4.x) + b2c.l[7] * pb4.y;
+      float rn = sqrtf(ru * ru + rv * rv);
+      if (rn > 0.0f) { ru = ru / rn; rv = rv / rn; }
+      dynamic_region_distance(*m.silhouette_renderer, m.region_id, m.max_considered_line_length,
+                              m.unconsidered_line_length, center_u, center_v, ru, rv, &length_f, &length_b);
+    }
     float l_f = pb4.z * cam.fu / Z;
     float l_b = pb4.w * cam.fu / Z;
     length_f = fminf(length_f, l_f - 2.0f * m.unconsidered_line_length);

@@ -103,6 +103,73 @@ class Body:
         self.api.call("body_get_body2world_pose", self.id, fptr(buf))
         return pose_ret(buf)
 
+    def set_geometry(self, vertices, triangles, geometry2body_pose=np.eye(4), geometry_counterclockwise=True,
+                     geometry_enable_culling=True, body_id=0, region_id=0):
+        """the mesh of body.h (vertices in metres) for the renderer-fed branches"""
+        v = np.ascontiguousarray(vertices, np.float32)
+        t = np.ascontiguousarray(triangles, np.int32)
+        g = _capi.BodyGeometry()
+        g.vertices, g.n_vertices = fptr(v), len(v)
+        g.triangles, g.n_triangles = iptr(t), len(t)
+        g2b = pose_arg(geometry2body_pose)
+        for i in range(16):
+            g.geometry2body[i] = float(g2b[i])
+        g.geometry_counterclockwise = int(geometry_counterclockwise)
+        g.geometry_enable_culling = int(geometry_enable_culling)
+        g.body_id, g.region_id = int(body_id), int(region_id)
+        self.api.call("body_set_geometry", self.id, C.byref(g))
+
+
+class RendererGeometry:
+    """m3t::RendererGeometry: the bodies a renderer draws, in draw order"""
+
+    def __init__(self, api):
+        self.api = api
+        self.id = api.call("renderer_geometry_create")
+
+    def AddBody(self, body):
+        self.api.call("renderer_geometry_add_body", self.id, body.id)
+
+
+class _FocusedRenderer:
+    def __init__(self, api, rid, image_size, silhouette):
+        self.api, self.id, self.image_size, self.silhouette = api, rid, image_size, silhouette
+
+    def AddReferencedBody(self, body):
+        self.api.call("renderer_add_referenced_body", self.id, body.id)
+
+    def StartRendering(self):
+        self.api.call("renderer_start_rendering", self.id)
+        return True
+
+    def images(self):
+        """(depth u16 [S,S], silhouette u8 [S,S] or None, corner_u, corner_v, scale, n_visible)"""
+        s = self.image_size
+        depth = np.zeros((s, s), np.uint16)
+        sil = np.zeros((s, s), np.uint8) if self.silhouette else None
+        info = np.zeros(3, np.float32)
+        n = C.c_int()
+        self.api.call("renderer_get_images", self.id, depth.ctypes.data_as(C.POINTER(C.c_uint16)),
+                      sil.ctypes.data_as(C.POINTER(C.c_uint8)) if sil is not None else None, fptr(info), C.byref(n))
+        return depth, sil, float(info[0]), float(info[1]), float(info[2]), n.value
+
+
+class FocusedBasicDepthRenderer(_FocusedRenderer):
+    """basic_depth_renderer.h:120-128"""
+
+    def __init__(self, api, renderer_geometry, camera, image_size=200, z_min=0.02, z_max=10.0):
+        rid = api.call("focused_depth_renderer_create", renderer_geometry.id, camera.id, image_size, z_min, z_max)
+        super().__init__(api, rid, image_size, False)
+
+
+class FocusedSilhouetteRenderer(_FocusedRenderer):
+    """silhouette_renderer.h:150-155; id_type 0 = IDType::BODY, 1 = IDType::REGION"""
+
+    def __init__(self, api, renderer_geometry, camera, id_type=0, image_size=200, z_min=0.02, z_max=10.0):
+        rid = api.call("focused_silhouette_renderer_create", renderer_geometry.id, camera.id, id_type, image_size,
+                       z_min, z_max)
+        super().__init__(api, rid, image_size, True)
+
 
 class _Camera:
     def __init__(self, api, cam_id, width, height, bytes_per_pixel):
@@ -237,6 +304,12 @@ class RegionModality(_Modality):
                            region_model.id, depth_camera.id if depth_camera is not None else -1)
         self.n_bins = self.params.n_histogram_bins
 
+    def ModelOcclusions(self, depth_renderer):
+        self.api.call("region_modality_model_occlusions", self.id, depth_renderer.id)
+
+    def UseRegionChecking(self, silhouette_renderer):
+        self.api.call("region_modality_use_region_checking", self.id, silhouette_renderer.id)
+
     def data_lines(self):
         n = C.c_int()
         cap = self.params.n_lines_max
@@ -263,6 +336,12 @@ class DepthModality(_Modality):
         self.api = api
         self.params = params if params is not None else DepthModalityParams(**kw)
         self.id = api.call("depth_modality_create", C.byref(self.params), body.id, depth_camera.id, depth_model.id)
+
+    def ModelOcclusions(self, depth_renderer):
+        self.api.call("depth_modality_model_occlusions", self.id, depth_renderer.id)
+
+    def UseSilhouetteChecking(self, silhouette_renderer):
+        self.api.call("depth_modality_use_silhouette_checking", self.id, silhouette_renderer.id)
 
     def data_points(self):
         n = C.c_int()
@@ -341,5 +420,6 @@ class SoftConstraint:
 
 
 __all__ = ["Tracker", "Body", "ColorCamera", "DepthCamera", "RegionModel", "DepthModel", "RegionModality",
-           "DepthModality", "Link", "Optimizer", "Constraint", "SoftConstraint", "M3TError", "RegionModalityParams",
+           "DepthModality", "Link", "Optimizer", "Constraint", "SoftConstraint", "RendererGeometry",
+           "FocusedBasicDepthRenderer", "FocusedSilhouetteRenderer", "M3TError", "RegionModalityParams",
            "DepthModalityParams"]

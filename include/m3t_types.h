@@ -30,6 +30,8 @@ extern "C" {
 #define M3T_REGION_POINT_FLOATS 38  /* RegionModel::DataPoint = 152 B */
 #define M3T_DEPTH_POINT_FLOATS 36   /* DepthModel::DataPoint  = 144 B */
 #define M3T_MAX_N_OCCLUSION_STRIDES 5 /* kMaxNOcclusionStrides, region_modality.h:145 */
+#define M3T_N_REGION_STRIDE 5          /* kNRegionStride, region_modality.h:146 */
+#define M3T_REGION_OFFSET 2.0f         /* kRegionOffset, region_modality.h:147 */
 
 /* status codes (the reference returns bool + std::cerr; 0 == true) */
 enum {
@@ -95,14 +97,17 @@ typedef struct m3t_region_modality_params {
   float unconsidered_line_length;
   float max_considered_line_length;
   /* occlusion handling and line validation */
-  int use_region_checking;  /* must be 0 (needs FocusedSilhouetteRenderer) */
+  int use_region_checking;  /* 0 at creation; switched on by *_region_modality_use_region_checking() */
   int measure_occlusions;
   float measured_depth_offset_radius;
   float measured_occlusion_radius;
   float measured_occlusion_threshold;
-  int model_occlusions;     /* must be 0 (needs FocusedDepthRenderer) */
+  int model_occlusions;     /* 0 at creation; switched on by *_region_modality_model_occlusions() */
   int n_unoccluded_iterations;
   int min_n_unoccluded_lines;
+  float modeled_depth_offset_radius;
+  float modeled_occlusion_radius;
+  float modeled_occlusion_threshold;
 } m3t_region_modality_params;
 
 typedef struct m3t_depth_modality_params {
@@ -115,15 +120,36 @@ typedef struct m3t_depth_modality_params {
   float considered_distances[M3T_MAX_SCALES];
   int n_standard_deviations;
   float standard_deviations[M3T_MAX_SCALES];
-  int use_silhouette_checking; /* must be 0 */
+  int use_silhouette_checking; /* 0 at creation; switched on by *_depth_modality_use_silhouette_checking() */
   int measure_occlusions;
   float measured_depth_offset_radius;
   float measured_occlusion_radius;
   float measured_occlusion_threshold;
-  int model_occlusions;        /* must be 0 */
+  int model_occlusions;        /* 0 at creation; switched on by *_depth_modality_model_occlusions() */
   int n_unoccluded_iterations;
   int min_n_unoccluded_points;
+  float modeled_depth_offset_radius;
+  float modeled_occlusion_radius;
+  float modeled_occlusion_threshold;
 } m3t_depth_modality_params;
+
+/* Body geometry for the renderer-fed branches (body.h:46-60, body.cpp:196-250): a triangle mesh in
+ * metres (geometry_unit_in_meter already applied), its pose in the body frame and the two ids the
+ * silhouette renderer writes (body.h: body_id / region_id). */
+typedef struct m3t_body_geometry {
+  const float* vertices; /* [n_vertices][3] */
+  int n_vertices;
+  const int* triangles;  /* [n_triangles][3] vertex indices */
+  int n_triangles;
+  float geometry2body[16];
+  int geometry_counterclockwise;
+  int geometry_enable_culling;
+  int body_id;   /* 0..255 */
+  int region_id; /* 0..255 */
+} m3t_body_geometry;
+#define M3T_ID_TYPE_BODY 0   /* IDType::BODY */
+#define M3T_ID_TYPE_REGION 1 /* IDType::REGION */
+#define M3T_MAX_RENDERER_BODIES 8
 
 /* RegionModality::DataLine, the fields CalculateGradientAndHessian reads
  * (region_modality.h:108-124).  Returned by *_region_modality_get_lines for
@@ -187,6 +213,9 @@ static inline void m3t_region_modality_params_default(m3t_region_modality_params
   p->model_occlusions = 0;
   p->n_unoccluded_iterations = 10;
   p->min_n_unoccluded_lines = 0;
+  p->modeled_depth_offset_radius = 0.01f;
+  p->modeled_occlusion_radius = 0.01f;
+  p->modeled_occlusion_threshold = 0.03f;
 }
 
 static inline void m3t_depth_modality_params_default(m3t_depth_modality_params* p) {
@@ -212,6 +241,9 @@ static inline void m3t_depth_modality_params_default(m3t_depth_modality_params* 
   p->model_occlusions = 0;
   p->n_unoccluded_iterations = 10;
   p->min_n_unoccluded_points = 0;
+  p->modeled_depth_offset_radius = 0.01f;
+  p->modeled_occlusion_radius = 0.01f;
+  p->modeled_occlusion_threshold = 0.03f;
 }
 
 #ifdef __cplusplus

@@ -511,8 +511,18 @@ struct Camera {
     return v;
   }
 };
+struct BodyGeometry {  // body.h:46-60, body.cpp:196-250
+  bool set = false;
+  std::vector<float> vertices;  // metres
+  std::vector<int> triangles;   // counter-clockwise after loading (body.cpp:227-236)
+  Mat4 geometry2body = Identity4();
+  bool enable_culling = true;
+  int body_id = 0, region_id = 0;
+  float maximum_body_diameter = 0.0f;
+};
 struct Body {
   Mat4 body2world = Identity4();
+  BodyGeometry geometry;
 };
 
 template <typename T>
@@ -535,6 +545,37 @@ struct Modality {
 struct Context;
 
 // ---------------------------------------------------------------------------
+// FocusedBasicDepthRenderer / FocusedSilhouetteRenderer restated for software
+// (renderer.cpp:348-405, basic_depth_renderer.cpp:45-84, silhouette_renderer.cpp:54-100): the
+// rasterisation follows OpenGL's rules (pixel centres at integer image coordinates as the
+// projection matrices of renderer.cpp place them, window coordinates snapped to 1/256 pixel,
+// top-left fill rule, GL_DEPTH_COMPONENT16 with GL_LESS in draw order).  The same rules,
+// prototyped in tests/golden/gl_model.py, reproduce the reference's own OpenGL model files.
+// ---------------------------------------------------------------------------
+struct FocusedRenderer {
+  bool silhouette = false;
+  int camera = -1, id_type = M3T_ID_TYPE_BODY, image_size = 200;
+  float z_min = 0.02f, z_max = 10.0f;
+  std::vector<int> geometry_bodies;    // draw order
+  std::vector<int> referenced_bodies;
+  // results of the last StartRendering
+  float corner_u = 0.0f, corner_v = 0.0f, scale = 1.0f;
+  float projection_term_a = 0.0f, projection_term_b = 0.0f;
+  std::vector<char> visible;            // per referenced body
+  std::vector<uint16_t> depth_image;
+  std::vector<uint8_t> silhouette_image;
+  bool rendered = false;
+
+  bool IsBodyVisible(int body) const {
+    for (size_t i = 0; i < referenced_bodies.size(); ++i)
+      if (referenced_bodies[i] == body) return rendered && visible[i] != 0;
+    return false;
+  }
+  float Depth(uint16_t value) const { return projection_term_a / (projection_term_b - float(value)); }
+  void StartRendering(const Context* ctx);
+};
+
+// ---------------------------------------------------------------------------
 // RegionModality  (src/region_modality.cpp)
 // ---------------------------------------------------------------------------
 struct DataLine {  // region_modality.h:108-124
@@ -542,6 +583,7 @@ struct DataLine {  // region_modality.h:108-124
   float center_f_camera[3];
   float center_u, center_v, normal_u, normal_v;
   float measured_depth_offset;
+  float modeled_depth_offset;
   float continuous_distance;
   float delta_r, normal_component_to_scale;
   float distribution[M3T_MAX_DISTRIBUTION_LENGTH];
@@ -563,7 +605,8 @@ struct RegionModality : Modality {
   int image_width_minus_1, image_height_minus_1, image_width_minus_2, image_height_minus_2;
   float depth_fu, depth_fv, depth_ppu, depth_ppv, depth_scale;
   int depth_image_width_minus_1, depth_image_height_minus_1;
-  int measured_depth_offset_id = 0;
+  int measured_depth_offset_id = 0, modeled_depth_offset_id = 0;
+  int depth_renderer = -1, silhouette_renderer = -1;  // ModelOcclusions / UseRegionChecking
   // pose variables
   Mat4 body2camera_pose, body2depth_camera_pose;
   Mat3 body2camera_rotation;
@@ -581,8 +624,13 @@ struct RegionModality : Modality {
   int NumberOfLines(int view) const;
   void AddLinePixelColorsToTempHistograms(bool handle_occlusions);
   void CalculateBasicLineData(const float* data_point, DataLine* data_line) const;
-  bool IsLineValid(const DataLine& data_line, bool measure_occlusions) const;
+  bool IsLineValid(const DataLine& data_line, bool use_region_checking, bool measure_occlusions,
+                   bool model_occlusions) const;
   bool IsLineUnoccludedMeasured(const float center_f_body[3], float depth_offset) const;
+  bool IsLineUnoccludedModeled(float center_u, float center_v, float depth, float depth_offset) const;
+  bool IsDynamicLineRegionSufficient(float center_u, float center_v, float normal_u, float normal_v) const;
+  void DynamicRegionDistance(float center_u, float center_v, float normal_u, float normal_v,
+                             float* dynamic_foreground_distance, float* dynamic_background_distance) const;
   bool CalculateSegmentProbabilities(float center_u, float center_v, float normal_u, float normal_v,
                                      float* segment_probabilities_f, float* segment_probabilities_b,
                                      float* normal_component_to_scale, float* delta_r) const;
@@ -603,7 +651,7 @@ struct RegionModality : Modality {
 struct DepthDataPoint {  // depth_modality.h:96-108
   float center_f_body[3], center_f_camera[3], normal_f_body[3];
   float center_u, center_v, depth;
-  float measured_depth_offset;
+  float measured_depth_offset, modeled_depth_offset;
   float correspondence_center_f_camera[3];
   int model_point_index;
 };
@@ -624,8 +672,12 @@ struct DepthModality : Modality {
   void PrecalculatePoseVariables();
   void PrecalculateIterationDependentVariables(int corr_iteration);
   void CalculateBasicPointData(const float* model_point, DepthDataPoint* dp) const;
-  bool IsPointValid(const DepthDataPoint& dp, bool measure_occlusions) const;
+  int depth_renderer = -1, silhouette_renderer = -1;  // ModelOcclusions / UseSilhouetteChecking
+  bool IsPointValid(const DepthDataPoint& dp, bool use_silhouette_checking, bool measure_occlusions,
+                    bool model_occlusions) const;
   bool IsPointUnoccludedMeasured(const DepthDataPoint& dp) const;
+  bool IsPointUnoccludedModeled(const DepthDataPoint& dp) const;
+  bool IsPointOnValidSilhouette(const DepthDataPoint& dp) const;
   bool FindCorrespondence(const DepthDataPoint& dp, float* correspondence) const;
 
   bool StartModality(int, int) override { return true; }  // depth_modality.cpp:248-250
@@ -685,6 +737,9 @@ struct Context {
   std::vector<std::unique_ptr<Camera>> cameras;
   std::vector<Body> bodies;
   std::vector<std::unique_ptr<Modality>> modalities;
+  std::vector<std::vector<int>> renderer_geometries;  // RendererGeometry: body ids in draw order
+  std::vector<FocusedRenderer> renderers;
+  std::vector<int> renderer_geometry_of;  // renderer -> RendererGeometry
   std::vector<Link> links;
   std::vector<Constraint> constraints;
   std::vector<SoftConstraint> soft_constraints;
@@ -697,6 +752,164 @@ struct Context {
     return l.body >= 0 ? bodies[l.body].body2world : l.link2world;
   }
 };
+
+// ===========================================================================
+// FocusedRenderer implementation
+// ===========================================================================
+namespace render {
+struct M44 { float m[16]; float operator()(int r, int c) const { return m[c * 4 + r]; } float& operator()(int r, int c) { return m[c * 4 + r]; } };
+M44 Mul(const M44& a, const M44& b) {
+  M44 o;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      o(r, c) = ((a(r, 0) * b(0, c) + a(r, 1) * b(1, c)) + a(r, 2) * b(2, c)) + a(r, 3) * b(3, c);
+  return o;
+}
+M44 FromPose(const Mat4& p) {
+  M44 o;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) o(r, c) = p(r, c);
+  return o;
+}
+int64_t FloorDiv(int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+}  // namespace render
+
+void FocusedRenderer::StartRendering(const Context* ctx) {
+  using namespace render;
+  const Camera& cam = *ctx->cameras[camera];
+  const m3t_intrinsics& in = cam.intr;
+  const int S = image_size;
+  // FocusedRenderer::CalculateProjectionMatrix renderer.cpp:348-405
+  visible.assign(referenced_bodies.size(), 0);
+  float u_min = std::numeric_limits<float>::max();
+  float u_max = std::numeric_limits<float>::min();
+  float v_min = std::numeric_limits<float>::max();
+  float v_max = std::numeric_limits<float>::min();
+  int n_visible = 0;
+  for (size_t k = 0; k < referenced_bodies.size(); ++k) {
+    const Body& b = ctx->bodies[referenced_bodies[k]];
+    float r = 0.5f * b.geometry.maximum_body_diameter;
+    float bt[3] = {b.body2world(0, 3), b.body2world(1, 3), b.body2world(2, 3)}, t[3];
+    Apply(cam.world2camera, bt, t);
+    float x = t[0], y = t[1], z = t[2];
+    if (z < r * 1.5f || z - r < z_min || z + r > z_max) continue;
+    float abs_x = std::fabs(x), abs_y = std::fabs(y);
+    float x2 = x * x, y2 = y * y, z2 = z * z, r2 = r * r;
+    float rz = r * z;
+    float z2_r2 = z2 - r2;
+    float z3_zr2 = z2_r2 * z;
+    float r_u = in.fu * (abs_x * r2 + rz * std::sqrt(z2_r2 + x2)) / z3_zr2;
+    float r_v = in.fv * (abs_y * r2 + rz * std::sqrt(z2_r2 + y2)) / z3_zr2;
+    float center_u = x * in.fu / z + in.ppu;
+    float center_v = y * in.fv / z + in.ppv;
+    float u_min_body = center_u - r_u, u_max_body = center_u + r_u;
+    float v_min_body = center_v - r_v, v_max_body = center_v + r_v;
+    if (u_min_body > in.width || u_max_body < 0 || v_min_body > in.height || v_max_body < 0) continue;
+    u_min = std::min(u_min, u_min_body);
+    u_max = std::max(u_max, u_max_body);
+    v_min = std::min(v_min, v_min_body);
+    v_max = std::max(v_max, v_max_body);
+    visible[k] = 1;
+    ++n_visible;
+  }
+  depth_image.assign(size_t(S) * S, 65535);
+  silhouette_image.assign(size_t(S) * S, 0);
+  projection_term_a = z_max * z_min * 65535.0f / (z_max - z_min);  // renderer.cpp:567-570
+  projection_term_b = z_max * 65535.0f / (z_max - z_min);
+  rendered = true;
+  if (n_visible == 0) {  // the reference renders with a meaningless crop here; nothing reads it
+    corner_u = corner_v = 0.0f;
+    scale = 1.0f;
+    return;
+  }
+  float d = std::max(u_max - u_min, v_max - v_min) * 1.05f;  // kImageSizeSafetyMargin
+  corner_u = 0.5f * (u_min + u_max - d);
+  corner_v = 0.5f * (v_min + v_max - d);
+  scale = float(S) / d;
+  float ppu_scaled = (in.ppu - corner_u) * scale;
+  float ppv_scaled = (in.ppv - corner_v) * scale;
+  M44 P;
+  for (float& f : P.m) f = 0.0f;
+  P(0, 0) = 2.0f * in.fu / d;
+  P(0, 2) = 2.0f * (ppu_scaled + 0.5f) / float(S) - 1.0f;
+  P(1, 1) = 2.0f * in.fv / d;
+  P(1, 2) = 2.0f * (ppv_scaled + 0.5f) / float(S) - 1.0f;
+  P(2, 2) = (z_max + z_min) / (z_max - z_min);
+  P(2, 3) = -2.0f * z_max * z_min / (z_max - z_min);
+  P(3, 2) = 1.0f;
+
+  // z-buffer of packed (depth16 << 16 | draw order << 8 | id): the minimum is GL_LESS on a 16-bit depth
+  // buffer with the earlier-drawn body winning ties
+  std::vector<uint32_t> packed(size_t(S) * S, 0xffffffffu);
+  const float half_s = 0.5f * float(S);
+  for (size_t order = 0; order < geometry_bodies.size(); ++order) {
+    const Body& b = ctx->bodies[geometry_bodies[order]];
+    const BodyGeometry& g = b.geometry;
+    const uint32_t id = uint32_t(silhouette ? (id_type == M3T_ID_TYPE_REGION ? g.region_id : g.body_id) : 0);
+    const M44 trans = Mul(P, Mul(FromPose(cam.world2camera), Mul(FromPose(b.body2world), FromPose(g.geometry2body))));
+    const size_t n_tri = g.triangles.size() / 3;
+    for (size_t t = 0; t < n_tri; ++t) {
+      int64_t sx[3], sy[3];
+      float wz[3];
+      bool behind = false;
+      for (int k = 0; k < 3; ++k) {
+        const float* p = &g.vertices[size_t(g.triangles[t * 3 + k]) * 3];
+        float cx = ((trans(0, 0) * p[0] + trans(0, 1) * p[1]) + trans(0, 2) * p[2]) + trans(0, 3);
+        float cy = ((trans(1, 0) * p[0] + trans(1, 1) * p[1]) + trans(1, 2) * p[2]) + trans(1, 3);
+        float cz = ((trans(2, 0) * p[0] + trans(2, 1) * p[1]) + trans(2, 2) * p[2]) + trans(2, 3);
+        float cw = ((trans(3, 0) * p[0] + trans(3, 1) * p[1]) + trans(3, 2) * p[2]) + trans(3, 3);
+        if (!(cw > 0.0f)) { behind = true; break; }  // no near-plane clipping: such triangles are dropped
+        float wx = (cx / cw + 1.0f) * half_s;
+        float wy = (cy / cw + 1.0f) * half_s;
+        wz[k] = (cz / cw + 1.0f) * 0.5f;
+        sx[k] = int64_t(std::floor(double(wx) * 256.0 + 0.5));
+        sy[k] = int64_t(std::floor(double(wy) * 256.0 + 0.5));
+      }
+      if (behind) continue;
+      int64_t area = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sy[1] - sy[0]) * (sx[2] - sx[0]);
+      if (area == 0) continue;
+      // counter-clockwise meshes seen from outside have negative area in the y-down image
+      // (glFrontFace(GL_CCW) + glCullFace(GL_FRONT) under the flipped projection)
+      if (area > 0 && g.enable_culling) continue;
+      int i0 = 0, i1 = 1, i2 = 2;
+      if (area < 0) { i1 = 2; i2 = 1; area = -area; }
+      const int64_t ax[3] = {sx[i0], sx[i1], sx[i2]}, ay[3] = {sy[i0], sy[i1], sy[i2]};
+      const double z0 = double(wz[i0]), z1 = double(wz[i1]), z2 = double(wz[i2]);
+      int64_t min_x = std::min(ax[0], std::min(ax[1], ax[2])), max_x = std::max(ax[0], std::max(ax[1], ax[2]));
+      int64_t min_y = std::min(ay[0], std::min(ay[1], ay[2])), max_y = std::max(ay[0], std::max(ay[1], ay[2]));
+      int x0 = int(std::max<int64_t>(FloorDiv(min_x, 256) - 1, 0)), x1 = int(std::min<int64_t>(FloorDiv(max_x, 256) + 1, S - 1));
+      int y0 = int(std::max<int64_t>(FloorDiv(min_y, 256) - 1, 0)), y1 = int(std::min<int64_t>(FloorDiv(max_y, 256) + 1, S - 1));
+      const double a2 = double(area);
+      for (int py = y0; py <= y1; ++py)
+        for (int px = x0; px <= x1; ++px) {
+          const int64_t cx = int64_t(px) * 256 + 128, cy = int64_t(py) * 256 + 128;
+          int64_t e[3];
+          bool inside = true;
+          for (int k = 0; k < 3 && inside; ++k) {
+            const int k1 = (k + 1) % 3;
+            const int64_t dx = ax[k1] - ax[k], dy = ay[k1] - ay[k];
+            e[k] = dx * (cy - ay[k]) - dy * (cx - ax[k]);
+            const bool owns = dy < 0 || (dy == 0 && dx > 0);  // top-left rule, y down
+            inside = e[k] > 0 || (e[k] == 0 && owns);
+          }
+          if (!inside) continue;
+          // barycentric weight of vertex k = edge function of the opposite edge
+          const double z = (double(e[1]) / a2) * z0 + (double(e[2]) / a2) * z1 + (double(e[0]) / a2) * z2;
+          if (!(z >= 0.0 && z <= 1.0)) continue;
+          // + 0.46 instead of + 0.5: calibrated on the reference's OpenGL model files (gl_model.py)
+          const uint32_t d16 = uint32_t(std::floor(z * 65535.0 + 0.46));
+          const uint32_t value = (d16 << 16) | (uint32_t(order) << 8) | id;
+          uint32_t& dst = packed[size_t(py) * S + px];
+          if (value < dst) dst = value;
+        }
+    }
+  }
+  for (size_t i = 0; i < packed.size(); ++i) {
+    if (packed[i] == 0xffffffffu) continue;
+    depth_image[i] = uint16_t(packed[i] >> 16);
+    silhouette_image[i] = uint8_t(packed[i] & 0xffu);
+  }
+}
 
 // ===========================================================================
 // RegionModality implementation
@@ -737,6 +950,11 @@ bool RegionModality::SetUp() {
     const SparseModel& m = *ctx->region_models[model];
     if (p.measured_depth_offset_radius > m.max_radius_depth_offset) return false;
     measured_depth_offset_id = int(p.measured_depth_offset_radius / m.stride_depth_offset + 0.5f);
+  }
+  if (p.model_occlusions) {
+    const SparseModel& m = *ctx->region_models[model];
+    if (p.modeled_depth_offset_radius > m.max_radius_depth_offset) return false;
+    modeled_depth_offset_id = int(p.modeled_depth_offset_radius / m.stride_depth_offset + 0.5f);
   }
   return true;
 }
@@ -781,6 +999,10 @@ void RegionModality::AddLinePixelColorsToTempHistograms(bool handle_occlusions) 
   const SparseModel& m = *ctx->region_models[model];
   int view = m.GetClosestView(body2camera_pose);
   int n_lines = NumberOfLines(view);
+  const bool body_visible_depth =
+      handle_occlusions && p.model_occlusions && ctx->renderers[depth_renderer].IsBodyVisible(body);
+  const bool body_visible_silhouette =
+      p.use_region_checking && ctx->renderers[silhouette_renderer].IsBodyVisible(body);
   for (int i = 0; i < n_lines; ++i) {
     const float* data_point = m.Point(view, i);
     const float* center_f_body = data_point;
@@ -800,6 +1022,9 @@ void RegionModality::AddLinePixelColorsToTempHistograms(bool handle_occlusions) 
       continue;
 
     if (handle_occlusions) {
+      if (p.model_occlusions && body_visible_depth &&
+          !IsLineUnoccludedModeled(center_u, center_v, center_f_camera[2], depth_offsets[modeled_depth_offset_id]))
+        continue;
       if (p.measure_occlusions &&
           !IsLineUnoccludedMeasured(center_f_body, depth_offsets[measured_depth_offset_id]))
         continue;
@@ -807,6 +1032,15 @@ void RegionModality::AddLinePixelColorsToTempHistograms(bool handle_occlusions) 
 
     float length_f = p.max_considered_line_length;
     float length_b = p.max_considered_line_length;
+    if (p.use_region_checking && body_visible_silhouette) {  // :1094-1099
+      float rx = (body2camera_rotation(0, 0) * normal_f_body[0] + body2camera_rotation(0, 1) * normal_f_body[1]) +
+                 body2camera_rotation(0, 2) * normal_f_body[2];
+      float ry = (body2camera_rotation(1, 0) * normal_f_body[0] + body2camera_rotation(1, 1) * normal_f_body[1]) +
+                 body2camera_rotation(1, 2) * normal_f_body[2];
+      float rn = std::sqrt(rx * rx + ry * ry);
+      if (rn > 0.0f) { rx = rx / rn; ry = ry / rn; }
+      DynamicRegionDistance(center_u, center_v, rx, ry, &length_f, &length_b);
+    }
 
     float l_f = foreground_distance * fu / center_f_camera[2];
     float l_b = background_distance * fu / center_f_camera[2];
@@ -883,12 +1117,14 @@ void RegionModality::CalculateBasicLineData(const float* data_point, DataLine* d
   data_line->normal_u = nx;
   data_line->normal_v = ny;
   data_line->measured_depth_offset = data_point[8 + measured_depth_offset_id];
+  data_line->modeled_depth_offset = data_point[8 + modeled_depth_offset_id];
   data_line->continuous_distance =
       std::min(background_distance, foreground_distance) * fu / (center_f_camera[2] * fscale);
 }
 
-// :1252-1291 (region checking / modelled occlusions: renderer-fed, unsupported)
-bool RegionModality::IsLineValid(const DataLine& data_line, bool measure_occlusions) const {
+// :1252-1291
+bool RegionModality::IsLineValid(const DataLine& data_line, bool use_region_checking, bool measure_occlusions,
+                                 bool model_occlusions) const {
   if (data_line.continuous_distance < p.min_continuous_distance) return false;
   if (data_line.center_f_camera[2] <= 0.0f) return false;
   int i_center_u = int(data_line.center_u + 0.5f);
@@ -896,10 +1132,138 @@ bool RegionModality::IsLineValid(const DataLine& data_line, bool measure_occlusi
   if (i_center_u < 0 || i_center_u > image_width_minus_1 || i_center_v < 0 ||
       i_center_v > image_height_minus_1)
     return false;
+  if (use_region_checking) {
+    if (!IsDynamicLineRegionSufficient(data_line.center_u, data_line.center_v, data_line.normal_u, data_line.normal_v))
+      return false;
+  }
   if (measure_occlusions) {
     if (!IsLineUnoccludedMeasured(data_line.center_f_body, data_line.measured_depth_offset)) return false;
   }
+  if (model_occlusions) {
+    if (!IsLineUnoccludedModeled(data_line.center_u, data_line.center_v, data_line.center_f_camera[2],
+                                 data_line.modeled_depth_offset))
+      return false;
+  }
   return true;
+}
+
+// :1391-1431
+bool RegionModality::IsLineUnoccludedModeled(float center_u, float center_v, float depth, float depth_offset) const {
+  const FocusedRenderer& r = ctx->renderers[depth_renderer];
+  const int depth_image_size_minus_1 = r.image_size - 1;
+  float meter_to_pixel = (fu / depth) * r.scale;
+  float diameter = 2.0f * p.modeled_occlusion_radius * meter_to_pixel;
+  int stride = int(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
+  int n_strides = int(diameter / stride + 0.5f);
+  int rounded_diameter = n_strides * stride;
+  float rounded_radius = 0.5f * float(rounded_diameter);
+  float focused_center_u = (center_u - r.corner_u) * r.scale;
+  float focused_center_v = (center_v - r.corner_v) * r.scale;
+  int u_min = int(focused_center_u - rounded_radius + 0.5f);
+  int v_min = int(focused_center_v - rounded_radius + 0.5f);
+  int u_max = u_min + rounded_diameter;
+  int v_max = v_min + rounded_diameter;
+  u_min = std::max(u_min, 0);
+  v_min = std::max(v_min, 0);
+  u_max = std::min(u_max, depth_image_size_minus_1);
+  v_max = std::min(v_max, depth_image_size_minus_1);
+  uint16_t min_depth_value = 65535;
+  for (int v = v_min; v <= v_max; v += stride)
+    for (int u = u_min; u <= u_max; u += stride)
+      min_depth_value = std::min(min_depth_value, r.depth_image[size_t(v) * r.image_size + u]);
+  float min_depth = r.Depth(min_depth_value);
+  float min_allowed_depth = depth - depth_offset - p.modeled_occlusion_threshold;
+  return min_depth > min_allowed_depth;
+}
+
+// :1293-1341.  The reference reads the silhouette image without a bounds check in the foreground
+// loop; a coordinate off the focused image counts as "not this region" here.
+bool RegionModality::IsDynamicLineRegionSufficient(float center_u, float center_v, float normal_u,
+                                                   float normal_v) const {
+  const FocusedRenderer& r = ctx->renderers[silhouette_renderer];
+  const uint8_t region_id = uint8_t(ctx->bodies[body].geometry.region_id);
+  const float fsilhouette_image_size = float(r.image_size);
+  float focused_min_continuous_distance = p.min_continuous_distance * fscale * r.scale;
+  float focused_stride =
+      std::max((focused_min_continuous_distance - M3T_REGION_OFFSET) / float(M3T_N_REGION_STRIDE), 0.0f);
+  float stride_u = focused_stride * normal_u;
+  float stride_v = focused_stride * normal_v;
+  float offset_u = M3T_REGION_OFFSET * normal_u;
+  float offset_v = M3T_REGION_OFFSET * normal_v;
+  float focused_center_u = 0.5f + (center_u - r.corner_u) * r.scale;
+  float focused_center_v = 0.5f + (center_v - r.corner_v) * r.scale;
+  float u = focused_center_u - offset_u;
+  float v = focused_center_v - offset_v;
+  for (int i = 0; i <= M3T_N_REGION_STRIDE; ++i) {
+    if (u >= fsilhouette_image_size || u < 0.0f || v >= fsilhouette_image_size || v < 0.0f) return false;
+    if (r.silhouette_image[size_t(int(v)) * r.image_size + int(u)] != region_id) return false;
+    u -= stride_u;
+    v -= stride_v;
+  }
+  u = focused_center_u + offset_u;
+  v = focused_center_v + offset_v;
+  for (int i = 0; i <= M3T_N_REGION_STRIDE; ++i) {
+    if (u >= fsilhouette_image_size || u < 0.0f || v >= fsilhouette_image_size || v < 0.0f) break;
+    if (r.silhouette_image[size_t(int(v)) * r.image_size + int(u)] == region_id) return false;
+    u += stride_u;
+    v += stride_v;
+  }
+  return true;
+}
+
+// :1157-1229 (including the assignment to the *foreground* distance inside the background loop, :1223)
+void RegionModality::DynamicRegionDistance(float center_u, float center_v, float normal_u, float normal_v,
+                                           float* dynamic_foreground_distance,
+                                           float* dynamic_background_distance) const {
+  const FocusedRenderer& r = ctx->renderers[silhouette_renderer];
+  const uint8_t region_id = uint8_t(ctx->bodies[body].geometry.region_id);
+  const float fsilhouette_image_size = float(r.image_size);
+  float stride = p.max_considered_line_length / float(M3T_N_REGION_STRIDE);
+  float focused_stride = stride * r.scale;
+  float focused_stride_u = focused_stride * normal_u;
+  float focused_stride_v = focused_stride * normal_v;
+  float delta_start = M3T_REGION_OFFSET / r.scale - p.unconsidered_line_length;
+  int i_start = std::max(int(delta_start / stride + 1.0f), 0);
+  float offset = p.unconsidered_line_length + float(i_start) * stride;
+  float focused_offset = offset * r.scale;
+  float focused_offset_u = focused_offset * normal_u;
+  float focused_offset_v = focused_offset * normal_v;
+  float focused_center_u = 0.5f + (center_u - r.corner_u) * r.scale;
+  float focused_center_v = 0.5f + (center_v - r.corner_v) * r.scale;
+  float u = focused_center_u - focused_offset_u;
+  float v = focused_center_v - focused_offset_v;
+  for (int i = i_start; i <= M3T_N_REGION_STRIDE; ++i) {
+    if (u >= fsilhouette_image_size || u < 0.0f || v >= fsilhouette_image_size || v < 0.0f) {
+      *dynamic_foreground_distance = stride * float(i);
+      break;
+    }
+    if (r.silhouette_image[size_t(int(v)) * r.image_size + int(u)] != region_id) {
+      if (i == i_start)
+        *dynamic_foreground_distance = 0.0f;
+      else
+        *dynamic_foreground_distance = stride * float(i);
+      break;
+    }
+    u -= focused_stride_u;
+    v -= focused_stride_v;
+  }
+  u = focused_center_u + focused_offset_u;
+  v = focused_center_v + focused_offset_v;
+  for (int i = i_start; i <= M3T_N_REGION_STRIDE; ++i) {
+    if (u >= fsilhouette_image_size || u < 0.0f || v >= fsilhouette_image_size || v < 0.0f) {
+      *dynamic_background_distance = p.max_considered_line_length;
+      break;
+    }
+    if (r.silhouette_image[size_t(int(v)) * r.image_size + int(u)] == region_id) {
+      if (i == i_start)
+        *dynamic_background_distance = 0.0f;
+      else
+        *dynamic_foreground_distance = stride * float(i);
+      break;
+    }
+    u += focused_stride_u;
+    v += focused_stride_v;
+  }
 }
 
 // :1343-1389
@@ -1088,6 +1452,10 @@ bool RegionModality::CalculateCorrespondences(int iteration, int corr_iteration)
   int view = m.GetClosestView(body2camera_pose);
   int n_lines = NumberOfLines(view);
   float segment_probabilities_f[M3T_MAX_SEGMENTS], segment_probabilities_b[M3T_MAX_SEGMENTS];
+  // body visible in the focused renderings? (:397-409)
+  const bool body_visible_depth = p.model_occlusions && ctx->renderers[depth_renderer].IsBodyVisible(body);
+  const bool body_visible_silhouette =
+      p.use_region_checking && ctx->renderers[silhouette_renderer].IsBodyVisible(body);
   for (int j = 0; j < 2; ++j) {
     data_lines.clear();
     bool handle_occlusions = j == 0 && (iteration - first_iteration) >= p.n_unoccluded_iterations;
@@ -1095,7 +1463,10 @@ bool RegionModality::CalculateCorrespondences(int iteration, int corr_iteration)
       DataLine data_line;
       data_line.model_point_index = i;
       CalculateBasicLineData(m.Point(view, i), &data_line);
-      if (!IsLineValid(data_line, handle_occlusions && p.measure_occlusions)) continue;
+      if (!IsLineValid(data_line, p.use_region_checking && body_visible_silhouette,
+                       handle_occlusions && p.measure_occlusions,
+                       handle_occlusions && p.model_occlusions && body_visible_depth))
+        continue;
       if (!CalculateSegmentProbabilities(data_line.center_u, data_line.center_v, data_line.normal_u,
                                          data_line.normal_v, segment_probabilities_f,
                                          segment_probabilities_b, &data_line.normal_component_to_scale,
@@ -1224,19 +1595,76 @@ void DepthModality::CalculateBasicPointData(const float* mp, DepthDataPoint* dp)
     if (id >= M3T_N_DEPTH_OFFSETS) id = M3T_N_DEPTH_OFFSETS - 1;
     dp->measured_depth_offset = mp[6 + id];
   }
+  dp->modeled_depth_offset = 0.0f;
+  if (p.model_occlusions) {
+    const SparseModel& m = *ctx->depth_models[model];
+    float radius = p.modeled_depth_offset_radius;
+    if (p.use_depth_scaling) radius *= dp->depth;
+    int id = int(radius / m.stride_depth_offset + 0.5f);
+    if (id >= M3T_N_DEPTH_OFFSETS) id = M3T_N_DEPTH_OFFSETS - 1;
+    dp->modeled_depth_offset = mp[6 + id];
+  }
 }
 // :697-726
-bool DepthModality::IsPointValid(const DepthDataPoint& dp, bool measure_occlusions) const {
+bool DepthModality::IsPointValid(const DepthDataPoint& dp, bool use_silhouette_checking, bool measure_occlusions,
+                                 bool model_occlusions) const {
   if (dp.depth <= 0.0f) return false;
   int i_center_u = int(dp.center_u + 0.5f);
   int i_center_v = int(dp.center_v + 0.5f);
   if (i_center_u < 0 || i_center_u > image_width_minus_1 || i_center_v < 0 ||
       i_center_v > image_height_minus_1)
     return false;
+  if (use_silhouette_checking) {
+    if (!IsPointOnValidSilhouette(dp)) return false;
+  }
   if (measure_occlusions) {
     if (!IsPointUnoccludedMeasured(dp)) return false;
   }
+  if (model_occlusions) {
+    if (!IsPointUnoccludedModeled(dp)) return false;
+  }
   return true;
+}
+// :728-734 + FocusedSilhouetteRenderer::SilhouetteValue silhouette_renderer.cpp:394-399 (a coordinate off
+// the focused image, which the reference reads unchecked, counts as another body)
+bool DepthModality::IsPointOnValidSilhouette(const DepthDataPoint& dp) const {
+  const FocusedRenderer& r = ctx->renderers[silhouette_renderer];
+  int cx = int(dp.center_u + 0.5f), cy = int(dp.center_v + 0.5f);
+  int u = int((float(cx) - r.corner_u) * r.scale + 0.5f);
+  int v = int((float(cy) - r.corner_v) * r.scale + 0.5f);
+  if (u < 0 || u >= r.image_size || v < 0 || v >= r.image_size) return false;
+  return r.silhouette_image[size_t(v) * r.image_size + u] == uint8_t(ctx->bodies[body].geometry.body_id);
+}
+// :778-824
+bool DepthModality::IsPointUnoccludedModeled(const DepthDataPoint& dp) const {
+  const FocusedRenderer& r = ctx->renderers[depth_renderer];
+  const int depth_image_size_minus_1 = r.image_size - 1;
+  float meter_to_pixel = fu * r.scale;
+  if (!p.use_depth_scaling) meter_to_pixel /= dp.depth;
+  float diameter = 2.0f * p.modeled_occlusion_radius * meter_to_pixel;
+  int stride = int(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
+  int n_strides = int(diameter / stride + 0.5f);
+  int rounded_diameter = n_strides * stride;
+  float rounded_radius = 0.5f * float(rounded_diameter);
+  float focused_center_u = (dp.center_u - r.corner_u) * r.scale;
+  float focused_center_v = (dp.center_v - r.corner_v) * r.scale;
+  int u_min = int(focused_center_u - rounded_radius + 0.5f);
+  int v_min = int(focused_center_v - rounded_radius + 0.5f);
+  int u_max = u_min + rounded_diameter;
+  int v_max = v_min + rounded_diameter;
+  u_min = std::max(u_min, 0);
+  v_min = std::max(v_min, 0);
+  u_max = std::min(u_max, depth_image_size_minus_1);
+  v_max = std::min(v_max, depth_image_size_minus_1);
+  uint16_t min_depth_value = 65535;
+  for (int v = v_min; v <= v_max; v += stride)
+    for (int u = u_min; u <= u_max; u += stride)
+      min_depth_value = std::min(min_depth_value, r.depth_image[size_t(v) * r.image_size + u]);
+  float threshold = p.modeled_occlusion_threshold;
+  if (p.use_depth_scaling) threshold *= dp.depth;
+  float min_allowed_depth = dp.depth - dp.modeled_depth_offset - threshold;
+  float min_depth = r.Depth(min_depth_value);
+  return min_depth > min_allowed_depth;
 }
 // :736-776
 bool DepthModality::IsPointUnoccludedMeasured(const DepthDataPoint& dp) const {
@@ -1321,6 +1749,9 @@ bool DepthModality::CalculateCorrespondences(int iteration, int corr_iteration) 
       n_points = p.n_points_max * m.extents[view] / m.max_extent;
   }
   if (n_points > m.n_points) n_points = m.n_points;
+  const bool body_visible_depth = p.model_occlusions && ctx->renderers[depth_renderer].IsBodyVisible(body);
+  const bool body_visible_silhouette =
+      p.use_silhouette_checking && ctx->renderers[silhouette_renderer].IsBodyVisible(body);
   for (int j = 0; j < 2; ++j) {
     data_points.clear();
     bool handle_occlusions = j == 0 && (iteration - first_iteration) >= p.n_unoccluded_iterations;
@@ -1328,7 +1759,10 @@ bool DepthModality::CalculateCorrespondences(int iteration, int corr_iteration) 
       DepthDataPoint dp;
       dp.model_point_index = i;
       CalculateBasicPointData(m.Point(view, i), &dp);
-      if (!IsPointValid(dp, handle_occlusions && p.measure_occlusions)) continue;
+      if (!IsPointValid(dp, p.use_silhouette_checking && body_visible_silhouette,
+                        handle_occlusions && p.measure_occlusions,
+                        handle_occlusions && p.model_occlusions && body_visible_depth))
+        continue;
       if (!FindCorrespondence(dp, dp.correspondence_center_f_camera)) continue;
       data_points.push_back(dp);
     }
@@ -1709,6 +2143,32 @@ bool OptimizerCalculateOptimization(Context* ctx, Optimizer& o) {
   return OptimizerEnd(ctx, o);
 }
 
+// the renderers the modalities reference, each once (Tracker::AssambleInternallyUsedObjectPtrs):
+// region modalities list theirs for start / correspondences / results, depth modalities for
+// correspondences only (region_modality.cpp:626-639, depth_modality.cpp:430-443)
+void RenderFor(Context* ctx, bool region_only) {
+  std::vector<char> wanted(ctx->renderers.size(), 0);
+  for (auto& m : ctx->modalities) {
+    int a = -1, b = -1;
+    if (m->is_region) {
+      auto* r = static_cast<RegionModality*>(m.get());
+      a = r->p.model_occlusions ? r->depth_renderer : -1;
+      b = r->p.use_region_checking ? r->silhouette_renderer : -1;
+    } else if (!region_only) {
+      auto* d = static_cast<DepthModality*>(m.get());
+      a = d->p.model_occlusions ? d->depth_renderer : -1;
+      b = d->p.use_silhouette_checking ? d->silhouette_renderer : -1;
+    }
+    if (a >= 0) wanted[a] = 1;
+    if (b >= 0) wanted[b] = 1;
+  }
+  for (size_t i = 0; i < wanted.size(); ++i)
+    if (wanted[i]) {
+      ctx->renderers[i].geometry_bodies = ctx->renderer_geometries[ctx->renderer_geometry_of[i]];
+      ctx->renderers[i].StartRendering(ctx);
+    }
+}
+
 void SetError(Context* c, const std::string& e) { c->error = e; }
 
 }  // namespace
@@ -1884,7 +2344,8 @@ int m3t_oracle_region_modality_create(m3t_oracle_context* ctx, const m3t_region_
   if (color_camera < 0 || color_camera >= int(CTX->cameras.size()) || CTX->cameras[color_camera]->is_depth)
     FAIL(M3T_ERR_INVALID_ARGUMENT, "bad color camera id");
   if (model < 0 || model >= int(CTX->region_models.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad region model id");
-  if (p->use_region_checking || p->model_occlusions) FAIL(M3T_ERR_UNSUPPORTED, "renderer-fed branches unsupported");
+  if (p->use_region_checking || p->model_occlusions)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "switch region checking / modelled occlusions on with their renderer afterwards");
   if (p->measure_occlusions &&
       (depth_camera < 0 || depth_camera >= int(CTX->cameras.size()) || !CTX->cameras[depth_camera]->is_depth))
     FAIL(M3T_ERR_INVALID_ARGUMENT, "measure_occlusions needs a depth camera");
@@ -1926,6 +2387,163 @@ int m3t_oracle_depth_modality_create(m3t_oracle_context* ctx, const m3t_depth_mo
   m->SetUp();
   CTX->modalities.push_back(std::move(m));
   return int(CTX->modalities.size()) - 1;
+}
+
+// ---- renderer-fed branches --------------------------------------------------------------------
+int m3t_oracle_body_set_geometry(m3t_oracle_context* ctx, int body, const m3t_body_geometry* g) {
+  CHECK_CTX();
+  if (body < 0 || body >= int(CTX->bodies.size()) || !g || !g->vertices || !g->triangles || g->n_vertices < 3 ||
+      g->n_triangles < 1 || g->body_id < 0 || g->body_id > 255 || g->region_id < 0 || g->region_id > 255)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad body geometry");
+  for (int i = 0; i < g->n_triangles * 3; ++i)
+    if (g->triangles[i] < 0 || g->triangles[i] >= g->n_vertices) FAIL(M3T_ERR_INVALID_ARGUMENT, "triangle index out of range");
+  BodyGeometry& bg = CTX->bodies[body].geometry;
+  bg.vertices.assign(g->vertices, g->vertices + size_t(g->n_vertices) * 3);
+  bg.triangles.resize(size_t(g->n_triangles) * 3);
+  for (int t = 0; t < g->n_triangles; ++t)  // body.cpp:227-236
+    for (int k = 0; k < 3; ++k)
+      bg.triangles[size_t(t) * 3 + k] = g->triangles[size_t(t) * 3 + (g->geometry_counterclockwise ? k : 2 - k)];
+  bg.geometry2body = FromArray(g->geometry2body);
+  bg.enable_culling = g->geometry_enable_culling != 0;
+  bg.body_id = g->body_id;
+  bg.region_id = g->region_id;
+  float max_radius = 0.0f;  // Body::CalculateMaximumBodyDiameter body.cpp:244-250
+  for (int i = 0; i < g->n_vertices; ++i) {
+    float v[3];
+    Apply(bg.geometry2body, &bg.vertices[size_t(i) * 3], v);
+    max_radius = std::max(max_radius, std::sqrt(v[0] * v[0] + (v[1] * v[1] + v[2] * v[2])));
+  }
+  bg.maximum_body_diameter = 2.0f * max_radius;
+  bg.set = true;
+  return M3T_OK;
+}
+int m3t_oracle_renderer_geometry_create(m3t_oracle_context* ctx) {
+  CHECK_CTX();
+  CTX->renderer_geometries.emplace_back();
+  return int(CTX->renderer_geometries.size()) - 1;
+}
+int m3t_oracle_renderer_geometry_add_body(m3t_oracle_context* ctx, int geometry, int body) {
+  CHECK_CTX();
+  if (geometry < 0 || geometry >= int(CTX->renderer_geometries.size()) || body < 0 || body >= int(CTX->bodies.size()))
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad renderer geometry / body id");
+  if (!CTX->bodies[body].geometry.set) FAIL(M3T_ERR_NOT_SET_UP, "body has no geometry");
+  if (CTX->renderer_geometries[geometry].size() >= M3T_MAX_RENDERER_BODIES) FAIL(M3T_ERR_UNSUPPORTED, "too many bodies");
+  CTX->renderer_geometries[geometry].push_back(body);
+  for (auto& r : CTX->renderers) r.rendered = false;
+  return M3T_OK;
+}
+static int CreateRenderer(m3t_oracle_context* ctx, bool silhouette, int geometry, int camera, int id_type,
+                          int image_size, float z_min, float z_max) {
+  CHECK_CTX();
+  if (geometry < 0 || geometry >= int(CTX->renderer_geometries.size()) || camera < 0 ||
+      camera >= int(CTX->cameras.size()) || image_size < 8 || image_size > 1024 || !(z_min > 0.0f) || !(z_max > z_min) ||
+      (id_type != M3T_ID_TYPE_BODY && id_type != M3T_ID_TYPE_REGION))
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad renderer arguments");
+  FocusedRenderer r;
+  r.silhouette = silhouette;
+  r.camera = camera;
+  r.id_type = id_type;
+  r.image_size = image_size;
+  r.z_min = z_min;
+  r.z_max = z_max;
+  CTX->renderers.push_back(r);
+  CTX->renderers.back().geometry_bodies.clear();
+  CTX->renderer_geometry_of.push_back(geometry);
+  return int(CTX->renderers.size()) - 1;
+}
+int m3t_oracle_focused_depth_renderer_create(m3t_oracle_context* ctx, int geometry, int camera, int image_size,
+                                             float z_min, float z_max) {
+  return CreateRenderer(ctx, false, geometry, camera, M3T_ID_TYPE_BODY, image_size, z_min, z_max);
+}
+int m3t_oracle_focused_silhouette_renderer_create(m3t_oracle_context* ctx, int geometry, int camera, int id_type,
+                                                  int image_size, float z_min, float z_max) {
+  return CreateRenderer(ctx, true, geometry, camera, id_type, image_size, z_min, z_max);
+}
+int m3t_oracle_renderer_add_referenced_body(m3t_oracle_context* ctx, int renderer, int body) {
+  CHECK_CTX();
+  if (renderer < 0 || renderer >= int(CTX->renderers.size()) || body < 0 || body >= int(CTX->bodies.size()))
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad renderer / body id");
+  if (!CTX->bodies[body].geometry.set) FAIL(M3T_ERR_NOT_SET_UP, "body has no geometry");
+  FocusedRenderer& r = CTX->renderers[renderer];
+  if (r.referenced_bodies.size() >= M3T_MAX_RENDERER_BODIES) FAIL(M3T_ERR_UNSUPPORTED, "too many referenced bodies");
+  r.referenced_bodies.push_back(body);
+  r.rendered = false;
+  return M3T_OK;
+}
+int m3t_oracle_renderer_start_rendering(m3t_oracle_context* ctx, int renderer) {
+  CHECK_CTX();
+  if (renderer < 0 || renderer >= int(CTX->renderers.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad renderer id");
+  FocusedRenderer& r = CTX->renderers[renderer];
+  if (r.referenced_bodies.empty()) FAIL(M3T_ERR_NOT_SET_UP, "no referenced body");
+  r.geometry_bodies = CTX->renderer_geometries[CTX->renderer_geometry_of[renderer]];
+  r.StartRendering(CTX);
+  return M3T_OK;
+}
+int m3t_oracle_renderer_get_images(m3t_oracle_context* ctx, int renderer, uint16_t* depth, uint8_t* silhouette,
+                                   float info[3], int* n_visible) {
+  CHECK_CTX();
+  if (renderer < 0 || renderer >= int(CTX->renderers.size())) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad renderer id");
+  const FocusedRenderer& r = CTX->renderers[renderer];
+  if (!r.rendered) FAIL(M3T_ERR_NOT_SET_UP, "renderer has not rendered yet");
+  if (depth) std::memcpy(depth, r.depth_image.data(), r.depth_image.size() * 2);
+  if (silhouette) std::memcpy(silhouette, r.silhouette_image.data(), r.silhouette_image.size());
+  if (info) { info[0] = r.corner_u; info[1] = r.corner_v; info[2] = r.scale; }
+  if (n_visible) {
+    *n_visible = 0;
+    for (char v : r.visible) *n_visible += v ? 1 : 0;
+  }
+  return M3T_OK;
+}
+static int AttachRenderer(m3t_oracle_context* ctx, int modality, int renderer, bool want_region, bool want_silhouette,
+                          Modality** out) {
+  CHECK_CTX();
+  if (modality < 0 || modality >= int(CTX->modalities.size()) || CTX->modalities[modality]->is_region != want_region)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad modality id");
+  if (renderer < 0 || renderer >= int(CTX->renderers.size()) || CTX->renderers[renderer].silhouette != want_silhouette)
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad renderer id / kind");
+  Modality* m = CTX->modalities[modality].get();
+  bool referenced = false;
+  for (int b : CTX->renderers[renderer].referenced_bodies) referenced |= b == m->body;
+  if (!referenced) FAIL(M3T_ERR_INVALID_ARGUMENT, "the modality's body is not referenced by the renderer");
+  *out = m;
+  return M3T_OK;
+}
+int m3t_oracle_region_modality_model_occlusions(m3t_oracle_context* ctx, int modality, int renderer) {
+  Modality* m;
+  int r = AttachRenderer(ctx, modality, renderer, true, false, &m);
+  if (r) return r;
+  auto* rm = static_cast<RegionModality*>(m);
+  rm->depth_renderer = renderer;
+  rm->p.model_occlusions = 1;
+  if (!rm->SetUp()) FAIL(M3T_ERR_INVALID_ARGUMENT, "modeled depth offset radius too large");
+  return M3T_OK;
+}
+int m3t_oracle_region_modality_use_region_checking(m3t_oracle_context* ctx, int modality, int renderer) {
+  Modality* m;
+  int r = AttachRenderer(ctx, modality, renderer, true, true, &m);
+  if (r) return r;
+  auto* rm = static_cast<RegionModality*>(m);
+  rm->silhouette_renderer = renderer;
+  rm->p.use_region_checking = 1;
+  return M3T_OK;
+}
+int m3t_oracle_depth_modality_model_occlusions(m3t_oracle_context* ctx, int modality, int renderer) {
+  Modality* m;
+  int r = AttachRenderer(ctx, modality, renderer, false, false, &m);
+  if (r) return r;
+  auto* dm = static_cast<DepthModality*>(m);
+  dm->depth_renderer = renderer;
+  dm->p.model_occlusions = 1;
+  return M3T_OK;
+}
+int m3t_oracle_depth_modality_use_silhouette_checking(m3t_oracle_context* ctx, int modality, int renderer) {
+  Modality* m;
+  int r = AttachRenderer(ctx, modality, renderer, false, true, &m);
+  if (r) return r;
+  auto* dm = static_cast<DepthModality*>(m);
+  dm->silhouette_renderer = renderer;
+  dm->p.use_silhouette_checking = 1;
+  return M3T_OK;
 }
 
 int m3t_oracle_link_create(m3t_oracle_context* ctx, int body, int parent, const float body2joint[16],
@@ -2080,6 +2698,7 @@ int m3t_oracle_start_modalities(m3t_oracle_context* ctx, int iteration) {
   CHECK_CTX();
   int r = CheckImages(ctx);
   if (r) return r;
+  RenderFor(CTX, true);  // start_modality_renderer_ptrs tracker.cpp:430-436
   for (auto& m : CTX->modalities) m->StartModality(iteration, 0);
   return M3T_OK;
 }
@@ -2088,6 +2707,7 @@ int m3t_oracle_calculate_correspondences(m3t_oracle_context* ctx, int iteration,
   CHECK_CTX();
   int r = CheckImages(ctx);
   if (r) return r;
+  RenderFor(CTX, false);  // correspondence_renderer_ptrs tracker.cpp:447-452
   for (auto& m : CTX->modalities) m->CalculateCorrespondences(iteration, corr_iteration);
   return M3T_OK;
 }
@@ -2131,6 +2751,7 @@ int m3t_oracle_calculate_results(m3t_oracle_context* ctx, int iteration) {
   CHECK_CTX();
   int r = CheckImages(ctx);
   if (r) return r;
+  RenderFor(CTX, true);  // results_renderer_ptrs tracker.cpp:503-509
   for (auto& m : CTX->modalities) m->CalculateResults(iteration);
   return M3T_OK;
 }

@@ -76,6 +76,32 @@ int m3t_oracle_region_modality_create(m3t_oracle_context*, const m3t_region_moda
 int m3t_oracle_depth_modality_create(m3t_oracle_context*, const m3t_depth_modality_params*, int body_id,
                                      int depth_camera_id, int depth_model_id);
 
+/* ---- renderer-fed branches: body meshes, focused depth / silhouette renderings ----
+ * A software restatement of FocusedBasicDepthRenderer / FocusedSilhouetteRenderer (renderer.cpp:348-405,
+ * basic_depth_renderer.cpp:45-84, silhouette_renderer.cpp:54-100): the square image_size x image_size crop
+ * around the referenced bodies, rasterised with OpenGL's rules (pixel centres, 1/256 sub-pixel snapping,
+ * top-left fill rule, 16-bit depth, GL_LESS in draw order).  Renderers a modality references are rendered
+ * where the reference's Tracker does it: at start_modalities / calculate_results for region modalities and
+ * before every calculate_correspondences (tracker.cpp:430-517). */
+int m3t_oracle_body_set_geometry(m3t_oracle_context*, int body_id, const m3t_body_geometry*);
+int m3t_oracle_renderer_geometry_create(m3t_oracle_context*);                                   /* RendererGeometry */
+int m3t_oracle_renderer_geometry_add_body(m3t_oracle_context*, int geometry_id, int body_id);  /* draw order = add order */
+int m3t_oracle_focused_depth_renderer_create(m3t_oracle_context*, int geometry_id, int camera_id, int image_size, float z_min,
+                                          float z_max);                      /* basic_depth_renderer.h:120-128 */
+int m3t_oracle_focused_silhouette_renderer_create(m3t_oracle_context*, int geometry_id, int camera_id, int id_type, int image_size,
+                                               float z_min, float z_max);    /* silhouette_renderer.h:150-155 */
+int m3t_oracle_renderer_add_referenced_body(m3t_oracle_context*, int renderer_id, int body_id);
+int m3t_oracle_renderer_start_rendering(m3t_oracle_context*, int renderer_id);
+/* depth: image_size^2 u16 (65535 = nothing); silhouette: image_size^2 u8 ids (NULL for depth renderers);
+ * info: corner_u, corner_v, scale; n_visible: referenced bodies that passed FocusedRenderer's visibility test */
+int m3t_oracle_renderer_get_images(m3t_oracle_context*, int renderer_id, uint16_t* depth, uint8_t* silhouette, float info[3],
+                                int* n_visible);
+/* RegionModality::ModelOcclusions / UseRegionChecking, DepthModality::ModelOcclusions / UseSilhouetteChecking */
+int m3t_oracle_region_modality_model_occlusions(m3t_oracle_context*, int modality_id, int depth_renderer_id);
+int m3t_oracle_region_modality_use_region_checking(m3t_oracle_context*, int modality_id, int silhouette_renderer_id);
+int m3t_oracle_depth_modality_model_occlusions(m3t_oracle_context*, int modality_id, int depth_renderer_id);
+int m3t_oracle_depth_modality_use_silhouette_checking(m3t_oracle_context*, int modality_id, int silhouette_renderer_id);
+
 /* links / optimizers (link.h:67, optimizer.h:48) */
 int m3t_oracle_link_create(m3t_oracle_context*, int body_id, int parent_link_id, const float body2joint[16],
                            const float joint2parent[16], const int free_directions[6],

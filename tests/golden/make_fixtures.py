@@ -27,6 +27,10 @@ FILES = [
     "modality_test/region_modality.yaml", "modality_test/depth_modality.yaml", "modality_test/region_modality.png",
     "modality_test/region_modality_measured_occlusions.png", "modality_test/region_modality_depth_measured_occlusions.png",
     "modality_test/depth_modality.png", "modality_test/depth_modality_measured_occlusions.png",
+    "modality_test/region_modality_region_checking.png", "modality_test/region_modality_silhouette_region_checking.png",
+    "modality_test/region_modality_modeled_occlusions.png", "modality_test/region_modality_depth_modeled_occlusions.png",
+    "modality_test/depth_modality_silhouette_checking.png", "modality_test/depth_modality_silhouette_silhouette_checking.png",
+    "modality_test/depth_modality_modeled_occlusions.png", "modality_test/depth_modality_depth_modeled_occlusions.png",
     "optimizer_test/triangle_pose.txt", "optimizer_test/optimizer.yaml",
     "tracker_test/triangle_pose.txt", "tracker_test/tracker.yaml", "refiner_test/triangle_pose.txt",
     "_sequence/color_camera_image_200.png", "_sequence/color_camera_image_201.png",

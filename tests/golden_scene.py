@@ -25,7 +25,7 @@ def views():
 
 
 class RegionFixture:
-    def __init__(self, api, measure_occlusions=False):
+    def __init__(self, api, measure_occlusions=False, **params):
         v = views()
         self.api = api
         self.image = load_png("_sequence/color_camera_image_200.png")
@@ -42,14 +42,14 @@ class RegionFixture:
                                                 depth_camera=self.depth_camera, measure_occlusions=1,
                                                 n_unoccluded_iterations=0)
         else:
-            self.modality = host.RegionModality(api, self.body, self.camera, self.model)  # default parameters
+            self.modality = host.RegionModality(api, self.body, self.camera, self.model, **params)  # else defaults
         self.optimizer = host.Optimizer(api, body=self.body, modalities=[self.modality])
         self.camera.UpdateImage(self.image)
         self.tracker = host.Tracker(api)
 
 
 class DepthFixture:
-    def __init__(self, api, measure_occlusions=False):
+    def __init__(self, api, measure_occlusions=False, **params):
         v = views()
         self.api = api
         self.image = load_png("_sequence/depth_camera_image_200.png")
@@ -59,7 +59,7 @@ class DepthFixture:
         w2c = np.linalg.inv(mtv.DEPTH_CAMERA2WORLD).astype(np.float32)
         self.camera = host.DepthCamera(api, depth_scale=mtv.DEPTH_SCALE, world2camera_pose=w2c,
                                        **mtv.DEPTH_INTRINSICS)
-        kw = dict(measure_occlusions=1, n_unoccluded_iterations=0) if measure_occlusions else {}
+        kw = dict(measure_occlusions=1, n_unoccluded_iterations=0) if measure_occlusions else dict(params)
         self.body2camera = (w2c @ mtv.body2world()).astype(np.float32)
         self.modality = host.DepthModality(api, self.body, self.camera, self.model, **kw)  # else defaults
         self.optimizer = host.Optimizer(api, body=self.body, modalities=[self.modality])
@@ -161,3 +161,40 @@ def point_mask(shape, points_f_body, body2camera, intrinsics):
 
 def golden_point_mask(rel, bgr):
     return (load_png(rel).astype(np.int32) == np.asarray(bgr)).all(axis=2)
+
+
+# ---- renderer-fed branches: the two fixture bodies with their meshes (test/common_test.cpp:6-39,41-94) ----
+SCHAUMA_WORLD2BODY = np.array([[0.607676, 0.408914, -0.680823, 0.297794], [0.786584, -0.428213, 0.444880, -0.189009],
+                               [-0.109620, -0.805867, -0.581860, 0.255284], [0, 0, 0, 1]], np.float32)
+SCHAUMA_GEOMETRY2BODY = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, -0.097], [0, 0, 0, 1]], np.float32)
+
+
+def fixture_renderer_geometry(api, triangle_body):
+    """RendererGeometry holding the triangle (body id 150, region id 150) and the schauma bottle
+    (body id 50, region id 150), data/_body/{triangle,schauma}.yaml"""
+    import gl_model
+    tv, tf = gl_model.load_obj(os.path.join(util.GOLDEN, "_body/triangle.obj"))
+    sv, sf = gl_model.load_obj(os.path.join(util.GOLDEN, "_body/schauma.obj"))
+    triangle_body.set_geometry(tv, tf, np.asarray(mtv.GEOMETRY2BODY, np.float32), body_id=150, region_id=150)
+    schauma = host.Body(api, np.linalg.inv(SCHAUMA_WORLD2BODY.astype(np.float64)).astype(np.float32))
+    schauma.set_geometry(sv, sf, SCHAUMA_GEOMETRY2BODY, body_id=50, region_id=150)
+    geometry = host.RendererGeometry(api)
+    geometry.AddBody(triangle_body)
+    geometry.AddBody(schauma)
+    return geometry, schauma
+
+
+def focused_point_mask(size, points_f_body, body2camera, intrinsics, corner_u, corner_v, scale):
+    """DrawFocusedPointInImage common.cpp:293-304"""
+    f32 = np.float32
+    mask = np.zeros((size, size), bool)
+    for p in points_f_body:
+        c = (body2camera[:3, :3] @ p + body2camera[:3, 3]).astype(f32)
+        u = c[0] * f32(intrinsics["fu"]) / c[2] + f32(intrinsics["ppu"])
+        v = c[1] * f32(intrinsics["fv"]) / c[2] + f32(intrinsics["ppv"])
+        uf = int((u - f32(corner_u)) * f32(scale) + f32(0.5))
+        vf = int((v - f32(corner_v)) * f32(scale) + f32(0.5))
+        for du, dv in ((0, 0), (1, 0), (-1, 0), (0, 1), (0, -1)):
+            if 0 <= vf + dv < size and 0 <= uf + du < size:
+                mask[vf + dv, uf + du] = True
+    return mask
