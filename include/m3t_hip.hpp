@@ -65,6 +65,24 @@ class Body {
     c_->Check(m3t_hip_body_get_body2world_pose(c_->get(), id_, p.data()), "Body");
     return p;
   }
+  // the triangle mesh of body.h (vertices in metres), needed only for the renderer-fed branches
+  void set_geometry(const m3t_body_geometry& geometry) {
+    c_->Check(m3t_hip_body_set_geometry(c_->get(), id_, &geometry), "Body");
+  }
+  int id() const { return id_; }
+
+ private:
+  ContextPtr c_;
+  int id_;
+};
+
+// Body mesh + renderers for the renderer-fed branches (m3t_hip.h "renderer-fed branches")
+class RendererGeometry {
+ public:
+  explicit RendererGeometry(ContextPtr c) : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_renderer_geometry_create(c_->get()), "RendererGeometry");
+  }
+  bool AddBody(const Body& body) { return c_->Step(m3t_hip_renderer_geometry_add_body(c_->get(), id_, body.id())); }
   int id() const { return id_; }
 
  private:
@@ -108,6 +126,40 @@ class DepthCamera : public Camera {
     c_ = std::move(c);
     id_ = c_->Check(m3t_hip_depth_camera_create(c_->get(), &intrinsics, world2camera_pose.data(), depth_scale),
                     "DepthCamera");
+  }
+};
+
+// m3t::FocusedBasicDepthRenderer / m3t::FocusedSilhouetteRenderer (software, no OpenGL context)
+class FocusedRenderer {
+ public:
+  bool AddReferencedBody(const Body& body) {
+    return c_->Step(m3t_hip_renderer_add_referenced_body(c_->get(), id_, body.id()));
+  }
+  bool StartRendering() { return c_->Step(m3t_hip_renderer_start_rendering(c_->get(), id_)); }
+  int id() const { return id_; }
+
+ protected:
+  ContextPtr c_;
+  int id_ = -1;
+};
+class FocusedBasicDepthRenderer : public FocusedRenderer {
+ public:
+  FocusedBasicDepthRenderer(ContextPtr c, const RendererGeometry& geometry, const Camera& camera, int image_size = 200,
+                            float z_min = 0.02f, float z_max = 10.0f) {
+    c_ = std::move(c);
+    id_ = c_->Check(m3t_hip_focused_depth_renderer_create(c_->get(), geometry.id(), camera.id(), image_size, z_min, z_max),
+                    "FocusedBasicDepthRenderer");
+  }
+};
+class FocusedSilhouetteRenderer : public FocusedRenderer {
+ public:
+  FocusedSilhouetteRenderer(ContextPtr c, const RendererGeometry& geometry, const Camera& camera,
+                            int id_type = M3T_ID_TYPE_BODY, int image_size = 200, float z_min = 0.02f,
+                            float z_max = 10.0f) {
+    c_ = std::move(c);
+    id_ = c_->Check(m3t_hip_focused_silhouette_renderer_create(c_->get(), geometry.id(), camera.id(), id_type,
+                                                               image_size, z_min, z_max),
+                    "FocusedSilhouetteRenderer");
   }
 };
 
@@ -167,6 +219,12 @@ class RegionModality : public Modality {
                                                    depth_camera ? depth_camera->id() : -1),
                     "RegionModality");
   }
+  bool ModelOcclusions(const FocusedBasicDepthRenderer& renderer) {
+    return c_->Step(m3t_hip_region_modality_model_occlusions(c_->get(), id_, renderer.id()));
+  }
+  bool UseRegionChecking(const FocusedSilhouetteRenderer& renderer) {
+    return c_->Step(m3t_hip_region_modality_use_region_checking(c_->get(), id_, renderer.id()));
+  }
   std::vector<m3t_data_line> data_lines(int capacity = 1024) const {
     std::vector<m3t_data_line> out(capacity);
     int n = 0;
@@ -182,6 +240,12 @@ class DepthModality : public Modality {
     c_ = std::move(c);
     id_ = c_->Check(m3t_hip_depth_modality_create(c_->get(), &params, body.id(), depth_camera.id(), depth_model.id()),
                     "DepthModality");
+  }
+  bool ModelOcclusions(const FocusedBasicDepthRenderer& renderer) {
+    return c_->Step(m3t_hip_depth_modality_model_occlusions(c_->get(), id_, renderer.id()));
+  }
+  bool UseSilhouetteChecking(const FocusedSilhouetteRenderer& renderer) {
+    return c_->Step(m3t_hip_depth_modality_use_silhouette_checking(c_->get(), id_, renderer.id()));
   }
 };
 

@@ -117,7 +117,7 @@ class TrackerFixture:
     modalities of the triangle on one link"""
 
     def __init__(self, api, measure_occlusions, tikhonov_rotation=1000.0, tikhonov_translation=30000.0,
-                 n_corr_iterations=7, n_update_iterations=2):
+                 n_corr_iterations=7, n_update_iterations=2, region_params=None, depth_params=None):
         v = views()
         self.region_model = host.RegionModel(api, data_points=v["region_points"],
                                              orientations=v["region_orientations"],
@@ -134,8 +134,10 @@ class TrackerFixture:
                                               depth_camera=self.depth_camera, measure_occlusions=1)
             self.depth = host.DepthModality(api, self.body, self.depth_camera, self.depth_model, measure_occlusions=1)
         else:
-            self.region = host.RegionModality(api, self.body, self.color_camera, self.region_model)
-            self.depth = host.DepthModality(api, self.body, self.depth_camera, self.depth_model)
+            self.region = host.RegionModality(api, self.body, self.color_camera, self.region_model,
+                                              **(region_params or {}))
+            self.depth = host.DepthModality(api, self.body, self.depth_camera, self.depth_model,
+                                            **(depth_params or {}))
         self.optimizer = host.Optimizer(api, body=self.body, modalities=[self.region, self.depth],
                                         tikhonov_parameter_rotation=tikhonov_rotation,
                                         tikhonov_parameter_translation=tikhonov_translation)
