@@ -50,6 +50,16 @@ class BodyGeometry(C.Structure):
                 ("geometry_enable_culling", C.c_int), ("body_id", C.c_int), ("region_id", C.c_int)]
 
 
+class ModelGenerationParams(C.Structure):
+    """m3t_model_generation_params; defaults = region_model.h:142-148"""
+    _fields_ = [("sphere_radius", C.c_float), ("n_divides", C.c_int), ("n_points", C.c_int),
+                ("max_radius_depth_offset", C.c_float), ("stride_depth_offset", C.c_float), ("image_size", C.c_int)]
+
+    def __init__(self, sphere_radius=0.8, n_divides=4, n_points=200, max_radius_depth_offset=0.05,
+                 stride_depth_offset=0.002, image_size=2000):
+        super().__init__(sphere_radius, n_divides, n_points, max_radius_depth_offset, stride_depth_offset, image_size)
+
+
 class RegionModalityParams(C.Structure):
     """m3t_region_modality_params; defaults = M3T/include/m3t/region_modality.h:411-443."""
     _fields_ = [
@@ -269,6 +279,10 @@ _SIGNATURES = {
 # entry points only the HIP library has (device plumbing)
 _HIP_ONLY = {
     "get_stream": [C.POINTER(C.c_void_p)],
+    "region_model_generate": [C.c_int, C.POINTER(ModelGenerationParams)],
+    "depth_model_generate": [C.c_int, C.POINTER(ModelGenerationParams)],
+    "region_model_get_views": [C.c_int, c_float_p, c_float_p, c_float_p],
+    "depth_model_get_views": [C.c_int, c_float_p, c_float_p, c_float_p],
     "device_info": [C.c_char_p, C.c_size_t, c_int_p, C.POINTER(C.c_size_t)],
     "set_fused_step": [C.c_int],
     "bodies_get_poses": [c_float_p, C.c_int],

@@ -11,12 +11,14 @@
 #include <fstream>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/m3t_hip.h"
 #include "m3t_device.h"
 #include "m3t_kernels.hip"
 #include "m3t_render.hip"
+#include "m3t_modelgen.hip"
 #include "m3t_links.hip"
 
 namespace {
@@ -70,6 +72,8 @@ struct Camera {
 struct BodyGeometryH {  // body.h:46-60 on the device
   bool set = false;
   DevMem vertices, triangles;
+  std::vector<float> h_vertices;  // host copies for model generation
+  std::vector<int> h_triangles;
   int n_triangles = 0;
   float geometry2body[16];
   int culling = 1, body_id = 0, region_id = 0;
@@ -1634,6 +1638,8 @@ int m3t_hip_body_set_geometry(m3t_hip_context* ctx, int body, const m3t_body_geo
   HIPCHK(hipMemcpy(bg->vertices.p, g->vertices, size_t(g->n_vertices) * 12, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(bg->triangles.p, tri.data(), tri.size() * 4, hipMemcpyHostToDevice));
   bg->n_triangles = g->n_triangles;
+  bg->h_vertices.assign(g->vertices, g->vertices + size_t(g->n_vertices) * 3);
+  bg->h_triangles = tri;
   std::memcpy(bg->geometry2body, g->geometry2body, 64);
   bg->culling = g->geometry_enable_culling ? 1 : 0;
   bg->body_id = g->body_id;
@@ -1820,6 +1826,126 @@ int m3t_hip_depth_modality_use_silhouette_checking(m3t_hip_context* ctx, int mod
   m->dev.body_id = ctx->body_geometries[m->body]->body_id;
   ctx->tables_dirty = true;
   return M3T_OK;
+}
+
+// ---- model generation (f-1) ---------------------------------------------------------------------------
+static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_model_generation_params* p) {
+  CHECK_CTX();
+  REQUIRE(p && p->sphere_radius > 0.0f && p->n_divides >= 0 && p->n_divides <= 6 && p->n_points >= 1 &&
+              p->image_size >= 64 && p->image_size <= 4096 && p->stride_depth_offset > 0.0f &&
+              p->max_radius_depth_offset >= 0.0f &&
+              int(p->max_radius_depth_offset / p->stride_depth_offset + 1.0f) <= M3T_N_DEPTH_OFFSETS,
+          M3T_ERR_INVALID_ARGUMENT, "bad model generation parameters");
+  REQUIRE(HasGeometry(ctx, body), M3T_ERR_NOT_SET_UP, "body has no geometry");
+  HIPCHK(hipSetDevice(ctx->device));
+  using namespace modelgen;
+  const BodyGeometryH& g = *ctx->body_geometries[body];
+  const int S = p->image_size;
+  const float d = g.maximum_body_diameter, radius = p->sphere_radius;
+  REQUIRE(0.5f * d < radius, M3T_ERR_INVALID_ARGUMENT, "sphere radius smaller than the body");
+  // Model::SetUpRenderer model.cpp:120-153
+  const float fu = 0.5f * float(S - 20) / tanf(asinf(0.5f * d / radius));
+  const float pp = float(S) / 2.0f;
+  const float z_min = radius - d * 0.5f, z_max = radius + d * 0.5f;
+  P4 P;
+  for (float& f : P.m) f = 0.0f;  // FullRenderer::CalculateProjectionMatrix renderer.cpp:257-264
+  P(0, 0) = 2.0f * fu / float(S);
+  P(0, 2) = 2.0f * (pp + 0.5f) / float(S) - 1.0f;
+  P(1, 1) = 2.0f * fu / float(S);
+  P(1, 2) = 2.0f * (pp + 0.5f) / float(S) - 1.0f;
+  P(2, 2) = (z_max + z_min) / (z_max - z_min);
+  P(2, 3) = -2.0f * z_max * z_min / (z_max - z_min);
+  P(3, 2) = 1.0f;
+  P4 g2b;
+  std::memcpy(g2b.m, g.geometry2body, 64);
+  const std::vector<P4> poses = GeodesicPoses(p->n_divides, radius);
+  const int n_views = int(poses.size());
+  const int pf = region ? M3T_REGION_POINT_FLOATS : M3T_DEPTH_POINT_FLOATS;
+  std::vector<float> points(size_t(n_views) * p->n_points * pf), orientations(size_t(n_views) * 3), extents(n_views);
+  const size_t px = size_t(S) * S;
+  const int batch = int(std::max<size_t>(1, std::min<size_t>(16, (size_t(768) << 20) / (px * 8))));
+  DevMem d_z, d_trans;
+  HIPCHK(d_z.alloc(size_t(batch) * px * 8));
+  HIPCHK(d_trans.alloc(size_t(batch) * 64));
+  std::vector<unsigned long long> h_z(size_t(batch) * px);
+  std::vector<P4> trans(batch), geometry2camera(batch);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int first = 0; first < n_views; first += batch) {
+    const int n = std::min(batch, n_views - first);
+    for (int k = 0; k < n; ++k) {
+      geometry2camera[k] = MulAffine(InverseAffine(poses[first + k]), g2b);  // body at the identity pose
+      trans[k] = MulGeneral(P, geometry2camera[k]);
+    }
+    HIPCHK(hipMemcpyAsync(d_trans.p, trans.data(), size_t(n) * 64, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_z.p, 0xff, size_t(n) * px * 8, ctx->stream));
+    ModelRenderDev job{};
+    job.vertices = g.vertices.as<float>();
+    job.triangles = g.triangles.as<int>();
+    job.n_triangles = g.n_triangles;
+    job.culling = g.culling;
+    job.image_size = S;
+    job.trans = d_trans.as<float>();
+    job.z_buffer = d_z.as<unsigned long long>();
+    const int slices = std::max(1, std::min(64, (g.n_triangles + M3T_BLOCK_THREADS - 1) / M3T_BLOCK_THREADS));
+    hipLaunchKernelGGL(model_render_kernel, dim3(slices, n), dim3(M3T_BLOCK_THREADS), 0, ctx->stream, job);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_z.data(), d_z.p, size_t(n) * px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<std::thread> workers;
+    for (int k = 0; k < n; ++k)
+      workers.emplace_back([&, k]() {
+        View v;
+        v.S = S;
+        v.fu = fu;
+        v.pp = pp;
+        v.term_a = z_max * z_min * 65535.0f / (z_max - z_min);  // renderer.cpp:475-478
+        v.term_b = z_max * 65535.0f / (z_max - z_min);
+        v.depth.resize(px);
+        v.triangle.resize(px);
+        const unsigned long long* z = h_z.data() + size_t(k) * px;
+        for (size_t i = 0; i < px; ++i) {
+          const bool hit = z[i] != ~0ull;
+          v.depth[i] = hit ? uint16_t(z[i] >> 32) : uint16_t(65535);
+          v.triangle[i] = hit ? int(z[i] & 0xffffffffull) : -1;
+        }
+        const int view = first + k;
+        const P4& c2b = poses[view];
+        float* out = points.data() + size_t(view) * p->n_points * pf;
+        if (region)
+          RegionViewData(v, c2b, radius, p->n_points, p->max_radius_depth_offset, p->stride_depth_offset, out,
+                         &extents[view]);
+        else
+          DepthViewData(v, c2b, geometry2camera[k], g.h_vertices, g.h_triangles, radius, p->n_points, p->max_radius_depth_offset,
+                        p->stride_depth_offset, out, &extents[view]);
+        for (int c = 0; c < 3; ++c) orientations[size_t(view) * 3 + c] = c2b(c, 2);
+      });
+    for (auto& w : workers) w.join();
+  }
+  return CreateModel(ctx, region, n_views, p->n_points, points.data(), orientations.data(), extents.data(),
+                     p->stride_depth_offset, p->max_radius_depth_offset);
+}
+int m3t_hip_region_model_generate(m3t_hip_context* ctx, int body, const m3t_model_generation_params* p) {
+  return GenerateModel(ctx, true, body, p);
+}
+int m3t_hip_depth_model_generate(m3t_hip_context* ctx, int body, const m3t_model_generation_params* p) {
+  return GenerateModel(ctx, false, body, p);
+}
+static int GetViews(m3t_hip_context* ctx, bool region, int id, float* points, float* orientations, float* extents) {
+  CHECK_CTX();
+  auto& models = region ? ctx->region_models : ctx->depth_models;
+  REQUIRE(id >= 0 && id < int(models.size()), M3T_ERR_INVALID_ARGUMENT, "bad model id");
+  HIPCHK(hipSetDevice(ctx->device));
+  const Model& m = *models[id];
+  if (points) HIPCHK(hipMemcpy(points, m.points.p, size_t(m.n_views) * m.n_points * m.point_floats * 4, hipMemcpyDeviceToHost));
+  if (orientations) HIPCHK(hipMemcpy(orientations, m.orientations.p, size_t(m.n_views) * 12, hipMemcpyDeviceToHost));
+  if (extents) HIPCHK(hipMemcpy(extents, m.extents.p, size_t(m.n_views) * 4, hipMemcpyDeviceToHost));
+  return M3T_OK;
+}
+int m3t_hip_region_model_get_views(m3t_hip_context* ctx, int id, float* points, float* orientations, float* extents) {
+  return GetViews(ctx, true, id, points, orientations, extents);
+}
+int m3t_hip_depth_model_get_views(m3t_hip_context* ctx, int id, float* points, float* orientations, float* extents) {
+  return GetViews(ctx, false, id, points, orientations, extents);
 }
 
 int m3t_hip_link_create(m3t_hip_context* ctx, int body, int parent, const float body2joint[16],

@@ -252,6 +252,24 @@ class RegionModel:
         self.api.call("region_model_closest_view", self.id, fptr(pose_arg(body2camera_pose)), C.byref(v))
         return v.value
 
+    @classmethod
+    def generate(cls, api, body, **params):
+        """RegionModel::GenerateModel without OpenGL (HIP library only); body needs set_geometry()"""
+        self = cls.__new__(cls)
+        self.api = api
+        self.id = api.call("region_model_generate", body.id, C.byref(_capi.ModelGenerationParams(**params)))
+        nv, npts, me = C.c_int(), C.c_int(), C.c_float()
+        api.call("region_model_info", self.id, C.byref(nv), C.byref(npts), C.byref(me))
+        self.n_views, self.n_points, self.max_contour_length = nv.value, npts.value, me.value
+        return self
+
+    def views(self):
+        pts = np.zeros((self.n_views, self.n_points, _capi.M3T_REGION_POINT_FLOATS), np.float32)
+        ori = np.zeros((self.n_views, 3), np.float32)
+        ext = np.zeros(self.n_views, np.float32)
+        self.api.call("region_model_get_views", self.id, fptr(pts), fptr(ori), fptr(ext))
+        return pts, ori, ext
+
 
 class DepthModel:
     def __init__(self, api, path=None, data_points=None, orientations=None, surface_areas=None,
@@ -275,6 +293,24 @@ class DepthModel:
         v = C.c_int()
         self.api.call("depth_model_closest_view", self.id, fptr(pose_arg(body2camera_pose)), C.byref(v))
         return v.value
+
+    @classmethod
+    def generate(cls, api, body, **params):
+        """DepthModel::GenerateModel without OpenGL (HIP library only); body needs set_geometry()"""
+        self = cls.__new__(cls)
+        self.api = api
+        self.id = api.call("depth_model_generate", body.id, C.byref(_capi.ModelGenerationParams(**params)))
+        nv, npts, me = C.c_int(), C.c_int(), C.c_float()
+        api.call("depth_model_info", self.id, C.byref(nv), C.byref(npts), C.byref(me))
+        self.n_views, self.n_points, self.max_surface_area = nv.value, npts.value, me.value
+        return self
+
+    def views(self):
+        pts = np.zeros((self.n_views, self.n_points, _capi.M3T_DEPTH_POINT_FLOATS), np.float32)
+        ori = np.zeros((self.n_views, 3), np.float32)
+        ext = np.zeros(self.n_views, np.float32)
+        self.api.call("depth_model_get_views", self.id, fptr(pts), fptr(ori), fptr(ext))
+        return pts, ori, ext
 
 
 class _Modality:

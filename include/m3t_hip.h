@@ -57,6 +57,15 @@ int m3t_hip_region_model_info(m3t_hip_context*, int model_id, int* n_views, int*
                               float* max_contour_length);
 int m3t_hip_depth_model_info(m3t_hip_context*, int model_id, int* n_views, int* n_points,
                              float* max_surface_area);
+/* Model generation without OpenGL (RegionModel::GenerateModel region_model.cpp:187-258,
+ * DepthModel::GenerateModel depth_model.cpp:144-212) for one body whose mesh was given with
+ * m3t_hip_body_set_geometry: the template views are rasterised on the device, sampled on the host
+ * (use_random_seed = false: std::mt19937{7}).  Returns the new model id.  *_get_views copies a model out
+ * ([n_views][n_points][38 | 36] points, [n_views][3] orientations, [n_views] contour lengths / surface areas). */
+int m3t_hip_region_model_generate(m3t_hip_context*, int body_id, const m3t_model_generation_params*);
+int m3t_hip_depth_model_generate(m3t_hip_context*, int body_id, const m3t_model_generation_params*);
+int m3t_hip_region_model_get_views(m3t_hip_context*, int model_id, float* points, float* orientations, float* extents);
+int m3t_hip_depth_model_get_views(m3t_hip_context*, int model_id, float* points, float* orientations, float* extents);
 /* RegionModel::GetClosestView (region_model.cpp:105-130) / DepthModel (depth_model.cpp:81-106),
  * evaluated on the device; returns the view index */
 int m3t_hip_region_model_closest_view(m3t_hip_context*, int model_id, const float body2camera[16],

@@ -147,6 +147,15 @@ typedef struct m3t_body_geometry {
   int body_id;   /* 0..255 */
   int region_id; /* 0..255 */
 } m3t_body_geometry;
+/* RegionModel / DepthModel generation parameters (region_model.h:142-148, depth_model.h:88-94) */
+typedef struct m3t_model_generation_params {
+  float sphere_radius;
+  int n_divides;
+  int n_points;
+  float max_radius_depth_offset;
+  float stride_depth_offset;
+  int image_size;
+} m3t_model_generation_params;
 #define M3T_ID_TYPE_BODY 0   /* IDType::BODY */
 #define M3T_ID_TYPE_REGION 1 /* IDType::REGION */
 #define M3T_MAX_RENDERER_BODIES 8
@@ -216,6 +225,15 @@ static inline void m3t_region_modality_params_default(m3t_region_modality_params
   p->modeled_depth_offset_radius = 0.01f;
   p->modeled_occlusion_radius = 0.01f;
   p->modeled_occlusion_threshold = 0.03f;
+}
+
+static inline void m3t_model_generation_params_default(m3t_model_generation_params* p) {
+  p->sphere_radius = 0.8f;
+  p->n_divides = 4;
+  p->n_points = 200;
+  p->max_radius_depth_offset = 0.05f;
+  p->stride_depth_offset = 0.002f;
+  p->image_size = 2000;
 }
 
 static inline void m3t_depth_modality_params_default(m3t_depth_modality_params* p) {

@@ -12,16 +12,13 @@
  * there is no oracle/_ref binary.  Parity pinning status:
  *   pinned   : ColorHistograms (closed-form KAT of color_histograms_test.cpp),
  *              .bin model loader + GetClosestView (data/model_test goldens),
- *              Optimizer/Link solve + pose update (optimizer_test golden pose, also
- *              through the full chain frames -> correspondences -> g/H -> solve),
- *              DepthModality correspondences + g/H (modality_test goldens, the
- *              reference's own 1e-3 criterion),
- *              RegionModality histograms, lines, distributions, local gradient and
- *              Hessian (modality_test goldens + the region_modality.png
- *              visualisation golden: 3 of 518 400 pixels differ).
- *   residual : RegionModality global-mode gradient 1.2e-3 in norm; the
- *              tracker / refiner end poses (14 / 21 Newton updates across a
- *              template-view switch) 2e-3 / 4e-3 instead of 1e-5.
+ *              RegionModality / DepthModality correspondences, gradients, Hessians
+ *              (modality_test goldens, the reference's own 1e-3 criterion) and all
+ *              their visualisation goldens pixel for pixel, incl. measured and modelled
+ *              occlusions, region and silhouette checking,
+ *              Optimizer/Link solve + pose update (optimizer_test golden pose),
+ *              a whole tracking step (tracker_test golden pose, 1e-5 relative).
+ *   residual : the refiner_test pose (a sequence that is chaotic on this fixture).
  * The models those goldens need are regenerated without OpenGL by
  * tests/golden/gl_model.py, itself checked against the .bin files of data/model_test.
  *

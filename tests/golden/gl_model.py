@@ -8,7 +8,8 @@ with models of data/_body/triangle.obj that are NOT shipped, so pinning the orac
 arithmetic against those goldens needs the models to be regenerated.  This module restates the
 generation with a software rasteriser that follows the OpenGL rules the reference relies on
 (pixel centres at integer image coordinates, renderer.cpp:257-264; 1/256 sub-pixel snapping,
-top-left fill rule, 16-bit depth, RGBA8 flat normals, normal_renderer.cpp:11-31,148-153) and
+top-left fill rule, 16-bit depth tested with GL_LESS in draw order, RGBA8 flat normals,
+normal_renderer.cpp:11-31,148-153) and
 OpenCV's border following (cv::findContours, RETR_LIST / CHAIN_APPROX_NONE) for the contour
 order, so that the same mt19937{7} draws select the same pixels.  It is validated against the
 reference's own generated models data/model_test/{region,depth}_model.bin (n_divides 2,
@@ -147,6 +148,35 @@ def geodesic_poses(n_divides, sphere_radius):
 
 
 # ---- the renderer -----------------------------------------------------------------------------
+def _mul44(a, b):
+    """4x4 product in float32, every element ((a0 b0 + a1 b1) + a2 b2) + a3 b3"""
+    a, b = np.asarray(a, F), np.asarray(b, F)
+    o = np.empty((4, 4), F)
+    for r in range(4):
+        for c in range(4):
+            o[r, c] = F(F(F(F(a[r, 0] * b[0, c]) + F(a[r, 1] * b[1, c])) + F(a[r, 2] * b[2, c])) + F(a[r, 3] * b[3, c]))
+    return o
+
+
+def _inverse_affine(t):
+    """Eigen's Transform::inverse(Affine) in float32: cofactor inverse of the linear part, -Linv t"""
+    t = np.asarray(t, F)
+
+    def cof(i, j):
+        i1, i2, j1, j2 = (i + 1) % 3, (i + 2) % 3, (j + 1) % 3, (j + 2) % 3
+        return F(F(t[i1, j1] * t[i2, j2]) - F(t[i1, j2] * t[i2, j1]))
+
+    det = F(F(F(cof(0, 0) * t[0, 0]) + F(cof(1, 0) * t[1, 0])) + F(cof(2, 0) * t[2, 0]))
+    invdet = F(F(1.0) / det)
+    r = np.eye(4, dtype=F)
+    for rr in range(3):
+        for cc in range(3):
+            r[rr, cc] = F(cof(cc, rr) * invdet)
+    for k in range(3):
+        r[k, 3] = -F(F(F(r[k, 0] * t[0, 3]) + F(r[k, 1] * t[1, 3])) + F(r[k, 2] * t[2, 3]))
+    return r
+
+
 class ConvexBody:
     def __init__(self, obj_path, geometry2body):
         self.vertices, self.faces = load_obj(obj_path)
@@ -179,14 +209,15 @@ class Render:
                       [0, 0, (z_max + z_min) / (z_max - z_min), F(-2.0) * z_max * z_min / (z_max - z_min)],
                       [0, 0, 1, 0]], F)
         c2b = np.asarray(camera2body, F)
-        w2c = np.eye(4, dtype=F)
-        w2c[:3, :3] = np.linalg.inv(c2b[:3, :3].astype(np.float64)).astype(F)
-        w2c[:3, 3] = -(w2c[:3, :3] @ c2b[:3, 3]).astype(F)
-        twp = (w2c @ body.geometry2body).astype(F)
-        trans = (P @ twp).astype(F)
+        w2c = _inverse_affine(c2b)
+        twp = _mul44(w2c, body.geometry2body)
+        trans = _mul44(P, twp)
         rot = twp[:3, :3]
-        vh = np.concatenate([body.vertices, np.ones((len(body.vertices), 1), F)], axis=1)
-        clip = (vh @ trans.T).astype(F)
+        v = body.vertices
+        clip = np.empty((len(v), 4), F)
+        for i in range(4):  # ((t_i0 x + t_i1 y) + t_i2 z) + t_i3, float32 at every step
+            clip[:, i] = ((trans[i, 0] * v[:, 0] + trans[i, 1] * v[:, 1]).astype(F) + trans[i, 2] * v[:, 2]).astype(F) \
+                + trans[i, 3]
         ndc = (clip[:, :3] / clip[:, 3:4]).astype(F)
         win = np.empty_like(ndc)
         win[:, 0] = (ndc[:, 0] + F(1.0)) * F(0.5 * S)
@@ -240,16 +271,18 @@ class Render:
             w2 = es[0] / a2
             z = w0 * float(zs[0]) + w1 * float(zs[1]) + w2 * float(zs[2])
             sl = (slice(y0, y1 + 1), slice(x0, x1 + 1))
-            closer = inside & (z < zbuf[sl])
-            zbuf[sl][closer] = z[closer]
+            # GL_DEPTH_COMPONENT16 + GL_LESS: the test runs on the quantised value, the triangle drawn
+            # first keeps a tie (this decides which face owns a contour pixel between two faces)
+            zq16 = np.floor(z * 65535.0 + 0.5 - quant_bias)
+            closer = inside & (zq16 < zbuf[sl])
+            zbuf[sl][closer] = zq16[closer]
             self.mask[sl][closer] = K_MAIN_BODY_ID
             n_cam = (rot @ body.normals[f]).astype(F)
             col = np.float64(0.5) - np.float64(0.5) * n_cam.astype(np.float64)
             rgba = np.floor(np.clip(col, 0, 1) * 255.0 + 0.5 - quant_bias).astype(np.uint8)
             self.normal[sl][closer] = (rgba[0], rgba[1], rgba[2], 255)
         cov = self.mask > 0
-        zq = zbuf[cov] * 65535.0
-        self.depth[cov] = np.floor(zq + 0.5 - quant_bias).astype(np.uint16)
+        self.depth[cov] = zbuf[cov].astype(np.uint16)
 
     def depth_of_value(self, value):
         return self.term_a / (self.term_b - F(value))

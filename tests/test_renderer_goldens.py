@@ -23,7 +23,7 @@ def _lines_image_matches(f, name, n_lines):
     hf, hb = f.modality.histograms()
     vis = gs.render_lines_visualisation(f.image, hf, hb, lines, n_bins=16, scale=6, distribution_length=12)
     gold = gs.load_png("modality_test/" + name).astype(np.int32)
-    assert int((np.abs(vis - gold).max(axis=2) > 0).sum()) <= 3
+    assert int((np.abs(vis - gold).max(axis=2) > 0).sum()) == 0
     return lines
 
 
