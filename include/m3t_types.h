@@ -38,7 +38,7 @@ enum {
   M3T_OK = 0,
   M3T_ERR_INVALID_ARGUMENT = -1,
   M3T_ERR_NOT_SET_UP = -2,     /* reference: "Set up ... first" -> false */
-  M3T_ERR_UNSUPPORTED = -3,    /* renderer-fed branches */
+  M3T_ERR_UNSUPPORTED = -3,    /* a limit of this implementation (e.g. more than 8 bodies in a renderer) */
   M3T_ERR_IO = -4,
   M3T_ERR_DEVICE = -5,         /* HIP / RCCL runtime error */
   M3T_ERR_NO_MEMORY = -6

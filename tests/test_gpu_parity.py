@@ -409,8 +409,12 @@ def test_error_conventions_match_reference():
     assert "first" in hip.last_error()
     assert not a.tracker.ExecuteTrackingStep(0)
     with pytest.raises(util.pkg.M3TError) as e:
+        # region checking needs its renderer: it is switched on with UseRegionChecking(renderer) afterwards
         host.RegionModality(hip, a.bodies[0], a.color_cams[0], a.region_models[0], use_region_checking=1)
-    assert e.value.code == -3
+    assert e.value.code == -1
+    with pytest.raises(util.pkg.M3TError) as e:  # a renderer geometry needs bodies with a mesh
+        host.RendererGeometry(hip).AddBody(a.bodies[0])
+    assert e.value.code == -2
     with pytest.raises(util.pkg.M3TError):
         host.RegionModality(hip, a.bodies[0], a.color_cams[0], a.region_models[0], n_histogram_bins=12)
     with pytest.raises(util.pkg.M3TError):
