@@ -171,6 +171,10 @@ class RegionModel {
   RegionModel(ContextPtr c, const m3t_region_model_desc& desc) : c_(std::move(c)) {
     id_ = c_->Check(m3t_hip_region_model_create(c_->get(), &desc), "RegionModel");
   }
+  // RegionModel::GenerateModel without OpenGL; the body needs set_geometry()
+  RegionModel(ContextPtr c, const Body& body, const m3t_model_generation_params& params) : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_region_model_generate(c_->get(), body.id(), &params), "RegionModel");
+  }
   int GetClosestView(const Pose& body2camera_pose) const {
     int v = 0;
     c_->Check(m3t_hip_region_model_closest_view(c_->get(), id_, body2camera_pose.data(), &v), "GetClosestView");
@@ -186,6 +190,10 @@ class DepthModel {
  public:
   DepthModel(ContextPtr c, const std::string& model_path) : c_(std::move(c)) {
     id_ = c_->Check(m3t_hip_depth_model_load(c_->get(), model_path.c_str()), "DepthModel");
+  }
+  // DepthModel::GenerateModel without OpenGL; the body needs set_geometry()
+  DepthModel(ContextPtr c, const Body& body, const m3t_model_generation_params& params) : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_depth_model_generate(c_->get(), body.id(), &params), "DepthModel");
   }
   DepthModel(ContextPtr c, const m3t_depth_model_desc& desc) : c_(std::move(c)) {
     id_ = c_->Check(m3t_hip_depth_model_create(c_->get(), &desc), "DepthModel");
