@@ -635,23 +635,15 @@ int UploadRendererTables(Ctx* ctx) {
   return M3T_OK;
 }
 
-// one workgroup per renderer; the packed z-buffer lives in LDS when image_size^2 words fit
-int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int largest_image_size) {
+// clear + crop, rasterise (32 slices of the triangle lists per renderer), unpack
+int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int /*largest_image_size*/) {
   if (n_which == 0) return M3T_OK;
-  const size_t words = size_t(largest_image_size) * largest_image_size;
-  const bool in_lds = words * 4 <= 160 * 1024 - 1024;
-  const size_t lds = in_lds ? words * 4 : 0;
-  if (lds > 64 * 1024) {
-    static bool attribute_set = false;
-    if (!attribute_set) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(focused_render_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-      attribute_set = true;
-    }
-  }
-  hipLaunchKernelGGL(focused_render_kernel, dim3(n_which), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
-                     ctx->d_renderers.as<RendererDev>(), which, ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
-                     in_lds ? 1 : 0);
+  hipLaunchKernelGGL(focused_clear_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                     ctx->d_renderers.as<RendererDev>(), which, ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>());
+  hipLaunchKernelGGL(focused_raster_kernel, dim3(32, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                     ctx->d_renderers.as<RendererDev>(), which, ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>());
+  hipLaunchKernelGGL(focused_unpack_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                     ctx->d_renderers.as<RendererDev>(), which);
   HIPCHK(hipGetLastError());
   return M3T_OK;
 }

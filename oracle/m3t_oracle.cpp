@@ -866,6 +866,9 @@ void FocusedRenderer::StartRendering(const Context* ctx) {
         sy[k] = int64_t(std::floor(double(wy) * 256.0 + 0.5));
       }
       if (behind) continue;
+      bool far_off = false;  // anything this far off the image cannot touch it
+      for (int k = 0; k < 3; ++k) far_off |= !(std::llabs(sx[k]) < 30000000LL && std::llabs(sy[k]) < 30000000LL);
+      if (far_off) continue;
       int64_t area = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sy[1] - sy[0]) * (sx[2] - sx[0]);
       if (area == 0) continue;
       // counter-clockwise meshes seen from outside have negative area in the y-down image
