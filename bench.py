@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--sweep", type=str, default="", help="comma separated object counts for a batch sweep (extra)")
+    p.add_argument("--extras", action="store_true",
+                   help="extra legs (never the headline): model generation without OpenGL and a tracking step with "
+                        "all renderer-fed branches, on the reference's own test fixture")
     p.add_argument("--ycb", type=int, default=0,
                    help="extra leg: N objects with Region+Depth fused modalities, YCB parameters (BASELINE configs[2])")
     return p.parse_args()
@@ -242,6 +245,8 @@ def main():
             out["batch_sweep"] = sweep
         if ycb:
             out["ycb_region_depth"] = ycb
+        if args.extras:
+            out["extras"] = extras_point(pkg)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
@@ -264,6 +269,57 @@ def measured_traffic(kernel, n_obj):
         return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+def extras_point(pkg):
+    """Rows f-1 / a14 on the reference's own fixture (tests/golden): wall time of generating the default
+    region + depth model of the triangle body (2 x 2562 views at 2000 x 2000) and of one tracking step of
+    Region + Depth modality with region checking, silhouette checking and modelled occlusions behind the
+    20 950-triangle bottle (4 focused renderers, refreshed before each of the 7 correspondence searches)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gl_model
+    import golden_scene as gs
+    import util
+    from util import host
+    api = pkg.open_context(0)
+    tv, tf = gl_model.load_obj(os.path.join(util.GOLDEN, "_body/triangle.obj"))
+    body = host.Body(api, gs.mtv.body2world())
+    body.set_geometry(tv, tf, np.asarray(gs.mtv.GEOMETRY2BODY, np.float32), body_id=150, region_id=150)
+    t0 = time.perf_counter()
+    host.RegionModel.generate(api, body)
+    t1 = time.perf_counter()
+    host.DepthModel.generate(api, body)
+    t2 = time.perf_counter()
+    api = pkg.open_context(0)
+    f = gs.TrackerFixture(api, measure_occlusions=False, region_params=dict(n_unoccluded_iterations=0),
+                          depth_params=dict(n_unoccluded_iterations=0))
+    geometry, _ = gs.fixture_renderer_geometry(api, f.body)
+    cd = host.FocusedBasicDepthRenderer(api, geometry, f.color_camera)
+    cs = host.FocusedSilhouetteRenderer(api, geometry, f.color_camera, id_type=1)
+    dd = host.FocusedBasicDepthRenderer(api, geometry, f.depth_camera)
+    ds = host.FocusedSilhouetteRenderer(api, geometry, f.depth_camera, id_type=0)
+    for r in (cd, cs, dd, ds):
+        r.AddReferencedBody(f.body)
+    f.region.ModelOcclusions(cd)
+    f.region.UseRegionChecking(cs)
+    f.depth.ModelOcclusions(dd)
+    f.depth.UseSilhouetteChecking(ds)
+    start = f.body.body2world_pose()
+    f.tracker.StartModalities(0)
+    f.tracker.ExecuteTrackingStep(0)
+    api.call("sync")
+    n = 20
+    t3 = time.perf_counter()
+    for _ in range(n):
+        f.body.set_body2world_pose(start)
+        f.tracker.ExecuteTrackingStep(0)
+    api.call("sync")
+    t4 = time.perf_counter()
+    return {"region_model_generation_s": round(t1 - t0, 2), "depth_model_generation_s": round(t2 - t1, 2),
+            "model": "2562 views x 200 points, 2000 x 2000 renderings, data/_body/triangle.obj",
+            "renderer_fed_tracking_step_ms": round((t4 - t3) / n * 1e3, 3),
+            "renderer_fed_config": "Region + Depth, region / silhouette checking + modelled occlusions, 4 focused "
+                                   "renderers of 20 958 triangles at 200 x 200, 7 x 2 iterations, 1 object"}
 
 
 B_ALG_YCB = 1094456  # SURVEY.md §8(d): Region + Depth with measured occlusions, YCB parameters
