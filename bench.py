@@ -377,7 +377,7 @@ def batch_point(pkg, scenes, n_obj, args):
     hip = pkg.open_context(0)
     K, W = 6, 2
     n_frames = K + W + 1
-    inputs = scenes.Inputs(min(n_obj, 64), n_frames, n_divides=args.n_divides, n_models=8)
+    inputs = scenes.Inputs(min(n_obj, 64), n_frames, n_divides=args.n_divides, n_models=min(8, n_obj))
     # replicate the 64 rendered streams to reach n_obj objects
     rep = scenes.Inputs.__new__(scenes.Inputs)
     rep.__dict__.update(inputs.__dict__)
