@@ -72,10 +72,11 @@ __global__ void __launch_bounds__(M3T_BLOCK_THREADS) model_render_kernel(ModelRe
   auto bbox = [&](const long long* ax, const long long* ay, int& x0, int& x1, int& y0, int& y1) {
     const long long min_x = min(ax[0], min(ax[1], ax[2])), max_x = max(ax[0], max(ax[1], ax[2]));
     const long long min_y = min(ay[0], min(ay[1], ay[2])), max_y = max(ay[0], max(ay[1], ay[2]));
-    x0 = (int)max(floor_div256(min_x) - 1, 0LL);
-    x1 = (int)min(floor_div256(max_x) + 1, (long long)(S - 1));
-    y0 = (int)max(floor_div256(min_y) - 1, 0LL);
-    y1 = (int)min(floor_div256(max_y) + 1, (long long)(S - 1));
+    // pixels whose centre (256 p + 128) lies inside the bounding box: nothing else can pass the edge tests
+    x0 = (int)max(floor_div256(min_x - 128 + 255), 0LL);
+    x1 = (int)min(floor_div256(max_x - 128), (long long)(S - 1));
+    y0 = (int)max(floor_div256(min_y - 128 + 255), 0LL);
+    y1 = (int)min(floor_div256(max_y - 128), (long long)(S - 1));
   };
   auto shade = [&](int t, const long long* ax, const long long* ay, const double* zs, double a2, int px, int py) {
     const long long cx = (long long)px * 256 + 128, cy = (long long)py * 256 + 128;

@@ -159,10 +159,11 @@ __device__ bool raster_setup(const M44& trans, const float* vertices, const int*
   o.area = area;
   const double min_x = fmin(o.ax[0], fmin(o.ax[1], o.ax[2])), max_x = fmax(o.ax[0], fmax(o.ax[1], o.ax[2]));
   const double min_y = fmin(o.ay[0], fmin(o.ay[1], o.ay[2])), max_y = fmax(o.ay[0], fmax(o.ay[1], o.ay[2]));
-  o.x0 = (int)fmax(floor(min_x / 256.0) - 1.0, 0.0);
-  o.x1 = (int)fmin(floor(max_x / 256.0) + 1.0, (double)(S - 1));
-  o.y0 = (int)fmax(floor(min_y / 256.0) - 1.0, 0.0);
-  o.y1 = (int)fmin(floor(max_y / 256.0) + 1.0, (double)(S - 1));
+  // pixels whose centre (256 p + 128) lies inside the bounding box: nothing else can pass the edge tests
+  o.x0 = (int)fmax(ceil((min_x - 128.0) / 256.0), 0.0);
+  o.x1 = (int)fmin(floor((max_x - 128.0) / 256.0), (double)(S - 1));
+  o.y0 = (int)fmax(ceil((min_y - 128.0) / 256.0), 0.0);
+  o.y1 = (int)fmin(floor((max_y - 128.0) / 256.0), (double)(S - 1));
   return o.x1 >= o.x0 && o.y1 >= o.y0;
 }
 // edge functions in f64: the snapped coordinates are integers below 2^26, products and their differences are
