@@ -48,6 +48,7 @@ def parse():
     p.add_argument("--n-divides", type=int, default=4, help="geodesic subdivisions (4 -> 2562 views)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-cpu-parallel", action="store_true", help="skip the one-process-per-object CPU leg")
     p.add_argument("--sweep", type=str, default="", help="comma separated object counts for a batch sweep (extra)")
     p.add_argument("--extras", action="store_true",
                    help="extra legs (never the headline): model generation without OpenGL and a tracking step with "
@@ -221,7 +222,11 @@ def main():
                 if spent >= args.cpu_seconds:
                     break
             oinst.set_poses([inputs.gt[i][0] for i in range(n_cpu)])
+        cpu_parallel = None
+        if not args.no_cpu_parallel:
+            cpu_parallel = cpu_all_cores(n_obj, args)
         cpu = {"value": round(done / spent, 1), "unit": "pose-updates/s", "cores": 1, "kind": "port",
+               "all_cores": cpu_parallel,
                "sample": "%d pose-updates of %d of the same objects, same frames, oracle/libm3t_oracle.so "
                          "(g++ -O3 -march=x86-64-v3), 1 thread, host has %d cores" % (done, n_cpu, os.cpu_count())}
 
@@ -251,6 +256,32 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_all_cores(n_obj, args):
+    """SURVEY 8(d) CPU baseline (ii): the same batch with one single-threaded oracle process per object on the
+    host's cores (what the reference's evaluators do over sequences, rbot_evaluator.cpp:144): aggregate
+    pose-updates/s over a common 8 s window.  Setup (model generation, rendering the frames) is excluded."""
+    import subprocess
+    n_proc = min(n_obj, os.cpu_count() or 1)
+    per = [n_obj // n_proc + (1 if i < n_obj % n_proc else 0) for i in range(n_proc)]
+    start = time.time() + 45.0  # every worker has to be set up by then
+    worker = os.path.join(ROOT, "tools", "cpu_baseline_worker.py")
+    procs, first = [], 0
+    for c in per:
+        procs.append(subprocess.Popen([sys.executable, worker, str(first), str(c), "6", str(args.n_divides),
+                                       repr(start), "8.0"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                      env=dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")))
+        first += c
+    total, late = 0.0, 0.0
+    for pr in procs:
+        out = pr.communicate(timeout=300)[0].decode().strip().splitlines()
+        r = json.loads(out[-1])
+        total += r["pose_updates"] / r["seconds"]
+        late = max(late, r["late_s"])
+    return {"value": round(total, 1), "unit": "pose-updates/s", "cores": n_proc,
+            "sample": "%d single-threaded oracle processes, %d objects, 8 s common window%s" %
+                      (n_proc, n_obj, "" if late == 0.0 else " (slowest worker %.1f s late)" % late)}
 
 
 def measured_traffic(kernel, n_obj):
