@@ -70,6 +70,16 @@ struct RendererDev {
   float* state;                 // [RS_FLOATS]
 };
 
+// a ColorHistograms object shared by several RegionModalities (region_modality.cpp:168-173)
+struct SharedHistogramsDev {
+  int n_bins;
+  float learning_rate_f, learning_rate_b;
+  float* histogram_f;
+  float* histogram_b;
+  float2* histogram_norm;
+  unsigned long long* counts;  // [n_bins^3] foreground count | background count << 32
+};
+
 struct RegionModDev {
   int body, camera, depth_camera;
   // sparse viewpoint model (shared between objects using the same model)
@@ -107,6 +117,7 @@ struct RegionModDev {
   float* histogram_b;     // [n_bins^3]
   float2* histogram_norm; // [n_bins^3] (pf/(pf+pb), pb/(pf+pb)) or (0.5,0.5): MultiplyPixelColorProbability hoisted per bin
   uint32_t* count_scratch; // [n_bins^3] packed counts, only when they do not fit in LDS (n_bins = 64)
+  unsigned long long* shared_counts;  // count table of the shared ColorHistograms object or nullptr
   float* line_state;      // [LS_FIELDS][n_lines_max]
   float* gradient_hessian;  // [6 + 36] gradient, column-major hessian
 };

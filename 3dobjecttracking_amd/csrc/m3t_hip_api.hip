@@ -87,9 +87,15 @@ struct RendererH {  // FocusedBasicDepthRenderer / FocusedSilhouetteRenderer
   DevMem depth, sil, packed, state;
   bool rendered = false;
 };
+struct SharedHistogramsH {  // a ColorHistograms object used by several RegionModalities
+  int n_bins = 16, bitshift = 4;
+  float learning_rate_f = 0.2f, learning_rate_b = 0.2f;
+  DevMem hist_f, hist_b, hist_norm, counts;
+};
 struct RegionMod {
   m3t_region_modality_params p{};
   int depth_renderer = -1, silhouette_renderer = -1;
+  int shared_histograms = -1;
   int body, camera, depth_camera, model;
   DevMem hist_f, hist_b, hist_norm, count_scratch, line_state, gh;
   RegionModDev dev{};
@@ -145,6 +151,8 @@ struct m3t_hip_context {
   std::vector<std::unique_ptr<RegionMod>> region_mods;
   std::vector<std::unique_ptr<DepthMod>> depth_mods;
   std::vector<ModalityRef> modalities;
+  std::vector<std::unique_ptr<SharedHistogramsH>> shared_histograms;
+  DevMem d_shared_histograms;
   std::vector<std::unique_ptr<BodyGeometryH>> body_geometries;  // parallel to the bodies (may be shorter)
   std::vector<std::vector<int>> renderer_geometries;
   std::vector<std::unique_ptr<RendererH>> renderers;
@@ -557,6 +565,22 @@ int UploadTreeTables(Ctx* ctx) {
 // RendererDev table + the renderer fields of the modality tables + the two "which renderers" lists
 // (region modalities' renderers for start / results, all referenced ones for correspondences)
 int UploadRendererTables(Ctx* ctx) {
+  {  // shared ColorHistograms objects
+    std::vector<SharedHistogramsDev> sh(ctx->shared_histograms.size());
+    for (size_t i = 0; i < sh.size(); ++i) {
+      SharedHistogramsH& h = *ctx->shared_histograms[i];
+      sh[i].n_bins = h.n_bins;
+      sh[i].learning_rate_f = h.learning_rate_f;
+      sh[i].learning_rate_b = h.learning_rate_b;
+      sh[i].histogram_f = h.hist_f.as<float>();
+      sh[i].histogram_b = h.hist_b.as<float>();
+      sh[i].histogram_norm = h.hist_norm.as<float2>();
+      sh[i].counts = h.counts.as<unsigned long long>();
+    }
+    HIPCHK(ctx->d_shared_histograms.alloc(std::max<size_t>(1, sh.size()) * sizeof(SharedHistogramsDev)));
+    if (!sh.empty())
+      HIPCHK(hipMemcpy(ctx->d_shared_histograms.p, sh.data(), sh.size() * sizeof(SharedHistogramsDev), hipMemcpyHostToDevice));
+  }
   const size_t n = ctx->renderers.size();
   std::vector<RendererDev> table(n);
   for (size_t i = 0; i < n; ++i) {
@@ -843,6 +867,10 @@ int LaunchHistogram(Ctx* ctx, int iteration, bool initialize) {
   hipLaunchKernelGGL(region_histogram_kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_hist, ctx->stream,
                      ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(), iteration,
                      initialize ? 1 : 0, ctx->hist_counts_in_lds ? 1 : 0);
+  if (!ctx->shared_histograms.empty())  // Initialize / UpdateHistograms of the shared objects, tracker.cpp:441-443,513-515
+    hipLaunchKernelGGL(shared_histogram_finish_kernel, dim3(unsigned(ctx->shared_histograms.size())),
+                       dim3(M3T_BLOCK_THREADS), 0, ctx->stream, ctx->d_shared_histograms.as<SharedHistogramsDev>(),
+                       initialize ? 1 : 0);
   HIPCHK(hipGetLastError());
   return M3T_OK;
 }
@@ -1568,8 +1596,9 @@ int m3t_hip_region_modality_get_histograms(m3t_hip_context* ctx, int id, float* 
   REQUIRE(m, M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (f) HIPCHK(hipMemcpy(f, m->hist_f.p, m->hist_f.bytes, hipMemcpyDeviceToHost));
-  if (b) HIPCHK(hipMemcpy(b, m->hist_b.p, m->hist_b.bytes, hipMemcpyDeviceToHost));
+  const size_t bytes = size_t(m->dev.n_bins) * m->dev.n_bins * m->dev.n_bins * 4;  // private or shared tables
+  if (f) HIPCHK(hipMemcpy(f, m->dev.histogram_f, bytes, hipMemcpyDeviceToHost));
+  if (b) HIPCHK(hipMemcpy(b, m->dev.histogram_b, bytes, hipMemcpyDeviceToHost));
   return M3T_OK;
 }
 int m3t_hip_region_modality_set_histograms(m3t_hip_context* ctx, int id, const float* f, const float* b) {
@@ -1578,7 +1607,7 @@ int m3t_hip_region_modality_set_histograms(m3t_hip_context* ctx, int id, const f
   REQUIRE(m && f && b, M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  size_t bins3 = m->hist_f.bytes / 4;
+  size_t bins3 = size_t(m->dev.n_bins) * m->dev.n_bins * m->dev.n_bins;
   std::vector<float> nrm(bins3 * 2);
   for (size_t i = 0; i < bins3; ++i) {  // MultiplyPixelColorProbability :1585-1593 per bin
     float pf = f[i], pb = b[i];
@@ -1592,9 +1621,9 @@ int m3t_hip_region_modality_set_histograms(m3t_hip_context* ctx, int id, const f
       nrm[2 * i + 1] = 0.5f;
     }
   }
-  HIPCHK(hipMemcpy(m->hist_f.p, f, bins3 * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(m->hist_b.p, b, bins3 * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(m->hist_norm.p, nrm.data(), bins3 * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->dev.histogram_f, f, bins3 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->dev.histogram_b, b, bins3 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m->dev.histogram_norm, nrm.data(), bins3 * 8, hipMemcpyHostToDevice));
   return M3T_OK;
 }
 
@@ -2024,6 +2053,56 @@ int m3t_hip_constraint_create(m3t_hip_context* ctx, int optimizer, int link1, in
   ctx->optimizers[optimizer].constraints.push_back(int(ctx->constraints.size()) - 1);
   ctx->tables_dirty = true;
   return int(ctx->constraints.size()) - 1;
+}
+int m3t_hip_color_histograms_create(m3t_hip_context* ctx, int n_bins, float learning_rate_f, float learning_rate_b) {
+  CHECK_CTX();
+  int bitshift;
+  switch (n_bins) {  // color_histograms.cpp:131-158
+    case 2: bitshift = 7; break;
+    case 4: bitshift = 6; break;
+    case 8: bitshift = 5; break;
+    case 16: bitshift = 4; break;
+    case 32: bitshift = 3; break;
+    case 64: bitshift = 2; break;
+    default: return Fail(ctx, M3T_ERR_INVALID_ARGUMENT, "n_bins has to be of value 2, 4, 8, 16, 32, or 64");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  auto h = std::make_unique<SharedHistogramsH>();
+  h->n_bins = n_bins;
+  h->bitshift = bitshift;
+  h->learning_rate_f = learning_rate_f;
+  h->learning_rate_b = learning_rate_b;
+  const size_t bins3 = size_t(n_bins) * n_bins * n_bins;
+  HIPCHK(h->hist_f.alloc(bins3 * 4));
+  HIPCHK(h->hist_b.alloc(bins3 * 4));
+  HIPCHK(h->hist_norm.alloc(bins3 * 8));
+  HIPCHK(h->counts.alloc(bins3 * 8));
+  HIPCHK(hipMemset(h->counts.p, 0, bins3 * 8));
+  std::vector<float> u(bins3, 1.0f / float(bins3)), nrm(bins3 * 2, 0.5f);  // SetUpHistograms color_histograms.cpp:160-172
+  HIPCHK(hipMemcpy(h->hist_f.p, u.data(), bins3 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->hist_b.p, u.data(), bins3 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->hist_norm.p, nrm.data(), bins3 * 8, hipMemcpyHostToDevice));
+  ctx->shared_histograms.push_back(std::move(h));
+  ctx->tables_dirty = true;
+  return int(ctx->shared_histograms.size()) - 1;
+}
+int m3t_hip_region_modality_use_shared_color_histograms(m3t_hip_context* ctx, int modality, int histograms) {
+  CHECK_CTX();
+  RegionMod* m = GetRegion(ctx, modality);
+  REQUIRE(m && histograms >= 0 && histograms < int(ctx->shared_histograms.size()), M3T_ERR_INVALID_ARGUMENT,
+          "bad modality / histograms id");
+  const SharedHistogramsH& h = *ctx->shared_histograms[histograms];
+  m->shared_histograms = histograms;
+  m->dev.n_bins = h.n_bins;
+  m->dev.bitshift = h.bitshift;
+  m->dev.learning_rate_f = h.learning_rate_f;
+  m->dev.learning_rate_b = h.learning_rate_b;
+  m->dev.histogram_f = h.hist_f.as<float>();
+  m->dev.histogram_b = h.hist_b.as<float>();
+  m->dev.histogram_norm = h.hist_norm.as<float2>();
+  m->dev.shared_counts = h.counts.as<unsigned long long>();
+  ctx->tables_dirty = true;
+  return M3T_OK;
 }
 int m3t_hip_soft_constraint_create(m3t_hip_context* ctx, int optimizer, int link1, int link2, const float b1[16],
                                    const float b2[16], const int dirs[6], float max_distance_rotation,

@@ -1629,13 +1629,21 @@ __device__ __forceinline__ void count_add(__attribute__((address_space(1))) uint
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename CountPtr>
+__device__ __forceinline__ void count_add(__attribute__((address_space(1))) unsigned long long* p,
+                                          unsigned long long v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// SHARED: the modality adds into a ColorHistograms object it shares with others (64-bit words, foreground
+// count in the low half, background in the high half); shared_histogram_finish() turns them into histograms
+template <bool SHARED = false, typename CountPtr>
 __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                         const Affine& b2dc, bool handle_occlusions, bool initialize,
                                                         CountPtr counts, float* misc) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n_bins3 = m.n_bins * m.n_bins * m.n_bins;
-  for (int i = tid; i < n_bins3; i += nt) counts[i] = 0;
+  if (!SHARED)
+    for (int i = tid; i < n_bins3; i += nt) counts[i] = 0;
   const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
   const int n_lines = number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length,
                                       as_global(m.extents), view, m.max_extent, m.n_points);
@@ -1727,7 +1735,10 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
         v += dv;
       }
     }
-    const uint32_t inc = background ? 65536u : 1u;
+    const auto inc = [&]() {
+      if constexpr (SHARED) return background ? (1ull << 32) : 1ull;
+      else return background ? 65536u : 1u;
+    }();
     float u = u0, v = v0;
     G<uint8_t> image = as_global(cam.image);
     for (int k = 0; k < n_valid; ++k) {
@@ -1740,6 +1751,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
       v += dv;
     }
   }
+  if constexpr (!SHARED) {
   __syncthreads();
   // sums (exact: integer counts)
   unsigned sf = 0, sb = 0;
@@ -1807,6 +1819,64 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     norm4[2 * i4] = n0;
     norm4[2 * i4 + 1] = n1;
   }
+  }  // !SHARED
+}
+
+// ColorHistograms::InitializeHistograms / UpdateHistograms (color_histograms.cpp:70-92,174-214) of a shared
+// object, one workgroup: sums, blend, per-bin normalisation, then ClearMemory
+__device__ void shared_histogram_finish(const SharedHistogramsDev& h, bool initialize, float* misc) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n_bins3 = h.n_bins * h.n_bins * h.n_bins;
+  unsigned sf = 0, sb = 0;
+  for (int i = tid; i < n_bins3; i += nt) {
+    unsigned long long c = h.counts[i];
+    sf += (unsigned)(c & 0xffffffffull);
+    sb += (unsigned)(c >> 32);
+  }
+  sf = (unsigned)wave_sum_i((int)sf);
+  sb = (unsigned)wave_sum_i((int)sb);
+  unsigned* umisc = reinterpret_cast<unsigned*>(misc);
+  if (tid % kWave == 0) { umisc[2 * (tid / kWave)] = sf; umisc[2 * (tid / kWave) + 1] = sb; }
+  __syncthreads();
+  sf = 0; sb = 0;
+  for (int w = 0; w < nt / kWave; ++w) { sf += umisc[2 * w]; sb += umisc[2 * w + 1]; }
+  const float sum_f = (float)sf, sum_b = (float)sb;
+  const float lr_f = initialize ? 1.0f : h.learning_rate_f, lr_b = initialize ? 1.0f : h.learning_rate_b;
+  const float comp_f = 1.0f - lr_f, comp_b = 1.0f - lr_b;
+  const float scale_f = lr_f / sum_f, scale_b = lr_b / sum_b;
+  const float uniform_value = 1.0f / (float)n_bins3;
+  for (int i = tid; i < n_bins3; i += nt) {
+    const unsigned long long c = h.counts[i];
+    const float cf = (float)(unsigned)(c & 0xffffffffull), cb = (float)(unsigned)(c >> 32);
+    float hf = h.histogram_f[i], hb = h.histogram_b[i];
+    if (sf == 0) {
+      if (lr_f == 1.0f) hf = uniform_value;
+    } else if (comp_f == 0.0f) {
+      hf = cf * scale_f;
+    } else {
+      hf *= comp_f;
+      hf += cf * scale_f;
+    }
+    if (sb == 0) {
+      if (lr_b == 1.0f) hb = uniform_value;
+    } else if (comp_b == 0.0f) {
+      hb = cb * scale_b;
+    } else {
+      hb *= comp_b;
+      hb += cb * scale_b;
+    }
+    h.histogram_f[i] = hf;
+    h.histogram_b[i] = hb;
+    float nx = 0.5f, ny = 0.5f;
+    if (hf || hb) {
+      float sum = hf;
+      sum += hb;
+      nx = hf / sum;
+      ny = hb / sum;
+    }
+    h.histogram_norm[i] = make_float2(nx, ny);
+    h.counts[i] = 0ull;
+  }
 }
 
 __device__ __forceinline__ void stage_histogram(CRegion& m, float* lds_hist) {
@@ -1838,6 +1908,11 @@ region_histogram_kernel(const RegionModDev* mods, const CameraDev* cams, const f
   bool handle_occlusions = initialize ? (m.n_unoccluded_iterations == 0)
                                       : ((iteration - m.first_iteration) >= m.n_unoccluded_iterations);
   float* misc = lds;
+  if (m.shared_counts) {  // UseSharedColorHistograms: only add this modality's samples
+    region_histogram_update<true>(m, cam, dcam, b2c, b2dc, handle_occlusions, initialize != 0,
+                                  (__attribute__((address_space(1))) unsigned long long*)m.shared_counts, misc);
+    return;
+  }
   if (counts_in_lds) {  // ds_add_u32 on the LDS count table
     region_histogram_update(m, cam, dcam, b2c, b2dc, handle_occlusions, initialize != 0,
                             (__attribute__((address_space(3))) uint32_t*)(lds + M3T_MISC_FLOATS), misc);
@@ -1845,6 +1920,13 @@ region_histogram_kernel(const RegionModDev* mods, const CameraDev* cams, const f
     region_histogram_update(m, cam, dcam, b2c, b2dc, handle_occlusions, initialize != 0,
                             (__attribute__((address_space(1))) uint32_t*)m.count_scratch, misc);
   }
+}
+
+// one workgroup per shared ColorHistograms object, after every modality has added its samples
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+shared_histogram_finish_kernel(const SharedHistogramsDev* shared, int initialize) {
+  __shared__ float misc[64];
+  shared_histogram_finish(shared[blockIdx.x], initialize != 0, misc);
 }
 
 extern "C++" {

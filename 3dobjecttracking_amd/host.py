@@ -120,6 +120,15 @@ class Body:
         self.api.call("body_set_geometry", self.id, C.byref(g))
 
 
+class ColorHistograms:
+    """m3t::ColorHistograms shared by several RegionModalities (color_histograms.h:36-40)"""
+
+    def __init__(self, api, n_bins=16, learning_rate_f=0.2, learning_rate_b=0.2):
+        self.api = api
+        self.n_bins = n_bins
+        self.id = api.call("color_histograms_create", n_bins, learning_rate_f, learning_rate_b)
+
+
 class RendererGeometry:
     """m3t::RendererGeometry: the bodies a renderer draws, in draw order"""
 
@@ -340,6 +349,10 @@ class RegionModality(_Modality):
                            region_model.id, depth_camera.id if depth_camera is not None else -1)
         self.n_bins = self.params.n_histogram_bins
 
+    def UseSharedColorHistograms(self, color_histograms):
+        self.api.call("region_modality_use_shared_color_histograms", self.id, color_histograms.id)
+        self.n_bins = color_histograms.n_bins
+
     def ModelOcclusions(self, depth_renderer):
         self.api.call("region_modality_model_occlusions", self.id, depth_renderer.id)
 
@@ -456,6 +469,6 @@ class SoftConstraint:
 
 
 __all__ = ["Tracker", "Body", "ColorCamera", "DepthCamera", "RegionModel", "DepthModel", "RegionModality",
-           "DepthModality", "Link", "Optimizer", "Constraint", "SoftConstraint", "RendererGeometry",
+           "DepthModality", "Link", "Optimizer", "Constraint", "SoftConstraint", "RendererGeometry", "ColorHistograms",
            "FocusedBasicDepthRenderer", "FocusedSilhouetteRenderer", "M3TError", "RegionModalityParams",
            "DepthModalityParams"]

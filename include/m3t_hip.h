@@ -162,6 +162,12 @@ int m3t_hip_region_modality_use_region_checking(m3t_hip_context*, int modality_i
 int m3t_hip_depth_modality_model_occlusions(m3t_hip_context*, int modality_id, int depth_renderer_id);
 int m3t_hip_depth_modality_use_silhouette_checking(m3t_hip_context*, int modality_id, int silhouette_renderer_id);
 
+/* ColorHistograms shared by several RegionModalities (color_histograms.h:36-40, RegionModality::UseSharedColorHistograms
+ * region_modality.cpp:168-173; cleared / initialised / updated once per step around all modalities, tracker.cpp:435-443,
+ * 507-515).  The modality's own n_histogram_bins and learning rates are ignored once it shares. */
+int m3t_hip_color_histograms_create(m3t_hip_context*, int n_bins, float learning_rate_f, float learning_rate_b);
+int m3t_hip_region_modality_use_shared_color_histograms(m3t_hip_context*, int modality_id, int histograms_id);
+
 int m3t_hip_link_create(m3t_hip_context*, int body_id, int parent_link_id, const float body2joint[16],
                         const float joint2parent[16], const int free_directions[6],
                         int fixed_body2joint_pose);

@@ -129,6 +129,21 @@ class DepthCamera : public Camera {
   }
 };
 
+// m3t::ColorHistograms shared by several RegionModalities
+class ColorHistograms {
+ public:
+  ColorHistograms(ContextPtr c, int n_bins = 16, float learning_rate_f = 0.2f, float learning_rate_b = 0.2f)
+      : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_color_histograms_create(c_->get(), n_bins, learning_rate_f, learning_rate_b),
+                    "ColorHistograms");
+  }
+  int id() const { return id_; }
+
+ private:
+  ContextPtr c_;
+  int id_;
+};
+
 // m3t::FocusedBasicDepthRenderer / m3t::FocusedSilhouetteRenderer (software, no OpenGL context)
 class FocusedRenderer {
  public:
@@ -226,6 +241,9 @@ class RegionModality : public Modality {
     id_ = c_->Check(m3t_hip_region_modality_create(c_->get(), &params, body.id(), color_camera.id(), region_model.id(),
                                                    depth_camera ? depth_camera->id() : -1),
                     "RegionModality");
+  }
+  bool UseSharedColorHistograms(const ColorHistograms& histograms) {
+    return c_->Step(m3t_hip_region_modality_use_shared_color_histograms(c_->get(), id_, histograms.id()));
   }
   bool ModelOcclusions(const FocusedBasicDepthRenderer& renderer) {
     return c_->Step(m3t_hip_region_modality_model_occlusions(c_->get(), id_, renderer.id()));

@@ -596,6 +596,9 @@ struct RegionModality : Modality {
   Context* ctx = nullptr;
   int color_camera = -1, depth_camera = -1, model = -1;
   Histograms hist;
+  int shared_histograms = -1;  // UseSharedColorHistograms region_modality.cpp:168-173 (-1: the private ones)
+  Histograms& Hist();
+  const Histograms& Hist() const;
   // PrecalculateFunctionLookup / DistributionVariables
   float function_lookup_f[M3T_MAX_FUNCTION_LENGTH], function_lookup_b[M3T_MAX_FUNCTION_LENGTH];
   int line_length_in_segments = 0;
@@ -737,6 +740,7 @@ struct Context {
   std::vector<std::unique_ptr<Camera>> cameras;
   std::vector<Body> bodies;
   std::vector<std::unique_ptr<Modality>> modalities;
+  std::vector<std::unique_ptr<Histograms>> shared_histograms;  // ColorHistograms objects used by several modalities
   std::vector<std::vector<int>> renderer_geometries;  // RendererGeometry: body ids in draw order
   std::vector<FocusedRenderer> renderers;
   std::vector<int> renderer_geometry_of;  // renderer -> RendererGeometry
@@ -917,6 +921,10 @@ void FocusedRenderer::StartRendering(const Context* ctx) {
 // ===========================================================================
 // RegionModality implementation
 // ===========================================================================
+Histograms& RegionModality::Hist() { return shared_histograms < 0 ? hist : *ctx->shared_histograms[shared_histograms]; }
+const Histograms& RegionModality::Hist() const {
+  return shared_histograms < 0 ? hist : *ctx->shared_histograms[shared_histograms];
+}
 bool RegionModality::SetUp() {
   // PrecalculateFunctionLookup :910-923
   for (int i = 0; i < p.function_length; ++i) {
@@ -1081,7 +1089,7 @@ void RegionModality::AddLinePixelColorsToTempHistograms(bool handle_occlusions) 
       i_u = int(u);
       i_v = int(v);
       if (i_u < 0 || i_u > image_width_minus_1 || i_v < 0 || i_v > image_height_minus_1) break;
-      hist.AddForegroundColor(image.Pixel(i_v, i_u));
+      Hist().AddForegroundColor(image.Pixel(i_v, i_u));
       u -= u_step;
       v -= v_step;
     }
@@ -1091,7 +1099,7 @@ void RegionModality::AddLinePixelColorsToTempHistograms(bool handle_occlusions) 
       i_u = int(u);
       i_v = int(v);
       if (i_u < 0 || i_u > image_width_minus_1 || i_v < 0 || i_v > image_height_minus_1) break;
-      hist.AddBackgroundColor(image.Pixel(i_v, i_u));
+      Hist().AddBackgroundColor(image.Pixel(i_v, i_u));
       u += u_step;
       v += v_step;
     }
@@ -1311,7 +1319,7 @@ bool RegionModality::IsLineUnoccludedMeasured(const float center_f_body[3], floa
 void RegionModality::MultiplyPixelColorProbability(const uint8_t* pixel_color, float* probability_f,
                                                    float* probability_b) const {
   float pixel_color_probability_f, pixel_color_probability_b;
-  hist.GetProbabilities(pixel_color, &pixel_color_probability_f, &pixel_color_probability_b);
+  Hist().GetProbabilities(pixel_color, &pixel_color_probability_f, &pixel_color_probability_b);
   if (pixel_color_probability_f || pixel_color_probability_b) {
     float sum = pixel_color_probability_f;
     sum += pixel_color_probability_b;
@@ -1441,9 +1449,9 @@ bool RegionModality::StartModality(int iteration, int) {
   first_iteration = iteration;
   PrecalculatePoseVariables();
   bool handle_occlusions = p.n_unoccluded_iterations == 0;
-  hist.ClearMemory();
+  if (shared_histograms < 0) hist.ClearMemory();
   AddLinePixelColorsToTempHistograms(handle_occlusions);
-  hist.InitializeHistograms();
+  if (shared_histograms < 0) hist.InitializeHistograms();
   return true;
 }
 
@@ -1547,11 +1555,11 @@ bool RegionModality::CalculateGradientAndHessian(int, int, int opt_iteration) {
 
 // :572-583
 bool RegionModality::CalculateResults(int iteration) {
-  hist.ClearMemory();
+  if (shared_histograms < 0) hist.ClearMemory();
   PrecalculatePoseVariables();
   bool handle_occlusions = (iteration - first_iteration) >= p.n_unoccluded_iterations;
   AddLinePixelColorsToTempHistograms(handle_occlusions);
-  hist.UpdateHistograms();
+  if (shared_histograms < 0) hist.UpdateHistograms();
   return true;
 }
 
@@ -2615,6 +2623,23 @@ int m3t_oracle_constraint_create(m3t_oracle_context* ctx, int optimizer, int lin
   CTX->optimizers[optimizer].constraints.push_back(int(CTX->constraints.size()) - 1);
   return int(CTX->constraints.size()) - 1;
 }
+// ColorHistograms shared by several RegionModalities (color_histograms.h, region_modality.cpp:168-173)
+int m3t_oracle_color_histograms_create(m3t_oracle_context* ctx, int n_bins, float learning_rate_f, float learning_rate_b) {
+  CHECK_CTX();
+  auto h = std::make_unique<Histograms>();
+  if (!h->SetUp(n_bins, learning_rate_f, learning_rate_b))
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "n_bins has to be of value 2, 4, 8, 16, 32, or 64");
+  CTX->shared_histograms.push_back(std::move(h));
+  return int(CTX->shared_histograms.size()) - 1;
+}
+int m3t_oracle_region_modality_use_shared_color_histograms(m3t_oracle_context* ctx, int modality, int histograms) {
+  CHECK_CTX();
+  if (modality < 0 || modality >= int(CTX->modalities.size()) || !CTX->modalities[modality]->is_region ||
+      histograms < 0 || histograms >= int(CTX->shared_histograms.size()))
+    FAIL(M3T_ERR_INVALID_ARGUMENT, "bad modality / histograms id");
+  static_cast<RegionModality*>(CTX->modalities[modality].get())->shared_histograms = histograms;
+  return M3T_OK;
+}
 int m3t_oracle_soft_constraint_create(m3t_oracle_context* ctx, int optimizer, int link1, int link2,
                                       const float b1[16], const float b2[16], const int dirs[6],
                                       float max_distance_rotation, float max_distance_translation,
@@ -2702,7 +2727,9 @@ int m3t_oracle_start_modalities(m3t_oracle_context* ctx, int iteration) {
   int r = CheckImages(ctx);
   if (r) return r;
   RenderFor(CTX, true);  // start_modality_renderer_ptrs tracker.cpp:430-436
+  for (auto& h : CTX->shared_histograms) h->ClearMemory();  // tracker.cpp:435-443
   for (auto& m : CTX->modalities) m->StartModality(iteration, 0);
+  for (auto& h : CTX->shared_histograms) h->InitializeHistograms();
   return M3T_OK;
 }
 // Tracker::CalculateCorrespondences src/tracker.cpp:447-457
@@ -2755,7 +2782,9 @@ int m3t_oracle_calculate_results(m3t_oracle_context* ctx, int iteration) {
   int r = CheckImages(ctx);
   if (r) return r;
   RenderFor(CTX, true);  // results_renderer_ptrs tracker.cpp:503-509
+  for (auto& h : CTX->shared_histograms) h->ClearMemory();  // tracker.cpp:507-515
   for (auto& m : CTX->modalities) m->CalculateResults(iteration);
+  for (auto& h : CTX->shared_histograms) h->UpdateHistograms();
   return M3T_OK;
 }
 // Tracker::ExecuteTrackingStep src/tracker.cpp:344-364
@@ -2847,8 +2876,8 @@ int m3t_oracle_region_modality_get_histograms(m3t_oracle_context* ctx, int id, f
   if (id < 0 || id >= int(CTX->modalities.size()) || !CTX->modalities[id]->is_region)
     FAIL(M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
   auto* r = static_cast<RegionModality*>(CTX->modalities[id].get());
-  if (f) std::memcpy(f, r->hist.histogram_f.data(), size_t(r->hist.n_bins_cubed) * 4);
-  if (b) std::memcpy(b, r->hist.histogram_b.data(), size_t(r->hist.n_bins_cubed) * 4);
+  if (f) std::memcpy(f, r->Hist().histogram_f.data(), size_t(r->Hist().n_bins_cubed) * 4);
+  if (b) std::memcpy(b, r->Hist().histogram_b.data(), size_t(r->Hist().n_bins_cubed) * 4);
   return M3T_OK;
 }
 int m3t_oracle_region_modality_set_histograms(m3t_oracle_context* ctx, int id, const float* f, const float* b) {
@@ -2856,8 +2885,8 @@ int m3t_oracle_region_modality_set_histograms(m3t_oracle_context* ctx, int id, c
   if (id < 0 || id >= int(CTX->modalities.size()) || !CTX->modalities[id]->is_region || !f || !b)
     FAIL(M3T_ERR_INVALID_ARGUMENT, "bad region modality id");
   auto* r = static_cast<RegionModality*>(CTX->modalities[id].get());
-  std::memcpy(r->hist.histogram_f.data(), f, size_t(r->hist.n_bins_cubed) * 4);
-  std::memcpy(r->hist.histogram_b.data(), b, size_t(r->hist.n_bins_cubed) * 4);
+  std::memcpy(r->Hist().histogram_f.data(), f, size_t(r->Hist().n_bins_cubed) * 4);
+  std::memcpy(r->Hist().histogram_b.data(), b, size_t(r->Hist().n_bins_cubed) * 4);
   return M3T_OK;
 }
 

@@ -217,3 +217,32 @@ def test_async_ingest_matches_blocking_upload():
                 inst.tracker.unregister_host_buffer(b)
         poses.append(seq)
     assert np.array_equal(poses[0][-1], poses[1][-1])
+
+
+def test_shared_color_histograms():
+    """three bodies whose RegionModalities share one ColorHistograms object (RTB configuration,
+    region_modality.cpp:168-173, tracker.cpp:435-443,507-515): every modality adds its samples, the object is
+    initialised / updated once; histograms and poses bit-identical to the oracle over three frames"""
+    inputs = scenes.Inputs(3, 4, n_divides=2)
+    out = []
+    for api in (util.open_hip(), util.open_oracle()):
+        if api.is_hip:
+            api.call("set_summation_mode", 1)
+        inst = scenes.Instance(api, inputs)
+        shared = host.ColorHistograms(api, n_bins=32, learning_rate_f=0.3, learning_rate_b=0.1)
+        for r in inst.region[:2]:
+            r.UseSharedColorHistograms(shared)  # the third keeps its private histograms
+        inst.upload_frame(0)
+        assert inst.tracker.StartModalities(0)
+        states = [inst.region[0].histograms(), inst.region[2].histograms()]
+        for k in range(1, 4):
+            inst.upload_frame(k)
+            assert inst.tracker.ExecuteTrackingStep(k)
+        states += [inst.region[0].histograms(), inst.region[1].histograms(), inst.region[2].histograms()]
+        out.append((states, inst.poses()))
+    (sa, pa), (sb, pb) = out
+    for (fa, ba), (fb, bb) in zip(sa, sb):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+    assert np.array_equal(sa[2][0], sa[3][0])          # modalities 0 and 1 read the same object
+    assert not np.array_equal(sa[2][0], sa[4][0])
+    assert np.array_equal(np.asarray(pa), np.asarray(pb))
