@@ -253,6 +253,7 @@ _SIGNATURES = {
     "depth_modality_use_silhouette_checking": [C.c_int, C.c_int],
     "color_histograms_create": [C.c_int, C.c_float, C.c_float],
     "region_modality_use_shared_color_histograms": [C.c_int, C.c_int],
+    "refine_poses": [C.c_int, C.c_int],
     "soft_constraint_create": [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, C.c_float, C.c_float,
                                C.c_float, C.c_float],
     "set_soft_constraints_active": [C.c_int],

@@ -2313,6 +2313,22 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   }
   return M3T_OK;
 }
+// Refiner::RefinePoses src/refiner.cpp:76-117 (one launch per sub-step)
+int m3t_hip_refine_poses(m3t_hip_context* ctx, int n_corr_iterations, int n_update_iterations) {
+  CHECK_CTX();
+  REQUIRE(n_corr_iterations >= 0 && n_update_iterations >= 0, M3T_ERR_INVALID_ARGUMENT, "bad iteration counts");
+  int r = m3t_hip_calculate_consistent_poses(ctx);
+  if (r) return r;
+  for (int c = 0; c < n_corr_iterations; ++c) {
+    if ((r = m3t_hip_start_modalities(ctx, 0))) return r;  // StartModality(0, corr_iteration)
+    if ((r = m3t_hip_calculate_correspondences(ctx, 0, c))) return r;
+    for (int u = 0; u < n_update_iterations; ++u) {
+      if ((r = m3t_hip_calculate_gradient_and_hessian(ctx, 0, c, u))) return r;
+      if ((r = m3t_hip_calculate_optimization(ctx, 0, c, u))) return r;
+    }
+  }
+  return M3T_OK;
+}
 int m3t_hip_execute_tracking_cycle(m3t_hip_context* ctx, int iteration) {
   return m3t_hip_execute_tracking_step(ctx, iteration);
 }

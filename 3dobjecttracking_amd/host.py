@@ -83,6 +83,10 @@ class Tracker:
     def ingest_sync(self):
         self.api.call("ingest_sync")
 
+    def RefinePoses(self, n_corr_iterations=7, n_update_iterations=2):
+        """m3t::Refiner::RefinePoses (refiner.cpp:76-117)"""
+        return self._step("refine_poses", n_corr_iterations, n_update_iterations)
+
     def ExecuteTrackingCycle(self, iteration):  # ICG/RBGT/SRT3D name
         return self._step("execute_tracking_cycle", iteration)
 

@@ -222,6 +222,9 @@ int m3t_hip_execute_tracking_cycle(m3t_hip_context*, int iteration);
  *    g/H of every iteration observable); 1 (default): fused device loop;
  * 2: fused + line/point state and g/H of the last iteration written back. */
 int m3t_hip_set_fused_step(m3t_hip_context*, int mode);
+/* Refiner::RefinePoses (refiner.cpp:76-117): CalculateConsistentPoses, then n_corr_iterations x
+ * (StartModalities + CalculateCorrespondences + n_update_iterations x (g/H + optimisation)), iteration index 0 */
+int m3t_hip_refine_poses(m3t_hip_context*, int n_corr_iterations, int n_update_iterations);
 int m3t_hip_sync(m3t_hip_context*);
 /* order of the gradient/Hessian sums over lines/points.  0 (default): wavefront DPP tree +
  * LDS across waves.  1: the reference's sequential f32 order (region_modality.cpp:550-554,

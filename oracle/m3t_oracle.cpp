@@ -2802,6 +2802,22 @@ int m3t_oracle_execute_tracking_step(m3t_oracle_context* ctx, int iteration) {
   }
   return m3t_oracle_calculate_results(ctx, iteration);
 }
+// Refiner::RefinePoses src/refiner.cpp:76-117
+int m3t_oracle_refine_poses(m3t_oracle_context* ctx, int n_corr_iterations, int n_update_iterations) {
+  CHECK_CTX();
+  if (n_corr_iterations < 0 || n_update_iterations < 0) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad iteration counts");
+  int r = m3t_oracle_calculate_consistent_poses(ctx);
+  if (r) return r;
+  for (int corr_iteration = 0; corr_iteration < n_corr_iterations; ++corr_iteration) {
+    if ((r = m3t_oracle_start_modalities(ctx, 0))) return r;  // StartModality(0, corr_iteration)
+    if ((r = m3t_oracle_calculate_correspondences(ctx, 0, corr_iteration))) return r;
+    for (int update_iteration = 0; update_iteration < n_update_iterations; ++update_iteration) {
+      if ((r = m3t_oracle_calculate_gradient_and_hessian(ctx, 0, corr_iteration, update_iteration))) return r;
+      if ((r = m3t_oracle_calculate_optimization(ctx, 0, corr_iteration, update_iteration))) return r;
+    }
+  }
+  return M3T_OK;
+}
 int m3t_oracle_execute_tracking_cycle(m3t_oracle_context* ctx, int iteration) {
   return m3t_oracle_execute_tracking_step(ctx, iteration);
 }

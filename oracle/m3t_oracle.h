@@ -148,6 +148,9 @@ int m3t_oracle_calculate_optimization_end(m3t_oracle_context*);
 int m3t_oracle_calculate_results(m3t_oracle_context*, int iteration);
 int m3t_oracle_execute_tracking_step(m3t_oracle_context*, int iteration);
 int m3t_oracle_execute_tracking_cycle(m3t_oracle_context*, int iteration); /* ICG name */
+/* Refiner::RefinePoses (refiner.cpp:76-117): CalculateConsistentPoses, then n_corr_iterations x
+ * (StartModalities + CalculateCorrespondences + n_update_iterations x (g/H + optimisation)), iteration index 0 */
+int m3t_oracle_refine_poses(m3t_oracle_context*, int n_corr_iterations, int n_update_iterations);
 int m3t_oracle_sync(m3t_oracle_context*);
 
 /* accessors */

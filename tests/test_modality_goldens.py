@@ -118,11 +118,7 @@ def check_tracker_and_refiner_goldens(api):
     assert np.max(np.abs((pose - golden)[:3] / golden[:3])) < 1e-5  # CompareToLoadedMatrix(..., 1.0e-5f)
 
     f = gs.TrackerFixture(api, measure_occlusions=True, n_update_iterations=3)
-    t = f.tracker
-    for c in range(7):
-        assert t.StartModalities(0) and t.CalculateCorrespondences(0, c)
-        for u in range(3):
-            assert t.CalculateGradientAndHessian(0, c, u) and t.CalculateOptimization(0, c, u)
+    assert f.tracker.RefinePoses(7, 3)
     golden = util.read_golden_matrix("refiner_test/triangle_pose.txt")
     start = gs.mtv.body2world()
     pose = f.body.body2world_pose()
