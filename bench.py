@@ -148,7 +148,7 @@ def main():
     # through m3t_hip_camera_upload (the boundary's Camera::UpdateImage); never the headline value ----
     pcie = None
     if rank == 0:
-        n_up = min(5, K)
+        n_up = max(1, min(5, K - 1))  # the asynchronous leg stages one frame ahead
         hip.call("cameras_select_slot", 0)
         hip.call("sync")
         tu = time.perf_counter()
