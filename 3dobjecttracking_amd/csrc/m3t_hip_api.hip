@@ -791,10 +791,6 @@ int UploadTables(Ctx* ctx) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_lds_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_occ2_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_lds_occ2_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_correspondence_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_corr)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_correspondence_lds_kernel),
@@ -2280,13 +2276,15 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   if (ctx->fused_mode >= 1 && ctx->fused_possible) {
     int n = int(ctx->opt_table.size());
     ScopedKernelTimer timer(ctx, 0);
-    // at least two objects per CU and two workgroups fit the LDS of a CU: use the 128-VGPR variants (measured:
-    // 256 objects 838 k/s plain vs 762 k/s, 1024 objects 893 k/s plain vs 1.06 M/s with them)
-    bool occ2 = n >= 2 * ctx->prop.multiProcessorCount && ctx->lds_track * 2 <= 160 * 1024;
-    if (const char* e = std::getenv("M3T_HIP_OCC2")) occ2 = e[0] == '1' && ctx->lds_track * 2 <= 160 * 1024;  // developer override
-    auto kernel = ctx->layout.off_hist >= 0 ? (occ2 ? tracking_step_lds_occ2_kernel : tracking_step_lds_kernel)
-                                            : (occ2 ? tracking_step_occ2_kernel : tracking_step_kernel);
-    hipLaunchKernelGGL(kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
+    // From two objects per CU on (and if two working sets fit the CU's LDS) the kernel runs with 256-thread
+    // workgroups, two per CU: one object's serial solve overlaps the other's parallel phases and no register is
+    // spilled (measured, pose-updates/s: 512 objects 1.11 M vs 0.87 M with 512 threads, 4096: 1.24 M vs 0.91 M;
+    // 128-VGPR variants of the 512-thread kernel reached 1.03 M / 1.11 M)
+    int threads = M3T_BLOCK_THREADS;
+    if (n >= 2 * ctx->prop.multiProcessorCount && ctx->lds_track * 2 <= 160 * 1024) threads = M3T_BLOCK_THREADS / 2;
+    if (const char* e = std::getenv("M3T_HIP_THREADS")) threads = std::atoi(e);  // developer override
+    auto kernel = ctx->layout.off_hist >= 0 ? tracking_step_lds_kernel : tracking_step_kernel;
+    hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), ctx->lds_track, ctx->stream,
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                        ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
                        ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,

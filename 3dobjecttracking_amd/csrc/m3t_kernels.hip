@@ -10,7 +10,7 @@
 //   region_gradient_hessian_kernel RegionModality::CalculateGradientAndHessian
 //   depth_correspondence_kernel / depth_gradient_hessian_kernel  DepthModality
 //   rigid_optimize_kernel     Optimizer::CalculateOptimization (dof 6) + Link::UpdatePoses
-//   tracking_step_kernel (+ _lds_, + _occ2_ 128-VGPR variants for batches > #CUs)
+//   tracking_step_kernel (+ _lds_); launched with 256-thread workgroups, two per CU, from two objects per CU on
 //                             the whole ExecuteTrackingStep loop nest fused on device
 //   (kinematic structures: m3t_links.hip)
 //
@@ -2149,25 +2149,6 @@ tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const D
 }
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_lds_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
-                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
-                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int sequential_sum) {
-  tracking_step_body<true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
-                            n_update_iterations, write_state, sequential_sum);
-}
-
-// throughput variants for batches larger than the CU count: registers capped at 128 so that two
-// workgroups share a CU and hide each other's dependent phases (some spilling in the solve)
-__global__ void __launch_bounds__(M3T_BLOCK_THREADS, 4)
-tracking_step_occ2_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
-                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
-                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int sequential_sum) {
-  tracking_step_body<false>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
-                            n_update_iterations, write_state, sequential_sum);
-}
-__global__ void __launch_bounds__(M3T_BLOCK_THREADS, 4)
-tracking_step_lds_occ2_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
                      int sequential_sum) {

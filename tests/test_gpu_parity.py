@@ -246,8 +246,11 @@ def test_sequences_bit_exact_in_reference_summation_order():
             assert np.array_equal(fa, hf) and np.array_equal(ba, hb)
 
 
-def test_region_depth_sequence_bit_exact_in_reference_summation_order():
-    """same for Region + Depth (YCB parameters, measured occlusions)."""
+@pytest.mark.parametrize("threads", [256, 128])
+def test_region_depth_sequence_bit_exact_in_reference_summation_order(threads, monkeypatch):
+    """same for Region + Depth (YCB parameters, measured occlusions), with the workgroup sizes the
+    large-batch launch uses (two 256-thread workgroups per CU from two objects per CU on)."""
+    monkeypatch.setenv("M3T_HIP_THREADS", str(threads))
     inputs = scenes.Inputs(3, 12, n_divides=2, with_depth=True)
     ora = util.open_oracle()
     b = scenes.Instance(ora, inputs, use_depth=True)
