@@ -147,7 +147,7 @@ def main():
     # ---- host-buffer (PCIe-inclusive) rate: every step first uploads its 64 frames from host memory
     # through m3t_hip_camera_upload (the boundary's Camera::UpdateImage); never the headline value ----
     pcie = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         n_up = max(1, min(5, K - 1))  # the asynchronous leg stages one frame ahead
         hip.call("cameras_select_slot", 0)
         hip.call("sync")
@@ -201,7 +201,7 @@ def main():
 
     # ---- CPU baseline: the oracle restatement, 1 thread, bounded sample (rank 0) ----
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only (the other ranks would idle)
         import util
         ora = util.open_oracle()
         n_cpu = min(8, n_obj)
