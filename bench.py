@@ -416,10 +416,15 @@ def batch_point(pkg, scenes, n_obj, args):
     rep.n_objects = n_obj
     for name in ("scenes", "model_of", "gt", "color", "depth", "start", "vertices"):
         rep.__dict__[name] = [inputs.__dict__[name][i] for i in idx]
+    if n_obj > 4096:  # beyond that the replicas look at the 64 frame streams through 64 shared cameras
+        rep.camera_of = idx
     inst = scenes.Instance(hip, rep)
-    for cam in inst.color_cams:
-        hip.call("camera_set_ring", cam.id, n_frames)
+    staged = set()
     for i, cam in enumerate(inst.color_cams):
+        if cam.id in staged:
+            continue
+        staged.add(cam.id)
+        hip.call("camera_set_ring", cam.id, n_frames)
         for k in range(n_frames):
             f = rep.color[i][k]
             hip.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])

@@ -66,10 +66,18 @@ class Instance:
         self.depth_models = [host.DepthModel(api, data_points=m[0], orientations=m[1], surface_areas=m[2])
                              for m in (inputs.depth_models or [])] if use_depth else []
         self.bodies, self.color_cams, self.depth_cams, self.region, self.depth, self.optimizers = [], [], [], [], [], []
+        # inputs.camera_of (optional): objects that look at the same frame stream share one camera
+        camera_of = getattr(inputs, "camera_of", None)
+        shared = {}
         for i in range(inputs.n_objects):
             body = host.Body(api, inputs.start[i])
-            cam = host.ColorCamera(api, **intr)
-            dcam = host.DepthCamera(api, depth_scale=inputs.depth_scale, **intr) if inputs.with_depth else None
+            if camera_of is not None and camera_of[i] in shared:
+                cam, dcam = shared[camera_of[i]]
+            else:
+                cam = host.ColorCamera(api, **intr)
+                dcam = host.DepthCamera(api, depth_scale=inputs.depth_scale, **intr) if inputs.with_depth else None
+                if camera_of is not None:
+                    shared[camera_of[i]] = (cam, dcam)
             mods = []
             if use_region:
                 r = host.RegionModality(api, body, cam, self.region_models[inputs.model_of[i]], depth_camera=dcam, **rp)
