@@ -1882,10 +1882,13 @@ static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_
   std::vector<float> points(size_t(n_views) * p->n_points * pf), orientations(size_t(n_views) * 3), extents(n_views);
   const size_t px = size_t(S) * S;
   const int batch = int(std::max<size_t>(1, std::min<size_t>(16, (size_t(768) << 20) / (px * 8))));
-  DevMem d_z, d_trans;
+  DevMem d_z, d_trans, d_depth, d_tri;
   HIPCHK(d_z.alloc(size_t(batch) * px * 8));
   HIPCHK(d_trans.alloc(size_t(batch) * 64));
-  std::vector<unsigned long long> h_z(size_t(batch) * px);
+  HIPCHK(d_depth.alloc(size_t(batch) * px * 2));
+  if (!region) HIPCHK(d_tri.alloc(size_t(batch) * px * 4));
+  std::vector<uint16_t> h_depth(size_t(batch) * px);
+  std::vector<int> h_tri(region ? 0 : size_t(batch) * px);
   std::vector<P4> trans(batch), geometry2camera(batch);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (int first = 0; first < n_views; first += batch) {
@@ -1906,8 +1909,12 @@ static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_
     job.z_buffer = d_z.as<unsigned long long>();
     const int slices = std::max(1, std::min(64, (g.n_triangles + M3T_BLOCK_THREADS - 1) / M3T_BLOCK_THREADS));
     hipLaunchKernelGGL(model_render_kernel, dim3(slices, n), dim3(M3T_BLOCK_THREADS), 0, ctx->stream, job);
+    hipLaunchKernelGGL(model_unpack_kernel, dim3(1024), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                       d_z.as<unsigned long long>(), size_t(n) * px, d_depth.as<uint16_t>(),
+                       region ? static_cast<int*>(nullptr) : d_tri.as<int>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_z.data(), d_z.p, size_t(n) * px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_depth.data(), d_depth.p, size_t(n) * px * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (!region) HIPCHK(hipMemcpyAsync(h_tri.data(), d_tri.p, size_t(n) * px * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     std::vector<std::thread> workers;
     for (int k = 0; k < n; ++k)
@@ -1918,14 +1925,8 @@ static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_
         v.pp = pp;
         v.term_a = z_max * z_min * 65535.0f / (z_max - z_min);  // renderer.cpp:475-478
         v.term_b = z_max * 65535.0f / (z_max - z_min);
-        v.depth.resize(px);
-        v.triangle.resize(px);
-        const unsigned long long* z = h_z.data() + size_t(k) * px;
-        for (size_t i = 0; i < px; ++i) {
-          const bool hit = z[i] != ~0ull;
-          v.depth[i] = hit ? uint16_t(z[i] >> 32) : uint16_t(65535);
-          v.triangle[i] = hit ? int(z[i] & 0xffffffffull) : -1;
-        }
+        v.depth = h_depth.data() + size_t(k) * px;
+        v.triangle = region ? nullptr : h_tri.data() + size_t(k) * px;
         const int view = first + k;
         const P4& c2b = poses[view];
         float* out = points.data() + size_t(view) * p->n_points * pf;
@@ -1933,8 +1934,8 @@ static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_
           RegionViewData(v, c2b, radius, p->n_points, p->max_radius_depth_offset, p->stride_depth_offset, out,
                          &extents[view]);
         else
-          DepthViewData(v, c2b, geometry2camera[k], g.h_vertices, g.h_triangles, radius, p->n_points, p->max_radius_depth_offset,
-                        p->stride_depth_offset, out, &extents[view]);
+          DepthViewData(v, c2b, geometry2camera[k], g.h_vertices, g.h_triangles, radius, p->n_points,
+                        p->max_radius_depth_offset, p->stride_depth_offset, out, &extents[view]);
         for (int c = 0; c < 3; ++c) orientations[size_t(view) * 3 + c] = c2b(c, 2);
       });
     for (auto& w : workers) w.join();

@@ -142,6 +142,18 @@ __global__ void __launch_bounds__(M3T_BLOCK_THREADS) model_render_kernel(ModelRe
   }
 }
 
+// depth16 (65535 = nothing) and, for the depth model, the visible triangle of every pixel: 2 or 6 bytes per
+// pixel cross PCIe instead of the 8-byte z-buffer words
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+model_unpack_kernel(const unsigned long long* z_buffer, size_t n, uint16_t* depth, int* triangle) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned long long v = z_buffer[i];
+    const bool hit = v != ~0ull;
+    depth[i] = hit ? (uint16_t)(v >> 32) : (uint16_t)65535;
+    if (triangle) triangle[i] = hit ? (int)(v & 0xffffffffull) : -1;
+  }
+}
+
 }  // extern "C"
 
 namespace modelgen {
@@ -239,9 +251,9 @@ inline std::vector<P4> GeodesicPoses(int n_divides, float sphere_radius) {
 struct View {  // one rendered template view on the host
   int S = 0;
   float fu = 0, pp = 0, term_a = 0, term_b = 0;
-  std::vector<uint16_t> depth;  // 65535 = nothing
-  std::vector<int> triangle;    // -1 = nothing
-  bool Covered(int x, int y) const { return triangle[size_t(y) * S + x] >= 0; }
+  const uint16_t* depth = nullptr;  // [S*S], 65535 = nothing (a body never reaches the far plane z_max)
+  const int* triangle = nullptr;    // [S*S] visible triangle or -1; only for the depth model
+  bool Covered(int x, int y) const { return depth[size_t(y) * S + x] != 65535; }
   float DepthOf(uint16_t v) const { return term_a / (term_b - float(v)); }
   float DepthAt(int x, int y) const { return DepthOf(depth[size_t(y) * S + x]); }
   void PointVector(int x, int y, float out[3]) const {  // FullDepthRenderer::PointVector renderer.cpp:445-452
@@ -449,7 +461,7 @@ inline void DepthViewData(const View& v, const P4& camera2body, const P4& geomet
                           float* points /*[n_points][36]*/, float* surface_area) {
   std::fill(points, points + size_t(n_points) * M3T_DEPTH_POINT_FLOATS, 0.0f);
   size_t n_pixels = 0;
-  for (int t : v.triangle) n_pixels += t >= 0 ? 1 : 0;
+  for (size_t i = 0; i < size_t(v.S) * v.S; ++i) n_pixels += v.depth[i] != 65535 ? 1 : 0;
   const float p2m = sphere_radius / v.fu;
   *surface_area = float(n_pixels) * (p2m * p2m);
   if (n_pixels == 0) return;
