@@ -178,6 +178,7 @@ struct m3t_hip_context {
   size_t pose_capacity = 0;
   std::vector<RigidOptDev> opt_table;
   bool fused_possible = false;
+  bool fuse_histogram_possible = false;  // ... and the histogram update can ride in the same launch
   bool state_valid = false;  // line/point state + g/H on the device reflect the last step
   TrackLdsLayout layout{};
   int np_max = 0, off_points = 0;
@@ -779,6 +780,11 @@ int UploadTables(Ctx* ctx) {
     if (attached != ctx->modalities.size()) ctx->fused_possible = false;
     // renderer-fed branches read other bodies' poses between the sub-steps: one launch per sub-step
     if (ctx->n_render_all > 0) ctx->fused_possible = false;
+    // the histogram update can ride in the tracking launch when every region modality sits alone on its
+    // optimizer, owns its histograms, and the count table fits the LDS
+    ctx->fuse_histogram_possible = ctx->fused_possible && !ctx->region_mods.empty();
+    for (auto& m : ctx->region_mods)
+      if (m->shared_histograms >= 0) ctx->fuse_histogram_possible = false;
     HIPCHK(ctx->d_opts.alloc(std::max<size_t>(1, ctx->opt_table.size()) * sizeof(RigidOptDev)));
     if (!ctx->opt_table.empty())
       HIPCHK(hipMemcpy(ctx->d_opts.p, ctx->opt_table.data(), ctx->opt_table.size() * sizeof(RigidOptDev),
@@ -787,10 +793,11 @@ int UploadTables(Ctx* ctx) {
     size_t max_lds = std::max(std::max(ctx->lds_track, ctx->lds_hist), ctx->lds_depth);
     REQUIRE(max_lds <= 160 * 1024, M3T_ERR_UNSUPPORTED,
             "per-object working set exceeds the 160 KB LDS of a CU");
+    if (!ctx->hist_counts_in_lds) ctx->fuse_histogram_possible = false;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_lds_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_track)));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_correspondence_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_corr)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(region_correspondence_lds_kernel),
@@ -2274,6 +2281,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   int r = Prepare(ctx, true);
   if (r) return r;
   ctx->untracked_launches = untracked_before;  // a whole step is tracked by its step_done event below
+  bool histogram_fused = false;
   if (ctx->fused_mode >= 1 && ctx->fused_possible) {
     int n = int(ctx->opt_table.size());
     ScopedKernelTimer timer(ctx, 0);
@@ -2285,11 +2293,17 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     if (n >= 2 * ctx->prop.multiProcessorCount && ctx->lds_track * 2 <= 160 * 1024) threads = M3T_BLOCK_THREADS / 2;
     if (const char* e = std::getenv("M3T_HIP_THREADS")) threads = std::atoi(e);  // developer override
     auto kernel = ctx->layout.off_hist >= 0 ? tracking_step_lds_kernel : tracking_step_kernel;
-    hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), ctx->lds_track, ctx->stream,
+    // One workgroup per CU: the histogram update (CalculateResults) runs at the end of the same launch, its
+    // count table taking over the line buffers' LDS.  With two workgroups per CU that table (128 KB at 32 bins)
+    // would not fit twice, so large batches keep the separate region_histogram_kernel.
+    histogram_fused = ctx->fuse_histogram_possible && threads == M3T_BLOCK_THREADS && !std::getenv("M3T_HIP_NO_FUSED_HISTOGRAM");
+    const size_t lds = histogram_fused ? std::max(ctx->lds_track, ctx->lds_hist) : ctx->lds_track;
+    hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), lds, ctx->stream,
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                        ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
                        ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
-                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, ctx->sequential_sum);
+                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, ctx->sequential_sum,
+                       histogram_fused ? 1 : 0);
     HIPCHK(hipGetLastError());
     ctx->state_valid = ctx->fused_mode == 2;
   } else {
@@ -2304,8 +2318,10 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     }
     ctx->state_valid = true;
   }
-  if ((r = RenderForModalities(ctx, true))) return r;
-  if ((r = LaunchHistogram(ctx, iteration, false))) return r;
+  if (!histogram_fused) {
+    if ((r = RenderForModalities(ctx, true))) return r;
+    if ((r = LaunchHistogram(ctx, iteration, false))) return r;
+  }
   if (ctx->async_ingest) {
     // remember which frame slots this step reads, so that a later asynchronous upload into one of
     // them waits for exactly this step and not for the ones enqueued after it

@@ -2053,7 +2053,7 @@ template <bool HIST_LDS>
 __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int sequential_sum) {
+                     int sequential_sum, int fuse_histogram) {
   extern __shared__ __attribute__((aligned(16))) float lds_t[];
   COpt& o = *(COpt*)(opts + blockIdx.x);
   CRegion* rm = o.region_modality >= 0 ? (CRegion*)(rmods + o.region_modality) : nullptr;
@@ -2136,6 +2136,18 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       if (threadIdx.x < 42) dm->gradient_hessian[threadIdx.x] = gh_depth[threadIdx.x];
     }
   }
+  if (fuse_histogram && rm) {
+    // RegionModality::CalculateResults :572-583 in the same launch: the packed count table takes over the LDS
+    // of the line buffers (misc block first, as in region_histogram_kernel)
+    const Affine b2w = load_pose(pose);
+    __syncthreads();
+    const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+    Affine b2dc = b2c;
+    if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
+    const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
+    region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
+                            (__attribute__((address_space(3))) uint32_t*)(lds_t + M3T_MISC_FLOATS), lds_t);
+  }
 }
 
 }  // extern "C++"
@@ -2143,17 +2155,17 @@ __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int sequential_sum) {
+                     int sequential_sum, int fuse_histogram) {
   tracking_step_body<false>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
-                            n_update_iterations, write_state, sequential_sum);
+                            n_update_iterations, write_state, sequential_sum, fuse_histogram);
 }
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_lds_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int sequential_sum) {
+                     int sequential_sum, int fuse_histogram) {
   tracking_step_body<true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
-                            n_update_iterations, write_state, sequential_sum);
+                            n_update_iterations, write_state, sequential_sum, fuse_histogram);
 }
 
 }  // extern "C"

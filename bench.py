@@ -133,16 +133,20 @@ def main():
         hip.call("get_kernel_timing", ms, cnt)
         hip.call("set_kernel_timing", 0)
         track_ms = ms[0] / max(cnt[0], 1)
+        fused_hist = cnt[1] == 0  # the histogram update rode in the tracking launch (one workgroup per CU)
         hist_ms = ms[1] / max(cnt[1], 1)
-        achieved = B_ALG_TRACK_KERNEL * n_obj / (track_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic("tracking_step_kernel", n_obj)
-        roofline = {"bound": "hbm", "kernel": "tracking_step_kernel", "achieved": round(achieved, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(track_ms, 4),
-                    "algorithmic_bytes_per_launch": B_ALG_TRACK_KERNEL * n_obj,
-                    "histogram_kernel_ms": round(hist_ms, 4),
-                    "histogram_kernel_GBs": round((B_HIST_RMW + B_HIST_PIXELS + B_VIEW_SCAN // 7 + B_VIEW_POINTS // 7) *
-                                                  n_obj / (hist_ms * 1e-3) / 1e9, 2)}
+        alg = B_ALG if fused_hist else B_ALG_TRACK_KERNEL
+        achieved = alg * n_obj / (track_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic("tracking_step_kernel", n_obj, fused_hist)
+        roofline = {"bound": "hbm",
+                    "kernel": "tracking_step_kernel" + (" (whole step incl. histogram update)" if fused_hist else ""),
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel_ms": round(track_ms, 4), "algorithmic_bytes_per_launch": alg * n_obj}
+        if not fused_hist:
+            roofline["histogram_kernel_ms"] = round(hist_ms, 4)
+            roofline["histogram_kernel_GBs"] = round((B_HIST_RMW + B_HIST_PIXELS + B_VIEW_SCAN // 7 + B_VIEW_POINTS // 7) *
+                                                     n_obj / (hist_ms * 1e-3) / 1e9, 2)
 
     # ---- host-buffer (PCIe-inclusive) rate: every step first uploads its 64 frames from host memory
     # through m3t_hip_camera_upload (the boundary's Camera::UpdateImage); never the headline value ----
@@ -284,7 +288,7 @@ def cpu_all_cores(n_obj, args):
                       (n_proc, n_obj, "" if late == 0.0 else " (slowest worker %.1f s late)" % late)}
 
 
-def measured_traffic(kernel, n_obj):
+def measured_traffic(kernel, n_obj, fused_histogram=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
     (profiles/rNN_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs of this same
     command, read side doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).  The counters
@@ -295,7 +299,7 @@ def measured_traffic(kernel, n_obj):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        if d.get("objects_per_launch") != n_obj:
+        if d.get("objects_per_launch") != n_obj or bool(d.get("histogram_update_fused", False)) != fused_histogram:
             return None, None
         return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], os.path.relpath(files[-1], ROOT)
     except Exception:
