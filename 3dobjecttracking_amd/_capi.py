@@ -258,6 +258,7 @@ _SIGNATURES = {
                                C.c_float, C.c_float],
     "set_soft_constraints_active": [C.c_int],
     "link_get_link2world_pose": [C.c_int, c_float_p],
+    "link_set_link2world_pose": [C.c_int, c_float_p],
     "link_set_joint_poses": [C.c_int, c_float_p, c_float_p],
     "link_get_joint_poses": [C.c_int, c_float_p, c_float_p],
     "calculate_consistent_poses": [],
@@ -373,6 +374,8 @@ class CApi:
         return self._fn[name](self.ctx, *args)
 
     def call(self, name, *args):
+        if name not in self._fn:
+            raise M3TError(-3, "%s%s: this entry point exists in the HIP library only" % (self.prefix, name))
         rc = self._fn[name](self.ctx, *args)
         if rc < 0:
             raise M3TError(rc, self.last_error())

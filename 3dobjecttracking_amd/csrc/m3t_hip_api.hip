@@ -2152,6 +2152,17 @@ int m3t_hip_link_get_link2world_pose(m3t_hip_context* ctx, int link, float pose[
   std::memcpy(pose, ctx->links[link].link2world, 64);
   return M3T_OK;
 }
+int m3t_hip_link_set_link2world_pose(m3t_hip_context* ctx, int link, const float pose[16]) {
+  CHECK_CTX();
+  REQUIRE(link >= 0 && link < int(ctx->links.size()) && pose, M3T_ERR_INVALID_ARGUMENT, "bad link id");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->links[link].body >= 0) return m3t_hip_body_set_body2world_pose(ctx, ctx->links[link].body, pose);
+  int r = PullLinks(ctx);
+  if (r) return r;
+  std::memcpy(ctx->links[link].link2world, pose, 64);
+  ctx->tables_dirty = true;
+  return M3T_OK;
+}
 int m3t_hip_link_set_joint_poses(m3t_hip_context* ctx, int link, const float body2joint[16],
                                  const float joint2parent[16]) {
   CHECK_CTX();

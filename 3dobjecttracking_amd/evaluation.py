@@ -1,0 +1,205 @@
+"""Evaluator front-ends of the reference's dataset benchmarks, over the batched tracker.
+
+RBOT (M3T/examples/rbot_evaluator.cpp): ground-truth pose file reader, the 5 cm / 5 degree success criterion,
+the frame loop with reset-on-loss.  YCB-Video (M3T/examples/ycb_evaluator.cpp): ground-truth reader, ADD /
+ADD-S per frame, the tracking-loss curves and the area under curve, reduced evaluation vertices.  The
+datasets themselves are external downloads; the loops take a frame source, so that synthetic sequences and
+the real datasets run through the same code.
+"""
+import time
+
+import numpy as np
+
+F = np.float32
+
+
+# ---------------------------------------------------------------------------------------------------------
+# RBOT
+# ---------------------------------------------------------------------------------------------------------
+def read_poses_rbot(path, n_frames=1000):
+    """RBOTEvaluator::ReadPosesRBOTDataset (rbot_evaluator.cpp:558-585): one header line, then per frame
+    nine rotation entries (row-major) and a translation in millimetres, tab separated; n_frames + 1 poses."""
+    poses = np.zeros((n_frames + 1, 4, 4), F)
+    with open(path) as f:
+        f.readline()
+        for i in range(n_frames + 1):
+            t = f.readline().split("\t")
+            if len(t) < 12:
+                raise ValueError("Could not read pose %d from %s" % (i, path))
+            v = [F(x) for x in t[:12]]
+            poses[i, :3, :3] = np.asarray(v[:9], F).reshape(3, 3)
+            poses[i, :3, 3] = np.asarray(v[9:12], F) * F(0.001)
+            poses[i, 3, 3] = 1.0
+    return poses
+
+
+def rbot_pose_result(body2world_pose, body2world_pose_gt, translation_error_threshold=0.05,
+                     rotation_error_threshold=5.0 * np.pi / 180.0):
+    """RBOTEvaluator::CalculatePoseResults (rbot_evaluator.cpp:416-433): (translation error [m], rotation error
+    [rad], tracking success 0/1).  Thresholds: rbot_evaluator.h:192-193."""
+    p, g = np.asarray(body2world_pose, F), np.asarray(body2world_pose_gt, F)
+    t_err = float(np.linalg.norm((p[:3, 3] - g[:3, 3]).astype(F)))
+    c = (np.trace((p[:3, :3].T @ g[:3, :3]).astype(F)) - F(1.0)) / F(2.0)
+    r_err = float(np.arccos(c))  # NaN for |c| > 1 exactly like acos(); the comparisons below are then false
+    lost = t_err > translation_error_threshold or r_err > rotation_error_threshold
+    return t_err, r_err, 0.0 if lost else 1.0
+
+
+def evaluate_rbot_sequence(tracker, body, poses_gt, load_image, n_frames=None, reset_renderers=()):
+    """RBOTEvaluator::EvaluateRunConfiguration (rbot_evaluator.cpp:174-210) for the main body: start on image 0
+    at its ground truth, then cycle i tracks image i + 1 (the loader camera advances once per UpdateCameras),
+    compares with the ground truth of image i + 1 and resets the body to it (ResetBody :334-342) whenever
+    tracking is lost.  `load_image(k)` makes image k the cameras' current image.
+    Returns the per-frame results and their average (CalculateAverageResult :435-470)."""
+    n_frames = len(poses_gt) - 1 if n_frames is None else n_frames
+
+    def reset(i):
+        body.set_body2world_pose(poses_gt[i])
+        for r in reset_renderers:
+            r.StartRendering()
+        tracker.StartModalities(0)
+
+    load_image(0)
+    reset(0)
+    frames = []
+    for i in range(n_frames):
+        load_image(i + 1)
+        t0 = time.perf_counter()
+        ok = tracker.ExecuteTrackingStep(i) and tracker.Sync()
+        dt = (time.perf_counter() - t0) * 1e6
+        if not ok:
+            raise RuntimeError("tracking step %d failed" % i)
+        t_err, r_err, success = rbot_pose_result(body.body2world_pose(), poses_gt[i + 1])
+        frames.append(dict(frame_index=i, translation_error=t_err, rotation_error=r_err,
+                           tracking_success=success, complete_cycle=dt))
+        if success == 0.0:
+            reset(i + 1)
+    avg = {k: float(np.mean([f[k] for f in frames])) for k in
+           ("translation_error", "rotation_error", "tracking_success", "complete_cycle")}
+    return frames, avg
+
+
+# ---------------------------------------------------------------------------------------------------------
+# YCB-Video
+# ---------------------------------------------------------------------------------------------------------
+K_N_CURVE_VALUES = 100   # ycb_evaluator.h:45
+K_THRESHOLD_MAX = 0.1    # ycb_evaluator.h:46
+
+
+def ycb_thresholds():
+    """ycb_evaluator.cpp:18-22"""
+    step = F(K_THRESHOLD_MAX) / F(K_N_CURVE_VALUES)
+    return (step * (F(0.5) + np.arange(K_N_CURVE_VALUES, dtype=F))).astype(F)
+
+
+def _quaternion_pose(w, x, y, z, tx, ty, tz):
+    q = np.asarray([w, x, y, z], F)
+    q = q / F(np.sqrt((q * q).sum(dtype=F)))
+    w, x, y, z = [float(v) for v in q]
+    pose = np.eye(4, dtype=F)
+    pose[:3, :3] = np.asarray([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                               [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                               [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], F)
+    pose[:3, 3] = (tx, ty, tz)
+    return pose
+
+
+def read_poses_ycb(path, pose_begin, n_frames, keyframes):
+    """YCBEvaluator::LoadGTPoses (ycb_evaluator.cpp:850-901): the per-body pose file holds one line
+    'qw qx qy qz tx ty tz' per frame of every sequence; skip `pose_begin` lines, then keep the lines whose
+    1-based frame index is a keyframe.  Quaternions are normalised, pose = translation * rotation."""
+    keyframes = list(keyframes)
+    poses = []
+    with open(path) as f:
+        for _ in range(pose_begin):
+            f.readline()
+        k = 0
+        for idx in range(1, n_frames + 1):
+            if k >= len(keyframes):
+                break
+            line = f.readline()
+            if idx == keyframes[k]:
+                v = [float(x) for x in line.split(" ")[:7]]
+                poses.append(_quaternion_pose(*v))
+                k += 1
+    return np.asarray(poses, F)
+
+
+def reduce_vertices(vertices, n_vertices_evaluation):
+    """YCBEvaluator::GenderateReducedVertices (ycb_evaluator.cpp:1222-1248): all vertices, or
+    n_vertices_evaluation draws `mt19937{7}() % n` with repetition"""
+    vertices = np.asarray(vertices, F)
+    n = len(vertices)
+    if n_vertices_evaluation <= 0 or n_vertices_evaluation >= n:
+        return vertices
+    raw = np.random.RandomState(7)._bit_generator.random_raw(n_vertices_evaluation)  # == std::mt19937{7}
+    return vertices[(raw % n).astype(np.int64)]
+
+
+class YCBBodyEvaluation:
+    """the per-body data of YCBEvaluator::CalculatePoseResults (ycb_evaluator.cpp:803-848): reduced vertices
+    and a nearest-neighbour index over them (nanoflann there, scipy's k-d tree here: both exact)"""
+
+    def __init__(self, vertices, n_vertices_evaluation=-1):
+        from scipy.spatial import cKDTree
+        self.vertices = reduce_vertices(vertices, n_vertices_evaluation)
+        self.tree = cKDTree(self.vertices.astype(np.float64))
+        self.thresholds = ycb_thresholds()
+
+    def errors(self, body2world_pose, gt_body2world_pose):
+        """(ADD, ADD-S) in metres: delta = body2world^-1 * gt; mean |v - delta v| and mean nearest-vertex
+        distance of delta v"""
+        p = np.asarray(body2world_pose, np.float64)
+        g = np.asarray(gt_body2world_pose, np.float64)
+        pi = np.eye(4)
+        pi[:3, :3] = p[:3, :3].T
+        pi[:3, 3] = -p[:3, :3].T @ p[:3, 3]
+        delta = (pi @ g).astype(F)
+        v = (self.vertices @ delta[:3, :3].T + delta[:3, 3]).astype(F)
+        add = float(np.sqrt(((self.vertices - v) ** 2).sum(axis=1, dtype=F)).mean(dtype=F))
+        dist, _ = self.tree.query(v.astype(np.float64), k=1)
+        adds = float(dist.astype(F).mean(dtype=F))
+        return add, adds
+
+    def result(self, body2world_pose, gt_body2world_pose):
+        add, adds = self.errors(body2world_pose, gt_body2world_pose)
+        out = dict(add_error=add, adds_error=adds)
+        for key, err in (("add", add), ("adds", adds)):
+            curve = np.ones(K_N_CURVE_VALUES, F)
+            for i in range(K_N_CURVE_VALUES):  # the curve is 0 below the error, 1 from the first threshold above
+                if err < self.thresholds[i]:
+                    break
+                curve[i] = 0.0
+            out[key + "_curve"] = curve
+            out[key + "_auc"] = float(F(1.0) - min(F(err) / F(K_THRESHOLD_MAX), F(1.0)))
+        return out
+
+
+def evaluate_ycb_sequence(tracker, bodies, evaluations, gt_body2world_poses, keyframes, update_cameras):
+    """YCBEvaluator::EvaluateRunConfiguration without refinement (ycb_evaluator.cpp:333-372): bodies start at
+    the ground truth of the first keyframe, StartModalities once, then one tracking step per keyframe and the
+    ADD / ADD-S results of every evaluated body.  bodies / evaluations / gt poses are dicts by body name."""
+    for name, body in bodies.items():
+        body.set_body2world_pose(gt_body2world_poses[name][0])
+    update_cameras(keyframes[0])
+    if not tracker.StartModalities(0):
+        raise RuntimeError("StartModalities failed")
+    results = {name: [] for name in evaluations}
+    for i, frame in enumerate(keyframes):
+        update_cameras(frame)
+        t0 = time.perf_counter()
+        if not (tracker.ExecuteTrackingStep(i) and tracker.Sync()):
+            raise RuntimeError("tracking step %d failed" % i)
+        dt = (time.perf_counter() - t0) * 1e6
+        for name, ev in evaluations.items():
+            r = ev.result(bodies[name].body2world_pose(), gt_body2world_poses[name][i])
+            r.update(frame_index=i, complete_cycle=dt)
+            results[name].append(r)
+    average = {}
+    for name, rs in results.items():
+        average[name] = dict(add_auc=float(np.mean([r["add_auc"] for r in rs])),
+                             adds_auc=float(np.mean([r["adds_auc"] for r in rs])),
+                             add_curve=np.mean([r["add_curve"] for r in rs], axis=0),
+                             adds_curve=np.mean([r["adds_curve"] for r in rs], axis=0),
+                             complete_cycle=float(np.mean([r["complete_cycle"] for r in rs])))
+    return results, average

@@ -412,6 +412,8 @@ class Link:
         self.id = api.call("link_create", body.id if body is not None else -1,
                            parent.id if parent is not None else -1, fptr(pose_arg(body2joint_pose)),
                            fptr(pose_arg(joint2parent_pose)), iptr(fd), int(fixed_body2joint_pose))
+        self._default_body2joint_pose = np.array(body2joint_pose, np.float32)
+        self._default_joint2parent_pose = np.array(joint2parent_pose, np.float32)
 
     def AddModality(self, modality):
         self.api.call("link_add_modality", self.id, modality.id)
@@ -420,6 +422,15 @@ class Link:
         buf = np.zeros(16, np.float32)
         self.api.call("link_get_link2world_pose", self.id, fptr(buf))
         return pose_ret(buf)
+
+    def set_link2world_pose(self, pose):
+        """Link::set_link2world_pose (link.cpp:138-140); for a link with a body this is the body's pose"""
+        self.api.call("link_set_link2world_pose", self.id, fptr(pose_arg(pose)))
+
+    def ResetJointPoses(self):
+        """Link::ResetJointPoses (link.cpp:243-246): back to the poses the link was created with"""
+        self.api.call("link_set_joint_poses", self.id, fptr(pose_arg(self._default_body2joint_pose)),
+                      fptr(pose_arg(self._default_joint2parent_pose)))
 
     def set_body2joint_pose(self, pose):
         self.api.call("link_set_joint_poses", self.id, fptr(pose_arg(pose)), None)

@@ -190,6 +190,9 @@ int m3t_hip_soft_constraint_create(m3t_hip_context*, int optimizer_id, int link1
                                    float standard_deviation_translation);
 int m3t_hip_set_soft_constraints_active(m3t_hip_context*, int active);
 int m3t_hip_link_get_link2world_pose(m3t_hip_context*, int link_id, float pose[16]);
+/* Link::set_link2world_pose (link.cpp:138-140; what Detector::UpdatePoses writes, detector.cpp:42-53):
+ * the body's pose for a link with a body, the link's own frame for a body-less root */
+int m3t_hip_link_set_link2world_pose(m3t_hip_context*, int link_id, const float pose[16]);
 /* Link::set_body2joint_pose / set_joint2parent_pose (either may be NULL) and the getters */
 int m3t_hip_link_set_joint_poses(m3t_hip_context*, int link_id, const float body2joint[16],
                                  const float joint2parent[16]);

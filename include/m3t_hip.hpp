@@ -326,6 +326,9 @@ class Link {
     c_->Check(m3t_hip_link_get_link2world_pose(c_->get(), id_, p.data()), "Link");
     return p;
   }
+  void set_link2world_pose(const Pose& p) {
+    c_->Check(m3t_hip_link_set_link2world_pose(c_->get(), id_, p.data()), "Link");
+  }
   int id() const { return id_; }
 
  private:

@@ -2676,6 +2676,15 @@ int m3t_oracle_link_get_link2world_pose(m3t_oracle_context* ctx, int link, float
   return M3T_OK;
 }
 
+int m3t_oracle_link_set_link2world_pose(m3t_oracle_context* ctx, int link, const float pose[16]) {
+  CHECK_CTX();
+  if (link < 0 || link >= int(CTX->links.size()) || !pose) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad link id");
+  Link& l = CTX->links[link];
+  if (l.body >= 0) return m3t_oracle_body_set_body2world_pose(ctx, l.body, pose);  // link2world_pose() is the body's
+  l.link2world = FromArray(pose);
+  return M3T_OK;
+}
+
 int m3t_oracle_link_set_joint_poses(m3t_oracle_context* ctx, int link, const float body2joint[16],
                                     const float joint2parent[16]) {
   CHECK_CTX();

@@ -128,6 +128,9 @@ int m3t_oracle_soft_constraint_create(m3t_oracle_context*, int optimizer_id, int
                                       float standard_deviation_translation);
 int m3t_oracle_set_soft_constraints_active(m3t_oracle_context*, int active);
 int m3t_oracle_link_get_link2world_pose(m3t_oracle_context*, int link_id, float pose[16]);
+/* Link::set_link2world_pose (link.cpp:138-140; what Detector::UpdatePoses writes, detector.cpp:42-53):
+ * the body's pose for a link with a body, the link's own frame for a body-less root */
+int m3t_oracle_link_set_link2world_pose(m3t_oracle_context*, int link_id, const float pose[16]);
 int m3t_oracle_link_set_joint_poses(m3t_oracle_context*, int link_id, const float body2joint[16],
                                     const float joint2parent[16]); /* either may be NULL */
 int m3t_oracle_link_get_joint_poses(m3t_oracle_context*, int link_id, float body2joint[16], float joint2parent[16]);

@@ -12,6 +12,8 @@ Provenance (all under /root/reference/M3T/data/):
   tracker_test/, refiner_test/ pose goldens (test/tracker_test.cpp:164-195)
   _sequence/{color,depth}_camera_image_20{0,1}.png + yaml   the fixture frames (test/common_test.cpp:96-118)
   _body/triangle.obj, schauma.obj + yaml   fixture meshes
+  tracker_test/tracker_config.yaml, _body/triangle_{region,depth}_model.yaml   the generator configuration of
+                                           TrackerTest.OptimizePoseMatrixGeneratorSetUp (test/tracker_test.cpp:182-195)
 """
 import os
 import shutil
@@ -38,6 +40,7 @@ FILES = [
     "_sequence/color_camera.yaml", "_sequence/depth_camera.yaml",
     "_body/triangle.obj", "_body/triangle.yaml", "_body/schauma.yaml", "_body/schauma.obj",
     "_body/triangle_static_detector.yaml", "color_histograms_test/color_histograms.yaml",
+    "tracker_test/tracker_config.yaml", "_body/triangle_region_model.yaml", "_body/triangle_depth_model.yaml",
 ]
 
 if __name__ == "__main__":

@@ -1,0 +1,124 @@
+"""Evaluator front-ends (M3T/examples/rbot_evaluator.cpp, ycb_evaluator.cpp): file readers, error metrics
+and the reset-on-loss loop, on known answers and on a synthetic sequence tracked by the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+import util
+
+ev = util.pkg.evaluation
+
+
+def rot(axis, angle):
+    axis = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K
+
+
+def pose(R=np.eye(3), t=(0, 0, 0)):
+    p = np.eye(4, dtype=np.float32)
+    p[:3, :3] = R
+    p[:3, 3] = t
+    return p
+
+
+def test_rbot_pose_file_and_criterion(tmp_path):
+    """poses_first.txt layout (rbot_evaluator.cpp:558-585): header line, rotation row-major, translation in mm"""
+    R = rot((1, 2, 3), 0.3).astype(np.float32)
+    path = tmp_path / "poses_first.txt"
+    with open(path, "w") as f:
+        f.write("r11\tr12\t...\n")
+        for i in range(4):
+            f.write("\t".join("%.7g" % v for v in list(R.reshape(-1)) + [10.0 * i, -20.0, 500.0 + i]) + "\n")
+    poses = ev.read_poses_rbot(str(path), n_frames=3)
+    assert poses.shape == (4, 4, 4)
+    assert np.allclose(poses[2, :3, :3], R, atol=1e-6)
+    assert np.allclose(poses[2, :3, 3], [0.02, -0.02, 0.502], atol=1e-7) and poses[2, 3, 3] == 1
+    with pytest.raises(ValueError):
+        ev.read_poses_rbot(str(path), n_frames=4)
+    # CalculatePoseResults :416-433: 5 cm and 5 degrees, strict comparisons
+    gt = pose(R, (0.1, 0.2, 0.6))
+    t_err, r_err, ok = ev.rbot_pose_result(pose(R @ rot((0, 0, 1), np.deg2rad(4.9)), (0.1, 0.2, 0.649)), gt)
+    assert ok == 1.0 and t_err == pytest.approx(0.049, abs=1e-6) and r_err == pytest.approx(np.deg2rad(4.9), abs=1e-4)
+    assert ev.rbot_pose_result(pose(R @ rot((0, 1, 0), np.deg2rad(5.1)), (0.1, 0.2, 0.6)), gt)[2] == 0.0
+    assert ev.rbot_pose_result(pose(R, (0.1, 0.2, 0.651)), gt)[2] == 0.0
+
+
+def test_ycb_metrics_known_answers():
+    th = ev.ycb_thresholds()
+    assert len(th) == 100 and th[0] == pytest.approx(0.0005) and th[-1] == pytest.approx(0.0995)  # :18-22
+    cube = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32) * 0.05
+    body = ev.YCBBodyEvaluation(cube)
+    # pure translation d: ADD = |d|; ADD-S = |d| too while every vertex stays closest to its own image
+    add, adds = body.errors(pose(t=(0.01, 0, 0)), pose())
+    assert add == pytest.approx(0.01, abs=1e-7) and adds == pytest.approx(0.01, abs=1e-7)
+    # a symmetry of the cube: ADD sees the rotation, ADD-S does not
+    add, adds = body.errors(pose(rot((0, 0, 1), np.pi / 2)), pose())
+    assert add == pytest.approx(0.05 * 2.0, abs=1e-6) and adds == pytest.approx(0.0, abs=1e-6)
+    r = body.result(pose(t=(0.0123, 0, 0)), pose())
+    assert r["add_auc"] == pytest.approx(1.0 - 0.123, abs=1e-5)  # 1 - min(e / 0.1, 1) :846-847
+    assert r["add_curve"].tolist() == [0.0] * 12 + [1.0] * 88    # thresholds 0.0005 … 0.0115 lie below the error
+    assert body.result(pose(t=(0.5, 0, 0)), pose())["adds_auc"] == 0.0
+    # the body2world pose enters inverted: identical non-trivial poses give zero error
+    p = pose(rot((1, 1, 0), 0.7), (0.3, -0.2, 0.9))
+    assert body.errors(p, p) == (pytest.approx(0.0, abs=1e-6), pytest.approx(0.0, abs=1e-6))
+
+
+def test_ycb_reduced_vertices_and_pose_file(tmp_path):
+    v = np.arange(3000, dtype=np.float32).reshape(1000, 3)
+    assert ev.reduce_vertices(v, -1) is not None and len(ev.reduce_vertices(v, 0)) == 1000
+    assert len(ev.reduce_vertices(v, 1000)) == 1000
+    r = ev.reduce_vertices(v, 5)
+    # std::mt19937{7}: 327741615, 976413892, 3349725721, 1369975286, 1882953283 (mod 1000)
+    assert (r[:, 0] / 3).astype(int).tolist() == [615, 892, 721, 286, 283]
+    path = tmp_path / "002_master_chef_can.txt"
+    q = np.array([0.5, 0.5, 0.5, 0.5])
+    with open(path, "w") as f:
+        for i in range(12):
+            f.write("%g %g %g %g %g %g %g\n" % (*(2 * q), 0.1 * i, 0.0, 1.0))  # unnormalised on purpose
+    poses = ev.read_poses_ycb(str(path), pose_begin=2, n_frames=8, keyframes=[1, 4, 8])
+    assert poses.shape == (3, 4, 4)
+    assert np.allclose(poses[:, 0, 3], [0.2, 0.5, 0.9], atol=1e-6)  # lines 2 + {1, 4, 8} - 1
+    assert np.allclose(poses[0, :3, :3], [[0, 0, 1], [1, 0, 0], [0, 1, 0]], atol=1e-6)  # q = (1,1,1,1)/2
+
+
+def test_rbot_loop_resets_a_lost_body():
+    """EvaluateRunConfiguration :174-210 on a synthetic sequence: one frame whose ground truth lies 20 cm off
+    counts as lost, the body is reset to that ground truth, is lost again on the next (honest) frame because it
+    now starts 20 cm off, is reset once more and tracks from there on"""
+    api = util.open_oracle()
+    n_frames = 6
+    inputs = scenes.Inputs(1, n_frames + 1)
+    inst = scenes.Instance(api, inputs)
+    poses_gt = np.asarray(inputs.gt[0], np.float32).copy()
+    bad = 3
+    poses_gt[bad, :3, 3] += (0.2, 0.0, 0.0)
+    frames, avg = ev.evaluate_rbot_sequence(inst.tracker, inst.bodies[0], poses_gt, inst.upload_frame,
+                                            n_frames=n_frames)
+    success = [f["tracking_success"] for f in frames]
+    assert success == [1.0, 1.0, 0.0, 0.0, 1.0, 1.0]  # cycle i is judged against poses_gt[i + 1]
+    assert frames[bad - 1]["translation_error"] == pytest.approx(0.2, abs=5e-3)
+    assert avg["tracking_success"] == pytest.approx(4.0 / 6.0)
+    assert all(f["complete_cycle"] > 0 for f in frames)
+
+
+def test_ycb_loop_on_a_synthetic_sequence():
+    """EvaluateRunConfiguration :333-372: Region + Depth tracking of two bodies over four keyframes, started at
+    the ground truth of the first; ADD-S stays in the millimetre range and the AUC near 1"""
+    api = util.open_oracle()
+    keyframes = [1, 2, 4, 5]  # 1-based image numbers like the dataset's keyframe lists
+    inputs = scenes.Inputs(2, 6, with_depth=True)
+    inst = scenes.Instance(api, inputs, use_region=True, use_depth=True)
+    names = ["body0", "body1"]
+    bodies = dict(zip(names, inst.bodies))
+    evaluations = {n: ev.YCBBodyEvaluation(inputs.vertices[i], 200) for i, n in enumerate(names)}
+    gt = {n: np.asarray([inputs.gt[i][k - 1] for k in keyframes], np.float32) for i, n in enumerate(names)}
+    results, average = ev.evaluate_ycb_sequence(inst.tracker, bodies, evaluations, gt, keyframes,
+                                                lambda k: inst.upload_frame(k - 1))
+    for n in names:
+        assert len(results[n]) == len(keyframes)
+        assert max(r["adds_error"] for r in results[n]) < 5e-3
+        assert average[n]["adds_auc"] > 0.95 and average[n]["add_auc"] > 0.9
+        assert average[n]["adds_curve"][-1] == 1.0 and average[n]["adds_curve"].shape == (100,)

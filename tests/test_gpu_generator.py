@@ -1,0 +1,54 @@
+"""GenerateConfiguredTracker on the device: the reference's tracker_config.yaml end to end — meshes and
+metafiles read, both sparse viewpoint models generated on the GPU and saved, poses detected, one tracking
+step — against the golden pose of TrackerTest.OptimizePoseMatrixGeneratorSetUp (test/tracker_test.cpp:182-195)."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+from test_generator import reference_tree, run_generated_tracker
+
+pytestmark = pytest.mark.gpu
+cfg = util.pkg.config
+
+
+def test_generated_tracker_with_generated_models(tmp_path):
+    root = reference_tree(tmp_path)
+    api = util.open_hip()
+    api.call("set_summation_mode", 1)  # the reference's summation order
+    tracker = run_generated_tracker(api, root)
+    golden = util.read_golden_matrix("tracker_test/triangle_pose.txt")
+    pose = tracker.body_ptrs()[0].body2world_pose()
+    assert np.max(np.abs((pose - golden)[:3] / golden[:3])) < 1e-5  # CompareToLoadedMatrix(..., 1.0e-5f)
+
+    # the models were saved where the metafiles say, in the reference's file format, for this body
+    body = tracker.objects["Body"]["triangle"]
+    for name, region in (("triangle_region_model", True), ("triangle_depth_model", False)):
+        model = tracker.objects["RegionModel" if region else "DepthModel"][name]
+        assert model.model_path == str(tmp_path / "temp" / (name + ".bin")) and model.n_views == 2562
+        assert cfg.model_bin_matches(model.model_path, region, model.parameters, body.body_data())
+        floats = (38 if region else 36) * 200 + 4
+        assert os.path.getsize(model.model_path) > 2562 * floats * 4
+
+    # a second tracker finds them and loads instead of generating: same pose, bit for bit
+    api2 = util.open_hip()
+    api2.call("set_summation_mode", 1)
+    stamp = os.path.getmtime(tracker.objects["RegionModel"]["triangle_region_model"].model_path)
+    tracker2 = run_generated_tracker(api2, root)
+    assert os.path.getmtime(tracker2.objects["RegionModel"]["triangle_region_model"].model_path) == stamp
+    assert np.array_equal(tracker2.body_ptrs()[0].body2world_pose(), pose)
+
+
+def test_tracker_process_over_the_fixture_sequence(tmp_path):
+    """RunTrackerProcess-style loop: detect, start, then one step per loaded frame until the images run out
+    (frames 200 and 201 exist); the pose stays at the detector's within millimetres"""
+    root = reference_tree(tmp_path)
+    api = util.open_hip()
+    tracker = util.pkg.generator.GenerateConfiguredTracker(api, str(root / "tracker_test" / "tracker_config.yaml"))
+    assert tracker.RunTrackerProcess(5) is False  # not set up
+    assert tracker.SetUp()
+    assert tracker.RunTrackerProcess(5) == 2      # image 202 is missing: the process stops there
+    detector = tracker.objects["StaticDetector"]["triangle_detector"].link2world_pose
+    pose = tracker.body_ptrs()[0].body2world_pose()
+    assert np.linalg.norm(pose[:3, 3] - detector[:3, 3]) < 5e-3
