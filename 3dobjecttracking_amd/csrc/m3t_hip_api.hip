@@ -174,7 +174,8 @@ struct m3t_hip_context {
   int sequential_sum = 0;
   // device tables
   DevMem d_cams, d_region, d_depth, d_opts, d_poses, d_scratch_view;
-  bool tables_dirty = true, cams_dirty = true, poses_dirty_host = true;
+  bool tables_dirty = true, cams_dirty = true, slots_dirty = false, poses_dirty_host = true;
+  const CameraDev* cams_active = nullptr;  // the camera table version the kernels read (UploadTables)
   size_t pose_capacity = 0;
   std::vector<RigidOptDev> opt_table;
   bool fused_possible = false;
@@ -665,9 +666,9 @@ int UploadRendererTables(Ctx* ctx) {
 int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int /*largest_image_size*/) {
   if (n_which == 0) return M3T_OK;
   hipLaunchKernelGGL(focused_clear_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
-                     ctx->d_renderers.as<RendererDev>(), which, ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>());
+                     ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
   hipLaunchKernelGGL(focused_raster_kernel, dim3(32, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
-                     ctx->d_renderers.as<RendererDev>(), which, ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>());
+                     ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
   hipLaunchKernelGGL(focused_unpack_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                      ctx->d_renderers.as<RendererDev>(), which);
   HIPCHK(hipGetLastError());
@@ -694,23 +695,38 @@ int UploadTables(Ctx* ctx) {
     }
     ctx->copies_pending = 0;
   }
-  if (ctx->cams_dirty || ctx->tables_dirty) {
-    std::vector<CameraDev> cams(ctx->cameras.size());
-    for (size_t i = 0; i < cams.size(); ++i) {
-      const Camera& c = *ctx->cameras[i];
-      CameraDev& d = cams[i];
-      d.image = c.ring.as<uint8_t>() + size_t(c.current) * c.frame_bytes;
-      d.pitch = c.pitch;
-      d.width = c.intr.width;
-      d.height = c.intr.height;
-      d.fu = c.intr.fu; d.fv = c.intr.fv; d.ppu = c.intr.ppu; d.ppv = c.intr.ppv;
-      d.depth_scale = c.depth_scale;
-      std::memcpy(d.world2camera, c.world2camera, 64);
+  if (ctx->cams_dirty || ctx->tables_dirty || ctx->slots_dirty) {
+    // Camera table versions: when every camera has the same number of ring slots, version s holds all cameras
+    // looking at slot s, and a frame switch of the whole batch (m3t_hip_cameras_select_slot) only moves the
+    // table pointer the kernels receive: nothing is copied between two tracking steps.  Cameras on different
+    // slots use the extra version behind them, rebuilt and staged per switch.
+    const size_t n_cams = ctx->cameras.size();
+    int n_versions = n_cams ? ctx->cameras[0]->n_slots : 0;
+    int uniform_slot = n_cams ? ctx->cameras[0]->current : 0;
+    for (auto& c : ctx->cameras) {
+      if (c->n_slots != n_versions) n_versions = 0;
+      if (c->current != uniform_slot) uniform_slot = -1;
     }
-    const size_t bytes = cams.size() * sizeof(CameraDev);
+    if (n_versions > 64) n_versions = 0;
+    auto fill = [&](CameraDev* out, int slot /* -1: every camera's own current slot */) {
+      for (size_t i = 0; i < n_cams; ++i) {
+        const Camera& c = *ctx->cameras[i];
+        CameraDev& d = out[i];
+        d.image = c.ring.as<uint8_t>() + size_t(slot < 0 ? c.current : slot) * c.frame_bytes;
+        d.pitch = c.pitch;
+        d.width = c.intr.width;
+        d.height = c.intr.height;
+        d.fu = c.intr.fu; d.fv = c.intr.fv; d.ppu = c.intr.ppu; d.ppv = c.intr.ppv;
+        d.depth_scale = c.depth_scale;
+        std::memcpy(d.world2camera, c.world2camera, 64);
+      }
+    };
+    const size_t version_bytes = n_cams * sizeof(CameraDev);
+    const size_t bytes = version_bytes * size_t(n_versions + 1);
     if (ctx->d_cams.bytes < bytes) {
       HIPCHK(hipStreamSynchronize(ctx->stream));
       HIPCHK(ctx->d_cams.alloc(bytes * 2));
+      ctx->cams_dirty = true;
     }
     if (ctx->cam_stage_bytes < bytes) {
       HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -721,15 +737,23 @@ int UploadTables(Ctx* ctx) {
       }
       ctx->cam_stage_bytes = bytes * 2;
     }
-    if (!cams.empty()) {
-      const int slot = ctx->cam_stage_next;
-      ctx->cam_stage_next = (slot + 1) % Ctx::kStage;
-      HIPCHK(hipEventSynchronize(ctx->cam_stage_done[slot]));  // normally long complete
-      std::memcpy(ctx->cam_stage[slot], cams.data(), bytes);
-      HIPCHK(hipMemcpyAsync(ctx->d_cams.p, ctx->cam_stage[slot], bytes, hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(hipEventRecord(ctx->cam_stage_done[slot], ctx->stream));
+    const bool rebuild = ctx->cams_dirty || ctx->tables_dirty;
+    const bool custom = uniform_slot < 0 || n_versions == 0;
+    if (n_cams && (rebuild || custom)) {
+      const int stage = ctx->cam_stage_next;
+      ctx->cam_stage_next = (stage + 1) % Ctx::kStage;
+      HIPCHK(hipEventSynchronize(ctx->cam_stage_done[stage]));  // normally long complete
+      CameraDev* host = static_cast<CameraDev*>(ctx->cam_stage[stage]);
+      size_t first = rebuild ? 0 : size_t(n_versions), last = size_t(n_versions) + 1;
+      for (size_t v = first; v < last; ++v) fill(host + v * n_cams, v < size_t(n_versions) ? int(v) : -1);
+      HIPCHK(hipMemcpyAsync(ctx->d_cams.as<uint8_t>() + first * version_bytes,
+                            reinterpret_cast<uint8_t*>(host) + first * version_bytes, (last - first) * version_bytes,
+                            hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipEventRecord(ctx->cam_stage_done[stage], ctx->stream));
     }
+    ctx->cams_active = ctx->d_cams.as<CameraDev>() + (custom ? size_t(n_versions) : size_t(uniform_slot)) * n_cams;
     ctx->cams_dirty = false;
+    ctx->slots_dirty = false;
   }
   if (ctx->tables_dirty) {
     int rr = UploadRendererTables(ctx);
@@ -869,7 +893,7 @@ int LaunchHistogram(Ctx* ctx, int iteration, bool initialize) {
   if (n == 0) return M3T_OK;
   ScopedKernelTimer timer(ctx, 1);
   hipLaunchKernelGGL(region_histogram_kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_hist, ctx->stream,
-                     ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(), iteration,
+                     ctx->d_region.as<RegionModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), iteration,
                      initialize ? 1 : 0, ctx->hist_counts_in_lds ? 1 : 0);
   if (!ctx->shared_histograms.empty())  // Initialize / UpdateHistograms of the shared objects, tracker.cpp:441-443,513-515
     hipLaunchKernelGGL(shared_histogram_finish_kernel, dim3(unsigned(ctx->shared_histograms.size())),
@@ -884,13 +908,13 @@ int LaunchCorrespondences(Ctx* ctx, int iteration, int corr_iteration) {
   if (nr) {
     hipLaunchKernelGGL(ctx->layout.off_hist >= 0 ? region_correspondence_lds_kernel : region_correspondence_kernel,
                        dim3(nr), dim3(M3T_BLOCK_THREADS), ctx->lds_corr, ctx->stream,
-                       ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->d_region.as<RegionModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                        ctx->layout, iteration, corr_iteration);
     HIPCHK(hipGetLastError());
   }
   if (nd) {
     hipLaunchKernelGGL(depth_correspondence_kernel, dim3(nd), dim3(M3T_BLOCK_THREADS), ctx->lds_depth, ctx->stream,
-                       ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                        ctx->np_max, iteration, corr_iteration);
     HIPCHK(hipGetLastError());
   }
@@ -901,13 +925,13 @@ int LaunchGradientHessian(Ctx* ctx, int corr_iteration, int opt_iteration) {
   int nr = int(ctx->region_mods.size()), nd = int(ctx->depth_mods.size());
   if (nr) {
     hipLaunchKernelGGL(region_gradient_hessian_kernel, dim3(nr), dim3(M3T_BLOCK_THREADS), ctx->lds_corr, ctx->stream,
-                       ctx->d_region.as<RegionModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->d_region.as<RegionModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                        ctx->layout, corr_iteration, opt_iteration, ctx->sequential_sum);
     HIPCHK(hipGetLastError());
   }
   if (nd) {
     hipLaunchKernelGGL(depth_gradient_hessian_kernel, dim3(nd), dim3(M3T_BLOCK_THREADS), ctx->lds_depth, ctx->stream,
-                       ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                        ctx->np_max, corr_iteration, ctx->sequential_sum);
     HIPCHK(hipGetLastError());
   }
@@ -1231,7 +1255,7 @@ int m3t_hip_camera_select_slot(m3t_hip_context* ctx, int id, int slot) {
   REQUIRE(slot >= 0 && slot < c.n_slots, M3T_ERR_INVALID_ARGUMENT, "bad frame slot");
   if (c.current != slot) {
     c.current = slot;
-    ctx->cams_dirty = true;
+    ctx->slots_dirty = true;
   }
   return M3T_OK;
 }
@@ -2311,7 +2335,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     const size_t lds = histogram_fused ? std::max(ctx->lds_track, ctx->lds_hist) : ctx->lds_track;
     hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), lds, ctx->stream,
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
-                       ctx->d_depth.as<DepthModDev>(), ctx->d_cams.as<CameraDev>(), ctx->d_poses.as<float>(),
+                       ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                        ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
                        ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, ctx->sequential_sum,
                        histogram_fused ? 1 : 0);
