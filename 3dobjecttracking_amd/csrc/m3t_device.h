@@ -178,5 +178,6 @@ struct TrackLdsLayout {
 #define M3T_BLOCK_THREADS 512
 #endif
 #define M3T_MISC_FLOATS 1024
+#define M3T_SPLIT_PARTS 4  /* workgroups per object in tracking_step_split_kernel */
 
 #endif  // M3T_DEVICE_H_

@@ -180,6 +180,12 @@ struct m3t_hip_context {
   std::vector<RigidOptDev> opt_table;
   bool fused_possible = false;
   bool fuse_histogram_possible = false;  // ... and the histogram update can ride in the same launch
+  // several workgroups per object (tracking_step_split_kernel) for batches that leave most CUs idle
+  bool split_possible = false;
+  DevMem d_split;            // [objects][2 rounds][M3T_SPLIT_PARTS][32] granules, then the timeout word
+  size_t split_objects = 0;  // capacity of d_split
+  unsigned split_seq = 0;    // launch counter inside the granule tags
+  bool split_check_pending = false;
   bool state_valid = false;  // line/point state + g/H on the device reflect the last step
   TrackLdsLayout layout{};
   int np_max = 0, off_points = 0;
@@ -376,13 +382,29 @@ int UploadFrame(Ctx* ctx, int id, int slot, const void* pixels, size_t row_step)
 }
 
 // ---- device tables -----------------------------------------------------------
+// After a synchronisation: did the workgroups of a split object ever give up waiting for each other?  (They
+// are all resident by construction; the bounded wait exists so that a surprise cannot hang the device.)
+int CheckSplitExchange(Ctx* ctx) {
+  if (!ctx->split_check_pending) return M3T_OK;
+  ctx->split_check_pending = false;
+  unsigned* flag = reinterpret_cast<unsigned*>(ctx->d_split.as<unsigned long long>() +
+                                               ctx->split_objects * (2 * M3T_SPLIT_PARTS * 32));
+  unsigned value = 0;
+  HIPCHK(hipMemcpy(&value, flag, sizeof(value), hipMemcpyDeviceToHost));
+  if (value) {
+    HIPCHK(hipMemset(flag, 0, sizeof(value)));
+    return Fail(ctx, M3T_ERR_DEVICE, "tracking_step_split_kernel: a workgroup waited in vain for its object's other "
+                                     "workgroups; the poses of this step are invalid (M3T_HIP_NO_SPLIT=1 avoids the kernel)");
+  }
+  return M3T_OK;
+}
 int SyncPosesToHost(Ctx* ctx) {
   // device is authoritative after any device-side optimisation
   size_t n = ctx->body_poses.size() / 16;
   if (n == 0 || ctx->poses_dirty_host) return M3T_OK;
   HIPCHK(hipMemcpyAsync(ctx->body_poses.data(), ctx->d_poses.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  return M3T_OK;
+  return CheckSplitExchange(ctx);
 }
 
 void ComputeLayout(Ctx* ctx) {
@@ -818,6 +840,15 @@ int UploadTables(Ctx* ctx) {
     REQUIRE(max_lds <= 160 * 1024, M3T_ERR_UNSUPPORTED,
             "per-object working set exceeds the 160 KB LDS of a CU");
     if (!ctx->hist_counts_in_lds) ctx->fuse_histogram_possible = false;
+    // the split kernel: free rigid bodies with one region modality each, pair table read from L2
+    ctx->split_possible = ctx->fused_possible && ctx->depth_mods.empty() && !ctx->region_mods.empty() &&
+                          ctx->layout.off_hist < 0;
+    for (auto& o : ctx->opt_table)
+      if (o.region_modality < 0 || o.depth_modality >= 0) ctx->split_possible = false;
+    for (auto& m : ctx->region_mods)
+      if (m->shared_histograms >= 0) ctx->split_possible = false;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_split_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_lds_kernel),
@@ -1337,7 +1368,7 @@ int m3t_hip_region_modality_create(m3t_hip_context* ctx, const m3t_region_modali
   REQUIRE(p->function_length >= 1 && p->function_length <= M3T_MAX_FUNCTION_LENGTH && p->distribution_length >= 2 &&
               p->distribution_length <= M3T_MAX_DISTRIBUTION_LENGTH && p->n_scales >= 1 &&
               p->n_scales <= M3T_MAX_SCALES && p->n_standard_deviations >= 1 &&
-              p->n_standard_deviations <= M3T_MAX_SCALES && p->n_lines_max >= 1,
+              p->n_standard_deviations <= M3T_MAX_SCALES && p->n_lines_max >= 1 && p->n_lines_max <= 1024,
           M3T_ERR_INVALID_ARGUMENT, "bad region modality parameters");
   int bitshift;
   switch (p->n_histogram_bins) {  // color_histograms.cpp:131-158
@@ -2333,6 +2364,33 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // would not fit twice, so large batches keep the separate region_histogram_kernel.
     histogram_fused = ctx->fuse_histogram_possible && threads == M3T_BLOCK_THREADS && !std::getenv("M3T_HIP_NO_FUSED_HISTOGRAM");
     const size_t lds = histogram_fused ? std::max(ctx->lds_track, ctx->lds_hist) : ctx->lds_track;
+    // Up to a quarter of the CUs busy: M3T_SPLIT_PARTS workgroups per object, each on its own CU (all resident at
+    // once, which their in-kernel exchange needs).  Not in the reference-summation-order mode: the partial sums
+    // of the workgroups are added per workgroup first.
+    const bool split = ctx->split_possible && threads == M3T_BLOCK_THREADS && !ctx->sequential_sum &&
+                       n * M3T_SPLIT_PARTS <= ctx->prop.multiProcessorCount &&
+                       ctx->n_corr_iterations * ctx->n_update_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT");
+    if (split) {
+      const size_t granules = size_t(2) * M3T_SPLIT_PARTS * 32;
+      if (ctx->split_objects < size_t(n) || ctx->split_seq >= (1u << 26) - 1) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->split_objects < size_t(n)) {
+          HIPCHK(ctx->d_split.alloc((size_t(n) * granules + 1) * sizeof(unsigned long long)));
+          ctx->split_objects = size_t(n);
+        }
+        HIPCHK(hipMemset(ctx->d_split.p, 0, (ctx->split_objects * granules + 1) * sizeof(unsigned long long)));
+        ctx->split_seq = 0;
+      }
+      ++ctx->split_seq;
+      unsigned long long* g = ctx->d_split.as<unsigned long long>();
+      hipLaunchKernelGGL(tracking_step_split_kernel, dim3(n * M3T_SPLIT_PARTS), dim3(threads), lds, ctx->stream,
+                         ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                         ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
+                         ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
+                         ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, g,
+                         reinterpret_cast<unsigned*>(g + ctx->split_objects * granules), ctx->split_seq);
+      ctx->split_check_pending = true;
+    } else
     hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), lds, ctx->stream,
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                        ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
@@ -2439,7 +2497,7 @@ int m3t_hip_sync(m3t_hip_context* ctx) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  return M3T_OK;
+  return CheckSplitExchange(ctx);
 }
 
 }  // extern "C"

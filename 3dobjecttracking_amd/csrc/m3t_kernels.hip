@@ -498,15 +498,16 @@ __device__ __forceinline__ void chain_fill(float* chain, float x, float step, in
 
 template <int SCALE, typename HistPtr>
 __device__ __forceinline__ void region_segments(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist,
-                                                int n_lines, int valid_mask, const Lds& s) {
+                                                int n_lines, int valid_mask, const Lds& s, int line_lo) {
   constexpr int B = SCALE >= 8 ? 2 : (SCALE >= 6 ? 3 : (SCALE >= 4 ? 4 : (SCALE == 3 ? 6 : 8)));  // <= 20 pixels in flight
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
   const int bin_bits = 8 - m.bitshift;  // n_bins == 1 << bin_bits
   const int bitshift = m.bitshift;
-  const int n_items = n_lines * n_seg;
+  const int n_items = (n_lines - line_lo) * n_seg;  // lines [line_lo, n_lines)
   // (line, segment) of item = tid, advanced by nt per step without divisions
   const int q = nt / n_seg, r = nt - q * n_seg;
   int line0 = tid / n_seg, sw0 = tid - line0 * n_seg;
+  line0 += line_lo;
   for (int base = tid; base < n_items; base += nt * B) {
     PHASE_T0();
     uint32_t px[B][SCALE];
@@ -607,13 +608,14 @@ __device__ __forceinline__ void region_segments(CRegion& m, G<uint8_t> image, ui
 // any scale (not unrolled); same arithmetic
 template <typename HistPtr>
 __device__ void region_segments_generic(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist, int n_lines,
-                                        int valid_mask, int scale, const Lds& s) {
+                                        int valid_mask, int scale, const Lds& s, int line_lo) {
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = m.n_bins * m.n_bins;
-  const int n_items = n_lines * n_seg;
+  const int n_items = (n_lines - line_lo) * n_seg;
   for (int item = tid; item < n_items; item += nt) {
     int line = item / n_seg;
     int sw = item - line * n_seg;
+    line += line_lo;
     int flags = f2i_bits(s.state[LS_VALID * nl + line]);
     if (!(flags & valid_mask)) continue;
     int start = f2i_bits(s.state[LS_WALK_START * nl + line]);
@@ -649,18 +651,19 @@ __device__ void region_segments_generic(CRegion& m, G<uint8_t> image, uint32_t p
 
 template <typename HistPtr>
 __device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist,
-                                                         int scale, int n_lines, int valid_mask, const Lds& s) {
+                                                         int scale, int n_lines, int valid_mask, const Lds& s,
+                                                         int line_lo) {
   switch (scale) {
-    case 1: region_segments<1>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 2: region_segments<2>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 3: region_segments<3>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 4: region_segments<4>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 5: region_segments<5>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 6: region_segments<6>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 7: region_segments<7>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 8: region_segments<8>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    case 9: region_segments<9>(m, image, pitch, hist, n_lines, valid_mask, s); break;
-    default: region_segments_generic(m, image, pitch, hist, n_lines, valid_mask, scale, s); break;
+    case 1: region_segments<1>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 2: region_segments<2>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 3: region_segments<3>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 4: region_segments<4>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 5: region_segments<5>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 6: region_segments<6>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 7: region_segments<7>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 8: region_segments<8>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 9: region_segments<9>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    default: region_segments_generic(m, image, pitch, hist, n_lines, valid_mask, scale, s, line_lo); break;
   }
 }
 
@@ -677,7 +680,7 @@ __device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> 
 template <bool HIST_LDS>
 __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                        const Affine& b2dc, int iteration, int corr_iteration,
-                                                       const Lds& s) {
+                                                       const Lds& s, int line_lo = 0, int line_hi = 1 << 30) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const RegionIter it = region_iter(m, corr_iteration);
   const int nl = s.nl;
@@ -821,10 +824,14 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   const int valid_mask = use_occ ? 1 : 2;
 
   // ---- phase B ----
+  // a workgroup that shares its object with others (tracking_step_split_kernel) walks only the lines
+  // [line_lo, line_hi) from here on; phase A above ran for all lines (its two-pass vote needs them)
+  const int n_lines_b = n_lines < line_hi ? n_lines : line_hi;
+  const int nl_b = nl < line_hi ? nl : line_hi;
   if (HIST_LDS) {  // pair table staged in LDS (n_bins <= 16)
-    region_segments_dispatch(m, image, pitch, (LdsF)s.hist, it.scale, n_lines, valid_mask, s);
+    region_segments_dispatch(m, image, pitch, (LdsF)s.hist, it.scale, n_lines_b, valid_mask, s, line_lo);
   } else {         // pair table gathered from L2 / HBM
-    region_segments_dispatch(m, image, pitch, (G<v2f>)m.histogram_norm, it.scale, n_lines, valid_mask, s);
+    region_segments_dispatch(m, image, pitch, (G<v2f>)m.histogram_norm, it.scale, n_lines_b, valid_mask, s, line_lo);
   }
   __syncthreads();
   PHASE_MARK(2);
@@ -838,11 +845,13 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
     // (line, d) of item = tid, advanced by nt per step without divisions
     const int q = nt / dl, r = nt - q * dl;
     int line = tid / dl, d = tid - line * dl;
+    line += line_lo;
+    const int n_items_c = (n_lines_b - line_lo) * dl;
     if (fl == 8) {  // default function_length: lookups as uniform scalars, independent LDS reads, ordered product
       float lfr[8], lbr[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) { lfr[k] = m.function_lookup_f[k]; lbr[k] = m.function_lookup_b[k]; }
-      for (int item = tid; item < n_lines * dl; item += nt) {
+      for (int item = tid; item < n_items_c; item += nt) {
         int flags = f2i_bits(s.state[LS_VALID * nl + line]);
         if (flags & valid_mask) {
           const float* sf = s.seg_f + line * s.ns + d;
@@ -860,7 +869,7 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
         if (d >= dl) { d -= dl; ++line; }
       }
     } else {
-      for (int item = tid; item < n_lines * dl; item += nt) {
+      for (int item = tid; item < n_items_c; item += nt) {
         int flags = f2i_bits(s.state[LS_VALID * nl + line]);
         if (flags & valid_mask) {
           const float* sf = s.seg_f + line * s.ns + d;
@@ -878,7 +887,7 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   __syncthreads();
   PHASE_MARK(3);
   // ---- phase C2: normalisation + moments, one thread per line ----
-  for (int line = tid; line < nl; line += nt) {
+  for (int line = line_lo + tid; line < nl_b; line += nt) {
     int flags = f2i_bits(s.state[LS_VALID * nl + line]);
     bool valid = (flags & valid_mask) != 0;
     if (valid) {
@@ -950,21 +959,69 @@ __device__ void block_reduce(float (&v)[N], int n_active_waves, float* scratch, 
 }
 
 // ---------------------------------------------------------------------------
+// Sum of the 27 partial g/H sums of the workgroups that share one object (tracking_step_split_kernel).
+// Each workgroup publishes its sums as 8-byte {tag, value} granules with one write-through store each and
+// re-reads the others' granules until every tag matches: the data is the flag, no fence (the hand-off form of
+// cdna_hip_programming.md, guideline 16, R2).  Slots alternate with the round: a workgroup can only be one
+// round ahead of another, because it cannot leave a round before it has read everybody's granules of it.
+// Every workgroup adds the parts in the same order and so continues with bit-identical sums.
+// ---------------------------------------------------------------------------
+struct SplitExchange {
+  __attribute__((address_space(1))) unsigned long long* granules;  // [2 rounds][M3T_SPLIT_PARTS][32]
+  __attribute__((address_space(1))) unsigned* timeout;             // set when a wait gave up
+  uint32_t tag;   // > 0, unique per (launch, round)
+  int part, round;
+};
+__device__ void split_exchange_sums(float* red /*LDS, 27 in / out*/, float* scratch /*LDS, 4 * 32*/,
+                                    const SplitExchange& x) {
+  const int tid = threadIdx.x;
+  if (tid < 27) {
+    unsigned long long g = (static_cast<unsigned long long>(x.tag) << 32) | (unsigned)__float_as_int(red[tid]);
+    __hip_atomic_store(x.granules + ((x.round & 1) * M3T_SPLIT_PARTS + x.part) * 32 + tid, g, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < M3T_SPLIT_PARTS * 32) {
+    const int p = tid >> 5, e = tid & 31;
+    bool done = e >= 27;
+    unsigned long long g = 0;
+    for (unsigned spins = 0; !__all(done); ++spins) {  // wave-uniform loop; bounded: never hangs the device
+      if (!done) {
+        g = __hip_atomic_load(x.granules + ((x.round & 1) * M3T_SPLIT_PARTS + p) * 32 + e, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
+        done = static_cast<uint32_t>(g >> 32) == x.tag;
+      }
+      if (spins > (1u << 18)) {  // ~0.3 s
+        if (!done) __hip_atomic_store(x.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (e < 27) scratch[p * 32 + e] = __int_as_float(static_cast<int>(static_cast<uint32_t>(g)));
+  }
+  __syncthreads();
+  if (tid < 27) {
+    float sum = scratch[tid];
+#pragma unroll
+    for (int p = 1; p < M3T_SPLIT_PARTS; ++p) sum += scratch[p * 32 + tid];
+    red[tid] = sum;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
 // RegionModality::CalculateGradientAndHessian (:485-558), whole block.
 // Result: gh[0..5] gradient, gh[6..41] column-major symmetric hessian (LDS or global).
 // ---------------------------------------------------------------------------
 __device__ void region_gradient_hessian(CRegion& m, CCam& cam, const Affine& b2c,
                                         int corr_iteration, int opt_iteration, const Lds& s, float* gh_out,
-                                        bool sequential_sum) {
+                                        bool sequential_sum, int split_part = -1,
+                                        const SplitExchange* exchange = nullptr) {
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
   const RegionIter it = region_iter(m, corr_iteration);
-  float acc[27];
-#pragma unroll
-  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
-  for (int line = tid; line < nl; line += nt) {
-    if (sequential_sum) s.chain[line * 9 + 8] = 0.0f;
+  // One line's terms: false when the line does not contribute (:497-513)
+  auto line_terms = [&](int line, float (&J)[6], float& wg, float& wh) -> bool {
     int flags = f2i_bits(s.state[LS_VALID * nl + line]);
-    if (!(flags & 1)) continue;
+    if (!(flags & 1)) return false;
     float cx = s.state[LS_CX * nl + line], cy = s.state[LS_CY * nl + line], cz = s.state[LS_CZ * nl + line];
     float x, y, z;
     apply_pose(b2c, cx, cy, cz, x, y, z);
@@ -985,7 +1042,7 @@ __device__ void region_gradient_hessian(CRegion& m, CCam& cam, const Affine& b2c
     } else {
       int upper = f2i(delta_cs + m.distribution_length_plus_1_half);
       int lower = upper - 1;
-      if (upper <= 0 || upper >= m.distribution_length) continue;
+      if (upper <= 0 || upper >= m.distribution_length) return false;
       // std::log(float): correctly rounded through f64 on both sides of the parity check
       dll = ((float)log((double)s.state[(LS_DIST0 + upper) * nl + line]) -
              (float)log((double)s.state[(LS_DIST0 + lower) * nl + line])) *
@@ -994,7 +1051,6 @@ __device__ void region_gradient_hessian(CRegion& m, CCam& cam, const Affine& b2c
     float dc0 = ncts * normal_u * fu_z;
     float dc1 = ncts * normal_v * fv_z;
     float dc2 = ncts * (-normal_u * xfu_z - normal_v * yfv_z) / z;
-    float J[6];
     // RowVector3f * Matrix3f (body2camera_rotation_)
     float t0 = (dc0 * b2c.l[0] + dc1 * b2c.l[1]) + dc2 * b2c.l[2];
     float t1 = (dc0 * b2c.l[3] + dc1 * b2c.l[4]) + dc2 * b2c.l[5];
@@ -1006,29 +1062,25 @@ __device__ void region_gradient_hessian(CRegion& m, CCam& cam, const Affine& b2c
     J[4] = t1;
     J[5] = t2;
     float weight = m.min_expected_variance / (ncts * ncts * it.variance);
-    float wg = weight * dll;
-    float wh = weight / measured_variance;
-    if (sequential_sum) {  // stage the per-line terms; summed below in line order
+    wg = weight * dll;
+    wh = weight / measured_variance;
+    return true;
+  };
+  float* red = s.misc + kMiscRed;
+  if (sequential_sum) {
+    // parity mode: the reference's summation order (line by line, f32), 27 lanes in one wave.
+    // s.chain must hold 9 * nl floats (nl * ns >= 9 * nl since ns >= 9 is enforced on the host).
+    for (int line = tid; line < nl; line += nt) {
+      float J[6], wg, wh;
       float* st = s.chain + line * 9;
+      st[8] = 0.0f;
+      if (!line_terms(line, J, wg, wh)) continue;
 #pragma unroll
       for (int r = 0; r < 6; ++r) st[r] = J[r];
       st[6] = wg;
       st[7] = wh;
       st[8] = 1.0f;
-      continue;
     }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) acc[r] += wg * J[r];
-    int k = 6;
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-#pragma unroll
-      for (int r = c; r < 6; ++r) acc[k++] -= (wh * J[r]) * J[c];
-  }
-  float* red = s.misc + kMiscRed;
-  if (sequential_sum) {
-    // parity mode: the reference's summation order (line by line, f32), 27 lanes in one wave.
-    // s.chain must hold 9 * nl floats (nl * ns >= 9 * nl since ns >= 9 is enforced on the host).
     __syncthreads();
     if (tid < 27) {
       int r, c;
@@ -1050,8 +1102,71 @@ __device__ void region_gradient_hessian(CRegion& m, CCam& cam, const Affine& b2c
     }
     __syncthreads();
   } else {
-    block_reduce<27>(acc, (nl + kWave - 1) / kWave, s.misc + kMiscPartials, red);
+    // Default order, the same for every launch shape: the lines form M3T_SPLIT_PARTS contiguous parts of
+    // ceil(nl / parts) lines; a part is cut into runs of 64 lines, each summed by one wave with the DPP tree;
+    // the runs of a part are added in order, then the parts in order.  A workgroup that shares its object with
+    // others (split_part >= 0) sums its own part, split_exchange_sums() adds the parts: bit-identical.
+    const int lane = tid % kWave, wave = tid / kWave, n_waves = nt / kWave;
+    const int per_part = (nl + M3T_SPLIT_PARTS - 1) / M3T_SPLIT_PARTS;
+    const int runs_per_part = (per_part + kWave - 1) / kWave;
+    const int part_begin = split_part >= 0 ? split_part : 0;
+    const int part_end = split_part >= 0 ? split_part + 1 : M3T_SPLIT_PARTS;
+    float* partials = s.misc + kMiscPartials;  // [run][27]; the host keeps parts * runs_per_part * 27 within it
+    // run r (counted from this workgroup's first) belongs to wave r mod n_waves (a power of two)
+    const int n_runs = (part_end - part_begin) * runs_per_part;
+    int part = part_begin, k = 0;  // (part, k) of run r, advanced without divisions
+    for (int r = 0; r < n_runs; ++r) {
+      const int run = part * runs_per_part + k;
+      const int index = k * kWave + lane;
+      const int line = part * per_part + index;
+      const bool mine = (r & (n_waves - 1)) == wave;
+      if (++k == runs_per_part) { k = 0; ++part; }
+      if (!mine) continue;
+      float acc[27];
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+      float J[6], wg, wh;
+      if (index < per_part && line < nl && line_terms(line, J, wg, wh)) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[r] += wg * J[r];
+        int k = 6;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+          for (int r = c; r < 6; ++r) acc[k++] -= (wh * J[r]) * J[c];
+      }
+      // level by level over all 27 values: independent DPP adds per level fill the DPP wait states
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x111, 0xf>(acc[i]);
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x112, 0xf>(acc[i]);
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x114, 0xf>(acc[i]);
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x118, 0xf>(acc[i]);
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x142, 0xa>(acc[i]);
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x143, 0xc>(acc[i]);
+      if (lane == kWave - 1) {
+#pragma unroll
+        for (int i = 0; i < 27; ++i) partials[run * 27 + i] = acc[i];
+      }
+    }
+    __syncthreads();
+    if (tid < 27) {
+      float total = 0.0f;
+      const float* run_sums = partials + part_begin * runs_per_part * 27 + tid;
+      for (int part = part_begin; part < part_end; ++part) {
+        float x = 0.0f;
+        for (int k = 0; k < runs_per_part; ++k, run_sums += 27) x += *run_sums;
+        total = part == part_begin ? x : total + x;
+      }
+      red[tid] = total;
+    }
+    __syncthreads();
   }
+  if (exchange) split_exchange_sums(red, s.misc + kMiscPartials, *exchange);
   if (tid < 6) gh_out[tid] = red[tid];
   if (tid < 36) {
     int c = tid / 6, r = tid % 6;
@@ -2049,13 +2164,30 @@ __global__ void rigid_optimize_kernel(const RigidOptDev* opts, int n_opts, const
 // Everything between the image/model gathers and the final pose stays in LDS.
 // ---------------------------------------------------------------------------
 extern "C++" {
-template <bool HIST_LDS>
+template <bool HIST_LDS, bool SPLIT = false>
 __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int sequential_sum, int fuse_histogram) {
+                     int sequential_sum, int fuse_histogram, unsigned long long* split_granules = nullptr,
+                     unsigned* split_timeout = nullptr, uint32_t split_seq = 0) {
   extern __shared__ __attribute__((aligned(16))) float lds_t[];
-  COpt& o = *(COpt*)(opts + blockIdx.x);
+  // SPLIT: M3T_SPLIT_PARTS workgroups (on as many CUs) share one object.  Each runs the whole step, but walks
+  // the pixels and sums g/H for its quarter of the correspondence lines only; the partial sums are exchanged
+  // before every solve (split_exchange_sums), every workgroup solves redundantly and so holds the same pose.
+  // With a multiple of 8 objects the workgroups of one object sit on one XCD (block b runs on XCD b % 8).
+  int object = blockIdx.x, part = 0;
+  if constexpr (SPLIT) {
+    const int b = blockIdx.x, n_objects = gridDim.x / M3T_SPLIT_PARTS;
+    if ((n_objects & 7) == 0) {
+      const int j = b >> 3;
+      object = (j / M3T_SPLIT_PARTS) * 8 + (b & 7);
+      part = j % M3T_SPLIT_PARTS;
+    } else {
+      object = b / M3T_SPLIT_PARTS;
+      part = b % M3T_SPLIT_PARTS;
+    }
+  }
+  COpt& o = *(COpt*)(opts + object);
   CRegion* rm = o.region_modality >= 0 ? (CRegion*)(rmods + o.region_modality) : nullptr;
   CDepth* dm = o.depth_modality >= 0 ? (CDepth*)(dmods + o.depth_modality) : nullptr;
   Lds s = carve(lds_t, layout);
@@ -2069,6 +2201,17 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
   CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
   CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
+  int line_lo = 0, line_hi = 1 << 30;
+  SplitExchange exchange{};
+  if constexpr (SPLIT) {
+    const int per_part = (s.nl + M3T_SPLIT_PARTS - 1) / M3T_SPLIT_PARTS;
+    line_lo = part * per_part;
+    line_hi = line_lo + per_part;
+    exchange.granules = (__attribute__((address_space(1))) unsigned long long*)split_granules +
+                        (size_t)object * (2 * M3T_SPLIT_PARTS * 32);
+    exchange.timeout = (__attribute__((address_space(1))) unsigned*)split_timeout;
+    exchange.part = part;
+  }
   for (int c = 0; c < n_corr_iterations; ++c) {
     {
       const Affine b2w = load_pose(pose);
@@ -2076,7 +2219,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_correspondences<HIST_LDS>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s);
+        region_correspondences<HIST_LDS>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, line_lo, line_hi);
       }
       if (dm) {
         PHASE_T0();
@@ -2090,7 +2233,13 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       const Affine b2w = load_pose(pose);
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
-        region_gradient_hessian(*rm, *cam, b2c, c, u, s, gh_region, sequential_sum != 0);
+        if constexpr (SPLIT) {
+          exchange.round = c * n_update_iterations + u;
+          exchange.tag = split_seq * 64u + (uint32_t)exchange.round + 1u;
+          region_gradient_hessian(*rm, *cam, b2c, c, u, s, gh_region, false, part, &exchange);
+        } else {
+          region_gradient_hessian(*rm, *cam, b2c, c, u, s, gh_region, sequential_sum != 0);
+        }
       }
       if (dm) {
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
@@ -2119,14 +2268,16 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       PHASE_MARK(6);
     }
   }
-  if (threadIdx.x < 16) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
+  // (every workgroup of a split object holds the same pose: the first one writes it; no other workgroup can
+  // still be waiting to read the old one, it had to publish its first sums before this one got here)
+  if (threadIdx.x < 16 && part == 0) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
   if (write_state) {
     if (rm) {
       for (int i = threadIdx.x; i < LS_FIELDS * rm->n_lines_max; i += blockDim.x) {
         int f = i / rm->n_lines_max, l = i - f * rm->n_lines_max;
-        rm->line_state[i] = s.state[f * s.nl + l];
+        if (l >= line_lo && l < line_hi) rm->line_state[i] = s.state[f * s.nl + l];
       }
-      if (threadIdx.x < 42) rm->gradient_hessian[threadIdx.x] = gh_region[threadIdx.x];
+      if (threadIdx.x < 42 && part == 0) rm->gradient_hessian[threadIdx.x] = gh_region[threadIdx.x];
     }
     if (dm) {
       for (int i = threadIdx.x; i < PS_FIELDS * dm->n_points_max; i += blockDim.x) {
@@ -2136,7 +2287,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       if (threadIdx.x < 42) dm->gradient_hessian[threadIdx.x] = gh_depth[threadIdx.x];
     }
   }
-  if (fuse_histogram && rm) {
+  if (fuse_histogram && rm && part == 0) {
     // RegionModality::CalculateResults :572-583 in the same launch: the packed count table takes over the LDS
     // of the line buffers (misc block first, as in region_histogram_kernel)
     const Affine b2w = load_pose(pose);
@@ -2166,6 +2317,17 @@ tracking_step_lds_kernel(const RigidOptDev* opts, const RegionModDev* rmods, con
                      int sequential_sum, int fuse_histogram) {
   tracking_step_body<true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
                             n_update_iterations, write_state, sequential_sum, fuse_histogram);
+}
+// M3T_SPLIT_PARTS workgroups per object (region modality only): for batches that leave most CUs idle
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_split_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int fuse_histogram, unsigned long long* split_granules, unsigned* split_timeout,
+                     unsigned split_seq) {
+  tracking_step_body<false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
+                                  n_corr_iterations, n_update_iterations, write_state, 0, fuse_histogram,
+                                  split_granules, split_timeout, split_seq);
 }
 
 }  // extern "C"
