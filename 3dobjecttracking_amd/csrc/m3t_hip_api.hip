@@ -2383,7 +2383,11 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       }
       ++ctx->split_seq;
       unsigned long long* g = ctx->d_split.as<unsigned long long>();
-      hipLaunchKernelGGL(tracking_step_split_kernel, dim3(n * M3T_SPLIT_PARTS), dim3(threads), lds, ctx->stream,
+      // (each workgroup counts a quarter of the histogram bins: a quarter of the count table)
+      const size_t lds_split = histogram_fused
+          ? std::max(ctx->lds_track, M3T_MISC_FLOATS * 4 + (ctx->lds_hist - M3T_MISC_FLOATS * 4) / M3T_SPLIT_PARTS)
+          : ctx->lds_track;
+      hipLaunchKernelGGL(tracking_step_split_kernel, dim3(n * M3T_SPLIT_PARTS), dim3(threads), lds_split, ctx->stream,
                          ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                          ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                          ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,

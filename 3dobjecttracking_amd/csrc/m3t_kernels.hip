@@ -1754,11 +1754,18 @@ __device__ __forceinline__ void count_add(__attribute__((address_space(1))) unsi
 template <bool SHARED = false, typename CountPtr>
 __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                         const Affine& b2dc, bool handle_occlusions, bool initialize,
-                                                        CountPtr counts, float* misc) {
+                                                        CountPtr counts, float* misc, int bin_lo = 0,
+                                                        int bin_hi = -1) {
+  // [bin_lo, bin_hi): the bins this workgroup counts and blends (all of them unless it shares its object with
+  // others: then every workgroup walks all lines, keeps the samples that fall into its bins, and no table
+  // has to be merged); counts[0] is bin_lo's word
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n_bins3 = m.n_bins * m.n_bins * m.n_bins;
+  if (bin_hi < 0) bin_hi = n_bins3;
+  const uint32_t n_own_bins = (uint32_t)(bin_hi - bin_lo);
   if (!SHARED)
-    for (int i = tid; i < n_bins3; i += nt) counts[i] = 0;
+    for (int i = tid; i < (int)n_own_bins; i += nt) counts[i] = 0;
+  unsigned sf = 0, sb = 0;  // this thread's foreground / background samples (all bins)
   const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
   const int n_lines = number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length,
                                       as_global(m.extents), view, m.max_extent, m.n_points);
@@ -1859,22 +1866,18 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     for (int k = 0; k < n_valid; ++k) {
       uint32_t off = __umul24((uint32_t)f2i(v), cam.pitch) + (uint32_t)f2i(u) * 3u;
       uint32_t px = reinterpret_cast<G<PackedU32>>(image + off)->v;
-      count_add(&counts[((px & 0xffu) >> bitshift) * n_bins2 + (((px >> 8) & 0xffu) >> bitshift) * n_bins +
-                        (((px >> 16) & 0xffu) >> bitshift)],
-                inc);
+      const uint32_t bin = ((px & 0xffu) >> bitshift) * n_bins2 + (((px >> 8) & 0xffu) >> bitshift) * n_bins +
+                           (((px >> 16) & 0xffu) >> bitshift) - (uint32_t)bin_lo;
+      if (SHARED || bin < n_own_bins) count_add(&counts[bin], inc);
       u += du;
       v += dv;
     }
+    if (background) sb += (unsigned)n_valid;
+    else sf += (unsigned)n_valid;
   }
   if constexpr (!SHARED) {
   __syncthreads();
-  // sums (exact: integer counts)
-  unsigned sf = 0, sb = 0;
-  for (int i = tid; i < n_bins3; i += nt) {
-    uint32_t c = counts[i];
-    sf += c & 0xffffu;
-    sb += c >> 16;
-  }
+  // sums of the count tables = numbers of samples (exact: integers)
   sf = (unsigned)wave_sum_i((int)sf);
   sb = (unsigned)wave_sum_i((int)sb);
   unsigned* umisc = reinterpret_cast<unsigned*>(misc);
@@ -1892,9 +1895,10 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
   GW<v4f> hist_f4 = (GW<v4f>)m.histogram_f;
   GW<v4f> hist_b4 = (GW<v4f>)m.histogram_b;
   GW<v4f> norm4 = (GW<v4f>)m.histogram_norm;
-  for (int i4 = tid; i4 < n_bins3 / 4; i4 += nt) {
+  for (int i4 = bin_lo / 4 + tid; i4 < bin_hi / 4; i4 += nt) {
     v4f hf4 = hist_f4[i4], hb4 = hist_b4[i4];
-    uint32_t c4[4] = {counts[4 * i4], counts[4 * i4 + 1], counts[4 * i4 + 2], counts[4 * i4 + 3]};
+    const int c0 = 4 * i4 - bin_lo;
+    uint32_t c4[4] = {counts[c0], counts[c0 + 1], counts[c0 + 2], counts[c0 + 3]};
     v4f n0, n1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2287,7 +2291,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       if (threadIdx.x < 42) dm->gradient_hessian[threadIdx.x] = gh_depth[threadIdx.x];
     }
   }
-  if (fuse_histogram && rm && part == 0) {
+  if (fuse_histogram && rm) {
     // RegionModality::CalculateResults :572-583 in the same launch: the packed count table takes over the LDS
     // of the line buffers (misc block first, as in region_histogram_kernel)
     const Affine b2w = load_pose(pose);
@@ -2296,8 +2300,13 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     Affine b2dc = b2c;
     if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
     const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
+    // (the workgroups of a split object take a quarter of the bins each: n_bins^3 is a multiple of 16)
+    const int n_bins3 = rm->n_bins * rm->n_bins * rm->n_bins;
+    const int bin_lo = SPLIT ? part * (n_bins3 / M3T_SPLIT_PARTS) : 0;
+    const int bin_hi = SPLIT ? bin_lo + n_bins3 / M3T_SPLIT_PARTS : n_bins3;
     region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
-                            (__attribute__((address_space(3))) uint32_t*)(lds_t + M3T_MISC_FLOATS), lds_t);
+                            (__attribute__((address_space(3))) uint32_t*)(lds_t + M3T_MISC_FLOATS), lds_t, bin_lo,
+                            bin_hi);
   }
 }
 
