@@ -302,6 +302,7 @@ _HIP_ONLY = {
     "set_summation_mode": [C.c_int],
     "set_kernel_timing": [C.c_int],
     "get_kernel_timing": [c_float_p, c_int_p],
+    "get_step_shape": [c_int_p],
 }
 
 

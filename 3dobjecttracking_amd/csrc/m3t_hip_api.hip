@@ -186,6 +186,7 @@ struct m3t_hip_context {
   size_t split_objects = 0;  // capacity of d_split
   unsigned split_seq = 0;    // launch counter inside the granule tags
   bool split_check_pending = false;
+  int last_step_shape[4] = {0, 0, 0, 0};  // m3t_hip_get_step_shape
   bool state_valid = false;  // line/point state + g/H on the device reflect the last step
   TrackLdsLayout layout{};
   int np_max = 0, off_points = 0;
@@ -2402,6 +2403,10 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
                        ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, ctx->sequential_sum,
                        histogram_fused ? 1 : 0);
     HIPCHK(hipGetLastError());
+    ctx->last_step_shape[0] = n;
+    ctx->last_step_shape[1] = split ? M3T_SPLIT_PARTS : 1;
+    ctx->last_step_shape[2] = threads;
+    ctx->last_step_shape[3] = histogram_fused ? 1 : 0;
     ctx->state_valid = ctx->fused_mode == 2;
   } else {
     // Tracker::ExecuteTrackingStep tracker.cpp:344-364, one launch per sub-step
@@ -2465,6 +2470,12 @@ int m3t_hip_set_kernel_timing(m3t_hip_context* ctx, int enable) {
   ctx->timing = enable != 0;
   ctx->kernel_ms[0] = ctx->kernel_ms[1] = 0.0;
   ctx->kernel_launches[0] = ctx->kernel_launches[1] = 0;
+  return M3T_OK;
+}
+int m3t_hip_get_step_shape(m3t_hip_context* ctx, int shape[4]) {
+  CHECK_CTX();
+  REQUIRE(shape, M3T_ERR_INVALID_ARGUMENT, "null output");
+  std::memcpy(shape, ctx->last_step_shape, sizeof(ctx->last_step_shape));
   return M3T_OK;
 }
 int m3t_hip_get_kernel_timing(m3t_hip_context* ctx, float total_ms[2], int launches[2]) {

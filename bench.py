@@ -132,14 +132,18 @@ def main():
         cnt = (C.c_int * 2)()
         hip.call("get_kernel_timing", ms, cnt)
         hip.call("set_kernel_timing", 0)
+        shape = (C.c_int * 4)()
+        hip.call("get_step_shape", shape)  # objects, workgroups per object, threads, histogram update fused
+        kernel = "tracking_step_split_kernel" if shape[1] > 1 else "tracking_step_kernel"
         track_ms = ms[0] / max(cnt[0], 1)
         fused_hist = cnt[1] == 0  # the histogram update rode in the tracking launch (one workgroup per CU)
         hist_ms = ms[1] / max(cnt[1], 1)
         alg = B_ALG if fused_hist else B_ALG_TRACK_KERNEL
         achieved = alg * n_obj / (track_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic("tracking_step_kernel", n_obj, fused_hist)
+        traffic, traffic_src = measured_traffic(kernel, n_obj, fused_hist)
         roofline = {"bound": "hbm",
-                    "kernel": "tracking_step_kernel" + (" (whole step incl. histogram update)" if fused_hist else ""),
+                    "kernel": kernel + (" (whole step incl. histogram update)" if fused_hist else ""),
+                    "workgroups_per_object": shape[1], "threads_per_workgroup": shape[2],
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_ms": round(track_ms, 4), "algorithmic_bytes_per_launch": alg * n_obj}

@@ -238,6 +238,10 @@ int m3t_hip_set_summation_mode(m3t_hip_context*, int mode);
  * [0] the fused tracking kernel and [1] the histogram kernel; totals since enable */
 int m3t_hip_set_kernel_timing(m3t_hip_context*, int enable);
 int m3t_hip_get_kernel_timing(m3t_hip_context*, float total_ms[2], int launches[2]);
+/* launch shape of the last fused tracking step: [0] objects, [1] workgroups per object (1, or 4 =
+ * tracking_step_split_kernel when the batch fills at most a quarter of the CUs), [2] threads per workgroup,
+ * [3] 1 if the histogram update ran inside the same launch; zeros before the first fused step */
+int m3t_hip_get_step_shape(m3t_hip_context*, int shape[4]);
 
 #ifdef __cplusplus
 }
