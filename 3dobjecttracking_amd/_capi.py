@@ -303,6 +303,7 @@ _HIP_ONLY = {
     "set_kernel_timing": [C.c_int],
     "get_kernel_timing": [c_float_p, c_int_p],
     "get_step_shape": [c_int_p],
+    "set_object_split": [C.c_int],
 }
 
 

@@ -182,6 +182,7 @@ struct m3t_hip_context {
   bool fuse_histogram_possible = false;  // ... and the histogram update can ride in the same launch
   // several workgroups per object (tracking_step_split_kernel) for batches that leave most CUs idle
   bool split_possible = false;
+  bool split_enabled = true;  // m3t_hip_set_object_split
   DevMem d_split;            // [objects][2 rounds][M3T_SPLIT_PARTS][32] granules, then the timeout word
   size_t split_objects = 0;  // capacity of d_split
   unsigned split_seq = 0;    // launch counter inside the granule tags
@@ -2259,6 +2260,12 @@ int m3t_hip_set_fused_step(m3t_hip_context* ctx, int mode) {
   return M3T_OK;
 }
 
+int m3t_hip_set_object_split(m3t_hip_context* ctx, int enable) {
+  CHECK_CTX();
+  ctx->split_enabled = enable != 0;
+  return M3T_OK;
+}
+
 int m3t_hip_start_modalities(m3t_hip_context* ctx, int iteration) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));
@@ -2368,7 +2375,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // Up to a quarter of the CUs busy: M3T_SPLIT_PARTS workgroups per object, each on its own CU (all resident at
     // once, which their in-kernel exchange needs).  Not in the reference-summation-order mode: the partial sums
     // of the workgroups are added per workgroup first.
-    const bool split = ctx->split_possible && threads == M3T_BLOCK_THREADS && !ctx->sequential_sum &&
+    const bool split = ctx->split_possible && ctx->split_enabled && threads == M3T_BLOCK_THREADS && !ctx->sequential_sum &&
                        n * M3T_SPLIT_PARTS <= ctx->prop.multiProcessorCount &&
                        ctx->n_corr_iterations * ctx->n_update_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT");
     if (split) {

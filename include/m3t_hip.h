@@ -218,13 +218,18 @@ int m3t_hip_calculate_optimization_end(m3t_hip_context*);
 int m3t_hip_calculate_consistent_poses(m3t_hip_context*); /* tracker.cpp:423, optimizer.cpp:135 */
 int m3t_hip_calculate_results(m3t_hip_context*, int iteration);                    /* :503 */
 /* Tracker::ExecuteTrackingStep (M3T tracker.cpp:344) == Tracker::ExecuteTrackingCycle
- * (ICG tracker.cpp:247): the whole loop nest on the device, two launches per frame. */
+ * (ICG tracker.cpp:247): the whole loop nest on the device, one launch per frame (two for large batches). */
 int m3t_hip_execute_tracking_step(m3t_hip_context*, int iteration);
 int m3t_hip_execute_tracking_cycle(m3t_hip_context*, int iteration);
 /* 0: execute_tracking_step issues the sub-step kernels one by one (line state and
  *    g/H of every iteration observable); 1 (default): fused device loop;
  * 2: fused + line/point state and g/H of the last iteration written back. */
 int m3t_hip_set_fused_step(m3t_hip_context*, int mode);
+/* Small batches (at most a quarter of the CUs busy, region modality only) run with four workgroups per object
+ * that exchange partial sums inside the launch; they are all resident at once only while this context has the
+ * GPU to itself.  A process that shares its GPU with other work switches the split off (enable = 0): results
+ * are bit-identical either way, a step is about 20 % slower.  Default: on. */
+int m3t_hip_set_object_split(m3t_hip_context*, int enable);
 /* Refiner::RefinePoses (refiner.cpp:76-117): CalculateConsistentPoses, then n_corr_iterations x
  * (StartModalities + CalculateCorrespondences + n_update_iterations x (g/H + optimisation)), iteration index 0 */
 int m3t_hip_refine_poses(m3t_hip_context*, int n_corr_iterations, int n_update_iterations);

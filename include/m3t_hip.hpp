@@ -394,6 +394,8 @@ class Tracker {
   bool CalculateConsistentPoses() { return c_->Step(m3t_hip_calculate_consistent_poses(c_->get())); }
   bool ExecuteTrackingStep(int iteration) { return c_->Step(m3t_hip_execute_tracking_step(c_->get(), iteration)); }
   bool ExecuteTrackingCycle(int iteration) { return c_->Step(m3t_hip_execute_tracking_cycle(c_->get(), iteration)); }
+  // four workgroups per object for small batches (needs the GPU to itself; results are identical either way)
+  void SetObjectSplit(bool enable) { c_->Check(m3t_hip_set_object_split(c_->get(), enable ? 1 : 0), "Tracker"); }
   // m3t::Refiner::RefinePoses (refiner.cpp:76-117)
   bool RefinePoses(int n_corr_iterations = 7, int n_update_iterations = 2) {
     return c_->Step(m3t_hip_refine_poses(c_->get(), n_corr_iterations, n_update_iterations));

@@ -82,3 +82,6 @@ def test_split_kernel_is_not_used_where_it_does_not_apply():
     api.call("set_summation_mode", 0)
     assert inst.tracker.ExecuteTrackingStep(1)
     assert step_shape(api)[:2] == [2, 4]
+    api.call("set_object_split", 0)  # a process that shares its GPU
+    assert inst.tracker.ExecuteTrackingStep(1)
+    assert step_shape(api)[:2] == [2, 1]
