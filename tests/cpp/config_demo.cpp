@@ -1,0 +1,127 @@
+// Drives include/m3t_hip_config.hpp for tests/test_cpp_config.py.
+//   yaml FILE KEY...        print the scalar / matrix at the key path ("Class/0/key" walks sequences by index)
+//   obj FILE UNIT           n_vertices n_triangles and the sums of coordinates / indices
+//   png FILE                width height channels bytes_per_channel and the sum of all pixel bytes
+//   bin FILE REGION OUT     re-write a model file from its parsed contents (byte-identical round trip)
+//   track CONFIG            GenerateConfiguredTracker + SetUp + DetectPoses + StartModalities + one step (needs a GPU)
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+
+#include "m3t_hip_config.hpp"
+
+using namespace m3t_hip;
+namespace cfg = m3t_hip::config;
+
+static void PrintNode(const cfg::Node& n) {
+  switch (n.kind) {
+    case cfg::Node::kScalar: std::printf("%s\n", n.scalar.c_str()); break;
+    case cfg::Node::kMatrix:
+      std::printf("matrix %d %d", n.rows, n.cols);
+      for (double v : n.data) std::printf(" %.9g", v);
+      std::printf("\n");
+      break;
+    case cfg::Node::kSeq:
+      std::printf("seq %zu", n.seq.size());
+      for (auto& e : n.seq)
+        if (e.kind == cfg::Node::kScalar) std::printf(" %s", e.scalar.c_str());
+      std::printf("\n");
+      break;
+    case cfg::Node::kMap:
+      std::printf("map %zu", n.map.size());
+      for (auto& kv : n.map) std::printf(" %s", kv.first.c_str());
+      std::printf("\n");
+      break;
+    default: std::printf("null\n");
+  }
+}
+
+int main(int argc, char** argv) {
+  try {
+    const std::string mode = argc > 1 ? argv[1] : "";
+    if (mode == "yaml" && argc >= 3) {
+      cfg::Node root = cfg::ReadYaml(argv[2]);
+      const cfg::Node* n = &root;
+      for (int i = 3; i < argc; ++i) {
+        std::string key = argv[i];
+        if (n->kind == cfg::Node::kSeq) n = &n->seq.at(size_t(std::atoi(key.c_str())));
+        else n = &(*n)[key];
+      }
+      PrintNode(*n);
+      return 0;
+    }
+    if (mode == "obj" && argc >= 4) {
+      cfg::Mesh m = cfg::LoadObj(argv[2], float(std::atof(argv[3])));
+      double vs = 0.0;
+      long long ts = 0;
+      for (float v : m.vertices) vs += v;
+      for (int t : m.triangles) ts += t;
+      std::printf("%zu %zu %.9g %lld %.9g\n", m.vertices.size() / 3, m.triangles.size() / 3, vs, ts,
+                  double(cfg::MaximumBodyDiameter(m, IdentityPose())));
+      return 0;
+    }
+    if (mode == "png" && argc >= 3) {
+      cfg::Image im = cfg::DecodePng(argv[2]);
+      unsigned long long sum = 0;
+      for (uint8_t b : im.pixels) sum += b;
+      std::printf("%d %d %d %d %llu\n", im.width, im.height, im.channels, im.bytes_per_channel, sum);
+      return 0;
+    }
+    if (mode == "bin" && argc >= 5) {
+      const bool region = std::atoi(argv[3]) != 0;
+      std::ifstream ifs(argv[2], std::ios::binary);
+      std::string b((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
+      size_t off = 5;
+      cfg::ModelParameters p;
+      int32_t i32 = 0;
+      cfg::detail::Get(b, &off, &p.sphere_radius);
+      cfg::detail::Get(b, &off, &i32); p.n_divides = i32;
+      cfg::detail::Get(b, &off, &i32); p.n_points = i32;
+      cfg::detail::Get(b, &off, &p.max_radius_depth_offset);
+      cfg::detail::Get(b, &off, &p.stride_depth_offset);
+      cfg::detail::Get(b, &off, &p.use_random_seed);
+      cfg::detail::Get(b, &off, &i32); p.image_size = i32;
+      cfg::BodyData body;
+      if (!cfg::detail::GetBody(b, &off, &body)) return 2;
+      off += size_t(region ? 5 : 1) * 8;  // no associated bodies in the fixtures
+      uint64_t n_views = 0;
+      cfg::detail::Get(b, &off, &n_views);
+      const size_t pf = size_t(region ? M3T_REGION_POINT_FLOATS : M3T_DEPTH_POINT_FLOATS) * size_t(p.n_points);
+      std::vector<float> points(n_views * pf), orientations(n_views * 3), extents(n_views);
+      for (uint64_t v = 0; v < n_views; ++v) {
+        std::memcpy(&points[v * pf], b.data() + off, pf * 4); off += pf * 4;
+        std::memcpy(&orientations[v * 3], b.data() + off, 12); off += 12;
+        std::memcpy(&extents[v], b.data() + off, 4); off += 4;
+      }
+      if (off != b.size()) return 3;
+      cfg::WriteModelBin(argv[4], region, p, body, size_t(n_views), points.data(), orientations.data(), extents.data());
+      std::printf("%d %d\n", cfg::ModelBinMatches(argv[4], region, p, body) ? 1 : 0,
+                  cfg::ModelBinMatches(argv[4], !region, p, body) ? 1 : 0);
+      return 0;
+    }
+    if (mode == "track" && argc >= 3) {
+      auto context = std::make_shared<Context>(0);
+      if (argc > 3) context->Check(m3t_hip_set_summation_mode(context->get(), std::atoi(argv[3])), "mode");
+      auto tracker = cfg::GenerateConfiguredTracker(context, argv[2]);
+      std::set<std::string> names;
+      for (auto& o : tracker->optimizers) names.insert(o.first);
+      if (tracker->DetectPoses(names)) return 4;  // must refuse before SetUp
+      if (!tracker->SetUp() || !tracker->DetectPoses(names) || !tracker->StartModalities(0) ||
+          !tracker->ExecuteTrackingStep(0))
+        return 5;
+      for (auto& b : tracker->bodies) {
+        Pose p = b.second->body2world_pose();
+        std::printf("%s %d %d", b.first.c_str(), tracker->n_corr_iterations, tracker->n_update_iterations);
+        for (float v : p) std::printf(" %a", double(v));
+        std::printf("\n");
+      }
+      for (auto& mp : tracker->model_paths) std::printf("model %s %s\n", mp.first.c_str(), mp.second.c_str());
+      return 0;
+    }
+    std::fprintf(stderr, "usage: config_demo yaml|obj|png|bin|track ...\n");
+    return 1;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 10;
+  }
+}
