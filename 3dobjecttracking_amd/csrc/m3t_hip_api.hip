@@ -731,7 +731,8 @@ int UploadTables(Ctx* ctx) {
       if (c->n_slots != n_versions) n_versions = 0;
       if (c->current != uniform_slot) uniform_slot = -1;
     }
-    if (n_versions > 64) n_versions = 0;
+    const size_t version_bytes = n_cams * sizeof(CameraDev);
+    if (n_versions > 4096 || version_bytes * size_t(n_versions + 1) > (size_t(32) << 20)) n_versions = 0;
     auto fill = [&](CameraDev* out, int slot /* -1: every camera's own current slot */) {
       for (size_t i = 0; i < n_cams; ++i) {
         const Camera& c = *ctx->cameras[i];
@@ -745,34 +746,38 @@ int UploadTables(Ctx* ctx) {
         std::memcpy(d.world2camera, c.world2camera, 64);
       }
     };
-    const size_t version_bytes = n_cams * sizeof(CameraDev);
     const size_t bytes = version_bytes * size_t(n_versions + 1);
     if (ctx->d_cams.bytes < bytes) {
       HIPCHK(hipStreamSynchronize(ctx->stream));
       HIPCHK(ctx->d_cams.alloc(bytes * 2));
       ctx->cams_dirty = true;
     }
-    if (ctx->cam_stage_bytes < bytes) {
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      for (int i = 0; i < Ctx::kStage; ++i) {
-        if (ctx->cam_stage[i]) (void)hipHostFree(ctx->cam_stage[i]);
-        HIPCHK(hipHostMalloc(&ctx->cam_stage[i], bytes * 2, hipHostMallocDefault));
-        if (!ctx->cam_stage_done[i]) HIPCHK(hipEventCreateWithFlags(&ctx->cam_stage_done[i], hipEventDisableTiming));
-      }
-      ctx->cam_stage_bytes = bytes * 2;
-    }
     const bool rebuild = ctx->cams_dirty || ctx->tables_dirty;
     const bool custom = uniform_slot < 0 || n_versions == 0;
-    if (n_cams && (rebuild || custom)) {
+    if (n_cams && rebuild && n_versions > 0) {
+      // all slot versions at once: rare (set-up, a camera pose change), so a plain blocking copy
+      std::vector<CameraDev> all(n_cams * size_t(n_versions));
+      for (int v = 0; v < n_versions; ++v) fill(all.data() + size_t(v) * n_cams, v);
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipMemcpy(ctx->d_cams.p, all.data(), all.size() * sizeof(CameraDev), hipMemcpyHostToDevice));
+    }
+    if (n_cams && custom) {
+      // one table for cameras on different slots, staged through a small pinned ring: no host sync per switch
+      if (ctx->cam_stage_bytes < version_bytes) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < Ctx::kStage; ++i) {
+          if (ctx->cam_stage[i]) (void)hipHostFree(ctx->cam_stage[i]);
+          HIPCHK(hipHostMalloc(&ctx->cam_stage[i], version_bytes * 2, hipHostMallocDefault));
+          if (!ctx->cam_stage_done[i]) HIPCHK(hipEventCreateWithFlags(&ctx->cam_stage_done[i], hipEventDisableTiming));
+        }
+        ctx->cam_stage_bytes = version_bytes * 2;
+      }
       const int stage = ctx->cam_stage_next;
       ctx->cam_stage_next = (stage + 1) % Ctx::kStage;
       HIPCHK(hipEventSynchronize(ctx->cam_stage_done[stage]));  // normally long complete
-      CameraDev* host = static_cast<CameraDev*>(ctx->cam_stage[stage]);
-      size_t first = rebuild ? 0 : size_t(n_versions), last = size_t(n_versions) + 1;
-      for (size_t v = first; v < last; ++v) fill(host + v * n_cams, v < size_t(n_versions) ? int(v) : -1);
-      HIPCHK(hipMemcpyAsync(ctx->d_cams.as<uint8_t>() + first * version_bytes,
-                            reinterpret_cast<uint8_t*>(host) + first * version_bytes, (last - first) * version_bytes,
-                            hipMemcpyHostToDevice, ctx->stream));
+      fill(static_cast<CameraDev*>(ctx->cam_stage[stage]), -1);
+      HIPCHK(hipMemcpyAsync(ctx->d_cams.as<uint8_t>() + size_t(n_versions) * version_bytes, ctx->cam_stage[stage],
+                            version_bytes, hipMemcpyHostToDevice, ctx->stream));
       HIPCHK(hipEventRecord(ctx->cam_stage_done[stage], ctx->stream));
     }
     ctx->cams_active = ctx->d_cams.as<CameraDev>() + (custom ? size_t(n_versions) : size_t(uniform_slot)) * n_cams;
