@@ -159,3 +159,221 @@ def test_generator_errors(tmp_path):
         '%YAML:1.2\nmodel_path: "../../temp/triangle_region_model.bin"\nn_points: 100\n')
     with pytest.raises(util.pkg.M3TError):
         generate(text)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a configuration with everything the generator wires: two bodies in a kinematic tree, a focused depth renderer
+# for modelled occlusions, shared colour histograms, a constraint and a soft constraint, link / optimizer /
+# modality metafiles — against the same object graph built by hand
+# ---------------------------------------------------------------------------------------------------------
+TREE_CONFIG = """%YAML:1.2
+LoaderColorCamera:
+  - name: "color_camera"
+    metafile_path: "../_sequence/color_camera.yaml"
+LoaderDepthCamera:
+  - name: "depth_camera"
+    metafile_path: "../_sequence/depth_camera.yaml"
+Body:
+  - name: "triangle"
+    metafile_path: "../_body/triangle.yaml"
+  - name: "schauma"
+    metafile_path: "../_body/schauma.yaml"
+ColorHistograms:
+  - name: "shared_histograms"
+    metafile_path: "histograms.yaml"
+RendererGeometry:
+  - name: "renderer_geometry"
+    bodies: ["triangle", "schauma"]
+FocusedBasicDepthRenderer:
+  - name: "depth_renderer"
+    metafile_path: "renderer.yaml"
+    renderer_geometry: "renderer_geometry"
+    camera: "color_camera"
+    referenced_bodies: ["triangle"]
+RegionModel:
+  - name: "triangle_region_model"
+    metafile_path: "../_body/triangle_region_model.yaml"
+    body: "triangle"
+  - name: "schauma_region_model"
+    metafile_path: "schauma_region_model.yaml"
+    body: "schauma"
+DepthModel:
+  - name: "triangle_depth_model"
+    metafile_path: "../_body/triangle_depth_model.yaml"
+    body: "triangle"
+RegionModality:
+  - name: "triangle_region_modality"
+    metafile_path: "region_modality.yaml"
+    body: "triangle"
+    color_camera: "color_camera"
+    region_model: "triangle_region_model"
+    model_occlusions: {focused_depth_renderer: "depth_renderer"}
+    use_shared_color_histograms: {color_histograms: "shared_histograms"}
+  - name: "schauma_region_modality"
+    body: "schauma"
+    color_camera: "color_camera"
+    region_model: "schauma_region_model"
+    use_shared_color_histograms: {color_histograms: "shared_histograms"}
+DepthModality:
+  - name: "triangle_depth_modality"
+    body: "triangle"
+    depth_camera: "depth_camera"
+    depth_model: "triangle_depth_model"
+Link:
+  - name: "schauma_link"
+    metafile_path: "schauma_link.yaml"
+    body: "schauma"
+    modalities: ["schauma_region_modality"]
+  - name: "triangle_link"
+    body: "triangle"
+    modalities: ["triangle_region_modality", "triangle_depth_modality"]
+    child_links: ["schauma_link"]
+Constraint:
+  - name: "hinge"
+    metafile_path: "constraint.yaml"
+    link1: "triangle_link"
+    link2: "schauma_link"
+SoftConstraint:
+  - name: "spring"
+    metafile_path: "soft_constraint.yaml"
+    link1: "triangle_link"
+    link2: "schauma_link"
+Optimizer:
+  - name: "optimizer"
+    metafile_path: "optimizer.yaml"
+    root_link: "triangle_link"
+    constraints: ["hinge"]
+    soft_constraints: ["spring"]
+StaticDetector:
+  - name: "detector"
+    metafile_path: "../_body/triangle_static_detector.yaml"
+    optimizer: "optimizer"
+Tracker:
+  - name: "tracker"
+    metafile_path: "tracker.yaml"
+    optimizers: ["optimizer"]
+    detectors: ["detector"]
+"""
+JOINT2PARENT = np.array([[1, 0, 0, 0.17], [0, 1, 0, 0.02], [0, 0, 1, 0.09], [0, 0, 0, 1]], np.float32)
+
+
+def _matrix_yaml(key, m):
+    return "%s: !!opencv-matrix\n  rows: 4\n  cols: 4\n  dt: d\n  data: [ %s ]\n" % (
+        key, ", ".join("%.9g" % v for v in np.asarray(m, np.float64).reshape(-1)))
+
+
+def write_tree_config(root):
+    t = root / "tracker_test"
+    (t / "tree_config.yaml").write_text(TREE_CONFIG)
+    (t / "histograms.yaml").write_text("%YAML:1.2\nn_bins: 32\nlearning_rate_f: 0.3\nlearning_rate_b: 0.1\n")
+    (t / "renderer.yaml").write_text("%YAML:1.2\nimage_size: 160\nz_min: 0.05\nz_max: 5.0\n")
+    (t / "region_modality.yaml").write_text("%YAML:1.2\nn_lines_max: 120\nscales: [5, 2, 1]\n"
+                                            "standard_deviations: [20.0, 7.0, 3.0]\nn_unoccluded_iterations: 0\n")
+    (t / "schauma_link.yaml").write_text("%YAML:1.2\n" + _matrix_yaml("joint2parent_pose", JOINT2PARENT) +
+                                         "free_directions: [0, 0, 1, 1, 1, 0]\n")
+    (t / "constraint.yaml").write_text("%YAML:1.2\nconstraint_directions: [1, 1, 0, 0, 0, 0]\n")
+    (t / "soft_constraint.yaml").write_text("%YAML:1.2\nconstraint_directions: [0, 0, 0, 1, 1, 1]\n"
+                                            "max_distance_translation: 0.002\nstandard_deviation_translation: 0.005\n")
+    (t / "optimizer.yaml").write_text("%YAML:1.2\ntikhonov_parameter_rotation: 5000\n"
+                                      "tikhonov_parameter_translation: 200000\n")
+    (t / "schauma_region_model.yaml").write_text(
+        '%YAML:1.2\nmodel_path: "../../temp/schauma_region_model.bin"\nsphere_radius: 0.4\nn_divides: 2\n'
+        'n_points: 10\nmax_radius_depth_offset: 0.05\nstride_depth_offset: 0.002\nimage_size: 500\n')
+    # the reference's own region model of the bottle, re-headed for the mesh file of this tree
+    src = os.path.join(util.GOLDEN, "model_test", "region_model.bin")
+    m = gl_model.read_model_bin(src, True)
+    body_yaml = cfg.read_yaml(str(root / "_body" / "schauma.yaml"))
+    v, _ = cfg.load_obj(str(root / "_body" / "schauma.obj"), body_yaml["geometry_unit_in_meter"])
+    g2b = cfg.pose(body_yaml["geometry2body_pose"])
+    bd = cfg.BodyData(str(root / "_body" / "schauma.obj"), body_yaml["geometry_unit_in_meter"],
+                      body_yaml["geometry_counterclockwise"], body_yaml["geometry_enable_culling"],
+                      cfg.maximum_body_diameter(v @ g2b[:3, :3].T + g2b[:3, 3]), g2b)
+    params = {k: m[k] for k in ("sphere_radius", "n_divides", "n_points", "max_radius_depth_offset",
+                                "stride_depth_offset", "use_random_seed", "image_size")}
+    cfg.write_model_bin(str(root.parent / "temp" / "schauma_region_model.bin"), True, params, bd, m["points"],
+                        m["orientations"], m["extents"])
+    return m
+
+
+def build_tree_by_hand(api, root, schauma_model):
+    """the object graph of TREE_CONFIG through the host classes, in the generator's creation order"""
+    h = util.host
+    ty = cfg.read_yaml(str(root / "_body" / "triangle.yaml"))
+    sy = cfg.read_yaml(str(root / "_body" / "schauma.yaml"))
+    triangle, schauma = h.Body(api), h.Body(api)
+    tv, tf = cfg.load_obj(str(root / "_body" / "triangle.obj"), ty["geometry_unit_in_meter"])
+    sv, sf = cfg.load_obj(str(root / "_body" / "schauma.obj"), sy["geometry_unit_in_meter"])
+    triangle.set_geometry(tv, tf, cfg.pose(ty["geometry2body_pose"]), True, True, ty["body_id"], ty["region_id"])
+    schauma.set_geometry(sv, sf, cfg.pose(sy["geometry2body_pose"]), bool(sy["geometry_counterclockwise"]),
+                         bool(sy["geometry_enable_culling"]), sy["body_id"], sy["region_id"])
+    histograms = h.ColorHistograms(api, 32, 0.3, 0.1)
+    geometry = h.RendererGeometry(api)
+    geometry.AddBody(triangle)
+    geometry.AddBody(schauma)
+    color = h.ColorCamera(api, **util.COLOR_INTR)
+    # (camera2world is a float transform in the reference: rounded to f32 before it is inverted)
+    depth = h.DepthCamera(api, depth_scale=0.001,
+                          world2camera_pose=generator._inverse_pose(cfg.pose(util.DEPTH_CAMERA2WORLD)), **util.DEPTH_INTR)
+    renderer = h.FocusedBasicDepthRenderer(api, geometry, color, image_size=160, z_min=0.05, z_max=5.0)
+    renderer.AddReferencedBody(triangle)
+    v = gs.views()
+    t_region = h.RegionModel(api, data_points=v["region_points"], orientations=v["region_orientations"],
+                             contour_lengths=v["region_contour_lengths"])
+    s_region = h.RegionModel(api, data_points=schauma_model["points"], orientations=schauma_model["orientations"],
+                             contour_lengths=schauma_model["extents"],
+                             stride_depth_offset=schauma_model["stride_depth_offset"],
+                             max_radius_depth_offset=schauma_model["max_radius_depth_offset"])
+    t_depth = h.DepthModel(api, data_points=v["depth_points"], orientations=v["depth_orientations"],
+                           surface_areas=v["depth_surface_areas"])
+    rm_t = h.RegionModality(api, triangle, color, t_region, n_lines_max=120, scales=[5, 2, 1],
+                            standard_deviations=[20.0, 7.0, 3.0], n_unoccluded_iterations=0)
+    rm_t.ModelOcclusions(renderer)
+    rm_t.UseSharedColorHistograms(histograms)
+    rm_s = h.RegionModality(api, schauma, color, s_region)
+    rm_s.UseSharedColorHistograms(histograms)
+    dm_t = h.DepthModality(api, triangle, depth, t_depth)
+    link_t = h.Link(api, triangle)
+    link_t.AddModality(rm_t)
+    link_t.AddModality(dm_t)
+    link_s = h.Link(api, schauma, link_t, np.eye(4), JOINT2PARENT, (0, 0, 1, 1, 1, 0))
+    link_s.AddModality(rm_s)
+    optimizer = h.Optimizer(api, link_t, tikhonov_parameter_rotation=5000.0, tikhonov_parameter_translation=200000.0)
+    h.Constraint(api, optimizer, link_t, link_s, constraint_directions=(1, 1, 0, 0, 0, 0))
+    h.SoftConstraint(api, optimizer, link_t, link_s, constraint_directions=(0, 0, 0, 1, 1, 1),
+                     max_distance_translation=0.002, standard_deviation_translation=0.005)
+    tracker = h.Tracker(api, 4, 2)
+    color.UpdateImage(util.load_color_frame(200))
+    depth.UpdateImage(util.load_depth_frame(200))
+    detector = cfg.pose(cfg.read_yaml(str(root / "_body" / "triangle_static_detector.yaml"))["link2world_pose"])
+    link_t.set_link2world_pose(detector)
+    assert tracker.CalculateConsistentPoses()
+    return tracker, (triangle, schauma), (rm_t, rm_s)
+
+
+def test_generator_wires_trees_renderers_shared_histograms_and_constraints(tmp_path):
+    root = reference_tree(tmp_path)
+    write_fixture_models(root)
+    schauma_model = write_tree_config(root)
+    (root / "tracker_test" / "tracker.yaml").write_text("%YAML:1.2\nn_corr_iterations: 4\nn_update_iterations: 2\n")
+
+    generated = generator.GenerateConfiguredTracker(util.open_oracle(), str(root / "tracker_test" / "tree_config.yaml"))
+    assert generated.SetUp() and generated.DetectPoses({"optimizer"})
+    assert generated.StartModalities(0) and generated.ExecuteTrackingStep(0)
+
+    tracker, bodies, region = build_tree_by_hand(util.open_oracle(), root, schauma_model)
+    assert tracker.StartModalities(0) and tracker.ExecuteTrackingStep(0)
+
+    for name, body in zip(("triangle", "schauma"), bodies):
+        assert np.array_equal(generated.objects["Body"][name].body2world_pose(), body.body2world_pose()), name
+    for name, modality in zip(("triangle_region_modality", "schauma_region_modality"), region):
+        a = generated.objects["RegionModality"][name].histograms()
+        b = modality.histograms()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # the child hangs on its parent through the joint: free are the rotation about z and the translations along
+    # x and y (schauma_link.yaml), so the relative pose keeps the joint's height and its z axis
+    t, s = (b.body2world_pose() for b in bodies)
+    relative = np.linalg.inv(t.astype(np.float64)) @ s
+    assert abs(relative[2, 3] - JOINT2PARENT[2, 3]) < 1e-5
+    assert np.allclose(relative[:3, 2], [0, 0, 1], atol=1e-5) and np.allclose(relative[2, :3], [0, 0, 1], atol=1e-5)
+    assert generated.objects["Link"]["schauma_link"].parent is generated.objects["Link"]["triangle_link"]
+    assert generated.objects["FocusedBasicDepthRenderer"]["depth_renderer"].image_size == 160
