@@ -3,12 +3,16 @@
 //   obj FILE UNIT           n_vertices n_triangles and the sums of coordinates / indices
 //   png FILE                width height channels bytes_per_channel and the sum of all pixel bytes
 //   bin FILE REGION OUT     re-write a model file from its parsed contents (byte-identical round trip)
+//   rbot POSES N            first / last translation of an RBOT pose file and a criterion check
+//   ycb POSES BEGIN N K...  keyframe poses of a YCB pose file
+//   adds OBJ N POSE16 GT16  ADD / ADD-S / AUC of a mesh's (reduced) vertices under two poses (row-major 4x4 each)
 //   track CONFIG            GenerateConfiguredTracker + SetUp + DetectPoses + StartModalities + one step (needs a GPU)
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
 
 #include "m3t_hip_config.hpp"
+#include "m3t_hip_evaluation.hpp"
 
 using namespace m3t_hip;
 namespace cfg = m3t_hip::config;
@@ -97,6 +101,49 @@ int main(int argc, char** argv) {
       cfg::WriteModelBin(argv[4], region, p, body, size_t(n_views), points.data(), orientations.data(), extents.data());
       std::printf("%d %d\n", cfg::ModelBinMatches(argv[4], region, p, body) ? 1 : 0,
                   cfg::ModelBinMatches(argv[4], !region, p, body) ? 1 : 0);
+      return 0;
+    }
+    namespace ev = m3t_hip::evaluation;
+    if (mode == "rbot" && argc >= 4) {
+      auto poses = ev::ReadPosesRBOT(argv[2], std::atoi(argv[3]));
+      std::printf("%zu %.9g %.9g %.9g %.9g\n", poses.size(), double(poses[2][12]), double(poses[2][13]),
+                  double(poses[2][14]), double(poses[2][4]));
+      ev::Pose moved = poses[1];
+      moved[14] += 0.049f;
+      auto ok = ev::RbotPoseResult(moved, poses[1]);
+      moved[14] += 0.002f;
+      auto lost = ev::RbotPoseResult(moved, poses[1]);
+      auto other = ev::RbotPoseResult(poses[2], poses[1]);  // two unrelated poses: a rotation error far from 0
+      std::printf("%.9g %.9g %g %g\n", double(ok.translation_error), double(other.rotation_error),
+                  double(ok.tracking_success), double(lost.tracking_success));
+      return 0;
+    }
+    if (mode == "ycb" && argc >= 6) {
+      std::vector<int> keyframes;
+      for (int i = 5; i < argc; ++i) keyframes.push_back(std::atoi(argv[i]));
+      for (auto& p : ev::ReadPosesYCB(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), keyframes)) {
+        for (float v : p) std::printf("%.9g ", double(v));
+        std::printf("\n");
+      }
+      return 0;
+    }
+    if (mode == "adds" && argc >= 36) {
+      cfg::Mesh m = cfg::LoadObj(argv[2], 1.0f);
+      std::vector<std::array<float, 3>> vertices(m.vertices.size() / 3);
+      for (size_t i = 0; i < vertices.size(); ++i) vertices[i] = {m.vertices[3 * i], m.vertices[3 * i + 1], m.vertices[3 * i + 2]};
+      vertices = ev::ReduceVertices(vertices, std::atoi(argv[3]));
+      ev::Pose a, b;
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+          a[size_t(c * 4 + r)] = float(std::atof(argv[4 + r * 4 + c]));
+          b[size_t(c * 4 + r)] = float(std::atof(argv[20 + r * 4 + c]));
+        }
+      auto r = ev::YcbPoseResult(vertices, a, b);
+      int add_zeros = 0, adds_zeros = 0;
+      for (float v : r.add_curve) add_zeros += v == 0.0f;
+      for (float v : r.adds_curve) adds_zeros += v == 0.0f;
+      std::printf("%zu %.9g %.9g %.9g %.9g %d %d %.9g\n", vertices.size(), double(r.add_error), double(r.adds_error),
+                  double(r.add_auc), double(r.adds_auc), add_zeros, adds_zeros, double(vertices[0][0]));
       return 0;
     }
     if (mode == "track" && argc >= 3) {
