@@ -12,6 +12,9 @@ Provenance (all under /root/reference/M3T/data/):
   tracker_test/, refiner_test/ pose goldens (test/tracker_test.cpp:164-195)
   _sequence/{color,depth}_camera_image_20{0,1}.png + yaml   the fixture frames (test/common_test.cpp:96-118)
   _body/triangle.obj, schauma.obj + yaml   fixture meshes
+  renderer_test/focused_{depth,silhouette}_image.png   FocusedSilhouetteRendererTest / FocusedBasicDepthRendererTest
+                                           goldens (test/renderer_test.cpp:301-323,892-902)
+  detector_test/detector_triangle_pose.txt StaticDetectorTest.DetectPose golden (test/detector_test.cpp:77-85)
   tracker_test/tracker_config.yaml, _body/triangle_{region,depth}_model.yaml   the generator configuration of
                                            TrackerTest.OptimizePoseMatrixGeneratorSetUp (test/tracker_test.cpp:182-195)
 """
@@ -41,6 +44,8 @@ FILES = [
     "_body/triangle.obj", "_body/triangle.yaml", "_body/schauma.yaml", "_body/schauma.obj",
     "_body/triangle_static_detector.yaml", "color_histograms_test/color_histograms.yaml",
     "tracker_test/tracker_config.yaml", "_body/triangle_region_model.yaml", "_body/triangle_depth_model.yaml",
+    "renderer_test/focused_depth_image.png", "renderer_test/focused_silhouette_image.png",
+    "detector_test/detector_triangle_pose.txt",
 ]
 
 if __name__ == "__main__":

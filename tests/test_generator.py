@@ -377,3 +377,22 @@ def test_generator_wires_trees_renderers_shared_histograms_and_constraints(tmp_p
     assert np.allclose(relative[:3, 2], [0, 0, 1], atol=1e-5) and np.allclose(relative[2, :3], [0, 0, 1], atol=1e-5)
     assert generated.objects["Link"]["schauma_link"].parent is generated.objects["Link"]["triangle_link"]
     assert generated.objects["FocusedBasicDepthRenderer"]["depth_renderer"].image_size == 160
+
+
+def test_static_detector_golden(tmp_path):
+    """StaticDetectorTest.DetectPose (test/detector_test.cpp:77-85): the detector's metafile pose lands on the body
+    exactly (CompareToLoadedMatrix(..., 0.0f)); a name that is not the detector's optimizer leaves it alone"""
+    root = reference_tree(tmp_path)
+    write_fixture_models(root)
+    tracker = generator.GenerateConfiguredTracker(util.open_oracle(), str(root / "tracker_test" / "tracker_config.yaml"))
+    assert tracker.SetUp()
+    body = tracker.body_ptrs()[0]
+    before = body.body2world_pose()
+    assert tracker.DetectPoses({"some_other_optimizer"})
+    assert np.array_equal(body.body2world_pose(), before)
+    detected = set()
+    assert tracker.DetectPoses({"triangle_optimizer"}, detected) and detected == {"triangle_optimizer"}
+    golden = util.read_golden_matrix("detector_test/detector_triangle_pose.txt").astype(np.float32)
+    assert np.array_equal(body.body2world_pose(), golden)
+    link = tracker.objects["Link"]["triangle_link"]
+    assert np.array_equal(link.link2world_pose(), golden)

@@ -90,6 +90,49 @@ def check_depth_branches(api):
             assert np.array_equal(sil.astype(np.int32)[~marks], gold[..., 0][~marks])
 
 
+def check_focused_renderer_images(api):
+    """FocusedSilhouetteRendererTest.TestSilhouetteImage / TestDepthImage and FocusedBasicDepthRendererTest.
+    TestDepthImage (test/renderer_test.cpp:152-193,301-323,748-778,892-902): triangle + bottle seen by a 640 x 480
+    camera 1 cm off the origin, focused on the triangle at 200 x 200, z range 0.1-2 m.  The reference's criterion
+    is CompareToLoadedImage(..., 0, 10): at most 10 pixels further than 1 from the golden.  Met with no such pixel:
+    the silhouette (body ids) is identical, the 16-bit depth buffer differs by one step on < 1 % of the pixels
+    (the last bit of the hardware's depth interpolation)."""
+    body = host.Body(api, gs.mtv.body2world())
+    geometry, _ = gs.fixture_renderer_geometry(api, body)
+    world2camera = np.eye(4, dtype=np.float32)
+    world2camera[0, 3] = 0.01
+    camera = host.ColorCamera(api, 698.128, 698.617, 478.459, 274.426, 640, 480, world2camera_pose=world2camera)
+    silhouette_renderer = host.FocusedSilhouetteRenderer(api, geometry, camera, id_type=0, image_size=200, z_min=0.1,
+                                                        z_max=2.0)
+    silhouette_renderer.AddReferencedBody(body)
+    depth_renderer = host.FocusedBasicDepthRenderer(api, geometry, camera, image_size=200, z_min=0.1, z_max=2.0)
+    depth_renderer.AddReferencedBody(body)
+    assert silhouette_renderer.StartRendering() and depth_renderer.StartRendering()
+    depth, silhouette, _, _, _, n_visible = silhouette_renderer.images()
+    assert n_visible == 1
+    gold_depth = gs.load_png("renderer_test/focused_depth_image.png")
+    gold_silhouette = gs.load_png("renderer_test/focused_silhouette_image.png")
+    assert gold_depth.dtype == np.uint16 and gold_depth.shape == (200, 200)
+    assert np.array_equal(silhouette, gold_silhouette)
+    assert set(np.unique(silhouette)) == {0, 50, 150}  # background, bottle, triangle (IDType::BODY)
+    difference = np.abs(depth.astype(np.int64) - gold_depth.astype(np.int64))
+    assert int((difference > 1).sum()) == 0            # the reference allows 10
+    assert int((difference > 0).sum()) < 400            # of 14 889 covered pixels
+    assert np.array_equal(depth_renderer.images()[0], depth)  # both renderers fill the same depth buffer
+    return depth, silhouette
+
+
+def test_oracle_focused_renderer_images():
+    check_focused_renderer_images(util.open_oracle())
+
+
+@pytest.mark.gpu
+def test_hip_focused_renderer_images():
+    depth, silhouette = check_focused_renderer_images(util.open_hip())
+    oracle_depth, oracle_silhouette = check_focused_renderer_images(util.open_oracle())
+    assert np.array_equal(depth, oracle_depth) and np.array_equal(silhouette, oracle_silhouette)
+
+
 @pytest.mark.parametrize("check", [check_region_checking, check_region_modeled_occlusions, check_depth_branches])
 def test_oracle_renderer_goldens(check):
     check(util.open_oracle())
