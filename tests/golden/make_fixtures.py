@@ -14,6 +14,8 @@ Provenance (all under /root/reference/M3T/data/):
   _body/triangle.obj, schauma.obj + yaml   fixture meshes
   renderer_test/focused_{depth,silhouette}_image.png   FocusedSilhouetteRendererTest / FocusedBasicDepthRendererTest
                                            goldens (test/renderer_test.cpp:301-323,892-902)
+  pen_paper_demo/*.yaml                    the reference's demo configuration (examples/run_pen_paper_demo.cpp): a larger
+                                           file for the YAML readers (unquoted names, comments, flow sequences)
   detector_test/detector_triangle_pose.txt StaticDetectorTest.DetectPose golden (test/detector_test.cpp:77-85)
   tracker_test/tracker_config.yaml, _body/triangle_{region,depth}_model.yaml   the generator configuration of
                                            TrackerTest.OptimizePoseMatrixGeneratorSetUp (test/tracker_test.cpp:182-195)
@@ -46,6 +48,7 @@ FILES = [
     "tracker_test/tracker_config.yaml", "_body/triangle_region_model.yaml", "_body/triangle_depth_model.yaml",
     "renderer_test/focused_depth_image.png", "renderer_test/focused_silhouette_image.png",
     "detector_test/detector_triangle_pose.txt",
+    "pen_paper_demo/config.yaml", "pen_paper_demo/stabilo_region_modality.yaml", "pen_paper_demo/paper_detector.yaml",
 ]
 
 if __name__ == "__main__":

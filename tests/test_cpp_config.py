@@ -45,6 +45,16 @@ def test_yaml_reader_agrees_with_the_python_reader(demo):
     assert demo("yaml", os.path.join(g, "_body", "triangle.yaml"), "geometry_path") == "triangle.obj"
     assert demo("yaml", os.path.join(g, "_sequence", "color_camera.yaml"), "intrinsics", "f_u") == "698.128"
     assert "Could not open file" in demo("yaml", os.path.join(g, "missing.yaml"), ok=False)
+    # the reference's demo configuration: unquoted names, comments after values, flow sequences of bare words
+    demo_config = os.path.join(g, "pen_paper_demo", "config.yaml")
+    d = cfg.read_yaml(demo_config)
+    assert demo("yaml", demo_config).split()[2:] == list(d.keys())
+    assert demo("yaml", demo_config, "Link", 0, "modalities").split()[2:] == d["Link"][0]["modalities"]
+    assert demo("yaml", demo_config, "Body", 3, "name") == "paper"
+    assert demo("yaml", demo_config, "RegionModel", 0, "fixed_bodies").split()[2:] == ["stabilo_body"]
+    assert demo("yaml", demo_config, "RegionModality", 2, "measure_occlusions", "depth_camera") == "depth_camera"
+    m = demo("yaml", os.path.join(g, "pen_paper_demo", "paper_detector.yaml"), "link2world_pose").split()
+    assert m[:3] == ["matrix", "4", "4"] and float(m[3]) == 0.9662 and float(m[-1]) == 1.0
 
 
 def test_mesh_png_and_model_files(demo, tmp_path):

@@ -396,3 +396,19 @@ def test_static_detector_golden(tmp_path):
     assert np.array_equal(body.body2world_pose(), golden)
     link = tracker.objects["Link"]["triangle_link"]
     assert np.array_equal(link.link2world_pose(), golden)
+
+
+def test_demo_configuration_is_read_and_refused_by_name():
+    """data/pen_paper_demo/config.yaml: unquoted scalars, comments after values, flow sequences; it asks for sensor
+    cameras and a texture modality, which the generator names when it refuses"""
+    path = os.path.join(util.GOLDEN, "pen_paper_demo", "config.yaml")
+    d = cfg.read_yaml(path)
+    assert [b["name"] for b in d["Body"]] == ["stabilo", "stabilo_body", "stabilo_tip", "paper"]
+    assert d["Link"][0]["modalities"] == ["stabilo_tip_region_modality", "stabilo_body_region_modality",
+                                          "stabilo_texture_modality", "stabilo_depth_modality"]
+    assert d["RegionModel"][0]["fixed_bodies"] == ["stabilo_body"]
+    assert d["RegionModality"][2]["measure_occlusions"] == {"depth_camera": "depth_camera"}
+    m = cfg.read_yaml(os.path.join(util.GOLDEN, "pen_paper_demo", "stabilo_region_modality.yaml"))
+    assert m == {"use_adaptive_coverage": 1, "reference_contour_length": 0.23, "measured_occlusion_threshold": 0.01}
+    with pytest.raises(ValueError, match="TextureModality|AzureKinect"):
+        generator.GenerateConfiguredTracker(util.open_oracle(), path)
