@@ -85,3 +85,16 @@ def test_split_kernel_is_not_used_where_it_does_not_apply():
     api.call("set_object_split", 0)  # a process that shares its GPU
     assert inst.tracker.ExecuteTrackingStep(1)
     assert step_shape(api)[:2] == [2, 1]
+
+
+def test_default_summation_order_does_not_depend_on_the_workgroup_size(monkeypatch):
+    """large batches run 256-thread workgroups (two per CU): same poses and histograms as 512 threads, bit for bit"""
+    inputs = scenes.Inputs(2, 4, n_divides=2)
+    monkeypatch.setenv("M3T_HIP_THREADS", "256")
+    pa, ha, _, _, shape_a = run(inputs, False, 1, 4)
+    monkeypatch.delenv("M3T_HIP_THREADS")
+    pb, hb, _, _, shape_b = run(inputs, False, 1, 4)
+    assert shape_a[2] == 256 and shape_b[2] == 512 and shape_a[1] == shape_b[1] == 1
+    assert np.array_equal(pa, pb)
+    for a, b in zip(ha, hb):
+        assert np.array_equal(a, b)
