@@ -20,7 +20,9 @@ import struct
 import numpy as np
 
 F = np.float32
-K_MAIN_BODY_ID = 255
+K_MAIN_BODY_ID = 255        # model.h: kMainBodyID
+K_BACKGROUND_ID = 0         # kBackgroundID
+K_DIFFERENT_BODY_ID = 120   # kDifferentBodyID
 REGION_POINT_FLOATS = 38
 DEPTH_POINT_FLOATS = 36
 N_DEPTH_OFFSETS = 30
@@ -192,7 +194,11 @@ class ConvexBody:
 class Render:
     """One view: silhouette mask, 16-bit depth image, RGBA8 flat-normal image"""
 
-    def __init__(self, body, camera2body, sphere_radius, image_size, subpixel_bits=8, quant_bias=0.04):
+    def __init__(self, body, camera2body, sphere_radius, image_size, subpixel_bits=8, quant_bias=0.04, others=(),
+                 main_id=None):
+        """others: (ConvexBody, id) pairs drawn after the main body into the same z-buffer — the associated /
+        occlusion bodies of Model::AddBodiesToRenderer (model.cpp:164-192): every body is 'centred', i.e. shares
+        the main body's frame, and widens the clip range to its own diameter; main_id: the main body's id"""
         S = image_size
         d = body.maximum_body_diameter
         # Model::SetUpRenderer model.cpp:120-153
@@ -201,6 +207,9 @@ class Render:
         self.size = S
         z_min = F(sphere_radius) - d * F(0.5)
         z_max = F(sphere_radius) + d * F(0.5)
+        for other, _ in others:
+            z_min = min(z_min, F(sphere_radius) - other.maximum_body_diameter * F(0.5))
+            z_max = max(z_max, F(sphere_radius) + other.maximum_body_diameter * F(0.5))
         self.term_a = z_max * z_min * F(65535.0) / (z_max - z_min)  # renderer.cpp:475-478
         self.term_b = z_max * F(65535.0) / (z_max - z_min)
         fu, pp = self.fu, self.pp
@@ -210,6 +219,21 @@ class Render:
                       [0, 0, 1, 0]], F)
         c2b = np.asarray(camera2body, F)
         w2c = _inverse_affine(c2b)
+        S_ = S
+        sub = 1 << subpixel_bits
+        self.mask = np.zeros((S, S), np.uint8)
+        self.depth = np.full((S, S), 65535, np.uint16)
+        self.normal = np.zeros((S, S, 4), np.uint8)
+        zbuf = np.full((S, S), np.inf)
+        self._covered = np.zeros((S, S), bool)
+        half = sub // 2
+        main = K_MAIN_BODY_ID if main_id is None else main_id
+        for drawn, body_id in [(body, main)] + list(others):
+            self._draw(drawn, body_id, P, w2c, S_, sub, half, zbuf, quant_bias)
+        cov = self._covered
+        self.depth[cov] = zbuf[cov].astype(np.uint16)
+
+    def _draw(self, body, body_id, P, w2c, S, sub, half, zbuf, quant_bias):
         twp = _mul44(w2c, body.geometry2body)
         trans = _mul44(P, twp)
         rot = twp[:3, :3]
@@ -223,13 +247,7 @@ class Render:
         win[:, 0] = (ndc[:, 0] + F(1.0)) * F(0.5 * S)
         win[:, 1] = (ndc[:, 1] + F(1.0)) * F(0.5 * S)
         win[:, 2] = (ndc[:, 2] + F(1.0)) * F(0.5)
-        sub = 1 << subpixel_bits
         snapped = np.floor(win[:, :2].astype(np.float64) * sub + 0.5).astype(np.int64)
-        self.mask = np.zeros((S, S), np.uint8)
-        self.depth = np.full((S, S), 65535, np.uint16)
-        self.normal = np.zeros((S, S, 4), np.uint8)
-        zbuf = np.full((S, S), np.inf)
-        half = sub // 2
         for f, (a, b, c) in enumerate(body.faces):
             xa, ya = snapped[a]
             xb, yb = snapped[b]
@@ -276,13 +294,12 @@ class Render:
             zq16 = np.floor(z * 65535.0 + 0.5 - quant_bias)
             closer = inside & (zq16 < zbuf[sl])
             zbuf[sl][closer] = zq16[closer]
-            self.mask[sl][closer] = K_MAIN_BODY_ID
+            self.mask[sl][closer] = body_id
+            self._covered[sl][closer] = True
             n_cam = (rot @ body.normals[f]).astype(F)
             col = np.float64(0.5) - np.float64(0.5) * n_cam.astype(np.float64)
             rgba = np.floor(np.clip(col, 0, 1) * 255.0 + 0.5 - quant_bias).astype(np.uint8)
             self.normal[sl][closer] = (rgba[0], rgba[1], rgba[2], 255)
-        cov = self.mask > 0
-        self.depth[cov] = zbuf[cov].astype(np.uint16)
 
     def depth_of_value(self, value):
         return self.term_a / (self.term_b - F(value))
@@ -411,11 +428,17 @@ def depth_offsets(r, x, y, pixel_to_meter, max_radius_depth_offset, stride_depth
 
 
 def depth_view(body, camera2body, sphere_radius, n_points, image_size, max_radius_depth_offset=0.05,
-               stride_depth_offset=0.002, **render_kw):
-    """DepthModel::GeneratePointData depth_model.cpp:302-351"""
+               stride_depth_offset=0.002, occlusion_bodies=(), **render_kw):
+    """DepthModel::GeneratePointData depth_model.cpp:302-351.  occlusion_bodies: ConvexBody list; the surface is
+    sampled where the occlusion renderer (main body id 255, occlusion bodies id 0 = background,
+    depth_model.cpp:170-177) still shows the main body, depths and normals come from the main renderer"""
     r = Render(body, camera2body, sphere_radius, image_size, **render_kw)
+    occlusion = r if not occlusion_bodies else Render(body, camera2body, sphere_radius, image_size,
+                                                      others=[(o, K_BACKGROUND_ID) for o in occlusion_bodies],
+                                                      **render_kw)
+    silhouette = occlusion.mask
     c2b = np.asarray(camera2body, F)
-    n_pix = int(np.count_nonzero(r.mask))
+    n_pix = int(np.count_nonzero(silhouette))
     area = F(n_pix) * F(F(sphere_radius) / r.fu) ** 2
     pts = np.zeros((n_points, DEPTH_POINT_FLOATS), F)
     if n_pix == 0:
@@ -426,7 +449,7 @@ def depth_view(body, camera2body, sphere_radius, n_points, image_size, max_radiu
         while True:
             idx = next(gen) % total
             x, y = idx // image_size, idx % image_size
-            if r.mask[y, x]:
+            if silhouette[y, x]:
                 break
         pc = r.point_vector(x, y)
         nc = r.normal_vector(x, y)

@@ -4,6 +4,8 @@ is mounted; the GPU box has no /root/reference).  Data files only — no sources
 
 Provenance (all under /root/reference/M3T/data/):
   model_test/{region,depth}_model.bin      RegionModelTest/DepthModelTest goldens (test/model_test.cpp:165-184)
+  model_test/depth_model_occlusion.bin, multi_region_model_{fixed,movable,same}.bin   the ValidationRule* goldens of
+                                           models with associated bodies (test/model_test.cpp:232-320,508-538)
   modality_test/*_{gradient,hessian}.txt   modality g/H goldens (test/modality_test.cpp:280-316,534-550)
   modality_test/region_modality.png        lines-correspondence visualisation golden (test/modality_test.cpp:180-193)
   modality_test/*measured_occlusions.png, depth_modality.png   visualisation goldens with / without measured
@@ -26,7 +28,9 @@ import shutil
 SRC = "/root/reference/M3T/data"
 DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference")
 FILES = [
-    "model_test/region_model.bin", "model_test/depth_model.bin", "model_test/region_model.yaml",
+    "model_test/region_model.bin", "model_test/depth_model.bin", "model_test/depth_model_occlusion.bin",
+    "model_test/multi_region_model_fixed.bin", "model_test/multi_region_model_movable.bin",
+    "model_test/multi_region_model_same.bin", "model_test/region_model.yaml",
     "model_test/depth_model.yaml",
     "modality_test/region_modality_global_gradient.txt", "modality_test/region_modality_global_hessian.txt",
     "modality_test/region_modality_local_gradient.txt", "modality_test/region_modality_local_hessian.txt",

@@ -88,3 +88,30 @@ def test_triangle_views_fixture_is_reproducible():
     for k in ("region_views", "region_points", "region_orientations", "region_contour_lengths", "depth_views",
               "depth_points", "depth_orientations", "depth_surface_areas"):
         assert np.array_equal(out[k], ref[k]), k
+
+
+def test_depth_views_with_an_occlusion_body_match_reference_model(schauma):
+    """DepthModelTest.ValidationRuleOcclusionBody (test/model_test.cpp:508-538): the bottle with the triangle prism
+    as occlusion body, its geometry shifted by (0, 0.05, -0.01) — data/model_test/depth_model_occlusion.bin, all
+    12 views.  Associated bodies share the main body's frame (Model::AddBodiesToRenderer centres every body,
+    model.cpp:164-192) and only take surface away: silhouette pixel counts exact, sampled points as above."""
+    m = g.read_model_bin(os.path.join(util.GOLDEN, "model_test/depth_model_occlusion.bin"), False)
+    assert (m["n_divides"], m["n_points"], m["image_size"]) == (0, 10, 500)
+    occluder = g.ConvexBody(os.path.join(util.GOLDEN, "_body/triangle.obj"),
+                            [[1, 0, 0, 0], [0, 1, 0, 0.05], [0, 0, 1, -0.006 - 0.01], [0, 0, 0, 1]])
+    poses = g.geodesic_poses(m["n_divides"], m["sphere_radius"])
+    assert len(poses) == 12 == len(m["orientations"])
+    n_occluded_views = 0
+    for v in range(12):
+        pts, ori, area, r = g.depth_view(schauma, poses[v], m["sphere_radius"], m["n_points"], m["image_size"],
+                                         m["max_radius_depth_offset"], m["stride_depth_offset"],
+                                         occlusion_bodies=[occluder])
+        ref = m["points"][v]
+        p2m2 = (m["sphere_radius"] / r.fu) ** 2
+        assert round(float(area / p2m2)) == round(float(m["extents"][v] / p2m2))  # silhouette pixel count
+        n_occluded_views += int(round(float(area / p2m2)) < int(np.count_nonzero(r.mask)))
+        assert np.array_equal(ori, m["orientations"][v])
+        assert np.abs(pts[:, :3] - ref[:, :3]).max() < DEPTH_LSB
+        assert np.abs(pts[:, 3:6] - ref[:, 3:6]).max() < 1.01 * NORMAL_LSB
+        assert np.abs(pts[:, 6:] - ref[:, 6:]).max() < 2 * DEPTH_LSB
+    assert n_occluded_views >= 4  # the prism does hide part of the bottle from several directions
