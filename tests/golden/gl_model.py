@@ -29,6 +29,7 @@ N_DEPTH_OFFSETS = 30
 K_CONTOUR_NORMAL_APPROX_RADIUS = 3  # region_model.h:62
 K_MIN_CONTOUR_LENGTH = 15           # region_model.h:63
 K_MAX_POINT_SAMPLING_TRIES = 100    # region_model.h:64
+K_MAX_SURFACE_GRADIENT = 10.0       # region_model.h:65
 K_IMAGE_SIZE_SAFETY_BOUNDARY = 20   # model.h:57
 FLT_MAX = np.finfo(np.float32).max
 
@@ -466,14 +467,49 @@ def _closest_contour_point(cont_xy, u, v):
 
 
 def region_view(body, camera2body, sphere_radius, n_points, image_size, max_radius_depth_offset=0.05,
-                stride_depth_offset=0.002, **render_kw):
-    """RegionModel::GeneratePointData region_model.cpp:457-555 (single body: no associated renderers)"""
-    r = Render(body, camera2body, sphere_radius, image_size, **render_kw)
+                stride_depth_offset=0.002, fixed=(), movable=(), fixed_same_region=(), movable_same_region=(),
+                **render_kw):
+    """RegionModel::GeneratePointData region_model.cpp:479-555.  The four lists are the associated bodies
+    (ConvexBody) of RegionModel::AddAssociatedBody; the renderers and ids are those of GenerateModel :207-213 and
+    AddBodiesToAssociatedRenderers :417-463."""
+    M, B, D = K_MAIN_BODY_ID, K_BACKGROUND_ID, K_DIFFERENT_BODY_ID
+
+    def render(main_id, *groups):
+        return Render(body, camera2body, sphere_radius, image_size, main_id=main_id,
+                      others=[(b, i) for bodies, i in groups for b in bodies], **render_kw)
+
+    r = render(M, (fixed, D))
+    occlusion = render(B, (fixed, B), (movable, M)) if movable else None
+    same_region = render(B, (fixed, B), (fixed_same_region, M), (movable_same_region, M)) \
+        if (fixed_same_region or movable_same_region) else None
+    if movable or fixed_same_region or movable_same_region:
+        foreground = render(M, (fixed, B), (movable, B), (fixed_same_region, M)).mask
+        background = render(M, (fixed, B), (fixed_same_region, M), (movable_same_region, M)).mask
+    else:
+        foreground = background = r.mask
     c2b = np.asarray(camera2body, F)
     pts = np.zeros((n_points, REGION_POINT_FLOATS), F)
-    contours = [c for c in find_contours(r.mask) if len(c) >= K_MIN_CONTOUR_LENGTH]
-    valid = [p for c in contours for p in c]  # IsContourPointValid is always true for a single body
+    # GenerateValidContours :556-596: everything except the main body black, then cv::findContours
+    contours = [c for c in find_contours((r.mask == M).astype(np.uint8) * M) if len(c) >= K_MIN_CONTOUR_LENGTH]
     pixel_to_meter = F(sphere_radius) / r.fu
+    max_depth_difference = pixel_to_meter * F(K_MAX_SURFACE_GRADIENT)
+
+    def contour_point_valid(x, y):  # IsContourPointValid :598-640
+        neighbours = ((x, y + 1), (x, y - 1), (x + 1, y), (x - 1, y))
+        if same_region is not None and any(same_region.mask[v, u] != B for u, v in neighbours):
+            return False
+        if occlusion is not None and occlusion.mask[y, x] != B:
+            return False
+        depths = [r.depth_at(u, v) for u, v in neighbours if r.mask[v, u] == D]
+        if depths:
+            total = F(0.0)
+            for d in depths:
+                total = F(total + d)
+            if F(total / F(len(depths))) < F(r.depth_at(x, y) - max_depth_difference):
+                return False
+        return True
+
+    valid = [p for c in contours for p in c if contour_point_valid(*p)]
     contour_length = F(len(valid)) * pixel_to_meter
     if not valid:
         return pts, c2b[:3, 2].copy(), F(0.0), r
@@ -524,7 +560,7 @@ def region_view(body, camera2body, sphere_radius, n_points, image_size, max_radi
         while True:
             u_in = F(u_in - u_step)
             v_in = F(v_in - v_step)
-            if r.mask[int(v_in), int(u_in)] != K_MAIN_BODY_ID:
+            if foreground[int(v_in), int(u_in)] != K_MAIN_BODY_ID:
                 q = _closest_contour_point(all_xy, u_in + u_step - F(0.5), v_in + v_step - F(0.5))
                 pts[i, 6] = p2m * F(np.hypot(F(q[0] - cx), F(q[1] - cy)))
                 break
@@ -534,7 +570,7 @@ def region_view(body, camera2body, sphere_radius, n_points, image_size, max_radi
             if int(u_out) < 0 or int(u_out) >= image_size or int(v_out) < 0 or int(v_out) >= image_size:
                 pts[i, 7] = FLT_MAX
                 break
-            if r.mask[int(v_out), int(u_out)] == K_MAIN_BODY_ID:
+            if background[int(v_out), int(u_out)] == K_MAIN_BODY_ID:
                 q = _closest_contour_point(all_xy, u_out - F(0.5), v_out - F(0.5))
                 pts[i, 7] = p2m * F(np.hypot(F(q[0] - cx), F(q[1] - cy)))
                 break

@@ -115,3 +115,70 @@ def test_depth_views_with_an_occlusion_body_match_reference_model(schauma):
         assert np.abs(pts[:, 3:6] - ref[:, 3:6]).max() < 1.01 * NORMAL_LSB
         assert np.abs(pts[:, 6:] - ref[:, 6:]).max() < 2 * DEPTH_LSB
     assert n_occluded_views >= 4  # the prism does hide part of the bottle from several directions
+
+
+# camera2body poses of RegionModelTest.ValidationRule{Fixed,Movable,SameRegion}Body and the max_error of their
+# CompareViewData (test/model_test.cpp:232-320)
+MULTI_REGION = {
+    "fixed": ([[0, -0.273266, 0.961938, -0.384775], [0, 0.961938, 0.273266, -0.109307], [-1, 0, 0, 0], [0, 0, 0, 1]], 1e-5),
+    "movable": ([[-0.525731, -0.262866, 0.809017, -0.323607], [0, 0.951056, 0.309017, -0.123607],
+                 [-0.850651, 0.16246, -0.5, 0.2], [0, 0, 0, 1]], 1e-5),
+    "same": ([[0.810147, -0.403436, 0.425325, -0.17013], [0, 0.72553, 0.688191, -0.275276],
+              [-0.586227, -0.557535, 0.587785, -0.235114], [0, 0, 0, 1]], 2e-5),
+}
+
+
+@pytest.mark.parametrize("kind", ["fixed", "movable", "same"])
+def test_region_views_with_associated_bodies_match_reference_models(schauma, kind):
+    """RegionModelTest.ValidationRule*Body: the bottle with the triangle prism as a fixed body (drawn with
+    kDifferentBodyID into the main rendering), a movable body (occlusion + foreground / background renderings) or a
+    fixed same-region body (same-region + foreground / background renderings), data/model_test/
+    multi_region_model_{fixed,movable,same}.bin, all 12 views: number of valid contour pixels exact, every sampled
+    point the same pixel; on the view the reference test looks at, its own criterion (CompareViewData)."""
+    import struct
+    path = os.path.join(util.GOLDEN, "model_test", "multi_region_model_%s.bin" % kind)
+    m = g.read_model_bin(path, True)
+    assert (m["n_divides"], m["n_points"], m["image_size"]) == (0, 10, 500)
+    # the associated bodies as the file records them: four groups in the order fixed, fixed same-region, movable,
+    # movable same-region (region_model.cpp:329-344), each with its geometry2body pose
+    raw = open(path, "rb").read()
+    cfg = util.pkg.config
+    _, off = cfg.BodyData.unpack(raw, 30)
+    off += 8
+    groups = {}
+    for key in ("fixed", "fixed_same_region", "movable", "movable_same_region"):
+        (n,) = struct.unpack_from("<Q", raw, off)
+        off += 8
+        groups[key] = []
+        for _ in range(n):
+            data, off = cfg.BodyData.unpack(raw, off)
+            assert data.geometry_path.endswith("triangle.obj")
+            groups[key].append(g.ConvexBody(os.path.join(util.GOLDEN, "_body/triangle.obj"), data.geometry2body_pose))
+    assert [len(groups[k]) for k in groups] == {"fixed": [1, 0, 0, 0], "same": [0, 1, 0, 0], "movable": [0, 0, 1, 0]}[kind]
+
+    poses = g.geodesic_poses(m["n_divides"], m["sphere_radius"])
+    camera2body, max_error = MULTI_REGION[kind]
+    direction = np.asarray(camera2body, np.float32)[:3, 2]
+    reference_view = int(np.argmax([np.dot(p[:3, 2], direction) for p in poses]))  # GetClosestView
+    single_body_counts = []
+    for v in range(12):
+        pts, ori, length, r = g.region_view(schauma, poses[v], m["sphere_radius"], m["n_points"], m["image_size"],
+                                            m["max_radius_depth_offset"], m["stride_depth_offset"], **groups)
+        ref = m["points"][v]
+        p2m = m["sphere_radius"] / r.fu
+        assert round(float(length / p2m)) == round(float(m["extents"][v] / p2m))  # valid contour pixels
+        single_body_counts.append(sum(len(c) for c in g.find_contours((r.mask == g.K_MAIN_BODY_ID).astype(np.uint8))
+                                      if len(c) >= g.K_MIN_CONTOUR_LENGTH))
+        assert np.array_equal(ori, m["orientations"][v])
+        finite = ref[:, 7] != g.FLT_MAX
+        assert np.array_equal(pts[:, 7] == g.FLT_MAX, ~finite)
+        errors = [np.abs(pts[:, :3] - ref[:, :3]).max(), np.abs(pts[:, 3:6] - ref[:, 3:6]).max(),
+                  np.abs(pts[:, 6] - ref[:, 6]).max(), np.abs(pts[finite, 7] - ref[finite, 7]).max(initial=0),
+                  np.abs(pts[:, 8:] - ref[:, 8:]).max()]
+        assert errors[0] < 2 * DEPTH_LSB and errors[1] < 3e-7 and errors[2] < 2e-6 and errors[3] < 2e-6
+        assert errors[4] < 3 * DEPTH_LSB  # a difference of two depths of the wider clip range
+        if v == reference_view:
+            assert max(errors) <= max_error
+    if kind != "fixed":  # the associated body does invalidate contour pixels of some views
+        lengths = [round(float(e / (m["sphere_radius"] / r.fu))) for e in m["extents"]]
+        assert sum(int(a < b) for a, b in zip(lengths, single_body_counts)) >= 3
