@@ -5,7 +5,7 @@
 // depth16 << 32 | triangle so that the flat normal of the visible triangle is known); the per-view
 // sampling (cv::findContours border following, std::mt19937{7} draws, contour normals, line
 // distances, depth offsets) runs on the host, a few hundred points per view.
-// The algorithm is the one prototyped in tests/golden/gl_model.py, which reproduces the reference's
+// The algorithm is the one restated in oracle/gl_model.py (numpy checker), which reproduces the reference's
 // own generated model files; tests/test_gpu_model_generation.py compares this implementation with
 // those files and with gl_model.py.  Included by m3t_hip_api.hip after m3t_render.hip.
 #ifndef M3T_MODELGEN_HIP_

@@ -316,12 +316,11 @@ def extras_point(pkg):
     Region + Depth modality with region checking, silhouette checking and modelled occlusions behind the
     20 950-triangle bottle (4 focused renderers, refreshed before each of the 7 correspondence searches)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    import gl_model
     import golden_scene as gs
     import util
     from util import host
     api = pkg.open_context(0)
-    tv, tf = gl_model.load_obj(os.path.join(util.GOLDEN, "_body/triangle.obj"))
+    tv, tf = pkg.config.load_obj(os.path.join(util.GOLDEN, "_body/triangle.obj"))
     body = host.Body(api, gs.mtv.body2world())
     body.set_geometry(tv, tf, np.asarray(gs.mtv.GEOMETRY2BODY, np.float32), body_id=150, region_id=150)
     t0 = time.perf_counter()

@@ -12,7 +12,6 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-import gl_model as g  # noqa: E402
 
 REF = os.path.join(HERE, "reference")
 # test/common_test.cpp:6-15 (world2body), data/_body/triangle.yaml (geometry2body)
@@ -46,6 +45,10 @@ N_VIEWS = 5  # the closest view and the neighbours a tracking step can switch to
 
 
 def generate():
+    # the checker is imported here, not at module level: the constants above are also read by bench.py's extras
+    # leg (through tests/golden_scene.py), which must not load anything under oracle/
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    import gl_model as g
     body = g.ConvexBody(os.path.join(REF, "_body/triangle.obj"), GEOMETRY2BODY)
     poses = g.geodesic_poses(N_DIVIDES, SPHERE_RADIUS)
     b2w = body2world().astype(np.float64)

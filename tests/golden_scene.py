@@ -10,6 +10,7 @@ import util
 from util import host
 
 sys.path.insert(0, os.path.join(util.ROOT, "tests", "golden"))
+sys.path.insert(0, os.path.join(util.ROOT, "oracle"))
 import make_triangle_views as mtv  # noqa: E402
 
 
@@ -174,9 +175,9 @@ SCHAUMA_GEOMETRY2BODY = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, -0.097],
 def fixture_renderer_geometry(api, triangle_body):
     """RendererGeometry holding the triangle (body id 150, region id 150) and the schauma bottle
     (body id 50, region id 150), data/_body/{triangle,schauma}.yaml"""
-    import gl_model
-    tv, tf = gl_model.load_obj(os.path.join(util.GOLDEN, "_body/triangle.obj"))
-    sv, sf = gl_model.load_obj(os.path.join(util.GOLDEN, "_body/schauma.obj"))
+    load_obj = util.pkg.config.load_obj  # (bench.py's extras leg comes through here: no checker code on that path)
+    tv, tf = load_obj(os.path.join(util.GOLDEN, "_body/triangle.obj"))
+    sv, sf = load_obj(os.path.join(util.GOLDEN, "_body/schauma.obj"))
     triangle_body.set_geometry(tv, tf, np.asarray(mtv.GEOMETRY2BODY, np.float32), body_id=150, region_id=150)
     schauma = host.Body(api, np.linalg.inv(SCHAUMA_WORLD2BODY.astype(np.float64)).astype(np.float32))
     schauma.set_geometry(sv, sf, SCHAUMA_GEOMETRY2BODY, body_id=50, region_id=150)

@@ -12,6 +12,7 @@ import pytest
 import util
 
 sys.path.insert(0, os.path.join(util.ROOT, "tests", "golden"))
+sys.path.insert(0, os.path.join(util.ROOT, "oracle"))
 import gl_model  # noqa: E402
 import golden_scene as gs  # noqa: E402
 

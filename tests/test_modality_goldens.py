@@ -2,7 +2,7 @@
 tracker goldens (test/modality_test.cpp:180-193,222-248,280-316,433-456,486-502,534-550,
 test/optimizer_test.cpp:97-105, test/tracker_test.cpp:164-178, test/refiner_test.cpp:96-105).  The
 models those goldens were made with are not shipped; they are regenerated without OpenGL by
-tests/golden/gl_model.py (validated against the reference's own model files in
+oracle/gl_model.py (validated against the reference's own model files in
 test_model_generation.py) and committed as tests/golden/triangle_views.npz.
 
 Everything except the refiner pose meets the reference's own criteria: gradients and Hessians 1e-3

@@ -1,4 +1,4 @@
-"""tests/golden/gl_model.py (OpenGL-free sparse-viewpoint-model generation) against
+"""oracle/gl_model.py (OpenGL-free sparse-viewpoint-model generation) against
 the reference's own generated models data/model_test/{region,depth}_model.bin (schauma bottle,
 n_divides 2, 10 points per view, image_size 500; RegionModelTest / DepthModelTest
 GenerateAndLoadModel, test/model_test.cpp:165-184): view orientations bit-exact, silhouette pixel
@@ -13,6 +13,7 @@ import pytest
 import util
 
 sys.path.insert(0, os.path.join(util.ROOT, "tests", "golden"))
+sys.path.insert(0, os.path.join(util.ROOT, "oracle"))
 import gl_model as g  # noqa: E402
 import make_triangle_views as mtv  # noqa: E402
 
