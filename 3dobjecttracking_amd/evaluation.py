@@ -203,3 +203,73 @@ def evaluate_ycb_sequence(tracker, bodies, evaluations, gt_body2world_poses, key
                              adds_curve=np.mean([r["adds_curve"] for r in rs], axis=0),
                              complete_cycle=float(np.mean([r["complete_cycle"] for r in rs])))
     return results, average
+
+
+# ---------------------------------------------------------------------------------------------------------
+# RBOT dataset driver (examples/evaluate_rbot_dataset.cpp + rbot_evaluator.cpp)
+# ---------------------------------------------------------------------------------------------------------
+RBOT_INTRINSICS = (650.048, 647.183, 324.328 - 0.5, 257.323 - 0.5, 640, 512)  # rbot_evaluator.h:40-41
+RBOT_BODY_NAMES = ("ape", "bakingsoda", "benchviseblue", "broccolisoup", "cam", "can", "cat", "clown", "cube", "driller",
+                   "duck", "eggbox", "glue", "iron", "koalacandy", "lamp", "phone", "squirrel")
+RBOT_SEQUENCE_NAMES = ("a_regular", "b_dynamiclight", "c_noisy", "d_occlusion")
+RBOT_REGION_PARAMETERS = dict(  # evaluate_rbot_dataset.cpp:25-44, rbot_evaluator.cpp:267
+    n_lines_max=200, use_adaptive_coverage=0, min_continuous_distance=3.0, function_length=8, distribution_length=12,
+    function_amplitude=0.36, function_slope=0.0, learning_rate=1.3, scales=[5, 2, 2, 1],
+    standard_deviations=[20.0, 7.0, 3.0, 1.5], n_histogram_bins=32, learning_rate_f=0.2, learning_rate_b=0.2,
+    unconsidered_line_length=0.5, max_considered_line_length=20.0, n_unoccluded_iterations=0)
+RBOT_MODEL_PARAMETERS = dict(sphere_radius=0.8, n_divides=4, n_points=200, max_radius_depth_offset=0.01,
+                             stride_depth_offset=0.002, use_random_seed=False, image_size=2000)  # :548-551
+
+
+def evaluate_rbot_dataset(open_context, dataset_directory, external_directory, body_names=RBOT_BODY_NAMES,
+                          sequence_names=RBOT_SEQUENCE_NAMES, n_frames=1000, region_parameters=None,
+                          model_parameters=None, tikhonov_parameter_rotation=1000.0,
+                          tikhonov_parameter_translation=30000.0, n_corr_iterations=7, n_update_iterations=2,
+                          report=None):
+    """RBOTEvaluator::SetUp + Evaluate for the region modality on the un-modelled sequences: for every (sequence,
+    body) a tracker on `dataset/<body>/frames/<sequence>NNNN.png`, started at `dataset/poses_first.txt`, reset on
+    loss, scored with the 5 cm / 5 degree criterion.  Bodies are `dataset/<body>/<body>.obj` in millimetres
+    (LoadSingleBody :527-535), their region models `external/models/<body>_model.bin` — generated on the device
+    when missing or made with other parameters (GenerateSingleModel :546-556).  `open_context()` returns a fresh
+    device context per run (one tracker per context).  Returns {(sequence, body): average result} and the overall
+    average (CalculateAverageResult); `report`, if given, is called with each run's title and result."""
+    import os
+
+    from . import config as cfg
+    from . import generator, host
+    poses_first = read_poses_rbot(os.path.join(dataset_directory, "poses_first.txt"), n_frames)
+    region_parameters = dict(RBOT_REGION_PARAMETERS, **(region_parameters or {}))
+    model_parameters = dict(RBOT_MODEL_PARAMETERS, **(model_parameters or {}))
+    results = {}
+    for sequence in sequence_names:
+        for name in body_names:
+            api = open_context()
+            body = generator.Body(api, name, os.path.join(dataset_directory, name, name + ".obj"), 0.001, True, False,
+                                  np.eye(4, dtype=F))
+            model_path = os.path.join(external_directory, "models", name + "_model.bin")
+            if cfg.model_bin_matches(model_path, True, model_parameters, body.body_data()):
+                model = host.RegionModel(api, path=model_path)
+            else:
+                generation = {k: v for k, v in model_parameters.items() if k != "use_random_seed"}
+                model = host.RegionModel.generate(api, body, **generation)
+                cfg.write_model_bin(model_path, True, model_parameters, body.body_data(), *model.views())
+            camera = generator.LoaderColorCamera(api, os.path.join(dataset_directory, name, "frames"), RBOT_INTRINSICS,
+                                                 sequence, 0, 4)
+            modality = host.RegionModality(api, body, camera, model, **region_parameters)
+            host.Optimizer(api, body=body, modalities=[modality],
+                           tikhonov_parameter_rotation=tikhonov_parameter_rotation,
+                           tikhonov_parameter_translation=tikhonov_parameter_translation)
+            tracker = host.Tracker(api, n_corr_iterations, n_update_iterations)
+
+            def load_image(k, camera=camera):
+                camera.set_load_index(k)
+                if not camera.UpdateImage():
+                    raise RuntimeError("Could not read image from %s" % camera.image_path())
+
+            _, average = evaluate_rbot_sequence(tracker, body, poses_first, load_image, n_frames)
+            results[(sequence, name)] = average
+            if report is not None:
+                report(sequence + "_" + name, average)
+    keys = ("translation_error", "rotation_error", "tracking_success", "complete_cycle")
+    overall = {k: float(np.mean([r[k] for r in results.values()])) for k in keys}
+    return results, overall

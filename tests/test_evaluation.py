@@ -122,3 +122,56 @@ def test_ycb_loop_on_a_synthetic_sequence():
         assert max(r["adds_error"] for r in results[n]) < 5e-3
         assert average[n]["adds_auc"] > 0.95 and average[n]["add_auc"] > 0.9
         assert average[n]["adds_curve"][-1] == 1.0 and average[n]["adds_curve"].shape == (100,)
+
+
+def test_rbot_dataset_driver_on_a_synthetic_dataset_in_the_rbot_layout(tmp_path):
+    """evaluate_rbot_dataset (examples/evaluate_rbot_dataset.cpp): bodies as <dataset>/<body>/<body>.obj in mm,
+    frames <dataset>/<body>/frames/<sequence>NNNN.png, one poses_first.txt for all bodies, models under
+    <external>/models/ — a two-body, one-sequence, five-frame dataset of the synthetic scenes, tracked by the oracle"""
+    from PIL import Image
+    cfg = util.pkg.config
+    n_frames = 5
+    dataset, external = tmp_path / "RBOT_dataset", tmp_path / "external"
+    scenes_ = [util.syn.Scene(i, intr=dict(zip(("fu", "fv", "ppu", "ppv", "width", "height"), ev.RBOT_INTRINSICS)))
+               for i in range(2)]
+    trajectory = [scenes_[0].pose.copy()]
+    for _ in range(n_frames):
+        scenes_[0].step_pose()
+        trajectory.append(scenes_[0].pose.copy())
+    with open(dataset.parent / "poses.tmp", "w") as f:
+        f.write("header\n")
+        for p in trajectory:
+            f.write("\t".join("%.9g" % v for v in list(p[:3, :3].reshape(-1)) + list(p[:3, 3] * 1000.0)) + "\n")
+    os.makedirs(dataset)
+    os.replace(dataset.parent / "poses.tmp", dataset / "poses_first.txt")
+    model_parameters = dict(ev.RBOT_MODEL_PARAMETERS, n_divides=2)
+    octahedron = [(60, 0, 0), (-60, 0, 0), (0, 50, 0), (0, -50, 0), (0, 0, 40), (0, 0, -40)]
+    faces = [(1, 3, 5), (3, 2, 5), (2, 4, 5), (4, 1, 5), (3, 1, 6), (2, 3, 6), (4, 2, 6), (1, 4, 6)]
+    names = ["ape", "cat"]
+    for name, scene in zip(names, scenes_):
+        os.makedirs(dataset / name / "frames")
+        with open(dataset / name / (name + ".obj"), "w") as f:
+            f.writelines("v %d %d %d\n" % v for v in octahedron)
+            f.writelines("f %d %d %d\n" % t for t in faces)
+        for k, p in enumerate(trajectory):
+            Image.fromarray(np.ascontiguousarray(scene.render(p)[:, :, ::-1])).save(
+                dataset / name / "frames" / ("a_regular%04d.png" % k))
+        # the model the device would generate from the mesh, here the synthetic body's (the oracle cannot generate)
+        points, orientations, lengths = util.syn.make_region_model(scene.body, n_divides=2, n_points=200)
+        vertices, _ = cfg.load_obj(str(dataset / name / (name + ".obj")), 0.001)
+        data = cfg.BodyData(str(dataset / name / (name + ".obj")), 0.001, True, False,
+                            cfg.maximum_body_diameter(vertices), np.eye(4))
+        cfg.write_model_bin(str(external / "models" / (name + "_model.bin")), True, model_parameters, data, points,
+                            orientations, lengths)
+    titles = []
+    results, overall = ev.evaluate_rbot_dataset(util.open_oracle, str(dataset), str(external), names, ["a_regular"],
+                                                n_frames=n_frames, model_parameters=model_parameters,
+                                                report=lambda title, r: titles.append(title))
+    assert titles == ["a_regular_ape", "a_regular_cat"] and set(results) == {("a_regular", "ape"), ("a_regular", "cat")}
+    for r in results.values():
+        assert r["tracking_success"] == 1.0 and r["translation_error"] < 5e-3 and r["rotation_error"] < np.deg2rad(2)
+    assert overall["tracking_success"] == 1.0
+    # a model made with other parameters is not accepted, and the oracle context cannot replace it
+    with pytest.raises(util.pkg.M3TError):
+        ev.evaluate_rbot_dataset(util.open_oracle, str(dataset), str(external), names[:1], ["a_regular"],
+                                 n_frames=n_frames)
