@@ -273,3 +273,144 @@ def evaluate_rbot_dataset(open_context, dataset_directory, external_directory, b
     keys = ("translation_error", "rotation_error", "tracking_success", "complete_cycle")
     overall = {k: float(np.mean([r[k] for r in results.values()])) for k in keys}
     return results, overall
+
+
+# ---------------------------------------------------------------------------------------------------------
+# YCB-Video dataset driver (examples/evaluate_ycb_dataset.cpp + ycb_evaluator.cpp), without refinement, without
+# modelled occlusions, single-region models
+# ---------------------------------------------------------------------------------------------------------
+YCB_INTRINSICS = (1066.778, 1067.487, 312.9869, 241.3109, 640, 480)  # ycb_evaluator.h:47-48
+YCB_REGION_PARAMETERS = dict(  # evaluate_ycb_dataset.cpp:46-65
+    n_lines_max=200, use_adaptive_coverage=0, min_continuous_distance=3.0, function_length=8, distribution_length=12,
+    function_amplitude=0.43, function_slope=0.5, learning_rate=1.3, scales=[7, 4, 2],
+    standard_deviations=[25.0, 15.0, 10.0], n_histogram_bins=16, learning_rate_f=0.2, learning_rate_b=0.2,
+    unconsidered_line_length=0.5, max_considered_line_length=20.0, measured_depth_offset_radius=0.01,
+    measured_occlusion_radius=0.01, measured_occlusion_threshold=0.03, n_unoccluded_iterations=0)
+YCB_DEPTH_PARAMETERS = dict(  # evaluate_ycb_dataset.cpp:66-76
+    n_points_max=200, use_adaptive_coverage=0, use_depth_scaling=0, stride_length=0.005,
+    considered_distances=[0.07, 0.05, 0.04], standard_deviations=[0.05, 0.03, 0.02],
+    measured_depth_offset_radius=0.01, measured_occlusion_radius=0.01, measured_occlusion_threshold=0.03,
+    n_unoccluded_iterations=0)
+YCB_MODEL_PARAMETERS = dict(sphere_radius=0.8, n_divides=4, n_points=500, max_radius_depth_offset=0.05,
+                            stride_depth_offset=0.002, use_random_seed=False, image_size=2000)  # :1131-1146
+
+
+def ycb_sequence_name(sequence_id):
+    return "%04d" % sequence_id  # SequenceIDToName :1312-1315
+
+
+def ycb_keyframes(dataset_directory, sequence_name):
+    """LoadKeyframes :1150-1183: image_sets/keyframe.txt holds lines '<sequence>/<frame>'"""
+    import os
+    frames = []
+    with open(os.path.join(dataset_directory, "image_sets", "keyframe.txt")) as f:
+        for line in f:
+            sequence, _, frame = line.strip().partition("/")
+            if sequence == sequence_name and frame:
+                frames.append(int(frame))
+    return frames
+
+
+def ycb_sequence_bodies(dataset_directory, sequence_name):
+    """SequenceBodyNames / BodyExistsInSequence :1262-1300: the first word of every line of 000001-box.txt"""
+    import os
+    with open(os.path.join(dataset_directory, "data", sequence_name, "000001-box.txt")) as f:
+        return [line.split(" ")[0] for line in f if line.strip()]
+
+
+def ycb_n_frames(dataset_directory, sequence_name):
+    """NFramesInSequence :1302-1310"""
+    import os
+    i = 1
+    while os.path.exists(os.path.join(dataset_directory, "data", sequence_name, "%06d-box.txt" % i)):
+        i += 1
+    return i - 1
+
+
+def read_matlab_poses_ycb(path):
+    """LoadMatlabGTPoses :903-944: one 'qw qx qy qz tx ty tz' line per keyframe"""
+    with open(path) as f:
+        return np.asarray([_quaternion_pose(*[float(x) for x in line.split(" ")[:7]]) for line in f if line.strip()], F)
+
+
+def evaluate_ycb_dataset(open_context, dataset_directory, external_directory, sequence_ids, body_names,
+                         use_matlab_gt_poses=True, n_vertices_evaluation=1000, region_parameters=None,
+                         depth_parameters=None, model_parameters=None, tikhonov_parameter_rotation=1000.0,
+                         tikhonov_parameter_translation=30000.0, n_corr_iterations=4, n_update_iterations=2,
+                         report=None):
+    """YCBEvaluator::SetUp + Evaluate with the region and the depth modality, measured occlusions, one run per
+    (sequence, body present in it) (CreateRunConfigurations :1006-1022): bodies `dataset/models/<body>/textured.obj`
+    in metres, frames `dataset/data/<sequence>/NNNNNN-{color,depth}.png` (depth scale 1e-4), keyframes from
+    `dataset/image_sets/keyframe.txt`, ground truth from `external/poses/ground_truth/<sequence>_<body>.txt` (or the
+    dataset's own `poses/<body>.txt`), models under `external/models/`.  Returns {(sequence, body): average} and
+    the averages over all frames of all runs (CalculateAverageResult)."""
+    import os
+
+    from . import config as cfg
+    from . import generator, host
+    region_parameters = dict(YCB_REGION_PARAMETERS, **(region_parameters or {}))
+    depth_parameters = dict(YCB_DEPTH_PARAMETERS, **(depth_parameters or {}))
+    model_parameters = dict(YCB_MODEL_PARAMETERS, **(model_parameters or {}))
+    generation = {k: v for k, v in model_parameters.items() if k != "use_random_seed"}
+    sequence_names = [ycb_sequence_name(i) for i in sequence_ids]
+    n_frames = {ycb_sequence_name(i): ycb_n_frames(dataset_directory, ycb_sequence_name(i))
+                for i in range(max(sequence_ids) + 1)
+                if os.path.isdir(os.path.join(dataset_directory, "data", ycb_sequence_name(i)))}
+    results, frame_results = {}, []
+    for sequence in sequence_names:
+        present = ycb_sequence_bodies(dataset_directory, sequence)
+        keyframes = ycb_keyframes(dataset_directory, sequence)
+        for name in body_names:
+            if name not in present:
+                continue
+            api = open_context()
+            body = generator.Body(api, name, os.path.join(dataset_directory, "models", name, "textured.obj"), 1.0, True,
+                                  True, np.eye(4, dtype=F))
+            models = []
+            for region, klass, suffix in ((True, host.RegionModel, "_region_model.bin"),
+                                          (False, host.DepthModel, "_depth_model.bin")):
+                path = os.path.join(external_directory, "models", name + suffix)
+                if cfg.model_bin_matches(path, region, model_parameters, body.body_data()):
+                    models.append(klass(api, path=path))
+                else:
+                    models.append(klass.generate(api, body, **generation))
+                    cfg.write_model_bin(path, region, model_parameters, body.body_data(), *models[-1].views())
+            directory = os.path.join(dataset_directory, "data", sequence)
+            color = generator.LoaderColorCamera(api, directory, YCB_INTRINSICS, "", 1, 6, "-color")
+            depth = generator.LoaderDepthCamera(api, directory, YCB_INTRINSICS, 0.0001, "", 1, 6, "-depth")
+            region_modality = host.RegionModality(api, body, color, models[0], depth_camera=depth, measure_occlusions=1,
+                                                  **region_parameters)
+            depth_modality = host.DepthModality(api, body, depth, models[1], measure_occlusions=1, **depth_parameters)
+            host.Optimizer(api, body=body, modalities=[region_modality, depth_modality],
+                           tikhonov_parameter_rotation=tikhonov_parameter_rotation,
+                           tikhonov_parameter_translation=tikhonov_parameter_translation)
+            tracker = host.Tracker(api, n_corr_iterations, n_update_iterations)
+            if use_matlab_gt_poses:
+                gt = read_matlab_poses_ycb(os.path.join(external_directory, "poses", "ground_truth",
+                                                        sequence + "_" + name + ".txt"))
+            else:  # the dataset's pose file: the body's frames of all earlier sequences come first (LoadPoseBegin)
+                begin = sum(n_frames[s] for s in sorted(n_frames) if s < sequence and
+                            name in ycb_sequence_bodies(dataset_directory, s))
+                gt = read_poses_ycb(os.path.join(dataset_directory, "poses", name + ".txt"), begin, n_frames[sequence],
+                                    keyframes)
+            if len(gt) < len(keyframes):
+                raise ValueError("ground truth of %s in sequence %s has %d poses for %d keyframes" %
+                                 (name, sequence, len(gt), len(keyframes)))
+
+            def update_cameras(frame, color=color, depth=depth):
+                for camera in (color, depth):
+                    camera.set_load_index(frame)
+                    if not camera.UpdateImage():
+                        raise RuntimeError("Could not read image from %s" % camera.image_path())
+
+            evaluation = YCBBodyEvaluation(body.vertices, n_vertices_evaluation)
+            per_frame, average = evaluate_ycb_sequence(tracker, {name: body}, {name: evaluation}, {name: gt}, keyframes,
+                                                       update_cameras)
+            results[(sequence, name)] = average[name]
+            frame_results += per_frame[name]
+            if report is not None:
+                report(sequence + ": " + name, average[name])
+    overall = dict(add_auc=float(np.mean([r["add_auc"] for r in frame_results])),
+                   adds_auc=float(np.mean([r["adds_auc"] for r in frame_results])),
+                   complete_cycle=float(np.mean([r["complete_cycle"] for r in frame_results])))
+    return results, overall

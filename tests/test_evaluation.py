@@ -175,3 +175,74 @@ def test_rbot_dataset_driver_on_a_synthetic_dataset_in_the_rbot_layout(tmp_path)
     with pytest.raises(util.pkg.M3TError):
         ev.evaluate_rbot_dataset(util.open_oracle, str(dataset), str(external), names[:1], ["a_regular"],
                                  n_frames=n_frames)
+
+
+def _pose_line(p):
+    """'qw qx qy qz tx ty tz' of a 4x4 pose (w >= 0)"""
+    m = np.asarray(p, np.float64)
+    w = np.sqrt(max(0.0, 1.0 + m[0, 0] + m[1, 1] + m[2, 2])) / 2.0
+    x, y, z = (m[2, 1] - m[1, 2]) / (4 * w), (m[0, 2] - m[2, 0]) / (4 * w), (m[1, 0] - m[0, 1]) / (4 * w)
+    return " ".join("%.9g" % v for v in (w, x, y, z, m[0, 3], m[1, 3], m[2, 3]))
+
+
+def test_ycb_dataset_driver_on_a_synthetic_dataset_in_the_ycb_layout(tmp_path):
+    """evaluate_ycb_dataset (examples/evaluate_ycb_dataset.cpp): models/<body>/textured.obj, data/<sequence>/
+    NNNNNN-{color,depth}.png + NNNNNN-box.txt, image_sets/keyframe.txt, ground truth per keyframe under
+    external/poses/ground_truth/ or per frame in the dataset's poses/<body>.txt — two sequences with one synthetic
+    body each, Region + Depth with measured occlusions on the oracle"""
+    from PIL import Image
+    cfg = util.pkg.config
+    dataset, external = tmp_path / "YCB-Video", tmp_path / "external"
+    intr = dict(zip(("fu", "fv", "ppu", "ppv", "width", "height"), ev.YCB_INTRINSICS))
+    names = ["002_master_chef_can", "003_cracker_box"]
+    keyframes = {"0000": [1, 2, 4, 5], "0001": [1, 3]}
+    n_frames = {"0000": 5, "0001": 3}
+    model_parameters = dict(ev.YCB_MODEL_PARAMETERS, n_divides=2, n_points=200)
+    octahedron = [(0.06, 0, 0), (-0.06, 0, 0), (0, 0.05, 0), (0, -0.05, 0), (0, 0, 0.04), (0, 0, -0.04)]
+    faces = [(1, 3, 5), (3, 2, 5), (2, 4, 5), (4, 1, 5), (3, 1, 6), (2, 3, 6), (4, 2, 6), (1, 4, 6)]
+    os.makedirs(dataset / "image_sets")
+    os.makedirs(dataset / "poses")
+    os.makedirs(external / "poses" / "ground_truth")
+    with open(dataset / "image_sets" / "keyframe.txt", "w") as f:
+        f.writelines("%s/%06d\n" % (s, k) for s in keyframes for k in keyframes[s])
+    for index, (sequence, name) in enumerate(zip(("0000", "0001"), names)):
+        scene = util.syn.Scene(index, intr=intr, with_depth=True, depth_scale=1e-4)
+        os.makedirs(dataset / "data" / sequence)
+        os.makedirs(dataset / "models" / name)
+        with open(dataset / "models" / name / "textured.obj", "w") as f:
+            f.writelines("v %g %g %g\n" % v for v in octahedron)
+            f.writelines("f %d %d %d\n" % t for t in faces)
+        poses = []
+        for k in range(1, n_frames[sequence] + 1):
+            if k > 1:
+                scene.step_pose()
+            poses.append(scene.pose.copy())
+            color, depth = scene.render()
+            Image.fromarray(np.ascontiguousarray(color[:, :, ::-1])).save(dataset / "data" / sequence / ("%06d-color.png" % k))
+            Image.fromarray(depth).save(dataset / "data" / sequence / ("%06d-depth.png" % k))
+            (dataset / "data" / sequence / ("%06d-box.txt" % k)).write_text("%s 10.0 20.0 110.0 120.0\n" % name)
+        (dataset / "poses" / (name + ".txt")).write_text("".join(_pose_line(p) + "\n" for p in poses))
+        (external / "poses" / "ground_truth" / ("%s_%s.txt" % (sequence, name))).write_text(
+            "".join(_pose_line(poses[k - 1]) + "\n" for k in keyframes[sequence]))
+        vertices, _ = cfg.load_obj(str(dataset / "models" / name / "textured.obj"))
+        data = cfg.BodyData(str(dataset / "models" / name / "textured.obj"), 1.0, True, True,
+                            cfg.maximum_body_diameter(vertices), np.eye(4))
+        rp, ro, rl = util.syn.make_region_model(scene.body, n_divides=2, n_points=200)
+        cfg.write_model_bin(str(external / "models" / (name + "_region_model.bin")), True, model_parameters, data, rp, ro, rl)
+        dp, do, da = util.syn.make_depth_model(scene.body, n_divides=2, n_points=200)
+        cfg.write_model_bin(str(external / "models" / (name + "_depth_model.bin")), False, model_parameters, data, dp, do, da)
+    assert ev.ycb_keyframes(str(dataset), "0000") == [1, 2, 4, 5] and ev.ycb_n_frames(str(dataset), "0001") == 3
+    assert ev.ycb_sequence_bodies(str(dataset), "0001") == [names[1]]
+    titles = []
+    outcomes = []
+    for matlab in (True, False):
+        results, overall = ev.evaluate_ycb_dataset(util.open_oracle, str(dataset), str(external), [0, 1], names,
+                                                   use_matlab_gt_poses=matlab, n_vertices_evaluation=4,
+                                                   model_parameters=model_parameters,
+                                                   report=lambda title, r: titles.append(title))
+        assert set(results) == {("0000", names[0]), ("0001", names[1])}  # only the bodies a sequence contains
+        # the octahedron stands in for the tracked shape: ADD-S over its vertices still measures the pose error
+        assert overall["adds_auc"] > 0.9 and overall["add_auc"] > 0.85
+        outcomes.append((overall["add_auc"], overall["adds_auc"]))
+    assert titles[:2] == ["0000: " + names[0], "0001: " + names[1]]
+    assert outcomes[0] == pytest.approx(outcomes[1], abs=1e-4)  # both ground-truth sources describe the same poses
