@@ -74,3 +74,40 @@ def test_product_fails_loudly_without_gpu():
         util.pkg.open_context(0)
     assert e.value.code == util.pkg._capi.M3T_ERR_DEVICE
     assert "HIP device" in str(e.value)
+
+
+def test_python_structs_match_the_c_structs_field_for_field(tmp_path):
+    """the ctypes mirrors in _capi.py against include/m3t_types.h as a C compiler lays it out: same size, same
+    field names, same offsets (a drifted field would shift every parameter behind it silently)"""
+    import subprocess
+    capi = util.pkg._capi
+    pairs = [("m3t_intrinsics", capi.Intrinsics), ("m3t_region_model_desc", capi.RegionModelDesc),
+             ("m3t_depth_model_desc", capi.DepthModelDesc), ("m3t_region_modality_params", capi.RegionModalityParams),
+             ("m3t_depth_modality_params", capi.DepthModalityParams), ("m3t_body_geometry", capi.BodyGeometry),
+             ("m3t_model_generation_params", capi.ModelGenerationParams), ("m3t_data_line", capi.DataLine),
+             ("m3t_data_point", capi.DataPoint)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "m3t_types.h"', "int main(void) {"]
+    for c_name, py in pairs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (c_name, c_name))
+        for field, _ in py._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (c_name, field, c_name, field))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+                           str(exe)])
+    layout = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    header = open(os.path.join(ROOT, "include", "m3t_types.h")).read()
+    for c_name, py in pairs:
+        assert int(layout[c_name]) == ctypes.sizeof(py), c_name
+        for field, _ in py._fields_:
+            assert int(layout[c_name + "." + field]) == getattr(py, field).offset, (c_name, field)
+        # and no C field without a Python counterpart: the field counts agree
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (c_name, c_name), header, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        n_c_fields = sum(d.count(",") + 1 for d in body.split(";") if d.strip())  # 'float fu, fv;' declares two
+        assert n_c_fields == len(py._fields_), (c_name, n_c_fields, len(py._fields_))
+    # the numpy record types the getters fill are the same records
+    assert capi.DATA_LINE_DTYPE.itemsize == ctypes.sizeof(capi.DataLine)
+    assert capi.DATA_POINT_DTYPE.itemsize == ctypes.sizeof(capi.DataPoint)
