@@ -111,3 +111,22 @@ def test_python_structs_match_the_c_structs_field_for_field(tmp_path):
     # the numpy record types the getters fill are the same records
     assert capi.DATA_LINE_DTYPE.itemsize == ctypes.sizeof(capi.DataLine)
     assert capi.DATA_POINT_DTYPE.itemsize == ctypes.sizeof(capi.DataPoint)
+
+
+def test_python_signatures_have_the_declared_argument_counts():
+    """every binding in _capi.py takes as many arguments as its prototype in include/m3t_hip.h (context first)"""
+    capi = util.pkg._capi
+    txt = open(os.path.join(ROOT, "include", "m3t_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    prototypes = {m.group(1): m.group(2) for m in re.finditer(r"\bint\s+m3t_hip_(\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S)}
+    bindings = dict(capi._SIGNATURES)
+    bindings.update(capi._HIP_ONLY)
+    checked = 0
+    for name, args in bindings.items():
+        assert name in prototypes, name
+        declared = [a for a in prototypes[name].split(",") if a.strip() and a.strip() != "void"]
+        assert len(declared) == len(args) + 1, (name, prototypes[name], args)
+        checked += 1
+    assert checked >= 70
+    unbound = set(prototypes) - set(bindings) - {"create", "destroy", "last_error"}
+    assert not unbound, sorted(unbound)  # the Python mirror reaches the whole boundary
