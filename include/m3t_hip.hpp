@@ -151,6 +151,13 @@ class FocusedRenderer {
     return c_->Step(m3t_hip_renderer_add_referenced_body(c_->get(), id_, body.id()));
   }
   bool StartRendering() { return c_->Step(m3t_hip_renderer_start_rendering(c_->get(), id_)); }
+  // focused_depth_image() / focused_silhouette_image(): image_size^2 values each (silhouette may be null);
+  // info = corner_u, corner_v, scale of the focused crop; returns the number of visible referenced bodies
+  int FetchImages(uint16_t* depth, uint8_t* silhouette, float info[3]) const {
+    int n_visible = 0;
+    c_->Check(m3t_hip_renderer_get_images(c_->get(), id_, depth, silhouette, info, &n_visible), "FocusedRenderer");
+    return n_visible;
+  }
   int id() const { return id_; }
 
  protected:
@@ -213,6 +220,11 @@ class DepthModel {
   DepthModel(ContextPtr c, const m3t_depth_model_desc& desc) : c_(std::move(c)) {
     id_ = c_->Check(m3t_hip_depth_model_create(c_->get(), &desc), "DepthModel");
   }
+  int GetClosestView(const Pose& body2camera_pose) const {
+    int v = 0;
+    c_->Check(m3t_hip_depth_model_closest_view(c_->get(), id_, body2camera_pose.data(), &v), "GetClosestView");
+    return v;
+  }
   int id() const { return id_; }
 
  private:
@@ -226,6 +238,10 @@ class Modality {
   // Modality::gradient() / hessian(): 6 floats, column-major 6x6
   void gradient_hessian(float gradient[6], float hessian[36]) const {
     c_->Check(m3t_hip_modality_get_gradient_hessian(c_->get(), id_, gradient, hessian), "Modality");
+  }
+  // test / adapter hook: feed g/H computed elsewhere into the optimizer
+  void set_gradient_hessian(const float gradient[6], const float hessian[36]) {
+    c_->Check(m3t_hip_modality_set_gradient_hessian(c_->get(), id_, gradient, hessian), "Modality");
   }
   int id() const { return id_; }
 
@@ -251,6 +267,13 @@ class RegionModality : public Modality {
   bool UseRegionChecking(const FocusedSilhouetteRenderer& renderer) {
     return c_->Step(m3t_hip_region_modality_use_region_checking(c_->get(), id_, renderer.id()));
   }
+  // ColorHistograms::histogram_f / histogram_b, n_bins^3 floats each
+  void histograms(float* histogram_f, float* histogram_b) const {
+    c_->Check(m3t_hip_region_modality_get_histograms(c_->get(), id_, histogram_f, histogram_b), "histograms");
+  }
+  void set_histograms(const float* histogram_f, const float* histogram_b) {
+    c_->Check(m3t_hip_region_modality_set_histograms(c_->get(), id_, histogram_f, histogram_b), "histograms");
+  }
   std::vector<m3t_data_line> data_lines(int capacity = 1024) const {
     std::vector<m3t_data_line> out(capacity);
     int n = 0;
@@ -272,6 +295,13 @@ class DepthModality : public Modality {
   }
   bool UseSilhouetteChecking(const FocusedSilhouetteRenderer& renderer) {
     return c_->Step(m3t_hip_depth_modality_use_silhouette_checking(c_->get(), id_, renderer.id()));
+  }
+  std::vector<m3t_data_point> data_points(int capacity = 1024) const {
+    std::vector<m3t_data_point> out(capacity);
+    int n = 0;
+    c_->Check(m3t_hip_depth_modality_get_points(c_->get(), id_, out.data(), capacity, &n), "data_points");
+    out.resize(n < capacity ? n : capacity);
+    return out;
   }
 };
 
@@ -401,6 +431,57 @@ class Tracker {
     return c_->Step(m3t_hip_refine_poses(c_->get(), n_corr_iterations, n_update_iterations));
   }
   bool Sync() { return c_->Step(m3t_hip_sync(c_->get())); }
+
+  // ---- the batch at once, and what has no counterpart in the reference (m3t_hip.h) ----
+  // poses of the first n bodies in creation order, one copy each way
+  void SetBodyPoses(const std::vector<Pose>& poses) {
+    c_->Check(m3t_hip_bodies_set_poses(c_->get(), poses.empty() ? nullptr : poses[0].data(), int(poses.size())), "Tracker");
+  }
+  std::vector<Pose> BodyPoses(int n) const {
+    std::vector<Pose> poses(static_cast<size_t>(n));
+    c_->Check(m3t_hip_bodies_get_poses(c_->get(), n ? poses[0].data() : nullptr, n), "Tracker");
+    return poses;
+  }
+  // frame ring of every camera + asynchronous ingest
+  bool SelectSlot(int slot) { return c_->Step(m3t_hip_cameras_select_slot(c_->get(), slot)); }
+  void RegisterHostBuffer(void* ptr, size_t bytes) { c_->Check(m3t_hip_host_register(c_->get(), ptr, bytes), "Tracker"); }
+  void UnregisterHostBuffer(void* ptr) { c_->Check(m3t_hip_host_unregister(c_->get(), ptr), "Tracker"); }
+  bool IngestSync() { return c_->Step(m3t_hip_ingest_sync(c_->get())); }
+  // a kinematic structure spread over GPUs: begin -> all-reduce(sum) of `count` floats at `partial` on stream() -> end
+  bool CalculateOptimizationBegin(float** partial, size_t* count) {
+    return c_->Step(m3t_hip_calculate_optimization_begin(c_->get(), partial, count));
+  }
+  bool CalculateOptimizationEnd() { return c_->Step(m3t_hip_calculate_optimization_end(c_->get())); }
+  void SetSoftConstraintsActive(bool active) {
+    c_->Check(m3t_hip_set_soft_constraints_active(c_->get(), active ? 1 : 0), "Tracker");
+  }
+  void* stream() const {
+    void* s = nullptr;
+    c_->Check(m3t_hip_get_stream(c_->get(), &s), "Tracker");
+    return s;
+  }
+  // launch shape and summation order (m3t_hip.h: set_fused_step, set_summation_mode, get_step_shape)
+  void SetFusedStep(int mode) { c_->Check(m3t_hip_set_fused_step(c_->get(), mode), "Tracker"); }
+  void SetSummationMode(int mode) { c_->Check(m3t_hip_set_summation_mode(c_->get(), mode), "Tracker"); }
+  std::array<int, 4> StepShape() const {
+    std::array<int, 4> shape{};
+    c_->Check(m3t_hip_get_step_shape(c_->get(), shape.data()), "Tracker");
+    return shape;
+  }
+  // measurement aids
+  void SetKernelTiming(bool enable) { c_->Check(m3t_hip_set_kernel_timing(c_->get(), enable ? 1 : 0), "Tracker"); }
+  void KernelTiming(float total_ms[2], int launches[2]) const {
+    c_->Check(m3t_hip_get_kernel_timing(c_->get(), total_ms, launches), "Tracker");
+  }
+  std::string DeviceName(int* compute_units = nullptr, size_t* total_memory_bytes = nullptr) const {
+    char name[256] = {0};
+    int cus = 0;
+    size_t bytes = 0;
+    c_->Check(m3t_hip_device_info(c_->get(), name, sizeof(name), &cus, &bytes), "Tracker");
+    if (compute_units) *compute_units = cus;
+    if (total_memory_bytes) *total_memory_bytes = bytes;
+    return name;
+  }
 
  private:
   ContextPtr c_;

@@ -130,3 +130,10 @@ def test_python_signatures_have_the_declared_argument_counts():
     assert checked >= 70
     unbound = set(prototypes) - set(bindings) - {"create", "destroy", "last_error"}
     assert not unbound, sorted(unbound)  # the Python mirror reaches the whole boundary
+
+
+def test_cpp_mirror_reaches_the_whole_boundary():
+    """every entry point of include/m3t_hip.h is wrapped by the C++ mirror headers"""
+    names = _declared("include/m3t_hip.h", "m3t_hip_")
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("m3t_hip.hpp", "m3t_hip_config.hpp"))
+    assert [n for n in names if n not in text] == []
