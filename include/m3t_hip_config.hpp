@@ -622,9 +622,11 @@ inline LoaderSettings Loader(const Node& d, const std::string& path) {
 
 class LoaderColorCamera : public ColorCamera {
  public:
-  LoaderColorCamera(ContextPtr c, const LoaderSettings& settings, const m3t_intrinsics& intrinsics,
+  LoaderColorCamera(ContextPtr c, const LoaderSettings& loader_settings, const m3t_intrinsics& intrinsics,
                     const Pose& camera2world_pose = IdentityPose())
-      : ColorCamera(std::move(c), intrinsics, InversePose(camera2world_pose)), settings(settings), intrinsics_(intrinsics) {}
+      : ColorCamera(std::move(c), intrinsics, InversePose(camera2world_pose)),
+        settings(loader_settings),
+        intrinsics_(intrinsics) {}
   static std::shared_ptr<LoaderColorCamera> FromMetafile(ContextPtr c, const std::string& path) {
     Node d = ReadYaml(path);
     Required(d, {"load_directory", "intrinsics"}, "body", path);
@@ -657,10 +659,10 @@ class LoaderColorCamera : public ColorCamera {
 
 class LoaderDepthCamera : public DepthCamera {
  public:
-  LoaderDepthCamera(ContextPtr c, const LoaderSettings& settings, const m3t_intrinsics& intrinsics, float depth_scale,
-                    const Pose& camera2world_pose = IdentityPose())
+  LoaderDepthCamera(ContextPtr c, const LoaderSettings& loader_settings, const m3t_intrinsics& intrinsics,
+                    float depth_scale, const Pose& camera2world_pose = IdentityPose())
       : DepthCamera(std::move(c), intrinsics, depth_scale, InversePose(camera2world_pose)),
-        settings(settings),
+        settings(loader_settings),
         intrinsics_(intrinsics) {}
   static std::shared_ptr<LoaderDepthCamera> FromMetafile(ContextPtr c, const std::string& path) {
     Node d = ReadYaml(path);
@@ -696,10 +698,10 @@ class LoaderDepthCamera : public DepthCamera {
 // m3t::Body with its mesh (body.cpp:13-42,152-252)
 class MeshBody : public Body {
  public:
-  MeshBody(ContextPtr c, const std::string& name, const BodyData& data, int body_id, int region_id)
-      : Body(std::move(c), IdentityPose()), name(name), data(data), body_id(body_id), region_id(region_id) {
+  MeshBody(ContextPtr c, const std::string& body_name, const BodyData& body_data, int id_body, int id_region)
+      : Body(std::move(c), IdentityPose()), name(body_name), data(body_data), body_id(id_body), region_id(id_region) {
     mesh = LoadObj(data.geometry_path, data.geometry_unit_in_meter);
-    this->data.maximum_body_diameter = MaximumBodyDiameter(mesh, data.geometry2body_pose);
+    data.maximum_body_diameter = MaximumBodyDiameter(mesh, data.geometry2body_pose);
     m3t_body_geometry g{};
     g.vertices = mesh.vertices.data();
     g.n_vertices = int(mesh.vertices.size() / 3);
