@@ -225,14 +225,17 @@ def evaluate_rbot_dataset(open_context, dataset_directory, external_directory, b
                           sequence_names=RBOT_SEQUENCE_NAMES, n_frames=1000, region_parameters=None,
                           model_parameters=None, tikhonov_parameter_rotation=1000.0,
                           tikhonov_parameter_translation=30000.0, n_corr_iterations=7, n_update_iterations=2,
-                          report=None):
+                          report=None, shard=(0, 1)):
     """RBOTEvaluator::SetUp + Evaluate for the region modality on the un-modelled sequences: for every (sequence,
     body) a tracker on `dataset/<body>/frames/<sequence>NNNN.png`, started at `dataset/poses_first.txt`, reset on
     loss, scored with the 5 cm / 5 degree criterion.  Bodies are `dataset/<body>/<body>.obj` in millimetres
     (LoadSingleBody :527-535), their region models `external/models/<body>_model.bin` — generated on the device
     when missing or made with other parameters (GenerateSingleModel :546-556).  `open_context()` returns a fresh
     device context per run (one tracker per context).  Returns {(sequence, body): average result} and the overall
-    average (CalculateAverageResult); `report`, if given, is called with each run's title and result."""
+    average (CalculateAverageResult); `report`, if given, is called with each run's title and result.
+    shard = (rank, world): this process takes every world-th run (the reference spreads the runs over OpenMP
+    threads, rbot_evaluator.cpp:139-156; here one process per GPU takes its share and the caller merges the
+    dictionaries)."""
     import os
 
     from . import config as cfg
@@ -241,35 +244,35 @@ def evaluate_rbot_dataset(open_context, dataset_directory, external_directory, b
     region_parameters = dict(RBOT_REGION_PARAMETERS, **(region_parameters or {}))
     model_parameters = dict(RBOT_MODEL_PARAMETERS, **(model_parameters or {}))
     results = {}
-    for sequence in sequence_names:
-        for name in body_names:
-            api = open_context()
-            body = generator.Body(api, name, os.path.join(dataset_directory, name, name + ".obj"), 0.001, True, False,
-                                  np.eye(4, dtype=F))
-            model_path = os.path.join(external_directory, "models", name + "_model.bin")
-            if cfg.model_bin_matches(model_path, True, model_parameters, body.body_data()):
-                model = host.RegionModel(api, path=model_path)
-            else:
-                generation = {k: v for k, v in model_parameters.items() if k != "use_random_seed"}
-                model = host.RegionModel.generate(api, body, **generation)
-                cfg.write_model_bin(model_path, True, model_parameters, body.body_data(), *model.views())
-            camera = generator.LoaderColorCamera(api, os.path.join(dataset_directory, name, "frames"), RBOT_INTRINSICS,
-                                                 sequence, 0, 4)
-            modality = host.RegionModality(api, body, camera, model, **region_parameters)
-            host.Optimizer(api, body=body, modalities=[modality],
-                           tikhonov_parameter_rotation=tikhonov_parameter_rotation,
-                           tikhonov_parameter_translation=tikhonov_parameter_translation)
-            tracker = host.Tracker(api, n_corr_iterations, n_update_iterations)
+    runs = [(sequence, name) for sequence in sequence_names for name in body_names]
+    for sequence, name in runs[shard[0]::shard[1]]:
+        api = open_context()
+        body = generator.Body(api, name, os.path.join(dataset_directory, name, name + ".obj"), 0.001, True, False,
+                              np.eye(4, dtype=F))
+        model_path = os.path.join(external_directory, "models", name + "_model.bin")
+        if cfg.model_bin_matches(model_path, True, model_parameters, body.body_data()):
+            model = host.RegionModel(api, path=model_path)
+        else:
+            generation = {k: v for k, v in model_parameters.items() if k != "use_random_seed"}
+            model = host.RegionModel.generate(api, body, **generation)
+            cfg.write_model_bin(model_path, True, model_parameters, body.body_data(), *model.views())
+        camera = generator.LoaderColorCamera(api, os.path.join(dataset_directory, name, "frames"), RBOT_INTRINSICS,
+                                             sequence, 0, 4)
+        modality = host.RegionModality(api, body, camera, model, **region_parameters)
+        host.Optimizer(api, body=body, modalities=[modality],
+                       tikhonov_parameter_rotation=tikhonov_parameter_rotation,
+                       tikhonov_parameter_translation=tikhonov_parameter_translation)
+        tracker = host.Tracker(api, n_corr_iterations, n_update_iterations)
 
-            def load_image(k, camera=camera):
-                camera.set_load_index(k)
-                if not camera.UpdateImage():
-                    raise RuntimeError("Could not read image from %s" % camera.image_path())
+        def load_image(k, camera=camera):
+            camera.set_load_index(k)
+            if not camera.UpdateImage():
+                raise RuntimeError("Could not read image from %s" % camera.image_path())
 
-            _, average = evaluate_rbot_sequence(tracker, body, poses_first, load_image, n_frames)
-            results[(sequence, name)] = average
-            if report is not None:
-                report(sequence + "_" + name, average)
+        _, average = evaluate_rbot_sequence(tracker, body, poses_first, load_image, n_frames)
+        results[(sequence, name)] = average
+        if report is not None:
+            report(sequence + "_" + name, average)
     keys = ("translation_error", "rotation_error", "tracking_success", "complete_cycle")
     overall = {k: float(np.mean([r[k] for r in results.values()])) for k in keys}
     return results, overall
@@ -337,13 +340,14 @@ def evaluate_ycb_dataset(open_context, dataset_directory, external_directory, se
                          use_matlab_gt_poses=True, n_vertices_evaluation=1000, region_parameters=None,
                          depth_parameters=None, model_parameters=None, tikhonov_parameter_rotation=1000.0,
                          tikhonov_parameter_translation=30000.0, n_corr_iterations=4, n_update_iterations=2,
-                         report=None):
+                         report=None, shard=(0, 1)):
     """YCBEvaluator::SetUp + Evaluate with the region and the depth modality, measured occlusions, one run per
     (sequence, body present in it) (CreateRunConfigurations :1006-1022): bodies `dataset/models/<body>/textured.obj`
     in metres, frames `dataset/data/<sequence>/NNNNNN-{color,depth}.png` (depth scale 1e-4), keyframes from
     `dataset/image_sets/keyframe.txt`, ground truth from `external/poses/ground_truth/<sequence>_<body>.txt` (or the
     dataset's own `poses/<body>.txt`), models under `external/models/`.  Returns {(sequence, body): average} and
-    the averages over all frames of all runs (CalculateAverageResult)."""
+    the averages over all frames of all runs (CalculateAverageResult).  shard = (rank, world): every world-th run
+    (see evaluate_rbot_dataset); the overall averages then cover this process's runs."""
     import os
 
     from . import config as cfg
@@ -357,59 +361,57 @@ def evaluate_ycb_dataset(open_context, dataset_directory, external_directory, se
                 for i in range(max(sequence_ids) + 1)
                 if os.path.isdir(os.path.join(dataset_directory, "data", ycb_sequence_name(i)))}
     results, frame_results = {}, []
-    for sequence in sequence_names:
-        present = ycb_sequence_bodies(dataset_directory, sequence)
+    runs = [(sequence, name) for sequence in sequence_names
+            for name in body_names if name in ycb_sequence_bodies(dataset_directory, sequence)]
+    for sequence, name in runs[shard[0]::shard[1]]:
         keyframes = ycb_keyframes(dataset_directory, sequence)
-        for name in body_names:
-            if name not in present:
-                continue
-            api = open_context()
-            body = generator.Body(api, name, os.path.join(dataset_directory, "models", name, "textured.obj"), 1.0, True,
-                                  True, np.eye(4, dtype=F))
-            models = []
-            for region, klass, suffix in ((True, host.RegionModel, "_region_model.bin"),
-                                          (False, host.DepthModel, "_depth_model.bin")):
-                path = os.path.join(external_directory, "models", name + suffix)
-                if cfg.model_bin_matches(path, region, model_parameters, body.body_data()):
-                    models.append(klass(api, path=path))
-                else:
-                    models.append(klass.generate(api, body, **generation))
-                    cfg.write_model_bin(path, region, model_parameters, body.body_data(), *models[-1].views())
-            directory = os.path.join(dataset_directory, "data", sequence)
-            color = generator.LoaderColorCamera(api, directory, YCB_INTRINSICS, "", 1, 6, "-color")
-            depth = generator.LoaderDepthCamera(api, directory, YCB_INTRINSICS, 0.0001, "", 1, 6, "-depth")
-            region_modality = host.RegionModality(api, body, color, models[0], depth_camera=depth, measure_occlusions=1,
-                                                  **region_parameters)
-            depth_modality = host.DepthModality(api, body, depth, models[1], measure_occlusions=1, **depth_parameters)
-            host.Optimizer(api, body=body, modalities=[region_modality, depth_modality],
-                           tikhonov_parameter_rotation=tikhonov_parameter_rotation,
-                           tikhonov_parameter_translation=tikhonov_parameter_translation)
-            tracker = host.Tracker(api, n_corr_iterations, n_update_iterations)
-            if use_matlab_gt_poses:
-                gt = read_matlab_poses_ycb(os.path.join(external_directory, "poses", "ground_truth",
-                                                        sequence + "_" + name + ".txt"))
-            else:  # the dataset's pose file: the body's frames of all earlier sequences come first (LoadPoseBegin)
-                begin = sum(n_frames[s] for s in sorted(n_frames) if s < sequence and
-                            name in ycb_sequence_bodies(dataset_directory, s))
-                gt = read_poses_ycb(os.path.join(dataset_directory, "poses", name + ".txt"), begin, n_frames[sequence],
-                                    keyframes)
-            if len(gt) < len(keyframes):
-                raise ValueError("ground truth of %s in sequence %s has %d poses for %d keyframes" %
-                                 (name, sequence, len(gt), len(keyframes)))
+        api = open_context()
+        body = generator.Body(api, name, os.path.join(dataset_directory, "models", name, "textured.obj"), 1.0, True,
+                              True, np.eye(4, dtype=F))
+        models = []
+        for region, klass, suffix in ((True, host.RegionModel, "_region_model.bin"),
+                                      (False, host.DepthModel, "_depth_model.bin")):
+            path = os.path.join(external_directory, "models", name + suffix)
+            if cfg.model_bin_matches(path, region, model_parameters, body.body_data()):
+                models.append(klass(api, path=path))
+            else:
+                models.append(klass.generate(api, body, **generation))
+                cfg.write_model_bin(path, region, model_parameters, body.body_data(), *models[-1].views())
+        directory = os.path.join(dataset_directory, "data", sequence)
+        color = generator.LoaderColorCamera(api, directory, YCB_INTRINSICS, "", 1, 6, "-color")
+        depth = generator.LoaderDepthCamera(api, directory, YCB_INTRINSICS, 0.0001, "", 1, 6, "-depth")
+        region_modality = host.RegionModality(api, body, color, models[0], depth_camera=depth, measure_occlusions=1,
+                                              **region_parameters)
+        depth_modality = host.DepthModality(api, body, depth, models[1], measure_occlusions=1, **depth_parameters)
+        host.Optimizer(api, body=body, modalities=[region_modality, depth_modality],
+                       tikhonov_parameter_rotation=tikhonov_parameter_rotation,
+                       tikhonov_parameter_translation=tikhonov_parameter_translation)
+        tracker = host.Tracker(api, n_corr_iterations, n_update_iterations)
+        if use_matlab_gt_poses:
+            gt = read_matlab_poses_ycb(os.path.join(external_directory, "poses", "ground_truth",
+                                                    sequence + "_" + name + ".txt"))
+        else:  # the dataset's pose file: the body's frames of all earlier sequences come first (LoadPoseBegin)
+            begin = sum(n_frames[s] for s in sorted(n_frames) if s < sequence and
+                        name in ycb_sequence_bodies(dataset_directory, s))
+            gt = read_poses_ycb(os.path.join(dataset_directory, "poses", name + ".txt"), begin, n_frames[sequence],
+                                keyframes)
+        if len(gt) < len(keyframes):
+            raise ValueError("ground truth of %s in sequence %s has %d poses for %d keyframes" %
+                             (name, sequence, len(gt), len(keyframes)))
 
-            def update_cameras(frame, color=color, depth=depth):
-                for camera in (color, depth):
-                    camera.set_load_index(frame)
-                    if not camera.UpdateImage():
-                        raise RuntimeError("Could not read image from %s" % camera.image_path())
+        def update_cameras(frame, color=color, depth=depth):
+            for camera in (color, depth):
+                camera.set_load_index(frame)
+                if not camera.UpdateImage():
+                    raise RuntimeError("Could not read image from %s" % camera.image_path())
 
-            evaluation = YCBBodyEvaluation(body.vertices, n_vertices_evaluation)
-            per_frame, average = evaluate_ycb_sequence(tracker, {name: body}, {name: evaluation}, {name: gt}, keyframes,
-                                                       update_cameras)
-            results[(sequence, name)] = average[name]
-            frame_results += per_frame[name]
-            if report is not None:
-                report(sequence + ": " + name, average[name])
+        evaluation = YCBBodyEvaluation(body.vertices, n_vertices_evaluation)
+        per_frame, average = evaluate_ycb_sequence(tracker, {name: body}, {name: evaluation}, {name: gt}, keyframes,
+                                                   update_cameras)
+        results[(sequence, name)] = average[name]
+        frame_results += per_frame[name]
+        if report is not None:
+            report(sequence + ": " + name, average[name])
     overall = dict(add_auc=float(np.mean([r["add_auc"] for r in frame_results])),
                    adds_auc=float(np.mean([r["adds_auc"] for r in frame_results])),
                    complete_cycle=float(np.mean([r["complete_cycle"] for r in frame_results])))

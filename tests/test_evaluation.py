@@ -171,6 +171,16 @@ def test_rbot_dataset_driver_on_a_synthetic_dataset_in_the_rbot_layout(tmp_path)
     for r in results.values():
         assert r["tracking_success"] == 1.0 and r["translation_error"] < 5e-3 and r["rotation_error"] < np.deg2rad(2)
     assert overall["tracking_success"] == 1.0
+    # two processes sharing the runs: together they cover the same (sequence, body) pairs with the same results
+    merged = {}
+    for rank in range(2):
+        part, _ = ev.evaluate_rbot_dataset(util.open_oracle, str(dataset), str(external), names, ["a_regular"],
+                                           n_frames=n_frames, model_parameters=model_parameters, shard=(rank, 2))
+        assert len(part) == 1
+        merged.update(part)
+    assert set(merged) == set(results)
+    for key in results:
+        assert merged[key]["translation_error"] == results[key]["translation_error"]
     # a model made with other parameters is not accepted, and the oracle context cannot replace it
     with pytest.raises(util.pkg.M3TError):
         ev.evaluate_rbot_dataset(util.open_oracle, str(dataset), str(external), names[:1], ["a_regular"],

@@ -19,10 +19,14 @@ def report(title, result):
     print("%s:\nsuccess rate = %g\ncomplete cycle = %g us" % (title, result["tracking_success"], result["complete_cycle"]))
 
 
+# one process per GPU (torch.distributed.run or any launcher that sets these): every process takes its share of runs
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
 if __name__ == "__main__":
     if len(sys.argv) < 3:
         sys.exit("usage: evaluate_rbot_dataset.py RBOT_DATASET_DIR EXTERNAL_DIR [body ...]")
     ev = pkg.evaluation
     bodies = sys.argv[3:] or ev.RBOT_BODY_NAMES
-    _, overall = ev.evaluate_rbot_dataset(lambda: pkg.open_context(0), sys.argv[1], sys.argv[2], bodies, report=report)
+    _, overall = ev.evaluate_rbot_dataset(lambda: pkg.open_context(local_rank), sys.argv[1], sys.argv[2], bodies, report=report, shard=(rank, world))
     report("all_sequences_all_bodies", overall)

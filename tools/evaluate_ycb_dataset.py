@@ -24,10 +24,14 @@ def report(title, result):
           (title, result["complete_cycle"], result["add_auc"], result["adds_auc"]))
 
 
+# one process per GPU (torch.distributed.run or any launcher that sets these): every process takes its share of runs
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
 if __name__ == "__main__":
     if len(sys.argv) < 3:
         sys.exit("usage: evaluate_ycb_dataset.py YCB_VIDEO_DIR EXTERNAL_DIR [sequence_id ...]")
     sequence_ids = [int(x) for x in sys.argv[3:]] or list(range(48, 60))  # evaluate_ycb_dataset.cpp:13
-    _, overall = pkg.evaluation.evaluate_ycb_dataset(lambda: pkg.open_context(0), sys.argv[1], sys.argv[2], sequence_ids,
-                                                     BODY_NAMES, report=report)
+    _, overall = pkg.evaluation.evaluate_ycb_dataset(lambda: pkg.open_context(local_rank), sys.argv[1], sys.argv[2], sequence_ids,
+                                                     BODY_NAMES, report=report, shard=(rank, world))
     report("all sequences, all bodies", overall)
