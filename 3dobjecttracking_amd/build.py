@@ -6,7 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libm3t_hip.so")
-SOURCES = ["m3t_hip_api.hip", "m3t_kernels.hip", "m3t_device.h"]
+# m3t_hip_api.hip is the one translation unit; it includes the other .hip files and m3t_device.h
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
 HEADERS = [os.path.join(HERE, "..", "include", "m3t_hip.h"), os.path.join(HERE, "..", "include", "m3t_types.h")]
 # -ffp-contract=off: the kernels follow the reference's f32 expression trees op by op
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",

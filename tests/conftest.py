@@ -19,8 +19,12 @@ def pkg():
 
 
 def pytest_sessionstart(session):
-    """On a GPU box initialise torch's HIP runtime BEFORE libm3t_hip.so loads /opt/rocm's: torch
+    """A fresh checkout has no built library (it is git-ignored): build it once, here, so that the ABI tests do not
+    depend on a step run before pytest.  On a GPU box initialise torch's HIP runtime BEFORE libm3t_hip.so loads /opt/rocm's: torch
     bundles its own libamdhip64 and reports "no GPUs" if it comes second (the RCCL test needs it)."""
+    build = importlib.import_module("3dobjecttracking_amd.build")
+    if not os.path.exists(build.LIB):
+        build.build()
     if os.path.exists("/dev/kfd"):
         try:
             import torch
