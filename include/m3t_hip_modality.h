@@ -1,0 +1,244 @@
+// m3t_hip_modality.h — the adapter a maintainer drops into the M3T tree ("adapter mode"):
+// HipRegionModality / HipDepthModality are m3t::Modality subclasses (include/m3t/modality.h:56-155) that forward the
+// seven steps to libm3t_hip.so and copy the device-computed gradient / Hessian back into gradient_ / hessian_, so
+// that the reference's unmodified Link, Optimizer and Tracker keep working (link.cpp:188-191 only reads those).
+//
+// All adapters of one tracker share a HipBatch: Tracker calls the modalities one after another
+// (tracker.cpp:447-457,471-479,503-517); the first call of a (iteration, corr_iteration[, opt_iteration]) round
+// pushes the host Bodies' poses (PrecalculatePoseVariables reads Body every time, region_modality.cpp:1000) and
+// launches the step for ALL registered modalities, the later calls of the round only fetch their own result.
+//
+// Needs the M3T headers (and through them Eigen / OpenCV); links -lm3t_hip.  In this repository it is compiled
+// against the interface stubs under tests/cpp/m3t_stub/ (tests/test_cpp_adapter.py).
+#ifndef M3T_HIP_MODALITY_H_
+#define M3T_HIP_MODALITY_H_
+
+#include <m3t/body.h>
+#include <m3t/camera.h>
+#include <m3t/modality.h>
+
+#include <filesystem>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "m3t_hip.h"
+
+namespace m3t_hip_adapter {
+
+struct HipBatch {
+  m3t_hip_context* ctx = nullptr;
+  long start_round = -1, corr_round = -1, gh_round = -1, res_round = -1;
+  std::vector<std::pair<int /*device body id*/, std::shared_ptr<m3t::Body>>> bodies;
+
+  explicit HipBatch(int device_id = 0) {
+    if (m3t_hip_create(&ctx, device_id) < 0) {
+      std::cerr << m3t_hip_last_error(nullptr) << std::endl;
+      ctx = nullptr;
+      return;
+    }
+    m3t_hip_set_fused_step(ctx, 0);  // the host drives the sub-steps one by one
+  }
+  ~HipBatch() {
+    if (ctx) m3t_hip_destroy(ctx);
+  }
+  HipBatch(const HipBatch&) = delete;
+  HipBatch& operator=(const HipBatch&) = delete;
+
+  // one device body per host Body, shared by the modalities of that body
+  int BodyId(const std::shared_ptr<m3t::Body>& body) {
+    for (auto& b : bodies)
+      if (b.second == body) return b.first;
+    int id = m3t_hip_body_create(ctx, body->body2world_pose().data());
+    if (id >= 0) bodies.push_back({id, body});
+    return id;
+  }
+  // one device camera per host Camera, shared by the modalities that look through it
+  struct SharedCamera {
+    std::shared_ptr<m3t::Camera> camera;
+    int id;
+    long uploaded_round;
+  };
+  std::vector<SharedCamera> cameras;
+  int ColorCameraId(const std::shared_ptr<m3t::ColorCamera>& camera) {
+    for (auto& c : cameras)
+      if (c.camera == camera) return c.id;
+    const auto& in = camera->intrinsics();
+    const m3t_intrinsics i{in.fu, in.fv, in.ppu, in.ppv, in.width, in.height};
+    int id = m3t_hip_color_camera_create(ctx, &i, camera->world2camera_pose().data());
+    if (id >= 0) cameras.push_back({camera, id, -1});
+    return id;
+  }
+  int DepthCameraId(const std::shared_ptr<m3t::DepthCamera>& camera) {
+    for (auto& c : cameras)
+      if (c.camera == camera) return c.id;
+    const auto& in = camera->intrinsics();
+    const m3t_intrinsics i{in.fu, in.fv, in.ppu, in.ppv, in.width, in.height};
+    int id = m3t_hip_depth_camera_create(ctx, &i, camera->world2camera_pose().data(), camera->depth_scale());
+    if (id >= 0) cameras.push_back({camera, id, -1});
+    return id;
+  }
+  // Camera::image() -> device, once per upload round however many modalities share the camera
+  bool Upload(int camera_id, long round) {
+    for (auto& c : cameras) {
+      if (c.id != camera_id) continue;
+      if (c.uploaded_round == round) return true;
+      c.uploaded_round = round;
+      const cv::Mat& image = c.camera->image();  // BGR8 or u16; rows may be padded: data + step
+      return m3t_hip_camera_upload(ctx, camera_id, image.data, image.step) >= 0;
+    }
+    return false;
+  }
+  void PushPoses() {
+    for (auto& b : bodies) m3t_hip_body_set_body2world_pose(ctx, b.first, b.second->body2world_pose().data());
+  }
+  // device -> host Bodies (only needed by hosts that let the library optimise, "fast mode")
+  bool PullPoses() {
+    bool ok = true;
+    for (auto& b : bodies) {
+      m3t::Transform3fA pose;
+      ok = m3t_hip_body_get_body2world_pose(ctx, b.first, pose.data()) >= 0 && ok;
+      b.second->set_body2world_pose(pose);
+    }
+    return ok;
+  }
+  // runs f once per round key; f returns a C-ABI status
+  template <typename F>
+  bool Once(long* round, long key, F f) {
+    if (*round == key) return true;
+    *round = key;
+    PushPoses();
+    const int rc = f();
+    if (rc < 0) std::cerr << m3t_hip_last_error(ctx) << std::endl;
+    return rc >= 0;
+  }
+};
+
+// what both adapters do the same way
+class HipModality : public m3t::Modality {
+ public:
+  bool StartModality(int iteration, int /*corr_iteration*/) override {
+    if (!CheckSetUp()) return false;
+    UploadImages(2 * iteration);
+    return batch_->Once(&batch_->start_round, iteration, [&] { return m3t_hip_start_modalities(batch_->ctx, iteration); });
+  }
+  bool CalculateCorrespondences(int iteration, int corr_iteration) override {
+    if (!CheckSetUp()) return false;
+    if (corr_iteration == 0) UploadImages(2 * iteration + 1);  // Tracker::UpdateCameras ran before this search
+    return batch_->Once(&batch_->corr_round, iteration * 64L + corr_iteration, [&] {
+      return m3t_hip_calculate_correspondences(batch_->ctx, iteration, corr_iteration);
+    });
+  }
+  bool CalculateGradientAndHessian(int iteration, int corr_iteration, int opt_iteration) override {
+    if (!CheckSetUp()) return false;
+    const bool ok = batch_->Once(&batch_->gh_round, (iteration * 64L + corr_iteration) * 8 + opt_iteration, [&] {
+      return m3t_hip_calculate_gradient_and_hessian(batch_->ctx, iteration, corr_iteration, opt_iteration);
+    });
+    // column-major like Eigen: what the unmodified Link adds up (link.cpp:188-191)
+    return ok && m3t_hip_modality_get_gradient_hessian(batch_->ctx, id_, gradient_.data(), hessian_.data()) >= 0;
+  }
+  bool CalculateResults(int iteration) override {
+    if (!CheckSetUp()) return false;
+    return batch_->Once(&batch_->res_round, iteration, [&] { return m3t_hip_calculate_results(batch_->ctx, iteration); });
+  }
+  bool VisualizeCorrespondences(int) override { return true; }
+  bool VisualizeOptimization(int) override { return true; }
+  bool VisualizeResults(int) override { return true; }
+  int device_id() const { return id_; }
+
+ protected:
+  HipModality(const std::string& name, const std::shared_ptr<m3t::Body>& body, std::shared_ptr<HipBatch> batch)
+      : m3t::Modality{name, body}, batch_{std::move(batch)} {}
+  bool CheckSetUp() const {
+    if (!set_up_) std::cerr << "Set up modality " << name_ << " first" << std::endl;  // region_modality.cpp:1813-1819
+    return set_up_;
+  }
+  virtual void UploadImages(long round) = 0;
+  std::shared_ptr<HipBatch> batch_;
+  int body_id_ = -1, id_ = -1;
+};
+
+class HipRegionModality : public HipModality {
+ public:
+  // region_model_path: the .bin the reference's RegionModel wrote (or m3t_hip_region_model_generate's);
+  // depth_camera: optional, switches measured occlusions on like RegionModality::MeasureOcclusions
+  HipRegionModality(const std::string& name, const std::shared_ptr<m3t::Body>& body,
+                    std::shared_ptr<m3t::ColorCamera> color_camera, std::filesystem::path region_model_path,
+                    std::shared_ptr<HipBatch> batch, const m3t_region_modality_params& params,
+                    std::shared_ptr<m3t::DepthCamera> depth_camera = nullptr)
+      : HipModality{name, body, std::move(batch)},
+        color_camera_{std::move(color_camera)},
+        depth_camera_{std::move(depth_camera)},
+        model_path_{std::move(region_model_path)},
+        params_{params} {}
+
+  bool SetUp() override {
+    set_up_ = false;
+    if (!batch_ || !batch_->ctx) return false;
+    color_id_ = batch_->ColorCameraId(color_camera_);
+    if (depth_camera_) {
+      depth_id_ = batch_->DepthCameraId(depth_camera_);
+      params_.measure_occlusions = 1;
+    }
+    model_id_ = m3t_hip_region_model_load(batch_->ctx, model_path_.string().c_str());
+    body_id_ = batch_->BodyId(body_ptr_);
+    if (color_id_ >= 0 && model_id_ >= 0 && body_id_ >= 0 && (!depth_camera_ || depth_id_ >= 0))
+      id_ = m3t_hip_region_modality_create(batch_->ctx, &params_, body_id_, color_id_, model_id_, depth_id_);
+    set_up_ = id_ >= 0;
+    if (!set_up_) std::cerr << m3t_hip_last_error(batch_->ctx) << std::endl;
+    return set_up_;
+  }
+  std::vector<std::shared_ptr<m3t::Camera>> camera_ptrs() const override {
+    if (depth_camera_) return {color_camera_, depth_camera_};
+    return {color_camera_};
+  }
+
+ private:
+  void UploadImages(long round) override {
+    batch_->Upload(color_id_, round);
+    if (depth_camera_) batch_->Upload(depth_id_, round);
+  }
+  std::shared_ptr<m3t::ColorCamera> color_camera_;
+  std::shared_ptr<m3t::DepthCamera> depth_camera_;
+  std::filesystem::path model_path_;
+  m3t_region_modality_params params_;
+  int color_id_ = -1, depth_id_ = -1, model_id_ = -1;
+};
+
+class HipDepthModality : public HipModality {
+ public:
+  HipDepthModality(const std::string& name, const std::shared_ptr<m3t::Body>& body,
+                   std::shared_ptr<m3t::DepthCamera> depth_camera, std::filesystem::path depth_model_path,
+                   std::shared_ptr<HipBatch> batch, const m3t_depth_modality_params& params)
+      : HipModality{name, body, std::move(batch)},
+        depth_camera_{std::move(depth_camera)},
+        model_path_{std::move(depth_model_path)},
+        params_{params} {}
+
+  bool SetUp() override {
+    set_up_ = false;
+    if (!batch_ || !batch_->ctx) return false;
+    depth_id_ = batch_->DepthCameraId(depth_camera_);
+    model_id_ = m3t_hip_depth_model_load(batch_->ctx, model_path_.string().c_str());
+    body_id_ = batch_->BodyId(body_ptr_);
+    if (depth_id_ >= 0 && model_id_ >= 0 && body_id_ >= 0)
+      id_ = m3t_hip_depth_modality_create(batch_->ctx, &params_, body_id_, depth_id_, model_id_);
+    set_up_ = id_ >= 0;
+    if (!set_up_) std::cerr << m3t_hip_last_error(batch_->ctx) << std::endl;
+    return set_up_;
+  }
+  std::vector<std::shared_ptr<m3t::Camera>> camera_ptrs() const override { return {depth_camera_}; }
+
+ private:
+  void UploadImages(long round) override { batch_->Upload(depth_id_, round); }
+  std::shared_ptr<m3t::DepthCamera> depth_camera_;
+  std::filesystem::path model_path_;
+  m3t_depth_modality_params params_;
+  int depth_id_ = -1, model_id_ = -1;
+};
+
+}  // namespace m3t_hip_adapter
+
+#endif  // M3T_HIP_MODALITY_H_

@@ -1,0 +1,115 @@
+// A host that only knows m3t::Modality drives include/m3t_hip_modality.h the way Tracker does
+// (tracker.cpp:430-517): every step for every modality in turn.  Built against the interface stubs of
+// tests/cpp/m3t_stub/ by tests/test_cpp_adapter.py — once with the C-ABI names mapped onto the CPU oracle (runs
+// anywhere), once against libm3t_hip.so (GPU).
+//   adapter_demo SCENE_DIR     SCENE_DIR/scene.txt: color intrinsics, depth intrinsics + scale, 16 floats depth
+//                              world2camera (column-major), 16 floats body2world; region.bin, depth.bin, color.raw,
+//                              depth.raw next to it
+// Prints per modality its name, 6 gradient and 36 Hessian floats (hex) after one correspondence search.
+#include <cstdio>
+#include <fstream>
+
+#include "m3t_hip_modality.h"
+
+namespace {
+std::vector<unsigned char> ReadFile(const std::string& path) {
+  std::ifstream ifs(path, std::ios::binary);
+  return std::vector<unsigned char>((std::istreambuf_iterator<char>(ifs)), std::istreambuf_iterator<char>());
+}
+template <typename BASE>
+class RawFileCamera : public BASE {
+ public:
+  RawFileCamera(const std::string& name, const std::string& path, const m3t::Intrinsics& intrinsics, int bytes_per_pixel)
+      : BASE{name}, path_{path}, bytes_per_pixel_{bytes_per_pixel} {
+    this->intrinsics_ = intrinsics;
+  }
+  bool SetUp() override { return UpdateImage(true); }
+  bool UpdateImage(bool) override {
+    pixels_ = ReadFile(path_);
+    const size_t row = size_t(this->intrinsics_.width) * size_t(bytes_per_pixel_);
+    if (pixels_.size() != row * size_t(this->intrinsics_.height)) return false;
+    this->image_.data = pixels_.data();
+    this->image_.step = row;
+    this->image_.rows = this->intrinsics_.height;
+    this->image_.cols = this->intrinsics_.width;
+    return true;
+  }
+  void set_world2camera_pose(const m3t::Transform3fA& pose) { this->world2camera_pose_ = pose; }
+  void set_depth_scale(float s) { SetScale(s, this); }
+
+ private:
+  static void SetScale(float s, m3t::DepthCamera* c) {
+    struct Access : m3t::DepthCamera {
+      using m3t::DepthCamera::depth_scale_;
+    };
+    c->*(&Access::depth_scale_) = s;
+  }
+  static void SetScale(float, m3t::ColorCamera*) {}
+  std::string path_;
+  int bytes_per_pixel_;
+  std::vector<unsigned char> pixels_;
+};
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 1;
+  const std::string dir = argv[1];
+  std::ifstream scene(dir + "/scene.txt");
+  m3t::Intrinsics ci{}, di{};
+  float depth_scale = 0.0f;
+  m3t::Transform3fA depth_world2camera, body2world;
+  scene >> ci.fu >> ci.fv >> ci.ppu >> ci.ppv >> ci.width >> ci.height;
+  scene >> di.fu >> di.fv >> di.ppu >> di.ppv >> di.width >> di.height >> depth_scale;
+  for (float& v : depth_world2camera.m) scene >> v;
+  for (float& v : body2world.m) scene >> v;
+  if (!scene) return 2;
+
+  auto body = std::make_shared<m3t::Body>("triangle");
+  body->set_body2world_pose(body2world);
+  auto color = std::make_shared<RawFileCamera<m3t::ColorCamera>>("color_camera", dir + "/color.raw", ci, 3);
+  auto depth = std::make_shared<RawFileCamera<m3t::DepthCamera>>("depth_camera", dir + "/depth.raw", di, 2);
+  depth->set_world2camera_pose(depth_world2camera);
+  depth->set_depth_scale(depth_scale);
+  if (!color->SetUp() || !depth->SetUp()) return 3;
+
+  using namespace m3t_hip_adapter;
+  auto batch = std::make_shared<HipBatch>(0);
+  if (!batch->ctx) return 4;
+  m3t_region_modality_params rp;
+  m3t_region_modality_params_default(&rp);
+  m3t_depth_modality_params dp;
+  m3t_depth_modality_params_default(&dp);
+  dp.measure_occlusions = 1;
+  std::vector<std::shared_ptr<m3t::Modality>> modalities{
+      std::make_shared<HipRegionModality>("triangle_region_modality", body, color, dir + "/region.bin", batch, rp, depth),
+      std::make_shared<HipDepthModality>("triangle_depth_modality", body, depth, dir + "/depth.bin", batch, dp)};
+
+  if (modalities[0]->CalculateCorrespondences(0, 0)) return 5;  // "Set up modality ... first" (TestWithoutSetUp)
+  for (auto& m : modalities)
+    if (!m->SetUp()) return 6;
+  if (batch->bodies.size() != 1 || batch->cameras.size() != 2) return 7;  // one device body, cameras shared
+  for (auto& m : modalities)
+    if (!m->StartModality(0, 0)) return 8;
+  for (auto& m : modalities)
+    if (!m->CalculateCorrespondences(0, 0)) return 9;
+  for (auto& m : modalities)
+    if (!m->CalculateGradientAndHessian(0, 0, 0)) return 10;
+  for (auto& m : modalities) {
+    std::printf("%s", m->name().c_str());
+    for (float v : m->gradient().v) std::printf(" %a", double(v));
+    for (float v : m->hessian().v) std::printf(" %a", double(v));
+    std::printf("\n");
+  }
+  // the host moves the body (its own optimizer would): the next round pushes the new pose to the device
+  m3t::Transform3fA moved = body->body2world_pose();
+  moved.m[12] += 0.001f;
+  body->set_body2world_pose(moved);
+  for (auto& m : modalities)
+    if (!m->CalculateGradientAndHessian(0, 0, 1)) return 11;
+  std::printf("moved");
+  for (float v : modalities[1]->gradient().v) std::printf(" %a", double(v));
+  std::printf("\n");
+  for (auto& m : modalities)
+    if (!m->CalculateResults(0)) return 12;
+  return 0;
+}

@@ -1,0 +1,33 @@
+#ifndef M3T_STUB_MODALITY_H_
+#define M3T_STUB_MODALITY_H_
+#include <m3t/body.h>
+#include <m3t/camera.h>
+namespace m3t {
+class Modality {  // include/m3t/modality.h:56-155: the seven steps, the g/H getters and what they read
+ public:
+  virtual ~Modality() = default;
+  virtual bool SetUp() = 0;
+  virtual bool StartModality(int iteration, int corr_iteration) = 0;
+  virtual bool CalculateCorrespondences(int iteration, int corr_iteration) = 0;
+  virtual bool VisualizeCorrespondences(int save_idx) = 0;
+  virtual bool CalculateGradientAndHessian(int iteration, int corr_iteration, int opt_iteration) = 0;
+  virtual bool VisualizeOptimization(int save_idx) = 0;
+  virtual bool CalculateResults(int iteration) = 0;
+  virtual bool VisualizeResults(int save_idx) = 0;
+  const Eigen::Matrix<float, 6, 1>& gradient() const { return gradient_; }
+  const Eigen::Matrix<float, 6, 6>& hessian() const { return hessian_; }
+  const std::string& name() const { return name_; }
+  const std::shared_ptr<Body>& body_ptr() const { return body_ptr_; }
+  virtual std::vector<std::shared_ptr<Camera>> camera_ptrs() const = 0;
+  bool set_up() const { return set_up_; }
+
+ protected:
+  Modality(const std::string& name, const std::shared_ptr<Body>& body_ptr) : name_{name}, body_ptr_{body_ptr} {}
+  std::string name_;
+  Eigen::Matrix<float, 6, 1> gradient_;
+  Eigen::Matrix<float, 6, 6> hessian_;
+  std::shared_ptr<Body> body_ptr_ = nullptr;
+  bool set_up_ = false;
+};
+}  // namespace m3t
+#endif  // M3T_STUB_MODALITY_H_
