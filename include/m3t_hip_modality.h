@@ -104,6 +104,34 @@ struct HipBatch {
     }
     return ok;
   }
+  // "fast mode" (INTEGRATION.md §2): the library also optimises.  Register one rigid optimizer per body with the
+  // device ids of its modalities (Optimizer::tikhonov_parameter_rotation / _translation, optimizer.h:135-136),
+  // then Tracker::ExecuteTrackingStep is ExecuteTrackingStep() below.
+  bool AddRigidOptimizer(const std::shared_ptr<m3t::Body>& body, const std::vector<int>& modality_ids,
+                         float tikhonov_parameter_rotation = 1000.0f, float tikhonov_parameter_translation = 30000.0f) {
+    const int rc = m3t_hip_optimizer_create_rigid(ctx, BodyId(body), int(modality_ids.size()), modality_ids.data(),
+                                                  tikhonov_parameter_rotation, tikhonov_parameter_translation);
+    if (rc < 0) std::cerr << m3t_hip_last_error(ctx) << std::endl;
+    return rc >= 0;
+  }
+  // StartModalities / ExecuteTrackingStep of tracker.cpp:344-364,430-445 for every registered body at once:
+  // images up, poses up, the whole loop nest on the device, poses back into the host Bodies
+  bool StartModalities(int iteration) {
+    for (auto& c : cameras) Upload(c.id, -2 - 2L * iteration);
+    PushPoses();
+    return Status(m3t_hip_start_modalities(ctx, iteration));
+  }
+  bool ExecuteTrackingStep(int iteration, int n_corr_iterations, int n_update_iterations) {
+    for (auto& c : cameras) Upload(c.id, -3 - 2L * iteration);
+    PushPoses();
+    return Status(m3t_hip_set_fused_step(ctx, 1)) &&
+           Status(m3t_hip_tracker_set_iterations(ctx, n_corr_iterations, n_update_iterations)) &&
+           Status(m3t_hip_execute_tracking_step(ctx, iteration)) && PullPoses();
+  }
+  bool Status(int rc) const {
+    if (rc < 0) std::cerr << m3t_hip_last_error(ctx) << std::endl;
+    return rc >= 0;
+  }
   // runs f once per round key; f returns a C-ABI status
   template <typename F>
   bool Once(long* round, long key, F f) {

@@ -2,7 +2,7 @@
 // (tracker.cpp:430-517): every step for every modality in turn.  Built against the interface stubs of
 // tests/cpp/m3t_stub/ by tests/test_cpp_adapter.py — once with the C-ABI names mapped onto the CPU oracle (runs
 // anywhere), once against libm3t_hip.so (GPU).
-//   adapter_demo SCENE_DIR     SCENE_DIR/scene.txt: color intrinsics, depth intrinsics + scale, 16 floats depth
+//   adapter_demo SCENE_DIR [adapter-only]     SCENE_DIR/scene.txt: color intrinsics, depth intrinsics + scale, 16 floats depth
 //                              world2camera (column-major), 16 floats body2world; region.bin, depth.bin, color.raw,
 //                              depth.raw next to it
 // Prints per modality its name, 6 gradient and 36 Hessian floats (hex) after one correspondence search.
@@ -111,5 +111,20 @@ int main(int argc, char** argv) {
   std::printf("\n");
   for (auto& m : modalities)
     if (!m->CalculateResults(0)) return 12;
+
+  if (argc > 2 && std::string(argv[2]) == "adapter-only") return 0;
+  // fast mode on a second batch: the library optimises, the host Body receives the pose
+  auto fast_body = std::make_shared<m3t::Body>("triangle");
+  fast_body->set_body2world_pose(body2world);
+  auto fast = std::make_shared<HipBatch>(0);
+  if (!fast->ctx) return 13;
+  auto region = std::make_shared<HipRegionModality>("region", fast_body, color, dir + "/region.bin", fast, rp, depth);
+  auto depth_modality = std::make_shared<HipDepthModality>("depth", fast_body, depth, dir + "/depth.bin", fast, dp);
+  if (!region->SetUp() || !depth_modality->SetUp()) return 14;
+  if (!fast->AddRigidOptimizer(fast_body, {region->device_id(), depth_modality->device_id()})) return 15;
+  if (!fast->StartModalities(0) || !fast->ExecuteTrackingStep(0, 7, 2)) return 16;
+  std::printf("fast");
+  for (float v : fast_body->body2world_pose().m) std::printf(" %a", double(v));
+  std::printf("\n");
   return 0;
 }

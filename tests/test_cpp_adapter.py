@@ -66,13 +66,31 @@ def expected(api, directory, world2camera, body2world):
     return first, depth_modality.gradient()
 
 
-def run_demo(exe, directory):
-    out = subprocess.run([exe, str(directory)], capture_output=True, text=True, timeout=300)
+def expected_fast_pose(api, directory, world2camera, body2world):
+    """TrackerTest.OptimizePoseMatrix's object graph: StartModalities + one ExecuteTrackingStep of 7 x 2 iterations"""
+    body = host.Body(api, body2world)
+    color = host.ColorCamera(api, **util.COLOR_INTR)
+    depth = host.DepthCamera(api, depth_scale=0.001, world2camera_pose=world2camera, **util.DEPTH_INTR)
+    region = host.RegionModality(api, body, color, host.RegionModel(api, path=str(directory / "region.bin")),
+                                 depth_camera=depth, measure_occlusions=1)
+    depth_modality = host.DepthModality(api, body, depth, host.DepthModel(api, path=str(directory / "depth.bin")),
+                                        measure_occlusions=1)
+    host.Optimizer(api, body=body, modalities=[region, depth_modality])
+    tracker = host.Tracker(api, 7, 2)
+    color.UpdateImage(util.load_color_frame(200))
+    depth.UpdateImage(util.load_depth_frame(200))
+    assert tracker.StartModalities(0) and tracker.ExecuteTrackingStep(0)
+    return body.body2world_pose()
+
+
+def run_demo(exe, directory, *args):
+    out = subprocess.run([exe, str(directory)] + list(args), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.returncode, out.stderr)
     assert "Set up modality triangle_region_modality first" in out.stderr
     rows = {line.split()[0]: np.array([float.fromhex(x) for x in line.split()[1:]], np.float32)
             for line in out.stdout.strip().splitlines()}
-    return [rows["triangle_region_modality"], rows["triangle_depth_modality"]], rows["moved"]
+    fast = rows["fast"].reshape(4, 4).T if "fast" in rows else None
+    return [rows["triangle_region_modality"], rows["triangle_depth_modality"]], rows["moved"], fast
 
 
 def test_adapter_header_compiles_against_the_interface_stubs():
@@ -95,12 +113,16 @@ def test_adapter_over_the_oracle_library(tmp_path):
                           [SRC, str(shim), "-o", exe, "-L", util.ORACLE_DIR, "-lm3t_oracle",
                            "-Wl,-rpath," + util.ORACLE_DIR])
     world2camera, body2world = write_scene(tmp_path)
-    got, got_moved = run_demo(exe, tmp_path)
+    got, got_moved, fast_pose = run_demo(exe, tmp_path)
     want, want_moved = expected(util.open_oracle(), tmp_path, world2camera, body2world)
     for a, b in zip(got, want):
         assert a.shape == (42,) and np.array_equal(a, b)
     assert np.abs(got[0]).max() > 0 and np.abs(got[1]).max() > 0
     assert np.array_equal(got_moved, want_moved) and not np.array_equal(got_moved, want[1][:6])
+    # fast mode: the host Body ends on the pose the Python-driven tracker reaches, which is the reference's golden
+    assert np.array_equal(fast_pose, expected_fast_pose(util.open_oracle(), tmp_path, world2camera, body2world))
+    golden = util.read_golden_matrix("tracker_test/triangle_pose.txt")
+    assert np.max(np.abs((fast_pose - golden)[:3] / golden[:3])) < 1e-5
 
 
 @pytest.mark.gpu
@@ -110,7 +132,7 @@ def test_adapter_over_the_hip_library(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall"] + INCLUDES + [SRC, "-o", exe, "-L", libdir, "-lm3t_hip",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     world2camera, body2world = write_scene(tmp_path)
-    got, got_moved = run_demo(exe, tmp_path)
+    got, got_moved, _ = run_demo(exe, tmp_path, "adapter-only")
     want, want_moved = expected(util.open_hip(), tmp_path, world2camera, body2world)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
