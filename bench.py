@@ -253,6 +253,7 @@ def main():
                        "tracked_within_5cm_5deg": "%d/%d" % (tracked, n_obj), "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "frac_of_hbm_roofline_whole_step": round(total / elapsed * B_ALG / (HBM_PEAK_GBS * 1e9 * n_gpus), 5),
+            "newton_steps_per_s": round(total / elapsed * 14, 1),  # 7 correspondence iterations x 2 updates
         }
         if sweep:
             out["batch_sweep"] = sweep
