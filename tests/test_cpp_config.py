@@ -167,3 +167,87 @@ def test_cpp_evaluators_agree_with_the_python_evaluators(demo, tmp_path):
         assert float(out[3]) == pytest.approx(want["add_auc"], abs=1e-5)
         assert float(out[4]) == pytest.approx(want["adds_auc"], abs=1e-5)
         assert int(out[5]) == int((want["add_curve"] == 0).sum()) and int(out[6]) == int((want["adds_curve"] == 0).sum())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the same C++ front-end over the CPU oracle: every m3t_hip_* name is mapped onto its m3t_oracle_* twin, the entry
+# points only the device library has become stubs that answer M3T_ERR_UNSUPPORTED — so the generator's wiring is
+# exercised without a GPU
+# ---------------------------------------------------------------------------------------------------------
+def _oracle_mapping(tmp):
+    import re
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "m3t_hip.h")).read(), flags=re.S)
+    oracle = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "oracle", "m3t_oracle.h")).read(), flags=re.S)
+    prototypes = re.findall(r"\bint\s+(m3t_hip_\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.S)
+    in_oracle = set(re.findall(r"\bm3t_oracle_(\w+)\s*\(", oracle))
+    names = sorted({n for n, _ in prototypes} | {"m3t_hip_create", "m3t_hip_destroy", "m3t_hip_last_error"})
+    rename = tmp / "rename.h"
+    rename.write_text("#define m3t_hip_context m3t_oracle_context\n" +
+                      "".join("#define %s %s\n" % (n, n.replace("m3t_hip_", "m3t_oracle_")) for n in names))
+    shim = tmp / "shim.cpp"
+    shim.write_text('#include "m3t_hip.h"\nextern "C" {\n' +
+                    "".join("int %s(%s) { return M3T_ERR_UNSUPPORTED; }\n" % (n, " ".join(a.split()))
+                            for n, a in prototypes if n[len("m3t_hip_"):] not in in_oracle) + "}\n")
+    return rename, shim
+
+
+@pytest.fixture(scope="module")
+def demo_oracle(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("cpp_config_oracle")
+    rename, shim = _oracle_mapping(tmp)
+    util.build_oracle()
+    exe = str(tmp / "config_demo_oracle")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-parameter", "-include", str(rename), "-I",
+                           os.path.join(ROOT, "include"), SRC, str(shim), "-o", exe, "-L", util.ORACLE_DIR,
+                           "-lm3t_oracle", "-lz", "-Wl,-rpath," + util.ORACLE_DIR])
+
+    def run(*args, ok=True):
+        out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+        assert (out.returncode == 0) == ok, (out.returncode, out.stdout, out.stderr)
+        return out.stdout.strip() if ok else out.stderr.strip()
+    return run
+
+
+def _pose_of(line):
+    name, n_corr, n_update, *pose = line.split()
+    return name, np.array([float.fromhex(x) for x in pose], np.float32).reshape(4, 4).T
+
+
+def test_cpp_generated_tracker_over_the_oracle(demo_oracle, tmp_path):
+    from test_generator import write_fixture_models
+    root = reference_tree(tmp_path)
+    write_fixture_models(root)
+    config = root / "tracker_test" / "tracker_config.yaml"
+    out = demo_oracle("track", config).splitlines()
+    name, pose = _pose_of(out[0])
+    golden = util.read_golden_matrix("tracker_test/triangle_pose.txt")
+    assert name == "triangle" and np.max(np.abs((pose - golden)[:3] / golden[:3])) < 1e-5
+    # the Python front-end over the same library reaches the same pose bit for bit
+    tracker = util.pkg.generator.GenerateConfiguredTracker(util.open_oracle(), str(config))
+    assert tracker.SetUp() and tracker.DetectPoses({"triangle_optimizer"})
+    assert tracker.StartModalities(0) and tracker.ExecuteTrackingStep(0)
+    assert np.array_equal(tracker.body_ptrs()[0].body2world_pose(), pose)
+    # errors keep the reference's wording
+    config.write_text(config.read_text().replace('    root_link: "triangle_link"\n', ""))
+    assert 'Required parameter "root_link" was not found for class Optimizer' in demo_oracle("track", config, ok=False)
+
+
+def test_cpp_generator_wires_trees_renderers_shared_histograms_and_constraints(demo_oracle, tmp_path):
+    """the configuration of test_generator.py's wiring test (two bodies in a kinematic tree, focused depth renderer
+    for modelled occlusions, shared colour histograms, hard and soft constraint, link / optimizer / modality
+    metafiles) through the C++ front-end: the poses of both bodies equal the Python front-end's, bit for bit"""
+    from test_generator import write_fixture_models, write_tree_config
+    root = reference_tree(tmp_path)
+    write_fixture_models(root)
+    write_tree_config(root)
+    (root / "tracker_test" / "tracker.yaml").write_text("%YAML:1.2\nn_corr_iterations: 4\nn_update_iterations: 2\n")
+    config = root / "tracker_test" / "tree_config.yaml"
+    rows = [line for line in demo_oracle("track", config).splitlines() if not line.startswith("model ")]
+    poses = dict(_pose_of(line) for line in rows)
+    assert set(poses) == {"triangle", "schauma"} and rows[0].split()[1:3] == ["4", "2"]
+    tracker = util.pkg.generator.GenerateConfiguredTracker(util.open_oracle(), str(config))
+    assert tracker.SetUp() and tracker.DetectPoses({"optimizer"})
+    assert tracker.StartModalities(0) and tracker.ExecuteTrackingStep(0)
+    for name in poses:
+        assert np.array_equal(tracker.objects["Body"][name].body2world_pose(), poses[name]), name
+    assert not np.array_equal(poses["triangle"], poses["schauma"])
