@@ -33,9 +33,7 @@ def test_cpp_mirror_compiles_and_links(tmp_path):
                            "-o", str(tmp_path / "abi.o")])
 
 
-@pytest.mark.gpu
-def test_cpp_host_matches_python_host(tmp_path):
-    exe = _build(tmp_path)
+def _run_cpp_host(exe, tmp_path):
     inputs = scenes.Inputs(3, 3, n_divides=2)
     d = tmp_path / "scene"
     d.mkdir()
@@ -57,12 +55,34 @@ def test_cpp_host_matches_python_host(tmp_path):
     assert out.returncode == 0, (out.returncode, out.stderr)
     assert "first" in out.stderr  # the reference's "Set up ... first" convention on the premature call
     cpp = np.array([[float.fromhex(x) for x in line.split()] for line in out.stdout.strip().splitlines()], np.float32)
-    hip = util.open_hip()
-    a = scenes.Instance(hip, inputs)
+    return inputs, cpp
+
+
+def _python_poses(api, inputs):
+    a = scenes.Instance(api, inputs)
     a.upload_frame(0)
     assert a.tracker.StartModalities(0)
     for k in range(inputs.n_frames):
         a.upload_frame(k)
         assert a.tracker.ExecuteTrackingStep(k)
-    py = np.stack([np.ascontiguousarray(p.T).reshape(16) for p in a.poses()])
-    assert np.array_equal(cpp, py)
+    return np.stack([np.ascontiguousarray(p.T).reshape(16) for p in a.poses()])
+
+
+def test_cpp_host_over_the_oracle_library(tmp_path):
+    """the same C++ program on CPU: the C-ABI names mapped onto the oracle library (tests/test_cpp_config.py)"""
+    from test_cpp_config import _oracle_mapping
+    rename, shim = _oracle_mapping(tmp_path)
+    util.build_oracle()
+    exe = str(tmp_path / "host_demo_oracle")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-parameter", "-include", str(rename), "-I",
+                           os.path.join(ROOT, "include"), SRC, str(shim), "-o", exe, "-L", util.ORACLE_DIR,
+                           "-lm3t_oracle", "-Wl,-rpath," + util.ORACLE_DIR])
+    inputs, cpp = _run_cpp_host(exe, tmp_path)
+    assert np.array_equal(cpp, _python_poses(util.open_oracle(), inputs))
+
+
+@pytest.mark.gpu
+def test_cpp_host_matches_python_host(tmp_path):
+    exe = _build(tmp_path)
+    inputs, cpp = _run_cpp_host(exe, tmp_path)
+    assert np.array_equal(cpp, _python_poses(util.open_hip(), inputs))
