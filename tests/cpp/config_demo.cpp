@@ -6,12 +6,15 @@
 //   rbot POSES N            first / last translation of an RBOT pose file and a criterion check
 //   ycb POSES BEGIN N K...  keyframe poses of a YCB pose file
 //   adds OBJ N POSE16 GT16  ADD / ADD-S / AUC of a mesh's (reduced) vertices under two poses (row-major 4x4 each)
+//   rbot-dataset DATASET EXTERNAL N_FRAMES N_DIVIDES BODY...       EvaluateRbotDataset on sequence a_regular
+//   ycb-dataset DATASET EXTERNAL N_DIVIDES N_POINTS N_VERTICES SEQ_ID... -- BODY...   EvaluateYcbDataset
 //   track CONFIG            GenerateConfiguredTracker + SetUp + DetectPoses + StartModalities + one step (needs a GPU)
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
 
 #include "m3t_hip_config.hpp"
+#include "m3t_hip_datasets.hpp"
 #include "m3t_hip_evaluation.hpp"
 
 using namespace m3t_hip;
@@ -144,6 +147,33 @@ int main(int argc, char** argv) {
       for (float v : r.adds_curve) adds_zeros += v == 0.0f;
       std::printf("%zu %.9g %.9g %.9g %.9g %d %d %.9g\n", vertices.size(), double(r.add_error), double(r.adds_error),
                   double(r.add_auc), double(r.adds_auc), add_zeros, adds_zeros, double(vertices[0][0]));
+      return 0;
+    }
+    namespace ds = m3t_hip::datasets;
+    if (mode == "rbot-dataset" && argc >= 7) {
+      cfg::ModelParameters p = ds::RbotModelParameters();
+      p.n_divides = std::atoi(argv[5]);
+      std::vector<std::string> bodies(argv + 6, argv + argc);
+      auto results = ds::EvaluateRbotDataset([] { return std::make_shared<Context>(0); }, argv[2], argv[3], bodies,
+                                             {"a_regular"}, std::atoi(argv[4]), ds::RbotRegionParameters(), p);
+      for (auto& r : results)
+        std::printf("%s %s %.9g %.9g %.9g\n", r.sequence.c_str(), r.body.c_str(), r.tracking_success,
+                    r.translation_error, r.rotation_error);
+      return 0;
+    }
+    if (mode == "ycb-dataset" && argc >= 9) {
+      cfg::ModelParameters p = ds::YcbModelParameters();
+      p.n_divides = std::atoi(argv[4]);
+      p.n_points = std::atoi(argv[5]);
+      std::vector<int> sequences;
+      std::vector<std::string> bodies;
+      int i = 7;
+      for (; i < argc && std::string(argv[i]) != "--"; ++i) sequences.push_back(std::atoi(argv[i]));
+      for (++i; i < argc; ++i) bodies.push_back(argv[i]);
+      auto results = ds::EvaluateYcbDataset([] { return std::make_shared<Context>(0); }, argv[2], argv[3], sequences,
+                                            bodies, std::atoi(argv[6]), p);
+      for (auto& r : results)
+        std::printf("%s %s %d %.9g %.9g\n", r.sequence.c_str(), r.body.c_str(), r.n_frames, r.add_auc, r.adds_auc);
       return 0;
     }
     if (mode == "track" && argc >= 3) {

@@ -251,3 +251,32 @@ def test_cpp_generator_wires_trees_renderers_shared_histograms_and_constraints(d
     for name in poses:
         assert np.array_equal(tracker.objects["Body"][name].body2world_pose(), poses[name]), name
     assert not np.array_equal(poses["triangle"], poses["schauma"])
+
+
+def test_cpp_dataset_drivers_over_the_oracle(demo_oracle, tmp_path):
+    """include/m3t_hip_datasets.hpp on the synthetic RBOT- and YCB-layout datasets of tests/test_evaluation.py: the
+    same runs, the same scores as the Python drivers over the same library"""
+    from test_evaluation import write_rbot_dataset, write_ycb_dataset
+    ev = util.pkg.evaluation
+    (tmp_path / "rbot").mkdir()
+    dataset, external, names, model_parameters = write_rbot_dataset(tmp_path / "rbot", 5)
+    rows = [line.split() for line in demo_oracle("rbot-dataset", dataset, external, 5, model_parameters["n_divides"],
+                                                  *names).splitlines()]
+    want, _ = ev.evaluate_rbot_dataset(util.open_oracle, str(dataset), str(external), names, ["a_regular"], n_frames=5,
+                                       model_parameters=model_parameters)
+    assert [(r[0], r[1]) for r in rows] == list(want)
+    for r in rows:
+        w = want[(r[0], r[1])]
+        assert float(r[2]) == w["tracking_success"] == 1.0
+        assert float(r[3]) == pytest.approx(w["translation_error"], abs=1e-7)
+        assert float(r[4]) == pytest.approx(w["rotation_error"], abs=2e-4)  # acos near 1 amplifies the last bit
+    (tmp_path / "ycb").mkdir()
+    dataset, external, names, model_parameters = write_ycb_dataset(tmp_path / "ycb")
+    rows = [line.split() for line in demo_oracle("ycb-dataset", dataset, external, model_parameters["n_divides"],
+                                                  model_parameters["n_points"], 4, 0, 1, "--", *names).splitlines()]
+    want, _ = ev.evaluate_ycb_dataset(util.open_oracle, str(dataset), str(external), [0, 1], names,
+                                      n_vertices_evaluation=4, model_parameters=model_parameters)
+    assert [(r[0], r[1]) for r in rows] == list(want) and [int(r[2]) for r in rows] == [4, 2]
+    for r in rows:
+        w = want[(r[0], r[1])]
+        assert float(r[3]) == pytest.approx(w["add_auc"], abs=1e-5) and float(r[4]) == pytest.approx(w["adds_auc"], abs=1e-5)

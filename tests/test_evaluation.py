@@ -124,13 +124,12 @@ def test_ycb_loop_on_a_synthetic_sequence():
         assert average[n]["adds_curve"][-1] == 1.0 and average[n]["adds_curve"].shape == (100,)
 
 
-def test_rbot_dataset_driver_on_a_synthetic_dataset_in_the_rbot_layout(tmp_path):
-    """evaluate_rbot_dataset (examples/evaluate_rbot_dataset.cpp): bodies as <dataset>/<body>/<body>.obj in mm,
-    frames <dataset>/<body>/frames/<sequence>NNNN.png, one poses_first.txt for all bodies, models under
-    <external>/models/ — a two-body, one-sequence, five-frame dataset of the synthetic scenes, tracked by the oracle"""
+def write_rbot_dataset(tmp_path, n_frames=5):
+    """a two-body, one-sequence dataset of the synthetic scenes in the RBOT layout, with the region models the
+    device would generate replaced by the synthetic bodies' (the oracle cannot generate); returns
+    (dataset, external, body names, model parameters)"""
     from PIL import Image
     cfg = util.pkg.config
-    n_frames = 5
     dataset, external = tmp_path / "RBOT_dataset", tmp_path / "external"
     scenes_ = [util.syn.Scene(i, intr=dict(zip(("fu", "fv", "ppu", "ppv", "width", "height"), ev.RBOT_INTRINSICS)))
                for i in range(2)]
@@ -163,6 +162,15 @@ def test_rbot_dataset_driver_on_a_synthetic_dataset_in_the_rbot_layout(tmp_path)
                             cfg.maximum_body_diameter(vertices), np.eye(4))
         cfg.write_model_bin(str(external / "models" / (name + "_model.bin")), True, model_parameters, data, points,
                             orientations, lengths)
+    return dataset, external, names, model_parameters
+
+
+def test_rbot_dataset_driver_on_a_synthetic_dataset_in_the_rbot_layout(tmp_path):
+    """evaluate_rbot_dataset (examples/evaluate_rbot_dataset.cpp): bodies as <dataset>/<body>/<body>.obj in mm,
+    frames <dataset>/<body>/frames/<sequence>NNNN.png, one poses_first.txt for all bodies, models under
+    <external>/models/ — a two-body, one-sequence, five-frame dataset of the synthetic scenes, tracked by the oracle"""
+    n_frames = 5
+    dataset, external, names, model_parameters = write_rbot_dataset(tmp_path, n_frames)
     titles = []
     results, overall = ev.evaluate_rbot_dataset(util.open_oracle, str(dataset), str(external), names, ["a_regular"],
                                                 n_frames=n_frames, model_parameters=model_parameters,
@@ -195,11 +203,9 @@ def _pose_line(p):
     return " ".join("%.9g" % v for v in (w, x, y, z, m[0, 3], m[1, 3], m[2, 3]))
 
 
-def test_ycb_dataset_driver_on_a_synthetic_dataset_in_the_ycb_layout(tmp_path):
-    """evaluate_ycb_dataset (examples/evaluate_ycb_dataset.cpp): models/<body>/textured.obj, data/<sequence>/
-    NNNNNN-{color,depth}.png + NNNNNN-box.txt, image_sets/keyframe.txt, ground truth per keyframe under
-    external/poses/ground_truth/ or per frame in the dataset's poses/<body>.txt — two sequences with one synthetic
-    body each, Region + Depth with measured occlusions on the oracle"""
+def write_ycb_dataset(tmp_path):
+    """two sequences with one synthetic body each in the YCB-Video layout, ground truth in both forms, models
+    pre-written; returns (dataset, external, body names, model parameters)"""
     from PIL import Image
     cfg = util.pkg.config
     dataset, external = tmp_path / "YCB-Video", tmp_path / "external"
@@ -241,6 +247,15 @@ def test_ycb_dataset_driver_on_a_synthetic_dataset_in_the_ycb_layout(tmp_path):
         cfg.write_model_bin(str(external / "models" / (name + "_region_model.bin")), True, model_parameters, data, rp, ro, rl)
         dp, do, da = util.syn.make_depth_model(scene.body, n_divides=2, n_points=200)
         cfg.write_model_bin(str(external / "models" / (name + "_depth_model.bin")), False, model_parameters, data, dp, do, da)
+    return dataset, external, names, model_parameters
+
+
+def test_ycb_dataset_driver_on_a_synthetic_dataset_in_the_ycb_layout(tmp_path):
+    """evaluate_ycb_dataset (examples/evaluate_ycb_dataset.cpp): models/<body>/textured.obj, data/<sequence>/
+    NNNNNN-{color,depth}.png + NNNNNN-box.txt, image_sets/keyframe.txt, ground truth per keyframe under
+    external/poses/ground_truth/ or per frame in the dataset's poses/<body>.txt — two sequences with one synthetic
+    body each, Region + Depth with measured occlusions on the oracle"""
+    dataset, external, names, model_parameters = write_ycb_dataset(tmp_path)
     assert ev.ycb_keyframes(str(dataset), "0000") == [1, 2, 4, 5] and ev.ycb_n_frames(str(dataset), "0001") == 3
     assert ev.ycb_sequence_bodies(str(dataset), "0001") == [names[1]]
     titles = []
