@@ -171,6 +171,10 @@ struct TrackLdsLayout {
   int off_seg_b;   // nl * ns
   int off_misc;    // reduction scratch
   int off_hist;    // optional LDS-staged histogram_norm (float2[n_bins^3]) or -1
+  // product rows of the gradient / Hessian sums ([27][pitch] floats each, 16-byte aligned); they take over the
+  // chain / segment buffers, which are dead between two correspondence searches
+  int off_rows_r, pitch_r;   // region modality: one column per correspondence line
+  int off_rows_d, pitch_d;   // depth modality: one column per correspondence point
   int total_floats;
 };
 
@@ -178,6 +182,7 @@ struct TrackLdsLayout {
 #define M3T_BLOCK_THREADS 512
 #endif
 #define M3T_MISC_FLOATS 1024
-#define M3T_SPLIT_PARTS 4  /* workgroups per object in tracking_step_split_kernel */
+#define M3T_SPLIT_LANES 256   /* tracking_step_split_kernel: workgroups per object x padded elements per part */
+#define M3T_SPLIT_MAX_PARTS 16
 
 #endif  // M3T_DEVICE_H_

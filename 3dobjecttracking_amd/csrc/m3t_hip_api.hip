@@ -183,10 +183,13 @@ struct m3t_hip_context {
   // several workgroups per object (tracking_step_split_kernel) for batches that leave most CUs idle
   bool split_possible = false;
   bool split_enabled = true;  // m3t_hip_set_object_split
-  DevMem d_split;            // [objects][2 rounds][M3T_SPLIT_PARTS][32] granules, then the timeout word
+  DevMem d_split;            // [objects][2 slots][parts][32 fields][256 / parts] granules, then one abort word per object
   size_t split_objects = 0;  // capacity of d_split
   unsigned split_seq = 0;    // launch counter inside the granule tags
-  bool split_check_pending = false;
+  int split_parts_override = 0;  // m3t_hip_set_object_split(ctx, n > 1): workgroups per object (0: automatic)
+  unsigned* split_abort_host = nullptr;  // mapped host word: sequence number of a split step that gave up
+  unsigned* split_abort_dev = nullptr;   // the same word as the device sees it
+  unsigned split_abort_seen = 0;
   int last_step_shape[4] = {0, 0, 0, 0};  // m3t_hip_get_step_shape
   bool state_valid = false;  // line/point state + g/H on the device reflect the last step
   TrackLdsLayout layout{};
@@ -387,16 +390,15 @@ int UploadFrame(Ctx* ctx, int id, int slot, const void* pixels, size_t row_step)
 // After a synchronisation: did the workgroups of a split object ever give up waiting for each other?  (They
 // are all resident by construction; the bounded wait exists so that a surprise cannot hang the device.)
 int CheckSplitExchange(Ctx* ctx) {
-  if (!ctx->split_check_pending) return M3T_OK;
-  ctx->split_check_pending = false;
-  unsigned* flag = reinterpret_cast<unsigned*>(ctx->d_split.as<unsigned long long>() +
-                                               ctx->split_objects * (2 * M3T_SPLIT_PARTS * 32));
-  unsigned value = 0;
-  HIPCHK(hipMemcpy(&value, flag, sizeof(value), hipMemcpyDeviceToHost));
-  if (value) {
-    HIPCHK(hipMemset(flag, 0, sizeof(value)));
-    return Fail(ctx, M3T_ERR_DEVICE, "tracking_step_split_kernel: a workgroup waited in vain for its object's other "
-                                     "workgroups; the poses of this step are invalid (M3T_HIP_NO_SPLIT=1 avoids the kernel)");
+  // the word lives in mapped host memory: no copy, no synchronisation; the kernel writes it with system scope
+  if (!ctx->split_abort_host) return M3T_OK;
+  const unsigned value = __atomic_load_n(ctx->split_abort_host, __ATOMIC_ACQUIRE);
+  if (value != ctx->split_abort_seen) {
+    ctx->split_abort_seen = value;
+    return Fail(ctx, M3T_ERR_DEVICE,
+                "tracking_step_split_kernel: a workgroup waited in vain for its object's other workgroups (is another "
+                "process using this GPU?); the step was abandoned for that object without writing its pose or "
+                "histograms; set the poses again and call start_modalities (m3t_hip_set_object_split(ctx, 0) avoids the kernel)");
   }
   return M3T_OK;
 }
@@ -427,12 +429,22 @@ void ComputeLayout(Ctx* ctx) {
   int off = 0;
   L.off_misc = off; off += M3T_MISC_FLOATS;
   L.off_state = off; off += LS_FIELDS * nl;
+  off = (off + 3) / 4 * 4;
+  // chain | seg_f | seg_b live during a correspondence search; the product rows of the g/H sums during the Newton
+  // steps between two searches: the same LDS
+  const int block = off;
   L.off_chain = off; off += nl * ns;
   L.off_seg_f = off; off += nl * ns;
   L.off_seg_b = off; off += nl * ns;
+  L.pitch_r = chain_pitch(nl);
+  L.pitch_d = chain_pitch(np);
+  L.off_rows_r = block;
+  L.off_rows_d = block + (ctx->region_mods.empty() ? 0 : 27 * L.pitch_r);
+  const int rows_end = L.off_rows_d + (ctx->depth_mods.empty() ? 0 : 27 * L.pitch_d);
+  off = (std::max(off, rows_end) + 3) / 4 * 4;
   ctx->off_points = off;
   ctx->np_max = np;
-  int off_with_points = off + (ctx->depth_mods.empty() ? 0 : (PS_FIELDS + 14) * np);  // + parity-mode staging
+  int off_with_points = off + (ctx->depth_mods.empty() ? 0 : PS_FIELDS * np);
   if (hist_lds) {
     L.off_hist = (off_with_points + 3) / 4 * 4;
     L.total_floats = L.off_hist + bins3 * 2;
@@ -444,7 +456,7 @@ void ComputeLayout(Ctx* ctx) {
   ctx->lds_track = size_t(L.total_floats) * 4;
   // the correspondence-only kernel does not need the depth point block
   ctx->lds_corr = ctx->lds_track;
-  ctx->lds_depth = size_t(M3T_MISC_FLOATS + (PS_FIELDS + 14) * np) * 4;
+  ctx->lds_depth = size_t(M3T_MISC_FLOATS + (PS_FIELDS * np + 3) / 4 * 4 + 27 * L.pitch_d) * 4;
   size_t counts = size_t(bins3) * 4;
   ctx->hist_counts_in_lds = (M3T_MISC_FLOATS * 4 + counts) <= 160 * 1024;
   ctx->lds_hist = M3T_MISC_FLOATS * 4 + (ctx->hist_counts_in_lds ? counts : 0);
@@ -797,10 +809,17 @@ int UploadTables(Ctx* ctx) {
     if (!d.empty()) HIPCHK(hipMemcpy(ctx->d_depth.p, d.data(), d.size() * sizeof(DepthModDev), hipMemcpyHostToDevice));
     // kinematic structures (m3t_links.hip) as soon as one optimizer is more than a free rigid body
     ctx->tree_mode = false;
-    for (auto& o : ctx->optimizers)
+    for (auto& o : ctx->optimizers) {
       if (!ctx->links[o.link].simple || !ctx->links[o.link].children.empty() || !o.constraints.empty() ||
           !o.soft_constraints.empty())
         ctx->tree_mode = true;
+      // a body seen by several cameras carries several modalities of one kind; the rigid table holds one region
+      // and one depth modality per body, the link kernels sum any number (Link::CalculateGradientAndHessian,
+      // link.cpp:184-193, in the order they were added)
+      int n_region = 0, n_depth = 0;
+      for (int mid : ctx->links[o.link].modalities) (ctx->modalities[mid].region ? n_region : n_depth) += 1;
+      if (n_region > 1 || n_depth > 1) ctx->tree_mode = true;
+    }
     if (ctx->tree_mode) {
       int r = UploadTreeTables(ctx);
       if (r) return r;
@@ -847,13 +866,10 @@ int UploadTables(Ctx* ctx) {
     REQUIRE(max_lds <= 160 * 1024, M3T_ERR_UNSUPPORTED,
             "per-object working set exceeds the 160 KB LDS of a CU");
     if (!ctx->hist_counts_in_lds) ctx->fuse_histogram_possible = false;
-    // the split kernel: free rigid bodies with one region modality each, pair table read from L2
-    ctx->split_possible = ctx->fused_possible && ctx->depth_mods.empty() && !ctx->region_mods.empty() &&
-                          ctx->layout.off_hist < 0;
-    for (auto& o : ctx->opt_table)
-      if (o.region_modality < 0 || o.depth_modality >= 0) ctx->split_possible = false;
+    // the split kernel: free rigid bodies with their own histograms (the pair table is read from L2)
+    ctx->split_possible = ctx->fused_possible;
     for (auto& m : ctx->region_mods)
-      if (m->shared_histograms >= 0) ctx->split_possible = false;
+      if (m->shared_histograms >= 0 || m->p.n_histogram_bins < 4) ctx->split_possible = false;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_split_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_kernel),
@@ -964,13 +980,13 @@ int LaunchGradientHessian(Ctx* ctx, int corr_iteration, int opt_iteration) {
   if (nr) {
     hipLaunchKernelGGL(region_gradient_hessian_kernel, dim3(nr), dim3(M3T_BLOCK_THREADS), ctx->lds_corr, ctx->stream,
                        ctx->d_region.as<RegionModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
-                       ctx->layout, corr_iteration, opt_iteration, ctx->sequential_sum);
+                       ctx->layout, corr_iteration, opt_iteration);
     HIPCHK(hipGetLastError());
   }
   if (nd) {
     hipLaunchKernelGGL(depth_gradient_hessian_kernel, dim3(nd), dim3(M3T_BLOCK_THREADS), ctx->lds_depth, ctx->stream,
                        ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
-                       ctx->np_max, corr_iteration, ctx->sequential_sum);
+                       ctx->np_max, corr_iteration);
     HIPCHK(hipGetLastError());
   }
   return M3T_OK;
@@ -1004,7 +1020,7 @@ int LaunchOptimization(Ctx* ctx) {
   }
   int n = int(ctx->opt_table.size());
   if (n == 0) return M3T_OK;
-  hipLaunchKernelGGL(rigid_optimize_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
+  hipLaunchKernelGGL(rigid_optimize_kernel, dim3(n), dim3(64), 0, ctx->stream,
                      ctx->d_opts.as<RigidOptDev>(), n, ctx->d_region.as<RegionModDev>(),
                      ctx->d_depth.as<DepthModDev>(), ctx->d_poses.as<float>());
   HIPCHK(hipGetLastError());
@@ -1081,6 +1097,7 @@ void m3t_hip_destroy(m3t_hip_context* ctx) {
     if (ctx->cam_stage[i]) (void)hipHostFree(ctx->cam_stage[i]);
     if (ctx->cam_stage_done[i]) (void)hipEventDestroy(ctx->cam_stage_done[i]);
   }
+  if (ctx->split_abort_host) (void)hipHostFree(ctx->split_abort_host);
   delete ctx;
 }
 
@@ -2267,7 +2284,9 @@ int m3t_hip_set_fused_step(m3t_hip_context* ctx, int mode) {
 
 int m3t_hip_set_object_split(m3t_hip_context* ctx, int enable) {
   CHECK_CTX();
+  REQUIRE(enable >= 0 && enable <= M3T_SPLIT_MAX_PARTS, M3T_ERR_INVALID_ARGUMENT, "0 (off), 1 (automatic) or the largest number of workgroups per object (2..16)");
   ctx->split_enabled = enable != 0;
+  ctx->split_parts_override = enable > 1 ? enable : 0;
   return M3T_OK;
 }
 
@@ -2360,6 +2379,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   int r = Prepare(ctx, true);
   if (r) return r;
   ctx->untracked_launches = untracked_before;  // a whole step is tracked by its step_done event below
+  if ((r = CheckSplitExchange(ctx))) return r;  // an earlier step that was abandoned on the device
   bool histogram_fused = false;
   if (ctx->fused_mode >= 1 && ctx->fused_possible) {
     int n = int(ctx->opt_table.size());
@@ -2377,46 +2397,74 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // would not fit twice, so large batches keep the separate region_histogram_kernel.
     histogram_fused = ctx->fuse_histogram_possible && threads == M3T_BLOCK_THREADS && !std::getenv("M3T_HIP_NO_FUSED_HISTOGRAM");
     const size_t lds = histogram_fused ? std::max(ctx->lds_track, ctx->lds_hist) : ctx->lds_track;
-    // Up to a quarter of the CUs busy: M3T_SPLIT_PARTS workgroups per object, each on its own CU (all resident at
-    // once, which their in-kernel exchange needs).  Not in the reference-summation-order mode: the partial sums
-    // of the workgroups are added per workgroup first.
-    const bool split = ctx->split_possible && ctx->split_enabled && threads == M3T_BLOCK_THREADS && !ctx->sequential_sum &&
-                       n * M3T_SPLIT_PARTS <= ctx->prop.multiProcessorCount &&
-                       ctx->n_corr_iterations * ctx->n_update_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT");
+    // Batches that leave CUs idle: several workgroups per object, each on its own CU (all resident at once, which
+    // their in-kernel exchange needs; a wait that runs out abandons the object's step, see CheckSplitExchange).
+    // parts x padded elements per part = 256 (the collecting threads of split_exchange_state).
+    int parts = 0;
+    if (ctx->split_possible && ctx->split_enabled && threads % M3T_SPLIT_LANES == 0 &&
+        ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT")) {
+      int limit = ctx->split_parts_override > 1 ? ctx->split_parts_override : 8;
+      if (const char* e = std::getenv("M3T_HIP_SPLIT_PARTS")) limit = std::atoi(e);  // developer override
+      const int elements = std::max(ctx->layout.nl, ctx->depth_mods.empty() ? 1 : ctx->np_max);
+      for (int p = M3T_SPLIT_MAX_PARTS; p >= 2; p >>= 1) {
+        if (p > limit || n * p > ctx->prop.multiProcessorCount) continue;
+        if ((elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;  // a part's elements fit its share of the lanes
+        parts = p;
+        break;
+      }
+    }
+    const bool split = parts >= 2;
     if (split) {
-      const size_t granules = size_t(2) * M3T_SPLIT_PARTS * 32;
+      const size_t per_object = size_t(2) * M3T_SPLIT_LANES * 32;  // granules
+      if (!ctx->split_abort_host) {
+        void* host = nullptr;
+        HIPCHK(hipHostMalloc(&host, 64, hipHostMallocMapped));
+        std::memset(host, 0, 64);
+        void* dev = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dev, host, 0));
+        ctx->split_abort_host = static_cast<unsigned*>(host);
+        ctx->split_abort_dev = static_cast<unsigned*>(dev);
+      }
       if (ctx->split_objects < size_t(n) || ctx->split_seq >= (1u << 26) - 1) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (ctx->split_objects < size_t(n)) {
-          HIPCHK(ctx->d_split.alloc((size_t(n) * granules + 1) * sizeof(unsigned long long)));
+          HIPCHK(ctx->d_split.alloc(size_t(n) * per_object * sizeof(unsigned long long) + size_t(n) * sizeof(unsigned)));
           ctx->split_objects = size_t(n);
         }
-        HIPCHK(hipMemset(ctx->d_split.p, 0, (ctx->split_objects * granules + 1) * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(ctx->d_split.p, 0, ctx->d_split.bytes));
         ctx->split_seq = 0;
       }
       ++ctx->split_seq;
-      unsigned long long* g = ctx->d_split.as<unsigned long long>();
-      // (each workgroup counts a quarter of the histogram bins: a quarter of the count table)
+      SplitParams sp{};
+      sp.granules = ctx->d_split.as<unsigned long long>();
+      sp.object_abort = reinterpret_cast<unsigned*>(sp.granules + ctx->split_objects * per_object);
+      sp.host_abort = ctx->split_abort_dev;
+      sp.seq = ctx->split_seq;
+      sp.n_parts = parts;
+      sp.lshift = 0;
+      while ((parts << sp.lshift) < M3T_SPLIT_LANES) ++sp.lshift;
+      sp.per_part_lines = (ctx->layout.nl + parts - 1) / parts;
+      sp.per_part_points = (ctx->np_max + parts - 1) / parts;
+      // (each workgroup counts its share of the histogram bins: that share of the count table; the pair table is
+      // read from L2, never staged)
+      const size_t lds_tracking = size_t(ctx->layout.off_hist >= 0 ? ctx->layout.off_hist : ctx->layout.total_floats) * 4;
       const size_t lds_split = histogram_fused
-          ? std::max(ctx->lds_track, M3T_MISC_FLOATS * 4 + (ctx->lds_hist - M3T_MISC_FLOATS * 4) / M3T_SPLIT_PARTS)
-          : ctx->lds_track;
-      hipLaunchKernelGGL(tracking_step_split_kernel, dim3(n * M3T_SPLIT_PARTS), dim3(threads), lds_split, ctx->stream,
+          ? std::max(lds_tracking, M3T_MISC_FLOATS * 4 + (ctx->lds_hist - M3T_MISC_FLOATS * 4) / parts)
+          : lds_tracking;
+      hipLaunchKernelGGL(tracking_step_split_kernel, dim3(n * parts), dim3(threads), lds_split, ctx->stream,
                          ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                          ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                          ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
-                         ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, g,
-                         reinterpret_cast<unsigned*>(g + ctx->split_objects * granules), ctx->split_seq);
-      ctx->split_check_pending = true;
+                         ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, sp);
     } else
     hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), lds, ctx->stream,
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                        ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                        ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
-                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, ctx->sequential_sum,
-                       histogram_fused ? 1 : 0);
+                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0);
     HIPCHK(hipGetLastError());
     ctx->last_step_shape[0] = n;
-    ctx->last_step_shape[1] = split ? M3T_SPLIT_PARTS : 1;
+    ctx->last_step_shape[1] = split ? parts : 1;
     ctx->last_step_shape[2] = threads;
     ctx->last_step_shape[3] = histogram_fused ? 1 : 0;
     ctx->state_valid = ctx->fused_mode == 2;
@@ -2466,7 +2514,8 @@ int m3t_hip_execute_tracking_cycle(m3t_hip_context* ctx, int iteration) {
 }
 int m3t_hip_set_summation_mode(m3t_hip_context* ctx, int mode) {
   CHECK_CTX();
-  REQUIRE(mode == 0 || mode == 1, M3T_ERR_INVALID_ARGUMENT, "mode must be 0 (tree) or 1 (reference order)");
+  // kept for callers of the first release: both modes now add the terms in the reference's order
+  REQUIRE(mode == 0 || mode == 1, M3T_ERR_INVALID_ARGUMENT, "mode must be 0 or 1");
   ctx->sequential_sum = mode;
   return M3T_OK;
 }

@@ -231,13 +231,23 @@ __device__ int closest_view(G<v4f> orientations4, int n_views, const Affine& b2c
   int* imisc = reinterpret_cast<int*>(misc);
   if (lane == 0) { misc[wave] = wbest; imisc[32 + wave] = wbi; }
   __syncthreads();
-  best = misc[0];
-  bi = imisc[32];
-  for (int w = 1; w < n_waves; ++w) {
-    float ob = misc[w];
-    int oi = imisc[32 + w];
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  // (largest value, lowest index) over the <= 16 waves: one LDS read per lane and a 16-lane DPP row tree instead of a
+  // serial walk over the per-wave results
+  const int w = lane & 15;
+  best = w < n_waves ? misc[w] : -2.0f;
+  bi = w < n_waves ? imisc[32 + w] : INT_MAX;
+#define M3T_ROW_ARGMAX_STEP(CTRL)                                             \
+  {                                                                           \
+    float ob = dpp_self<CTRL, 0xf>(best);                                     \
+    int oi = dpp_self_i<CTRL, 0xf>(bi);                                       \
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }         \
   }
+  M3T_ROW_ARGMAX_STEP(0x111)
+  M3T_ROW_ARGMAX_STEP(0x112)
+  M3T_ROW_ARGMAX_STEP(0x114)
+  M3T_ROW_ARGMAX_STEP(0x118)
+#undef M3T_ROW_ARGMAX_STEP
+  bi = __builtin_amdgcn_readlane(bi, 15);
   __syncthreads();
   return bi == INT_MAX ? 0 : bi;
 }
@@ -886,34 +896,18 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   }
   __syncthreads();
   PHASE_MARK(3);
-  // ---- phase C2: normalisation + moments, one thread per line ----
-  for (int line = line_lo + tid; line < nl_b; line += nt) {
+  // ---- phase C2: normalisation, one thread per line (the moments follow in region_moments) ----
+  // (the final flag is set for the lines of all parts: it follows from phase A, which every workgroup ran in full)
+  for (int line = tid; line < nl; line += nt) {
     int flags = f2i_bits(s.state[LS_VALID * nl + line]);
     bool valid = (flags & valid_mask) != 0;
-    if (valid) {
+    if (valid && line >= line_lo && line < nl_b) {
       const float* r = raw + line * s.ns;
       float area = 0.0f;
       for (int d = 0; d < dl; ++d) area += r[d];
-      float mean_from_begin = 0.0f;
-      float dist[M3T_MAX_DISTRIBUTION_LENGTH];
 #pragma unroll
-      for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d) {
-        if (d < dl) {
-          dist[d] = r[d] / area;
-          mean_from_begin += (float)d * dist[d];
-        }
-      }
-      float var = 0.0f;
-#pragma unroll
-      for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d) {
-        if (d < dl) {
-          float dd = (float)d - mean_from_begin;
-          var += (dd * dd) * dist[d];
-          s.state[(LS_DIST0 + d) * nl + line] = dist[d];
-        }
-      }
-      s.state[LS_MEAN * nl + line] = mean_from_begin - m.distribution_length_minus_1_half;
-      s.state[LS_VAR * nl + line] = fmaxf(var, m.min_expected_variance);
+      for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d)
+        if (d < dl) s.state[(LS_DIST0 + d) * nl + line] = r[d] / area;
     }
     // final flag: bit0 = line is in data_lines_
     s.state[LS_VALID * nl + line] = i2f_bits((flags & ~1) | (valid ? 1 : 0));
@@ -922,262 +916,301 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   PHASE_MARK(4);
 }
 
-// ---------------------------------------------------------------------------
-// Block reduction of N per-thread partial sums: wave shuffle tree, then the
-// per-wave partials are added in wave order.  out[] valid for threads < N.
-// scratch: n_waves * N floats.  Two __syncthreads().
-// ---------------------------------------------------------------------------
-template <int N>
-__device__ void block_reduce(float (&v)[N], int n_active_waves, float* scratch, float* out /*LDS, N floats*/) {
-  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
-  if (wave < n_active_waves) {
-    // level by level over all N values: N independent DPP adds per level fill the DPP wait states
+// CalculateDistributionMoments :1639-1658 for every line of the object, from the normalised distributions in LDS
+// (its own part's, and -- tracking_step_split_kernel -- the ones received from the other workgroups).  Ends with a barrier.
+__device__ void region_moments(CRegion& m, const Lds& s) {
+  const int nl = s.nl, dl = m.distribution_length;
+  for (int line = threadIdx.x; line < nl; line += blockDim.x) {
+    if (!(f2i_bits(s.state[LS_VALID * nl + line]) & 1)) continue;
+    float mean_from_begin = 0.0f;
+    float dist[M3T_MAX_DISTRIBUTION_LENGTH];
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x111, 0xf>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x112, 0xf>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x114, 0xf>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x118, 0xf>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x142, 0xa>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_zero<0x143, 0xc>(v[i]);
-    if (lane == kWave - 1) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) scratch[wave * N + i] = v[i];
+    for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d) {
+      if (d < dl) {
+        dist[d] = s.state[(LS_DIST0 + d) * nl + line];
+        mean_from_begin += (float)d * dist[d];
+      }
     }
-  }
-  __syncthreads();
-  if (threadIdx.x < N) {
-    float x = 0.0f;
-    for (int w = 0; w < n_active_waves; ++w) x += scratch[w * N + threadIdx.x];
-    out[threadIdx.x] = x;
+    float var = 0.0f;
+#pragma unroll
+    for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d) {
+      if (d < dl) {
+        float dd = (float)d - mean_from_begin;
+        var += (dd * dd) * dist[d];
+      }
+    }
+    s.state[LS_MEAN * nl + line] = mean_from_begin - m.distribution_length_minus_1_half;
+    s.state[LS_VAR * nl + line] = fmaxf(var, m.min_expected_variance);
   }
   __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
-// Sum of the 27 partial g/H sums of the workgroups that share one object (tracking_step_split_kernel).
-// Each workgroup publishes its sums as 8-byte {tag, value} granules with one write-through store each and
-// re-reads the others' granules until every tag matches: the data is the flag, no fence (the hand-off form of
-// cdna_hip_programming.md, guideline 16, R2).  Slots alternate with the round: a workgroup can only be one
-// round ahead of another, because it cannot leave a round before it has read everybody's granules of it.
-// Every workgroup adds the parts in the same order and so continues with bit-identical sums.
+// Gradient / Hessian sums in the reference's order.
+// The reference adds the terms of one data line (or data point) after the other into gradient_ / hessian_
+// (region_modality.cpp:550-554, depth_modality.cpp:361-377): 27 independent f32 chains (6 gradient entries,
+// 21 entries of a Hessian triangle).  The products of every line are formed in parallel, one thread per line,
+// and written as 27 rows P[row][line] to LDS; then the first 42 lanes of one wave (the layout of
+// Modality::gradient() / hessian(): 6 + 36, mirrored entries read the same row) run down their rows with one
+// dependent subtraction per line.  A line that does not contribute stores zeros (x -/+ 0 = x; a chain that
+// started at +0 never holds -0).  Rows: r < 6: the gradient entry r; 6 + c*6 - c*(c-1)/2 + (r - c): H(r, c), r >= c.
+// Every row stores what is to be SUBTRACTED from the running sum (the region gradient is negated: a - (-b) = a + b).
 // ---------------------------------------------------------------------------
-struct SplitExchange {
-  __attribute__((address_space(1))) unsigned long long* granules;  // [2 rounds][M3T_SPLIT_PARTS][32]
-  __attribute__((address_space(1))) unsigned* timeout;             // set when a wait gave up
-  uint32_t tag;   // > 0, unique per (launch, round)
-  int part, round;
-};
-__device__ void split_exchange_sums(float* red /*LDS, 27 in / out*/, float* scratch /*LDS, 4 * 32*/,
-                                    const SplitExchange& x) {
-  const int tid = threadIdx.x;
-  if (tid < 27) {
-    unsigned long long g = (static_cast<unsigned long long>(x.tag) << 32) | (unsigned)__float_as_int(red[tid]);
-    __hip_atomic_store(x.granules + ((x.round & 1) * M3T_SPLIT_PARTS + x.part) * 32 + tid, g, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (tid < M3T_SPLIT_PARTS * 32) {
-    const int p = tid >> 5, e = tid & 31;
-    bool done = e >= 27;
-    unsigned long long g = 0;
-    for (unsigned spins = 0; !__all(done); ++spins) {  // wave-uniform loop; bounded: never hangs the device
-      if (!done) {
-        g = __hip_atomic_load(x.granules + ((x.round & 1) * M3T_SPLIT_PARTS + p) * 32 + e, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_AGENT);
-        done = static_cast<uint32_t>(g >> 32) == x.tag;
-      }
-      if (spins > (1u << 18)) {  // ~0.3 s
-        if (!done) __hip_atomic_store(x.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (e < 27) scratch[p * 32 + e] = __int_as_float(static_cast<int>(static_cast<uint32_t>(g)));
-  }
-  __syncthreads();
-  if (tid < 27) {
-    float sum = scratch[tid];
-#pragma unroll
-    for (int p = 1; p < M3T_SPLIT_PARTS; ++p) sum += scratch[p * 32 + tid];
-    red[tid] = sum;
-  }
-  __syncthreads();
+constexpr int kChainBlock = 12;  // lines per pipeline step of the chain (3 x ds_read_b128)
+
+__host__ __device__ inline int chain_slots(int n) { return (n + kChainBlock - 1) / kChainBlock * kChainBlock; }
+// row pitch in floats: a multiple of 4 with an odd quarter, so that 16 lanes reading 16 bytes of 16 rows hit 64 banks
+__host__ __device__ inline int chain_pitch(int n) {
+  const int slots = chain_slots(n);
+  return ((slots / 4) & 1) ? slots : slots + 4;
 }
 
+__device__ __forceinline__ int gh_lane_row(int lane) {  // lane < 42 of the gradient()/hessian() layout -> product row
+  if (lane < 6) return lane;
+  const int idx = lane - 6, c = idx / 6, r = idx - c * 6;
+  const int lo = r >= c ? r : c, hi = r >= c ? c : r;
+  return 6 + hi * 6 - hi * (hi - 1) / 2 + (lo - hi);
+}
+
+typedef const __attribute__((address_space(3))) v4f* LdsV4;
+#define M3T_CHAIN_STEP(S, A0, A1, A2)                                             \
+  S -= A0.x; S -= A0.y; S -= A0.z; S -= A0.w; S -= A1.x; S -= A1.y; S -= A1.z;    \
+  S -= A1.w; S -= A2.x; S -= A2.y; S -= A2.z; S -= A2.w;
+
+// lanes < 42 of the calling wave; rows_a / rows_b: product tables of up to two modalities (either may be null),
+// walked together: two independent dependent chains interleave for free
+__device__ __forceinline__ void chain_sums(const float* rows_a, int pitch_a, int slots_a, const float* rows_b,
+                                           int pitch_b, int slots_b, int row, float& sum_a, float& sum_b) {
+  float sa = 0.0f, sb = 0.0f;
+  const int na = rows_a ? slots_a / kChainBlock : 0, nb = rows_b ? slots_b / kChainBlock : 0;
+  const int common = na < nb ? na : nb;
+  LdsV4 pa = (LdsV4)(rows_a ? rows_a + row * pitch_a : nullptr);
+  LdsV4 pb = (LdsV4)(rows_b ? rows_b + row * pitch_b : nullptr);
+  int blk = 0;
+  if (common > 0) {
+    v4f a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+    for (; blk < common; ++blk) {
+      const int nx = blk + 1 < common ? blk + 1 : blk;
+      const v4f n0 = pa[3 * nx], n1 = pa[3 * nx + 1], n2 = pa[3 * nx + 2];
+      const v4f m0 = pb[3 * nx], m1 = pb[3 * nx + 1], m2 = pb[3 * nx + 2];
+      M3T_CHAIN_STEP(sa, a0, a1, a2)
+      M3T_CHAIN_STEP(sb, b0, b1, b2)
+      a0 = n0; a1 = n1; a2 = n2; b0 = m0; b1 = m1; b2 = m2;
+    }
+  }
+  if (blk < na) {
+    v4f a0 = pa[3 * blk], a1 = pa[3 * blk + 1], a2 = pa[3 * blk + 2];
+    for (; blk < na; ++blk) {
+      const int nx = blk + 1 < na ? blk + 1 : blk;
+      const v4f n0 = pa[3 * nx], n1 = pa[3 * nx + 1], n2 = pa[3 * nx + 2];
+      M3T_CHAIN_STEP(sa, a0, a1, a2)
+      a0 = n0; a1 = n1; a2 = n2;
+    }
+  }
+  blk = common;
+  if (blk < nb) {
+    v4f b0 = pb[3 * blk], b1 = pb[3 * blk + 1], b2 = pb[3 * blk + 2];
+    for (; blk < nb; ++blk) {
+      const int nx = blk + 1 < nb ? blk + 1 : blk;
+      const v4f m0 = pb[3 * nx], m1 = pb[3 * nx + 1], m2 = pb[3 * nx + 2];
+      M3T_CHAIN_STEP(sb, b0, b1, b2)
+      b0 = m0; b1 = m1; b2 = m2;
+    }
+  }
+  sum_a = sa;
+  sum_b = sb;
+}
+#undef M3T_CHAIN_STEP
+
 // ---------------------------------------------------------------------------
-// RegionModality::CalculateGradientAndHessian (:485-558), whole block.
-// Result: gh[0..5] gradient, gh[6..41] column-major symmetric hessian (LDS or global).
+// RegionModality::CalculateGradientAndHessian (:485-558), the per-line part: one thread per line slot
+// writes the line's 27 products to rows[row * pitch + line] (zeros for slots that do not contribute).
 // ---------------------------------------------------------------------------
-__device__ void region_gradient_hessian(CRegion& m, CCam& cam, const Affine& b2c,
-                                        int corr_iteration, int opt_iteration, const Lds& s, float* gh_out,
-                                        bool sequential_sum, int split_part = -1,
-                                        const SplitExchange* exchange = nullptr) {
+__device__ void region_products(CRegion& m, CCam& cam, const Affine& b2c, int corr_iteration, int opt_iteration,
+                                const Lds& s, float* rows, int pitch) {
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
   const RegionIter it = region_iter(m, corr_iteration);
-  // One line's terms: false when the line does not contribute (:497-513)
-  auto line_terms = [&](int line, float (&J)[6], float& wg, float& wh) -> bool {
-    int flags = f2i_bits(s.state[LS_VALID * nl + line]);
-    if (!(flags & 1)) return false;
-    float cx = s.state[LS_CX * nl + line], cy = s.state[LS_CY * nl + line], cz = s.state[LS_CZ * nl + line];
-    float x, y, z;
-    apply_pose(b2c, cx, cy, cz, x, y, z);
-    float normal_u = s.state[LS_NORMAL_U * nl + line], normal_v = s.state[LS_NORMAL_V * nl + line];
-    float center_u = s.state[LS_CENTER_U * nl + line], center_v = s.state[LS_CENTER_V * nl + line];
-    float ncts = s.state[LS_NCTS * nl + line];
-    float measured_variance = s.state[LS_VAR * nl + line];
-    float fu_z = cam.fu / z;
-    float fv_z = cam.fv / z;
-    float xfu_z = x * fu_z;
-    float yfv_z = y * fv_z;
-    float delta_cs = (normal_u * (xfu_z + cam.ppu - center_u) + normal_v * (yfv_z + cam.ppv - center_v) -
-                      s.state[LS_DELTA_R * nl + line]) *
-                     ncts;
-    float dll;
-    if (opt_iteration < m.n_global_iterations) {
-      dll = (s.state[LS_MEAN * nl + line] - delta_cs) / measured_variance;
+  const int slots = chain_slots(nl);
+  for (int line = tid; line < slots; line += nt) {
+    float J[6], wg = 0.0f, wh = 0.0f;
+    bool ok = false;
+    if (line < nl && (f2i_bits(s.state[LS_VALID * nl + line]) & 1)) {  // :497-513
+      ok = true;
+      float cx = s.state[LS_CX * nl + line], cy = s.state[LS_CY * nl + line], cz = s.state[LS_CZ * nl + line];
+      float x, y, z;
+      apply_pose(b2c, cx, cy, cz, x, y, z);
+      float normal_u = s.state[LS_NORMAL_U * nl + line], normal_v = s.state[LS_NORMAL_V * nl + line];
+      float center_u = s.state[LS_CENTER_U * nl + line], center_v = s.state[LS_CENTER_V * nl + line];
+      float ncts = s.state[LS_NCTS * nl + line];
+      float measured_variance = s.state[LS_VAR * nl + line];
+      float fu_z = cam.fu / z;
+      float fv_z = cam.fv / z;
+      float xfu_z = x * fu_z;
+      float yfv_z = y * fv_z;
+      float delta_cs = (normal_u * (xfu_z + cam.ppu - center_u) + normal_v * (yfv_z + cam.ppv - center_v) -
+                        s.state[LS_DELTA_R * nl + line]) *
+                       ncts;
+      float dll = 0.0f;
+      if (opt_iteration < m.n_global_iterations) {
+        dll = (s.state[LS_MEAN * nl + line] - delta_cs) / measured_variance;
+      } else {
+        int upper = f2i(delta_cs + m.distribution_length_plus_1_half);
+        int lower = upper - 1;
+        if (upper <= 0 || upper >= m.distribution_length) {
+          ok = false;
+        } else {
+          // std::log(float): correctly rounded through f64 on both sides of the parity check
+          dll = ((float)log((double)s.state[(LS_DIST0 + upper) * nl + line]) -
+                 (float)log((double)s.state[(LS_DIST0 + lower) * nl + line])) *
+                m.learning_rate / measured_variance;
+        }
+      }
+      float dc0 = ncts * normal_u * fu_z;
+      float dc1 = ncts * normal_v * fv_z;
+      float dc2 = ncts * (-normal_u * xfu_z - normal_v * yfv_z) / z;
+      // RowVector3f * Matrix3f (body2camera_rotation_)
+      float t0 = (dc0 * b2c.l[0] + dc1 * b2c.l[1]) + dc2 * b2c.l[2];
+      float t1 = (dc0 * b2c.l[3] + dc1 * b2c.l[4]) + dc2 * b2c.l[5];
+      float t2 = (dc0 * b2c.l[6] + dc1 * b2c.l[7]) + dc2 * b2c.l[8];
+      J[0] = cy * t2 - cz * t1;
+      J[1] = cz * t0 - cx * t2;
+      J[2] = cx * t1 - cy * t0;
+      J[3] = t0;
+      J[4] = t1;
+      J[5] = t2;
+      float weight = m.min_expected_variance / (ncts * ncts * it.variance);
+      wg = weight * dll;
+      wh = weight / measured_variance;
+    }
+    float* out = rows + line;
+    if (ok) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) out[r * pitch] = -(wg * J[r]);  // gradient_ += (weight * dll) * J^T
+      int k = 6;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int r = c; r < 6; ++r) out[(k++) * pitch] = (wh * J[r]) * J[c];  // hessian_ (lower) -= ((w / var) J^T) J
     } else {
-      int upper = f2i(delta_cs + m.distribution_length_plus_1_half);
-      int lower = upper - 1;
-      if (upper <= 0 || upper >= m.distribution_length) return false;
-      // std::log(float): correctly rounded through f64 on both sides of the parity check
-      dll = ((float)log((double)s.state[(LS_DIST0 + upper) * nl + line]) -
-             (float)log((double)s.state[(LS_DIST0 + lower) * nl + line])) *
-            m.learning_rate / measured_variance;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) out[k * pitch] = 0.0f;
     }
-    float dc0 = ncts * normal_u * fu_z;
-    float dc1 = ncts * normal_v * fv_z;
-    float dc2 = ncts * (-normal_u * xfu_z - normal_v * yfv_z) / z;
-    // RowVector3f * Matrix3f (body2camera_rotation_)
-    float t0 = (dc0 * b2c.l[0] + dc1 * b2c.l[1]) + dc2 * b2c.l[2];
-    float t1 = (dc0 * b2c.l[3] + dc1 * b2c.l[4]) + dc2 * b2c.l[5];
-    float t2 = (dc0 * b2c.l[6] + dc1 * b2c.l[7]) + dc2 * b2c.l[8];
-    J[0] = cy * t2 - cz * t1;
-    J[1] = cz * t0 - cx * t2;
-    J[2] = cx * t1 - cy * t0;
-    J[3] = t0;
-    J[4] = t1;
-    J[5] = t2;
-    float weight = m.min_expected_variance / (ncts * ncts * it.variance);
-    wg = weight * dll;
-    wh = weight / measured_variance;
-    return true;
-  };
-  float* red = s.misc + kMiscRed;
-  if (sequential_sum) {
-    // parity mode: the reference's summation order (line by line, f32), 27 lanes in one wave.
-    // s.chain must hold 9 * nl floats (nl * ns >= 9 * nl since ns >= 9 is enforced on the host).
-    for (int line = tid; line < nl; line += nt) {
-      float J[6], wg, wh;
-      float* st = s.chain + line * 9;
-      st[8] = 0.0f;
-      if (!line_terms(line, J, wg, wh)) continue;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) st[r] = J[r];
-      st[6] = wg;
-      st[7] = wh;
-      st[8] = 1.0f;
-    }
-    __syncthreads();
-    if (tid < 27) {
-      int r, c;
-      if (tid < 6) { r = tid; c = 0; }
-      else {
-        int k = tid - 6;
-        c = 0;
-        while (k >= 6 - c) { k -= 6 - c; ++c; }
-        r = c + k;
-      }
-      float sum = 0.0f;
-      for (int line = 0; line < nl; ++line) {
-        const float* st = s.chain + line * 9;
-        if (st[8] == 0.0f) continue;
-        if (tid < 6) sum += st[6] * st[r];
-        else sum -= (st[7] * st[r]) * st[c];
-      }
-      red[tid] = sum;
-    }
-    __syncthreads();
-  } else {
-    // Default order, the same for every launch shape: the lines form M3T_SPLIT_PARTS contiguous parts of
-    // ceil(nl / parts) lines; a part is cut into runs of 64 lines, each summed by one wave with the DPP tree;
-    // the runs of a part are added in order, then the parts in order.  A workgroup that shares its object with
-    // others (split_part >= 0) sums its own part, split_exchange_sums() adds the parts: bit-identical.
-    const int lane = tid % kWave, wave = tid / kWave, n_waves = nt / kWave;
-    const int per_part = (nl + M3T_SPLIT_PARTS - 1) / M3T_SPLIT_PARTS;
-    const int runs_per_part = (per_part + kWave - 1) / kWave;
-    const int part_begin = split_part >= 0 ? split_part : 0;
-    const int part_end = split_part >= 0 ? split_part + 1 : M3T_SPLIT_PARTS;
-    float* partials = s.misc + kMiscPartials;  // [run][27]; the host keeps parts * runs_per_part * 27 within it
-    // run r (counted from this workgroup's first) belongs to wave r mod n_waves (a power of two)
-    const int n_runs = (part_end - part_begin) * runs_per_part;
-    int part = part_begin, k = 0;  // (part, k) of run r, advanced without divisions
-    for (int r = 0; r < n_runs; ++r) {
-      const int run = part * runs_per_part + k;
-      const int index = k * kWave + lane;
-      const int line = part * per_part + index;
-      const bool mine = (r & (n_waves - 1)) == wave;
-      if (++k == runs_per_part) { k = 0; ++part; }
-      if (!mine) continue;
-      float acc[27];
-#pragma unroll
-      for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
-      float J[6], wg, wh;
-      if (index < per_part && line < nl && line_terms(line, J, wg, wh)) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) acc[r] += wg * J[r];
-        int k = 6;
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-#pragma unroll
-          for (int r = c; r < 6; ++r) acc[k++] -= (wh * J[r]) * J[c];
-      }
-      // level by level over all 27 values: independent DPP adds per level fill the DPP wait states
-#pragma unroll
-      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x111, 0xf>(acc[i]);
-#pragma unroll
-      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x112, 0xf>(acc[i]);
-#pragma unroll
-      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x114, 0xf>(acc[i]);
-#pragma unroll
-      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x118, 0xf>(acc[i]);
-#pragma unroll
-      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x142, 0xa>(acc[i]);
-#pragma unroll
-      for (int i = 0; i < 27; ++i) acc[i] += dpp_zero<0x143, 0xc>(acc[i]);
-      if (lane == kWave - 1) {
-#pragma unroll
-        for (int i = 0; i < 27; ++i) partials[run * 27 + i] = acc[i];
-      }
-    }
-    __syncthreads();
-    if (tid < 27) {
-      float total = 0.0f;
-      const float* run_sums = partials + part_begin * runs_per_part * 27 + tid;
-      for (int part = part_begin; part < part_end; ++part) {
-        float x = 0.0f;
-        for (int k = 0; k < runs_per_part; ++k, run_sums += 27) x += *run_sums;
-        total = part == part_begin ? x : total + x;
-      }
-      red[tid] = total;
-    }
-    __syncthreads();
-  }
-  if (exchange) split_exchange_sums(red, s.misc + kMiscPartials, *exchange);
-  if (tid < 6) gh_out[tid] = red[tid];
-  if (tid < 36) {
-    int c = tid / 6, r = tid % 6;
-    int lo = r >= c ? r : c, hi = r >= c ? c : r;  // lower triangle (row lo, col hi)
-    int k = 6 + hi * 6 - hi * (hi - 1) / 2 + (lo - hi);
-    gh_out[6 + c * 6 + r] = red[k];
   }
 }
 
 // ---------------------------------------------------------------------------
-// 3x3 helpers for the pose update (column-major, Eigen coefficient order)
+// Line results of the workgroups that share one object (tracking_step_split_kernel).
+// Every workgroup walks the pixels of its own part of the lines (and scans the depth windows of its own part of
+// the points); what the Newton steps of ALL workgroups need from that -- mean, variance and distribution of a line,
+// correspondence and validity of a point -- crosses CUs once per correspondence iteration as 8-byte {tag, value}
+// granules: one write-through store each, re-read by the others until the tag matches.  The data is the flag, no
+// fence (cdna_hip_programming.md guideline 16, form R2).  Slots alternate with the round: a workgroup can only be
+// one round ahead of another, because it cannot leave a round before it has read everybody's granules of it.
+// From there on every workgroup holds the same line / point state, forms the same sums in the reference's order
+// and solves the same system: no exchange inside the Newton steps, bit-identical poses in every workgroup.
+// A wait that runs out (a partner that is not resident: another process on the GPU) ends the whole object's step
+// without writing anything and raises the context's abort flag, which the host reads at its next call.
+// ---------------------------------------------------------------------------
+struct SplitExchange {
+  __attribute__((address_space(1))) unsigned long long* granules;  // this object's [2 slots][parts][32 fields][1 << lshift]
+  __attribute__((address_space(1))) unsigned* object_abort;        // launch sequence number of an aborted step
+  unsigned* host_abort;                                            // mapped host word, set to the sequence number
+  uint32_t seq;    // launch sequence number (> 0)
+  int part, n_parts, lshift;
+  int per_part_lines, per_part_points;
+  int n_region_fields;                      // distribution_length: rows LS_DIST0 .. of the line state
+  int n_depth_fields, first_depth_row;      // rows first_depth_row .. PS_VALID of the point state
+};
+constexpr int kExchangeFieldBits = 5;
+
+// returns false when the exchange timed out (block-uniform)
+__device__ __forceinline__ bool split_exchange_state(const SplitExchange& x, int round, const Lds& s, bool with_region,
+                                                     float* ps, int np, bool with_depth) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t tag = x.seq * 64u + (uint32_t)round + 1u;
+  const int lmask = (1 << x.lshift) - 1;
+  const int nfr = with_region ? x.n_region_fields : 0, nfd = with_depth ? x.n_depth_fields : 0, nf = nfr + nfd;
+  auto* slot = x.granules + ((size_t)(round & 1) * x.n_parts << (kExchangeFieldBits + x.lshift));
+  float* const lds0 = s.misc;  // the lowest address of the workgroup's LDS carve-up
+  // field f -> element offset of its row from lds0, row length, elements per part
+  const int region_row0 = int(s.state - lds0) + LS_DIST0 * s.nl;
+  const int depth_row0 = int(ps - lds0) + x.first_depth_row * np;
+  // publish this part's elements
+  {
+    auto* mine = slot + ((size_t)x.part << (kExchangeFieldBits + x.lshift));
+    for (int idx = tid; idx < (nf << x.lshift); idx += nt) {
+      const int f = idx >> x.lshift, l = idx & lmask;
+      const bool region = f < nfr;
+      const int per_part = region ? x.per_part_lines : x.per_part_points, count = region ? s.nl : np;
+      const int e = x.part * per_part + l;
+      if (l < per_part && e < count) {
+        const float v = lds0[(region ? region_row0 + f * s.nl : depth_row0 + (f - nfr) * np) + e];
+        const unsigned long long g = (static_cast<unsigned long long>(tag) << 32) | (unsigned)__float_as_int(v);
+        __hip_atomic_store(mine + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  // collect the other parts': thread -> (part q, element l) fixed; its wave takes the fields group, group + n_groups, ...
+  // (the field index is wave-uniform: granule row and LDS row are scalar, per thread only one offset of each kind)
+  bool timed_out = false;
+  {
+    const int lanes = x.n_parts << x.lshift;  // M3T_SPLIT_LANES, a multiple of the wave size
+    const int ql = tid & (lanes - 1);
+    const int q = ql >> x.lshift, l = ql & lmask;
+    const int n_groups = nt / lanes, group = __builtin_amdgcn_readfirstlane(tid / lanes);
+    const int e_r = q * x.per_part_lines + l, e_d = q * x.per_part_points + l;
+    const bool ok_r = q != x.part && l < x.per_part_lines && e_r < s.nl;
+    const bool ok_d = q != x.part && l < x.per_part_points && e_d < np;
+    auto* theirs = slot + ((size_t)q << (kExchangeFieldBits + x.lshift)) + l;
+    // batches of 8 granules per thread: all loads of a batch are issued before the first tag is looked at
+    // (straight-line code on named registers: an indexed private array would live in scratch memory)
+    for (int f0 = group; f0 < nf; f0 += 8 * n_groups) {
+      unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0;
+#define M3T_EXCHANGE_LOAD(J, G)                                                                                      \
+      {                                                                                                              \
+        const int f = f0 + J * n_groups;                                                                             \
+        if (f < nf && (f < nfr ? ok_r : ok_d))                                                                       \
+          G = __hip_atomic_load(theirs + ((size_t)f << x.lshift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        \
+      }
+#define M3T_EXCHANGE_WAIT(J, G)                                                                                      \
+      {                                                                                                              \
+        const int f = f0 + J * n_groups;                                                                             \
+        if (f < nf && (f < nfr ? ok_r : ok_d)) {                                                                     \
+          unsigned spins = 0;                                                                                        \
+          while (static_cast<uint32_t>(G >> 32) != tag) {                                                            \
+            if (++spins > (1u << 18) || /* ~0.3 s */                                                                 \
+                ((spins & 255u) == 0 &&                                                                              \
+                 __hip_atomic_load(x.object_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == x.seq)) {          \
+              timed_out = true;                                                                                      \
+              break;                                                                                                 \
+            }                                                                                                        \
+            __builtin_amdgcn_s_sleep(1);                                                                             \
+            G = __hip_atomic_load(theirs + ((size_t)f << x.lshift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
+          }                                                                                                          \
+          lds0[f < nfr ? region_row0 + f * s.nl + e_r : depth_row0 + (f - nfr) * np + e_d] =                         \
+              __int_as_float(static_cast<int>(static_cast<uint32_t>(G)));                                            \
+        }                                                                                                            \
+      }
+      M3T_EXCHANGE_LOAD(0, g0) M3T_EXCHANGE_LOAD(1, g1) M3T_EXCHANGE_LOAD(2, g2) M3T_EXCHANGE_LOAD(3, g3)
+      M3T_EXCHANGE_LOAD(4, g4) M3T_EXCHANGE_LOAD(5, g5) M3T_EXCHANGE_LOAD(6, g6) M3T_EXCHANGE_LOAD(7, g7)
+      M3T_EXCHANGE_WAIT(0, g0) M3T_EXCHANGE_WAIT(1, g1) M3T_EXCHANGE_WAIT(2, g2) M3T_EXCHANGE_WAIT(3, g3)
+      M3T_EXCHANGE_WAIT(4, g4) M3T_EXCHANGE_WAIT(5, g5) M3T_EXCHANGE_WAIT(6, g6) M3T_EXCHANGE_WAIT(7, g7)
+#undef M3T_EXCHANGE_LOAD
+#undef M3T_EXCHANGE_WAIT
+    }
+  }
+  if (__syncthreads_or(timed_out ? 1 : 0)) {
+    if (tid == 0) {
+      __hip_atomic_store(x.object_abort, x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(x.host_abort, x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return false;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// serial 3x3 helpers (column-major, Eigen coefficient order): used by the kinematic-structure kernels (m3t_links.hip)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void mul3(const float* a, const float* b, float* r) {
 #pragma unroll
@@ -1291,140 +1324,366 @@ __device__ void expm3(const float* a_in, float* r) {
 
 // ---------------------------------------------------------------------------
 // Optimizer::CalculateOptimization (optimizer.cpp:144-167) for dof = 6, J = I, plus
-// Link::UpdatePoses (link.cpp:205-241) with body2joint = I: one thread.
-// A = -H + diag(lambda) (lower), Eigen-style LDLT with diagonal pivoting, NaN guard,
-// dT = [exp(skew(theta_r)) | theta_t], pose <- pose * dT.
+// Link::UpdatePoses (link.cpp:205-241) with body2joint = I, executed by ONE WAVE.
+//
+// Eigen's LDLT<Lower> (the oracle's LdltSolve) is the bordered, "lazy" variant: step k only writes
+// column k, the trailing matrix is never updated, so the diagonal pivoting looks at the ORIGINAL
+// diagonal entries and the whole transposition sequence is known before the factorisation starts.
+// With distinct, non-NaN |a_ii| the pivots are simply the diagonal in descending order: lane j finds
+// its rank with six compares, the permuted matrix P A P^T is gathered from LDS, and the factorisation
+// runs without pivoting on six lanes (lane i = row i): element for element the operations of the
+// pivoted in-place algorithm, only moved to where the swaps would have carried them.  Equal or NaN
+// diagonal entries (H = 0: no valid line) take the serial restatement below.  exp(skew) and the pose
+// product run column-per-lane.  Everything is IEEE f32, -ffp-contract=off: bit-identical to the oracle.
 // ---------------------------------------------------------------------------
-__device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-major 6x6*/, float lambda_rot,
-                                   float lambda_trans, float* pose /*16 col-major, in/out*/) {
-  // Every index below is a compile-time constant after unrolling, so a/x stay in VGPRs
-  // (a dynamically indexed local array would live in scratch memory: ~100x slower).
-  PHASE_T0();
-  float a[36], x[6];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) a[i] = 0.0f;
-#pragma unroll
-  for (int c = 0; c < 6; ++c)
-#pragma unroll
-    for (int r = c; r < 6; ++r) a[c * 6 + r] = 0.0f - h_sum[c * 6 + r];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    x[i] = 0.0f + g_sum[i];
-    a[i * 6 + i] += i < 3 ? lambda_rot : lambda_trans;
-  }
-  PHASE_MARK(12);  // build A, b
-  int trans[6] = {0, 1, 2, 3, 4, 5};
-  bool degenerate = false;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    if (!degenerate) {
-      int piv = k;
-      float best = fabsf(a[k * 6 + k]);
-#pragma unroll
-      for (int i = k + 1; i < 6; ++i) {
-        float v = fabsf(a[i * 6 + i]);
-        if (v > best) { best = v; piv = i; }
-      }
-      trans[k] = piv;
-#pragma unroll
-      for (int j = k + 1; j < 6; ++j) {
-        if (piv == j) {  // symmetric swap of k and j inside the lower triangle (Eigen ldlt_inplace)
-#pragma unroll
-          for (int c = 0; c < k; ++c) { float t = a[c * 6 + k]; a[c * 6 + k] = a[c * 6 + j]; a[c * 6 + j] = t; }
-#pragma unroll
-          for (int i = j + 1; i < 6; ++i) { float t = a[k * 6 + i]; a[k * 6 + i] = a[j * 6 + i]; a[j * 6 + i] = t; }
-          { float t = a[k * 6 + k]; a[k * 6 + k] = a[j * 6 + j]; a[j * 6 + j] = t; }
-#pragma unroll
-          for (int i = k + 1; i < j; ++i) { float t = a[k * 6 + i]; a[k * 6 + i] = a[i * 6 + j]; a[i * 6 + j] = t; }
-        }
-      }
-      if (k > 0) {
-        float temp[5];
-#pragma unroll
-        for (int c = 0; c < k; ++c) temp[c] = a[c * 6 + c] * a[c * 6 + k];
-        float acc = 0.0f;
-#pragma unroll
-        for (int c = 0; c < k; ++c) acc += a[c * 6 + k] * temp[c];
-        a[k * 6 + k] -= acc;
-#pragma unroll
-        for (int i = k + 1; i < 6; ++i) {
-          float sacc = 0.0f;
-#pragma unroll
-          for (int c = 0; c < k; ++c) sacc += a[c * 6 + i] * temp[c];
-          a[k * 6 + i] -= sacc;
-        }
-      }
-      float akk = a[k * 6 + k];
-      bool pivot_valid = fabsf(akk) > 0.0f;
-      if (k == 0 && !pivot_valid) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) trans[j] = j;
-        degenerate = true;
-      } else if (pivot_valid) {
-#pragma unroll
-        for (int i = k + 1; i < 6; ++i) a[k * 6 + i] /= akk;
+constexpr int kMiscSolve = 160;  // 128 floats of LDS scratch inside `misc`
+
+__device__ __forceinline__ float rlf(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Serial fallback (lane 0): the oracle's LdltSolve for n = 6 on LDS arrays.  a: column-major, lower.
+__device__ void ldlt6_fallback(float* a, float* x, int* trans, float* temp) {
+  constexpr int n = 6;
+#pragma nounroll
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    float best = fabsf(a[k * n + k]);
+#pragma nounroll
+    for (int i = k + 1; i < n; ++i) {
+      float v = fabsf(a[i * n + i]);
+      if (v > best) { best = v; piv = i; }
+    }
+    trans[k] = piv;
+    if (piv != k) {  // symmetric swap of k and piv inside the lower triangle (Eigen ldlt_inplace)
+#pragma nounroll
+      for (int c = 0; c < k; ++c) { float t = a[c * n + k]; a[c * n + k] = a[c * n + piv]; a[c * n + piv] = t; }
+#pragma nounroll
+      for (int i = piv + 1; i < n; ++i) { float t = a[k * n + i]; a[k * n + i] = a[piv * n + i]; a[piv * n + i] = t; }
+      { float t = a[k * n + k]; a[k * n + k] = a[piv * n + piv]; a[piv * n + piv] = t; }
+#pragma nounroll
+      for (int i = k + 1; i < piv; ++i) { float t = a[k * n + i]; a[k * n + i] = a[i * n + piv]; a[i * n + piv] = t; }
+    }
+    if (k > 0) {
+#pragma nounroll
+      for (int c = 0; c < k; ++c) temp[c] = a[c * n + c] * a[c * n + k];
+      float acc = 0.0f;
+#pragma nounroll
+      for (int c = 0; c < k; ++c) acc += a[c * n + k] * temp[c];
+      a[k * n + k] -= acc;
+#pragma nounroll
+      for (int i = k + 1; i < n; ++i) {
+        float sacc = 0.0f;
+#pragma nounroll
+        for (int c = 0; c < k; ++c) sacc += a[c * n + i] * temp[c];
+        a[k * n + i] -= sacc;
       }
     }
+    float akk = a[k * n + k];
+    bool pivot_valid = fabsf(akk) > 0.0f;
+    if (k == 0 && !pivot_valid) {
+#pragma nounroll
+      for (int j = 0; j < n; ++j) trans[j] = j;
+      break;
+    }
+    if (pivot_valid) {
+#pragma nounroll
+      for (int i = k + 1; i < n; ++i) a[k * n + i] /= akk;
+    }
   }
-  PHASE_MARK(13);  // LDLT factorisation
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-#pragma unroll
-    for (int j = k + 1; j < 6; ++j)
-      if (trans[k] == j) { float t = x[k]; x[k] = x[j]; x[j] = t; }
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
+#pragma nounroll
+  for (int k = 0; k < n; ++k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
+#pragma nounroll
+  for (int i = 0; i < n; ++i) {
     float sacc = x[i];
-#pragma unroll
-    for (int c = 0; c < i; ++c) sacc -= a[c * 6 + i] * x[c];
+#pragma nounroll
+    for (int c = 0; c < i; ++c) sacc -= a[c * n + i] * x[c];
     x[i] = sacc;
   }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    if (fabsf(a[i * 6 + i]) > 1.17549435e-38f) x[i] /= a[i * 6 + i];
+#pragma nounroll
+  for (int i = 0; i < n; ++i) {
+    if (fabsf(a[i * n + i]) > 1.17549435e-38f) x[i] /= a[i * n + i];
     else x[i] = 0.0f;
   }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {
+#pragma nounroll
+  for (int i = n - 1; i >= 0; --i) {
     float sacc = x[i];
-#pragma unroll
-    for (int r = i + 1; r < 6; ++r) sacc -= a[i * 6 + r] * x[r];
+#pragma nounroll
+    for (int r = i + 1; r < n; ++r) sacc -= a[i * n + r] * x[r];
     x[i] = sacc;
   }
+#pragma nounroll
+  for (int k = n - 1; k >= 0; --k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
+}
+
+// ---- column-per-lane 3x3 helpers (column c of a matrix lives in lane c; `u` = the same matrix in every lane,
+// column-major like Eigen).  The expression trees are those of the oracle's Mul3 / AddScaled / Solve3.
+__device__ __forceinline__ void colmul(const float (&u)[9], const float (&col)[3], float (&r)[3]) {
 #pragma unroll
-  for (int k = 5; k >= 0; --k) {
+  for (int k = 0; k < 3; ++k) r[k] = (u[k] * col[0] + u[3 + k] * col[1]) + u[6 + k] * col[2];
+}
+__device__ __forceinline__ void colgather(const float (&col)[3], float (&u)[9]) {
 #pragma unroll
-    for (int j = k + 1; j < 6; ++j)
-      if (trans[k] == j) { float t = x[k]; x[k] = x[j]; x[j] = t; }
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) u[c * 3 + r] = rlf(col[r], c);
+}
+__device__ __forceinline__ void coladd(const float (&a)[3], float sa, const float (&b)[3], float sb, float (&r)[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r[i] = sa * a[i] + sb * b[i];
+}
+// X = A^-1 B: Gaussian elimination with partial pivoting (first largest |a(i,k)| wins) on the uniform A,
+// every lane carries its own column of B through the same row operations
+__device__ __forceinline__ void colsolve3(float (&a)[9], float (&b)[3], float (&x)[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int p = k;
+    float best = fabsf(a[k * 3 + k]);
+#pragma unroll
+    for (int i = k + 1; i < 3; ++i) {
+      float v = fabsf(a[k * 3 + i]);
+      if (v > best) { best = v; p = i; }
+    }
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j) {
+      if (p == j) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { float t = a[c * 3 + k]; a[c * 3 + k] = a[c * 3 + j]; a[c * 3 + j] = t; }
+        float t = b[k]; b[k] = b[j]; b[j] = t;
+      }
+    }
+#pragma unroll
+    for (int i = k + 1; i < 3; ++i) {
+      float f = a[k * 3 + i] / a[k * 3 + k];
+      a[k * 3 + i] = f;
+#pragma unroll
+      for (int c = k + 1; c < 3; ++c) a[c * 3 + i] -= f * a[c * 3 + k];
+      b[i] -= f * b[k];
+    }
   }
+#pragma unroll
+  for (int i = 2; i >= 0; --i) {
+    float sacc = b[i];
+#pragma unroll
+    for (int j = i + 1; j < 3; ++j) sacc -= a[j * 3 + i] * x[j];
+    x[i] = sacc / a[i * 3 + i];
+  }
+}
+
+// exp(skew(theta_r)): Pade approximant with scaling and squaring like Eigen's MatrixFunctions (link.cpp:224),
+// operation for operation the oracle's Expm3; the result's column c is returned in lane c (c < 3).
+__device__ __forceinline__ void colexpm3(const float (&K)[9], int c, float (&R)[3]) {
+  float l1 = 0.0f;
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc) {
+    float sacc = 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) sacc += fabsf(K[cc * 3 + rr]);
+    l1 = fmaxf(l1, sacc);
+  }
+  const float Ic[3] = {c == 0 ? 1.0f : 0.0f, c == 1 ? 1.0f : 0.0f, c == 2 ? 1.0f : 0.0f};
+  float a[9], ac[3], U[3], V[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a[i] = K[i];
+  int squarings = 0;
+  if (l1 >= 1.880152677804762e+000f) {
+    int e;
+    (void)frexpf(l1 / 3.925724783138660f, &e);
+    squarings = e > 0 ? e : 0;
+    float sc = ldexpf(1.0f, -squarings);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] *= sc;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) ac[r] = c == 0 ? a[r] : (c == 1 ? a[3 + r] : a[6 + r]);
+  float a2c[3], tmp[3];
+  colmul(a, ac, a2c);  // a2 = a * a
+  if (l1 < 4.258730016922831e-001f) {
+    coladd(a2c, 1.0f, Ic, 60.0f, tmp);
+    colmul(a, tmp, U);
+    coladd(a2c, 12.0f, Ic, 120.0f, V);
+  } else {
+    float a2[9], a4c[3], t2[3];
+    colgather(a2c, a2);
+    colmul(a2, a2c, a4c);  // a4 = a2 * a2
+    if (l1 < 1.880152677804762e+000f) {
+      coladd(a4c, 1.0f, a2c, 420.0f, t2);
+      coladd(t2, 1.0f, Ic, 15120.0f, tmp);
+      colmul(a, tmp, U);
+      coladd(a4c, 30.0f, a2c, 3360.0f, t2);
+      coladd(t2, 1.0f, Ic, 30240.0f, V);
+    } else {
+      float a4[9], a6c[3], t3[3];
+      colgather(a4c, a4);
+      colmul(a4, a2c, a6c);  // a6 = a4 * a2
+      coladd(a6c, 1.0f, a4c, 1512.0f, t2);
+      coladd(t2, 1.0f, a2c, 277200.0f, t3);
+      coladd(t3, 1.0f, Ic, 8648640.0f, tmp);
+      colmul(a, tmp, U);
+      coladd(a6c, 56.0f, a4c, 25200.0f, t2);
+      coladd(t2, 1.0f, a2c, 1995840.0f, t3);
+      coladd(t3, 1.0f, Ic, 17297280.0f, V);
+    }
+  }
+  float num[3], denc[3], den[9];
+  coladd(U, 1.0f, V, 1.0f, num);
+  coladd(U, -1.0f, V, 1.0f, denc);
+  colgather(denc, den);
+  colsolve3(den, num, R);
+#pragma nounroll
+  for (int i = 0; i < squarings; ++i) {
+    float r9[9], t[3];
+    colgather(R, r9);
+    colmul(r9, R, t);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[j] = t[j];
+  }
+}
+
+// gh: lane l < 6 holds the link's gradient sum g[l], lane 6 + c * 6 + r the Hessian sum H(r, c) (full, symmetric:
+// the layout of Modality::gradient() / hessian()).  pose: 16 floats in LDS (column-major), updated in place.
+// scratch: 128 floats of LDS.  All 64 lanes of the wave must call this together.
+__device__ void rigid_solve_wave(float gh, float lambda_rot, float lambda_trans, float* pose, float* scratch) {
+  const int lane = threadIdx.x & (kWave - 1);
+  PHASE_T0();
+  if (lane < 42) scratch[lane] = gh;
+  __builtin_amdgcn_wave_barrier();
+  // A = -H + diag(lambda) (only the lower triangle is ever read), b = g
+  float v[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) v[j] = fabsf((0.0f - scratch[6 + j * 7]) + (j < 3 ? lambda_rot : lambda_trans));
+  const int lj = lane < 6 ? lane : 5;
+  const float my = fabsf((0.0f - scratch[6 + lj * 7]) + (lj < 3 ? lambda_rot : lambda_trans));
+  int rank = 0, equal = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    rank += v[j] > my ? 1 : 0;
+    equal += v[j] == my ? 1 : 0;
+  }
+  const bool slow = __builtin_amdgcn_ballot_w64(lane < 6 && equal != 1) != 0;  // ties or NaN on the diagonal
+  float th[6];  // theta, uniform
+  if (!slow) {
+    // position i of the pivoted order holds the original row pos[i]; lane i < 6 works on row i of P A P^T
+    // (lanes >= 6 push to themselves: the six ranks are a permutation of 0..5, nothing collides)
+    const int pi = __builtin_amdgcn_ds_permute((lane < 6 ? rank : lane) << 2, lane);
+    int pos[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pos[c] = __builtin_amdgcn_readlane(lane < 6 ? pi : 0, c);
+    float b[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      b[c] = 0.0f - scratch[6 + pos[c] * 6 + (lane < 6 ? pi : 0)];
+      const float lam = pos[c] < 3 ? lambda_rot : lambda_trans;
+      b[c] = c == lane ? b[c] + lam : b[c];
+    }
+    float x = 0.0f + scratch[lane < 6 ? pi : 0];
+    PHASE_MARK(12);  // build P A P^T, b
+    float D[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (k > 0) {
+        float T[5];
+#pragma unroll
+        for (int c = 0; c < k; ++c) T[c] = rlf(D[c] * b[c], k);  // temp = D * A10^T, from row k
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < k; ++c) acc += b[c] * T[c];
+        b[k] -= acc;  // row k: the pivot D_k; rows below: A21 -= A20 * temp
+      }
+      D[k] = rlf(b[k], k);
+      if (k < 5) {
+        const bool pivot_valid = fabsf(D[k]) > 0.0f;
+        const float q = b[k] / D[k];
+        b[k] = (pivot_valid && lane > k) ? q : b[k];
+      }
+    }
+    PHASE_MARK(13);  // LDLT factorisation
+    // L y = P b (row i: c ascending)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float xc = rlf(x, c);
+      x = lane > c ? x - b[c] * xc : x;
+    }
+    // D z = y with the pseudo-inverse of D
+    float dself = D[5];
+#pragma unroll
+    for (int k = 4; k >= 0; --k) dself = lane == k ? D[k] : dself;
+    x = fabsf(dself) > 1.17549435e-38f ? x / dself : 0.0f;
+    // L^T w = z: row i needs x[i+1] first, so this part is a chain; every lane runs it on broadcast values
+    float X[6], Lt[15];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) X[i] = rlf(x, i);
+    {
+      int n = 0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int r = i + 1; r < 6; ++r) Lt[n++] = rlf(b[i], r);  // L(r, i)
+    }
+    {
+      int base = 15;
+#pragma unroll
+      for (int i = 4; i >= 0; --i) {
+        base -= 5 - i;
+        float sacc = X[i];
+#pragma unroll
+        for (int r = i + 1; r < 6; ++r) sacc -= Lt[base + (r - i - 1)] * X[r];
+        X[i] = sacc;
+      }
+    }
+    // theta = P^T w: original row j sits at position rank[j]
+    float mine = X[5];
+#pragma unroll
+    for (int k = 4; k >= 0; --k) mine = rank == k ? X[k] : mine;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) th[j] = rlf(mine, j);
+  } else {
+    float* a = scratch + 48;
+    float* xs = scratch + 84;
+    int* trans = reinterpret_cast<int*>(scratch + 90);
+    float* temp = scratch + 96;
+    if (lane < 36) {
+      const int c = lane / 6, r = lane - c * 6;
+      float e = r >= c ? 0.0f - scratch[6 + lane] : 0.0f;
+      if (r == c) e += c < 3 ? lambda_rot : lambda_trans;
+      a[lane] = e;
+    }
+    if (lane < 6) xs[lane] = 0.0f + scratch[lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) ldlt6_fallback(a, xs, trans, temp);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 6; ++j) th[j] = xs[j];
+  }
+  PHASE_MARK(14);  // triangular solves
   // NaN guard (optimizer.cpp:165): skip the update, still success
   bool has_nan = false;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) has_nan |= (x[i] != x[i]);
+  for (int i = 0; i < 6; ++i) has_nan |= (th[i] != th[i]);
   if (has_nan) return;
-  PHASE_MARK(14);  // triangular solves
-  // exp(skew(theta_r)): Pade approximant with scaling and squaring like Eigen's
-  // MatrixFunctions (link.cpp:224), operation for operation the oracle's Expm3.
+  // dT = [exp(skew(theta_r)) | theta_t], pose <- pose * dT (link.cpp:218-232 with body2joint = I)
   float K[9];  // column-major skew(theta_r), common.h:62-68
-  K[0] = 0.0f;  K[3] = -x[2]; K[6] = x[1];
-  K[1] = x[2];  K[4] = 0.0f;  K[7] = -x[0];
-  K[2] = -x[1]; K[5] = x[0];  K[8] = 0.0f;
-  float R[9];
-  expm3(K, R);
+  K[0] = 0.0f;   K[3] = -th[2]; K[6] = th[1];
+  K[1] = th[2];  K[4] = 0.0f;   K[7] = -th[0];
+  K[2] = -th[1]; K[5] = th[0];  K[8] = 0.0f;
+  const int c = lane & 3;
+  float col[3];
+  colexpm3(K, c, col);
   PHASE_MARK(15);  // expm
-  Affine T = load_pose(pose), D;
+  if (c == 3) { col[0] = th[3]; col[1] = th[4]; col[2] = th[5]; }
+  const Affine T = load_pose(pose);
+  float N[3];
+  colmul(T.l, col, N);
+  if (c == 3) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) D.l[i] = R[i];
-  D.t[0] = x[3]; D.t[1] = x[4]; D.t[2] = x[5];
-  Affine N = mul_pose(T, D);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) pose[c * 4 + r] = N.l[c * 3 + r];
-    pose[c * 4 + 3] = 0.0f;
+    for (int k = 0; k < 3; ++k) N[k] = N[k] + T.t[k];
   }
-  pose[12] = N.t[0]; pose[13] = N.t[1]; pose[14] = N.t[2]; pose[15] = 1.0f;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 4) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pose[lane * 4 + k] = N[k];
+    pose[lane * 4 + 3] = lane == 3 ? 1.0f : 0.0f;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1434,8 +1693,13 @@ __device__ void rigid_solve_update(const float* g_sum, const float* h_sum /*col-
 // first strictly smaller distance wins in (v outer, u inner) order).
 // Point state lives in `ps` (LDS, [PS_FIELDS][np]).
 // ---------------------------------------------------------------------------
-__device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, int iteration,
-                                      int corr_iteration, float* ps, int np, float* misc) {
+// Part 1 (depth_correspondences_scan): everything up to the per-point flags {bit 0: unoccluded, bit 1: valid} for the
+// points [pt_lo, pt_hi); a workgroup that shares its object with others (tracking_step_split_kernel) also loads the
+// model data of the other parts' points, whose correspondences arrive through split_exchange_state().
+// Part 2 (depth_correspondences_vote): the two-pass fallback :282-313 over all points.
+__device__ void depth_correspondences_scan(CDepth& m, CCam& cam, const Affine& b2c, int iteration,
+                                           int corr_iteration, float* ps, int np, float* misc, int pt_lo = 0,
+                                           int pt_hi = 1 << 30) {
   // 16 lanes (one DPP row) per model point: the strided search window of FindCorrespondence
   // (<= 15x15 depth samples) and the occlusion window (<= 6x6) are scanned by the row in
   // parallel; the winner is the smallest distance, ties to the lowest scan index == the
@@ -1458,11 +1722,12 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
       m.use_silhouette_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
   const bool occlusion_pass = measured_pass || modeled_pass;
   G<uint8_t> image = as_global(cam.image);
-  int my_valid_occ = 0;
-  const int np_round = (np + nt / kGroup - 1) / (nt / kGroup) * (nt / kGroup);
-  for (int i = tid / kGroup; i < np_round; i += nt / kGroup) {
+  const int own_hi = pt_hi < np ? pt_hi : np;
+  const int own_count = own_hi > pt_lo ? own_hi - pt_lo : 0;
+  const int np_round = (own_count + nt / kGroup - 1) / (nt / kGroup) * (nt / kGroup);
+  for (int i = pt_lo + tid / kGroup; i < pt_lo + np_round; i += nt / kGroup) {
     int flags = 0;
-    const bool in_model = i < n_points;
+    const bool in_model = i < n_points && i < own_hi;
     const int ip = in_model ? i : 0;
     G<float> p = as_global(m.points) + ((size_t)view * m.n_points + ip) * M3T_DEPTH_POINT_FLOATS;
     G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + ip) * 2;
@@ -1603,7 +1868,7 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
     occluded |= dpp_self_i<0x114, 0xf>(occluded);
     occluded |= dpp_self_i<0x118, 0xf>(occluded);
     PHASE_MARK(20);
-    if (gl == kGroup - 1 && i < np) {  // lane 15 of the row owns the reduced result
+    if (gl == kGroup - 1 && i < own_hi) {  // lane 15 of the row owns the reduced result
       valid = valid && best != min_considered;
       if (valid) {
         // recompute the winning sample (same operations as in the scan)
@@ -1629,7 +1894,6 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
           valid_occ = renderer_depth(dr, min_value) > depth - p[6 + id] - threshold;
         }
         flags = (valid_occ ? 1 : 0) | 2;
-        my_valid_occ += valid_occ ? 1 : 0;
         ps[PS_CX * np + i] = cx; ps[PS_CY * np + i] = cy; ps[PS_CZ * np + i] = cz;
         ps[PS_NX * np + i] = pa.w; ps[PS_NY * np + i] = pb4.x; ps[PS_NZ * np + i] = pb4.y;
         ps[PS_CENTER_U * np + i] = center_u;
@@ -1641,9 +1905,30 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
     }
     PHASE_MARK(21);
   }
+  // model data of the points other workgroups scan (their correspondences and flags arrive by exchange)
+  if (pt_lo > 0 || own_hi < np) {
+    for (int i = tid; i < n_points && i < np; i += nt) {
+      if (i >= pt_lo && i < own_hi) continue;
+      G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + i) * 2;
+      const v4f pa = p8[0], pb4 = p8[1];
+      ps[PS_CX * np + i] = pa.x; ps[PS_CY * np + i] = pa.y; ps[PS_CZ * np + i] = pa.z;
+      ps[PS_NX * np + i] = pa.w; ps[PS_NY * np + i] = pb4.x; ps[PS_NZ * np + i] = pb4.y;
+    }
+  }
+  __syncthreads();
+}
+
+__device__ void depth_correspondences_vote(CDepth& m, int iteration, float* ps, int np, float* misc) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const bool handle_occlusions = (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
+  const bool measured_pass = m.measure_occlusions && handle_occlusions;
+  const bool modeled_pass = m.model_occlusions && handle_occlusions &&
+                            renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
   bool use_occ = false;
-  if (occlusion_pass) {
-    int cnt = wave_sum_i(my_valid_occ);
+  if (measured_pass || modeled_pass) {
+    int mine = 0;
+    for (int i = tid; i < np; i += nt) mine += f2i_bits(ps[PS_VALID * np + i]) & 1;
+    int cnt = wave_sum_i(mine);
     int* imisc = reinterpret_cast<int*>(misc);
     if (tid % kWave == 0) imisc[64 + tid / kWave] = cnt;
     __syncthreads();
@@ -1651,7 +1936,6 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
     for (int w = 0; w < nt / kWave; ++w) total += imisc[64 + w];
     use_occ = total >= m.min_n_unoccluded_points;
   }
-  __syncthreads();
   const int valid_mask = use_occ ? 1 : 2;
   for (int i = tid; i < np; i += nt) {
     int flags = f2i_bits(ps[PS_VALID * np + i]);
@@ -1659,75 +1943,46 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
   }
   __syncthreads();
 }
+__device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, int iteration, int corr_iteration,
+                                      float* ps, int np, float* misc) {
+  depth_correspondences_scan(m, cam, b2c, iteration, corr_iteration, ps, np, misc);
+  depth_correspondences_vote(m, iteration, ps, np, misc);
+}
 
-// DepthModality::CalculateGradientAndHessian (depth_modality.cpp:333-381), whole block.
-__device__ void depth_gradient_hessian(CDepth& m, const Affine& b2c, int corr_iteration, const float* ps,
-                                       int np, float* misc, float* gh_out, bool sequential_sum, float* stage) {
+// DepthModality::CalculateGradientAndHessian (depth_modality.cpp:333-381), the per-point part: one thread per
+// point slot writes the point's 27 products to rows[row * pitch + point] (see chain_sums above).
+__device__ void depth_products(CDepth& m, const Affine& b2c, int corr_iteration, const float* ps, int np, float* rows,
+                               int pitch) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const Affine c2b = inverse_pose(b2c);
   const float standard_deviation = last_valid(m.standard_deviations, m.n_standard_deviations, corr_iteration);
-  float acc[27];
+  const int slots = chain_slots(np);
+  for (int i = tid; i < slots; i += nt) {
+    float* out = rows + i;
+    if (i < np && (f2i_bits(ps[PS_VALID * np + i]) & 1)) {
+      float qx, qy, qz;
+      apply_pose(c2b, ps[PS_CORR_X * np + i], ps[PS_CORR_Y * np + i], ps[PS_CORR_Z * np + i], qx, qy, qz);
+      float nx = ps[PS_NX * np + i], ny = ps[PS_NY * np + i], nz = ps[PS_NZ * np + i];
+      float d0 = ps[PS_CX * np + i] - qx, d1 = ps[PS_CY * np + i] - qy, d2 = ps[PS_CZ * np + i] - qz;
+      float epsilon = (nx * d0 + ny * d1) + nz * d2;
+      float c0 = qy * nz - qz * ny, c1 = qz * nx - qx * nz, c2 = qx * ny - qy * nx;
+      float weight = 1.0f / (standard_deviation * ps[PS_CORR_Z * np + i]);
+      float se = (weight * weight) * epsilon;
+      const float v[6] = {c0, c1, c2, nx, ny, nz};
+      float w[6];
 #pragma unroll
-  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
-  for (int i = tid; i < np; i += nt) {
-    if (sequential_sum) stage[i * 14 + 13] = 0.0f;
-    if (!(f2i_bits(ps[PS_VALID * np + i]) & 1)) continue;
-    float qx, qy, qz;
-    apply_pose(c2b, ps[PS_CORR_X * np + i], ps[PS_CORR_Y * np + i], ps[PS_CORR_Z * np + i], qx, qy, qz);
-    float nx = ps[PS_NX * np + i], ny = ps[PS_NY * np + i], nz = ps[PS_NZ * np + i];
-    float d0 = ps[PS_CX * np + i] - qx, d1 = ps[PS_CY * np + i] - qy, d2 = ps[PS_CZ * np + i] - qz;
-    float epsilon = (nx * d0 + ny * d1) + nz * d2;
-    float c0 = qy * nz - qz * ny, c1 = qz * nx - qx * nz, c2 = qx * ny - qy * nx;
-    float weight = 1.0f / (standard_deviation * ps[PS_CORR_Z * np + i]);
-    float se = (weight * weight) * epsilon;
-    float w[6] = {weight * c0, weight * c1, weight * c2, weight * nx, weight * ny, weight * nz};
-    if (sequential_sum) {
-      float* st = stage + i * 14;
-      st[0] = c0; st[1] = c1; st[2] = c2; st[3] = nx; st[4] = ny; st[5] = nz;
+      for (int r = 0; r < 6; ++r) w[r] = weight * v[r];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) st[6 + r] = w[r];
-      st[12] = se;
-      st[13] = 1.0f;
-      continue;
+      for (int r = 0; r < 6; ++r) out[r * pitch] = se * v[r];  // gradient_ -= (w^2 epsilon) * [p x n; n]
+      int k = 6;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int r = c; r < 6; ++r) out[(k++) * pitch] = w[c] * w[r];  // hessian_ (upper, (c, r)) -= w_c w_r
+    } else {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) out[k * pitch] = 0.0f;
     }
-    acc[0] -= se * c0; acc[1] -= se * c1; acc[2] -= se * c2;
-    acc[3] -= se * nx; acc[4] -= se * ny; acc[5] -= se * nz;
-    // upper triangle, column by column (r <= c)
-    int k = 6;
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-#pragma unroll
-      for (int r = 0; r <= c; ++r) acc[k++] -= w[r] * w[c];
-  }
-  float* red = misc + kMiscRed;
-  if (sequential_sum) {
-    __syncthreads();
-    if (tid < 27) {
-      int r = tid, c = 0;
-      if (tid >= 6) {
-        int k = tid - 6;
-        c = 0;
-        while (k > c) { k -= c + 1; ++c; }
-        r = k;
-      }
-      float sum = 0.0f;
-      for (int i = 0; i < np; ++i) {
-        const float* st = stage + i * 14;
-        if (st[13] == 0.0f) continue;
-        if (tid < 6) sum -= st[12] * st[r];
-        else sum -= st[6 + r] * st[6 + c];
-      }
-      red[tid] = sum;
-    }
-    __syncthreads();
-  } else {
-    block_reduce<27>(acc, (np + kWave - 1) / kWave, misc + kMiscPartials, red);
-  }
-  if (tid < 6) gh_out[tid] = red[tid];
-  if (tid < 36) {
-    int c = tid / 6, r = tid % 6;
-    int hi = r <= c ? c : r, lo = r <= c ? r : c;  // upper triangle entry (row lo, col hi)
-    gh_out[6 + c * 6 + r] = red[6 + hi * (hi + 1) / 2 + lo];
   }
 }
 
@@ -2066,6 +2321,7 @@ __device__ __forceinline__ void region_correspondence_body(const RegionModDev* m
   Affine b2dc = b2c;
   if (dcam) b2dc = mul_pose(load_pose(dcam->world2camera), b2w);
   region_correspondences<HIST_LDS>(m, cam, dcam, b2c, b2dc, iteration, corr_iteration, s);
+  region_moments(m, s);
   // LDS -> global line state (compact stride n_lines_max)
   for (int i = threadIdx.x; i < LS_FIELDS * m.n_lines_max; i += blockDim.x) {
     int f = i / m.n_lines_max, l = i - f * m.n_lines_max;
@@ -2087,7 +2343,7 @@ region_correspondence_lds_kernel(const RegionModDev* mods, const CameraDev* cams
 
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 region_gradient_hessian_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses,
-                               TrackLdsLayout layout, int corr_iteration, int opt_iteration, int sequential_sum) {
+                               TrackLdsLayout layout, int corr_iteration, int opt_iteration) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   CRegion& m = *(CRegion*)(mods + blockIdx.x);
   CCam& cam = *(CCam*)(cams + m.camera);
@@ -2099,7 +2355,14 @@ region_gradient_hessian_kernel(const RegionModDev* mods, const CameraDev* cams, 
   for (int l = m.n_lines_max + threadIdx.x; l < s.nl; l += blockDim.x) s.state[LS_VALID * s.nl + l] = i2f_bits(0);
   __syncthreads();
   const Affine b2c = mul_pose(load_pose(cam.world2camera), load_pose(body_poses + 16 * m.body));
-  region_gradient_hessian(m, cam, b2c, corr_iteration, opt_iteration, s, m.gradient_hessian, sequential_sum != 0);
+  float* rows = lds + layout.off_rows_r;
+  region_products(m, cam, b2c, corr_iteration, opt_iteration, s, rows, layout.pitch_r);
+  __syncthreads();
+  if (threadIdx.x < 42) {  // the first wave: the sums in the layout of gradient() / hessian()
+    float sum, unused;
+    chain_sums(rows, layout.pitch_r, chain_slots(s.nl), nullptr, 0, 0, gh_lane_row(threadIdx.x), sum, unused);
+    m.gradient_hessian[threadIdx.x] = sum;
+  }
 }
 
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
@@ -2118,14 +2381,15 @@ depth_correspondence_kernel(const DepthModDev* mods, const CameraDev* cams, cons
   }
 }
 
+// LDS: misc | point state [PS_FIELDS][np] (rounded up to 16 bytes) | product rows [27][chain_pitch(np)]
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 depth_gradient_hessian_kernel(const DepthModDev* mods, const CameraDev* cams, const float* body_poses, int np,
-                              int corr_iteration, int sequential_sum) {
+                              int corr_iteration) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   CDepth& m = *(CDepth*)(mods + blockIdx.x);
   CCam& cam = *(CCam*)(cams + m.camera);
-  float* misc = lds;
   float* ps = lds + M3T_MISC_FLOATS;
+  float* rows = ps + (PS_FIELDS * np + 3) / 4 * 4;
   for (int i = threadIdx.x; i < PS_FIELDS * m.n_points_max; i += blockDim.x) {
     int f = i / m.n_points_max, l = i - f * m.n_points_max;
     ps[f * np + l] = m.point_state[i];
@@ -2133,33 +2397,34 @@ depth_gradient_hessian_kernel(const DepthModDev* mods, const CameraDev* cams, co
   for (int l = m.n_points_max + threadIdx.x; l < np; l += blockDim.x) ps[PS_VALID * np + l] = i2f_bits(0);
   __syncthreads();
   const Affine b2c = mul_pose(load_pose(cam.world2camera), load_pose(body_poses + 16 * m.body));
-  depth_gradient_hessian(m, b2c, corr_iteration, ps, np, misc, m.gradient_hessian, sequential_sum != 0,
-                         ps + PS_FIELDS * np);
+  const int pitch = chain_pitch(np);
+  depth_products(m, b2c, corr_iteration, ps, np, rows, pitch);
+  __syncthreads();
+  if (threadIdx.x < 42) {
+    float sum, unused;
+    chain_sums(rows, pitch, chain_slots(np), nullptr, 0, 0, gh_lane_row(threadIdx.x), sum, unused);
+    m.gradient_hessian[threadIdx.x] = sum;
+  }
 }
 
-// One thread per rigid optimizer (Link::CalculateGradientAndHessian link.cpp:184-193 + solve + update).
-__global__ void rigid_optimize_kernel(const RigidOptDev* opts, int n_opts, const RegionModDev* rmods,
-                                      const DepthModDev* dmods, float* body_poses) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_opts) return;
-  COpt& o = *(COpt*)(opts + i);
-  float g[6], h[36];
-  for (int k = 0; k < 6; ++k) g[k] = 0.0f;
-  for (int k = 0; k < 36; ++k) h[k] = 0.0f;
-  if (o.region_modality >= 0) {
-    const float* gh = rmods[o.region_modality].gradient_hessian;
-    for (int k = 0; k < 6; ++k) g[k] += gh[k];
-    for (int k = 0; k < 36; ++k) h[k] += gh[6 + k];
+// One wave per rigid optimizer (Link::CalculateGradientAndHessian link.cpp:184-193 + solve + update).
+__global__ void __launch_bounds__(64)
+rigid_optimize_kernel(const RigidOptDev* opts, int n_opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                      float* body_poses) {
+  __shared__ float pose[16];
+  __shared__ float scratch[128];
+  COpt& o = *(COpt*)(opts + blockIdx.x);
+  const int lane = threadIdx.x;
+  float gh = 0.0f;
+  if (lane < 42) {
+    if (o.region_modality >= 0) gh += rmods[o.region_modality].gradient_hessian[lane];
+    if (o.depth_modality >= 0) gh += dmods[o.depth_modality].gradient_hessian[lane];
   }
-  if (o.depth_modality >= 0) {
-    const float* gh = dmods[o.depth_modality].gradient_hessian;
-    for (int k = 0; k < 6; ++k) g[k] += gh[k];
-    for (int k = 0; k < 36; ++k) h[k] += gh[6 + k];
-  }
-  float pose[16];
-  for (int k = 0; k < 16; ++k) pose[k] = body_poses[16 * o.body + k];
-  rigid_solve_update(g, h, o.tikhonov_rotation, o.tikhonov_translation, pose);
-  for (int k = 0; k < 16; ++k) body_poses[16 * o.body + k] = pose[k];
+  if (lane < 16) pose[lane] = body_poses[16 * o.body + lane];
+  __builtin_amdgcn_wave_barrier();
+  rigid_solve_wave(gh, o.tikhonov_rotation, o.tikhonov_translation, pose, scratch);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 16) body_poses[16 * o.body + lane] = pose[lane];
 }
 
 // ---------------------------------------------------------------------------
@@ -2167,28 +2432,38 @@ __global__ void rigid_optimize_kernel(const RigidOptDev* opts, int n_opts, const
 // one block per rigid optimizer; n_corr x (correspondences + n_update x (g/H + solve)).
 // Everything between the image/model gathers and the final pose stays in LDS.
 // ---------------------------------------------------------------------------
+struct SplitParams {               // tracking_step_split_kernel: n_parts workgroups (on as many CUs) per object
+  unsigned long long* granules;    // [objects][2 slots][n_parts][32 fields][1 << lshift]
+  unsigned* object_abort;          // [objects]
+  unsigned* host_abort;            // mapped host word
+  unsigned seq;                    // launch sequence number
+  int n_parts, lshift;             // n_parts << lshift == 256
+  int per_part_lines, per_part_points;
+};
+
 extern "C++" {
 template <bool HIST_LDS, bool SPLIT = false>
 __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int sequential_sum, int fuse_histogram, unsigned long long* split_granules = nullptr,
-                     unsigned* split_timeout = nullptr, uint32_t split_seq = 0) {
+                     int fuse_histogram, const SplitParams* split = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds_t[];
-  // SPLIT: M3T_SPLIT_PARTS workgroups (on as many CUs) share one object.  Each runs the whole step, but walks
-  // the pixels and sums g/H for its quarter of the correspondence lines only; the partial sums are exchanged
-  // before every solve (split_exchange_sums), every workgroup solves redundantly and so holds the same pose.
-  // With a multiple of 8 objects the workgroups of one object sit on one XCD (block b runs on XCD b % 8).
-  int object = blockIdx.x, part = 0;
+  // SPLIT: n_parts workgroups share one object.  Each runs the whole step, but walks the pixels (and scans the depth
+  // windows) of its own part of the lines (points) only; the line results are exchanged once per correspondence
+  // iteration (split_exchange_state), after which every workgroup holds the same state, forms the same sums and
+  // solves redundantly.  With a multiple of 8 objects the workgroups of one object sit on one XCD (block b runs on
+  // XCD b % 8): a speed bonus, not a correctness condition.
+  int object = blockIdx.x, part = 0, n_parts = 1;
   if constexpr (SPLIT) {
-    const int b = blockIdx.x, n_objects = gridDim.x / M3T_SPLIT_PARTS;
+    n_parts = split->n_parts;
+    const int b = blockIdx.x, n_objects = gridDim.x / n_parts;
     if ((n_objects & 7) == 0) {
       const int j = b >> 3;
-      object = (j / M3T_SPLIT_PARTS) * 8 + (b & 7);
-      part = j % M3T_SPLIT_PARTS;
+      object = (j / n_parts) * 8 + (b & 7);
+      part = j % n_parts;
     } else {
-      object = b / M3T_SPLIT_PARTS;
-      part = b % M3T_SPLIT_PARTS;
+      object = b / n_parts;
+      part = b % n_parts;
     }
   }
   COpt& o = *(COpt*)(opts + object);
@@ -2196,6 +2471,8 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   CDepth* dm = o.depth_modality >= 0 ? (CDepth*)(dmods + o.depth_modality) : nullptr;
   Lds s = carve(lds_t, layout);
   float* ps = lds_t + off_points;
+  float* rows_r = lds_t + layout.off_rows_r;
+  float* rows_d = lds_t + layout.off_rows_d;
   float* pose = s.misc + kMiscPose;           // 16 floats
   float* gh_region = s.misc + kMiscGhRegion;  // 42
   float* gh_depth = s.misc + kMiscGhDepth;    // 42
@@ -2205,16 +2482,26 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
   CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
   CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
-  int line_lo = 0, line_hi = 1 << 30;
+  int line_lo = 0, line_hi = 1 << 30, pt_lo = 0, pt_hi = 1 << 30;
   SplitExchange exchange{};
   if constexpr (SPLIT) {
-    const int per_part = (s.nl + M3T_SPLIT_PARTS - 1) / M3T_SPLIT_PARTS;
-    line_lo = part * per_part;
-    line_hi = line_lo + per_part;
-    exchange.granules = (__attribute__((address_space(1))) unsigned long long*)split_granules +
-                        (size_t)object * (2 * M3T_SPLIT_PARTS * 32);
-    exchange.timeout = (__attribute__((address_space(1))) unsigned*)split_timeout;
+    line_lo = part * split->per_part_lines;
+    line_hi = line_lo + split->per_part_lines;
+    pt_lo = part * split->per_part_points;
+    pt_hi = pt_lo + split->per_part_points;
+    exchange.granules = (__attribute__((address_space(1))) unsigned long long*)split->granules +
+                        ((size_t)object * 2 * n_parts << (kExchangeFieldBits + split->lshift));
+    exchange.object_abort = (__attribute__((address_space(1))) unsigned*)split->object_abort + object;
+    exchange.host_abort = split->host_abort;
+    exchange.seq = split->seq;
     exchange.part = part;
+    exchange.n_parts = n_parts;
+    exchange.lshift = split->lshift;
+    exchange.per_part_lines = split->per_part_lines;
+    exchange.per_part_points = split->per_part_points;
+    exchange.n_region_fields = rm ? rm->distribution_length : 0;
+    exchange.n_depth_fields = write_state ? PS_VALID + 1 - PS_CENTER_U : PS_VALID + 1 - PS_CORR_X;
+    exchange.first_depth_row = write_state ? PS_CENTER_U : PS_CORR_X;
   }
   for (int c = 0; c < n_corr_iterations; ++c) {
     {
@@ -2228,60 +2515,58 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       if (dm) {
         PHASE_T0();
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
-        depth_correspondences(*dm, *dcam, b2c, iteration, c, ps, np, s.misc);
+        depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, pt_lo, pt_hi);
         PHASE_MARK(16);
       }
+      if constexpr (SPLIT) {
+        PHASE_T0();
+        if (!split_exchange_state(exchange, c, s, rm != nullptr, ps, np, dm != nullptr)) return;
+        PHASE_MARK(22);
+      }
+      if (rm) region_moments(*rm, s);
+      if (dm) depth_correspondences_vote(*dm, iteration, ps, np, s.misc);
     }
     for (int u = 0; u < n_update_iterations; ++u) {
       PHASE_T0();
       const Affine b2w = load_pose(pose);
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
-        if constexpr (SPLIT) {
-          exchange.round = c * n_update_iterations + u;
-          exchange.tag = split_seq * 64u + (uint32_t)exchange.round + 1u;
-          region_gradient_hessian(*rm, *cam, b2c, c, u, s, gh_region, false, part, &exchange);
-        } else {
-          region_gradient_hessian(*rm, *cam, b2c, c, u, s, gh_region, sequential_sum != 0);
-        }
+        region_products(*rm, *cam, b2c, c, u, s, rows_r, layout.pitch_r);
       }
       if (dm) {
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
-        depth_gradient_hessian(*dm, b2c, c, ps, np, s.misc, gh_depth, sequential_sum != 0, ps + PS_FIELDS * np);
+        depth_products(*dm, b2c, c, ps, np, rows_d, layout.pitch_d);
       }
       __syncthreads();
       PHASE_MARK(5);
-      if (threadIdx.x == 0) {
-        float g[6], h[36];
-        for (int k = 0; k < 6; ++k) g[k] = 0.0f;
-        for (int k = 0; k < 36; ++k) h[k] = 0.0f;
-        if (rm) {
-          for (int k = 0; k < 6; ++k) g[k] += gh_region[k];
-          for (int k = 0; k < 36; ++k) h[k] += gh_region[6 + k];
+      if (threadIdx.x < kWave) {  // one wave: the sums in the reference's order, Link sum, solve, pose update
+        float sum_r = 0.0f, sum_d = 0.0f;
+        chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
+                   chain_slots(np), gh_lane_row(threadIdx.x < 42 ? threadIdx.x : 0), sum_r, sum_d);
+        float gh = 0.0f;  // Link::CalculateGradientAndHessian link.cpp:184-193
+        if (rm) gh += sum_r;
+        if (dm) gh += sum_d;
+        if (write_state && threadIdx.x < 42) {
+          gh_region[threadIdx.x] = sum_r;
+          gh_depth[threadIdx.x] = sum_d;
         }
-        if (dm) {
-          for (int k = 0; k < 6; ++k) g[k] += gh_depth[k];
-          for (int k = 0; k < 36; ++k) h[k] += gh_depth[6 + k];
-        }
-        float p[16];
-        for (int k = 0; k < 16; ++k) p[k] = pose[k];
-        rigid_solve_update(g, h, o.tikhonov_rotation, o.tikhonov_translation, p);
-        for (int k = 0; k < 16; ++k) pose[k] = p[k];
+        PHASE_MARK(23);
+        rigid_solve_wave(gh, o.tikhonov_rotation, o.tikhonov_translation, pose, s.misc + kMiscSolve);
       }
       __syncthreads();
       PHASE_MARK(6);
     }
   }
   // (every workgroup of a split object holds the same pose: the first one writes it; no other workgroup can
-  // still be waiting to read the old one, it had to publish its first sums before this one got here)
+  // still be waiting to read the old one, it had to publish its first results before this one got here)
   if (threadIdx.x < 16 && part == 0) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
-  if (write_state) {
+  if (write_state && part == 0) {
     if (rm) {
       for (int i = threadIdx.x; i < LS_FIELDS * rm->n_lines_max; i += blockDim.x) {
         int f = i / rm->n_lines_max, l = i - f * rm->n_lines_max;
-        if (l >= line_lo && l < line_hi) rm->line_state[i] = s.state[f * s.nl + l];
+        rm->line_state[i] = s.state[f * s.nl + l];
       }
-      if (threadIdx.x < 42 && part == 0) rm->gradient_hessian[threadIdx.x] = gh_region[threadIdx.x];
+      if (threadIdx.x < 42) rm->gradient_hessian[threadIdx.x] = gh_region[threadIdx.x];
     }
     if (dm) {
       for (int i = threadIdx.x; i < PS_FIELDS * dm->n_points_max; i += blockDim.x) {
@@ -2300,10 +2585,10 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     Affine b2dc = b2c;
     if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
     const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
-    // (the workgroups of a split object take a quarter of the bins each: n_bins^3 is a multiple of 16)
+    // (the workgroups of a split object take an equal share of the bins each: n_bins^3 is a multiple of 64)
     const int n_bins3 = rm->n_bins * rm->n_bins * rm->n_bins;
-    const int bin_lo = SPLIT ? part * (n_bins3 / M3T_SPLIT_PARTS) : 0;
-    const int bin_hi = SPLIT ? bin_lo + n_bins3 / M3T_SPLIT_PARTS : n_bins3;
+    const int bin_lo = SPLIT ? part * (n_bins3 / n_parts) : 0;
+    const int bin_hi = SPLIT ? bin_lo + n_bins3 / n_parts : n_bins3;
     region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
                             (__attribute__((address_space(3))) uint32_t*)(lds_t + M3T_MISC_FLOATS), lds_t, bin_lo,
                             bin_hi);
@@ -2315,28 +2600,26 @@ __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int sequential_sum, int fuse_histogram) {
+                     int fuse_histogram) {
   tracking_step_body<false>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
-                            n_update_iterations, write_state, sequential_sum, fuse_histogram);
+                            n_update_iterations, write_state, fuse_histogram);
 }
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_lds_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int sequential_sum, int fuse_histogram) {
+                     int fuse_histogram) {
   tracking_step_body<true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
-                            n_update_iterations, write_state, sequential_sum, fuse_histogram);
+                            n_update_iterations, write_state, fuse_histogram);
 }
-// M3T_SPLIT_PARTS workgroups per object (region modality only): for batches that leave most CUs idle
+// several workgroups per object: for batches that leave most CUs idle
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_split_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int fuse_histogram, unsigned long long* split_granules, unsigned* split_timeout,
-                     unsigned split_seq) {
+                     int fuse_histogram, SplitParams split) {
   tracking_step_body<false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
-                                  n_corr_iterations, n_update_iterations, write_state, 0, fuse_histogram,
-                                  split_granules, split_timeout, split_seq);
+                                  n_corr_iterations, n_update_iterations, write_state, fuse_histogram, &split);
 }
 
 }  // extern "C"

@@ -110,8 +110,9 @@ int m3t_hip_bodies_get_poses(m3t_hip_context*, float* poses, int n);
 
 /* ---- Modalities (modality.h:56-155) -------------------------------------------
  * RegionModality ctor + SetUp (region_modality.h:169-176, region_modality.cpp:25-99);
- * depth_camera_id = -1 unless measure_occlusions.  Renderer-fed options
- * (use_region_checking / model_occlusions / use_silhouette_checking) -> M3T_ERR_UNSUPPORTED. */
+ * depth_camera_id = -1 unless measure_occlusions.  The renderer-fed options (use_region_checking /
+ * model_occlusions / use_silhouette_checking) are switched on afterwards with the *_model_occlusions / *_use_*
+ * calls below, which name the renderer; set in the parameter struct they are rejected (M3T_ERR_INVALID_ARGUMENT). */
 int m3t_hip_region_modality_create(m3t_hip_context*, const m3t_region_modality_params*, int body_id,
                                    int color_camera_id, int region_model_id, int depth_camera_id);
 int m3t_hip_depth_modality_create(m3t_hip_context*, const m3t_depth_modality_params*, int body_id,
@@ -225,26 +226,28 @@ int m3t_hip_execute_tracking_cycle(m3t_hip_context*, int iteration);
  *    g/H of every iteration observable); 1 (default): fused device loop;
  * 2: fused + line/point state and g/H of the last iteration written back. */
 int m3t_hip_set_fused_step(m3t_hip_context*, int mode);
-/* Small batches (at most a quarter of the CUs busy, region modality only) run with four workgroups per object
- * that exchange partial sums inside the launch; they are all resident at once only while this context has the
- * GPU to itself.  A process that shares its GPU with other work switches the split off (enable = 0): results
- * are bit-identical either way, a step is about 20 % slower.  Default: on. */
+/* Batches that leave CUs idle run with several (4, 8 or 16) workgroups per object, which hand each other their
+ * share of the line / point results inside the launch; that needs all of them resident at once, which holds while
+ * this context has the GPU to itself.  If a workgroup waits in vain (another process occupies the CUs), the step
+ * of that object is abandoned without writing its pose or histograms and the NEXT call of execute_tracking_step /
+ * sync / a pose getter returns M3T_ERR_DEVICE: set the poses again and call start_modalities.  A process that
+ * shares its GPU switches the split off.  enable: 0 = off, 1 = automatic (default), 2..16 = at most that many
+ * workgroups per object.  Results are bit-identical in every shape. */
 int m3t_hip_set_object_split(m3t_hip_context*, int enable);
 /* Refiner::RefinePoses (refiner.cpp:76-117): CalculateConsistentPoses, then n_corr_iterations x
  * (StartModalities + CalculateCorrespondences + n_update_iterations x (g/H + optimisation)), iteration index 0 */
 int m3t_hip_refine_poses(m3t_hip_context*, int n_corr_iterations, int n_update_iterations);
 int m3t_hip_sync(m3t_hip_context*);
-/* order of the gradient/Hessian sums over lines/points.  0 (default): wavefront DPP tree +
- * LDS across waves.  1: the reference's sequential f32 order (region_modality.cpp:550-554,
- * depth_modality.cpp:361-377) on 27 lanes -- ~10x slower per call, for bit-level parity
- * checks of whole tracking sequences against the CPU restatement. */
+/* Kept for callers of the first release, no effect: the gradient / Hessian sums over lines / points are always
+ * taken in the reference's sequential f32 order (region_modality.cpp:550-554, depth_modality.cpp:361-377), so
+ * whole tracking sequences reproduce the CPU path bit for bit in every launch shape. */
 int m3t_hip_set_summation_mode(m3t_hip_context*, int mode);
 /* measurement aid (bench.py roofline leg): HIP events on the context stream around
  * [0] the fused tracking kernel and [1] the histogram kernel; totals since enable */
 int m3t_hip_set_kernel_timing(m3t_hip_context*, int enable);
 int m3t_hip_get_kernel_timing(m3t_hip_context*, float total_ms[2], int launches[2]);
-/* launch shape of the last fused tracking step: [0] objects, [1] workgroups per object (1, or 4 =
- * tracking_step_split_kernel when the batch fills at most a quarter of the CUs), [2] threads per workgroup,
+/* launch shape of the last fused tracking step: [0] objects, [1] workgroups per object (1, or 4 / 8 / 16 =
+ * tracking_step_split_kernel when the batch leaves CUs idle), [2] threads per workgroup,
  * [3] 1 if the histogram update ran inside the same launch; zeros before the first fused step */
 int m3t_hip_get_step_shape(m3t_hip_context*, int shape[4]);
 

@@ -18,6 +18,10 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -2810,6 +2814,59 @@ int m3t_oracle_execute_tracking_step(m3t_oracle_context* ctx, int iteration) {
     }
   }
   return m3t_oracle_calculate_results(ctx, iteration);
+}
+// The same step with an OpenMP `parallel for` over the optimizers: the CPU baseline at nproc threads (SURVEY 8d (ii);
+// the reference's evaluators parallelise over sequences the same way, rbot_evaluator.cpp:144).  Only for independent
+// rigid objects (no renderers, no shared histograms, no kinematic trees or constraints): then the optimizers touch
+// disjoint state and every object's loop nest runs on its own, with results identical to the serial step.
+// seconds[4] (optional) accumulates the wall time of the four buckets the evaluators report
+// (rbot_evaluator.cpp:354-414: correspondences, gradient + Hessian, optimisation, results), summed over threads.
+int m3t_oracle_execute_tracking_step_parallel(m3t_oracle_context* ctx, int iteration, int n_threads, double* seconds) {
+  CHECK_CTX();
+  if (!CTX->renderers.empty() || !CTX->shared_histograms.empty() || !CTX->constraints.empty() ||
+      !CTX->soft_constraints.empty())
+    FAIL(M3T_ERR_UNSUPPORTED, "parallel step: independent rigid objects only");
+  size_t attached = 0;
+  for (auto& o : CTX->optimizers) {
+    const Link& l = CTX->links[o.root_link];
+    if (!l.children.empty() || l.body < 0) FAIL(M3T_ERR_UNSUPPORTED, "parallel step: independent rigid objects only");
+    attached += l.modalities.size();
+  }
+  if (attached != CTX->modalities.size()) FAIL(M3T_ERR_UNSUPPORTED, "parallel step: a modality without optimizer");
+  int r = CheckImages(ctx);
+  if (r) return r;
+  const int n = int(CTX->optimizers.size());
+  double bucket[4] = {0.0, 0.0, 0.0, 0.0};
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+#ifdef _OPENMP
+  if (n_threads <= 0) n_threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : bucket[:4])
+#endif
+  for (int i = 0; i < n; ++i) {
+    Optimizer& o = CTX->optimizers[i];
+    const std::vector<int>& mods = CTX->links[o.root_link].modalities;
+    for (int c = 0; c < CTX->n_corr_iterations; ++c) {
+      double t0 = now();
+      for (int m : mods) CTX->modalities[m]->CalculateCorrespondences(iteration, c);
+      double t1 = now();
+      bucket[0] += t1 - t0;
+      for (int u = 0; u < CTX->n_update_iterations; ++u) {
+        t0 = now();
+        for (int m : mods) CTX->modalities[m]->CalculateGradientAndHessian(iteration, c, u);
+        t1 = now();
+        OptimizerCalculateOptimization(CTX, o);
+        const double t2 = now();
+        bucket[1] += t1 - t0;
+        bucket[2] += t2 - t1;
+      }
+    }
+    const double t0 = now();
+    for (int m : mods) CTX->modalities[m]->CalculateResults(iteration);
+    bucket[3] += now() - t0;
+  }
+  if (seconds)
+    for (int k = 0; k < 4; ++k) seconds[k] += bucket[k];
+  return M3T_OK;
 }
 // Refiner::RefinePoses src/refiner.cpp:76-117
 int m3t_oracle_refine_poses(m3t_oracle_context* ctx, int n_corr_iterations, int n_update_iterations) {

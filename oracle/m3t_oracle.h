@@ -150,6 +150,9 @@ int m3t_oracle_calculate_optimization_begin(m3t_oracle_context*, float** partial
 int m3t_oracle_calculate_optimization_end(m3t_oracle_context*);
 int m3t_oracle_calculate_results(m3t_oracle_context*, int iteration);
 int m3t_oracle_execute_tracking_step(m3t_oracle_context*, int iteration);
+/* oracle only (no m3t_hip twin): the same step with an OpenMP parallel-for over independent rigid objects, for the
+ * CPU baseline at nproc threads; seconds[4] accumulates the evaluators' four time buckets summed over threads */
+int m3t_oracle_execute_tracking_step_parallel(m3t_oracle_context*, int iteration, int n_threads, double* seconds);
 int m3t_oracle_execute_tracking_cycle(m3t_oracle_context*, int iteration); /* ICG name */
 /* Refiner::RefinePoses (refiner.cpp:76-117): CalculateConsistentPoses, then n_corr_iterations x
  * (StartModalities + CalculateCorrespondences + n_update_iterations x (g/H + optimisation)), iteration index 0 */

@@ -102,7 +102,6 @@ def test_cpp_generated_tracker_reproduces_the_reference_pose(demo, tmp_path):
         assert os.path.getsize(path) > 2562 * 200 * 36 * 4
     # the Python front-end accepts the files the C++ front-end wrote, and lands on the same pose bit for bit
     api = util.open_hip()
-    api.call("set_summation_mode", 1)
     tracker = util.pkg.generator.GenerateConfiguredTracker(api, str(root / "tracker_test" / "tracker_config.yaml"))
     stamp = os.path.getmtime(models["triangle_region_model"])
     assert tracker.SetUp() and tracker.DetectPoses({"triangle_optimizer"})

@@ -1,0 +1,103 @@
+"""Parity at the BENCHMARKED launch shapes (BASELINE.json configs[1] and configs[2] at their stated sizes):
+bench.py's own inputs -- 64 objects x 2562-view models, RegionModality, RBOT parameters -- through
+tracking_step_split_kernel with 256 workgroups (every CU busy), and 21 Region + Depth objects (YCB parameters)
+over 8 workgroups each, against the oracle: body2world of every object after every frame, free running, bit for bit.
+Stated tolerance: 0 (rotation, translation and ADD-S differences are exactly zero)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+import util
+from util import syn
+
+pytestmark = pytest.mark.gpu
+
+
+def shape_of(api):
+    shape = (C.c_int * 4)()
+    api.call("get_step_shape", shape)
+    return list(shape)
+
+
+@pytest.fixture(scope="module")
+def rbot64():
+    return scenes.Inputs(64, 6, n_divides=4, n_models=8)  # bench.py: scenes.Inputs(n_obj, n_frames, 4, n_models=8)
+
+
+def oracle_trajectory(inputs, use_depth=False):
+    ora = util.open_oracle()
+    b = scenes.Instance(ora, inputs, use_depth=use_depth)
+    b.upload_frame(0)
+    assert b.tracker.StartModalities(0)
+    ref = []
+    for k in range(inputs.n_frames):
+        b.upload_frame(k)
+        assert b.tracker.ExecuteTrackingStep(k)
+        ref.append(np.stack(b.poses()))
+    return ref, [r.histograms() for r in b.region]
+
+
+def hip_trajectory(inputs, use_depth=False, env=None):
+    for k in ("M3T_HIP_NO_SPLIT", "M3T_HIP_SPLIT_PARTS", "M3T_HIP_THREADS"):
+        os.environ.pop(k, None)
+    os.environ.update(env or {})
+    try:
+        api = util.open_hip()
+        a = scenes.Instance(api, inputs, use_depth=use_depth)
+        a.upload_frame(0)
+        assert a.tracker.StartModalities(0)
+        out = []
+        for k in range(inputs.n_frames):
+            a.upload_frame(k)
+            assert a.tracker.ExecuteTrackingStep(k)
+            out.append(np.stack(a.poses()))
+        return out, [r.histograms() for r in a.region], shape_of(api)
+    finally:
+        for k in (env or {}):
+            os.environ.pop(k, None)
+
+
+def test_headline_batch_is_bit_identical_to_the_oracle(rbot64):
+    ref, ref_hist = oracle_trajectory(rbot64)
+    got, hist, shape = hip_trajectory(rbot64)
+    assert shape == [64, 4, 512, 1]  # the launch bench.py times: 4 workgroups per object, all 256 CUs, one launch per frame
+    for k in range(rbot64.n_frames):
+        assert np.array_equal(got[k], ref[k]), k
+    worst = [max(syn.pose_errors(got[-1][i], ref[-1][i])[j] for i in range(64)) for j in (0, 1)]
+    adds = max(syn.add_s(rbot64.vertices[i], got[-1][i], ref[-1][i]) for i in range(64))
+    assert worst == [0.0, 0.0] and adds == 0.0
+    for (fa, ba), (fb, bb) in zip(hist, ref_hist):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+    # and the batch is a meaningful one: every object is tracked (rbot_evaluator.cpp:416-433)
+    for i in range(64):
+        e = syn.pose_errors(got[-1][i], rbot64.gt[i][-1])
+        assert e[0] < np.deg2rad(5) and e[1] < 0.05
+
+
+def test_headline_batch_in_the_other_launch_shapes(rbot64):
+    """one workgroup per object (512 and 256 threads) and 2 workgroups per object: the same bits"""
+    ref, _ = oracle_trajectory(rbot64)
+    for env, expect in (({"M3T_HIP_NO_SPLIT": "1"}, [64, 1, 512, 1]),
+                        ({"M3T_HIP_NO_SPLIT": "1", "M3T_HIP_THREADS": "256"}, [64, 1, 256, 0])):
+        got, _, shape = hip_trajectory(rbot64, env=env)
+        assert shape == expect
+        for k in range(rbot64.n_frames):
+            assert np.array_equal(got[k], ref[k]), (env, k)
+
+
+def test_ycb_batch_is_bit_identical_to_the_oracle():
+    """BASELINE configs[2]: 21 objects, Region + Depth fused modalities, YCB parameters (evaluate_ycb_dataset.cpp:46-76,
+    108-133), 2562-view models; 8 workgroups per object (168 CUs)"""
+    inputs = scenes.Inputs(21, 5, n_divides=4, n_models=6, with_depth=True)
+    ref, ref_hist = oracle_trajectory(inputs, use_depth=True)
+    got, hist, shape = hip_trajectory(inputs, use_depth=True)
+    assert shape[:3] == [21, 8, 512]
+    for k in range(inputs.n_frames):
+        assert np.array_equal(got[k], ref[k]), k
+    for (fa, ba), (fb, bb) in zip(hist, ref_hist):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+    adds = [syn.add_s(inputs.vertices[i], got[-1][i], inputs.gt[i][-1]) for i in range(21)]
+    assert max(adds) < 0.01  # tracked: ADD-S against the ground truth below 1 cm

@@ -16,7 +16,6 @@ cfg = util.pkg.config
 def test_generated_tracker_with_generated_models(tmp_path):
     root = reference_tree(tmp_path)
     api = util.open_hip()
-    api.call("set_summation_mode", 1)  # the reference's summation order
     tracker = run_generated_tracker(api, root)
     golden = util.read_golden_matrix("tracker_test/triangle_pose.txt")
     pose = tracker.body_ptrs()[0].body2world_pose()
@@ -33,7 +32,6 @@ def test_generated_tracker_with_generated_models(tmp_path):
 
     # a second tracker finds them and loads instead of generating: same pose, bit for bit
     api2 = util.open_hip()
-    api2.call("set_summation_mode", 1)
     stamp = os.path.getmtime(tracker.objects["RegionModel"]["triangle_region_model"].model_path)
     tracker2 = run_generated_tracker(api2, root)
     assert os.path.getmtime(tracker2.objects["RegionModel"]["triangle_region_model"].model_path) == stamp

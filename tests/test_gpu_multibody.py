@@ -95,8 +95,6 @@ def test_kinematic_chain_tracking_matches_oracle():
     start_a = syn.perturb_pose(gt[0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
     results = {}
     for name, api in (("hip", util.open_hip()), ("oracle", util.open_oracle())):
-        if name == "hip":
-            api.call("set_summation_mode", 1)
         ch = Chain(api, inputs, joint2parent, start_a, gt[0][2] + 0.01)
         ch.upload(inputs, 0)
         assert ch.tracker.StartModalities(0)

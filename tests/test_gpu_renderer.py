@@ -55,8 +55,6 @@ def test_tracking_step_with_all_branches_matches_oracle():
     for the histogram update); reference summation order -> bit-identical poses and states"""
     res = []
     for api in (util.open_hip(), util.open_oracle()):
-        if api.prefix == "m3t_hip_":
-            api.call("set_summation_mode", 1)
         f, schauma, r = _scene(api, 200)
         f.region.ModelOcclusions(r["color_depth"])
         f.region.UseRegionChecking(r["color_sil"])

@@ -109,8 +109,6 @@ def check_tracker_and_refiner_goldens(api):
     own criterion, and RefinerTest.OptimizePoseMatrix (test/refiner_test.cpp:96-105, refiner.cpp:98-117:
     7 x (StartModalities + correspondences + 3 updates)), which is chaotic on this fixture (see the
     module docstring) and only approached."""
-    if api.is_hip:
-        api.call("set_summation_mode", 1)  # the reference's summation order: bit-identical to the oracle
     f = gs.TrackerFixture(api, measure_occlusions=True)
     assert f.tracker.StartModalities(0) and f.tracker.ExecuteTrackingStep(0)
     golden = util.read_golden_matrix("tracker_test/triangle_pose.txt")

@@ -190,3 +190,33 @@ def test_not_set_up_returns_false():
     assert not tracker.CalculateCorrespondences(0, 0)
     assert not tracker.ExecuteTrackingStep(0)
     assert "first" in api.last_error()
+
+
+def test_oracle_parallel_step_equals_the_serial_step():
+    """m3t_oracle_execute_tracking_step_parallel (OpenMP parallel-for over objects, bench.py's all-cores CPU
+    baseline) walks every object's loop nest on its own: the poses and histograms equal the serial step's."""
+    import ctypes as C
+    import scenes
+    inputs = scenes.Inputs(5, 3, n_divides=1)
+    out = []
+    for parallel in (False, True):
+        ora = util.open_oracle()
+        inst = scenes.Instance(ora, inputs)
+        inst.upload_frame(0)
+        assert inst.tracker.StartModalities(0)
+        f = ora.lib.m3t_oracle_execute_tracking_step_parallel
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        buckets = (C.c_double * 4)()
+        for k in range(3):
+            inst.upload_frame(k)
+            if parallel:
+                assert f(ora.ctx, k, 3, buckets) == 0
+            else:
+                assert inst.tracker.ExecuteTrackingStep(k)
+        if parallel:
+            assert all(b > 0 for b in buckets)
+        out.append((np.stack(inst.poses()), [np.concatenate(r.histograms()) for r in inst.region]))
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)

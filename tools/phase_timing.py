@@ -24,10 +24,13 @@ n = 4
 for k in range(4, 8):
     inst.upload_frame(k); inst.tracker.ExecuteTrackingStep(k)
 f(hip.ctx, buf, 1)
-names = ["view search", "phase A (lines)", "phase B (pixels)", "phase C1 (dist)", "phase C2 (moments)", "g/H", "solve",
+names = ["view search", "phase A (lines)", "phase B (pixels)", "phase C1 (dist)", "phase C2 (moments)",
+         "g/H products + barrier", "solve (wave) + barrier",
          "  B: addr+issue", "  B: pixel wait", "  B: gather issue", "  B: gather wait", "  B: products",
-         "  solve: build", "  solve: LDLT", "  solve: trisolve", "  solve: expm", "depth correspondences", "  d: view search", "  d: point setup", "  d: window scan", "  d: reduce+occlusion", "  d: write"]
-tot = sum(buf[i] for i in range(7)) + buf[16]
+         "  solve: permute + gather", "  solve: LDLT", "  solve: trisolve", "  solve: expm", "depth scan (all)",
+         "  d: view search", "  d: point setup", "  d: window scan", "  d: reduce+occlusion", "  d: write",
+         "split exchange", "g/H chain (42 lanes)"]
+tot = sum(buf[i] for i in range(7)) + buf[16] + buf[22] + buf[23]
 for i, nme in enumerate(names):
     print("%-20s %10.0f cycles/frame  %5.1f%%" % (nme, buf[i] / n, 100.0 * buf[i] / tot))
 print("total %.0f cycles/frame" % (tot / n))
