@@ -297,6 +297,13 @@ _HIP_ONLY = {
     "host_register": [C.c_void_p, C.c_size_t],
     "host_unregister": [C.c_void_p],
     "ingest_sync": [],
+    "comm_get_unique_id": [C.c_void_p, C.c_size_t],
+    "comm_init_rank": [C.c_void_p, C.c_size_t, C.c_int, C.c_int],
+    "comm_set": [C.c_void_p],
+    "comm_destroy": [],
+    "calculate_optimization_allreduce": [],
+    "cameras_set_ring": [c_int_p, C.c_int, C.c_int],
+    "cameras_upload_batch_async": [c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t],
     "camera_select_slot": [C.c_int, C.c_int],
     "cameras_select_slot": [C.c_int],
     "set_summation_mode": [C.c_int],

@@ -3,6 +3,8 @@
 // Single translation unit together with the kernels (one hipcc invocation).
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is opened with dlopen when a structure spans GPUs
 
 #include <algorithm>
 #include <cmath>
@@ -67,7 +69,15 @@ struct Camera {
   int n_slots = 1, current = 0;
   std::vector<bool> has_image;
   std::vector<long> last_read_step;  // per slot: the last streaming step that read it (-1: none)
-  DevMem ring;
+  DevMem ring;          // this camera's own frame ring, or empty when it lives in a shared slab
+  int slab = -1, slab_index = 0;  // shared slab (m3t_hip_cameras_set_ring): [slot][camera of the group][frame]
+  uint8_t* frames = nullptr;      // slot 0 of this camera
+  size_t slot_stride = 0;         // bytes from one slot of this camera to the next
+  uint8_t* frame(int slot) const { return frames + size_t(slot) * slot_stride; }
+};
+struct FrameSlab {  // the frame rings of a group of cameras of equal geometry in one allocation
+  DevMem mem;
+  std::vector<int> cameras;
 };
 
 struct BodyGeometryH {  // body.h:46-60 on the device
@@ -148,6 +158,7 @@ struct m3t_hip_context {
   std::string error;
   std::vector<std::unique_ptr<Model>> region_models, depth_models;
   std::vector<std::unique_ptr<Camera>> cameras;
+  std::vector<std::unique_ptr<FrameSlab>> slabs;
   std::vector<float> body_poses;  // host mirror [n][16] (valid when !poses_on_device_newer)
   std::vector<std::unique_ptr<RegionMod>> region_mods;
   std::vector<std::unique_ptr<DepthMod>> depth_mods;
@@ -169,6 +180,9 @@ struct m3t_hip_context {
   DevMem d_links, d_constraints, d_soft, d_treeopts, d_work, d_partial;
   size_t partial_count = 0;
   bool partial_ready = false;
+  // a kinematic structure spread over GPUs: this rank's RCCL communicator (m3t_hip_comm_init_rank) or the host's
+  ncclComm_t comm = nullptr;
+  bool comm_owned = false;
   int n_corr_iterations = 5, n_update_iterations = 2;
   int fused_mode = 1;
   int sequential_sum = 0;
@@ -224,6 +238,32 @@ struct m3t_hip_context {
 namespace {
 
 using Ctx = m3t_hip_context;
+
+// RCCL entry points, resolved on first use from the process's librccl.so.1 (the one torch.distributed loaded, if any:
+// a communicator and the all-reduce that uses it must come from the same library)
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+  bool Load() {
+    if (AllReduce) return true;
+    handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!handle) handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!handle) { error = std::string("librccl.so.1: ") + dlerror(); return false; }
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce) { error = "librccl.so.1 lacks the nccl* entry points"; AllReduce = nullptr; return false; }
+    return true;
+  }
+};
+Rccl g_rccl;
 
 int Fail(Ctx* c, int code, const std::string& msg) {
   if (c) c->error = msg;
@@ -367,6 +407,8 @@ int CreateCamera(Ctx* ctx, const m3t_intrinsics* intr, const float* w2c, bool de
   c->has_image.assign(1, false);
   c->last_read_step.assign(1, -1);
   HIPCHK(c->ring.alloc(c->frame_bytes + 64));  // +64: pixels are fetched as one 4-byte load (B,G,R,+1)
+  c->frames = c->ring.as<uint8_t>();
+  c->slot_stride = c->frame_bytes;
   ctx->cameras.push_back(std::move(c));
   ctx->cams_dirty = true;
   return int(ctx->cameras.size()) - 1;
@@ -378,7 +420,7 @@ int UploadFrame(Ctx* ctx, int id, int slot, const void* pixels, size_t row_step)
   REQUIRE(slot >= 0 && slot < c.n_slots, M3T_ERR_INVALID_ARGUMENT, "bad frame slot");
   size_t row = size_t(c.intr.width) * (c.is_depth ? 2 : 3);
   REQUIRE(row_step >= row, M3T_ERR_INVALID_ARGUMENT, "row_step smaller than one image row");
-  uint8_t* dst = c.ring.as<uint8_t>() + size_t(slot) * c.frame_bytes;
+  uint8_t* dst = c.frame(slot);
   HIPCHK(hipMemcpy2DAsync(dst, c.pitch, pixels, row_step, row, c.intr.height, hipMemcpyHostToDevice, ctx->stream));
   // the host buffer is only borrowed for the duration of the call
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -749,7 +791,7 @@ int UploadTables(Ctx* ctx) {
       for (size_t i = 0; i < n_cams; ++i) {
         const Camera& c = *ctx->cameras[i];
         CameraDev& d = out[i];
-        d.image = c.ring.as<uint8_t>() + size_t(slot < 0 ? c.current : slot) * c.frame_bytes;
+        d.image = c.frame(slot < 0 ? c.current : slot);
         d.pitch = c.pitch;
         d.width = c.intr.width;
         d.height = c.intr.height;
@@ -1098,6 +1140,7 @@ void m3t_hip_destroy(m3t_hip_context* ctx) {
     if (ctx->cam_stage_done[i]) (void)hipEventDestroy(ctx->cam_stage_done[i]);
   }
   if (ctx->split_abort_host) (void)hipHostFree(ctx->split_abort_host);
+  if (ctx->comm && ctx->comm_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
   delete ctx;
 }
 
@@ -1229,6 +1272,9 @@ int m3t_hip_camera_set_ring(m3t_hip_context* ctx, int id, int n_slots) {
   Camera& c = *ctx->cameras[id];
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(c.ring.alloc(c.frame_bytes * size_t(n_slots) + 64));
+  c.frames = c.ring.as<uint8_t>();
+  c.slot_stride = c.frame_bytes;
+  c.slab = -1;
   c.n_slots = n_slots;
   c.current = 0;
   c.has_image.assign(n_slots, false);
@@ -1286,13 +1332,105 @@ int m3t_hip_camera_upload_slot_async(m3t_hip_context* ctx, int id, int slot, con
     HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->step_done[c.last_read_step[slot] % Ctx::kStepEvents], 0));
     ctx->copy_waited_step[cs] = c.last_read_step[slot];
   }
-  uint8_t* dst = c.ring.as<uint8_t>() + size_t(slot) * c.frame_bytes;
+  uint8_t* dst = c.frame(slot);
   if (row_step == c.pitch)  // contiguous on both sides: one linear DMA transfer
     HIPCHK(hipMemcpyAsync(dst, pixels, c.frame_bytes - (c.pitch - row), hipMemcpyHostToDevice, ctx->copy_stream[cs]));
   else
     HIPCHK(hipMemcpy2DAsync(dst, c.pitch, pixels, row_step, row, c.intr.height, hipMemcpyHostToDevice,
                             ctx->copy_stream[cs]));
   c.has_image[slot] = true;
+  ctx->copies_pending |= 1u << cs;
+  return M3T_OK;
+}
+// One frame ring for a group of cameras of equal geometry: [slot][camera][frame], so that slot s of the whole group is
+// one contiguous block of device memory and a batch-frame arrives as ONE transfer (m3t_hip_cameras_upload_batch_async).
+int m3t_hip_cameras_set_ring(m3t_hip_context* ctx, const int* ids, int n, int n_slots) {
+  CHECK_CTX();
+  REQUIRE(ids && n >= 1 && n_slots >= 1, M3T_ERR_INVALID_ARGUMENT, "bad arguments");
+  for (int i = 0; i < n; ++i) {
+    REQUIRE(ids[i] >= 0 && ids[i] < int(ctx->cameras.size()), M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+    const Camera& a = *ctx->cameras[ids[0]];
+    const Camera& b = *ctx->cameras[ids[i]];
+    REQUIRE(a.frame_bytes == b.frame_bytes && a.pitch == b.pitch && a.is_depth == b.is_depth, M3T_ERR_INVALID_ARGUMENT,
+            "the cameras of a shared ring must have the same image geometry");
+    for (int j = 0; j < i; ++j) REQUIRE(ids[j] != ids[i], M3T_ERR_INVALID_ARGUMENT, "camera listed twice");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  auto slab = std::make_unique<FrameSlab>();
+  const size_t frame_bytes = ctx->cameras[ids[0]]->frame_bytes;
+  HIPCHK(slab->mem.alloc(frame_bytes * size_t(n) * size_t(n_slots) + 64));
+  slab->cameras.assign(ids, ids + n);
+  const int slab_id = int(ctx->slabs.size());
+  for (int i = 0; i < n; ++i) {
+    Camera& c = *ctx->cameras[ids[i]];
+    c.ring.release();
+    c.slab = slab_id;
+    c.slab_index = i;
+    c.frames = slab->mem.as<uint8_t>() + size_t(i) * frame_bytes;
+    c.slot_stride = frame_bytes * size_t(n);
+    c.n_slots = n_slots;
+    c.current = 0;
+    c.has_image.assign(n_slots, false);
+    c.last_read_step.assign(n_slots, -1);
+  }
+  ctx->slabs.push_back(std::move(slab));
+  ctx->cams_dirty = true;
+  return M3T_OK;
+}
+// The frames of n cameras for one ring slot, frame i at base + i * camera_stride, enqueued from here (what a capture
+// process hands over per batch-frame; replaces n blocking cv::Mat hand-overs, loader_camera.cpp:76-98).  Cameras
+// that share a ring (m3t_hip_cameras_set_ring, listed in its order) and a host block in the ring's layout
+// (camera_stride = height * row_step, row_step = the device pitch) make it ONE linear DMA transfer.
+int m3t_hip_cameras_upload_batch_async(m3t_hip_context* ctx, const int* ids, int n, int slot, const void* base,
+                                       size_t camera_stride, size_t row_step) {
+  CHECK_CTX();
+  REQUIRE(ids && n >= 1 && base, M3T_ERR_INVALID_ARGUMENT, "bad arguments");
+  bool one_block = true;
+  for (int i = 0; i < n; ++i) {
+    REQUIRE(ids[i] >= 0 && ids[i] < int(ctx->cameras.size()), M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+    const Camera& c = *ctx->cameras[ids[i]];
+    REQUIRE(slot >= 0 && slot < c.n_slots, M3T_ERR_INVALID_ARGUMENT, "bad frame slot");
+    const Camera& c0 = *ctx->cameras[ids[0]];
+    if (c.slab < 0 || c.slab != c0.slab || c.slab_index != c0.slab_index + i) one_block = false;
+  }
+  const Camera& c0 = *ctx->cameras[ids[0]];
+  const size_t row = size_t(c0.intr.width) * (c0.is_depth ? 2 : 3);
+  REQUIRE(row_step >= row, M3T_ERR_INVALID_ARGUMENT, "row_step smaller than one image row");
+  if (!(one_block && camera_stride == size_t(c0.intr.height) * row_step)) {
+    for (int i = 0; i < n; ++i) {  // scattered on one side: one transfer per camera, still without a host round trip each
+      int r = m3t_hip_camera_upload_slot_async(ctx, ids[i], slot, static_cast<const uint8_t*>(base) + size_t(i) * camera_stride,
+                                               row_step);
+      if (r) return r;
+    }
+    return M3T_OK;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->async_ingest) {
+    for (auto& cs : ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    for (auto& e : ctx->copies_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : ctx->step_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->async_ingest = true;
+    ctx->untracked_launches = true;
+  }
+  const int cs = 0;
+  long last_read = -1;
+  for (int i = 0; i < n; ++i) last_read = std::max(last_read, ctx->cameras[ids[i]]->last_read_step[slot]);
+  if (ctx->untracked_launches) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->untracked_launches = false;
+  } else if (last_read > ctx->copy_waited_step[cs]) {  // overwrite only after the last step that read this slot
+    HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->step_done[last_read % Ctx::kStepEvents], 0));
+    ctx->copy_waited_step[cs] = last_read;
+  }
+  uint8_t* dst = c0.frame(slot);
+  if (row_step == c0.pitch)
+    HIPCHK(hipMemcpyAsync(dst, base, c0.frame_bytes * size_t(n) - (c0.pitch - row), hipMemcpyHostToDevice,
+                          ctx->copy_stream[cs]));
+  else
+    HIPCHK(hipMemcpy2DAsync(dst, c0.pitch, base, row_step, row, size_t(c0.intr.height) * size_t(n), hipMemcpyHostToDevice,
+                            ctx->copy_stream[cs]));
+  for (int i = 0; i < n; ++i) ctx->cameras[ids[i]]->has_image[slot] = true;
   ctx->copies_pending |= 1u << cs;
   return M3T_OK;
 }
@@ -2326,6 +2464,11 @@ int m3t_hip_calculate_optimization(m3t_hip_context* ctx, int, int, int) {
   HIPCHK(hipSetDevice(ctx->device));
   int r = Prepare(ctx, false);
   if (r) return r;
+  if (ctx->comm) {  // the structures span GPUs: project, ONE all-reduce, solve (every rank the same system)
+    if ((r = m3t_hip_calculate_optimization_begin(ctx, nullptr, nullptr))) return r;
+    if ((r = m3t_hip_calculate_optimization_allreduce(ctx))) return r;
+    return m3t_hip_calculate_optimization_end(ctx);
+  }
   return LaunchOptimization(ctx);
 }
 // Optimizer::CalculateOptimization split at the multi-GPU exchange point: *partial is a
@@ -2353,6 +2496,68 @@ int m3t_hip_calculate_optimization_end(m3t_hip_context* ctx) {
   HIPCHK(hipSetDevice(ctx->device));
   REQUIRE(ctx->partial_ready, M3T_ERR_NOT_SET_UP, "calculate_optimization_begin has to be called first");
   return LaunchSolve(ctx, false);
+}
+// ---- RCCL: the one collective of the path (a kinematic structure spread over GPUs) ----
+#define RCCLCHK(expr)                                                                                      \
+  do {                                                                                                     \
+    ncclResult_t _r = (expr);                                                                              \
+    if (_r != ncclSuccess)                                                                                 \
+      return Fail(ctx, M3T_ERR_DEVICE, std::string(#expr) + ": " +                                         \
+                                           (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "RCCL error")); \
+  } while (0)
+int m3t_hip_comm_get_unique_id(m3t_hip_context* ctx, void* id, size_t bytes) {
+  CHECK_CTX();
+  REQUIRE(id && bytes >= sizeof(ncclUniqueId), M3T_ERR_INVALID_ARGUMENT, "the id buffer must hold 128 bytes");
+  REQUIRE(g_rccl.Load(), M3T_ERR_DEVICE, g_rccl.error);
+  ncclUniqueId u;
+  RCCLCHK(g_rccl.GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof(u));
+  return M3T_OK;
+}
+int m3t_hip_comm_init_rank(m3t_hip_context* ctx, const void* id, size_t bytes, int n_ranks, int rank) {
+  CHECK_CTX();
+  REQUIRE(id && bytes >= sizeof(ncclUniqueId) && n_ranks >= 1 && rank >= 0 && rank < n_ranks, M3T_ERR_INVALID_ARGUMENT,
+          "bad communicator description");
+  REQUIRE(g_rccl.Load(), M3T_ERR_DEVICE, g_rccl.error);
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->comm && ctx->comm_owned) RCCLCHK(g_rccl.CommDestroy(ctx->comm));
+  ctx->comm = nullptr;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  ncclComm_t comm = nullptr;
+  RCCLCHK(g_rccl.CommInitRank(&comm, n_ranks, u, rank));
+  ctx->comm = comm;
+  ctx->comm_owned = true;
+  return M3T_OK;
+}
+int m3t_hip_comm_set(m3t_hip_context* ctx, void* nccl_comm) {
+  CHECK_CTX();
+  REQUIRE(nccl_comm == nullptr || g_rccl.Load(), M3T_ERR_DEVICE, g_rccl.error);
+  if (ctx->comm && ctx->comm_owned) RCCLCHK(g_rccl.CommDestroy(ctx->comm));
+  ctx->comm = static_cast<ncclComm_t>(nccl_comm);
+  ctx->comm_owned = false;
+  return M3T_OK;
+}
+int m3t_hip_comm_destroy(m3t_hip_context* ctx) {
+  CHECK_CTX();
+  if (ctx->comm && ctx->comm_owned) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    RCCLCHK(g_rccl.CommDestroy(ctx->comm));
+  }
+  ctx->comm = nullptr;
+  ctx->comm_owned = false;
+  return M3T_OK;
+}
+// sum of the stacked [dof x dof | dof] buffers of all structures over the ranks of the communicator: ONE
+// ncclAllReduce on the context's stream, in place (optimizer.cpp:309-321 is the sum being distributed)
+int m3t_hip_calculate_optimization_allreduce(m3t_hip_context* ctx) {
+  CHECK_CTX();
+  REQUIRE(ctx->partial_ready, M3T_ERR_NOT_SET_UP, "calculate_optimization_begin has to be called first");
+  REQUIRE(ctx->comm != nullptr, M3T_ERR_NOT_SET_UP, "no communicator: m3t_hip_comm_init_rank / m3t_hip_comm_set first");
+  HIPCHK(hipSetDevice(ctx->device));
+  float* buffer = ctx->d_partial.as<float>();
+  RCCLCHK(g_rccl.AllReduce(buffer, buffer, ctx->partial_count, ncclFloat, ncclSum, ctx->comm, ctx->stream));
+  return M3T_OK;
 }
 // Tracker::CalculateConsistentPoses tracker.cpp:423 -> Optimizer::CalculateConsistentPoses optimizer.cpp:135
 int m3t_hip_calculate_consistent_poses(m3t_hip_context* ctx) {
@@ -2395,19 +2600,29 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // One workgroup per CU: the histogram update (CalculateResults) runs at the end of the same launch, its
     // count table taking over the line buffers' LDS.  With two workgroups per CU that table (128 KB at 32 bins)
     // would not fit twice, so large batches keep the separate region_histogram_kernel.
-    histogram_fused = ctx->fuse_histogram_possible && threads == M3T_BLOCK_THREADS && !std::getenv("M3T_HIP_NO_FUSED_HISTOGRAM");
+    const bool want_fused_histogram = ctx->fuse_histogram_possible && !std::getenv("M3T_HIP_NO_FUSED_HISTOGRAM");
+    histogram_fused = want_fused_histogram && threads == M3T_BLOCK_THREADS;
     const size_t lds = histogram_fused ? std::max(ctx->lds_track, ctx->lds_hist) : ctx->lds_track;
     // Batches that leave CUs idle: several workgroups per object, each on its own CU (all resident at once, which
     // their in-kernel exchange needs; a wait that runs out abandons the object's step, see CheckSplitExchange).
     // parts x padded elements per part = 256 (the collecting threads of split_exchange_state).
     int parts = 0;
+    const size_t lds_tracking = size_t(ctx->layout.off_hist >= 0 ? ctx->layout.off_hist : ctx->layout.total_floats) * 4;
+    // (each workgroup counts its share of the histogram bins: that share of the count table; the pair table is
+    // read from L2, never staged)
+    auto lds_split_for = [&](int p) {
+      return want_fused_histogram ? std::max(lds_tracking, M3T_MISC_FLOATS * 4 + (ctx->lds_hist - M3T_MISC_FLOATS * 4) / p)
+                                  : lds_tracking;
+    };
     if (ctx->split_possible && ctx->split_enabled && threads % M3T_SPLIT_LANES == 0 &&
         ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT")) {
       int limit = ctx->split_parts_override > 1 ? ctx->split_parts_override : 8;
       if (const char* e = std::getenv("M3T_HIP_SPLIT_PARTS")) limit = std::atoi(e);  // developer override
       const int elements = std::max(ctx->layout.nl, ctx->depth_mods.empty() ? 1 : ctx->np_max);
       for (int p = M3T_SPLIT_MAX_PARTS; p >= 2; p >>= 1) {
-        if (p > limit || n * p > ctx->prop.multiProcessorCount) continue;
+        // 256-thread workgroups (developer override): two are resident per CU if their LDS fits twice
+        const int per_cu = (threads == M3T_SPLIT_LANES && lds_split_for(p) * 2 <= size_t(160) * 1024) ? 2 : 1;
+        if (p > limit || n * p > ctx->prop.multiProcessorCount * per_cu) continue;
         if ((elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;  // a part's elements fit its share of the lanes
         parts = p;
         break;
@@ -2445,12 +2660,8 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       while ((parts << sp.lshift) < M3T_SPLIT_LANES) ++sp.lshift;
       sp.per_part_lines = (ctx->layout.nl + parts - 1) / parts;
       sp.per_part_points = (ctx->np_max + parts - 1) / parts;
-      // (each workgroup counts its share of the histogram bins: that share of the count table; the pair table is
-      // read from L2, never staged)
-      const size_t lds_tracking = size_t(ctx->layout.off_hist >= 0 ? ctx->layout.off_hist : ctx->layout.total_floats) * 4;
-      const size_t lds_split = histogram_fused
-          ? std::max(lds_tracking, M3T_MISC_FLOATS * 4 + (ctx->lds_hist - M3T_MISC_FLOATS * 4) / parts)
-          : lds_tracking;
+      histogram_fused = want_fused_histogram;
+      const size_t lds_split = lds_split_for(parts);
       hipLaunchKernelGGL(tracking_step_split_kernel, dim3(n * parts), dim3(threads), lds_split, ctx->stream,
                          ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                          ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
@@ -2561,9 +2772,9 @@ int m3t_hip_get_kernel_timing(m3t_hip_context* ctx, float total_ms[2], int launc
 int m3t_hip_debug_phase_cycles(m3t_hip_context* ctx, unsigned long long* out24, int reset) {
   CHECK_CTX();
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_phase_cycles), 24 * sizeof(unsigned long long)));
+  HIPCHK(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_phase_cycles), 32 * sizeof(unsigned long long)));
   if (reset) {
-    unsigned long long z[24] = {0};
+    unsigned long long z[32] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
   }
   return M3T_OK;

@@ -29,7 +29,7 @@
 
 #ifdef M3T_PHASE_TIMING
 // developer instrumentation: accumulated s_memtime cycles per phase, block 0 thread 0
-__device__ unsigned long long g_phase_cycles[24];
+__device__ unsigned long long g_phase_cycles[32];
 #define PHASE_T0() unsigned long long _pt = clock64()
 #define PHASE_MARK(i)                                                         \
   do {                                                                        \
@@ -506,10 +506,13 @@ __device__ __forceinline__ void chain_fill(float* chain, float x, float step, in
   }
 }
 
-template <int SCALE, typename HistPtr>
+// BMAX caps the batch: a workgroup that walks only its share of an object's lines (tracking_step_split_kernel) has
+// one or two items per thread, a batch of 8 would be mostly empty slots.
+template <int SCALE, int BMAX, typename HistPtr>
 __device__ __forceinline__ void region_segments(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist,
                                                 int n_lines, int valid_mask, const Lds& s, int line_lo) {
-  constexpr int B = SCALE >= 8 ? 2 : (SCALE >= 6 ? 3 : (SCALE >= 4 ? 4 : (SCALE == 3 ? 6 : 8)));  // <= 20 pixels in flight
+  constexpr int B0 = SCALE >= 8 ? 2 : (SCALE >= 6 ? 3 : (SCALE >= 4 ? 4 : (SCALE == 3 ? 6 : 8)));  // <= 20 pixels in flight
+  constexpr int B = B0 < BMAX ? B0 : BMAX;
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
   const int bin_bits = 8 - m.bitshift;  // n_bins == 1 << bin_bits
   const int bitshift = m.bitshift;
@@ -576,7 +579,7 @@ __device__ __forceinline__ void region_segments(CRegion& m, G<uint8_t> image, ui
     for (int b = 0; b < B; ++b)
 #pragma unroll
       for (int j = 0; j < SCALE; ++j) {
-        uint32_t v = px[b][j];
+          uint32_t v = px[b][j];
         // (B >> s) * n^2 + (G >> s) * n + (R >> s) with n = 2^bin_bits (color_histograms.cpp:97-99)
         uint32_t idx = ((((v & 0xffu) >> bitshift) << bin_bits | ((v >> 8) & 0xffu) >> bitshift) << bin_bits) |
                        (((v >> 16) & 0xffu) >> bitshift);
@@ -659,20 +662,20 @@ __device__ void region_segments_generic(CRegion& m, G<uint8_t> image, uint32_t p
   }
 }
 
-template <typename HistPtr>
+template <int BMAX, typename HistPtr>
 __device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist,
                                                          int scale, int n_lines, int valid_mask, const Lds& s,
                                                          int line_lo) {
   switch (scale) {
-    case 1: region_segments<1>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
-    case 2: region_segments<2>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
-    case 3: region_segments<3>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
-    case 4: region_segments<4>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
-    case 5: region_segments<5>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
-    case 6: region_segments<6>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
-    case 7: region_segments<7>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
-    case 8: region_segments<8>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
-    case 9: region_segments<9>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 1: region_segments<1, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 2: region_segments<2, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 3: region_segments<3, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 4: region_segments<4, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 5: region_segments<5, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 6: region_segments<6, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 7: region_segments<7, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 8: region_segments<8, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 9: region_segments<9, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
     default: region_segments_generic(m, image, pitch, hist, n_lines, valid_mask, scale, s, line_lo); break;
   }
 }
@@ -687,7 +690,7 @@ __device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> 
 // Phase C  one thread per (line, d): CalculateDistribution :1600 products; then one
 //          thread per line: normalisation + CalculateDistributionMoments :1639.
 // ---------------------------------------------------------------------------
-template <bool HIST_LDS>
+template <bool HIST_LDS, int BMAX = 8>
 __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                        const Affine& b2dc, int iteration, int corr_iteration,
                                                        const Lds& s, int line_lo = 0, int line_hi = 1 << 30) {
@@ -839,9 +842,9 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   const int n_lines_b = n_lines < line_hi ? n_lines : line_hi;
   const int nl_b = nl < line_hi ? nl : line_hi;
   if (HIST_LDS) {  // pair table staged in LDS (n_bins <= 16)
-    region_segments_dispatch(m, image, pitch, (LdsF)s.hist, it.scale, n_lines_b, valid_mask, s, line_lo);
+    region_segments_dispatch<BMAX>(m, image, pitch, (LdsF)s.hist, it.scale, n_lines_b, valid_mask, s, line_lo);
   } else {         // pair table gathered from L2 / HBM
-    region_segments_dispatch(m, image, pitch, (G<v2f>)m.histogram_norm, it.scale, n_lines_b, valid_mask, s, line_lo);
+    region_segments_dispatch<BMAX>(m, image, pitch, (G<v2f>)m.histogram_norm, it.scale, n_lines_b, valid_mask, s, line_lo);
   }
   __syncthreads();
   PHASE_MARK(2);
@@ -896,21 +899,38 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   }
   __syncthreads();
   PHASE_MARK(3);
-  // ---- phase C2: normalisation, one thread per line (the moments follow in region_moments) ----
-  // (the final flag is set for the lines of all parts: it follows from phase A, which every workgroup ran in full)
-  for (int line = tid; line < nl; line += nt) {
-    int flags = f2i_bits(s.state[LS_VALID * nl + line]);
-    bool valid = (flags & valid_mask) != 0;
-    if (valid && line >= line_lo && line < nl_b) {
-      const float* r = raw + line * s.ns;
-      float area = 0.0f;
-      for (int d = 0; d < dl; ++d) area += r[d];
-#pragma unroll
-      for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d)
-        if (d < dl) s.state[(LS_DIST0 + d) * nl + line] = r[d] / area;
+  // ---- phase C2: normalisation, one thread per (line, d): every thread adds up the line's raw values in the
+  // reference's order (the same area in all of them) and divides its own (the moments follow in region_moments) ----
+  {
+    const int q = nt / dl, r = nt - q * dl;
+    int line = tid / dl, d = tid - line * dl;
+    line += line_lo;
+    const int n_items_c = (n_lines_b - line_lo) * dl;
+    for (int item = tid; item < n_items_c; item += nt) {
+      const int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+      if (flags & valid_mask) {
+        const float* rr = raw + line * s.ns;
+        float area = 0.0f;
+        if (dl == 12) {  // the default distribution length: independent LDS reads, then the ordered sum
+          const float v0 = rr[0], v1 = rr[1], v2 = rr[2], v3 = rr[3], v4 = rr[4], v5 = rr[5], v6 = rr[6], v7 = rr[7],
+                      v8 = rr[8], v9 = rr[9], v10 = rr[10], v11 = rr[11];
+          area += v0; area += v1; area += v2; area += v3; area += v4; area += v5;
+          area += v6; area += v7; area += v8; area += v9; area += v10; area += v11;
+        } else {
+          for (int k = 0; k < dl; ++k) area += rr[k];
+        }
+        s.state[(LS_DIST0 + d) * nl + line] = rr[d] / area;
+      }
+      line += q;
+      d += r;
+      if (d >= dl) { d -= dl; ++line; }
     }
-    // final flag: bit0 = line is in data_lines_
-    s.state[LS_VALID * nl + line] = i2f_bits((flags & ~1) | (valid ? 1 : 0));
+  }
+  // the final flag (bit 0 = line is in data_lines_), for the lines of all parts: it follows from phase A, which every
+  // workgroup ran in full.  (Threads above may still test `flags & valid_mask`: bit 0 only ever takes that test's value.)
+  for (int line = tid; line < nl; line += nt) {
+    const int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+    s.state[LS_VALID * nl + line] = i2f_bits((flags & ~1) | ((flags & valid_mask) ? 1 : 0));
   }
   __syncthreads();
   PHASE_MARK(4);
@@ -956,7 +976,7 @@ __device__ void region_moments(CRegion& m, const Lds& s) {
 // started at +0 never holds -0).  Rows: r < 6: the gradient entry r; 6 + c*6 - c*(c-1)/2 + (r - c): H(r, c), r >= c.
 // Every row stores what is to be SUBTRACTED from the running sum (the region gradient is negated: a - (-b) = a + b).
 // ---------------------------------------------------------------------------
-constexpr int kChainBlock = 12;  // lines per pipeline step of the chain (3 x ds_read_b128)
+constexpr int kChainBlock = 24;  // lines per pipeline step of a single chain (6 x ds_read_b128, the next 6 in flight)
 
 __host__ __device__ inline int chain_slots(int n) { return (n + kChainBlock - 1) / kChainBlock * kChainBlock; }
 // row pitch in floats: a multiple of 4 with an odd quarter, so that 16 lanes reading 16 bytes of 16 rows hit 64 banks
@@ -973,54 +993,66 @@ __device__ __forceinline__ int gh_lane_row(int lane) {  // lane < 42 of the grad
 }
 
 typedef const __attribute__((address_space(3))) v4f* LdsV4;
-#define M3T_CHAIN_STEP(S, A0, A1, A2)                                             \
-  S -= A0.x; S -= A0.y; S -= A0.z; S -= A0.w; S -= A1.x; S -= A1.y; S -= A1.z;    \
-  S -= A1.w; S -= A2.x; S -= A2.y; S -= A2.z; S -= A2.w;
+// one dependent subtraction per line; Q quads (4 lines each) per step, the next step's quads already in flight
+template <int Q>
+__device__ __forceinline__ float chain_walk(LdsV4 p, int n_quads, float s) {
+  v4f cur[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) cur[i] = p[i];
+  for (int q = 0; q < n_quads; q += Q) {
+    const int nq = q + Q < n_quads ? q + Q : q;  // the last step re-reads its own quads (harmless)
+    v4f nxt[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) nxt[i] = p[nq + i];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      s -= cur[i].x;
+      s -= cur[i].y;
+      s -= cur[i].z;
+      s -= cur[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) cur[i] = nxt[i];
+  }
+  return s;
+}
+// two chains at once (two independent dependency chains interleave for free), 3 quads each per step
+__device__ __forceinline__ void chain_walk2(LdsV4 pa, LdsV4 pb, int n_quads, float& sa, float& sb) {
+  constexpr int Q = 3;
+  v4f ca[Q], cb[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) { ca[i] = pa[i]; cb[i] = pb[i]; }
+  for (int q = 0; q < n_quads; q += Q) {
+    const int nq = q + Q < n_quads ? q + Q : q;
+    v4f na[Q], nb[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { na[i] = pa[nq + i]; nb[i] = pb[nq + i]; }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      sa -= ca[i].x; sb -= cb[i].x;
+      sa -= ca[i].y; sb -= cb[i].y;
+      sa -= ca[i].z; sb -= cb[i].z;
+      sa -= ca[i].w; sb -= cb[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+  }
+}
 
-// lanes < 42 of the calling wave; rows_a / rows_b: product tables of up to two modalities (either may be null),
-// walked together: two independent dependent chains interleave for free
+// lanes < 42 of the calling wave; rows_a / rows_b: product tables of up to two modalities (either may be null)
 __device__ __forceinline__ void chain_sums(const float* rows_a, int pitch_a, int slots_a, const float* rows_b,
                                            int pitch_b, int slots_b, int row, float& sum_a, float& sum_b) {
   float sa = 0.0f, sb = 0.0f;
-  const int na = rows_a ? slots_a / kChainBlock : 0, nb = rows_b ? slots_b / kChainBlock : 0;
-  const int common = na < nb ? na : nb;
+  const int qa = rows_a ? slots_a / 4 : 0, qb = rows_b ? slots_b / 4 : 0;  // multiples of 6
   LdsV4 pa = (LdsV4)(rows_a ? rows_a + row * pitch_a : nullptr);
   LdsV4 pb = (LdsV4)(rows_b ? rows_b + row * pitch_b : nullptr);
-  int blk = 0;
-  if (common > 0) {
-    v4f a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-    for (; blk < common; ++blk) {
-      const int nx = blk + 1 < common ? blk + 1 : blk;
-      const v4f n0 = pa[3 * nx], n1 = pa[3 * nx + 1], n2 = pa[3 * nx + 2];
-      const v4f m0 = pb[3 * nx], m1 = pb[3 * nx + 1], m2 = pb[3 * nx + 2];
-      M3T_CHAIN_STEP(sa, a0, a1, a2)
-      M3T_CHAIN_STEP(sb, b0, b1, b2)
-      a0 = n0; a1 = n1; a2 = n2; b0 = m0; b1 = m1; b2 = m2;
-    }
-  }
-  if (blk < na) {
-    v4f a0 = pa[3 * blk], a1 = pa[3 * blk + 1], a2 = pa[3 * blk + 2];
-    for (; blk < na; ++blk) {
-      const int nx = blk + 1 < na ? blk + 1 : blk;
-      const v4f n0 = pa[3 * nx], n1 = pa[3 * nx + 1], n2 = pa[3 * nx + 2];
-      M3T_CHAIN_STEP(sa, a0, a1, a2)
-      a0 = n0; a1 = n1; a2 = n2;
-    }
-  }
-  blk = common;
-  if (blk < nb) {
-    v4f b0 = pb[3 * blk], b1 = pb[3 * blk + 1], b2 = pb[3 * blk + 2];
-    for (; blk < nb; ++blk) {
-      const int nx = blk + 1 < nb ? blk + 1 : blk;
-      const v4f m0 = pb[3 * nx], m1 = pb[3 * nx + 1], m2 = pb[3 * nx + 2];
-      M3T_CHAIN_STEP(sb, b0, b1, b2)
-      b0 = m0; b1 = m1; b2 = m2;
-    }
-  }
+  const int common = qa < qb ? qa : qb;
+  if (common > 0) chain_walk2(pa, pb, common, sa, sb);
+  if (qa > common) sa = chain_walk<6>(pa + common, qa - common, sa);
+  if (qb > common) sb = chain_walk<6>(pb + common, qb - common, sb);
   sum_a = sa;
   sum_b = sb;
 }
-#undef M3T_CHAIN_STEP
 
 // ---------------------------------------------------------------------------
 // RegionModality::CalculateGradientAndHessian (:485-558), the per-line part: one thread per line slot
@@ -2510,7 +2542,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_correspondences<HIST_LDS>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, line_lo, line_hi);
+        region_correspondences<HIST_LDS, SPLIT ? 2 : 8>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, line_lo, line_hi);
       }
       if (dm) {
         PHASE_T0();
@@ -2523,8 +2555,12 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         if (!split_exchange_state(exchange, c, s, rm != nullptr, ps, np, dm != nullptr)) return;
         PHASE_MARK(22);
       }
-      if (rm) region_moments(*rm, s);
-      if (dm) depth_correspondences_vote(*dm, iteration, ps, np, s.misc);
+      {
+        PHASE_T0();
+        if (rm) region_moments(*rm, s);
+        if (dm) depth_correspondences_vote(*dm, iteration, ps, np, s.misc);
+        PHASE_MARK(25);
+      }
     }
     for (int u = 0; u < n_update_iterations; ++u) {
       PHASE_T0();
@@ -2538,7 +2574,9 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         depth_products(*dm, b2c, c, ps, np, rows_d, layout.pitch_d);
       }
       __syncthreads();
-      PHASE_MARK(5);
+#ifdef M3T_PHASE_TIMING
+      if (u == 0) { PHASE_MARK(5); } else { PHASE_MARK(24); }
+#endif
       if (threadIdx.x < kWave) {  // one wave: the sums in the reference's order, Link sum, solve, pose update
         float sum_r = 0.0f, sum_d = 0.0f;
         chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
@@ -2576,6 +2614,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       if (threadIdx.x < 42) dm->gradient_hessian[threadIdx.x] = gh_depth[threadIdx.x];
     }
   }
+  PHASE_T0();
   if (fuse_histogram && rm) {
     // RegionModality::CalculateResults :572-583 in the same launch: the packed count table takes over the LDS
     // of the line buffers (misc block first, as in region_histogram_kernel)
@@ -2593,6 +2632,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
                             (__attribute__((address_space(3))) uint32_t*)(lds_t + M3T_MISC_FLOATS), lds_t, bin_lo,
                             bin_hi);
   }
+  PHASE_MARK(26);
 }
 
 }  // extern "C++"

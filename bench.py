@@ -1,15 +1,21 @@
 #!/usr/bin/env python
 """bench.py — pose-updates/s of the M3T per-frame pose-optimisation hot path on MI355X.
 
-One "step" = Tracker::ExecuteTrackingStep (7 correspondence iterations x 2 Newton updates +
-histogram update, RBOT parameters, 200 lines) for every object of the batch on the next
-synthetic 640x512 frame.  Workload at every N: 64 batched RBOT-geometry objects PER GPU
-(BASELINE.json configs[1]); objects are independent, so ranks share nothing on the data
-path (weak scaling, no collective).  Frames, models and histograms are resident in HBM
-before the timed region starts (the reference's evaluators also exclude image loading,
-rbot_evaluator.cpp:354-414).
+One "step" = Tracker::ExecuteTrackingStep (the whole loop nest of correspondence iterations x Newton updates +
+histogram update) for every object of the batch on the next synthetic frame.  Configurations (BASELINE.json):
 
-Prints ONE JSON line on rank 0 (see DESIGN.md §6 for the roofline and cpu_baseline legs).
+  --config rbot64   (default, configs[1]) 64 batched RBOT-geometry objects PER GPU, RegionModality, 200 lines x 7 x 2,
+                    640x512 BGR8, 32 bins.  Objects are independent: ranks share nothing on the data path (weak scaling).
+  --config ycb21    (configs[2]) 21 objects, Region + Depth fused modalities, YCB parameters, 640x480.
+  --config synth512 (configs[3]) 512 synthetic objects (random sparse viewpoint models), Region + Depth, sharded
+                    over the GPUs (strong scaling: 512 / N objects per GPU).
+  --config chain8   (configs[4]) kinematic chain of 8 bodies / 13 dof tracked by 8 RegionModalities, the structure's
+                    joint Hessian summed over the GPUs with ONE all-reduce per Newton step; plus the sweep over
+                    1..50 bodies of examples/optimization_time.cpp.
+
+Frames, models and histograms are resident in HBM before the timed region starts (the reference's evaluators also
+exclude image loading, rbot_evaluator.cpp:354-414).  Prints ONE JSON line on rank 0 (roofline,
+cpu_baseline and parity blocks).
 """
 import argparse
 import ctypes as C
@@ -35,7 +41,30 @@ B_HIST_PIXELS = 200 * 40 * 3
 B_POSE = 64
 B_ALG = B_PIXELS + B_HIST_READ + B_VIEW_SCAN + B_VIEW_POINTS + B_HIST_RMW + B_HIST_PIXELS + B_POSE  # 1 386 704
 B_ALG_TRACK_KERNEL = B_PIXELS + B_HIST_READ + B_VIEW_SCAN + B_VIEW_POINTS + B_POSE  # fused tracking kernel only
+# Region + Depth with measured occlusions, YCB parameters (16 bins, 4 correspondence iterations)
+B_ALG_YCB = 1094456
+B_ALG_YCB_HIST = 65536 + 24000 + 122976 // 4 + 121600 // 4  # the histogram update's share when it is a launch of its own
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+CONFIGS = {
+    "rbot64": dict(metric="pose-updates/sec (64 objects, 200 lines, 7 it)", scaling="weak", with_depth=False,
+                   objects=64, models=8, alg=B_ALG, alg_track=B_ALG_TRACK_KERNEL, newton=14,
+                   workload="BASELINE configs[1]: %(n)d batched RBOT-geometry objects per GPU, RegionModality only, "
+                            "200 lines x 7 corr-iterations x 2 updates, 640x512 BGR8, 32-bin histograms, "
+                            "%(views)d views x 200 points models (%(models)d distinct)"),
+    "ycb21": dict(metric="pose-updates/sec (YCB-Video scene, 21 objects, Region+Depth)", scaling="strong",
+                  with_depth=True, objects=21, models=6, alg=B_ALG_YCB, alg_track=B_ALG_YCB - B_ALG_YCB_HIST, newton=8,
+                  workload="BASELINE configs[2]: %(n)d objects in one scene, Region + Depth fused modalities (ICG), YCB "
+                           "parameters (scales 7/4/2, 16 bins, measured occlusions, 4 corr-iterations x 2 updates), "
+                           "640x480 BGR8 + u16 depth, %(views)d views x 200 points models (%(models)d distinct)"),
+    "synth512": dict(metric="pose-updates/sec (512 synthetic objects, Region+Depth)", scaling="strong",
+                     with_depth=True, objects=512, models=16, alg=B_ALG_YCB, alg_track=B_ALG_YCB - B_ALG_YCB_HIST,
+                     newton=8,
+                     workload="BASELINE configs[3]: %(n)d synthetic objects on this GPU (512 over all GPUs; random "
+                              "star-shaped bodies, %(models)d distinct sparse viewpoint models of %(views)d views x 200 "
+                              "points), Region + Depth, YCB parameters, every object its own 640x480 frame ring "
+                              "(64 distinct rendered streams)"),
+}
 
 
 def parse():
@@ -43,20 +72,47 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--objects", type=int, default=64, help="objects per GPU")
-    p.add_argument("--models", type=int, default=8, help="distinct sparse viewpoint models per GPU")
+    p.add_argument("--config", default="rbot64", choices=sorted(CONFIGS) + ["chain8"])
+    p.add_argument("--objects", type=int, default=0, help="objects (per GPU for rbot64, in total otherwise); 0 = the config's")
+    p.add_argument("--models", type=int, default=0, help="distinct sparse viewpoint models; 0 = the config's")
     p.add_argument("--n-divides", type=int, default=4, help="geodesic subdivisions (4 -> 2562 views)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (1 thread)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-cpu-parallel", action="store_true", help="skip the all-cores (OpenMP) CPU leg")
     p.add_argument("--repeats", type=int, default=5, help="how often the timed region of K steps is repeated")
+    p.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) legs")
     p.add_argument("--sweep", type=str, default="", help="comma separated object counts for a batch sweep (extra)")
     p.add_argument("--extras", action="store_true",
                    help="extra legs (never the headline): model generation without OpenGL and a tracking step with "
                         "all renderer-fed branches, on the reference's own test fixture")
-    p.add_argument("--ycb", type=int, default=0,
-                   help="extra leg: N objects with Region+Depth fused modalities, YCB parameters (BASELINE configs[2])")
     return p.parse_args()
+
+
+def replicate(scenes, inputs, n_obj):
+    """n_obj objects over the rendered streams of `inputs` (object i looks at stream i mod n_streams through its OWN
+    camera and frame ring: distinct device memory, identical content)"""
+    if n_obj == inputs.n_objects:
+        return inputs
+    rep = scenes.Inputs.__new__(scenes.Inputs)
+    rep.__dict__.update(inputs.__dict__)
+    idx = [i % inputs.n_objects for i in range(n_obj)]
+    rep.n_objects = n_obj
+    for name in ("scenes", "model_of", "gt", "color", "depth", "start", "vertices"):
+        rep.__dict__[name] = [inputs.__dict__[name][i] for i in idx]
+    return rep
+
+
+def stage_frames(hip, inst, inputs, n_frames):
+    for cams, frames in ((inst.color_cams, inputs.color), (inst.depth_cams, inputs.depth)):
+        done = set()
+        for i, cam in enumerate(cams):
+            if cam is None or cam.id in done:
+                continue
+            done.add(cam.id)
+            hip.call("camera_set_ring", cam.id, n_frames)
+            for k in range(n_frames):
+                f = frames[i][k]
+                hip.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
 
 
 def main():
@@ -71,27 +127,44 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    n_gpus = world
 
     pkg = importlib.import_module("3dobjecttracking_amd")
     import scenes
+    if args.config == "chain8":
+        import bench_chain
+        out = bench_chain.run(args, pkg, rank, local_rank, world, dist, torch)
+    else:
+        out = run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
+    cfg = CONFIGS[args.config]
     syn = pkg.synthetic
     hip = pkg.open_context(local_rank)
-
-    n_obj, K, W = args.objects, args.steps, args.warmup
+    K, W = args.steps, args.warmup
     n_frames = K + W + 1
+    use_depth = cfg["with_depth"]
     t0 = time.time()
-    # weak scaling: rank r owns the global objects [r * n_obj, (r + 1) * n_obj)
-    my_objects = pkg.sharding.shard_objects(n_obj * world, rank, world, mode="block")
-    inputs = scenes.Inputs(n_obj, n_frames, n_divides=args.n_divides, n_models=min(args.models, n_obj),
-                           first_object=int(my_objects[0]))
-    inst = scenes.Instance(hip, inputs)
-    for cam in inst.color_cams:
-        hip.call("camera_set_ring", cam.id, n_frames)
-    for i, cam in enumerate(inst.color_cams):
-        for k in range(n_frames):
-            f = inputs.color[i][k]
-            hip.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+    total_objects = args.objects or cfg["objects"]
+    if cfg["scaling"] == "weak":  # rank r owns the global objects [r * n, (r + 1) * n)
+        n_obj = total_objects
+        first = int(pkg.sharding.shard_objects(n_obj * world, rank, world, mode="block")[0])
+        total_objects = n_obj * world
+    else:                         # fixed total, object i -> GPU i mod G
+        mine = pkg.sharding.shard_objects(total_objects, rank, world, mode="round_robin")
+        n_obj, first = len(mine), 0
+    n_streams = min(n_obj, 64)
+    n_models = min(args.models or cfg["models"], n_streams)
+    base = scenes.Inputs(n_streams, n_frames, n_divides=args.n_divides, n_models=n_models, with_depth=use_depth,
+                         first_object=first + (rank * 1000 if cfg["scaling"] == "strong" else 0))
+    inputs = replicate(scenes, base, n_obj)
+    inst = scenes.Instance(hip, inputs, use_depth=use_depth)
+    stage_frames(hip, inst, inputs, n_frames)
     setup_s = time.time() - t0
 
     def barrier():
@@ -101,10 +174,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(first, count):
-        for k in range(first, first + count):
+    def run(first_frame, count):
+        for k in range(first_frame, first_frame + count):
             hip.call("cameras_select_slot", k)
             hip.call("execute_tracking_step", k)
+
+    def get_poses():
+        poses = np.zeros((n_obj, 16), np.float32)
+        hip.call("bodies_get_poses", poses.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+        return poses
 
     hip.call("cameras_select_slot", 0)
     hip.call("start_modalities", 0)
@@ -113,10 +191,8 @@ def main():
     t = time.perf_counter()
     run(1 + W, K)
     barrier()
-    elapsed = time.perf_counter() - t
-    elapsed = pkg.sharding.max_over_ranks(elapsed, dist, device="cuda")
-    poses = np.zeros((n_obj, 16), np.float32)
-    hip.call("bodies_get_poses", poses.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+    elapsed = pkg.sharding.max_over_ranks(time.perf_counter() - t, dist, device="cuda")
+    poses = get_poses()
     # the same K steps again, args.repeats - 1 more times (restarted from the ground-truth pose of frame W; the
     # trajectory checked below is the first one): min / median of the timed region, MAX over ranks each
     times = [elapsed]
@@ -129,16 +205,17 @@ def main():
         barrier()
         times.append(pkg.sharding.max_over_ranks(time.perf_counter() - t, dist, device="cuda"))
     elapsed = float(np.median(times))
-    tracked = 0
+    tracked, adds_gt = 0, []
     for i in range(n_obj):
         e = syn.pose_errors(poses[i].reshape(4, 4).T, inputs.gt[i][W + K])
         tracked += int(e[0] < np.deg2rad(5) and e[1] < 0.05)  # rbot_evaluator.cpp:416-433
+        if i < 64:
+            adds_gt.append(syn.add_s(inputs.vertices[i], poses[i].reshape(4, 4).T, inputs.gt[i][W + K]))
 
     # ---- roofline leg: HIP events around the kernels on the context stream (rank 0) ----
     roofline = None
     if rank == 0:
-        hip.call("bodies_set_poses", np.stack([np.ascontiguousarray(inputs.gt[i][W].T, np.float32).reshape(16)
-                                               for i in range(n_obj)]).ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+        hip.call("bodies_set_poses", restart.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
         hip.call("set_kernel_timing", 1)
         run(1 + W, K)
         ms = (C.c_float * 2)()
@@ -147,13 +224,14 @@ def main():
         hip.call("set_kernel_timing", 0)
         shape = (C.c_int * 4)()
         hip.call("get_step_shape", shape)  # objects, workgroups per object, threads, histogram update fused
-        kernel = "tracking_step_split_kernel" if shape[1] > 1 else "tracking_step_kernel"
+        kernel = "tracking_step_split_kernel" if shape[1] > 1 else (
+            "tracking_step_lds_kernel" if use_depth else "tracking_step_kernel")
         track_ms = ms[0] / max(cnt[0], 1)
-        fused_hist = cnt[1] == 0  # the histogram update rode in the tracking launch (one workgroup per CU)
+        fused_hist = cnt[1] == 0  # the histogram update rode in the tracking launch
         hist_ms = ms[1] / max(cnt[1], 1)
-        alg = B_ALG if fused_hist else B_ALG_TRACK_KERNEL
+        alg = cfg["alg"] if fused_hist else cfg["alg_track"]
         achieved = alg * n_obj / (track_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(kernel, n_obj, fused_hist)
+        traffic, traffic_src = measured_traffic(args.config, kernel, n_obj, fused_hist)
         roofline = {"bound": "hbm",
                     "kernel": kernel + (" (whole step incl. histogram update)" if fused_hist else ""),
                     "workgroups_per_object": shape[1], "threads_per_workgroup": shape[2],
@@ -162,66 +240,20 @@ def main():
                     "kernel_ms": round(track_ms, 4), "algorithmic_bytes_per_launch": alg * n_obj}
         if not fused_hist:
             roofline["histogram_kernel_ms"] = round(hist_ms, 4)
-            roofline["histogram_kernel_GBs"] = round((B_HIST_RMW + B_HIST_PIXELS + B_VIEW_SCAN // 7 + B_VIEW_POINTS // 7) *
-                                                     n_obj / (hist_ms * 1e-3) / 1e9, 2)
 
-    # ---- host-buffer (PCIe-inclusive) rate: every step first uploads its 64 frames from host memory
-    # through m3t_hip_camera_upload (the boundary's Camera::UpdateImage); never the headline value ----
+    # ---- host-buffer (PCIe-inclusive) rate: every step first receives its frames from host memory; never `value` ----
     pcie = None
-    if rank == 0 and world == 1:
-        n_up = max(1, min(5, K - 1))  # the asynchronous leg stages one frame ahead
-        hip.call("cameras_select_slot", 0)
-        hip.call("sync")
-        tu = time.perf_counter()
-        for k in range(1 + W, 1 + W + n_up):
-            for i, cam in enumerate(inst.color_cams):
-                f = inputs.color[i][k]
-                hip.call("camera_upload", cam.id, f.ctypes.data_as(C.c_void_p), f.strides[0])
-            hip.call("execute_tracking_step", k)
-        hip.call("sync")
-        el = time.perf_counter() - tu
-        frame_bytes = sum(inputs.color[i][0].nbytes for i in range(n_obj))
-        pcie = {"pose_updates_per_s": round(n_obj * n_up / el, 1), "ms_per_step": round(el / n_up * 1e3, 3),
-                "host_bytes_per_step": frame_bytes, "upload_GBs": round(frame_bytes * n_up / el / 1e9, 2),
-                "note": "pageable host frames, synchronous m3t_hip_camera_upload per camera, then the step"}
-        # the same with page-locked frames and the double-buffered asynchronous ingest: frame k+1 crosses
-        # PCIe on the copy stream while step k runs (m3t_hip_camera_upload_slot_async)
-        blocks = [np.stack([inputs.color[i][k] for i in range(n_obj)]) for k in range(1 + W, 2 + W + n_up)]
-        for b in blocks:
-            inst.tracker.register_host_buffer(b)
-        for i, cam in enumerate(inst.color_cams):
-            cam.upload_slot(0, blocks[0][i], asynchronous=True)
-        hip.call("ingest_sync")
-        hip.call("sync")
-        tu = time.perf_counter()
-        for j in range(n_up):
-            hip.call("cameras_select_slot", j % 2)
-            hip.call("execute_tracking_step", 1 + W + j)
-            for i, cam in enumerate(inst.color_cams):
-                cam.upload_slot((j + 1) % 2, blocks[j + 1][i], asynchronous=True)
-        hip.call("ingest_sync")
-        hip.call("sync")
-        el = time.perf_counter() - tu
-        for b in blocks:
-            inst.tracker.unregister_host_buffer(b)
-        pcie["async_pinned"] = {"pose_updates_per_s": round(n_obj * n_up / el, 1),
-                                "ms_per_step": round(el / n_up * 1e3, 3),
-                                "upload_GBs": round(frame_bytes * n_up / el / 1e9, 2),
-                                "note": "page-locked frames, m3t_hip_camera_upload_slot_async on the copy stream, "
-                                        "two ring slots; the copy of frame k+1 overlaps step k"}
+    if rank == 0 and world == 1 and args.config == "rbot64" and not args.no_pcie:
+        pcie = pcie_legs(hip, inst, inputs, n_obj, W, K)
 
-    # ---- optional batch sweep (extra lines on stderr, not the headline) ----
+    # ---- optional batch sweep (extra, not the headline) ----
     sweep = []
     if rank == 0 and args.sweep:
         for n in [int(x) for x in args.sweep.split(",") if x]:
-            sweep.append(batch_point(pkg, scenes, n, args))
-
-    ycb = None
-    if rank == 0 and args.ycb:
-        ycb = ycb_point(pkg, scenes, args.ycb, args)
+            sweep.append(batch_point(pkg, scenes, base, n, use_depth, cfg))
 
     # ---- CPU baseline: the oracle restatement, bounded sample (rank 0); its first pass over the frames is also
-    # the parity check of the benchmarked trajectory: the same 8 objects, the same frames, free running ----
+    # the parity check of the benchmarked trajectory: the same objects, the same frames, free running ----
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only (the other ranks would idle)
         import util
@@ -230,7 +262,7 @@ def main():
         sub = scenes.Inputs.__new__(scenes.Inputs)
         sub.__dict__.update(inputs.__dict__)
         sub.n_objects = n_cpu
-        oinst = scenes.Instance(ora, sub)
+        oinst = scenes.Instance(ora, sub, use_depth=use_depth)
         oinst.upload_frame(0)
         oinst.tracker.StartModalities(0)
         done, spent, first_pass = 0, 0.0, True
@@ -259,59 +291,131 @@ def main():
             oinst.set_poses([inputs.gt[i][0] for i in range(n_cpu)])
         cpu_parallel = None
         if not args.no_cpu_parallel:
-            cpu_parallel = cpu_all_cores(ora, scenes, inputs, n_obj, n_frames)
+            cpu_parallel = cpu_all_cores(scenes, replicate(scenes, base, min(n_obj, 64)), min(n_obj, 64), n_frames,
+                                         use_depth)
         cpu = {"value": round(done / spent, 1), "unit": "pose-updates/s", "cores": 1, "kind": "port",
                "all_cores": cpu_parallel,
                "sample": "%d pose-updates of %d of the same objects, same frames, oracle/libm3t_oracle.so "
                          "(g++ -O3 -march=x86-64-v3), 1 thread, host has %d cores" % (done, n_cpu, os.cpu_count())}
 
-    if rank == 0:
-        total = n_obj * n_gpus * K
-        out = {
-            "metric": "pose-updates/sec (64 objects, 200 lines, 7 it)", "value": round(total / elapsed, 1),
-            "unit": "pose-updates/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
-            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d batched RBOT-geometry objects per GPU, RegionModality only, "
-                                   "200 lines x 7 corr-iterations x 2 updates, 640x512 BGR8, 32-bin histograms, "
-                                   "%d views x 200 points models (%d distinct)" %
-                                   (n_obj, inputs.region_models[0][1].shape[0], len(inputs.region_models)),
-                       "objects_per_gpu": n_obj, "parallelism": "objects sharded over %d GPU(s), no collective" % n_gpus,
-                       "tracked_within_5cm_5deg": "%d/%d" % (tracked, n_obj), "setup_s": round(setup_s, 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
-            "repeats": {"n": len(times), "ms_per_step_min": round(min(times) / K * 1e3, 4),
-                        "ms_per_step_median": round(elapsed / K * 1e3, 4),
-                        "ms_per_step_all": [round(x / K * 1e3, 4) for x in times]},
-            "pcie_inclusive": pcie,
-            "frac_of_hbm_roofline_whole_step": round(total / elapsed * B_ALG / (HBM_PEAK_GBS * 1e9 * n_gpus), 5),
-            "newton_steps_per_s": round(total / elapsed * 14, 1),  # 7 correspondence iterations x 2 updates
-        }
-        if sweep:
-            out["batch_sweep"] = sweep
-        if ycb:
-            out["ycb_region_depth"] = ycb
-        if args.extras:
-            out["extras"] = extras_point(pkg)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    total = total_objects * K if cfg["scaling"] == "weak" else total_objects * K
+    n_views = inputs.region_models[0][1].shape[0]
+    out = {
+        "metric": cfg["metric"], "value": round(total / elapsed, 1),
+        "unit": "pose-updates/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": cfg["scaling"],
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["workload"] % dict(n=n_obj, views=n_views, models=len(inputs.region_models)),
+                   "objects_per_gpu": n_obj,
+                   "parallelism": "objects sharded over %d GPU(s), no collective" % world,
+                   "tracked_within_5cm_5deg": "%d/%d" % (tracked, n_obj),
+                   "mean_add_s_vs_ground_truth_m": round(float(np.mean(adds_gt)), 6), "setup_s": round(setup_s, 1)},
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "repeats": {"n": len(times), "ms_per_step_min": round(min(times) / K * 1e3, 4),
+                    "ms_per_step_median": round(elapsed / K * 1e3, 4),
+                    "ms_per_step_all": [round(x / K * 1e3, 4) for x in times]},
+        "pcie_inclusive": pcie,
+        "frac_of_hbm_roofline_whole_step": round(total / elapsed * cfg["alg"] / (HBM_PEAK_GBS * 1e9 * world), 5),
+        "newton_steps_per_s": round(total / elapsed * cfg["newton"], 1),  # corr-iterations x updates
+    }
+    if sweep:
+        out["batch_sweep"] = sweep
+    if args.extras:
+        out["extras"] = extras_point(pkg)
+    return out
 
 
-def cpu_all_cores(ora_unused, scenes, inputs, n_obj, n_frames, seconds=8.0):
-    """SURVEY 8(d) CPU baseline (ii): the whole batch in ONE oracle context, stepped with an OpenMP `parallel for`
-    over the objects at nproc threads (m3t_oracle_execute_tracking_step_parallel; what the reference's evaluators
-    do over sequences, rbot_evaluator.cpp:144).  Also the evaluators' four time buckets
+def pcie_legs(hip, inst, inputs, n_obj, W, K):
+    n_up = max(1, min(5, K - 1))  # the asynchronous leg stages one frame ahead
+    hip.call("cameras_select_slot", 0)
+    hip.call("sync")
+    tu = time.perf_counter()
+    for k in range(1 + W, 1 + W + n_up):
+        for i, cam in enumerate(inst.color_cams):
+            f = inputs.color[i][k]
+            hip.call("camera_upload", cam.id, f.ctypes.data_as(C.c_void_p), f.strides[0])
+        hip.call("execute_tracking_step", k)
+    hip.call("sync")
+    el = time.perf_counter() - tu
+    frame_bytes = sum(inputs.color[i][0].nbytes for i in range(n_obj))
+    pcie = {"pose_updates_per_s": round(n_obj * n_up / el, 1), "ms_per_step": round(el / n_up * 1e3, 3),
+            "host_bytes_per_step": frame_bytes, "upload_GBs": round(frame_bytes * n_up / el / 1e9, 2),
+            "note": "pageable host frames, synchronous m3t_hip_camera_upload per camera, then the step"}
+    # the same with ONE page-locked slab per batch-frame and the double-buffered asynchronous ingest: the 64 frames of
+    # step k+1 cross PCIe as one DMA on the copy stream while step k runs (m3t_hip_cameras_upload_batch_async)
+    blocks = [np.stack([inputs.color[i][k] for i in range(n_obj)]) for k in range(1 + W, 2 + W + n_up)]
+    ids = (C.c_int * n_obj)(*[cam.id for cam in inst.color_cams])
+    for b in blocks:
+        inst.tracker.register_host_buffer(b)
+
+    def upload(slot, block):
+        hip.call("cameras_upload_batch_async", ids, n_obj, slot, block.ctypes.data_as(C.c_void_p),
+                 block.strides[0], block.strides[1])
+
+    hip.call("cameras_set_ring", ids, n_obj, 2)  # one ring for the batch: slot s of all cameras is one block
+    upload(0, blocks[0])
+    hip.call("ingest_sync")
+    hip.call("sync")
+    tu = time.perf_counter()
+    for j in range(n_up):
+        hip.call("cameras_select_slot", j % 2)
+        hip.call("execute_tracking_step", 1 + W + j)
+        upload((j + 1) % 2, blocks[j + 1])
+    hip.call("ingest_sync")
+    hip.call("sync")
+    el = time.perf_counter() - tu
+    for b in blocks:
+        inst.tracker.unregister_host_buffer(b)
+    pcie["async_pinned"] = {"pose_updates_per_s": round(n_obj * n_up / el, 1),
+                            "ms_per_step": round(el / n_up * 1e3, 3),
+                            "upload_GBs": round(frame_bytes * n_up / el / 1e9, 2),
+                            "note": "one page-locked slab per batch-frame, m3t_hip_cameras_upload_batch_async on the "
+                                    "copy stream, two ring slots; the copy of frame k+1 overlaps step k"}
+    return pcie
+
+
+def usable_cpus():
+    """cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota of the container
+    (os.cpu_count() reports the host's hardware threads, which a container with a quota cannot all run on)"""
+    info = {"cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_cpus": None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    info["cgroup_cpus"] = float(txt[0]) / float(txt[1])
+            else:
+                quota = float(txt[0])
+                period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    info["cgroup_cpus"] = quota / period
+            break
+        except Exception:
+            continue
+    n = info["affinity"]
+    if info["cgroup_cpus"]:
+        n = min(n, max(1, int(info["cgroup_cpus"])))
+    info["usable"] = max(1, n)
+    return info
+
+
+def cpu_all_cores(scenes, inputs, n_obj, n_frames, use_depth, seconds=8.0):
+    """SURVEY 8(d) CPU baseline (ii): the batch (at most 64 objects) in ONE oracle context, stepped with an OpenMP
+    `parallel for` over the objects at nproc threads (m3t_oracle_execute_tracking_step_parallel; what the
+    reference's evaluators do over sequences, rbot_evaluator.cpp:144).  Also the evaluators' four time buckets
     (rbot_evaluator.cpp:354-414), summed over threads."""
     import util
     ora = util.open_oracle()
     f = ora.lib.m3t_oracle_execute_tracking_step_parallel
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
-    inst = scenes.Instance(ora, inputs)
+    inst = scenes.Instance(ora, inputs, use_depth=use_depth)
     inst.upload_frame(0)
     inst.tracker.StartModalities(0)
-    n_threads = os.cpu_count() or 1
+    host = usable_cpus()
+    n_threads = min(host["usable"], n_obj)
     buckets = (C.c_double * 4)()
     done, spent = 0, 0.0
     while spent < seconds:
@@ -326,21 +430,22 @@ def cpu_all_cores(ora_unused, scenes, inputs, n_obj, n_frames, seconds=8.0):
                 break
         inst.set_poses([inputs.gt[i][0] for i in range(n_obj)])
     tot = sum(buckets) or 1.0
-    return {"value": round(done / spent, 1), "unit": "pose-updates/s", "cores": n_threads,
-            "sample": "%d pose-updates, all %d objects in one oracle context, OpenMP parallel for over objects, "
+    return {"value": round(done / spent, 1), "unit": "pose-updates/s", "cores": n_threads, "host": host,
+            "sample": "%d pose-updates, %d objects in one oracle context, OpenMP parallel for over objects, "
                       "%d threads" % (done, n_obj, n_threads),
             "bucket_share": {"correspondences": round(buckets[0] / tot, 3), "gradient_hessian": round(buckets[1] / tot, 3),
                              "optimization": round(buckets[2] / tot, 3), "results": round(buckets[3] / tot, 3)},
-            "thread_seconds_per_pose_update_us": round(tot / done * 1e6, 1)}
+            "thread_us_per_pose_update": round(tot / done * 1e6, 1)}
 
 
-def measured_traffic(kernel, n_obj, fused_histogram=False):
+def measured_traffic(config, kernel, n_obj, fused_histogram=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/rNN_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs of this same
+    (profiles/rNN_hbm_traffic*.json: FETCH_SIZE and WRITE_SIZE in separate runs of this same
     command, read side doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).  The counters
-    cannot be collected from inside this process; null when no profile for this batch size exists."""
+    cannot be collected from inside this process; null when no profile for this configuration exists."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    suffix = "" if config == "rbot64" else "_" + config
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic%s.json" % suffix)))
     if not files:
         return None, None
     try:
@@ -402,81 +507,17 @@ def extras_point(pkg):
                                    "renderers of 20 958 triangles at 200 x 200, 7 x 2 iterations, 1 object"}
 
 
-B_ALG_YCB = 1094456  # Region + Depth with measured occlusions, YCB parameters
-
-
-def ycb_point(pkg, scenes, n_obj, args):
-    """BASELINE configs[2]-shaped leg: n_obj objects, Region + Depth (ICG), YCB parameters, 640x480"""
-    import util
-    hip = pkg.open_context(0)
-    K, W = 10, 3
-    n_frames = K + W + 1
-    inputs = scenes.Inputs(n_obj, n_frames, n_divides=args.n_divides, n_models=min(8, n_obj), with_depth=True)
-    inst = scenes.Instance(hip, inputs, use_depth=True)
-    for cams, frames in ((inst.color_cams, inputs.color), (inst.depth_cams, inputs.depth)):
-        for i, cam in enumerate(cams):
-            hip.call("camera_set_ring", cam.id, n_frames)
-            for k in range(n_frames):
-                f = frames[i][k]
-                hip.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
-    hip.call("cameras_select_slot", 0)
-    hip.call("start_modalities", 0)
-    for k in range(1, 1 + W):
-        hip.call("cameras_select_slot", k)
-        hip.call("execute_tracking_step", k)
-    hip.call("sync")
-    t = time.perf_counter()
-    for k in range(1 + W, 1 + W + K):
-        hip.call("cameras_select_slot", k)
-        hip.call("execute_tracking_step", k)
-    hip.call("sync")
-    el = time.perf_counter() - t
-    poses = np.zeros((n_obj, 16), np.float32)
-    hip.call("bodies_get_poses", poses.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
-    adds = [pkg.synthetic.add_s(inputs.vertices[i], poses[i].reshape(4, 4).T, inputs.gt[i][W + K]) for i in range(n_obj)]
-    # CPU restatement on the same objects / frames (1 thread)
-    ora = util.open_oracle()
-    oinst = scenes.Instance(ora, inputs, use_depth=True)
-    oinst.upload_frame(0)
-    oinst.tracker.StartModalities(0)
-    tc = 0.0
-    for k in range(1, 1 + W + K):
-        oinst.upload_frame(k)
-        t0 = time.perf_counter()
-        oinst.tracker.ExecuteTrackingStep(k)
-        tc += time.perf_counter() - t0
-    rate = n_obj * K / el
-    return {"objects": n_obj, "pose_updates_per_s": round(rate, 1), "ms_per_step": round(el / K * 1e3, 4),
-            "frac_of_hbm_roofline": round(rate * B_ALG_YCB / (HBM_PEAK_GBS * 1e9), 5),
-            "mean_add_s_vs_gt_m": round(float(np.mean(adds)), 5),
-            "cpu_port_pose_updates_per_s": round(n_obj * (W + K) / tc, 1)}
-
-
-def batch_point(pkg, scenes, n_obj, args):
-    """pose-updates/s at another batch size (few frames, models shared)"""
+def batch_point(pkg, scenes, base, n_obj, use_depth, cfg):
+    """pose-updates/s at another batch size (few frames; every object its own camera and frame ring up to 4096
+    objects, beyond that the objects look at the 64 rendered streams through 64 shared cameras)"""
     hip = pkg.open_context(0)
     K, W = 6, 2
     n_frames = K + W + 1
-    inputs = scenes.Inputs(min(n_obj, 64), n_frames, n_divides=args.n_divides, n_models=min(8, n_obj))
-    # replicate the 64 rendered streams to reach n_obj objects
-    rep = scenes.Inputs.__new__(scenes.Inputs)
-    rep.__dict__.update(inputs.__dict__)
-    idx = [i % inputs.n_objects for i in range(n_obj)]
-    rep.n_objects = n_obj
-    for name in ("scenes", "model_of", "gt", "color", "depth", "start", "vertices"):
-        rep.__dict__[name] = [inputs.__dict__[name][i] for i in idx]
-    if n_obj > 4096:  # beyond that the replicas look at the 64 frame streams through 64 shared cameras
-        rep.camera_of = idx
-    inst = scenes.Instance(hip, rep)
-    staged = set()
-    for i, cam in enumerate(inst.color_cams):
-        if cam.id in staged:
-            continue
-        staged.add(cam.id)
-        hip.call("camera_set_ring", cam.id, n_frames)
-        for k in range(n_frames):
-            f = rep.color[i][k]
-            hip.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+    rep = replicate(scenes, base, n_obj)
+    if n_obj > 4096:
+        rep.camera_of = [i % base.n_objects for i in range(n_obj)]
+    inst = scenes.Instance(hip, rep, use_depth=use_depth)
+    stage_frames(hip, inst, rep, n_frames)
     hip.call("cameras_select_slot", 0)
     hip.call("start_modalities", 0)
     for k in range(1, 1 + W):
@@ -490,8 +531,12 @@ def batch_point(pkg, scenes, n_obj, args):
     hip.call("sync")
     el = time.perf_counter() - t
     rate = n_obj * K / el
+    shape = (C.c_int * 4)()
+    hip.call("get_step_shape", shape)
     return {"objects": n_obj, "pose_updates_per_s": round(rate, 1), "ms_per_step": round(el / K * 1e3, 4),
-            "frac_of_hbm_roofline": round(rate * B_ALG / (HBM_PEAK_GBS * 1e9), 5)}
+            "frac_of_hbm_roofline": round(rate * cfg["alg"] / (HBM_PEAK_GBS * 1e9), 5),
+            "workgroups_per_object": shape[1], "threads_per_workgroup": shape[2],
+            "distinct_frame_rings": len({c.id for c in inst.color_cams})}
 
 
 if __name__ == "__main__":

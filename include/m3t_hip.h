@@ -98,6 +98,15 @@ int m3t_hip_cameras_select_slot(m3t_hip_context*, int slot); /* all cameras */
 int m3t_hip_host_register(m3t_hip_context*, void* ptr, size_t bytes);
 int m3t_hip_host_unregister(m3t_hip_context*, void* ptr);
 int m3t_hip_camera_upload_slot_async(m3t_hip_context*, int camera_id, int slot, const void* pixels, size_t row_step);
+/* Batch ingest: a group of cameras of equal geometry fed by one capture process.  cameras_set_ring puts their frame
+ * rings into one allocation ([slot][camera][frame]); cameras_upload_batch_async then moves the n frames of one
+ * batch-frame (frame i at base + i * camera_stride, rows row_step apart) in ONE asynchronous transfer when the ids are
+ * listed in the ring's order and the host block has the ring's layout (row_step = width * bytes per pixel rounded up
+ * to 64, camera_stride = height * row_step); otherwise it falls back to one transfer per camera.  Same lifetime and
+ * ordering rules as camera_upload_slot_async. */
+int m3t_hip_cameras_set_ring(m3t_hip_context*, const int* camera_ids, int n_cameras, int n_slots);
+int m3t_hip_cameras_upload_batch_async(m3t_hip_context*, const int* camera_ids, int n_cameras, int slot, const void* base,
+                                       size_t camera_stride, size_t row_step);
 int m3t_hip_ingest_sync(m3t_hip_context*); /* wait until all enqueued frame copies have landed */
 
 /* ---- Bodies (body.h:46: only body2world_pose crosses the boundary) ------------ */
@@ -216,6 +225,17 @@ int m3t_hip_calculate_optimization(m3t_hip_context*, int iteration, int corr_ite
  * Tikhonov diagonal, solves and updates the poses identically on every rank. */
 int m3t_hip_calculate_optimization_begin(m3t_hip_context*, float** partial, size_t* count);
 int m3t_hip_calculate_optimization_end(m3t_hip_context*);
+/* The collective itself, inside the library: one ncclAllReduce(sum, float, count) on the context's stream, in place on
+ * the buffer of begin().  The communicator is either the library's own (comm_get_unique_id on one rank, the 128 bytes
+ * carried to the others by whatever the host uses -- MPI, a file, torch.distributed -- then comm_init_rank on every
+ * rank, one rank per GPU) or one the host already has (comm_set(ctx, ncclComm_t)).  While a communicator is set,
+ * m3t_hip_calculate_optimization (and with it execute_tracking_step / refine_poses) runs begin -> allreduce -> end
+ * by itself, so the host's tracking loop is the single-GPU one.  librccl.so.1 is opened on first use only. */
+int m3t_hip_comm_get_unique_id(m3t_hip_context*, void* id, size_t id_bytes /* >= 128 */);
+int m3t_hip_comm_init_rank(m3t_hip_context*, const void* id, size_t id_bytes, int n_ranks, int rank);
+int m3t_hip_comm_set(m3t_hip_context*, void* nccl_comm /* ncclComm_t or NULL */);
+int m3t_hip_comm_destroy(m3t_hip_context*);
+int m3t_hip_calculate_optimization_allreduce(m3t_hip_context*);
 int m3t_hip_calculate_consistent_poses(m3t_hip_context*); /* tracker.cpp:423, optimizer.cpp:135 */
 int m3t_hip_calculate_results(m3t_hip_context*, int iteration);                    /* :503 */
 /* Tracker::ExecuteTrackingStep (M3T tracker.cpp:344) == Tracker::ExecuteTrackingCycle

@@ -447,11 +447,33 @@ class Tracker {
   void RegisterHostBuffer(void* ptr, size_t bytes) { c_->Check(m3t_hip_host_register(c_->get(), ptr, bytes), "Tracker"); }
   void UnregisterHostBuffer(void* ptr) { c_->Check(m3t_hip_host_unregister(c_->get(), ptr), "Tracker"); }
   bool IngestSync() { return c_->Step(m3t_hip_ingest_sync(c_->get())); }
+  // batch ingest: one frame ring for a group of cameras, one transfer per batch-frame
+  void SetSharedRing(const std::vector<int>& camera_ids, int n_slots) {
+    c_->Check(m3t_hip_cameras_set_ring(c_->get(), camera_ids.data(), int(camera_ids.size()), n_slots), "Tracker");
+  }
+  bool UploadBatchAsync(const std::vector<int>& camera_ids, int slot, const void* base, size_t camera_stride,
+                        size_t row_step) {
+    return c_->Step(m3t_hip_cameras_upload_batch_async(c_->get(), camera_ids.data(), int(camera_ids.size()), slot, base,
+                                                       camera_stride, row_step));
+  }
   // a kinematic structure spread over GPUs: begin -> all-reduce(sum) of `count` floats at `partial` on stream() -> end
   bool CalculateOptimizationBegin(float** partial, size_t* count) {
     return c_->Step(m3t_hip_calculate_optimization_begin(c_->get(), partial, count));
   }
   bool CalculateOptimizationEnd() { return c_->Step(m3t_hip_calculate_optimization_end(c_->get())); }
+  // ... with the library's own RCCL call site: one rank creates the id, every rank joins; from then on
+  // CalculateOptimization / ExecuteTrackingStep sum over the ranks by themselves
+  std::vector<char> CommUniqueId() {
+    std::vector<char> id(128);
+    c_->Check(m3t_hip_comm_get_unique_id(c_->get(), id.data(), id.size()), "Tracker");
+    return id;
+  }
+  void CommInitRank(const std::vector<char>& id, int n_ranks, int rank) {
+    c_->Check(m3t_hip_comm_init_rank(c_->get(), id.data(), id.size(), n_ranks, rank), "Tracker");
+  }
+  void CommSet(void* nccl_comm) { c_->Check(m3t_hip_comm_set(c_->get(), nccl_comm), "Tracker"); }
+  void CommDestroy() { c_->Check(m3t_hip_comm_destroy(c_->get()), "Tracker"); }
+  bool CalculateOptimizationAllReduce() { return c_->Step(m3t_hip_calculate_optimization_allreduce(c_->get())); }
   void SetSoftConstraintsActive(bool active) {
     c_->Check(m3t_hip_set_soft_constraints_active(c_->get(), active ? 1 : 0), "Tracker");
   }

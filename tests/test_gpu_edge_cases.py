@@ -215,6 +215,93 @@ def test_async_ingest_matches_blocking_upload():
     assert np.array_equal(poses[0][-1], poses[1][-1])
 
 
+def test_batch_ingest_matches_blocking_upload():
+    """m3t_hip_cameras_set_ring + m3t_hip_cameras_upload_batch_async: the frames of all cameras for one ring slot as
+    ONE page-locked block and one transfer, double-buffered against the tracking steps: the pose sequence of the
+    blocking Camera::UpdateImage hand-over, bit for bit; a block in another layout takes the per-camera path"""
+    import ctypes as C
+    n_frames = 6
+    inputs = scenes.Inputs(4, n_frames, n_divides=2)
+    ref = None
+    for layout in ("blocking", "ring order", "padded rows"):
+        hip = util.open_hip()
+        inst = scenes.Instance(hip, inputs)
+        inst.upload_frame(0)
+        assert inst.tracker.StartModalities(0)
+        if layout == "blocking":
+            for k in range(1, n_frames):
+                inst.upload_frame(k)
+                assert inst.tracker.ExecuteTrackingStep(k)
+        else:
+            h, w = inputs.color[0][0].shape[:2]
+            pad = 0 if layout == "ring order" else 64
+            blocks = []
+            for k in range(n_frames):
+                b = np.zeros((inputs.n_objects, h, w * 3 + pad), np.uint8)
+                for i in range(inputs.n_objects):
+                    b[i, :, :w * 3] = inputs.color[i][k].reshape(h, w * 3)
+                inst.tracker.register_host_buffer(b)
+                blocks.append(b)
+            ids = (C.c_int * inputs.n_objects)(*[cam.id for cam in inst.color_cams])
+            hip.call("cameras_set_ring", ids, inputs.n_objects, 2)
+
+            def upload(slot, b):
+                hip.call("cameras_upload_batch_async", ids, inputs.n_objects, slot, b.ctypes.data_as(C.c_void_p),
+                         b.strides[0], b.strides[1])
+            upload(1, blocks[1])
+            for k in range(1, n_frames):
+                inst.tracker.select_slot(k % 2)
+                assert inst.tracker.ExecuteTrackingStep(k)
+                if k + 1 < n_frames:
+                    upload((k + 1) % 2, blocks[k + 1])
+            inst.tracker.ingest_sync()
+        poses = np.stack(inst.poses())
+        if ref is None:
+            ref = poses
+        assert np.array_equal(poses, ref), layout
+
+
+def test_body_with_two_region_modalities():
+    """a body seen by two colour cameras carries two RegionModalities: Link::CalculateGradientAndHessian sums ALL
+    modalities of the link (link.cpp:184-193).  The rigid fast path keeps one modality of each kind per body, so
+    such a body takes the link kernels; poses equal the oracle's bit for bit"""
+    inputs = scenes.Inputs(2, 3, n_divides=2)
+    out = []
+    for api in (util.open_hip(), util.open_oracle()):
+        models = [host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
+                  for m in inputs.region_models]
+        bodies, cams = [], []
+        for i in range(inputs.n_objects):
+            body = host.Body(api, inputs.start[i])
+            cam_a, cam_b = host.ColorCamera(api, **inputs.intr), host.ColorCamera(api, **inputs.intr)
+            ra = host.RegionModality(api, body, cam_a, models[inputs.model_of[i]], **dict(syn.RBOT_REGION_PARAMS, measure_occlusions=0))
+            rb = host.RegionModality(api, body, cam_b, models[inputs.model_of[i]],
+                                     **dict(syn.RBOT_REGION_PARAMS, measure_occlusions=0, n_lines_max=120, n_histogram_bins=16))
+            host.Optimizer(api, body=body, modalities=[ra, rb])
+            bodies.append(body)
+            cams.append((cam_a, cam_b))
+        tracker = host.Tracker(api, 7, 2)
+        seq = []
+        for k in range(inputs.n_frames):
+            for i, (ca, cb) in enumerate(cams):
+                ca.UpdateImage(inputs.color[i][k])
+                cb.UpdateImage(inputs.color[i][k])
+            if k == 0:
+                assert tracker.StartModalities(0)
+            assert tracker.ExecuteTrackingStep(k)
+            seq.append(np.stack([b.body2world_pose() for b in bodies]))
+        out.append(np.stack(seq))
+    assert np.array_equal(out[0], out[1])
+    # and the second modality matters: a single-modality tracker ends elsewhere
+    ref = scenes.Instance(util.open_oracle(), inputs)
+    ref.upload_frame(0)
+    assert ref.tracker.StartModalities(0)
+    for k in range(inputs.n_frames):
+        ref.upload_frame(k)
+        assert ref.tracker.ExecuteTrackingStep(k)
+    assert not np.array_equal(np.stack(ref.poses()), out[1][-1])
+
+
 def test_shared_color_histograms():
     """three bodies whose RegionModalities share one ColorHistograms object (RTB configuration,
     region_modality.cpp:168-173, tracker.cpp:435-443,507-515): every modality adds its samples, the object is

@@ -162,6 +162,36 @@ def test_begin_allreduce_end_with_rccl_world1():
 
 
 @gpu
+def test_native_rccl_allreduce_world1():
+    """the library's own communicator (m3t_hip_comm_get_unique_id / comm_init_rank, RCCL opened with dlopen) and its
+    own ncclAllReduce call site: with a communicator set, CalculateOptimization runs begin -> all-reduce -> end by
+    itself; with one rank the poses equal the plain call bit for bit"""
+    out = []
+    for with_comm in (False, True):
+        rng = np.random.default_rng(3)
+        api = util.open_hip()
+        b1, b2 = random_pose(rng), random_pose(rng)
+        link1, link2, opt = build(api, b1, b2, directions=(1, 1, 0, 1, 1, 1))
+        d = random_pose(rng)
+        d[:3, :3] = syn.rot_vec(rng.normal(size=3) * 0.3)
+        link2.set_joint2parent_pose(np.linalg.inv(b1) @ d)
+        tracker = host.Tracker(api, 1, 1)
+        if with_comm:
+            uid = C.create_string_buffer(128)
+            api.call("comm_get_unique_id", uid, 128)
+            api.call("comm_init_rank", uid, 128, 1, 0)
+            assert api.raw("calculate_optimization_allreduce") == -2  # begin() first
+        assert tracker.CalculateConsistentPoses()
+        for it in range(3):
+            assert tracker.CalculateOptimization(0, 0, 0)
+        out.append((link1.link2world_pose(), link2.link2world_pose(), link2.joint2parent_pose()))
+        if with_comm:
+            api.call("comm_destroy")
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
+
+@gpu
 def test_rigid_context_switches_to_general_path_for_begin_end():
     """begin/end on a rigid-only context == the rigid fast path within one Newton-step tolerance"""
     inputs = scenes.Inputs(2, 2, n_divides=2)

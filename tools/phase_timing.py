@@ -16,7 +16,7 @@ inputs = scenes.Inputs(n_obj, 8, n_divides=4, n_models=8, with_depth=ycb)
 inst = scenes.Instance(hip, inputs, use_depth=ycb)
 inst.upload_frame(0)
 inst.tracker.StartModalities(0)
-buf = (C.c_ulonglong * 24)()
+buf = (C.c_ulonglong * 32)()
 for k in range(1, 4):
     inst.upload_frame(k); inst.tracker.ExecuteTrackingStep(k)
 f(hip.ctx, buf, 1)
@@ -25,12 +25,13 @@ for k in range(4, 8):
     inst.upload_frame(k); inst.tracker.ExecuteTrackingStep(k)
 f(hip.ctx, buf, 1)
 names = ["view search", "phase A (lines)", "phase B (pixels)", "phase C1 (dist)", "phase C2 (moments)",
-         "g/H products + barrier", "solve (wave) + barrier",
+         "g/H products + barrier (u=0, global)", "solve (wave) + barrier",
          "  B: addr+issue", "  B: pixel wait", "  B: gather issue", "  B: gather wait", "  B: products",
          "  solve: permute + gather", "  solve: LDLT", "  solve: trisolve", "  solve: expm", "depth scan (all)",
          "  d: view search", "  d: point setup", "  d: window scan", "  d: reduce+occlusion", "  d: write",
-         "split exchange", "g/H chain (42 lanes)"]
-tot = sum(buf[i] for i in range(7)) + buf[16] + buf[22] + buf[23]
+         "split exchange", "g/H chain (42 lanes)", "g/H products + barrier (u>=1, local)", "moments / depth vote",
+         "histogram update (tail)"]
+tot = sum(buf[i] for i in range(7)) + buf[16] + sum(buf[22:27])
 for i, nme in enumerate(names):
-    print("%-20s %10.0f cycles/frame  %5.1f%%" % (nme, buf[i] / n, 100.0 * buf[i] / tot))
+    print("%-38s %10.0f cycles/frame  %5.1f%%" % (nme, buf[i] / n, 100.0 * buf[i] / tot))
 print("total %.0f cycles/frame" % (tot / n))

@@ -57,7 +57,8 @@ def main():
     if "rbot" in what:
         inputs = scenes.Inputs(64, 12, n_divides=4, n_models=8)
         for n, envs in ((64, [{"M3T_HIP_NO_SPLIT": "1"}, {"M3T_HIP_SPLIT_PARTS": "2"}, {"M3T_HIP_SPLIT_PARTS": "4"},
-                              {"M3T_HIP_SPLIT_PARTS": "4", "M3T_HIP_NO_FUSED_HISTOGRAM": "1"}]),
+                              {"M3T_HIP_SPLIT_PARTS": "8", "M3T_HIP_THREADS": "256"},
+                              {"M3T_HIP_SPLIT_PARTS": "4", "M3T_HIP_THREADS": "256"}]),
                         (32, [{"M3T_HIP_SPLIT_PARTS": "4"}, {"M3T_HIP_SPLIT_PARTS": "8"}]),
                         (16, [{"M3T_HIP_SPLIT_PARTS": "8"}, {"M3T_HIP_SPLIT_PARTS": "16"}]),
                         (1, [{"M3T_HIP_NO_SPLIT": "1"}, {"M3T_HIP_SPLIT_PARTS": "8"}, {"M3T_HIP_SPLIT_PARTS": "16"}])):
@@ -72,7 +73,8 @@ def main():
     if "ycb" in what:
         inputs = scenes.Inputs(21, 12, n_divides=4, n_models=6, with_depth=True)
         ref = None
-        for env in ({"M3T_HIP_NO_SPLIT": "1"}, {"M3T_HIP_SPLIT_PARTS": "4"}, {"M3T_HIP_SPLIT_PARTS": "8"}):
+        for env in ({"M3T_HIP_NO_SPLIT": "1"}, {"M3T_HIP_SPLIT_PARTS": "8"}, {"M3T_HIP_SPLIT_PARTS": "16"},
+                    {"M3T_HIP_SPLIT_PARTS": "16", "M3T_HIP_THREADS": "256"}):
             mn, med, shape, poses = measure(inputs, True, env)
             same = ref is None or bool(np.array_equal(ref, poses))
             ref = poses if ref is None else ref
