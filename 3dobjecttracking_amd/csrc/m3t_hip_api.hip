@@ -179,6 +179,7 @@ struct m3t_hip_context {
   bool links_device_newer = false;  // joint poses on the device are ahead of the host mirror
   DevMem d_links, d_constraints, d_soft, d_treeopts, d_work, d_partial;
   size_t partial_count = 0;
+  size_t tree_lds = 0;  // bytes of LDS per structure for the link kernels, 0: work arrays in global memory
   bool partial_ready = false;
   // a kinematic structure spread over GPUs: this rank's RCCL communicator (m3t_hip_comm_init_rank) or the host's
   ncclComm_t comm = nullptr;
@@ -539,7 +540,7 @@ int UploadTreeTables(Ctx* ctx) {
   std::vector<TreeOptDev> opts(ctx->optimizers.size());
   std::vector<size_t> link_off(ctx->optimizers.size()), con_off(ctx->optimizers.size()), work_off(ctx->optimizers.size()),
       soft_off(ctx->optimizers.size());
-  size_t work_total = 0, partial_total = 0;
+  size_t work_total = 0, partial_total = 0, tree_work_max = 0;
   for (auto& l : ctx->links) { l.optimizer = -1; l.local_index = -1; }
   for (size_t oi = 0; oi < ctx->optimizers.size(); ++oi) {
     Optimizer& o = ctx->optimizers[oi];
@@ -609,6 +610,7 @@ int UploadTreeTables(Ctx* ctx) {
     }
     work_off[oi] = work_total;
     work_total += tree_work_floats(int(o.order.size()), dof, o.n_rows);
+    tree_work_max = std::max(tree_work_max, tree_work_floats(int(o.order.size()), dof, o.n_rows));
     o.partial_offset = partial_total;
     partial_total += size_t(dof) * dof + dof;
   }
@@ -617,6 +619,12 @@ int UploadTreeTables(Ctx* ctx) {
   HIPCHK(ctx->d_soft.alloc(std::max<size_t>(1, soft.size()) * sizeof(SoftConstraintDev)));
   HIPCHK(ctx->d_treeopts.alloc(std::max<size_t>(1, opts.size()) * sizeof(TreeOptDev)));
   HIPCHK(ctx->d_work.alloc(std::max<size_t>(1, work_total) * 4));
+  // the structures' work arrays live in LDS when the largest fits (one wave per structure, m3t_links.hip)
+  ctx->tree_lds = tree_work_max * 4 <= size_t(152) * 1024 ? tree_work_max * 4 : 0;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(links_project_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->tree_lds)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(links_solve_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->tree_lds)));
   HIPCHK(ctx->d_partial.alloc(std::max<size_t>(1, partial_total) * 4));
   HIPCHK(hipMemset(ctx->d_partial.p, 0, ctx->d_partial.bytes));
   ctx->partial_count = partial_total;
@@ -1037,8 +1045,8 @@ int LaunchGradientHessian(Ctx* ctx, int corr_iteration, int opt_iteration) {
 int LaunchProject(Ctx* ctx) {
   int n = int(ctx->optimizers.size());
   if (n == 0) return M3T_OK;
-  hipLaunchKernelGGL(links_project_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
-                     ctx->d_treeopts.as<TreeOptDev>(), n, ctx->d_poses.as<float>());
+  hipLaunchKernelGGL(links_project_kernel, dim3(n), dim3(64), ctx->tree_lds, ctx->stream,
+                     ctx->d_treeopts.as<TreeOptDev>(), n, ctx->d_poses.as<float>(), ctx->tree_lds ? 1 : 0);
   HIPCHK(hipGetLastError());
   ctx->partial_ready = true;
   return M3T_OK;
@@ -1046,8 +1054,9 @@ int LaunchProject(Ctx* ctx) {
 int LaunchSolve(Ctx* ctx, bool zero_theta) {
   int n = int(ctx->optimizers.size());
   if (n == 0) return M3T_OK;
-  hipLaunchKernelGGL(links_solve_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
-                     ctx->d_treeopts.as<TreeOptDev>(), n, ctx->d_poses.as<float>(), zero_theta ? 1 : 0);
+  hipLaunchKernelGGL(links_solve_kernel, dim3(n), dim3(64), ctx->tree_lds, ctx->stream,
+                     ctx->d_treeopts.as<TreeOptDev>(), n, ctx->d_poses.as<float>(), zero_theta ? 1 : 0,
+                     ctx->tree_lds ? 1 : 0);
   HIPCHK(hipGetLastError());
   ctx->links_device_newer = true;
   ctx->partial_ready = false;

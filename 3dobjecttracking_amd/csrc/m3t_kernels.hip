@@ -202,6 +202,16 @@ __device__ __forceinline__ int wave_min_i(int v) {  // broadcast result
 __device__ int closest_view(G<v4f> orientations4, int n_views, const Affine& b2c, float* misc) {
   float tn = sqrtf((b2c.t[0] * b2c.t[0] + b2c.t[1] * b2c.t[1]) + b2c.t[2] * b2c.t[2]);
   if (tn == 0.0f) return 0;  // block-uniform
+  const int nt = blockDim.x;
+  // the view table does not depend on the pose: its loads (up to six views per thread: 3072 views at 512 threads)
+  // are in flight while the viewing direction is worked out
+  constexpr int kPre = 6;
+  v4f pre[kPre];
+#pragma unroll
+  for (int j = 0; j < kPre; ++j) {
+    const int v = threadIdx.x + j * nt;
+    pre[j] = orientations4[v < n_views ? v : 0];
+  }
   float tx = b2c.t[0] / tn, ty = b2c.t[1] / tn, tz = b2c.t[2] / tn;
   float ri[9];
   inverse3(b2c.l, ri);
@@ -210,8 +220,13 @@ __device__ int closest_view(G<v4f> orientations4, int n_views, const Affine& b2c
   float o2 = (ri[2] * tx + ri[5] * ty) + ri[8] * tz;
   float best = -1.0f;
   int bi = INT_MAX;
-  const int nt = blockDim.x;
-  for (int v0 = threadIdx.x; v0 < n_views; v0 += 4 * nt) {
+#pragma unroll
+  for (int j = 0; j < kPre; ++j) {
+    const int v = threadIdx.x + j * nt;
+    float d = (o0 * pre[j].x + o1 * pre[j].y) + o2 * pre[j].z;
+    if (v < n_views && d > best) { best = d; bi = v; }
+  }
+  for (int v0 = threadIdx.x + kPre * nt; v0 < n_views; v0 += 4 * nt) {
     v4f p[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -936,33 +951,38 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   PHASE_MARK(4);
 }
 
-// CalculateDistributionMoments :1639-1658 for every line of the object, from the normalised distributions in LDS
-// (its own part's, and -- tracking_step_split_kernel -- the ones received from the other workgroups).  Ends with a barrier.
-__device__ void region_moments(CRegion& m, const Lds& s) {
-  const int nl = s.nl, dl = m.distribution_length;
+// CalculateDistributionMoments :1639-1658 from the normalised distributions in LDS, for the lines [lo, hi) if
+// `inside`, for all other lines if not (tracking_step_split_kernel: the own part's lines while the other parts'
+// are still on their way, the received ones afterwards).  No barrier.
+template <int DL>
+__device__ __forceinline__ void region_moments_lines(CRegion& m, const Lds& s, int lo, int hi, bool inside, int dl) {
+  const int nl = s.nl;
   for (int line = threadIdx.x; line < nl; line += blockDim.x) {
+    if ((line >= lo && line < hi) != inside) continue;
     if (!(f2i_bits(s.state[LS_VALID * nl + line]) & 1)) continue;
-    float mean_from_begin = 0.0f;
-    float dist[M3T_MAX_DISTRIBUTION_LENGTH];
+    constexpr int N = DL > 0 ? DL : M3T_MAX_DISTRIBUTION_LENGTH;
+    float dist[N];
 #pragma unroll
-    for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d) {
-      if (d < dl) {
-        dist[d] = s.state[(LS_DIST0 + d) * nl + line];
-        mean_from_begin += (float)d * dist[d];
-      }
-    }
+    for (int d = 0; d < N; ++d) dist[d] = (DL > 0 || d < dl) ? s.state[(LS_DIST0 + d) * nl + line] : 0.0f;  // independent reads
+    float mean_from_begin = 0.0f;
+#pragma unroll
+    for (int d = 0; d < N; ++d)
+      if (DL > 0 || d < dl) mean_from_begin += (float)d * dist[d];
     float var = 0.0f;
 #pragma unroll
-    for (int d = 0; d < M3T_MAX_DISTRIBUTION_LENGTH; ++d) {
-      if (d < dl) {
+    for (int d = 0; d < N; ++d)
+      if (DL > 0 || d < dl) {
         float dd = (float)d - mean_from_begin;
         var += (dd * dd) * dist[d];
       }
-    }
     s.state[LS_MEAN * nl + line] = mean_from_begin - m.distribution_length_minus_1_half;
     s.state[LS_VAR * nl + line] = fmaxf(var, m.min_expected_variance);
   }
-  __syncthreads();
+}
+__device__ void region_moments(CRegion& m, const Lds& s, int lo = 0, int hi = 1 << 30, bool inside = true) {
+  const int dl = m.distribution_length;
+  if (dl == 12) region_moments_lines<12>(m, s, lo, hi, inside, dl);  // the default length: straight-line code
+  else region_moments_lines<0>(m, s, lo, hi, inside, dl);
 }
 
 // ---------------------------------------------------------------------------
@@ -992,50 +1012,80 @@ __device__ __forceinline__ int gh_lane_row(int lane) {  // lane < 42 of the grad
   return 6 + hi * 6 - hi * (hi - 1) / 2 + (lo - hi);
 }
 
-typedef const __attribute__((address_space(3))) v4f* LdsV4;
-// one dependent subtraction per line; Q quads (4 lines each) per step, the next step's quads already in flight
+// volatile: every quad is read exactly once and in program order, so the reads of the NEXT step really are in flight
+// while the current step's subtractions run (a plain load is re-materialised at its use by the compiler, which puts
+// the whole LDS latency in front of every step: measured 2.6 k instead of ~1.1 k cycles per 216-line chain)
+typedef const volatile __attribute__((address_space(3))) v4f* LdsV4;
+// one dependent subtraction per line; Q quads (4 lines each) per step, the next step's quads already in flight:
+// two register sets take turns (no copies), a scheduling barrier keeps each set's reads ahead of the other set's sums
 template <int Q>
 __device__ __forceinline__ float chain_walk(LdsV4 p, int n_quads, float s) {
-  v4f cur[Q];
+  v4f a[Q], b[Q];
 #pragma unroll
-  for (int i = 0; i < Q; ++i) cur[i] = p[i];
-  for (int q = 0; q < n_quads; q += Q) {
-    const int nq = q + Q < n_quads ? q + Q : q;  // the last step re-reads its own quads (harmless)
-    v4f nxt[Q];
+  for (int i = 0; i < Q; ++i) a[i] = p[i];
+  int q = 0;
+  while (true) {
+    {
+      const int nq = q + Q < n_quads ? q + Q : q;  // past the end: re-read the own quads (harmless, never summed)
 #pragma unroll
-    for (int i = 0; i < Q; ++i) nxt[i] = p[nq + i];
+      for (int i = 0; i < Q; ++i) b[i] = p[nq + i];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < Q; ++i) {
-      s -= cur[i].x;
-      s -= cur[i].y;
-      s -= cur[i].z;
-      s -= cur[i].w;
+      for (int i = 0; i < Q; ++i) { s -= a[i].x; s -= a[i].y; s -= a[i].z; s -= a[i].w; }
+      q += Q;
+      if (q >= n_quads) break;
     }
+    {
+      const int nq = q + Q < n_quads ? q + Q : q;
 #pragma unroll
-    for (int i = 0; i < Q; ++i) cur[i] = nxt[i];
+      for (int i = 0; i < Q; ++i) a[i] = p[nq + i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) { s -= b[i].x; s -= b[i].y; s -= b[i].z; s -= b[i].w; }
+      q += Q;
+      if (q >= n_quads) break;
+    }
   }
   return s;
 }
 // two chains at once (two independent dependency chains interleave for free), 3 quads each per step
 __device__ __forceinline__ void chain_walk2(LdsV4 pa, LdsV4 pb, int n_quads, float& sa, float& sb) {
   constexpr int Q = 3;
-  v4f ca[Q], cb[Q];
+  v4f a0[Q], b0[Q], a1[Q], b1[Q];
 #pragma unroll
-  for (int i = 0; i < Q; ++i) { ca[i] = pa[i]; cb[i] = pb[i]; }
-  for (int q = 0; q < n_quads; q += Q) {
-    const int nq = q + Q < n_quads ? q + Q : q;
-    v4f na[Q], nb[Q];
+  for (int i = 0; i < Q; ++i) { a0[i] = pa[i]; b0[i] = pb[i]; }
+  int q = 0;
+  while (true) {
+    {
+      const int nq = q + Q < n_quads ? q + Q : q;
 #pragma unroll
-    for (int i = 0; i < Q; ++i) { na[i] = pa[nq + i]; nb[i] = pb[nq + i]; }
+      for (int i = 0; i < Q; ++i) { a1[i] = pa[nq + i]; b1[i] = pb[nq + i]; }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < Q; ++i) {
-      sa -= ca[i].x; sb -= cb[i].x;
-      sa -= ca[i].y; sb -= cb[i].y;
-      sa -= ca[i].z; sb -= cb[i].z;
-      sa -= ca[i].w; sb -= cb[i].w;
+      for (int i = 0; i < Q; ++i) {
+        sa -= a0[i].x; sb -= b0[i].x;
+        sa -= a0[i].y; sb -= b0[i].y;
+        sa -= a0[i].z; sb -= b0[i].z;
+        sa -= a0[i].w; sb -= b0[i].w;
+      }
+      q += Q;
+      if (q >= n_quads) break;
     }
+    {
+      const int nq = q + Q < n_quads ? q + Q : q;
 #pragma unroll
-    for (int i = 0; i < Q; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+      for (int i = 0; i < Q; ++i) { a0[i] = pa[nq + i]; b0[i] = pb[nq + i]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        sa -= a1[i].x; sb -= b1[i].x;
+        sa -= a1[i].y; sb -= b1[i].y;
+        sa -= a1[i].z; sb -= b1[i].z;
+        sa -= a1[i].w; sb -= b1[i].w;
+      }
+      q += Q;
+      if (q >= n_quads) break;
+    }
   }
 }
 
@@ -1155,33 +1205,56 @@ struct SplitExchange {
 };
 constexpr int kExchangeFieldBits = 5;
 
-// returns false when the exchange timed out (block-uniform)
-__device__ __forceinline__ bool split_exchange_state(const SplitExchange& x, int round, const Lds& s, bool with_region,
-                                                     float* ps, int np, bool with_depth) {
+struct SplitExchangeView {  // what publish and collect derive from the descriptor
+  uint32_t tag;
+  int lmask, nfr, nfd, nf, region_row0, depth_row0;
+  __attribute__((address_space(1))) unsigned long long* slot;
+  float* lds0;
+};
+__device__ __forceinline__ SplitExchangeView split_exchange_view(const SplitExchange& x, int round, const Lds& s,
+                                                                 bool with_region, float* ps, int np, bool with_depth) {
+  SplitExchangeView v;
+  v.tag = x.seq * 64u + (uint32_t)round + 1u;
+  v.lmask = (1 << x.lshift) - 1;
+  v.nfr = with_region ? x.n_region_fields : 0;
+  v.nfd = with_depth ? x.n_depth_fields : 0;
+  v.nf = v.nfr + v.nfd;
+  v.slot = x.granules + ((size_t)(round & 1) * x.n_parts << (kExchangeFieldBits + x.lshift));
+  v.lds0 = s.misc;  // the lowest address of the workgroup's LDS carve-up
+  // field f -> element offset of its row from lds0
+  v.region_row0 = int(s.state - v.lds0) + LS_DIST0 * s.nl;
+  v.depth_row0 = int(ps - v.lds0) + x.first_depth_row * np;
+  return v;
+}
+__device__ __forceinline__ void split_exchange_publish(const SplitExchange& x, int round, const Lds& s, bool with_region,
+                                                       float* ps, int np, bool with_depth) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const uint32_t tag = x.seq * 64u + (uint32_t)round + 1u;
-  const int lmask = (1 << x.lshift) - 1;
-  const int nfr = with_region ? x.n_region_fields : 0, nfd = with_depth ? x.n_depth_fields : 0, nf = nfr + nfd;
-  auto* slot = x.granules + ((size_t)(round & 1) * x.n_parts << (kExchangeFieldBits + x.lshift));
-  float* const lds0 = s.misc;  // the lowest address of the workgroup's LDS carve-up
-  // field f -> element offset of its row from lds0, row length, elements per part
-  const int region_row0 = int(s.state - lds0) + LS_DIST0 * s.nl;
-  const int depth_row0 = int(ps - lds0) + x.first_depth_row * np;
-  // publish this part's elements
-  {
-    auto* mine = slot + ((size_t)x.part << (kExchangeFieldBits + x.lshift));
-    for (int idx = tid; idx < (nf << x.lshift); idx += nt) {
-      const int f = idx >> x.lshift, l = idx & lmask;
-      const bool region = f < nfr;
-      const int per_part = region ? x.per_part_lines : x.per_part_points, count = region ? s.nl : np;
-      const int e = x.part * per_part + l;
-      if (l < per_part && e < count) {
-        const float v = lds0[(region ? region_row0 + f * s.nl : depth_row0 + (f - nfr) * np) + e];
-        const unsigned long long g = (static_cast<unsigned long long>(tag) << 32) | (unsigned)__float_as_int(v);
-        __hip_atomic_store(mine + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+  const SplitExchangeView v = split_exchange_view(x, round, s, with_region, ps, np, with_depth);
+  const uint32_t tag = v.tag;
+  const int lmask = v.lmask, nfr = v.nfr, nf = v.nf, region_row0 = v.region_row0, depth_row0 = v.depth_row0;
+  float* const lds0 = v.lds0;
+  auto* mine = v.slot + ((size_t)x.part << (kExchangeFieldBits + x.lshift));
+  for (int idx = tid; idx < (nf << x.lshift); idx += nt) {
+    const int f = idx >> x.lshift, l = idx & lmask;
+    const bool region = f < nfr;
+    const int per_part = region ? x.per_part_lines : x.per_part_points, count = region ? s.nl : np;
+    const int e = x.part * per_part + l;
+    if (l < per_part && e < count) {
+      const float val = lds0[(region ? region_row0 + f * s.nl : depth_row0 + (f - nfr) * np) + e];
+      const unsigned long long g = (static_cast<unsigned long long>(tag) << 32) | (unsigned)__float_as_int(val);
+      __hip_atomic_store(mine + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+// returns false when the exchange timed out (block-uniform); ends with a barrier
+__device__ __forceinline__ bool split_exchange_collect(const SplitExchange& x, int round, const Lds& s, bool with_region,
+                                                       float* ps, int np, bool with_depth) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const SplitExchangeView v = split_exchange_view(x, round, s, with_region, ps, np, with_depth);
+  const uint32_t tag = v.tag;
+  const int lmask = v.lmask, nfr = v.nfr, nf = v.nf, region_row0 = v.region_row0, depth_row0 = v.depth_row0;
+  float* const lds0 = v.lds0;
+  auto* slot = v.slot;
   // collect the other parts': thread -> (part q, element l) fixed; its wave takes the fields group, group + n_groups, ...
   // (the field index is wave-uniform: granule row and LDS row are scalar, per thread only one offset of each kind)
   bool timed_out = false;
@@ -2150,14 +2223,24 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     }();
     float u = u0, v = v0;
     G<uint8_t> image = as_global(cam.image);
-    for (int k = 0; k < n_valid; ++k) {
-      uint32_t off = __umul24((uint32_t)f2i(v), cam.pitch) + (uint32_t)f2i(u) * 3u;
-      uint32_t px = reinterpret_cast<G<PackedU32>>(image + off)->v;
-      const uint32_t bin = ((px & 0xffu) >> bitshift) * n_bins2 + (((px >> 8) & 0xffu) >> bitshift) * n_bins +
-                           (((px >> 16) & 0xffu) >> bitshift) - (uint32_t)bin_lo;
-      if (SHARED || bin < n_own_bins) count_add(&counts[bin], inc);
-      u += du;
-      v += dv;
+    // eight pixels at a time: the loads of a batch are independent (the float chain only feeds the addresses), the
+    // count-table atomics follow once all are issued
+    for (int k0 = 0; k0 < n_valid; k0 += 8) {
+      uint32_t px[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t off = __umul24((uint32_t)f2i(v), cam.pitch) + (uint32_t)f2i(u) * 3u;
+        px[j] = 0;
+        if (k0 + j < n_valid) px[j] = reinterpret_cast<G<PackedU32>>(image + off)->v;
+        u += du;
+        v += dv;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t bin = ((px[j] & 0xffu) >> bitshift) * n_bins2 + (((px[j] >> 8) & 0xffu) >> bitshift) * n_bins +
+                             (((px[j] >> 16) & 0xffu) >> bitshift) - (uint32_t)bin_lo;
+        if (k0 + j < n_valid && (SHARED || bin < n_own_bins)) count_add(&counts[bin], inc);
+      }
     }
     if (background) sb += (unsigned)n_valid;
     else sf += (unsigned)n_valid;
@@ -2354,6 +2437,7 @@ __device__ __forceinline__ void region_correspondence_body(const RegionModDev* m
   if (dcam) b2dc = mul_pose(load_pose(dcam->world2camera), b2w);
   region_correspondences<HIST_LDS>(m, cam, dcam, b2c, b2dc, iteration, corr_iteration, s);
   region_moments(m, s);
+  __syncthreads();
   // LDS -> global line state (compact stride n_lines_max)
   for (int i = threadIdx.x; i < LS_FIELDS * m.n_lines_max; i += blockDim.x) {
     int f = i / m.n_lines_max, l = i - f * m.n_lines_max;
@@ -2552,13 +2636,20 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       }
       if constexpr (SPLIT) {
         PHASE_T0();
-        if (!split_exchange_state(exchange, c, s, rm != nullptr, ps, np, dm != nullptr)) return;
+        // publish the own part's results, take the moments of the own lines while the other parts' results are on
+        // their way, collect them, then the moments of the received lines
+        split_exchange_publish(exchange, c, s, rm != nullptr, ps, np, dm != nullptr);
+        if (rm) region_moments(*rm, s, line_lo, line_hi, true);
+        if (!split_exchange_collect(exchange, c, s, rm != nullptr, ps, np, dm != nullptr)) return;
         PHASE_MARK(22);
+        if (rm) region_moments(*rm, s, line_lo, line_hi, false);
+      } else {
+        if (rm) region_moments(*rm, s);
       }
       {
         PHASE_T0();
-        if (rm) region_moments(*rm, s);
         if (dm) depth_correspondences_vote(*dm, iteration, ps, np, s.misc);
+        else __syncthreads();
         PHASE_MARK(25);
       }
     }

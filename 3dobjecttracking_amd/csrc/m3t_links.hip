@@ -4,9 +4,9 @@
 // constraint rows (src/optimizer.cpp:144-167, 281-346).  Included by m3t_hip_api.hip after
 // m3t_kernels.hip (same translation unit, shares its pose helpers).
 //
-// These systems are tiny (dof <= a few dozen) and strictly sequential, so one lane per
-// kinematic structure executes them; the data-parallel work (correspondences, g/H) stays in
-// the modality kernels.  The optimisation is split in two kernels at the only point where a
+// These systems are tiny (dof <= a few dozen): one wave per kinematic structure executes them with
+// its work arrays in LDS (lanes over matrix elements and links); the data-parallel work
+// (correspondences, g/H) stays in the modality kernels.  The optimisation is split in two kernels at the only point where a
 // structure spread over several GPUs exchanges data:
 //   links_project_kernel : J per link, link g/H, partial A = sum J^T H J (lower), b = sum J^T g
 //   [ one all-reduce(sum) over the stacked [dof*dof | dof] buffers of all structures ]
@@ -54,7 +54,7 @@ namespace {
 
 __host__ __device__ inline size_t tree_work_floats(int n_links, int dof, int n_rows) {
   size_t size = size_t(dof) + n_rows;
-  return size_t(n_links) * (6 * dof + 42) + size * size + 4 * size + size_t(n_rows) * (dof + 1) + 2 * 6 * 6 + 64;
+  return size_t(n_links) * (12 * dof + 42 + 72) + size * size + 4 * size + size_t(n_rows) * (dof + 1) + 2 * 6 * 6 + 64;
 }
 
 __device__ inline void affine_to_array(const Affine& a, float* p) {
@@ -165,63 +165,6 @@ __device__ void constraint_unprojected_jacobian(const ConstraintDev& c, const Af
   }
 }
 
-// Eigen::LDLT<MatrixXf, Lower> + solve (optimizer.cpp:162-163), any size, in global scratch
-__device__ void ldlt_solve_dynamic(float* a, float* x, int n, float* temp, int* trans) {
-#define A_(r, c) a[(size_t)(c) * n + (r)]
-  bool degenerate = false;
-  for (int k = 0; k < n && !degenerate; ++k) {
-    int piv = k;
-    float best = fabsf(A_(k, k));
-    for (int i = k + 1; i < n; ++i)
-      if (fabsf(A_(i, i)) > best) { best = fabsf(A_(i, i)); piv = i; }
-    trans[k] = piv;
-    if (piv != k) {
-      int s = n - piv - 1;
-      for (int c = 0; c < k; ++c) { float t = A_(k, c); A_(k, c) = A_(piv, c); A_(piv, c) = t; }
-      for (int i = 0; i < s; ++i) { float t = A_(piv + 1 + i, k); A_(piv + 1 + i, k) = A_(piv + 1 + i, piv); A_(piv + 1 + i, piv) = t; }
-      { float t = A_(k, k); A_(k, k) = A_(piv, piv); A_(piv, piv) = t; }
-      for (int i = k + 1; i < piv; ++i) { float t = A_(i, k); A_(i, k) = A_(piv, i); A_(piv, i) = t; }
-    }
-    int rs = n - k - 1;
-    if (k > 0) {
-      for (int c = 0; c < k; ++c) temp[c] = A_(c, c) * A_(k, c);
-      float acc = 0.0f;
-      for (int c = 0; c < k; ++c) acc += A_(k, c) * temp[c];
-      A_(k, k) -= acc;
-      for (int i = 0; i < rs; ++i) {
-        float s = 0.0f;
-        for (int c = 0; c < k; ++c) s += A_(k + 1 + i, c) * temp[c];
-        A_(k + 1 + i, k) -= s;
-      }
-    }
-    float akk = A_(k, k);
-    bool pivot_valid = fabsf(akk) > 0.0f;
-    if (k == 0 && !pivot_valid) {
-      for (int j = 0; j < n; ++j) trans[j] = j;
-      degenerate = true;
-    } else if (rs > 0 && pivot_valid) {
-      for (int i = 0; i < rs; ++i) A_(k + 1 + i, k) /= akk;
-    }
-  }
-  for (int k = 0; k < n; ++k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
-  for (int i = 0; i < n; ++i) {
-    float s = x[i];
-    for (int c = 0; c < i; ++c) s -= A_(i, c) * x[c];
-    x[i] = s;
-  }
-  for (int i = 0; i < n; ++i) {
-    if (fabsf(A_(i, i)) > 1.17549435e-38f) x[i] /= A_(i, i);
-    else x[i] = 0.0f;
-  }
-  for (int i = n - 1; i >= 0; --i) {
-    float s = x[i];
-    for (int r = i + 1; r < n; ++r) s -= A_(r, i) * x[r];
-    x[i] = s;
-  }
-  for (int k = n - 1; k >= 0; --k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
-#undef A_
-}
-
 }  // namespace
 
 // SoftConstraint::AddGradientsAndHessiansToLink soft_constraint.cpp:220-272, one residual group
@@ -286,168 +229,299 @@ __device__ void soft_constraint_add_group(const SoftConstraintDev& sc, bool rota
     }
 }
 
+// ---------------------------------------------------------------------------
+// One wave (a 64-thread workgroup) per kinematic structure, all structures of a frame in one launch.  The work arrays
+// live in LDS when they fit (tree_work_floats <= ~38 K floats: up to ~40 bodies), else in the structure's global
+// scratch; lanes share the loops over matrix elements / links, the accumulation order of every element stays the
+// serial one (the oracle's), so the poses equal the CPU restatement bit for bit.
+// ---------------------------------------------------------------------------
+struct TreeWork {
+  float *J, *GH, *AD, *HJ, *A, *b, *temp, *cres, *j1, *j2;
+  int* trans;
+};
+__device__ __forceinline__ TreeWork tree_carve(float* w, int n_links, int dof, int n_rows) {
+  const int size = dof + n_rows;
+  TreeWork t;
+  t.J = w;                                  // [n_links][6 * dof]
+  t.GH = t.J + (size_t)n_links * 6 * dof;   // [n_links][42]
+  t.AD = t.GH + (size_t)n_links * 42;       // [n_links][72]: adjoint(parent2body) | adjoint(joint2body); later [n_links][12] variations
+  t.HJ = t.AD + (size_t)n_links * 72;       // [n_links][6 * dof]
+  t.A = t.HJ + (size_t)n_links * 6 * dof;   // [size][size]
+  t.b = t.A + (size_t)size * size;
+  t.temp = t.b + size;
+  t.trans = reinterpret_cast<int*>(t.temp + size);
+  t.cres = t.temp + 2 * size + size;        // [n_rows]
+  t.j1 = t.cres + n_rows + (size_t)n_rows * dof;
+  t.j2 = t.j1 + 36;
+  return t;
+}
+
+// Eigen::LDLT<MatrixXf, Lower> + solve (optimizer.cpp:162-163) by one wave: the oracle's LdltSolve, its loops over
+// rows / columns spread over the lanes
+__device__ void ldlt_solve_wave(float* a, float* x, int n, float* temp, int* trans) {
+#define A_(r, c) a[(size_t)(c) * n + (r)]
+  const int lane = threadIdx.x;
+  bool degenerate = false;
+  for (int k = 0; k < n && !degenerate; ++k) {
+    // first largest |A(i,i)|, i >= k (a NaN never beats `best`; a NaN at k keeps piv = k)
+    float v = -1.0f;
+    int vi = INT_MAX;
+    for (int i = k + lane; i < n; i += kWave) {
+      const float d = fabsf(A_(i, i));
+      const float key = i == k ? (d != d ? __int_as_float(0x7f800000) : d) : (d != d ? -1.0f : d);
+      if (key > v) { v = key; vi = i; }
+    }
+    const float m = wave_max(v);
+    const int piv = wave_min_i(v == m ? vi : INT_MAX);
+    if (lane == 0) trans[k] = piv;
+    if (piv != k) {
+      for (int c = lane; c < k; c += kWave) { float t = A_(k, c); A_(k, c) = A_(piv, c); A_(piv, c) = t; }
+      for (int i = piv + 1 + lane; i < n; i += kWave) { float t = A_(i, k); A_(i, k) = A_(i, piv); A_(i, piv) = t; }
+      if (lane == 0) { float t = A_(k, k); A_(k, k) = A_(piv, piv); A_(piv, piv) = t; }
+      for (int i = k + 1 + lane; i < piv; i += kWave) { float t = A_(i, k); A_(i, k) = A_(piv, i); A_(piv, i) = t; }
+    }
+    __syncthreads();
+    if (k > 0) {
+      for (int c = lane; c < k; c += kWave) temp[c] = A_(c, c) * A_(k, c);
+      __syncthreads();
+      for (int i = k + lane; i < n; i += kWave) {  // i == k: the pivot; below: A21 -= A20 * temp
+        float sacc = 0.0f;
+        for (int c = 0; c < k; ++c) sacc += A_(i, c) * temp[c];
+        A_(i, k) -= sacc;
+      }
+      __syncthreads();
+    }
+    const float akk = A_(k, k);
+    const bool pivot_valid = fabsf(akk) > 0.0f;
+    if (k == 0 && !pivot_valid) {
+      for (int j = lane; j < n; j += kWave) trans[j] = j;
+      degenerate = true;
+    } else if (pivot_valid) {
+      for (int i = k + 1 + lane; i < n; i += kWave) A_(i, k) /= akk;
+    }
+    __syncthreads();
+  }
+  if (lane == 0)
+    for (int k = 0; k < n; ++k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
+  __syncthreads();
+  for (int c = 0; c + 1 < n; ++c) {  // L y = P b, column sweep: row i sees its c in ascending order
+    const float xc = x[c];
+    for (int i = c + 1 + lane; i < n; i += kWave) x[i] -= A_(i, c) * xc;
+    __syncthreads();
+  }
+  for (int i = lane; i < n; i += kWave) {
+    if (fabsf(A_(i, i)) > 1.17549435e-38f) x[i] /= A_(i, i);
+    else x[i] = 0.0f;
+  }
+  __syncthreads();
+  for (int i = n - 1; i >= 0; --i) {  // L^T w = z: products by the lanes, the ordered subtraction by one
+    for (int r = i + 1 + lane; r < n; r += kWave) temp[r] = A_(r, i) * x[r];
+    __syncthreads();
+    if (lane == 0) {
+      float sacc = x[i];
+      for (int r = i + 1; r < n; ++r) sacc -= temp[r];
+      x[i] = sacc;
+    }
+    __syncthreads();
+  }
+  if (lane == 0)
+    for (int k = n - 1; k >= 0; --k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
+  __syncthreads();
+#undef A_
+}
+
 extern "C" {
 
 // Optimizer::CalculateDataLinks (:281-296) + AddProjectedGradientsAndHessians (:309-321)
-__global__ void links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses) {
-  int oi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (oi >= n_opts) return;
-  const TreeOptDev& o = opts[oi];
-  const int dof = o.dof;
-  float* jac_all = o.work;                                // [n_links][6 * dof]
-  float* gh_all = jac_all + (size_t)o.n_links * 6 * dof;  // [n_links][42]
-  for (int li = 0; li < o.n_links; ++li) {
+__global__ void __launch_bounds__(64)
+links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses, int work_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) float tree_lds[];
+  const TreeOptDev& o = opts[blockIdx.x];
+  const int lane = threadIdx.x, dof = o.dof, n_links = o.n_links;
+  const TreeWork w = tree_carve(work_in_lds ? tree_lds : o.work, n_links, dof, o.n_rows);
+  // adjoints of every link, one lane per link (they depend on the link's own joint poses only)
+  for (int li = lane; li < n_links; li += kWave) {
     const LinkDev& l = o.links[li];
-    float* J = jac_all + (size_t)li * 6 * dof;
-    // Link::CalculateJacobian link.cpp:159-182
-    for (int i = 0; i < 6 * dof; ++i) J[i] = 0.0f;
-    float ad[36];
-    if (l.parent >= 0) {
-      const float* Jp = jac_all + (size_t)l.parent * 6 * dof;
-      Affine parent2body = inverse_pose(mul_pose(load_pose(l.joint2parent), load_pose(l.body2joint)));
-      adjoint6(parent2body, ad);
-      for (int c = 0; c < dof; ++c)
-        for (int r = 0; r < 6; ++r) {
-          float s = 0.0f;
-          for (int k = 0; k < 6; ++k) s += ad[k * 6 + r] * Jp[(size_t)c * 6 + k];
-          J[(size_t)c * 6 + r] = s;
-        }
-    }
-    adjoint6(inverse_pose(load_pose(l.body2joint)), ad);
-    int jidx = l.first_jacobian_index;
-    for (int d = 0; d < 6; ++d)
-      if (l.free_directions[d]) {
-        for (int r = 0; r < 6; ++r) J[(size_t)jidx * 6 + r] = ad[d * 6 + r];
-        jidx++;
+    if (l.parent >= 0)
+      adjoint6(inverse_pose(mul_pose(load_pose(l.joint2parent), load_pose(l.body2joint))), w.AD + (size_t)li * 72);
+    adjoint6(inverse_pose(load_pose(l.body2joint)), w.AD + (size_t)li * 72 + 36);
+  }
+  __syncthreads();
+  // Link::CalculateJacobian link.cpp:159-182, parents before children
+  for (int li = 0; li < n_links; ++li) {
+    const LinkDev& l = o.links[li];
+    float* J = w.J + (size_t)li * 6 * dof;
+    const float* ad = w.AD + (size_t)li * 72;
+    const float* Jp = l.parent >= 0 ? w.J + (size_t)l.parent * 6 * dof : nullptr;
+    for (int e = lane; e < 6 * dof; e += kWave) {
+      const int c = e / 6, r = e - c * 6;
+      float v = 0.0f;
+      if (Jp) {
+        float sacc = 0.0f;
+        for (int k = 0; k < 6; ++k) sacc += ad[k * 6 + r] * Jp[(size_t)c * 6 + k];
+        v = sacc;
       }
-    // Link::CalculateGradientAndHessian link.cpp:184-193
-    float* gh = gh_all + (size_t)li * 42;
-    for (int i = 0; i < 42; ++i) gh[i] = 0.0f;
-    for (int m = 0; m < l.n_gh; ++m)
-      for (int i = 0; i < 42; ++i) gh[i] += l.gh[m][i];
+      J[e] = v;
+    }
+    __syncthreads();
+    if (lane < 36) {
+      const int d = lane / 6, r = lane - d * 6;
+      if (l.free_directions[d]) {
+        int jidx = l.first_jacobian_index;
+        for (int dd = 0; dd < d; ++dd) jidx += l.free_directions[dd] ? 1 : 0;
+        J[(size_t)jidx * 6 + r] = ad[36 + d * 6 + r];
+      }
+    }
+    __syncthreads();
   }
+  // Link::CalculateGradientAndHessian link.cpp:184-193
+  for (int e = lane; e < n_links * 42; e += kWave) {
+    const int li = e / 42, i = e - li * 42;
+    const LinkDev& l = o.links[li];
+    float sacc = 0.0f;
+    for (int m = 0; m < l.n_gh; ++m) sacc += l.gh[m][i];
+    w.GH[e] = sacc;
+  }
+  __syncthreads();
   // SoftConstraint::AddGradientsAndHessiansToLinks soft_constraint.cpp:113-131 (optimizer.cpp:283-284)
-  for (int si = 0; si < o.n_soft; ++si) {
-    const SoftConstraintDev& sc = o.soft[si];
-    Affine b12j1 = load_pose(sc.joint.body12joint1);
-    Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(link_pose(o.links[sc.joint.link1], body_poses))),
-                                   link_pose(o.links[sc.joint.link2], body_poses));
-    Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(sc.joint.body22joint2)));
-    for (int which = 0; which < 2; ++which) {
-      float g[6], h[36];
-      for (int i = 0; i < 6; ++i) g[i] = 0.0f;
-      for (int i = 0; i < 36; ++i) h[i] = 0.0f;
-      const Affine& body2joint1 = which == 0 ? b12j1 : body22joint1;
-      const float sign = which == 0 ? -1.0f : 1.0f;
-      soft_constraint_add_group(sc, true, joint22joint1, body2joint1, sign, g, h);
-      soft_constraint_add_group(sc, false, joint22joint1, body2joint1, sign, g, h);
-      float* gh = gh_all + (size_t)(which == 0 ? sc.joint.link1 : sc.joint.link2) * 42;
-      for (int i = 0; i < 6; ++i) gh[i] += g[i];
-      for (int i = 0; i < 36; ++i) gh[6 + i] += h[i];
+  if (lane == 0) {
+    for (int si = 0; si < o.n_soft; ++si) {
+      const SoftConstraintDev& sc = o.soft[si];
+      Affine b12j1 = load_pose(sc.joint.body12joint1);
+      Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(link_pose(o.links[sc.joint.link1], body_poses))),
+                                     link_pose(o.links[sc.joint.link2], body_poses));
+      Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(sc.joint.body22joint2)));
+      for (int which = 0; which < 2; ++which) {
+        float g[6], h[36];
+        for (int i = 0; i < 6; ++i) g[i] = 0.0f;
+        for (int i = 0; i < 36; ++i) h[i] = 0.0f;
+        const Affine& body2joint1 = which == 0 ? b12j1 : body22joint1;
+        const float sign = which == 0 ? -1.0f : 1.0f;
+        soft_constraint_add_group(sc, true, joint22joint1, body2joint1, sign, g, h);
+        soft_constraint_add_group(sc, false, joint22joint1, body2joint1, sign, g, h);
+        float* gh = w.GH + (size_t)(which == 0 ? sc.joint.link1 : sc.joint.link2) * 42;
+        for (int i = 0; i < 6; ++i) gh[i] += g[i];
+        for (int i = 0; i < 36; ++i) gh[6 + i] += h[i];
+      }
     }
   }
+  __syncthreads();
+  // H J of every link, then b = sum J^T g and A = -sum J^T (H J) (lower), link after link per element
+  for (int e = lane; e < n_links * 6 * dof; e += kWave) {
+    const int li = e / (6 * dof), rem = e - li * 6 * dof, c = rem / 6, r = rem - c * 6;
+    const float* H = w.GH + (size_t)li * 42 + 6;
+    const float* J = w.J + (size_t)li * 6 * dof;
+    float sacc = 0.0f;
+    for (int k = 0; k < 6; ++k) sacc += H[k * 6 + r] * J[(size_t)c * 6 + k];
+    w.HJ[e] = sacc;
+  }
+  __syncthreads();
   float* A = o.partial;
   float* b = o.partial + (size_t)dof * dof;
-  for (int i = 0; i < dof * dof + dof; ++i) o.partial[i] = 0.0f;
-  float* hj = gh_all + (size_t)o.n_links * 42;  // reuse the head of the solve scratch: 6 * dof floats
-  for (int li = 0; li < o.n_links; ++li) {
-    const float* J = jac_all + (size_t)li * 6 * dof;
-    const float* g = gh_all + (size_t)li * 42;
-    const float* H = g + 6;
-    for (int i = 0; i < dof; ++i) {
-      float s = 0.0f;
-      for (int k = 0; k < 6; ++k) s += J[(size_t)i * 6 + k] * g[k];
-      b[i] += s;
+  for (int i = lane; i < dof; i += kWave) {
+    float acc = 0.0f;
+    for (int li = 0; li < n_links; ++li) {
+      const float* J = w.J + (size_t)li * 6 * dof;
+      const float* g = w.GH + (size_t)li * 42;
+      float sacc = 0.0f;
+      for (int k = 0; k < 6; ++k) sacc += J[(size_t)i * 6 + k] * g[k];
+      acc += sacc;
     }
-    for (int c = 0; c < dof; ++c)
-      for (int r = 0; r < 6; ++r) {
-        float s = 0.0f;
-        for (int k = 0; k < 6; ++k) s += H[k * 6 + r] * J[(size_t)c * 6 + k];
-        hj[(size_t)c * 6 + r] = s;
-      }
-    for (int c = 0; c < dof; ++c)
-      for (int r = c; r < dof; ++r) {
-        float s = 0.0f;
-        for (int k = 0; k < 6; ++k) s += J[(size_t)r * 6 + k] * hj[(size_t)c * 6 + k];
-        A[(size_t)c * dof + r] -= s;
-      }
+    b[i] = acc;
   }
+  for (int e = lane; e < dof * dof; e += kWave) {
+    const int c = e / dof, r = e - c * dof;
+    float acc = 0.0f;
+    if (r >= c) {
+      for (int li = 0; li < n_links; ++li) {
+        const float* J = w.J + (size_t)li * 6 * dof;
+        const float* hj = w.HJ + (size_t)li * 6 * dof;
+        float sacc = 0.0f;
+        for (int k = 0; k < 6; ++k) sacc += J[(size_t)r * 6 + k] * hj[(size_t)c * 6 + k];
+        acc -= sacc;
+      }
+    }
+    A[e] = acc;
+  }
+  if (work_in_lds)  // the Jacobians are needed again by the solve kernel (constraint rows)
+    for (int e = lane; e < n_links * 6 * dof; e += kWave) o.work[e] = w.J[e];
 }
 
 // the rest of Optimizer::CalculateOptimization + Optimizer::UpdatePoses (:335-346)
-__global__ void links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int zero_theta) {
-  int oi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (oi >= n_opts) return;
-  const TreeOptDev& o = opts[oi];
-  const int dof = o.dof, size = o.dof + o.n_rows;
-  float* jac_all = o.work;
-  float* gh_all = jac_all + (size_t)o.n_links * 6 * dof;
-  float* A = gh_all + (size_t)o.n_links * 42;
-  float* b = A + (size_t)size * size;
-  float* temp = b + size;
-  int* trans = reinterpret_cast<int*>(temp + size);
-  float* cres = temp + 2 * size + size;  // [n_rows]
-  float* cjac = cres + o.n_rows;         // [n_rows x dof] (per constraint block, column-major n_c x dof)
-  float* j1 = cjac + (size_t)o.n_rows * dof;
-  float* j2 = j1 + 36;
-  for (size_t i = 0; i < (size_t)size * size; ++i) A[i] = 0.0f;
-  for (int i = 0; i < size; ++i) b[i] = 0.0f;
+__global__ void __launch_bounds__(64)
+links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int zero_theta, int work_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) float tree_lds[];
+  const TreeOptDev& o = opts[blockIdx.x];
+  const int lane = threadIdx.x, dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
+  const TreeWork w = tree_carve(work_in_lds ? tree_lds : o.work, n_links, dof, o.n_rows);
+  float* A = w.A;
+  float* b = w.b;
+  if (work_in_lds)
+    for (int e = lane; e < n_links * 6 * dof; e += kWave) w.J[e] = o.work[e];
+  for (int e = lane; e < size * size; e += kWave) {
+    const int c = e / size, r = e - c * size;
+    A[e] = (!zero_theta && c < dof && r < dof) ? o.partial[(size_t)c * dof + r] : 0.0f;
+  }
+  for (int i = lane; i < size; i += kWave) b[i] = (!zero_theta && i < dof) ? o.partial[(size_t)dof * dof + i] : 0.0f;
+  __syncthreads();
   if (!zero_theta) {  // zero_theta: Optimizer::CalculateConsistentPoses optimizer.cpp:135 (theta = 0)
-  for (int c = 0; c < dof; ++c)
-    for (int r = 0; r < dof; ++r) A[(size_t)c * size + r] = o.partial[(size_t)c * dof + r];
-  for (int i = 0; i < dof; ++i) b[i] = o.partial[(size_t)dof * dof + i];
-  // constraints: Constraint::CalculateResidualAndConstraintJacobian constraint.cpp:81-102
-  int idx = dof;
-  for (int ci = 0; ci < o.n_constraints; ++ci) {
-    const ConstraintDev& c = o.constraints[ci];
-    const LinkDev& l1 = o.links[c.link1];
-    const LinkDev& l2 = o.links[c.link2];
-    Affine b12j1 = load_pose(c.body12joint1);
-    Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(link_pose(l1, body_poses))), link_pose(l2, body_poses));
-    Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(c.body22joint2)));
-    float angle, axis[3];
-    angle_axis(joint22joint1.l, &angle, axis);
-    float rv[3] = {angle * axis[0], angle * axis[1], angle * axis[2]};
-    int n_c = c.n, ri = 0;
-    for (int d = 0; d < 6; ++d)
-      if (c.directions[d]) cres[ri++] = d < 3 ? rv[d] : joint22joint1.t[d - 3];
-    constraint_unprojected_jacobian(c, joint22joint1, body22joint1, j2);
-    constraint_unprojected_jacobian(c, joint22joint1, b12j1, j1);
-    const float* J1 = jac_all + (size_t)c.link1 * 6 * dof;
-    const float* J2 = jac_all + (size_t)c.link2 * 6 * dof;
-    for (int col = 0; col < dof; ++col)
-      for (int r = 0; r < n_c; ++r) {
+    // constraints: Constraint::CalculateResidualAndConstraintJacobian constraint.cpp:81-102
+    int idx = dof;
+    for (int ci = 0; ci < o.n_constraints; ++ci) {
+      const ConstraintDev& c = o.constraints[ci];
+      const int n_c = c.n;
+      if (lane == 0) {
+        const LinkDev& l1 = o.links[c.link1];
+        const LinkDev& l2 = o.links[c.link2];
+        Affine b12j1 = load_pose(c.body12joint1);
+        Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(link_pose(l1, body_poses))), link_pose(l2, body_poses));
+        Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(c.body22joint2)));
+        float angle, axis[3];
+        angle_axis(joint22joint1.l, &angle, axis);
+        float rv[3] = {angle * axis[0], angle * axis[1], angle * axis[2]};
+        int ri = 0;
+        for (int d = 0; d < 6; ++d)
+          if (c.directions[d]) w.cres[ri++] = d < 3 ? rv[d] : joint22joint1.t[d - 3];
+        constraint_unprojected_jacobian(c, joint22joint1, body22joint1, w.j2);
+        constraint_unprojected_jacobian(c, joint22joint1, b12j1, w.j1);
+      }
+      __syncthreads();
+      const float* J1 = w.J + (size_t)c.link1 * 6 * dof;
+      const float* J2 = w.J + (size_t)c.link2 * 6 * dof;
+      for (int e = lane; e < dof * n_c; e += kWave) {
+        const int col = e / n_c, r = e - col * n_c;
         float s2 = 0.0f, s1 = 0.0f;
         for (int k = 0; k < 6; ++k) {
-          s2 += j2[k * n_c + r] * J2[(size_t)col * 6 + k];
-          s1 += j1[k * n_c + r] * J1[(size_t)col * 6 + k];
+          s2 += w.j2[k * n_c + r] * J2[(size_t)col * 6 + k];
+          s1 += w.j1[k * n_c + r] * J1[(size_t)col * 6 + k];
         }
-        cjac[(size_t)col * n_c + r] = s2 - s1;
+        // AddResidualsAndConstraintJacobians optimizer.cpp:323-333
+        A[(size_t)col * size + idx + r] = -(s2 - s1);
       }
-    // AddResidualsAndConstraintJacobians optimizer.cpp:323-333
-    for (int r = 0; r < n_c; ++r) {
-      b[idx + r] = cres[r];
-      for (int col = 0; col < dof; ++col) A[(size_t)col * size + idx + r] = -cjac[(size_t)col * n_c + r];
+      if (lane < n_c) b[idx + lane] = w.cres[lane];
+      __syncthreads();
+      idx += n_c;
     }
-    idx += n_c;
+    // Tikhonov vector optimizer.cpp:252-271 (free-direction order, rotation first)
+    for (int li = lane; li < n_links; li += kWave) {
+      const LinkDev& l = o.links[li];
+      int j = l.first_jacobian_index;
+      for (int d = 0; d < 6; ++d)
+        if (l.free_directions[d]) {
+          A[(size_t)j * size + j] += d < 3 ? o.tikhonov_rotation : o.tikhonov_translation;
+          j++;
+        }
+    }
+    __syncthreads();
+    ldlt_solve_wave(A, b, size, w.temp, w.trans);
+    int has_nan = 0;
+    for (int i = lane; i < size; i += kWave) has_nan |= (b[i] != b[i]) ? 1 : 0;
+    if (__syncthreads_or(has_nan)) return;  // NaN guard optimizer.cpp:165
   }
-  // Tikhonov vector optimizer.cpp:252-271 (free-direction order, rotation first)
-  for (int li = 0; li < o.n_links; ++li) {
+  // Link::UpdatePoses link.cpp:205-241: the variations of all links at once (one lane per link) ...
+  float* var_all = w.AD;  // [n_links][12]
+  for (int li = lane; li < n_links; li += kWave) {
     const LinkDev& l = o.links[li];
-    int j = l.first_jacobian_index;
-    for (int d = 0; d < 6; ++d)
-      if (l.free_directions[d]) {
-        A[(size_t)j * size + j] += d < 3 ? o.tikhonov_rotation : o.tikhonov_translation;
-        j++;
-      }
-  }
-  ldlt_solve_dynamic(A, b, size, temp, trans);
-  for (int i = 0; i < size; ++i)
-    if (b[i] != b[i]) return;  // NaN guard optimizer.cpp:165
-  }
-  // Link::UpdatePoses link.cpp:205-241, parents before children
-  for (int li = 0; li < o.n_links; ++li) {
-    LinkDev& l = o.links[li];
     float th[6];
     int j = l.first_jacobian_index;
     for (int d = 0; d < 6; ++d) th[d] = l.free_directions[d] ? b[j++] : 0.0f;
@@ -456,26 +530,37 @@ __global__ void links_solve_kernel(const TreeOptDev* opts, int n_opts, float* bo
     K[1] = th[2];  K[4] = 0.0f;   K[7] = -th[0];
     K[2] = -th[1]; K[5] = th[0];  K[8] = 0.0f;
     expm3(K, R);
-    Affine var;
-    for (int i = 0; i < 9; ++i) var.l[i] = R[i];
-    var.t[0] = th[3]; var.t[1] = th[4]; var.t[2] = th[5];
-    Affine l2w;
-    if (l.parent >= 0) {
-      if (l.fixed_body2joint_pose) {
-        Affine j2p = mul_pose(load_pose(l.joint2parent), var);
-        affine_to_array(j2p, l.joint2parent);
+    float* v = var_all + (size_t)li * 12;
+    for (int i = 0; i < 9; ++i) v[i] = R[i];
+    v[9] = th[3]; v[10] = th[4]; v[11] = th[5];
+  }
+  __syncthreads();
+  // ... then the poses, parents before children
+  if (lane == 0) {
+    for (int li = 0; li < n_links; ++li) {
+      LinkDev& l = o.links[li];
+      const float* v = var_all + (size_t)li * 12;
+      Affine var;
+      for (int i = 0; i < 9; ++i) var.l[i] = v[i];
+      var.t[0] = v[9]; var.t[1] = v[10]; var.t[2] = v[11];
+      Affine l2w;
+      if (l.parent >= 0) {
+        if (l.fixed_body2joint_pose) {
+          Affine j2p = mul_pose(load_pose(l.joint2parent), var);
+          affine_to_array(j2p, l.joint2parent);
+        } else {
+          Affine b2j = mul_pose(var, load_pose(l.body2joint));
+          affine_to_array(b2j, l.body2joint);
+        }
+        l2w = mul_pose(mul_pose(link_pose(o.links[l.parent], body_poses), load_pose(l.joint2parent)),
+                       load_pose(l.body2joint));
       } else {
-        Affine b2j = mul_pose(var, load_pose(l.body2joint));
-        affine_to_array(b2j, l.body2joint);
+        Affine b2j = load_pose(l.body2joint);
+        l2w = mul_pose(mul_pose(mul_pose(link_pose(l, body_poses), inverse_pose(b2j)), var), b2j);
       }
-      l2w = mul_pose(mul_pose(link_pose(o.links[l.parent], body_poses), load_pose(l.joint2parent)),
-                     load_pose(l.body2joint));
-    } else {
-      Affine b2j = load_pose(l.body2joint);
-      l2w = mul_pose(mul_pose(mul_pose(link_pose(l, body_poses), inverse_pose(b2j)), var), b2j);
+      affine_to_array(l2w, l.link2world);
+      if (l.body >= 0) affine_to_array(l2w, body_poses + 16 * l.body);
     }
-    affine_to_array(l2w, l.link2world);
-    if (l.body >= 0) affine_to_array(l2w, body_poses + 16 * l.body);
   }
 }
 

@@ -1,0 +1,214 @@
+"""bench.py --config chain8 (BASELINE configs[4]): one kinematic structure -- a chain of 8 bodies, a free root and seven
+1-dof revolute joints (13 dof) -- tracked by one RegionModality per body; with N GPUs every rank holds the whole link
+tree but only the modalities of its own bodies (body i -> rank i mod N), and each Newton step sums the stacked
+[dof x dof | dof] buffers with ONE ncclAllReduce inside the library (m3t_hip_comm_init_rank: while a communicator is
+set, ExecuteTrackingStep runs project -> all-reduce -> solve by itself).  Also the sweep of
+examples/optimization_time.cpp:14-79: Optimizer::CalculateOptimization for chains of 1..50 one-dof links."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+B_ALG = 1386704  # bytes per pose-update of a RegionModality with RBOT parameters
+
+
+def chain_inputs(scenes, syn, n_bodies, n_frames, n_divides):
+    """bodies, models and rendered frames of a serial chain: body 0 free, body j rotates about its joint's z axis"""
+    inputs = scenes.Inputs(n_bodies, 1, n_divides=n_divides, n_models=min(n_bodies, 4))
+    rng = np.random.default_rng(11)
+    joints = [syn.make_pose(syn.rot_vec(rng.uniform(-0.3, 0.3, 3)), [0.02 * (1 + j % 3), 0.01 * (j % 2), 0.0])
+              for j in range(n_bodies - 1)]
+    pose_root = inputs.gt[0][0].copy()
+    angles = rng.uniform(-0.2, 0.2, n_bodies - 1)
+    gt = []
+    inputs.color = [[] for _ in range(n_bodies)]
+    for k in range(n_frames):
+        pose_root = syn.perturb_pose(pose_root, rng, rot_deg=0.7, trans=0.002)
+        angles = angles + rng.uniform(-0.03, 0.03, n_bodies - 1)
+        poses = [pose_root.copy()]
+        for j in range(n_bodies - 1):
+            poses.append(poses[-1] @ joints[j] @ syn.make_pose(syn.rot_vec([0, 0, angles[j]]), [0, 0, 0]))
+        gt.append(([p.copy() for p in poses], angles.copy()))
+        for i in range(n_bodies):
+            inputs.color[i].append(inputs.scenes[i].render(poses[i]))
+    return inputs, joints, gt
+
+
+class Chain:
+    def __init__(self, api, host, syn, inputs, joints, start_root, start_angles, owned):
+        rp = dict(syn.RBOT_REGION_PARAMS, measure_occlusions=0)
+        n = inputs.n_objects
+        self.api = api
+        self.models = [host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
+                       for m in inputs.region_models]
+        self.bodies = [host.Body(api, np.eye(4)) for _ in range(n)]
+        self.cams = [host.ColorCamera(api, **inputs.intr) for _ in range(n)]
+        self.mods = {i: host.RegionModality(api, self.bodies[i], self.cams[i], self.models[inputs.model_of[i]], **rp)
+                     for i in owned}
+        self.links = [host.Link(api, body=self.bodies[0])]
+        for j in range(1, n):
+            self.links.append(host.Link(
+                api, body=self.bodies[j], parent=self.links[j - 1],
+                joint2parent_pose=joints[j - 1] @ syn.make_pose(syn.rot_vec([0, 0, start_angles[j - 1]]), [0, 0, 0]),
+                free_directions=(0, 0, 1, 0, 0, 0)))
+        for i in owned:
+            self.links[i].AddModality(self.mods[i])
+        self.opt = host.Optimizer(api, root_link=self.links[0])
+        self.tracker = host.Tracker(api, 7, 2)
+        self.bodies[0].set_body2world_pose(start_root)
+        assert self.tracker.CalculateConsistentPoses()
+        self.owned = list(owned)
+
+    def upload(self, inputs, k):
+        for i in self.owned:
+            self.cams[i].UpdateImage(inputs.color[i][k])
+
+    def poses(self):
+        return np.stack([b.body2world_pose() for b in self.bodies])
+
+
+def optimization_time_structures(api, host, n_bodies, n_structures):
+    """examples/optimization_time.cpp:23-57 (test_constraints = false): a body-less root without free directions and
+    n_bodies chained links with one free direction each, joint2parent = translate(0.01, 0, 0); no modalities"""
+    for _ in range(n_structures):
+        root = host.Link(api, free_directions=(0, 0, 0, 0, 0, 0))
+        parent = root
+        for j in range(n_bodies):
+            t = np.eye(4)
+            t[0, 3] = 0.01
+            parent = host.Link(api, parent=parent, joint2parent_pose=t, free_directions=(1, 0, 0, 0, 0, 0))
+        host.Optimizer(api, root_link=root)
+    return host.Tracker(api, 1, 1)
+
+
+def run(args, pkg, rank, local_rank, world, dist, torch):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes
+    import util
+    syn, host = pkg.synthetic, pkg.host
+    n_bodies, K, W = args.objects or 8, args.steps, args.warmup
+    n_frames = K + W + 1
+    n_div = min(args.n_divides, 2)  # the link kernels, not the model size, are the subject of this leg
+    t0 = time.time()
+    inputs, joints, gt = chain_inputs(scenes, syn, n_bodies, n_frames, n_div)
+    start_root = syn.perturb_pose(gt[0][0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
+    start_angles = gt[0][1] + 0.01
+    hip = pkg.open_context(local_rank)
+    owned = [i for i in range(n_bodies) if i % world == rank]
+    ch = Chain(hip, host, syn, inputs, joints, start_root, start_angles, owned)
+    if world > 1:  # the library's own RCCL communicator: rank 0 creates the id, torch.distributed carries it
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            hip.call("comm_get_unique_id", buf, 128)
+            uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        raw = bytes(uid.cpu().tolist())
+        hip.call("comm_init_rank", C.create_string_buffer(raw, 128), 128, world, rank)
+    for cam_i in owned:
+        hip.call("camera_set_ring", ch.cams[cam_i].id, n_frames)
+        for k in range(n_frames):
+            f = inputs.color[cam_i][k]
+            hip.call("camera_upload_slot", ch.cams[cam_i].id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+    setup_s = time.time() - t0
+
+    def barrier():
+        hip.call("sync")
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_steps(first, count):
+        for k in range(first, first + count):
+            hip.call("cameras_select_slot", k)
+            hip.call("execute_tracking_step", k)
+
+    hip.call("cameras_select_slot", 0)
+    hip.call("start_modalities", 0)
+    run_steps(1, W)
+    barrier()
+    times = []
+    first_poses = None
+    for r in range(max(1, args.repeats)):
+        t = time.perf_counter()
+        run_steps(1 + W, K)
+        barrier()
+        times.append(pkg.sharding.max_over_ranks(time.perf_counter() - t, dist, device="cuda"))
+        if first_poses is None:
+            first_poses = ch.poses()
+    elapsed = float(np.median(times))
+    if rank != 0:
+        return None
+    # ---- CPU restatement of the same chain (all bodies in one process) + parity of the first timed trajectory ----
+    cpu, parity = None, None
+    if not args.no_cpu_baseline:
+        ora = util.open_oracle()
+        oc = Chain(ora, host, syn, inputs, joints, start_root, start_angles, range(n_bodies))
+        oc.upload(inputs, 0)
+        assert oc.tracker.StartModalities(0)
+        spent = 0.0
+        for k in range(1, 1 + W + K):
+            oc.upload(inputs, k)
+            tc = time.perf_counter()
+            assert oc.tracker.ExecuteTrackingStep(k)
+            spent += time.perf_counter() - tc
+        op = oc.poses()
+        errs = [syn.pose_errors(first_poses[i], op[i]) for i in range(n_bodies)]
+        parity = {"rot_max": float(max(e[0] for e in errs)), "trans_max": float(max(e[1] for e in errs)),
+                  "add_s_max": float(max(syn.add_s(inputs.vertices[i], first_poses[i], op[i]) for i in range(n_bodies))),
+                  "n": n_bodies, "frames": W + K, "bit_identical": bool(np.array_equal(first_poses, op)),
+                  "what": "body2world of every body after %d free-running frames, HIP vs oracle" % (W + K)}
+        cpu = {"value": round(n_bodies * (W + K) / spent, 1), "unit": "pose-updates/s", "cores": 1, "kind": "port",
+               "sample": "%d tracking steps of the same %d-body chain, oracle/libm3t_oracle.so, 1 thread" % (W + K, n_bodies)}
+    gt_err = [syn.pose_errors(first_poses[i], gt[W + K][0][i]) for i in range(n_bodies)]
+    # ---- examples/optimization_time.cpp: CalculateOptimization for chains of 1..50 one-dof links ----
+    sweep = []
+    n_structures = 256
+    for nb in (1, 2, 4, 8, 16, 32, 50):
+        api = pkg.open_context(local_rank)
+        tracker = optimization_time_structures(api, host, nb, n_structures)
+        assert tracker.CalculateOptimization(0, 0, 0)
+        api.call("sync")
+        reps = 20
+        t = time.perf_counter()
+        for _ in range(reps):
+            api.call("calculate_optimization", 0, 0, 0)
+        api.call("sync")
+        gpu_us = (time.perf_counter() - t) / reps * 1e6
+        ora = util.open_oracle()
+        otr = optimization_time_structures(ora, host, nb, 1)
+        assert otr.CalculateOptimization(0, 0, 0)
+        t = time.perf_counter()
+        for _ in range(200):
+            ora.call("calculate_optimization", 0, 0, 0)
+        cpu_us = (time.perf_counter() - t) / 200 * 1e6
+        sweep.append({"bodies": nb, "gpu_us_per_launch_of_%d_structures" % n_structures: round(gpu_us, 1),
+                      "gpu_us_per_structure": round(gpu_us / n_structures, 3), "cpu_port_us_per_structure": round(cpu_us, 2)})
+    total = n_bodies * K
+    rate = total / elapsed
+    return {
+        "metric": "pose-updates/sec (Mb-ICG kinematic chain, %d bodies, %d dof)" % (n_bodies, 6 + n_bodies - 1),
+        "value": round(rate, 1), "unit": "pose-updates/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: one kinematic chain of %d bodies (free root + %d revolute joints), one "
+                               "RegionModality per body (RBOT parameters, 200 lines x 7 x 2), link kernels: one wave per "
+                               "structure; body i on GPU i mod %d, ONE ncclAllReduce of %d floats per Newton step%s" %
+                               (n_bodies, n_bodies - 1, world, (6 + n_bodies - 1) ** 2 + 6 + n_bodies - 1,
+                                "" if world > 1 else " when N > 1"),
+                   "bodies": n_bodies, "parallelism": "bodies sharded over %d GPU(s)" % world,
+                   "max_rotation_error_vs_ground_truth_rad": round(float(max(e[0] for e in gt_err)), 5),
+                   "setup_s": round(setup_s, 1)},
+        "roofline": {"bound": "hbm", "kernel": "whole step: 7 x (correspondence + 2 x (g/H, project, solve)) + results launches",
+                     "achieved": round(rate * B_ALG / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(rate * B_ALG / 8e12, 6), "traffic": None,
+                     "note": "launch- and latency-bound by construction: 50 dependent launches per frame for one structure"},
+        "cpu_baseline": cpu, "parity": parity,
+        "repeats": {"n": len(times), "ms_per_step_min": round(min(times) / K * 1e3, 4),
+                    "ms_per_step_median": round(elapsed / K * 1e3, 4)},
+        "optimization_time_sweep": sweep,
+    }

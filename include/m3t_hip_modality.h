@@ -30,7 +30,6 @@ namespace m3t_hip_adapter {
 
 struct HipBatch {
   m3t_hip_context* ctx = nullptr;
-  long start_round = -1, corr_round = -1, gh_round = -1, res_round = -1;
   std::vector<std::pair<int /*device body id*/, std::shared_ptr<m3t::Body>>> bodies;
 
   explicit HipBatch(int device_id = 0) {
@@ -59,7 +58,6 @@ struct HipBatch {
   struct SharedCamera {
     std::shared_ptr<m3t::Camera> camera;
     int id;
-    long uploaded_round;
   };
   std::vector<SharedCamera> cameras;
   int ColorCameraId(const std::shared_ptr<m3t::ColorCamera>& camera) {
@@ -68,7 +66,7 @@ struct HipBatch {
     const auto& in = camera->intrinsics();
     const m3t_intrinsics i{in.fu, in.fv, in.ppu, in.ppv, in.width, in.height};
     int id = m3t_hip_color_camera_create(ctx, &i, camera->world2camera_pose().data());
-    if (id >= 0) cameras.push_back({camera, id, -1});
+    if (id >= 0) cameras.push_back({camera, id});
     return id;
   }
   int DepthCameraId(const std::shared_ptr<m3t::DepthCamera>& camera) {
@@ -77,19 +75,18 @@ struct HipBatch {
     const auto& in = camera->intrinsics();
     const m3t_intrinsics i{in.fu, in.fv, in.ppu, in.ppv, in.width, in.height};
     int id = m3t_hip_depth_camera_create(ctx, &i, camera->world2camera_pose().data(), camera->depth_scale());
-    if (id >= 0) cameras.push_back({camera, id, -1});
+    if (id >= 0) cameras.push_back({camera, id});
     return id;
   }
-  // Camera::image() -> device, once per upload round however many modalities share the camera
-  bool Upload(int camera_id, long round) {
+  // Camera::image() -> device for every registered camera.  Called once per round (Once() below de-duplicates
+  // the calls of the modalities of one round); never keyed on the iteration index, which hosts repeat
+  bool UploadAll() {
+    bool ok = true;
     for (auto& c : cameras) {
-      if (c.id != camera_id) continue;
-      if (c.uploaded_round == round) return true;
-      c.uploaded_round = round;
       const cv::Mat& image = c.camera->image();  // BGR8 or u16; rows may be padded: data + step
-      return m3t_hip_camera_upload(ctx, camera_id, image.data, image.step) >= 0;
+      ok = m3t_hip_camera_upload(ctx, c.id, image.data, image.step) >= 0 && ok;
     }
-    return false;
+    return ok;
   }
   void PushPoses() {
     for (auto& b : bodies) m3t_hip_body_set_body2world_pose(ctx, b.first, b.second->body2world_pose().data());
@@ -117,12 +114,12 @@ struct HipBatch {
   // StartModalities / ExecuteTrackingStep of tracker.cpp:344-364,430-445 for every registered body at once:
   // images up, poses up, the whole loop nest on the device, poses back into the host Bodies
   bool StartModalities(int iteration) {
-    for (auto& c : cameras) Upload(c.id, -2 - 2L * iteration);
+    if (!UploadAll()) return Status(-1);
     PushPoses();
     return Status(m3t_hip_start_modalities(ctx, iteration));
   }
   bool ExecuteTrackingStep(int iteration, int n_corr_iterations, int n_update_iterations) {
-    for (auto& c : cameras) Upload(c.id, -3 - 2L * iteration);
+    if (!UploadAll()) return Status(-1);
     PushPoses();
     return Status(m3t_hip_set_fused_step(ctx, 1)) &&
            Status(m3t_hip_tracker_set_iterations(ctx, n_corr_iterations, n_update_iterations)) &&
@@ -132,16 +129,32 @@ struct HipBatch {
     if (rc < 0) std::cerr << m3t_hip_last_error(ctx) << std::endl;
     return rc >= 0;
   }
-  // runs f once per round key; f returns a C-ABI status
+  // One sub-step of the host's Tracker reaches every modality in turn (tracker.cpp:447-489); the first call of such a
+  // round launches for the whole batch, the others of the round are served from it.  A round ends when its key
+  // (the iteration indices) changes OR when a modality asks a second time: hosts legitimately repeat indices
+  // (RBOTEvaluator::ResetBody -> StartModality(0, 0) after every loss, Refiner::RefinePoses on every call).
+  struct Round {
+    long key = 0;
+    bool open = false, ok = true;
+    std::vector<char> served;  // by device modality id
+  };
   template <typename F>
-  bool Once(long* round, long key, F f) {
-    if (*round == key) return true;
-    *round = key;
-    PushPoses();
-    const int rc = f();
-    if (rc < 0) std::cerr << m3t_hip_last_error(ctx) << std::endl;
-    return rc >= 0;
+  bool Once(Round* round, int modality_id, long key, bool with_images, F f) {
+    if (modality_id >= int(round->served.size())) round->served.resize(size_t(modality_id) + 1, 0);
+    if (!round->open || round->key != key || round->served[size_t(modality_id)]) {
+      round->open = true;
+      round->key = key;
+      std::fill(round->served.begin(), round->served.end(), 0);
+      round->ok = !with_images || UploadAll();
+      PushPoses();
+      const int rc = f();
+      if (rc < 0) std::cerr << m3t_hip_last_error(ctx) << std::endl;
+      round->ok = round->ok && rc >= 0;
+    }
+    round->served[size_t(modality_id)] = 1;
+    return round->ok;
   }
+  Round start_round, corr_round, gh_round, res_round;
 };
 
 // what both adapters do the same way
@@ -149,19 +162,19 @@ class HipModality : public m3t::Modality {
  public:
   bool StartModality(int iteration, int /*corr_iteration*/) override {
     if (!CheckSetUp()) return false;
-    UploadImages(2 * iteration);
-    return batch_->Once(&batch_->start_round, iteration, [&] { return m3t_hip_start_modalities(batch_->ctx, iteration); });
+    return batch_->Once(&batch_->start_round, id_, iteration, true,
+                        [&] { return m3t_hip_start_modalities(batch_->ctx, iteration); });
   }
   bool CalculateCorrespondences(int iteration, int corr_iteration) override {
     if (!CheckSetUp()) return false;
-    if (corr_iteration == 0) UploadImages(2 * iteration + 1);  // Tracker::UpdateCameras ran before this search
-    return batch_->Once(&batch_->corr_round, iteration * 64L + corr_iteration, [&] {
+    // (Tracker::UpdateCameras ran before the first search of a step: its images go up with that round)
+    return batch_->Once(&batch_->corr_round, id_, iteration * 4096L + corr_iteration, corr_iteration == 0, [&] {
       return m3t_hip_calculate_correspondences(batch_->ctx, iteration, corr_iteration);
     });
   }
   bool CalculateGradientAndHessian(int iteration, int corr_iteration, int opt_iteration) override {
     if (!CheckSetUp()) return false;
-    const bool ok = batch_->Once(&batch_->gh_round, (iteration * 64L + corr_iteration) * 8 + opt_iteration, [&] {
+    const bool ok = batch_->Once(&batch_->gh_round, id_, (iteration * 4096L + corr_iteration) * 4096L + opt_iteration, false, [&] {
       return m3t_hip_calculate_gradient_and_hessian(batch_->ctx, iteration, corr_iteration, opt_iteration);
     });
     // column-major like Eigen: what the unmodified Link adds up (link.cpp:188-191)
@@ -169,7 +182,8 @@ class HipModality : public m3t::Modality {
   }
   bool CalculateResults(int iteration) override {
     if (!CheckSetUp()) return false;
-    return batch_->Once(&batch_->res_round, iteration, [&] { return m3t_hip_calculate_results(batch_->ctx, iteration); });
+    return batch_->Once(&batch_->res_round, id_, iteration, false,
+                        [&] { return m3t_hip_calculate_results(batch_->ctx, iteration); });
   }
   bool VisualizeCorrespondences(int) override { return true; }
   bool VisualizeOptimization(int) override { return true; }
@@ -183,7 +197,6 @@ class HipModality : public m3t::Modality {
     if (!set_up_) std::cerr << "Set up modality " << name_ << " first" << std::endl;  // region_modality.cpp:1813-1819
     return set_up_;
   }
-  virtual void UploadImages(long round) = 0;
   std::shared_ptr<HipBatch> batch_;
   int body_id_ = -1, id_ = -1;
 };
@@ -224,10 +237,6 @@ class HipRegionModality : public HipModality {
   }
 
  private:
-  void UploadImages(long round) override {
-    batch_->Upload(color_id_, round);
-    if (depth_camera_) batch_->Upload(depth_id_, round);
-  }
   std::shared_ptr<m3t::ColorCamera> color_camera_;
   std::shared_ptr<m3t::DepthCamera> depth_camera_;
   std::filesystem::path model_path_;
@@ -260,7 +269,6 @@ class HipDepthModality : public HipModality {
   std::vector<std::shared_ptr<m3t::Camera>> camera_ptrs() const override { return {depth_camera_}; }
 
  private:
-  void UploadImages(long round) override { batch_->Upload(depth_id_, round); }
   std::shared_ptr<m3t::DepthCamera> depth_camera_;
   std::filesystem::path model_path_;
   m3t_depth_modality_params params_;

@@ -112,6 +112,21 @@ int main(int argc, char** argv) {
   for (auto& m : modalities)
     if (!m->CalculateResults(0)) return 12;
 
+  // hosts repeat iteration indices: RBOTEvaluator::ResetBody calls StartModality(0, 0) after every tracking loss and
+  // starts over.  Same pose, same images, same indices must run again (not be served from the earlier round) and
+  // reproduce the first gradient / Hessian
+  body->set_body2world_pose(body2world);
+  for (auto& m : modalities)
+    if (!m->StartModality(0, 0)) return 17;
+  for (auto& m : modalities)
+    if (!m->CalculateCorrespondences(0, 0)) return 18;
+  for (auto& m : modalities)
+    if (!m->CalculateGradientAndHessian(0, 0, 0)) return 19;
+  std::printf("again");
+  for (float v : modalities[0]->gradient().v) std::printf(" %a", double(v));
+  for (float v : modalities[0]->hessian().v) std::printf(" %a", double(v));
+  std::printf("\n");
+
   if (argc > 2 && std::string(argv[2]) == "adapter-only") return 0;
   // fast mode on a second batch: the library optimises, the host Body receives the pose
   auto fast_body = std::make_shared<m3t::Body>("triangle");

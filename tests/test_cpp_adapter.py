@@ -90,6 +90,8 @@ def run_demo(exe, directory, *args):
     rows = {line.split()[0]: np.array([float.fromhex(x) for x in line.split()[1:]], np.float32)
             for line in out.stdout.strip().splitlines()}
     fast = rows["fast"].reshape(4, 4).T if "fast" in rows else None
+    # a repeated round (same iteration indices after a reset) ran again and reproduced the first result
+    assert np.array_equal(rows["again"], rows["triangle_region_modality"])
     return [rows["triangle_region_modality"], rows["triangle_depth_modality"]], rows["moved"], fast
 
 

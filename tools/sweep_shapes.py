@@ -54,6 +54,12 @@ def measure(inputs, use_depth, env, K=8, W=3, repeats=3):
 
 def main():
     what = sys.argv[1:] or ["rbot", "ycb"]
+    if "rbot64" in what:
+        inputs = scenes.Inputs(64, 12, n_divides=4, n_models=8)
+        for env in ({"M3T_HIP_NO_SPLIT": "1"}, {"M3T_HIP_SPLIT_PARTS": "4"}):
+            mn, med, shape, poses = measure(inputs, False, env)
+            print(json.dumps({"config": "rbot", "objects": 64, "env": env, "shape": shape, "ms_min": round(mn, 4),
+                              "ms_median": round(med, 4), "k_pose_updates_s": round(64 / mn, 1)}), flush=True)
     if "rbot" in what:
         inputs = scenes.Inputs(64, 12, n_divides=4, n_models=8)
         for n, envs in ((64, [{"M3T_HIP_NO_SPLIT": "1"}, {"M3T_HIP_SPLIT_PARTS": "2"}, {"M3T_HIP_SPLIT_PARTS": "4"},
@@ -73,8 +79,7 @@ def main():
     if "ycb" in what:
         inputs = scenes.Inputs(21, 12, n_divides=4, n_models=6, with_depth=True)
         ref = None
-        for env in ({"M3T_HIP_NO_SPLIT": "1"}, {"M3T_HIP_SPLIT_PARTS": "8"}, {"M3T_HIP_SPLIT_PARTS": "16"},
-                    {"M3T_HIP_SPLIT_PARTS": "16", "M3T_HIP_THREADS": "256"}):
+        for env in ({"M3T_HIP_NO_SPLIT": "1"}, {"M3T_HIP_SPLIT_PARTS": "8"}):
             mn, med, shape, poses = measure(inputs, True, env)
             same = ref is None or bool(np.array_equal(ref, poses))
             ref = poses if ref is None else ref
