@@ -1,0 +1,70 @@
+"""Launched by test_gpu_multigpu.py through torch.distributed.run, one rank per GPU: the 8-body chain of
+bench_chain.py with body i on rank i mod N, the library's own RCCL communicator and ONE ncclAllReduce per Newton
+step.  Every rank must end on the same poses (bit for bit), and they must equal the oracle's single-process run."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    pkg = importlib.import_module("3dobjecttracking_amd")
+    import bench_chain as bc
+    import scenes
+    import util
+    syn, host = pkg.synthetic, pkg.host
+    n_bodies, n_frames = 8, 4
+    inputs, joints, gt = bc.chain_inputs(scenes, syn, n_bodies, n_frames, 2)
+    start_root = syn.perturb_pose(gt[0][0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
+    start_angles = gt[0][1] + 0.01
+    hip = pkg.open_context(local)
+    owned = [i for i in range(n_bodies) if i % world == rank]
+    ch = bc.Chain(hip, host, syn, inputs, joints, start_root, start_angles, owned)
+    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        buf = C.create_string_buffer(128)
+        hip.call("comm_get_unique_id", buf, 128)
+        uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device="cuda")
+    dist.broadcast(uid, 0)
+    hip.call("comm_init_rank", C.create_string_buffer(bytes(uid.cpu().tolist()), 128), 128, world, rank)
+    ch.upload(inputs, 0)
+    assert ch.tracker.StartModalities(0)
+    for k in range(n_frames):
+        ch.upload(inputs, k)
+        assert ch.tracker.ExecuteTrackingStep(k)
+    poses = torch.from_numpy(ch.poses()).cuda()
+    gathered = [torch.zeros_like(poses) for _ in range(world)]
+    dist.all_gather(gathered, poses)
+    hip.call("comm_destroy")
+    if rank == 0:
+        for r in range(1, world):
+            assert torch.equal(gathered[0], gathered[r]), "replicas differ on rank %d" % r
+        ora = util.open_oracle()
+        oc = bc.Chain(ora, host, syn, inputs, joints, start_root, start_angles, range(n_bodies))
+        oc.upload(inputs, 0)
+        assert oc.tracker.StartModalities(0)
+        for k in range(n_frames):
+            oc.upload(inputs, k)
+            assert oc.tracker.ExecuteTrackingStep(k)
+        # the all-reduce adds the ranks' partial sums in RCCL's order, not link after link: replicas agree bit for
+        # bit with each other, and with the single-process oracle within the rounding of that one sum
+        err = np.abs(gathered[0].cpu().numpy() - oc.poses()).max()
+        assert err < 1e-4, err
+        print("multigpu chain ok: %d ranks, max |pose - oracle| = %.3g" % (world, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
