@@ -285,6 +285,8 @@ _HIP_ONLY = {
     "get_stream": [C.POINTER(C.c_void_p)],
     "region_model_generate": [C.c_int, C.POINTER(ModelGenerationParams)],
     "depth_model_generate": [C.c_int, C.POINTER(ModelGenerationParams)],
+    "region_model_generate_associated": [C.c_int, C.POINTER(ModelGenerationParams), C.c_int, c_int_p, c_int_p, c_int_p],
+    "depth_model_generate_occluded": [C.c_int, C.POINTER(ModelGenerationParams), C.c_int, c_int_p],
     "region_model_get_views": [C.c_int, c_float_p, c_float_p, c_float_p],
     "depth_model_get_views": [C.c_int, c_float_p, c_float_p, c_float_p],
     "device_info": [C.c_char_p, C.c_size_t, c_int_p, C.POINTER(C.c_size_t)],

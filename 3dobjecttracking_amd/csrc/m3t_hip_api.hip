@@ -2080,7 +2080,10 @@ int m3t_hip_depth_modality_use_silhouette_checking(m3t_hip_context* ctx, int mod
 }
 
 // ---- model generation (f-1) ---------------------------------------------------------------------------
-static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_model_generation_params* p) {
+// groups (RegionModel::AddAssociatedBody region_model.cpp:365-388): 0 fixed, 1 movable, 2 fixed same-region,
+// 3 movable same-region; for the depth model 0 = occlusion bodies (DepthModel::AddOcclusionBody depth_model.cpp:61-70)
+static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_model_generation_params* p,
+                         const std::vector<int> (&groups)[4] = {}) {
   CHECK_CTX();
   REQUIRE(p && p->sphere_radius > 0.0f && p->n_divides >= 0 && p->n_divides <= 6 && p->n_points >= 1 &&
               p->image_size >= 64 && p->image_size <= 4096 && p->stride_depth_offset > 0.0f &&
@@ -2088,25 +2091,88 @@ static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_
               int(p->max_radius_depth_offset / p->stride_depth_offset + 1.0f) <= M3T_N_DEPTH_OFFSETS,
           M3T_ERR_INVALID_ARGUMENT, "bad model generation parameters");
   REQUIRE(HasGeometry(ctx, body), M3T_ERR_NOT_SET_UP, "body has no geometry");
+  for (auto& grp : groups)
+    for (int b : grp) REQUIRE(HasGeometry(ctx, b) && b != body, M3T_ERR_NOT_SET_UP, "associated body has no geometry");
   HIPCHK(hipSetDevice(ctx->device));
   using namespace modelgen;
   const BodyGeometryH& g = *ctx->body_geometries[body];
   const int S = p->image_size;
   const float d = g.maximum_body_diameter, radius = p->sphere_radius;
   REQUIRE(0.5f * d < radius, M3T_ERR_INVALID_ARGUMENT, "sphere radius smaller than the body");
-  // Model::SetUpRenderer model.cpp:120-153
+  // Model::SetUpRenderer model.cpp:120-153: intrinsics from the main body
   const float fu = 0.5f * float(S - 20) / tanf(asinf(0.5f * d / radius));
   const float pp = float(S) / 2.0f;
-  const float z_min = radius - d * 0.5f, z_max = radius + d * 0.5f;
-  P4 P;
-  for (float& f : P.m) f = 0.0f;  // FullRenderer::CalculateProjectionMatrix renderer.cpp:257-264
-  P(0, 0) = 2.0f * fu / float(S);
-  P(0, 2) = 2.0f * (pp + 0.5f) / float(S) - 1.0f;
-  P(1, 1) = 2.0f * fu / float(S);
-  P(1, 2) = 2.0f * (pp + 0.5f) / float(S) - 1.0f;
-  P(2, 2) = (z_max + z_min) / (z_max - z_min);
-  P(2, 3) = -2.0f * z_max * z_min / (z_max - z_min);
-  P(3, 2) = 1.0f;
+  // the renderers of one view: which bodies are drawn, in which order, with which id.  Renderers that draw the same
+  // bodies share one rasterisation; their silhouette images differ only in the ids.
+  constexpr uint8_t M = 255, B = 0, D = 120;  // kMainBodyID, kBackgroundID, kDifferentBodyID
+  struct Draw { int body; uint8_t id; };
+  struct Renderer { std::vector<Draw> draws; };
+  auto draws = [&](std::initializer_list<std::pair<const std::vector<int>*, uint8_t>> parts, uint8_t main_id) {
+    Renderer r;
+    r.draws.push_back({body, main_id});
+    for (auto& part : parts)
+      for (int b : *part.first) r.draws.push_back({b, part.second});
+    return r;
+  };
+  const std::vector<int>&fixed = groups[0], &movable = groups[1], &fixed_same = groups[2], &movable_same = groups[3];
+  const bool any_associated = !fixed.empty() || !movable.empty() || !fixed_same.empty() || !movable_same.empty();
+  enum { R_MAIN = 0, R_OCCLUSION, R_SAME_REGION, R_FOREGROUND, R_BACKGROUND, N_RENDERERS };
+  Renderer renderers[N_RENDERERS];
+  bool used[N_RENDERERS] = {true, false, false, false, false};
+  if (region) {  // region_model.cpp:207-213, 417-463
+    renderers[R_MAIN] = draws({{&fixed, D}}, M);
+    if (!movable.empty()) {
+      renderers[R_OCCLUSION] = draws({{&fixed, B}, {&movable, M}}, B);
+      used[R_OCCLUSION] = true;
+    }
+    if (!fixed_same.empty() || !movable_same.empty()) {
+      renderers[R_SAME_REGION] = draws({{&fixed, B}, {&fixed_same, M}, {&movable_same, M}}, B);
+      used[R_SAME_REGION] = true;
+    }
+    if (!movable.empty() || !fixed_same.empty() || !movable_same.empty()) {
+      renderers[R_FOREGROUND] = draws({{&fixed, B}, {&movable, B}, {&fixed_same, M}}, M);
+      renderers[R_BACKGROUND] = draws({{&fixed, B}, {&fixed_same, M}, {&movable_same, M}}, M);
+      used[R_FOREGROUND] = used[R_BACKGROUND] = true;
+    }
+  } else {  // depth_model.cpp:165-177: the main (normal) renderer draws the body alone
+    renderers[R_MAIN] = draws({}, M);
+    if (!fixed.empty()) {
+      renderers[R_OCCLUSION] = draws({{&fixed, B}}, M);
+      used[R_OCCLUSION] = true;
+    }
+  }
+  for (auto& r : renderers) REQUIRE(r.draws.size() <= 64, M3T_ERR_UNSUPPORTED, "more than 63 associated bodies");
+  // clip range of a renderer: widened to every body it draws (Model::AddBodiesToRenderer model.cpp:164-192)
+  auto clip_range = [&](const Renderer& r, float* z_min, float* z_max) {
+    *z_min = radius - d * 0.5f;
+    *z_max = radius + d * 0.5f;
+    for (const Draw& dr : r.draws) {
+      const float db = ctx->body_geometries[dr.body]->maximum_body_diameter;
+      *z_min = std::min(*z_min, radius - db * 0.5f);
+      *z_max = std::max(*z_max, radius + db * 0.5f);
+    }
+  };
+  auto projection = [&](float z_min, float z_max) {
+    P4 P;
+    for (float& f : P.m) f = 0.0f;  // FullRenderer::CalculateProjectionMatrix renderer.cpp:257-264
+    P(0, 0) = 2.0f * fu / float(S);
+    P(0, 2) = 2.0f * (pp + 0.5f) / float(S) - 1.0f;
+    P(1, 1) = 2.0f * fu / float(S);
+    P(1, 2) = 2.0f * (pp + 0.5f) / float(S) - 1.0f;
+    P(2, 2) = (z_max + z_min) / (z_max - z_min);
+    P(2, 3) = -2.0f * z_max * z_min / (z_max - z_min);
+    P(3, 2) = 1.0f;
+    return P;
+  };
+  {
+    float z_min, z_max;
+    for (int r = 0; r < N_RENDERERS; ++r)
+      if (used[r]) {
+        clip_range(renderers[r], &z_min, &z_max);
+        REQUIRE(z_min >= radius * 0.2f, M3T_ERR_INVALID_ARGUMENT,  // kMinimumClipSpaceRatio model.h:59
+                "z_min too small for the model's sphere radius");
+      }
+  }
   P4 g2b;
   std::memcpy(g2b.m, g.geometry2body, 64);
   const std::vector<P4> poses = GeodesicPoses(p->n_divides, radius);
@@ -2115,40 +2181,77 @@ static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_
   std::vector<float> points(size_t(n_views) * p->n_points * pf), orientations(size_t(n_views) * 3), extents(n_views);
   const size_t px = size_t(S) * S;
   const int batch = int(std::max<size_t>(1, std::min<size_t>(16, (size_t(768) << 20) / (px * 8))));
-  DevMem d_z, d_trans, d_depth, d_tri;
+  DevMem d_z, d_trans, d_depth, d_tri, d_body;
   HIPCHK(d_z.alloc(size_t(batch) * px * 8));
   HIPCHK(d_trans.alloc(size_t(batch) * 64));
   HIPCHK(d_depth.alloc(size_t(batch) * px * 2));
   if (!region) HIPCHK(d_tri.alloc(size_t(batch) * px * 4));
+  if (any_associated) HIPCHK(d_body.alloc(size_t(batch) * px));
   std::vector<uint16_t> h_depth(size_t(batch) * px);
   std::vector<int> h_tri(region ? 0 : size_t(batch) * px);
+  std::vector<uint8_t> h_body(any_associated ? size_t(batch) * px : 0);
+  std::vector<uint8_t> h_ids[N_RENDERERS];  // silhouette images of the renderers in use (only with associated bodies)
+  if (any_associated)
+    for (int r = 0; r < N_RENDERERS; ++r)
+      if (used[r]) h_ids[r].resize(size_t(batch) * px);
   std::vector<P4> trans(batch), geometry2camera(batch);
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  float main_z_min, main_z_max;
+  clip_range(renderers[R_MAIN], &main_z_min, &main_z_max);
   for (int first = 0; first < n_views; first += batch) {
     const int n = std::min(batch, n_views - first);
-    for (int k = 0; k < n; ++k) {
-      geometry2camera[k] = MulAffine(InverseAffine(poses[first + k]), g2b);  // body at the identity pose
-      trans[k] = MulGeneral(P, geometry2camera[k]);
+    for (int k = 0; k < n; ++k) geometry2camera[k] = MulAffine(InverseAffine(poses[first + k]), g2b);  // body at the identity pose
+    for (int r = 0; r < N_RENDERERS; ++r) {
+      if (!used[r]) continue;
+      if (r == R_BACKGROUND && used[R_SAME_REGION]) continue;  // same bodies as the same-region renderer: ids only
+      if (!any_associated && r != R_MAIN) continue;
+      float z_min, z_max;
+      clip_range(renderers[r], &z_min, &z_max);
+      const P4 P = projection(z_min, z_max);
+      HIPCHK(hipMemsetAsync(d_z.p, 0xff, size_t(n) * px * 8, ctx->stream));
+      for (size_t order = 0; order < renderers[r].draws.size(); ++order) {
+        const BodyGeometryH& bg = *ctx->body_geometries[renderers[r].draws[order].body];
+        P4 bg2b;
+        std::memcpy(bg2b.m, bg.geometry2body, 64);
+        for (int k = 0; k < n; ++k) trans[k] = MulGeneral(P, MulAffine(InverseAffine(poses[first + k]), bg2b));
+        HIPCHK(hipMemcpyAsync(d_trans.p, trans.data(), size_t(n) * 64, hipMemcpyHostToDevice, ctx->stream));
+        ModelRenderDev job{};
+        job.vertices = bg.vertices.as<float>();
+        job.triangles = bg.triangles.as<int>();
+        job.n_triangles = bg.n_triangles;
+        job.culling = bg.culling;
+        job.image_size = S;
+        job.order = int(order);
+        job.trans = d_trans.as<float>();
+        job.z_buffer = d_z.as<unsigned long long>();
+        const int slices = std::max(1, std::min(64, (bg.n_triangles + M3T_BLOCK_THREADS - 1) / M3T_BLOCK_THREADS));
+        hipLaunchKernelGGL(model_render_kernel, dim3(slices, n), dim3(M3T_BLOCK_THREADS), 0, ctx->stream, job);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // `trans` is reused by the next body
+      }
+      const bool is_main = r == R_MAIN;
+      hipLaunchKernelGGL(model_unpack_kernel, dim3(1024), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                         d_z.as<unsigned long long>(), size_t(n) * px, is_main ? d_depth.as<uint16_t>() : nullptr,
+                         (is_main && !region) ? d_tri.as<int>() : static_cast<int*>(nullptr),
+                         any_associated ? d_body.as<uint8_t>() : static_cast<uint8_t*>(nullptr));
+      HIPCHK(hipGetLastError());
+      if (is_main) {
+        HIPCHK(hipMemcpyAsync(h_depth.data(), d_depth.p, size_t(n) * px * 2, hipMemcpyDeviceToHost, ctx->stream));
+        if (!region) HIPCHK(hipMemcpyAsync(h_tri.data(), d_tri.p, size_t(n) * px * 4, hipMemcpyDeviceToHost, ctx->stream));
+      }
+      if (any_associated) HIPCHK(hipMemcpyAsync(h_body.data(), d_body.p, size_t(n) * px, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (any_associated) {  // draw order -> id, for this renderer and the one that shares its bodies
+        auto to_ids = [&](int which) {
+          uint8_t lut[256];
+          for (int i = 0; i < 256; ++i) lut[i] = 0;
+          for (size_t o = 0; o < renderers[which].draws.size(); ++o) lut[o] = renderers[which].draws[o].id;
+          for (size_t i = 0; i < size_t(n) * px; ++i) h_ids[which][i] = lut[h_body[i]];
+        };
+        to_ids(r);
+        if (r == R_SAME_REGION && used[R_BACKGROUND]) to_ids(R_BACKGROUND);
+      }
     }
-    HIPCHK(hipMemcpyAsync(d_trans.p, trans.data(), size_t(n) * 64, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(d_z.p, 0xff, size_t(n) * px * 8, ctx->stream));
-    ModelRenderDev job{};
-    job.vertices = g.vertices.as<float>();
-    job.triangles = g.triangles.as<int>();
-    job.n_triangles = g.n_triangles;
-    job.culling = g.culling;
-    job.image_size = S;
-    job.trans = d_trans.as<float>();
-    job.z_buffer = d_z.as<unsigned long long>();
-    const int slices = std::max(1, std::min(64, (g.n_triangles + M3T_BLOCK_THREADS - 1) / M3T_BLOCK_THREADS));
-    hipLaunchKernelGGL(model_render_kernel, dim3(slices, n), dim3(M3T_BLOCK_THREADS), 0, ctx->stream, job);
-    hipLaunchKernelGGL(model_unpack_kernel, dim3(1024), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
-                       d_z.as<unsigned long long>(), size_t(n) * px, d_depth.as<uint16_t>(),
-                       region ? static_cast<int*>(nullptr) : d_tri.as<int>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_depth.data(), d_depth.p, size_t(n) * px * 2, hipMemcpyDeviceToHost, ctx->stream));
-    if (!region) HIPCHK(hipMemcpyAsync(h_tri.data(), d_tri.p, size_t(n) * px * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     std::vector<std::thread> workers;
     for (int k = 0; k < n; ++k)
       workers.emplace_back([&, k]() {
@@ -2156,10 +2259,18 @@ static int GenerateModel(m3t_hip_context* ctx, bool region, int body, const m3t_
         v.S = S;
         v.fu = fu;
         v.pp = pp;
-        v.term_a = z_max * z_min * 65535.0f / (z_max - z_min);  // renderer.cpp:475-478
-        v.term_b = z_max * 65535.0f / (z_max - z_min);
+        v.term_a = main_z_max * main_z_min * 65535.0f / (main_z_max - main_z_min);  // renderer.cpp:475-478
+        v.term_b = main_z_max * 65535.0f / (main_z_max - main_z_min);
         v.depth = h_depth.data() + size_t(k) * px;
         v.triangle = region ? nullptr : h_tri.data() + size_t(k) * px;
+        if (any_associated) {
+          auto image = [&](int which) { return used[which] ? h_ids[which].data() + size_t(k) * px : nullptr; };
+          if (region) v.main_id = image(R_MAIN);
+          v.occlusion = image(R_OCCLUSION);
+          v.same_region = image(R_SAME_REGION);
+          v.foreground = image(R_FOREGROUND);
+          v.background = image(R_BACKGROUND);
+        }
         const int view = first + k;
         const P4& c2b = poses[view];
         float* out = points.data() + size_t(view) * p->n_points * pf;
@@ -2181,6 +2292,22 @@ int m3t_hip_region_model_generate(m3t_hip_context* ctx, int body, const m3t_mode
 }
 int m3t_hip_depth_model_generate(m3t_hip_context* ctx, int body, const m3t_model_generation_params* p) {
   return GenerateModel(ctx, false, body, p);
+}
+int m3t_hip_region_model_generate_associated(m3t_hip_context* ctx, int body, const m3t_model_generation_params* p, int n,
+                                             const int* body_ids, const int* movable, const int* same_region) {
+  CHECK_CTX();
+  REQUIRE(n >= 0 && (n == 0 || (body_ids && movable && same_region)), M3T_ERR_INVALID_ARGUMENT, "bad associated bodies");
+  std::vector<int> groups[4];
+  for (int i = 0; i < n; ++i) groups[(movable[i] ? 1 : 0) + (same_region[i] ? 2 : 0)].push_back(body_ids[i]);
+  return GenerateModel(ctx, true, body, p, groups);
+}
+int m3t_hip_depth_model_generate_occluded(m3t_hip_context* ctx, int body, const m3t_model_generation_params* p, int n,
+                                          const int* body_ids) {
+  CHECK_CTX();
+  REQUIRE(n >= 0 && (n == 0 || body_ids), M3T_ERR_INVALID_ARGUMENT, "bad occlusion bodies");
+  std::vector<int> groups[4];
+  groups[0].assign(body_ids, body_ids + n);
+  return GenerateModel(ctx, false, body, p, groups);
 }
 static int GetViews(m3t_hip_context* ctx, bool region, int id, float* points, float* orientations, float* extents) {
   CHECK_CTX();

@@ -20,9 +20,11 @@ struct ModelRenderDev {
   int n_triangles;
   int culling;
   int image_size;
+  int order;                     // draw order of this body inside its renderer (GL_LESS: the body drawn first keeps a tie)
   const float* trans;            // [n_views_in_batch][16] projection * world2camera * geometry2body, column-major
-  unsigned long long* z_buffer;  // [n_views_in_batch][image_size^2]
+  unsigned long long* z_buffer;  // [n_views_in_batch][image_size^2]: depth16 << 32 | order << 26 | triangle
 };
+#define M3T_MODEL_TRIANGLE_BITS 26
 
 extern "C" {
 
@@ -93,7 +95,8 @@ __global__ void __launch_bounds__(M3T_BLOCK_THREADS) model_render_kernel(ModelRe
     const double z = ((double)e[1] / a2) * zs[0] + ((double)e[2] / a2) * zs[1] + ((double)e[0] / a2) * zs[2];
     if (!(z >= 0.0 && z <= 1.0)) return;
     const unsigned long long d16 = (unsigned long long)floor(z * 65535.0 + 0.46);
-    atomicMin(&z_buffer[(size_t)py * S + px], (d16 << 32) | (unsigned long long)(unsigned)t);
+    atomicMin(&z_buffer[(size_t)py * S + px],
+              (d16 << 32) | ((unsigned long long)job.order << M3T_MODEL_TRIANGLE_BITS) | (unsigned long long)(unsigned)t);
   };
 
   if (tid == 0) n_queued = 0;
@@ -142,15 +145,16 @@ __global__ void __launch_bounds__(M3T_BLOCK_THREADS) model_render_kernel(ModelRe
   }
 }
 
-// depth16 (65535 = nothing) and, for the depth model, the visible triangle of every pixel: 2 or 6 bytes per
-// pixel cross PCIe instead of the 8-byte z-buffer words
+// depth16 (65535 = nothing), the body that owns the pixel (its draw order, 255 = nothing) and, for the depth model, the
+// visible triangle: 1 to 7 bytes per pixel cross PCIe instead of the 8-byte z-buffer words (any output may be null)
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
-model_unpack_kernel(const unsigned long long* z_buffer, size_t n, uint16_t* depth, int* triangle) {
+model_unpack_kernel(const unsigned long long* z_buffer, size_t n, uint16_t* depth, int* triangle, uint8_t* body) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const unsigned long long v = z_buffer[i];
     const bool hit = v != ~0ull;
-    depth[i] = hit ? (uint16_t)(v >> 32) : (uint16_t)65535;
-    if (triangle) triangle[i] = hit ? (int)(v & 0xffffffffull) : -1;
+    if (depth) depth[i] = hit ? (uint16_t)(v >> 32) : (uint16_t)65535;
+    if (triangle) triangle[i] = hit ? (int)(v & ((1ull << M3T_MODEL_TRIANGLE_BITS) - 1)) : -1;
+    if (body) body[i] = hit ? (uint8_t)((v >> M3T_MODEL_TRIANGLE_BITS) & 63ull) : (uint8_t)255;
   }
 }
 
@@ -253,7 +257,17 @@ struct View {  // one rendered template view on the host
   float fu = 0, pp = 0, term_a = 0, term_b = 0;
   const uint16_t* depth = nullptr;  // [S*S], 65535 = nothing (a body never reaches the far plane z_max)
   const int* triangle = nullptr;    // [S*S] visible triangle or -1; only for the depth model
-  bool Covered(int x, int y) const { return depth[size_t(y) * S + x] != 65535; }
+  // silhouette images (body ids) when the model has associated / occlusion bodies, else null:
+  // main renderer (main body 255, fixed bodies 120) and the renderers of region_model.cpp:417-463 / depth_model.cpp:170-177
+  const uint8_t* main_id = nullptr;
+  const uint8_t *occlusion = nullptr, *same_region = nullptr, *foreground = nullptr, *background = nullptr;
+  static uint8_t At(const uint8_t* image, int S, int x, int y) {
+    return (x < 0 || y < 0 || x >= S || y >= S) ? 0 : image[size_t(y) * S + x];
+  }
+  // the main body shows at this pixel of the main renderer
+  bool Covered(int x, int y) const { return main_id ? main_id[size_t(y) * S + x] == 255 : depth[size_t(y) * S + x] != 65535; }
+  bool Foreground(int x, int y) const { return foreground ? foreground[size_t(y) * S + x] == 255 : Covered(x, y); }
+  bool Background(int x, int y) const { return background ? background[size_t(y) * S + x] == 255 : Covered(x, y); }
   float DepthOf(uint16_t v) const { return term_a / (term_b - float(v)); }
   float DepthAt(int x, int y) const { return DepthOf(depth[size_t(y) * S + x]); }
   void PointVector(int x, int y, float out[3]) const {  // FullDepthRenderer::PointVector renderer.cpp:445-452
@@ -357,9 +371,30 @@ inline void RegionViewData(const View& v, const P4& camera2body, float sphere_ra
   auto contours = FindContours(v);
   contours.erase(std::remove_if(contours.begin(), contours.end(), [](const std::vector<Px>& c) { return c.size() < 15; }),
                  contours.end());  // kMinContourLength
-  std::vector<Px> valid;
-  for (auto& c : contours) valid.insert(valid.end(), c.begin(), c.end());
   const float pixel_to_meter = sphere_radius / v.fu;
+  const float max_depth_difference = pixel_to_meter * 10.0f;  // kMaxSurfaceGradient
+  auto contour_point_valid = [&](const Px& p) {  // IsContourPointValid :598-640
+    const Px neighbours[4] = {{p.x, p.y + 1}, {p.x, p.y - 1}, {p.x + 1, p.y}, {p.x - 1, p.y}};
+    if (v.same_region)
+      for (const Px& n : neighbours)
+        if (View::At(v.same_region, v.S, n.x, n.y) != 0) return false;
+    if (v.occlusion && View::At(v.occlusion, v.S, p.x, p.y) != 0) return false;
+    if (v.main_id) {
+      float sum = 0.0f;
+      int count = 0;
+      for (const Px& n : neighbours)
+        if (View::At(v.main_id, v.S, n.x, n.y) == 120) {  // kDifferentBodyID
+          sum += v.DepthAt(n.x, n.y);
+          ++count;
+        }
+      if (count > 0 && sum / float(count) < v.DepthAt(p.x, p.y) - max_depth_difference) return false;
+    }
+    return true;
+  };
+  std::vector<Px> valid;
+  for (auto& c : contours)
+    for (auto& p : c)
+      if (!v.main_id || contour_point_valid(p)) valid.push_back(p);
   *contour_length = float(valid.size()) * pixel_to_meter;
   if (valid.empty()) return;
   auto closest = [&](float u, float vv, int* cu, int* cv) {  // FindClosestContourPoint :775-790
@@ -427,7 +462,7 @@ inline void RegionViewData(const View& v, const P4& camera2body, float sphere_ra
       u_in -= u_step;
       v_in -= v_step;
       const int iu = int(u_in), iv = int(v_in);
-      if (iu < 0 || iu >= v.S || iv < 0 || iv >= v.S || !v.Covered(iu, iv)) {
+      if (iu < 0 || iu >= v.S || iv < 0 || iv >= v.S || !v.Foreground(iu, iv)) {
         int eu = center.x, ev = center.y;
         closest(u_in + u_step - 0.5f, v_in + v_step - 0.5f, &eu, &ev);
         dp[6] = p2m * hypotf(float(eu - center.x), float(ev - center.y));
@@ -441,7 +476,7 @@ inline void RegionViewData(const View& v, const P4& camera2body, float sphere_ra
         dp[7] = std::numeric_limits<float>::max();
         break;
       }
-      if (v.Covered(int(u_out), int(v_out))) {
+      if (v.Background(int(u_out), int(v_out))) {
         int eu = center.x, ev = center.y;
         closest(u_out - 0.5f, v_out - 0.5f, &eu, &ev);
         dp[7] = p2m * hypotf(float(eu - center.x), float(ev - center.y));
@@ -460,8 +495,13 @@ inline void DepthViewData(const View& v, const P4& camera2body, const P4& geomet
                           float sphere_radius, int n_points, float max_radius, float stride_m,
                           float* points /*[n_points][36]*/, float* surface_area) {
   std::fill(points, points + size_t(n_points) * M3T_DEPTH_POINT_FLOATS, 0.0f);
+  // the surface is sampled where the occlusion renderer still shows the main body (depth_model.cpp:170-177,311)
+  auto visible = [&](int x, int y) {
+    return v.occlusion ? v.occlusion[size_t(y) * v.S + x] == 255 : v.depth[size_t(y) * v.S + x] != 65535;
+  };
   size_t n_pixels = 0;
-  for (size_t i = 0; i < size_t(v.S) * v.S; ++i) n_pixels += v.depth[i] != 65535 ? 1 : 0;
+  for (int y = 0; y < v.S; ++y)
+    for (int x = 0; x < v.S; ++x) n_pixels += visible(x, y) ? 1 : 0;
   const float p2m = sphere_radius / v.fu;
   *surface_area = float(n_pixels) * (p2m * p2m);
   if (n_pixels == 0) return;
@@ -473,7 +513,7 @@ inline void DepthViewData(const View& v, const P4& camera2body, const P4& geomet
       int idx = int(generator() % total);
       x = idx / v.S;
       y = idx % v.S;
-      if (v.Covered(x, y)) break;
+      if (visible(x, y)) break;
     }
     float pc[3];
     v.PointVector(x, y, pc);

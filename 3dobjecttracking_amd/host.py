@@ -270,7 +270,16 @@ class RegionModel:
         """RegionModel::GenerateModel without OpenGL (HIP library only); body needs set_geometry()"""
         self = cls.__new__(cls)
         self.api = api
-        self.id = api.call("region_model_generate", body.id, C.byref(_capi.ModelGenerationParams(**params)))
+        # associated: (body, movable, same_region) triples of RegionModel::AddAssociatedBody
+        associated = params.pop("associated", ())
+        gp = C.byref(_capi.ModelGenerationParams(**params))
+        if associated:
+            ids = np.asarray([b.id for b, _, _ in associated], np.int32)
+            mov = np.asarray([int(m) for _, m, _ in associated], np.int32)
+            same = np.asarray([int(s) for _, _, s in associated], np.int32)
+            self.id = api.call("region_model_generate_associated", body.id, gp, len(ids), iptr(ids), iptr(mov), iptr(same))
+        else:
+            self.id = api.call("region_model_generate", body.id, gp)
         nv, npts, me = C.c_int(), C.c_int(), C.c_float()
         api.call("region_model_info", self.id, C.byref(nv), C.byref(npts), C.byref(me))
         self.n_views, self.n_points, self.max_contour_length = nv.value, npts.value, me.value
@@ -312,7 +321,13 @@ class DepthModel:
         """DepthModel::GenerateModel without OpenGL (HIP library only); body needs set_geometry()"""
         self = cls.__new__(cls)
         self.api = api
-        self.id = api.call("depth_model_generate", body.id, C.byref(_capi.ModelGenerationParams(**params)))
+        occlusion_bodies = params.pop("occlusion_bodies", ())  # DepthModel::AddOcclusionBody
+        gp = C.byref(_capi.ModelGenerationParams(**params))
+        if occlusion_bodies:
+            ids = np.asarray([b.id for b in occlusion_bodies], np.int32)
+            self.id = api.call("depth_model_generate_occluded", body.id, gp, len(ids), iptr(ids))
+        else:
+            self.id = api.call("depth_model_generate", body.id, gp)
         nv, npts, me = C.c_int(), C.c_int(), C.c_float()
         api.call("depth_model_info", self.id, C.byref(nv), C.byref(npts), C.byref(me))
         self.n_views, self.n_points, self.max_surface_area = nv.value, npts.value, me.value

@@ -64,6 +64,15 @@ int m3t_hip_depth_model_info(m3t_hip_context*, int model_id, int* n_views, int* 
  * ([n_views][n_points][38 | 36] points, [n_views][3] orientations, [n_views] contour lengths / surface areas). */
 int m3t_hip_region_model_generate(m3t_hip_context*, int body_id, const m3t_model_generation_params*);
 int m3t_hip_depth_model_generate(m3t_hip_context*, int body_id, const m3t_model_generation_params*);
+/* ... with associated bodies (RegionModel::AddAssociatedBody region_model.cpp:365-388: bodies that are drawn with the
+ * main body when its views are rendered -- fixed or movable relative to it, of the same colour region or not;
+ * region_model.cpp:417-463, 598-640, 695-770) and with occlusion bodies (DepthModel::AddOcclusionBody
+ * depth_model.cpp:61-70, 165-177).  The bodies share the main body's frame; all need m3t_hip_body_set_geometry. */
+int m3t_hip_region_model_generate_associated(m3t_hip_context*, int body_id, const m3t_model_generation_params*,
+                                             int n_associated, const int* body_ids, const int* movable,
+                                             const int* same_region);
+int m3t_hip_depth_model_generate_occluded(m3t_hip_context*, int body_id, const m3t_model_generation_params*,
+                                          int n_occlusion_bodies, const int* body_ids);
 int m3t_hip_region_model_get_views(m3t_hip_context*, int model_id, float* points, float* orientations, float* extents);
 int m3t_hip_depth_model_get_views(m3t_hip_context*, int model_id, float* points, float* orientations, float* extents);
 /* RegionModel::GetClosestView (region_model.cpp:105-130) / DepthModel (depth_model.cpp:81-106),

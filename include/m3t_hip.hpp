@@ -197,6 +197,15 @@ class RegionModel {
   RegionModel(ContextPtr c, const Body& body, const m3t_model_generation_params& params) : c_(std::move(c)) {
     id_ = c_->Check(m3t_hip_region_model_generate(c_->get(), body.id(), &params), "RegionModel");
   }
+  // ... with associated bodies (RegionModel::AddAssociatedBody): body ids and their movable / same-region flags
+  RegionModel(ContextPtr c, const Body& body, const m3t_model_generation_params& params,
+              const std::vector<int>& associated_body_ids, const std::vector<int>& movable,
+              const std::vector<int>& same_region)
+      : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_region_model_generate_associated(c_->get(), body.id(), &params, int(associated_body_ids.size()),
+                                                             associated_body_ids.data(), movable.data(), same_region.data()),
+                    "RegionModel");
+  }
   int GetClosestView(const Pose& body2camera_pose) const {
     int v = 0;
     c_->Check(m3t_hip_region_model_closest_view(c_->get(), id_, body2camera_pose.data(), &v), "GetClosestView");
@@ -216,6 +225,14 @@ class DepthModel {
   // DepthModel::GenerateModel without OpenGL; the body needs set_geometry()
   DepthModel(ContextPtr c, const Body& body, const m3t_model_generation_params& params) : c_(std::move(c)) {
     id_ = c_->Check(m3t_hip_depth_model_generate(c_->get(), body.id(), &params), "DepthModel");
+  }
+  // ... with occlusion bodies (DepthModel::AddOcclusionBody)
+  DepthModel(ContextPtr c, const Body& body, const m3t_model_generation_params& params,
+             const std::vector<int>& occlusion_body_ids)
+      : c_(std::move(c)) {
+    id_ = c_->Check(m3t_hip_depth_model_generate_occluded(c_->get(), body.id(), &params, int(occlusion_body_ids.size()),
+                                                          occlusion_body_ids.data()),
+                    "DepthModel");
   }
   DepthModel(ContextPtr c, const m3t_depth_model_desc& desc) : c_(std::move(c)) {
     id_ = c_->Check(m3t_hip_depth_model_create(c_->get(), &desc), "DepthModel");
