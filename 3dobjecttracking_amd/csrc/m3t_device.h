@@ -22,10 +22,10 @@ enum {
   LS_DELTA_R, LS_NCTS,              // normal_component_to_scale
   LS_MEAN, LS_VAR,                  // measured_variance
   LS_CONT,                          // continuous_distance
-  LS_VALID,                         // int bits: bit0 valid, bit1 valid w/o occlusion handling, bit2 horizontal walk, bit3 reversed fill
   LS_WALK_START,                    // int bits: first major-axis pixel coordinate
   LS_WALK_STEP,                     // minor-axis increment per pixel
-  LS_DIST0,                         // distribution[M3T_MAX_DISTRIBUTION_LENGTH]
+  LS_VALID,                         // int bits: bit0 valid, bit1 valid w/o occlusion handling, bit2 horizontal walk, bit3 reversed fill
+  LS_DIST0,                         // distribution[M3T_MAX_DISTRIBUTION_LENGTH]; LS_VALID .. are the rows a split object's workgroups exchange
   LS_FIELDS = LS_DIST0 + M3T_MAX_DISTRIBUTION_LENGTH
 };
 // ---- per-point state (depth modality), field-major -------------------------
@@ -149,6 +149,9 @@ struct DepthModDev {
   int depth_renderer_slot, silhouette_renderer_slot;
   float* point_state;       // [PS_FIELDS][n_points_max]
   float* gradient_hessian;  // [6 + 36]
+  // 1: the region modality on the same rigid optimizer uses a model with the same view orientations and a camera
+  // with the same world2camera pose, so both GetClosestView searches give the same index (set by UploadTables)
+  int view_search_shared;
 };
 
 // One rigid body with an unconstrained 6-dof root link (body2joint = I):

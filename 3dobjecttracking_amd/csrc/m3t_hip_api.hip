@@ -57,6 +57,7 @@ struct Model {
   float stride_depth_offset = 0.002f, max_radius_depth_offset = 0.05f, max_extent = 0.0f;
   DevMem points, orientations, extents;
   DevMem points8, orientations4;  // device-only compact copies of the hot fields
+  std::vector<float> h_orientations;  // host copy: modalities whose models share their view table share the view search
 };
 
 struct Camera {
@@ -361,6 +362,7 @@ int CreateModel(Ctx* ctx, bool region, int n_views, int n_points, const float* p
   m->stride_depth_offset = stride;
   m->max_radius_depth_offset = max_radius;
   for (int v = 0; v < n_views; ++v) m->max_extent = std::max(m->max_extent, ext[v]);
+  m->h_orientations.assign(ori, ori + size_t(n_views) * 3);
   size_t pb = size_t(n_views) * n_points * m->point_floats * 4;
   HIPCHK(m->points.alloc(pb));
   HIPCHK(m->orientations.alloc(size_t(n_views) * 12));
@@ -876,6 +878,7 @@ int UploadTables(Ctx* ctx) {
     }
     // optimizer table
     ctx->opt_table.clear();
+    bool depth_table_changed = false;
     ctx->fused_possible = !ctx->optimizers.empty() && !ctx->tree_mode;
     std::vector<char> body_used(ctx->body_poses.size() / 16, 0);
     for (auto& o : ctx->optimizers) {
@@ -892,6 +895,18 @@ int UploadTables(Ctx* ctx) {
         if (ref.region) od.region_modality = ref.index;
         else od.depth_modality = ref.index;
       }
+      if (od.region_modality >= 0 && od.depth_modality >= 0) {
+        const RegionMod& rmod = *ctx->region_mods[od.region_modality];
+        DepthMod& dmod = *ctx->depth_mods[od.depth_modality];
+        const Model& a = *ctx->region_models[rmod.model];
+        const Model& b = *ctx->depth_models[dmod.model];
+        const bool shared = a.h_orientations == b.h_orientations &&
+                            std::memcmp(ctx->cameras[rmod.camera]->world2camera, ctx->cameras[dmod.camera]->world2camera, 64) == 0;
+        if (dmod.dev.view_search_shared != (shared ? 1 : 0)) {
+          dmod.dev.view_search_shared = shared ? 1 : 0;
+          depth_table_changed = true;
+        }
+      }
       if (body_used[l.body]) ctx->fused_possible = false;
       body_used[l.body] = 1;
       ctx->opt_table.push_back(od);
@@ -907,6 +922,10 @@ int UploadTables(Ctx* ctx) {
     ctx->fuse_histogram_possible = ctx->fused_possible && !ctx->region_mods.empty();
     for (auto& m : ctx->region_mods)
       if (m->shared_histograms >= 0) ctx->fuse_histogram_possible = false;
+    if (depth_table_changed) {
+      for (size_t i = 0; i < d.size(); ++i) d[i] = ctx->depth_mods[i]->dev;
+      HIPCHK(hipMemcpy(ctx->d_depth.p, d.data(), d.size() * sizeof(DepthModDev), hipMemcpyHostToDevice));
+    }
     HIPCHK(ctx->d_opts.alloc(std::max<size_t>(1, ctx->opt_table.size()) * sizeof(RigidOptDev)));
     if (!ctx->opt_table.empty())
       HIPCHK(hipMemcpy(ctx->d_opts.p, ctx->opt_table.data(), ctx->opt_table.size() * sizeof(RigidOptDev),
@@ -1272,6 +1291,7 @@ int m3t_hip_camera_set_world2camera_pose(m3t_hip_context* ctx, int id, const flo
   REQUIRE(id >= 0 && id < int(ctx->cameras.size()) && w2c, M3T_ERR_INVALID_ARGUMENT, "bad camera id");
   std::memcpy(ctx->cameras[id]->world2camera, w2c, 64);
   ctx->cams_dirty = true;
+  ctx->tables_dirty = true;  // (whether a body's two modalities share their view search depends on the camera poses)
   return M3T_OK;
 }
 int m3t_hip_camera_set_ring(m3t_hip_context* ctx, int id, int n_slots) {

@@ -706,7 +706,7 @@ __device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> 
 //          thread per line: normalisation + CalculateDistributionMoments :1639.
 // ---------------------------------------------------------------------------
 template <bool HIST_LDS, int BMAX = 8>
-__device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
+__device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                        const Affine& b2dc, int iteration, int corr_iteration,
                                                        const Lds& s, int line_lo = 0, int line_hi = 1 << 30) {
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -729,6 +729,11 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   const bool region_checking =
       m.use_region_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
   const bool occlusion_pass = measured_pass || modeled_pass;
+  // A workgroup that shares its object with others (line_hi set) runs the occlusion tests -- up to 36 depth samples per
+  // line -- for its own lines only and defers the two-pass vote :435-463 until the flags of all lines have been
+  // exchanged (region_finish_flags): meanwhile it walks every valid line of its part.  The lines the vote then drops
+  // were walked in vain; the result is the reference's.
+  const bool defer_vote = occlusion_pass && line_hi < (1 << 30);
   const int n_seg = m.n_seg;
   G<uint8_t> image = as_global(cam.image);
   const uint32_t pitch = cam.pitch;
@@ -780,14 +785,15 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
         valid = dynamic_line_region_sufficient(*m.silhouette_renderer, m.region_id, m.min_continuous_distance,
                                                it.fscale, center_u, center_v, nu, nv);
       bool valid_occ = valid;
-      if (valid && modeled_pass) {
+      const bool test_occlusion = !defer_vote || (line >= line_lo && line < line_hi);
+      if (valid && modeled_pass && test_occlusion) {
         G<float> p = as_global(m.points) + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
         float diameter = 2.0f * m.modeled_occlusion_radius * ((cam.fu / Z) * m.depth_renderer->state[RS_SCALE]);
         unsigned short min_value = modeled_window_min(*m.depth_renderer, center_u, center_v, diameter);
         valid_occ = renderer_depth(*m.depth_renderer, min_value) >
                     Z - p[8 + m.modeled_depth_offset_id] - m.modeled_occlusion_threshold;
       }
-      if (valid_occ && measured_pass) {
+      if (valid_occ && measured_pass && test_occlusion) {
         float dx, dy, dz;
         apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
         float du = dx * dcam->fu / dz + dcam->ppu;
@@ -838,7 +844,7 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   }
   // two-pass fallback :435-463: use the occlusion-handled set only if it has enough lines
   bool use_occ = false;
-  if (occlusion_pass) {
+  if (occlusion_pass && !defer_vote) {
     int cnt = wave_sum_i(my_valid_occ);
     int* imisc = reinterpret_cast<int*>(s.misc);
     if (tid % kWave == 0) imisc[64 + tid / kWave] = cnt;
@@ -943,12 +949,34 @@ __device__ __forceinline__ void region_correspondences(CRegion& m, CCam& cam, CC
   }
   // the final flag (bit 0 = line is in data_lines_), for the lines of all parts: it follows from phase A, which every
   // workgroup ran in full.  (Threads above may still test `flags & valid_mask`: bit 0 only ever takes that test's value.)
+  if (!defer_vote)
+    for (int line = tid; line < nl; line += nt) {
+      const int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+      s.state[LS_VALID * nl + line] = i2f_bits((flags & ~1) | ((flags & valid_mask) ? 1 : 0));
+    }
+  __syncthreads();
+  PHASE_MARK(4);
+  return view;  // the closest view (a depth modality of the same body with the same view table and camera pose reuses it)
+}
+
+// tracking_step_split_kernel, occlusion handling on: the two-pass vote :435-463 and the final flags once every
+// workgroup's occlusion results (bit 0 of the flags) are in.  Barriers inside; ends without one.
+__device__ void region_finish_flags(CRegion& m, const Lds& s) {
+  const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
+  int mine = 0;
+  for (int line = tid; line < nl; line += nt) mine += f2i_bits(s.state[LS_VALID * nl + line]) & 1;
+  const int cnt = wave_sum_i(mine);
+  int* imisc = reinterpret_cast<int*>(s.misc);
+  if (tid % kWave == 0) imisc[64 + tid / kWave] = cnt;
+  __syncthreads();
+  int total = 0;
+  for (int w = 0; w < nt / kWave; ++w) total += imisc[64 + w];
+  const int valid_mask = total >= m.min_n_unoccluded_lines ? 1 : 2;
   for (int line = tid; line < nl; line += nt) {
     const int flags = f2i_bits(s.state[LS_VALID * nl + line]);
     s.state[LS_VALID * nl + line] = i2f_bits((flags & ~1) | ((flags & valid_mask) ? 1 : 0));
   }
   __syncthreads();
-  PHASE_MARK(4);
 }
 
 // CalculateDistributionMoments :1639-1658 from the normalised distributions in LDS, for the lines [lo, hi) if
@@ -1200,7 +1228,7 @@ struct SplitExchange {
   uint32_t seq;    // launch sequence number (> 0)
   int part, n_parts, lshift;
   int per_part_lines, per_part_points;
-  int n_region_fields;                      // distribution_length: rows LS_DIST0 .. of the line state
+  int n_region_fields, first_region_row;    // rows LS_DIST0 .. (from LS_VALID on while the occlusion vote is deferred)
   int n_depth_fields, first_depth_row;      // rows first_depth_row .. PS_VALID of the point state
 };
 constexpr int kExchangeFieldBits = 5;
@@ -1222,7 +1250,7 @@ __device__ __forceinline__ SplitExchangeView split_exchange_view(const SplitExch
   v.slot = x.granules + ((size_t)(round & 1) * x.n_parts << (kExchangeFieldBits + x.lshift));
   v.lds0 = s.misc;  // the lowest address of the workgroup's LDS carve-up
   // field f -> element offset of its row from lds0
-  v.region_row0 = int(s.state - v.lds0) + LS_DIST0 * s.nl;
+  v.region_row0 = int(s.state - v.lds0) + x.first_region_row * s.nl;
   v.depth_row0 = int(ps - v.lds0) + x.first_depth_row * np;
   return v;
 }
@@ -1804,7 +1832,7 @@ __device__ void rigid_solve_wave(float gh, float lambda_rot, float lambda_trans,
 // Part 2 (depth_correspondences_vote): the two-pass fallback :282-313 over all points.
 __device__ void depth_correspondences_scan(CDepth& m, CCam& cam, const Affine& b2c, int iteration,
                                            int corr_iteration, float* ps, int np, float* misc, int pt_lo = 0,
-                                           int pt_hi = 1 << 30) {
+                                           int pt_hi = 1 << 30, int known_view = -1) {
   // 16 lanes (one DPP row) per model point: the strided search window of FindCorrespondence
   // (<= 15x15 depth samples) and the occlusion window (<= 6x6) are scanned by the row in
   // parallel; the winner is the smallest distance, ties to the lowest scan index == the
@@ -1813,7 +1841,7 @@ __device__ void depth_correspondences_scan(CDepth& m, CCam& cam, const Affine& b
   const int tid = threadIdx.x, nt = blockDim.x;
   const int gl = tid % kGroup;
   PHASE_T0();
-  const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);
+  const int view = known_view >= 0 ? known_view : closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);
   PHASE_MARK(17);
   int n_points = number_of_lines(m.n_points_max, m.use_adaptive_coverage, m.reference_surface_area, as_global(m.extents), view,
                                  m.max_extent, m.n_points);
@@ -2616,33 +2644,50 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     exchange.per_part_lines = split->per_part_lines;
     exchange.per_part_points = split->per_part_points;
     exchange.n_region_fields = rm ? rm->distribution_length : 0;
+    exchange.first_region_row = LS_DIST0;
     exchange.n_depth_fields = write_state ? PS_VALID + 1 - PS_CENTER_U : PS_VALID + 1 - PS_CORR_X;
     exchange.first_depth_row = write_state ? PS_CENTER_U : PS_CORR_X;
   }
   for (int c = 0; c < n_corr_iterations; ++c) {
     {
       const Affine b2w = load_pose(pose);
+      int region_view = -1;
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_correspondences<HIST_LDS, SPLIT ? 2 : 8>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, line_lo, line_hi);
+        region_view = region_correspondences<HIST_LDS, SPLIT ? 2 : 8>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, line_lo,
+                                                                      line_hi);
       }
       if (dm) {
         PHASE_T0();
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
-        depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, pt_lo, pt_hi);
+        // (same view table and same camera pose as the region modality of this body: its search is this one's)
+        depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, pt_lo, pt_hi,
+                                   (rm && dm->view_search_shared) ? region_view : -1);
         PHASE_MARK(16);
       }
       if constexpr (SPLIT) {
         PHASE_T0();
+        // with occlusion handling on, the flags of the own lines (their occlusion results) travel too and the vote
+        // over all lines follows the exchange (region_correspondences, defer_vote)
+        const bool vote_deferred = rm && rm->measure_occlusions && (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
+        if (rm) {
+          exchange.n_region_fields = rm->distribution_length + (vote_deferred ? 1 : 0);
+          exchange.first_region_row = vote_deferred ? LS_VALID : LS_DIST0;
+        }
         // publish the own part's results, take the moments of the own lines while the other parts' results are on
         // their way, collect them, then the moments of the received lines
         split_exchange_publish(exchange, c, s, rm != nullptr, ps, np, dm != nullptr);
-        if (rm) region_moments(*rm, s, line_lo, line_hi, true);
+        if (rm && !vote_deferred) region_moments(*rm, s, line_lo, line_hi, true);
         if (!split_exchange_collect(exchange, c, s, rm != nullptr, ps, np, dm != nullptr)) return;
         PHASE_MARK(22);
-        if (rm) region_moments(*rm, s, line_lo, line_hi, false);
+        if (vote_deferred) {
+          region_finish_flags(*rm, s);
+          region_moments(*rm, s);
+        } else if (rm) {
+          region_moments(*rm, s, line_lo, line_hi, false);
+        }
       } else {
         if (rm) region_moments(*rm, s);
       }

@@ -40,3 +40,30 @@ def max_over_ranks(value, dist=None, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def place_bodies(n_bodies, world_size, shared_histograms=()):
+    """Rank of every body of ONE kinematic structure spread over `world_size` GPUs: bodies are placed
+    round-robin, except that bodies whose RegionModalities share a ColorHistograms object
+    (RegionModality::UseSharedColorHistograms, region_modality.h:200-201; evaluate_rtb_dataset.cpp:75) stay
+    together on the rank of the group's first body -- the shared count table is then summed inside one context and
+    the structure keeps its single all-reduce per Newton step (no second collective for the histograms).
+    shared_histograms: iterable of body-index groups.  Returns a list: body -> rank."""
+    rank_of = [None] * n_bodies
+    group_of = {}
+    for g, bodies in enumerate(shared_histograms):
+        for b in bodies:
+            if b in group_of:
+                raise ValueError("body %d is in two shared-histogram groups" % b)
+            group_of[b] = g
+    group_rank, nxt = {}, 0
+    for b in range(n_bodies):
+        g = group_of.get(b)
+        if g is not None and g in group_rank:
+            rank_of[b] = group_rank[g]
+            continue
+        rank_of[b] = nxt % world_size
+        nxt += 1
+        if g is not None:
+            group_rank[g] = rank_of[b]
+    return rank_of

@@ -29,7 +29,7 @@ def main():
     start_root = syn.perturb_pose(gt[0][0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
     start_angles = gt[0][1] + 0.01
     hip = pkg.open_context(local)
-    owned = [i for i in range(n_bodies) if i % world == rank]
+    owned = [i for i, r in enumerate(pkg.sharding.place_bodies(n_bodies, world)) if r == rank]
     ch = bc.Chain(hip, host, syn, inputs, joints, start_root, start_angles, owned)
     uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
     if rank == 0:

@@ -123,3 +123,14 @@ def test_kinematic_structure_over_two_ranks(tmp_path):
     r1 = np.load(os.path.join(str(tmp_path), "chain_2_1.npy"))
     assert np.array_equal(r0, r1)       # replicas stay bit-identical
     assert np.array_equal(r0, ref)      # and equal the single-process run
+
+
+def test_bodies_that_share_color_histograms_stay_on_one_rank():
+    import importlib
+    sh = importlib.import_module("3dobjecttracking_amd.sharding")
+    assert sh.place_bodies(8, 4) == [0, 1, 2, 3, 0, 1, 2, 3]
+    placed = sh.place_bodies(8, 4, shared_histograms=[(1, 5, 6), (2, 3)])
+    assert placed[1] == placed[5] == placed[6] and placed[2] == placed[3]
+    assert sorted(set(placed)) == [0, 1, 2, 3]  # every GPU still has work
+    with pytest.raises(ValueError):
+        sh.place_bodies(4, 2, shared_histograms=[(0, 1), (1, 2)])
