@@ -323,6 +323,44 @@ __device__ bool occlusion_window_clear(CCam& dc, float center_u, float center_v,
   return true;
 }
 
+// the same window scanned by the 16 lanes of a DPP row (lane gl takes samples gl, gl + 16, gl + 32): true if one
+// of THIS lane's samples occludes; the caller ORs the row
+__device__ __forceinline__ bool occlusion_window_lane_hit(CCam& dc, float center_u, float center_v, float diameter,
+                                                          float depth, float depth_offset, float threshold, int gl) {
+  int stride = f2i(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
+  if (stride < 1) stride = 1;  // (a body behind the camera: no meaningful window, but no division by zero either)
+  int n_strides = f2i(diameter / stride + 0.5f);
+  int rounded_diameter = n_strides * stride;
+  float rounded_radius = 0.5f * (float)rounded_diameter;
+  int u_min = f2i(center_u - rounded_radius + 0.5f);
+  int v_min = f2i(center_v - rounded_radius + 0.5f);
+  int u_max = u_min + rounded_diameter;
+  int v_max = v_min + rounded_diameter;
+  u_min = max(u_min, 0);
+  v_min = max(v_min, 0);
+  u_max = min(u_max, dc.width - 1);
+  v_max = min(v_max, dc.height - 1);
+  unsigned short min_depth = (unsigned short)f2i((depth - depth_offset - threshold) / dc.depth_scale);
+  G<uint8_t> image = as_global(dc.image);
+  const int n_u = u_max >= u_min ? (u_max - u_min) / stride + 1 : 0;
+  const int n_v = v_max >= v_min ? (v_max - v_min) / stride + 1 : 0;
+  const int total = n_u * n_v;  // <= 36
+  unsigned short d[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int pos = gl + 16 * k;
+    if (pos < total) {
+      const int vi = pos / n_u, ui = pos - vi * n_u;
+      d[k] = *reinterpret_cast<G<unsigned short>>(image + (uint32_t)(v_min + vi * stride) * dc.pitch +
+                                                  (uint32_t)(u_min + ui * stride) * 2u);
+    }
+  }
+  bool hit = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) hit |= (d[k] > 0 && d[k] < min_depth);
+  return hit;
+}
+
 // ---------------------------------------------------------------------------
 // renderer-fed branches: what the modalities read from a focused rendering (m3t_render.hip writes it)
 // ---------------------------------------------------------------------------
@@ -742,6 +780,7 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   int my_valid_occ = 0;
   for (int line = tid; line < nl; line += nt) {
     int flags = 0;
+    if (measured_pass) s.seg_f[line * 5 + 2] = -1.0f;  // no occlusion window to scan (yet)
     if (line < n_lines) {
       G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
       const v4f pa = p8[0], pb4 = p8[1];
@@ -793,16 +832,24 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
         valid_occ = renderer_depth(*m.depth_renderer, min_value) >
                     Z - p[8 + m.modeled_depth_offset_id] - m.modeled_occlusion_threshold;
       }
-      if (valid_occ && measured_pass && test_occlusion) {
-        float dx, dy, dz;
-        apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
-        float du = dx * dcam->fu / dz + dcam->ppu;
-        float dv = dy * dcam->fv / dz + dcam->ppv;
-        float meter_to_pixel = dcam->fu / dz;
-        float diameter = 2.0f * m.measured_occlusion_radius * meter_to_pixel;
-        G<float> p = as_global(m.points) + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
-        valid_occ = occlusion_window_clear(*dcam, du, dv, diameter, dz, p[8 + m.measured_depth_offset_id],
-                                           m.measured_occlusion_threshold);
+      // IsLineUnoccludedMeasured :1343-1389: the window of up to 36 depth samples is scanned by 16 lanes per line
+      // after this loop (measured_occlusion_pass); here only its parameters are set aside (seg_f is free until phase B)
+      if (measured_pass) {
+        float* w = s.seg_f + line * 5;
+        if (valid_occ && test_occlusion) {
+          float dx, dy, dz;
+          apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
+          float du = dx * dcam->fu / dz + dcam->ppu;
+          float dv = dy * dcam->fv / dz + dcam->ppv;
+          float meter_to_pixel = dcam->fu / dz;
+          float diameter = 2.0f * m.measured_occlusion_radius * meter_to_pixel;
+          G<float> p = as_global(m.points) + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
+          w[0] = du;
+          w[1] = dv;
+          w[2] = diameter;
+          w[3] = dz;
+          w[4] = p[8 + m.measured_depth_offset_id];
+        }
       }
       if (valid) {
         flags = (valid_occ ? 1 : 0) | 2 | (horiz ? 4 : 0) | ((ndom > 0.0f) ? 0 : 8);
@@ -841,6 +888,33 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
       }
     }
     s.state[LS_VALID * nl + line] = i2f_bits(flags);
+  }
+  if (measured_pass) {  // 16 lanes per line: the occlusion windows
+    __syncthreads();
+    const int gl = tid & 15;
+    const int lo = defer_vote ? line_lo : 0, hi = defer_vote ? (line_hi < nl ? line_hi : nl) : nl;
+    const int groups = nt >> 4;
+    for (int line0 = lo; line0 < hi; line0 += groups) {  // uniform trip count: the DPP row OR needs all lanes of a row
+      const int line = line0 + (tid >> 4);
+      int occluded = 0;
+      if (line < hi) {
+        const float* w = s.seg_f + line * 5;
+        if (w[2] >= 0.0f &&
+            occlusion_window_lane_hit(*dcam, w[0], w[1], w[2], w[3], w[4], m.measured_occlusion_threshold, gl))
+          occluded = 1;
+      }
+      occluded |= dpp_self_i<0x111, 0xf>(occluded);
+      occluded |= dpp_self_i<0x112, 0xf>(occluded);
+      occluded |= dpp_self_i<0x114, 0xf>(occluded);
+      occluded |= dpp_self_i<0x118, 0xf>(occluded);
+      if (gl == 15 && line < hi && occluded) {
+        const int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+        s.state[LS_VALID * nl + line] = i2f_bits(flags & ~1);
+      }
+    }
+    __syncthreads();
+    my_valid_occ = 0;  // counted from the flags now
+    for (int line = tid; line < nl; line += nt) my_valid_occ += f2i_bits(s.state[LS_VALID * nl + line]) & 1;
   }
   // two-pass fallback :435-463: use the occlusion-handled set only if it has enough lines
   bool use_occ = false;
@@ -2162,6 +2236,36 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
   const bool visible_depth = m.model_occlusions && renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
   const bool visible_silhouette =
       m.use_region_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
+  // IsLineUnoccludedMeasured at the final pose :1084-1087: the windows of all lines first, 16 lanes per line (the
+  // result per line in the misc block, which holds 768 of them; longer models test inside the walk)
+  int* line_occluded = reinterpret_cast<int*>(misc) + 256;
+  const bool measured = handle_occlusions && m.measure_occlusions;
+  const bool windows_first = measured && n_lines <= M3T_MISC_FLOATS - 256;
+  if (windows_first) {
+    const int gl = tid & 15, groups = nt >> 4;
+    for (int line0 = 0; line0 < n_lines; line0 += groups) {
+      const int line = line0 + (tid >> 4);
+      int occluded = 0;
+      if (line < n_lines) {
+        G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
+        const v4f pa = p8[0];
+        float dx, dy, dz;
+        apply_pose(b2dc, pa.x, pa.y, pa.z, dx, dy, dz);
+        const float du = dx * dcam->fu / dz + dcam->ppu;
+        const float dv = dy * dcam->fv / dz + dcam->ppv;
+        const float diameter = 2.0f * m.measured_occlusion_radius * (dcam->fu / dz);
+        const float offset = as_global(m.points)[((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS + 8 +
+                                                 m.measured_depth_offset_id];
+        occluded = occlusion_window_lane_hit(*dcam, du, dv, diameter, dz, offset, m.measured_occlusion_threshold, gl) ? 1 : 0;
+      }
+      occluded |= dpp_self_i<0x111, 0xf>(occluded);
+      occluded |= dpp_self_i<0x112, 0xf>(occluded);
+      occluded |= dpp_self_i<0x114, 0xf>(occluded);
+      occluded |= dpp_self_i<0x118, 0xf>(occluded);
+      if (gl == 15 && line < n_lines) line_occluded[line] = occluded;
+    }
+    __syncthreads();
+  }
   // two lanes per line: even lane = foreground walk (inwards), odd lane = background walk
   for (int item = tid; item < 2 * n_lines; item += nt) {
     const int line = item >> 1;
@@ -2184,7 +2288,9 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
             Z - p[8 + m.modeled_depth_offset_id] - m.modeled_occlusion_threshold))
         continue;
     }
-    if (handle_occlusions && m.measure_occlusions) {
+    if (windows_first) {
+      if (line_occluded[line]) continue;
+    } else if (measured) {
       float dx, dy, dz;
       apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
       float du = dx * dcam->fu / dz + dcam->ppu;
