@@ -275,6 +275,7 @@ _SIGNATURES = {
     "sync": [],
     "modality_get_gradient_hessian": [C.c_int, c_float_p, c_float_p],
     "modality_set_gradient_hessian": [C.c_int, c_float_p, c_float_p],
+    "modalities_get_gradient_hessian": [c_float_p, C.c_int],
     "region_modality_get_lines": [C.c_int, C.c_void_p, C.c_int, c_int_p],
     "depth_modality_get_points": [C.c_int, C.c_void_p, C.c_int, c_int_p],
     "region_modality_get_histograms": [C.c_int, c_float_p, c_float_p],

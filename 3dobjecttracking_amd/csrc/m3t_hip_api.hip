@@ -190,6 +190,8 @@ struct m3t_hip_context {
   int sequential_sum = 0;
   // device tables
   DevMem d_cams, d_region, d_depth, d_opts, d_poses, d_scratch_view;
+  DevMem d_gh_sources, d_gh_all;  // m3t_hip_modalities_get_gradient_hessian
+  int gh_sources_count = -1;
   bool tables_dirty = true, cams_dirty = true, slots_dirty = false, poses_dirty_host = true;
   const CameraDev* cams_active = nullptr;  // the camera table version the kernels read (UploadTables)
   size_t pose_capacity = 0;
@@ -1747,6 +1749,36 @@ int m3t_hip_modality_get_gradient_hessian(m3t_hip_context* ctx, int id, float g[
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (g) std::memcpy(g, buf, 24);
   if (h) std::memcpy(h, buf + 6, 144);
+  return M3T_OK;
+}
+}  // extern "C"
+// gradient | Hessian of every modality into one contiguous buffer (one read-back per round for an adapter host)
+extern "C" __global__ void gather_gradient_hessian_kernel(const float* const* sources, float* out) {
+  out[blockIdx.x * 42 + threadIdx.x] = sources[blockIdx.x][threadIdx.x];
+}
+extern "C" {
+int m3t_hip_modalities_get_gradient_hessian(m3t_hip_context* ctx, float* out, int capacity) {
+  CHECK_CTX();
+  const int n = int(ctx->modalities.size());
+  REQUIRE(out && capacity >= n, M3T_ERR_INVALID_ARGUMENT, "the buffer must hold 42 floats per modality");
+  REQUIRE(ctx->state_valid, M3T_ERR_NOT_SET_UP,
+          "gradient/hessian are not written back in fused mode 1 (use m3t_hip_set_fused_step(ctx, 0 or 2))");
+  if (n == 0) return M3T_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->gh_sources_count != n) {
+    std::vector<const float*> src(size_t(n), nullptr);
+    for (int i = 0; i < n; ++i) src[size_t(i)] = ModalityGh(ctx, i);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx->d_gh_sources.alloc(size_t(n) * sizeof(float*)));
+    HIPCHK(ctx->d_gh_all.alloc(size_t(n) * 42 * sizeof(float)));
+    HIPCHK(hipMemcpy(ctx->d_gh_sources.p, src.data(), size_t(n) * sizeof(float*), hipMemcpyHostToDevice));
+    ctx->gh_sources_count = n;
+  }
+  hipLaunchKernelGGL(gather_gradient_hessian_kernel, dim3(n), dim3(42), 0, ctx->stream,
+                     ctx->d_gh_sources.as<const float*>(), ctx->d_gh_all.as<float>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, ctx->d_gh_all.p, size_t(n) * 42 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return M3T_OK;
 }
 int m3t_hip_modality_set_gradient_hessian(m3t_hip_context* ctx, int id, const float g[6], const float h[36]) {

@@ -241,6 +241,12 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
         if not fused_hist:
             roofline["histogram_kernel_ms"] = round(hist_ms, 4)
 
+    # ---- the evaluators' four time buckets (rbot_evaluator.cpp:354-414) on the device, one launch per sub-step
+    # (m3t_hip_set_fused_step(0)), each bucket synchronised and timed on the host: what the fused launch replaces ----
+    buckets = None
+    if rank == 0 and world == 1 and args.config in ("rbot64", "ycb21"):
+        buckets = device_buckets(hip, restart, n_obj, W, min(K, 5), cfg)
+
     # ---- host-buffer (PCIe-inclusive) rate: every step first receives its frames from host memory; never `value` ----
     pcie = None
     if rank == 0 and world == 1 and args.config == "rbot64" and not args.no_pcie:
@@ -316,7 +322,7 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
         "repeats": {"n": len(times), "ms_per_step_min": round(min(times) / K * 1e3, 4),
                     "ms_per_step_median": round(elapsed / K * 1e3, 4),
                     "ms_per_step_all": [round(x / K * 1e3, 4) for x in times]},
-        "pcie_inclusive": pcie,
+        "pcie_inclusive": pcie, "device_buckets_unfused": buckets,
         "frac_of_hbm_roofline_whole_step": round(total / elapsed * cfg["alg"] / (HBM_PEAK_GBS * 1e9 * world), 5),
         "newton_steps_per_s": round(total / elapsed * cfg["newton"], 1),  # corr-iterations x updates
     }
@@ -325,6 +331,37 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
     if args.extras:
         out["extras"] = extras_point(pkg)
     return out
+
+
+def device_buckets(hip, restart, n_obj, W, K, cfg):
+    n_corr, n_update = (7, 2) if cfg["newton"] == 14 else (4, 2)
+    hip.call("bodies_set_poses", restart.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+    hip.call("set_fused_step", 0)
+    t = [0.0, 0.0, 0.0, 0.0]
+
+    def timed(i, name, *a):
+        t0 = time.perf_counter()
+        hip.call(name, *a)
+        hip.call("sync")
+        t[i] += time.perf_counter() - t0
+
+    for k in range(1 + W, 1 + W + K):
+        hip.call("cameras_select_slot", k)
+        for c in range(n_corr):
+            timed(0, "calculate_correspondences", k, c)
+            for u in range(n_update):
+                timed(1, "calculate_gradient_and_hessian", k, c, u)
+                timed(2, "calculate_optimization", k, c, u)
+        timed(3, "calculate_results", k)
+    hip.call("set_fused_step", 1)
+    tot = sum(t)
+    return {"ms_per_step": {"correspondences": round(t[0] / K * 1e3, 4), "gradient_hessian": round(t[1] / K * 1e3, 4),
+                            "optimization": round(t[2] / K * 1e3, 4), "results": round(t[3] / K * 1e3, 4),
+                            "total": round(tot / K * 1e3, 4)},
+            "share": {"correspondences": round(t[0] / tot, 3), "gradient_hessian": round(t[1] / tot, 3),
+                      "optimization": round(t[2] / tot, 3), "results": round(t[3] / tot, 3)},
+            "note": "one launch per sub-step (%d launches per frame), host-timed with a sync after every launch; the "
+                    "fused launch does the same work in ms_per_step" % (n_corr * (1 + 2 * n_update) + 1)}
 
 
 def pcie_legs(hip, inst, inputs, n_obj, W, K):

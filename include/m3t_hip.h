@@ -140,6 +140,9 @@ int m3t_hip_modality_get_gradient_hessian(m3t_hip_context*, int modality_id, flo
                                           float hessian[36]);
 int m3t_hip_modality_set_gradient_hessian(m3t_hip_context*, int modality_id, const float gradient[6],
                                           const float hessian[36]);
+/* the same for ALL modalities at once, in creation order: out[modality][6 + 36]; one device-to-host copy per round
+ * instead of one per modality (what an adapter host calls after calculate_gradient_and_hessian) */
+int m3t_hip_modalities_get_gradient_hessian(m3t_hip_context*, float* out, int capacity_modalities);
 /* data_lines_ / data_points_ of the last CalculateCorrespondences (for visualisation / parity) */
 int m3t_hip_region_modality_get_lines(m3t_hip_context*, int modality_id, m3t_data_line* out, int capacity,
                                       int* n_lines);

@@ -464,6 +464,12 @@ class Tracker {
   void RegisterHostBuffer(void* ptr, size_t bytes) { c_->Check(m3t_hip_host_register(c_->get(), ptr, bytes), "Tracker"); }
   void UnregisterHostBuffer(void* ptr) { c_->Check(m3t_hip_host_unregister(c_->get(), ptr), "Tracker"); }
   bool IngestSync() { return c_->Step(m3t_hip_ingest_sync(c_->get())); }
+  // gradient | Hessian of every modality (creation order), one read-back
+  std::vector<float> GradientsAndHessians(int n_modalities) const {
+    std::vector<float> out(size_t(n_modalities) * 42);
+    c_->Check(m3t_hip_modalities_get_gradient_hessian(c_->get(), out.data(), n_modalities), "Tracker");
+    return out;
+  }
   // batch ingest: one frame ring for a group of cameras, one transfer per batch-frame
   void SetSharedRing(const std::vector<int>& camera_ids, int n_slots) {
     c_->Check(m3t_hip_cameras_set_ring(c_->get(), camera_ids.data(), int(camera_ids.size()), n_slots), "Tracker");

@@ -17,6 +17,7 @@
 #include <m3t/camera.h>
 #include <m3t/modality.h>
 
+#include <algorithm>
 #include <filesystem>
 #include <iostream>
 #include <memory>
@@ -155,6 +156,8 @@ struct HipBatch {
     return round->ok;
   }
   Round start_round, corr_round, gh_round, res_round;
+  int n_modalities = 0;            // device modality ids are 0 .. n_modalities - 1
+  std::vector<float> gh_cache;     // [n_modalities][6 + 36] of the last gradient / Hessian round
 };
 
 // what both adapters do the same way
@@ -175,10 +178,18 @@ class HipModality : public m3t::Modality {
   bool CalculateGradientAndHessian(int iteration, int corr_iteration, int opt_iteration) override {
     if (!CheckSetUp()) return false;
     const bool ok = batch_->Once(&batch_->gh_round, id_, (iteration * 4096L + corr_iteration) * 4096L + opt_iteration, false, [&] {
-      return m3t_hip_calculate_gradient_and_hessian(batch_->ctx, iteration, corr_iteration, opt_iteration);
+      int rc = m3t_hip_calculate_gradient_and_hessian(batch_->ctx, iteration, corr_iteration, opt_iteration);
+      if (rc < 0) return rc;
+      // ONE read-back for the whole batch per round; the modalities of the round copy their 42 floats from it
+      batch_->gh_cache.resize(size_t(batch_->n_modalities) * 42);
+      return m3t_hip_modalities_get_gradient_hessian(batch_->ctx, batch_->gh_cache.data(), batch_->n_modalities);
     });
+    if (!ok || size_t(id_ + 1) * 42 > batch_->gh_cache.size()) return false;
     // column-major like Eigen: what the unmodified Link adds up (link.cpp:188-191)
-    return ok && m3t_hip_modality_get_gradient_hessian(batch_->ctx, id_, gradient_.data(), hessian_.data()) >= 0;
+    const float* gh = batch_->gh_cache.data() + size_t(id_) * 42;
+    std::copy(gh, gh + 6, gradient_.data());
+    std::copy(gh + 6, gh + 42, hessian_.data());
+    return true;
   }
   bool CalculateResults(int iteration) override {
     if (!CheckSetUp()) return false;
@@ -228,6 +239,7 @@ class HipRegionModality : public HipModality {
     if (color_id_ >= 0 && model_id_ >= 0 && body_id_ >= 0 && (!depth_camera_ || depth_id_ >= 0))
       id_ = m3t_hip_region_modality_create(batch_->ctx, &params_, body_id_, color_id_, model_id_, depth_id_);
     set_up_ = id_ >= 0;
+    if (set_up_) batch_->n_modalities = std::max(batch_->n_modalities, id_ + 1);
     if (!set_up_) std::cerr << m3t_hip_last_error(batch_->ctx) << std::endl;
     return set_up_;
   }
@@ -263,6 +275,7 @@ class HipDepthModality : public HipModality {
     if (depth_id_ >= 0 && model_id_ >= 0 && body_id_ >= 0)
       id_ = m3t_hip_depth_modality_create(batch_->ctx, &params_, body_id_, depth_id_, model_id_);
     set_up_ = id_ >= 0;
+    if (set_up_) batch_->n_modalities = std::max(batch_->n_modalities, id_ + 1);
     if (!set_up_) std::cerr << m3t_hip_last_error(batch_->ctx) << std::endl;
     return set_up_;
   }

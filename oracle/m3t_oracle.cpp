@@ -2899,6 +2899,16 @@ int m3t_oracle_modality_get_gradient_hessian(m3t_oracle_context* ctx, int id, fl
   if (h) std::memcpy(h, CTX->modalities[id]->hessian, 144);
   return M3T_OK;
 }
+int m3t_oracle_modalities_get_gradient_hessian(m3t_oracle_context* ctx, float* out, int capacity) {
+  CHECK_CTX();
+  const int n = int(CTX->modalities.size());
+  if (!out || capacity < n) FAIL(M3T_ERR_INVALID_ARGUMENT, "the buffer must hold 42 floats per modality");
+  for (int i = 0; i < n; ++i) {
+    std::memcpy(out + size_t(i) * 42, CTX->modalities[i]->gradient, 24);
+    std::memcpy(out + size_t(i) * 42 + 6, CTX->modalities[i]->hessian, 144);
+  }
+  return M3T_OK;
+}
 int m3t_oracle_modality_set_gradient_hessian(m3t_oracle_context* ctx, int id, const float g[6], const float h[36]) {
   CHECK_CTX();
   if (id < 0 || id >= int(CTX->modalities.size()) || !g || !h) FAIL(M3T_ERR_INVALID_ARGUMENT, "bad modality id");

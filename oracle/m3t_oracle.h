@@ -162,6 +162,7 @@ int m3t_oracle_sync(m3t_oracle_context*);
 /* accessors */
 int m3t_oracle_modality_get_gradient_hessian(m3t_oracle_context*, int modality_id, float gradient[6],
                                              float hessian[36]);
+int m3t_oracle_modalities_get_gradient_hessian(m3t_oracle_context*, float* out, int capacity_modalities);
 int m3t_oracle_modality_set_gradient_hessian(m3t_oracle_context*, int modality_id, const float gradient[6],
                                              const float hessian[36]);
 int m3t_oracle_region_modality_get_lines(m3t_oracle_context*, int modality_id, m3t_data_line* out,
