@@ -12,15 +12,16 @@
 //   rigid_optimize_kernel     Optimizer::CalculateOptimization (dof 6) + Link::UpdatePoses
 //   tracking_step_kernel (+ _lds_); launched with 256-thread workgroups, two per CU, from two objects per CU on
 //                             the whole ExecuteTrackingStep loop nest fused on device
+//   tracking_step_split_kernel the same with 4 / 8 / 16 workgroups per object (batches that leave CUs idle)
 //   (kinematic structures: m3t_links.hip)
 //
 // Arithmetic follows the reference expression by expression in IEEE f32
 // (compile with -ffp-contract=off; hipcc's f32 divide / sqrt are correctly
 // rounded by default), so every discrete decision (pixel truncation, validity
-// tests, distribution index) matches the CPU restatement bit for bit; only
-// the order of the g/H sums over lines differs in the default mode (wave DPP
-// tree instead of sequential; m3t_hip_set_summation_mode(1) restores the
-// reference order).  Reference citations are relative to M3T/src/.
+// tests, distribution index) matches the CPU restatement bit for bit, and the
+// g/H sums over lines / points are formed in the reference's order (product
+// rows in LDS, one sequential chain per gradient / Hessian entry: chain_sums),
+// so do the poses.  Reference citations are relative to M3T/src/.
 
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -199,7 +200,7 @@ __device__ __forceinline__ int wave_min_i(int v) {  // broadcast result
 // orientations4: one float4 per view (xyz + pad).  misc: >= 128 floats of LDS scratch.
 // Contains two __syncthreads().
 // ---------------------------------------------------------------------------
-__device__ int closest_view(G<v4f> orientations4, int n_views, const Affine& b2c, float* misc) {
+__device__ __forceinline__ int closest_view(G<v4f> orientations4, int n_views, const Affine& b2c, float* misc) {
   float tn = sqrtf((b2c.t[0] * b2c.t[0] + b2c.t[1] * b2c.t[1]) + b2c.t[2] * b2c.t[2]);
   if (tn == 0.0f) return 0;  // block-uniform
   const int nt = blockDim.x;
@@ -323,10 +324,18 @@ __device__ bool occlusion_window_clear(CCam& dc, float center_u, float center_v,
   return true;
 }
 
-// the same window scanned by the 16 lanes of a DPP row (lane gl takes samples gl, gl + 16, gl + 32): true if one
-// of THIS lane's samples occludes; the caller ORs the row
-__device__ __forceinline__ bool occlusion_window_lane_hit(CCam& dc, float center_u, float center_v, float diameter,
-                                                          float depth, float depth_offset, float threshold, int gl) {
+// The same window for a scan by the 16 lanes of a DPP row.  Its limits -- two float and two integer divisions, a
+// dozen conversions -- are worked out ONCE, by the thread that owns the line (occlusion_window_pack), and handed
+// over as three words; the row then only turns sample numbers into addresses (occlusion_window_lane_hit: lane gl
+// takes samples gl, gl + 16, gl + 32; true if one of THIS lane's samples occludes; the caller ORs the row).
+struct OcclusionWindow {
+  uint32_t base;    // byte offset of sample (0, 0)
+  uint32_t packed;  // min_depth | n_samples << 16 | n_u << 24; n_samples == 0: nothing to test (never occluded)
+  uint32_t stride;
+};
+__device__ __forceinline__ OcclusionWindow occlusion_window_pack(CCam& dc, float center_u, float center_v,
+                                                                 float diameter, float depth, float depth_offset,
+                                                                 float threshold) {
   int stride = f2i(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
   if (stride < 1) stride = 1;  // (a body behind the camera: no meaningful window, but no division by zero either)
   int n_strides = f2i(diameter / stride + 0.5f);
@@ -340,25 +349,47 @@ __device__ __forceinline__ bool occlusion_window_lane_hit(CCam& dc, float center
   v_min = max(v_min, 0);
   u_max = min(u_max, dc.width - 1);
   v_max = min(v_max, dc.height - 1);
-  unsigned short min_depth = (unsigned short)f2i((depth - depth_offset - threshold) / dc.depth_scale);
-  G<uint8_t> image = as_global(dc.image);
+  const unsigned short min_depth = (unsigned short)f2i((depth - depth_offset - threshold) / dc.depth_scale);
   const int n_u = u_max >= u_min ? (u_max - u_min) / stride + 1 : 0;
   const int n_v = v_max >= v_min ? (v_max - v_min) / stride + 1 : 0;
-  const int total = n_u * n_v;  // <= 36
+  int total = n_u * n_v;  // <= 36 (at most 6 x 6 samples: n_strides <= M3T_MAX_N_OCCLUSION_STRIDES)
+  OcclusionWindow w;
+  w.base = (uint32_t)v_min * dc.pitch + (uint32_t)u_min * 2u;
+  w.packed = (uint32_t)min_depth | ((uint32_t)total << 16) | ((uint32_t)n_u << 24);
+  w.stride = (uint32_t)stride;
+  return w;
+}
+// (two steps, so that a caller can have the samples of several lines in flight before it looks at the first)
+__device__ __forceinline__ void occlusion_window_lane_load(CCam& dc, uint32_t base, uint32_t packed, uint32_t stride,
+                                                           int gl, unsigned short& d0, unsigned short& d1,
+                                                           unsigned short& d2) {
+  const int total = (int)((packed >> 16) & 0xffu), n_u = (int)(packed >> 24);
+  G<uint8_t> image = as_global(dc.image);
+  // sample number -> (row, column): (pos + 0.5) / n_u is at least 0.5 / n_u away from an integer, the approximate
+  // reciprocal's 1 ulp cannot carry it across (pos < 48, n_u <= 6)
+  const float inv_n_u = __builtin_amdgcn_rcpf((float)n_u);
   unsigned short d[3] = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int pos = gl + 16 * k;
     if (pos < total) {
-      const int vi = pos / n_u, ui = pos - vi * n_u;
-      d[k] = *reinterpret_cast<G<unsigned short>>(image + (uint32_t)(v_min + vi * stride) * dc.pitch +
-                                                  (uint32_t)(u_min + ui * stride) * 2u);
+      const int vi = (int)(((float)pos + 0.5f) * inv_n_u), ui = pos - vi * n_u;
+      d[k] = *reinterpret_cast<G<unsigned short>>(image + base + (uint32_t)vi * stride * dc.pitch +
+                                                  (uint32_t)ui * stride * 2u);
     }
   }
-  bool hit = false;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) hit |= (d[k] > 0 && d[k] < min_depth);
-  return hit;
+  d0 = d[0]; d1 = d[1]; d2 = d[2];
+}
+__device__ __forceinline__ bool occlusion_window_lane_test(uint32_t packed, unsigned short d0, unsigned short d1,
+                                                           unsigned short d2) {
+  const unsigned short min_depth = (unsigned short)(packed & 0xffffu);
+  return (d0 > 0 && d0 < min_depth) || (d1 > 0 && d1 < min_depth) || (d2 > 0 && d2 < min_depth);
+}
+__device__ __forceinline__ bool occlusion_window_lane_hit(CCam& dc, uint32_t base, uint32_t packed, uint32_t stride,
+                                                          int gl) {
+  unsigned short d0, d1, d2;
+  occlusion_window_lane_load(dc, base, packed, stride, gl, d0, d1, d2);
+  return occlusion_window_lane_test(packed, d0, d1, d2);
 }
 
 // ---------------------------------------------------------------------------
@@ -780,7 +811,7 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   int my_valid_occ = 0;
   for (int line = tid; line < nl; line += nt) {
     int flags = 0;
-    if (measured_pass) s.seg_f[line * 5 + 2] = -1.0f;  // no occlusion window to scan (yet)
+    if (measured_pass) reinterpret_cast<uint32_t*>(s.seg_f)[line * 3 + 1] = 0u;  // no occlusion window to scan (yet)
     if (line < n_lines) {
       G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
       const v4f pa = p8[0], pb4 = p8[1];
@@ -835,7 +866,6 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
       // IsLineUnoccludedMeasured :1343-1389: the window of up to 36 depth samples is scanned by 16 lanes per line
       // after this loop (measured_occlusion_pass); here only its parameters are set aside (seg_f is free until phase B)
       if (measured_pass) {
-        float* w = s.seg_f + line * 5;
         if (valid_occ && test_occlusion) {
           float dx, dy, dz;
           apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
@@ -844,11 +874,12 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
           float meter_to_pixel = dcam->fu / dz;
           float diameter = 2.0f * m.measured_occlusion_radius * meter_to_pixel;
           G<float> p = as_global(m.points) + ((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS;
-          w[0] = du;
-          w[1] = dv;
-          w[2] = diameter;
-          w[3] = dz;
-          w[4] = p[8 + m.measured_depth_offset_id];
+          const OcclusionWindow ow = occlusion_window_pack(*dcam, du, dv, diameter, dz, p[8 + m.measured_depth_offset_id],
+                                                           m.measured_occlusion_threshold);
+          uint32_t* w = reinterpret_cast<uint32_t*>(s.seg_f) + line * 3;
+          w[0] = ow.base;
+          w[1] = ow.packed;
+          w[2] = ow.stride;
         }
       }
       if (valid) {
@@ -898,10 +929,8 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
       const int line = line0 + (tid >> 4);
       int occluded = 0;
       if (line < hi) {
-        const float* w = s.seg_f + line * 5;
-        if (w[2] >= 0.0f &&
-            occlusion_window_lane_hit(*dcam, w[0], w[1], w[2], w[3], w[4], m.measured_occlusion_threshold, gl))
-          occluded = 1;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(s.seg_f) + line * 3;
+        if (occlusion_window_lane_hit(*dcam, w[0], w[1], w[2], gl)) occluded = 1;
       }
       occluded |= dpp_self_i<0x111, 0xf>(occluded);
       occluded |= dpp_self_i<0x112, 0xf>(occluded);
@@ -1035,7 +1064,7 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
 
 // tracking_step_split_kernel, occlusion handling on: the two-pass vote :435-463 and the final flags once every
 // workgroup's occlusion results (bit 0 of the flags) are in.  Barriers inside; ends without one.
-__device__ void region_finish_flags(CRegion& m, const Lds& s) {
+__device__ __forceinline__ void region_finish_flags(CRegion& m, const Lds& s) {
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
   int mine = 0;
   for (int line = tid; line < nl; line += nt) mine += f2i_bits(s.state[LS_VALID * nl + line]) & 1;
@@ -1081,7 +1110,7 @@ __device__ __forceinline__ void region_moments_lines(CRegion& m, const Lds& s, i
     s.state[LS_VAR * nl + line] = fmaxf(var, m.min_expected_variance);
   }
 }
-__device__ void region_moments(CRegion& m, const Lds& s, int lo = 0, int hi = 1 << 30, bool inside = true) {
+__device__ __forceinline__ void region_moments(CRegion& m, const Lds& s, int lo = 0, int hi = 1 << 30, bool inside = true) {
   const int dl = m.distribution_length;
   if (dl == 12) region_moments_lines<12>(m, s, lo, hi, inside, dl);  // the default length: straight-line code
   else region_moments_lines<0>(m, s, lo, hi, inside, dl);
@@ -1210,7 +1239,7 @@ __device__ __forceinline__ void chain_sums(const float* rows_a, int pitch_a, int
 // RegionModality::CalculateGradientAndHessian (:485-558), the per-line part: one thread per line slot
 // writes the line's 27 products to rows[row * pitch + line] (zeros for slots that do not contribute).
 // ---------------------------------------------------------------------------
-__device__ void region_products(CRegion& m, CCam& cam, const Affine& b2c, int corr_iteration, int opt_iteration,
+__device__ __forceinline__ void region_products(CRegion& m, CCam& cam, const Affine& b2c, int corr_iteration, int opt_iteration,
                                 const Lds& s, float* rows, int pitch) {
   const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
   const RegionIter it = region_iter(m, corr_iteration);
@@ -1904,7 +1933,7 @@ __device__ void rigid_solve_wave(float gh, float lambda_rot, float lambda_trans,
 // points [pt_lo, pt_hi); a workgroup that shares its object with others (tracking_step_split_kernel) also loads the
 // model data of the other parts' points, whose correspondences arrive through split_exchange_state().
 // Part 2 (depth_correspondences_vote): the two-pass fallback :282-313 over all points.
-__device__ void depth_correspondences_scan(CDepth& m, CCam& cam, const Affine& b2c, int iteration,
+__device__ __forceinline__ void depth_correspondences_scan(CDepth& m, CCam& cam, const Affine& b2c, int iteration,
                                            int corr_iteration, float* ps, int np, float* misc, int pt_lo = 0,
                                            int pt_hi = 1 << 30, int known_view = -1) {
   // 16 lanes (one DPP row) per model point: the strided search window of FindCorrespondence
@@ -2125,7 +2154,7 @@ __device__ void depth_correspondences_scan(CDepth& m, CCam& cam, const Affine& b
   __syncthreads();
 }
 
-__device__ void depth_correspondences_vote(CDepth& m, int iteration, float* ps, int np, float* misc) {
+__device__ __forceinline__ void depth_correspondences_vote(CDepth& m, int iteration, float* ps, int np, float* misc) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const bool handle_occlusions = (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
   const bool measured_pass = m.measure_occlusions && handle_occlusions;
@@ -2150,7 +2179,7 @@ __device__ void depth_correspondences_vote(CDepth& m, int iteration, float* ps, 
   }
   __syncthreads();
 }
-__device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, int iteration, int corr_iteration,
+__device__ __forceinline__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, int iteration, int corr_iteration,
                                       float* ps, int np, float* misc) {
   depth_correspondences_scan(m, cam, b2c, iteration, corr_iteration, ps, np, misc);
   depth_correspondences_vote(m, iteration, ps, np, misc);
@@ -2158,7 +2187,7 @@ __device__ void depth_correspondences(CDepth& m, CCam& cam, const Affine& b2c, i
 
 // DepthModality::CalculateGradientAndHessian (depth_modality.cpp:333-381), the per-point part: one thread per
 // point slot writes the point's 27 products to rows[row * pitch + point] (see chain_sums above).
-__device__ void depth_products(CDepth& m, const Affine& b2c, int corr_iteration, const float* ps, int np, float* rows,
+__device__ __forceinline__ void depth_products(CDepth& m, const Affine& b2c, int corr_iteration, const float* ps, int np, float* rows,
                                int pitch) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const Affine c2b = inverse_pose(b2c);
@@ -2228,6 +2257,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
   if (!SHARED)
     for (int i = tid; i < (int)n_own_bins; i += nt) counts[i] = 0;
   unsigned sf = 0, sb = 0;  // this thread's foreground / background samples (all bins)
+  PHASE_T0();
   const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
   const int n_lines = number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length,
                                       as_global(m.extents), view, m.max_extent, m.n_points);
@@ -2236,36 +2266,60 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
   const bool visible_depth = m.model_occlusions && renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
   const bool visible_silhouette =
       m.use_region_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
-  // IsLineUnoccludedMeasured at the final pose :1084-1087: the windows of all lines first, 16 lanes per line (the
-  // result per line in the misc block, which holds 768 of them; longer models test inside the walk)
-  int* line_occluded = reinterpret_cast<int*>(misc) + 256;
+  // IsLineUnoccludedMeasured at the final pose :1084-1087: the windows of all lines first -- their limits by one thread
+  // per line, the samples by 16 lanes per line (three words per line in the misc block, which holds 256 lines; the
+  // verdict replaces the first word; longer models test inside the walk)
+  int* line_occluded = reinterpret_cast<int*>(misc) + 256;  // [3 * line]
   const bool measured = handle_occlusions && m.measure_occlusions;
-  const bool windows_first = measured && n_lines <= M3T_MISC_FLOATS - 256;
+  const bool windows_first = measured && 3 * n_lines <= M3T_MISC_FLOATS - 256;
+  PHASE_MARK(27);  // tail: view search
   if (windows_first) {
+    uint32_t* windows = reinterpret_cast<uint32_t*>(line_occluded);
+    for (int line = tid; line < n_lines; line += nt) {
+      G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
+      const v4f pa = p8[0];
+      float dx, dy, dz;
+      apply_pose(b2dc, pa.x, pa.y, pa.z, dx, dy, dz);
+      const float du = dx * dcam->fu / dz + dcam->ppu;
+      const float dv = dy * dcam->fv / dz + dcam->ppv;
+      const float diameter = 2.0f * m.measured_occlusion_radius * (dcam->fu / dz);
+      const float offset = as_global(m.points)[((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS + 8 +
+                                               m.measured_depth_offset_id];
+      const OcclusionWindow ow =
+          occlusion_window_pack(*dcam, du, dv, diameter, dz, offset, m.measured_occlusion_threshold);
+      windows[3 * line] = ow.base;
+      windows[3 * line + 1] = ow.packed;
+      windows[3 * line + 2] = ow.stride;
+    }
+    __syncthreads();
     const int gl = tid & 15, groups = nt >> 4;
-    for (int line0 = 0; line0 < n_lines; line0 += groups) {
-      const int line = line0 + (tid >> 4);
-      int occluded = 0;
-      if (line < n_lines) {
-        G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
-        const v4f pa = p8[0];
-        float dx, dy, dz;
-        apply_pose(b2dc, pa.x, pa.y, pa.z, dx, dy, dz);
-        const float du = dx * dcam->fu / dz + dcam->ppu;
-        const float dv = dy * dcam->fv / dz + dcam->ppv;
-        const float diameter = 2.0f * m.measured_occlusion_radius * (dcam->fu / dz);
-        const float offset = as_global(m.points)[((size_t)view * m.n_points + line) * M3T_REGION_POINT_FLOATS + 8 +
-                                                 m.measured_depth_offset_id];
-        occluded = occlusion_window_lane_hit(*dcam, du, dv, diameter, dz, offset, m.measured_occlusion_threshold, gl) ? 1 : 0;
+    for (int line0 = 0; line0 < n_lines; line0 += 8 * groups) {  // eight lines per row and trip: 24 samples in flight
+      uint32_t packed[8];
+      unsigned short d0[8], d1[8], d2[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int line = line0 + r * groups + (tid >> 4);
+        packed[r] = 0u;
+        d0[r] = d1[r] = d2[r] = 0;
+        if (line < n_lines) {
+          packed[r] = windows[3 * line + 1];
+          occlusion_window_lane_load(*dcam, windows[3 * line], packed[r], windows[3 * line + 2], gl, d0[r], d1[r], d2[r]);
+        }
       }
-      occluded |= dpp_self_i<0x111, 0xf>(occluded);
-      occluded |= dpp_self_i<0x112, 0xf>(occluded);
-      occluded |= dpp_self_i<0x114, 0xf>(occluded);
-      occluded |= dpp_self_i<0x118, 0xf>(occluded);
-      if (gl == 15 && line < n_lines) line_occluded[line] = occluded;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int line = line0 + r * groups + (tid >> 4);
+        int occluded = occlusion_window_lane_test(packed[r], d0[r], d1[r], d2[r]) ? 1 : 0;
+        occluded |= dpp_self_i<0x111, 0xf>(occluded);
+        occluded |= dpp_self_i<0x112, 0xf>(occluded);
+        occluded |= dpp_self_i<0x114, 0xf>(occluded);
+        occluded |= dpp_self_i<0x118, 0xf>(occluded);
+        if (gl == 15 && line < n_lines) line_occluded[3 * line] = occluded;
+      }
     }
     __syncthreads();
   }
+  PHASE_MARK(28);  // tail: occlusion windows
   // two lanes per line: even lane = foreground walk (inwards), odd lane = background walk
   for (int item = tid; item < 2 * n_lines; item += nt) {
     const int line = item >> 1;
@@ -2289,7 +2343,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
         continue;
     }
     if (windows_first) {
-      if (line_occluded[line]) continue;
+      if (line_occluded[3 * line]) continue;
     } else if (measured) {
       float dx, dy, dz;
       apply_pose(b2dc, cx, cy, cz, dx, dy, dz);
@@ -2340,32 +2394,29 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     const float v0 = background ? center_v + nv * m.unconsidered_line_length + 0.5f
                                 : center_v - nv * m.unconsidered_line_length + 0.5f;
     const float du = sgn * u_step, dv = sgn * v_step;  // u -= u_step == u += (-u_step), exactly
-    int n_valid = 0;
-    {
-      float u = u0, v = v0;
-      for (int k = 0; k < projected_length; ++k) {
-        int iu = f2i(u), iv = f2i(v);
-        if (iu < 0 || iu > w1 || iv < 0 || iv > h1) break;
-        ++n_valid;
-        u += du;
-        v += dv;
-      }
-    }
     const auto inc = [&]() {
       if constexpr (SHARED) return background ? (1ull << 32) : 1ull;
       else return background ? 65536u : 1u;
     }();
+    // One pass, eight steps at a time: the float chain u += du only feeds the addresses, so the loads of a batch are
+    // independent; `alive` reproduces the reference's break at the first step off the image (nothing after it
+    // counts), the count-table atomics follow once a batch's loads are issued.
+    int n_valid = 0;
     float u = u0, v = v0;
+    bool alive = true;
     G<uint8_t> image = as_global(cam.image);
-    // eight pixels at a time: the loads of a batch are independent (the float chain only feeds the addresses), the
-    // count-table atomics follow once all are issued
-    for (int k0 = 0; k0 < n_valid; k0 += 8) {
+    for (int k0 = 0; k0 < projected_length && alive; k0 += 8) {
       uint32_t px[8];
+      uint32_t taken = 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const uint32_t off = __umul24((uint32_t)f2i(v), cam.pitch) + (uint32_t)f2i(u) * 3u;
+        const int iu = f2i(u), iv = f2i(v);
+        alive = alive && k0 + j < projected_length && !(iu < 0 || iu > w1 || iv < 0 || iv > h1);
         px[j] = 0;
-        if (k0 + j < n_valid) px[j] = reinterpret_cast<G<PackedU32>>(image + off)->v;
+        if (alive) {
+          px[j] = reinterpret_cast<G<PackedU32>>(image + (__umul24((uint32_t)iv, cam.pitch) + (uint32_t)iu * 3u))->v;
+          taken |= 1u << j;
+        }
         u += du;
         v += dv;
       }
@@ -2373,14 +2424,16 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
       for (int j = 0; j < 8; ++j) {
         const uint32_t bin = ((px[j] & 0xffu) >> bitshift) * n_bins2 + (((px[j] >> 8) & 0xffu) >> bitshift) * n_bins +
                              (((px[j] >> 16) & 0xffu) >> bitshift) - (uint32_t)bin_lo;
-        if (k0 + j < n_valid && (SHARED || bin < n_own_bins)) count_add(&counts[bin], inc);
+        if (((taken >> j) & 1u) && (SHARED || bin < n_own_bins)) count_add(&counts[bin], inc);
       }
+      n_valid += __builtin_popcount(taken);
     }
     if (background) sb += (unsigned)n_valid;
     else sf += (unsigned)n_valid;
   }
   if constexpr (!SHARED) {
   __syncthreads();
+  PHASE_MARK(29);  // tail: pixel walk
   // sums of the count tables = numbers of samples (exact: integers)
   sf = (unsigned)wave_sum_i((int)sf);
   sb = (unsigned)wave_sum_i((int)sb);
@@ -2399,10 +2452,30 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
   GW<v4f> hist_f4 = (GW<v4f>)m.histogram_f;
   GW<v4f> hist_b4 = (GW<v4f>)m.histogram_b;
   GW<v4f> norm4 = (GW<v4f>)m.histogram_norm;
-  for (int i4 = bin_lo / 4 + tid; i4 < bin_hi / 4; i4 += nt) {
-    v4f hf4 = hist_f4[i4], hb4 = hist_b4[i4];
+  // (the old histograms of four trips are requested before the first is blended: one memory round trip for a
+  // workgroup's 8192 bins at 512 threads instead of four)
+  const int i4_end = bin_hi / 4;
+  for (int i40 = bin_lo / 4 + tid; i40 < i4_end; i40 += 4 * nt) {
+  v4f old_f[4], old_b[4];
+#pragma unroll
+  for (int trip = 0; trip < 4; ++trip) {
+    const int i4 = i40 + trip * nt;
+    if (i4 < i4_end) { old_f[trip] = hist_f4[i4]; old_b[trip] = hist_b4[i4]; }
+  }
+#pragma unroll
+  for (int trip = 0; trip < 4; ++trip) {
+    const int i4 = i40 + trip * nt;
+    if (i4 < i4_end) {  // (no `continue`: it would send the unrolled loop's arrays to scratch memory)
+    v4f hf4 = old_f[trip], hb4 = old_b[trip];
     const int c0 = 4 * i4 - bin_lo;
     uint32_t c4[4] = {counts[c0], counts[c0 + 1], counts[c0 + 2], counts[c0 + 3]};
+    // Four bins that were empty and got no sample stay as they are -- 0 * (1 - lr) + 0 * scale = 0, pair (0.5, 0.5)
+    // -- and are not written back: most of a 32^3 table, frame after frame.  (Not while initialising, and not in
+    // the no-sample cases below, which may set the uniform value.)
+    if (!initialize && sf != 0 && sb != 0 && (c4[0] | c4[1] | c4[2] | c4[3]) == 0u &&
+        hf4.x == 0.0f && hf4.y == 0.0f && hf4.z == 0.0f && hf4.w == 0.0f &&
+        hb4.x == 0.0f && hb4.y == 0.0f && hb4.z == 0.0f && hb4.w == 0.0f) {
+    } else {
     v4f n0, n1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2441,6 +2514,9 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     hist_b4[i4] = hb4;
     norm4[2 * i4] = n0;
     norm4[2 * i4 + 1] = n1;
+    }
+    }
+  }
   }
   }  // !SHARED
 }

@@ -35,3 +35,5 @@ tot = sum(buf[i] for i in range(7)) + buf[16] + sum(buf[22:27])
 for i, nme in enumerate(names):
     print("%-38s %10.0f cycles/frame  %5.1f%%" % (nme, buf[i] / n, 100.0 * buf[i] / tot))
 print("total %.0f cycles/frame" % (tot / n))
+print("tail: view search %.0f, occlusion windows %.0f, pixel walk %.0f cycles/frame (blend = the rest)" %
+      (buf[27] / n, buf[28] / n, buf[29] / n))

@@ -45,24 +45,27 @@ def main(out_dir, target, config):
         ratios["wave_cycles_parked_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES)"] = g("SQ_WAIT_ANY", 0) / g("SQ_WAVE_CYCLES")
         ratios["wave_cycles_issue_stall_frac (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)"] = g("SQ_WAIT_INST_ANY", 0) / g("SQ_WAVE_CYCLES")
         ratios["wave_cycles_issuing_frac (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)"] = g("SQ_ACTIVE_INST_ANY", 0) / g("SQ_WAVE_CYCLES")
-    if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE"):
+    # GRBM_GUI_ACTIVE comes out as the sum over the 8 XCDs (rocprofv3 prints one row per XCC, means() adds them up):
+    # one XCD's count is an eighth -- 403 k cycles for the 161 us launch of rbot64
+    gui = g("GRBM_GUI_ACTIVE", 0) / 8.0
+    if g("SQ_ACTIVE_INST_VALU") and gui:
         # rocprof's VALUBusy: 100 x SQ_ACTIVE_INST_VALU x 4 / (number of SIMDs = 4 x 256) / GRBM_GUI_ACTIVE
-        ratios["valu_busy_pct (100 x SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / GRBM_GUI_ACTIVE)"] = \
-            100.0 * g("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / g("GRBM_GUI_ACTIVE")
-    if g("SQ_WAVE_CYCLES") and g("GRBM_GUI_ACTIVE"):
-        # SQ_WAVE_CYCLES counts quad-cycles summed over all waves: x 4 / GRBM_GUI_ACTIVE = waves resident on the chip
-        ratios["mean_resident_waves_per_cu (SQ_WAVE_CYCLES x 4 / GRBM_GUI_ACTIVE / 256)"] = \
-            g("SQ_WAVE_CYCLES") * 4.0 / g("GRBM_GUI_ACTIVE") / 256.0
+        ratios["valu_busy_pct (100 x SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs))"] = \
+            100.0 * g("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / gui
+    if g("SQ_WAVE_CYCLES") and gui:
+        # SQ_WAVE_CYCLES counts quad-cycles summed over all waves
+        ratios["mean_resident_waves_per_cu (SQ_WAVE_CYCLES x 4 / (GRBM_GUI_ACTIVE / 8) / 256)"] = \
+            g("SQ_WAVE_CYCLES") * 4.0 / gui / 256.0
     if g("SQ_WAVES") and g("SQ_INSTS_VALU") is not None:
         ratios["valu_instructions_per_wave"] = g("SQ_INSTS_VALU") / g("SQ_WAVES")
     if g("SQ_LDS_IDX_ACTIVE"):
         ratios["lds_bank_conflict_frac (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)"] = g("SQ_LDS_BANK_CONFLICT", 0) / g("SQ_LDS_IDX_ACTIVE")
     if g("TCC_HIT_sum") is not None and (g("TCC_HIT_sum", 0) + g("TCC_MISS_sum", 0)):
         ratios["l2_hit_frac (TCC_HIT / (TCC_HIT + TCC_MISS))"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
-    if g("TA_TA_BUSY_sum") and g("GRBM_GUI_ACTIVE"):
-        ratios["ta_busy_frac_per_cu (TA_TA_BUSY_sum / (256 x GRBM_GUI_ACTIVE))"] = g("TA_TA_BUSY_sum") / (256.0 * g("GRBM_GUI_ACTIVE"))
-    if g("TCP_TCP_TA_DATA_STALL_CYCLES_sum") and g("GRBM_GUI_ACTIVE"):
-        ratios["tcp_ta_data_stall_frac_per_cu"] = g("TCP_TCP_TA_DATA_STALL_CYCLES_sum") / (256.0 * g("GRBM_GUI_ACTIVE"))
+    if g("TA_TA_BUSY_sum") and gui:
+        ratios["ta_busy_frac_per_cu (TA_TA_BUSY_sum / (256 x GRBM_GUI_ACTIVE / 8))"] = g("TA_TA_BUSY_sum") / (256.0 * gui)
+    if g("TCP_TCP_TA_DATA_STALL_CYCLES_sum") and gui:
+        ratios["tcp_ta_data_stall_frac_per_cu"] = g("TCP_TCP_TA_DATA_STALL_CYCLES_sum") / (256.0 * gui)
     hbm = None
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
         hbm = {"FETCH_SIZE_KB": g("FETCH_SIZE"), "WRITE_SIZE_KB": g("WRITE_SIZE"),
