@@ -2967,6 +2967,12 @@ int m3t_hip_debug_phase_cycles(m3t_hip_context* ctx, unsigned long long* out24, 
   }
   return M3T_OK;
 }
+int m3t_hip_debug_exchange_times(m3t_hip_context* ctx, unsigned long long* out768) {
+  CHECK_CTX();
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpyFromSymbol(out768, HIP_SYMBOL(g_exchange_times), 768 * sizeof(unsigned long long)));
+  return M3T_OK;
+}
 #endif
 int m3t_hip_sync(m3t_hip_context* ctx) {
   CHECK_CTX();

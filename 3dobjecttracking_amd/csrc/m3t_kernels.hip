@@ -31,6 +31,12 @@
 #ifdef M3T_PHASE_TIMING
 // developer instrumentation: accumulated s_memtime cycles per phase, block 0 thread 0
 __device__ unsigned long long g_phase_cycles[32];
+__device__ unsigned long long g_exchange_times[3 * 16 * 16];  // [kind][round][part] of object 0, last frame
+#define EXCHANGE_STAMP(kind, round, part, object)                                                      \
+  do {                                                                                                 \
+    if ((object) == 0 && threadIdx.x == 0 && (round) < 16 && (part) < 16)                              \
+      g_exchange_times[((kind) * 16 + (round)) * 16 + (part)] = clock64();                             \
+  } while (0)
 #define PHASE_T0() unsigned long long _pt = clock64()
 #define PHASE_MARK(i)                                                         \
   do {                                                                        \
@@ -39,6 +45,7 @@ __device__ unsigned long long g_phase_cycles[32];
     _pt = _n;                                                                 \
   } while (0)
 #else
+#define EXCHANGE_STAMP(kind, round, part, object) do {} while (0)
 #define PHASE_T0() do {} while (0)
 #define PHASE_MARK(i) do {} while (0)
 #endif
@@ -2860,9 +2867,12 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         }
         // publish the own part's results, take the moments of the own lines while the other parts' results are on
         // their way, collect them, then the moments of the received lines
+        EXCHANGE_STAMP(0, c, part, object);
         split_exchange_publish(exchange, c, s, rm != nullptr, ps, np, dm != nullptr);
+        EXCHANGE_STAMP(1, c, part, object);
         if (rm && !vote_deferred) region_moments(*rm, s, line_lo, line_hi, true);
         if (!split_exchange_collect(exchange, c, s, rm != nullptr, ps, np, dm != nullptr)) return;
+        EXCHANGE_STAMP(2, c, part, object);
         PHASE_MARK(22);
         if (vote_deferred) {
           region_finish_flags(*rm, s);

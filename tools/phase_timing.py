@@ -37,3 +37,26 @@ for i, nme in enumerate(names):
 print("total %.0f cycles/frame" % (tot / n))
 print("tail: view search %.0f, occlusion windows %.0f, pixel walk %.0f cycles/frame (blend = the rest)" %
       (buf[27] / n, buf[28] / n, buf[29] / n))
+
+# split exchange of object 0, last frame: when each part published and when it had everybody's results
+try:
+    g = hip.lib.m3t_hip_debug_exchange_times
+    g.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    xt = (C.c_ulonglong * 768)()
+    g(hip.ctx, xt)
+    shape = (C.c_int * 4)()
+    hip.call("get_step_shape", shape)
+    parts = shape[1]
+    if parts > 1:
+        print("split exchange, object 0 (cycles relative to the first part's publish start of the round):")
+        for rnd in range(16):
+            start = [xt[(0 * 16 + rnd) * 16 + p] for p in range(parts)]
+            if not any(start):
+                break
+            pub = [xt[(1 * 16 + rnd) * 16 + p] for p in range(parts)]
+            done = [xt[(2 * 16 + rnd) * 16 + p] for p in range(parts)]
+            t0 = min(start)
+            print("  round %d: publish start %s  published %s  collected %s" %
+                  (rnd, [int(v - t0) for v in start], [int(v - t0) for v in pub], [int(v - t0) for v in done]))
+except AttributeError:
+    pass
