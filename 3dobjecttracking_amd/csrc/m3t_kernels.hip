@@ -27,6 +27,7 @@
 #include <limits.h>
 
 #include "m3t_device.h"
+#include "m3t_log.h"
 
 #ifdef M3T_PHASE_TIMING
 // developer instrumentation: accumulated s_memtime cycles per phase, block 0 thread 0
@@ -79,7 +80,8 @@ constexpr int kWave = 64;
 // misc LDS scratch layout (floats): [0,128) view search / counters, [128,160) reduced sums,
 // [160,640) per-wave partials (16 waves x 27), [640,656) pose, [704,746) region g/H, [768,810) depth g/H
 constexpr int kMiscRed = 128, kMiscPartials = 160, kMiscPose = 640, kMiscGhRegion = 704, kMiscGhDepth = 768,
-              kMiscLookup = 832;  // function_lookup_f[16], function_lookup_b[16]
+              kMiscLookup = 832,  // function_lookup_f[16], function_lookup_b[16]
+              kMiscLogTable = 288;  // 128 doubles: the table of m3t_log.h, misc[288, 544) (free again in the histogram tail)
 
 // ---------------------------------------------------------------------------
 // pose math (column-major like Eigen; same expression trees as the reference)
@@ -1279,10 +1281,19 @@ __device__ __forceinline__ void region_products(CRegion& m, CCam& cam, const Aff
         if (upper <= 0 || upper >= m.distribution_length) {
           ok = false;
         } else {
-          // std::log(float): correctly rounded through f64 on both sides of the parity check
-          dll = ((float)log((double)s.state[(LS_DIST0 + upper) * nl + line]) -
-                 (float)log((double)s.state[(LS_DIST0 + lower) * nl + line])) *
-                m.learning_rate / measured_variance;
+          // std::log(float): the f32 nearest to the logarithm, taken through f64 on both sides of the parity check.
+          // m3t_log.h gets there with a fifth of a general double logarithm's instructions and says when it cannot
+          // vouch for the rounding (one call in 10^5: the general logarithm decides)
+          const float d_upper = s.state[(LS_DIST0 + upper) * nl + line], d_lower = s.state[(LS_DIST0 + lower) * nl + line];
+          typedef const __attribute__((address_space(3))) double* LdsDoubles;
+          LdsDoubles log_table = (LdsDoubles)(s.misc + kMiscLogTable);
+          float log_upper = 0.0f, log_lower = 0.0f;
+          const bool vouched = m3t_log_fast(d_upper, log_table, &log_upper) & m3t_log_fast(d_lower, log_table, &log_lower);
+          if (!vouched) {
+            log_upper = (float)log((double)d_upper);
+            log_lower = (float)log((double)d_lower);
+          }
+          dll = (log_upper - log_lower) * m.learning_rate / measured_variance;
         }
       }
       float dc0 = ncts * normal_u * fu_z;
@@ -2585,6 +2596,12 @@ __device__ void shared_histogram_finish(const SharedHistogramsDev& h, bool initi
   }
 }
 
+// the table of m3t_log.h into the misc block (the kernels that form region products call this before a barrier)
+__device__ const uint64_t g_log_table_bits[M3T_LOG_TABLE_DOUBLES] = M3T_LOG_TABLE_INIT;
+__device__ __forceinline__ void stage_log_table(float* misc) {
+  if (threadIdx.x < M3T_LOG_TABLE_DOUBLES)
+    reinterpret_cast<uint64_t*>(misc + kMiscLogTable)[threadIdx.x] = g_log_table_bits[threadIdx.x];
+}
 __device__ __forceinline__ void stage_histogram(CRegion& m, float* lds_hist) {
   const int n2 = m.n_bins * m.n_bins * m.n_bins * 2;
   const float* src = reinterpret_cast<const float*>(m.histogram_norm);
@@ -2686,6 +2703,7 @@ region_gradient_hessian_kernel(const RegionModDev* mods, const CameraDev* cams, 
     s.state[f * s.nl + l] = m.line_state[i];
   }
   for (int l = m.n_lines_max + threadIdx.x; l < s.nl; l += blockDim.x) s.state[LS_VALID * s.nl + l] = i2f_bits(0);
+  stage_log_table(s.misc);
   __syncthreads();
   const Affine b2c = mul_pose(load_pose(cam.world2camera), load_pose(body_poses + 16 * m.body));
   float* rows = lds + layout.off_rows_r;
@@ -2810,6 +2828,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   float* gh_region = s.misc + kMiscGhRegion;  // 42
   float* gh_depth = s.misc + kMiscGhDepth;    // 42
   if (threadIdx.x < 16) pose[threadIdx.x] = body_poses[16 * o.body + threadIdx.x];
+  if (rm) stage_log_table(s.misc);
   if (HIST_LDS && rm) stage_histogram(*rm, lds_t + layout.off_hist);
   __syncthreads();
   CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;

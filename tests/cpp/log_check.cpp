@@ -1,0 +1,38 @@
+// Host check of 3dobjecttracking_amd/csrc/m3t_log.h against float(std::log(double(x))) -- the expression of the oracle
+// (oracle/m3t_oracle.cpp, RegionModality g/H): usage  log_check [stride]  (stride 1 = every float in [FLT_MIN, 1]).
+// Prints "checked N mismatches M fallbacks F"; the test requires M == 0.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../3dobjecttracking_amd/csrc/m3t_log.h"
+
+int main(int argc, char** argv) {
+  const unsigned stride = argc > 1 ? (unsigned)std::atoi(argv[1]) : 1u;
+  static const uint64_t bits[M3T_LOG_TABLE_DOUBLES] = M3T_LOG_TABLE_INIT;
+  double table[M3T_LOG_TABLE_DOUBLES];
+  std::memcpy(table, bits, sizeof table);
+  unsigned long long checked = 0, mismatches = 0, fallbacks = 0;
+  const uint32_t first = 0x00800000u, last = 0x3f800000u;
+#pragma omp parallel for reduction(+ : checked, mismatches, fallbacks) schedule(static)
+  for (long long b = first; b <= (long long)last; b += stride) {
+    const uint32_t ix = (uint32_t)b;
+    float x;
+    std::memcpy(&x, &ix, sizeof x);
+    const float want = (float)std::log((double)x);
+    float got;
+    ++checked;
+    if (!m3t_log_fast(x, table, &got)) { ++fallbacks; continue; }
+    if (std::memcmp(&got, &want, sizeof got) != 0) ++mismatches;
+  }
+  // everything outside (0, 1] normal has to be refused
+  const float refused[] = {0.0f, -1.0f, 1e-45f, 1.17549421e-38f, 1.0000001f, 2.0f, INFINITY, NAN};
+  unsigned wrongly_taken = 0;
+  for (float x : refused) {
+    float got;
+    if (m3t_log_fast(x, table, &got)) ++wrongly_taken;
+  }
+  std::printf("checked %llu mismatches %llu fallbacks %llu wrongly_taken %u\n", checked, mismatches, fallbacks, wrongly_taken);
+  return mismatches == 0 && wrongly_taken == 0 ? 0 : 1;
+}
