@@ -23,7 +23,13 @@ def open_context(device_id=0):
     """Create one device context (one per GPU per host thread).
 
     Fails loudly when the HIP extension has not been built or no GPU is
-    usable: there is no CPU fallback in the product path."""
+    usable: there is no CPU fallback in the product path.
+
+    Small batches (fewer objects than CUs) run several workgroups per object that
+    exchange results inside one launch; that launch shape assumes the context has
+    the GPU to itself.  A process that shares the GPU with other contexts, streams
+    or processes calls ``ctx.call("set_object_split", 0)`` (include/m3t_hip.h,
+    m3t_hip_set_object_split)."""
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("%s missing: build it with `python __graft_entry__.py`" % LIB_PATH)
     return CApi(LIB_PATH, "m3t_hip_", device_id)

@@ -309,7 +309,6 @@ _HIP_ONLY = {
     "cameras_upload_batch_async": [c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t],
     "camera_select_slot": [C.c_int, C.c_int],
     "cameras_select_slot": [C.c_int],
-    "set_summation_mode": [C.c_int],
     "set_kernel_timing": [C.c_int],
     "get_kernel_timing": [c_float_p, c_int_p],
     "get_step_shape": [c_int_p],

@@ -187,7 +187,6 @@ struct m3t_hip_context {
   bool comm_owned = false;
   int n_corr_iterations = 5, n_update_iterations = 2;
   int fused_mode = 1;
-  int sequential_sum = 0;
   // device tables
   DevMem d_cams, d_region, d_depth, d_opts, d_poses, d_scratch_view;
   DevMem d_gh_sources, d_gh_all;  // m3t_hip_modalities_get_gradient_hessian
@@ -208,6 +207,7 @@ struct m3t_hip_context {
   unsigned* split_abort_host = nullptr;  // mapped host word: sequence number of a split step that gave up
   unsigned* split_abort_dev = nullptr;   // the same word as the device sees it
   unsigned split_abort_seen = 0;
+  unsigned split_launches = 0;  // never reset (unlike split_seq): the value an aborting launch leaves in the host word
   int last_step_shape[4] = {0, 0, 0, 0};  // m3t_hip_get_step_shape
   bool state_valid = false;  // line/point state + g/H on the device reflect the last step
   TrackLdsLayout layout{};
@@ -444,8 +444,10 @@ int CheckSplitExchange(Ctx* ctx) {
     ctx->split_abort_seen = value;
     return Fail(ctx, M3T_ERR_DEVICE,
                 "tracking_step_split_kernel: a workgroup waited in vain for its object's other workgroups (is another "
-                "process using this GPU?); the step was abandoned for that object without writing its pose or "
-                "histograms; set the poses again and call start_modalities (m3t_hip_set_object_split(ctx, 0) avoids the kernel)");
+                "process or stream using this GPU?); the object's step was abandoned part-way: workgroups that had "
+                "already finished may have written the new pose and blended their share of the histogram bins, so "
+                "the object's pose and histograms are undefined; set the poses again and call start_modalities "
+                "(m3t_hip_set_object_split(ctx, 0) avoids the kernel)");
   }
   return M3T_OK;
 }
@@ -1084,7 +1086,36 @@ int LaunchSolve(Ctx* ctx, bool zero_theta) {
   return M3T_OK;
 }
 
+// sum of the stacked [dof x dof | dof] buffers of all structures over the ranks of the communicator: ONE
+// ncclAllReduce on the context's stream, in place (optimizer.cpp:309-321 is the sum being distributed)
+int AllReducePartial(Ctx* ctx) {
+  REQUIRE(ctx->partial_ready, M3T_ERR_NOT_SET_UP, "calculate_optimization_begin has to be called first");
+  REQUIRE(ctx->comm != nullptr, M3T_ERR_NOT_SET_UP, "no communicator: m3t_hip_comm_init_rank / m3t_hip_comm_set first");
+  float* buffer = ctx->d_partial.as<float>();
+  const ncclResult_t rc =
+      g_rccl.AllReduce(buffer, buffer, ctx->partial_count, ncclFloat, ncclSum, ctx->comm, ctx->stream);
+  if (rc != ncclSuccess)
+    return Fail(ctx, M3T_ERR_DEVICE,
+                std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+  return M3T_OK;
+}
+
+// Optimizer::CalculateOptimization for every optimizer.  With a communicator set the structures span GPUs
+// (SURVEY 8e): project -> ONE all-reduce of the stacked sums -> solve, on every path that reaches this function
+// (m3t_hip_calculate_optimization and the sub-step loop of m3t_hip_execute_tracking_step alike).
 int LaunchOptimization(Ctx* ctx) {
+  if (ctx->comm) {
+    if (!ctx->tree_mode) {  // rigid bodies only: force the general path so that the sums exist
+      ctx->tree_mode = true;
+      ctx->fused_possible = false;
+      int r = UploadTreeTables(ctx);
+      if (r) return r;
+    }
+    int r = LaunchProject(ctx);
+    if (r) return r;
+    if ((r = AllReducePartial(ctx))) return r;
+    return LaunchSolve(ctx, false);
+  }
   if (ctx->tree_mode) {
     int r = LaunchProject(ctx);
     if (r) return r;
@@ -1382,8 +1413,11 @@ int m3t_hip_cameras_set_ring(m3t_hip_context* ctx, const int* ids, int n, int n_
     REQUIRE(ids[i] >= 0 && ids[i] < int(ctx->cameras.size()), M3T_ERR_INVALID_ARGUMENT, "bad camera id");
     const Camera& a = *ctx->cameras[ids[0]];
     const Camera& b = *ctx->cameras[ids[i]];
-    REQUIRE(a.frame_bytes == b.frame_bytes && a.pitch == b.pitch && a.is_depth == b.is_depth, M3T_ERR_INVALID_ARGUMENT,
-            "the cameras of a shared ring must have the same image geometry");
+    // (the row pitch is rounded up to 64 bytes, so equal pitch does not imply equal width: the one-block upload
+    // copies every camera's rows with camera 0's row length)
+    REQUIRE(a.frame_bytes == b.frame_bytes && a.pitch == b.pitch && a.is_depth == b.is_depth &&
+                a.intr.width == b.intr.width && a.intr.height == b.intr.height,
+            M3T_ERR_INVALID_ARGUMENT, "the cameras of a shared ring must have the same image geometry (width, height, type)");
     for (int j = 0; j < i; ++j) REQUIRE(ids[j] != ids[i], M3T_ERR_INVALID_ARGUMENT, "camera listed twice");
   }
   HIPCHK(hipSetDevice(ctx->device));
@@ -2652,12 +2686,7 @@ int m3t_hip_calculate_optimization(m3t_hip_context* ctx, int, int, int) {
   HIPCHK(hipSetDevice(ctx->device));
   int r = Prepare(ctx, false);
   if (r) return r;
-  if (ctx->comm) {  // the structures span GPUs: project, ONE all-reduce, solve (every rank the same system)
-    if ((r = m3t_hip_calculate_optimization_begin(ctx, nullptr, nullptr))) return r;
-    if ((r = m3t_hip_calculate_optimization_allreduce(ctx))) return r;
-    return m3t_hip_calculate_optimization_end(ctx);
-  }
-  return LaunchOptimization(ctx);
+  return LaunchOptimization(ctx);  // (with a communicator: project, ONE all-reduce, solve)
 }
 // Optimizer::CalculateOptimization split at the multi-GPU exchange point: *partial is a
 // DEVICE pointer to `count` floats (the stacked [dof*dof | dof] sums of every structure); sum it over the
@@ -2740,12 +2769,8 @@ int m3t_hip_comm_destroy(m3t_hip_context* ctx) {
 // ncclAllReduce on the context's stream, in place (optimizer.cpp:309-321 is the sum being distributed)
 int m3t_hip_calculate_optimization_allreduce(m3t_hip_context* ctx) {
   CHECK_CTX();
-  REQUIRE(ctx->partial_ready, M3T_ERR_NOT_SET_UP, "calculate_optimization_begin has to be called first");
-  REQUIRE(ctx->comm != nullptr, M3T_ERR_NOT_SET_UP, "no communicator: m3t_hip_comm_init_rank / m3t_hip_comm_set first");
   HIPCHK(hipSetDevice(ctx->device));
-  float* buffer = ctx->d_partial.as<float>();
-  RCCLCHK(g_rccl.AllReduce(buffer, buffer, ctx->partial_count, ncclFloat, ncclSum, ctx->comm, ctx->stream));
-  return M3T_OK;
+  return AllReducePartial(ctx);
 }
 // Tracker::CalculateConsistentPoses tracker.cpp:423 -> Optimizer::CalculateConsistentPoses optimizer.cpp:135
 int m3t_hip_calculate_consistent_poses(m3t_hip_context* ctx) {
@@ -2774,7 +2799,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   ctx->untracked_launches = untracked_before;  // a whole step is tracked by its step_done event below
   if ((r = CheckSplitExchange(ctx))) return r;  // an earlier step that was abandoned on the device
   bool histogram_fused = false;
-  if (ctx->fused_mode >= 1 && ctx->fused_possible) {
+  if (ctx->fused_mode >= 1 && ctx->fused_possible && !ctx->comm) {  // (a communicator: the structures span GPUs)
     int n = int(ctx->opt_table.size());
     ScopedKernelTimer timer(ctx, 0);
     // From two objects per CU on (and if two working sets fit the CU's LDS) the kernel runs with 256-thread
@@ -2812,6 +2837,16 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
         const int per_cu = (threads == M3T_SPLIT_LANES && lds_split_for(p) * 2 <= size_t(160) * 1024) ? 2 : 1;
         if (p > limit || n * p > ctx->prop.multiProcessorCount * per_cu) continue;
         if ((elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;  // a part's elements fit its share of the lanes
+        // the exchange needs every workgroup of the grid resident at once: ask the runtime how many of these
+        // workgroups (registers, LDS) a CU takes, instead of assuming the LDS arithmetic above is the only limit
+        int resident = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, tracking_step_split_kernel, threads,
+                                                         lds_split_for(p)) != hipSuccess) {
+          (void)hipGetLastError();
+          resident = 0;
+        }
+        if (resident > per_cu) resident = per_cu;  // (the query is known to over-report by one block for SGPR-heavy kernels)
+        if (resident < 1 || n * p > ctx->prop.multiProcessorCount * resident) continue;
         parts = p;
         break;
       }
@@ -2843,6 +2878,8 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       sp.object_abort = reinterpret_cast<unsigned*>(sp.granules + ctx->split_objects * per_object);
       sp.host_abort = ctx->split_abort_dev;
       sp.seq = ctx->split_seq;
+      if (++ctx->split_launches == 0) ctx->split_launches = 1;  // (0 = the word's initial value)
+      sp.abort_id = ctx->split_launches;
       sp.n_parts = parts;
       sp.lshift = 0;
       while ((parts << sp.lshift) < M3T_SPLIT_LANES) ++sp.lshift;
@@ -2910,13 +2947,6 @@ int m3t_hip_refine_poses(m3t_hip_context* ctx, int n_corr_iterations, int n_upda
 }
 int m3t_hip_execute_tracking_cycle(m3t_hip_context* ctx, int iteration) {
   return m3t_hip_execute_tracking_step(ctx, iteration);
-}
-int m3t_hip_set_summation_mode(m3t_hip_context* ctx, int mode) {
-  CHECK_CTX();
-  // kept for callers of the first release: both modes now add the terms in the reference's order
-  REQUIRE(mode == 0 || mode == 1, M3T_ERR_INVALID_ARGUMENT, "mode must be 0 or 1");
-  ctx->sequential_sum = mode;
-  return M3T_OK;
 }
 int m3t_hip_set_kernel_timing(m3t_hip_context* ctx, int enable) {
   CHECK_CTX();

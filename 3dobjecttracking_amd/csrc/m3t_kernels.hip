@@ -786,7 +786,8 @@ __device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> 
 template <bool HIST_LDS, int BMAX = 8>
 __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                        const Affine& b2dc, int iteration, int corr_iteration,
-                                                       const Lds& s, int line_lo = 0, int line_hi = 1 << 30) {
+                                                       const Lds& s, int line_lo = 0, int line_hi = 1 << 30,
+                                                       bool* vote_deferred = nullptr) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const RegionIter it = region_iter(m, corr_iteration);
   const int nl = s.nl;
@@ -812,6 +813,7 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   // exchanged (region_finish_flags): meanwhile it walks every valid line of its part.  The lines the vote then drops
   // were walked in vain; the result is the reference's.
   const bool defer_vote = occlusion_pass && line_hi < (1 << 30);
+  if (vote_deferred) *vote_deferred = defer_vote;  // the caller exchanges the flags and calls region_finish_flags
   const int n_seg = m.n_seg;
   G<uint8_t> image = as_global(cam.image);
   const uint32_t pitch = cam.pitch;
@@ -1347,6 +1349,7 @@ struct SplitExchange {
   __attribute__((address_space(1))) unsigned* object_abort;        // launch sequence number of an aborted step
   unsigned* host_abort;                                            // mapped host word, set to the sequence number
   uint32_t seq;    // launch sequence number (> 0)
+  uint32_t abort_id;
   int part, n_parts, lshift;
   int per_part_lines, per_part_points;
   int n_region_fields, first_region_row;    // rows LS_DIST0 .. (from LS_VALID on while the occlusion vote is deferred)
@@ -1432,7 +1435,7 @@ __device__ __forceinline__ bool split_exchange_collect(const SplitExchange& x, i
         if (f < nf && (f < nfr ? ok_r : ok_d)) {                                                                     \
           unsigned spins = 0;                                                                                        \
           while (static_cast<uint32_t>(G >> 32) != tag) {                                                            \
-            if (++spins > (1u << 18) || /* ~0.3 s */                                                                 \
+            if (++spins > (1u << 12) || /* ~5 ms: resident partners answer within microseconds */                    \
                 ((spins & 255u) == 0 &&                                                                              \
                  __hip_atomic_load(x.object_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == x.seq)) {          \
               timed_out = true;                                                                                      \
@@ -1456,7 +1459,7 @@ __device__ __forceinline__ bool split_exchange_collect(const SplitExchange& x, i
   if (__syncthreads_or(timed_out ? 1 : 0)) {
     if (tid == 0) {
       __hip_atomic_store(x.object_abort, x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(x.host_abort, x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(x.host_abort, x.abort_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return false;
   }
@@ -1797,7 +1800,9 @@ __device__ __forceinline__ void colexpm3(const float (&K)[9], int c, float (&R)[
 // gh: lane l < 6 holds the link's gradient sum g[l], lane 6 + c * 6 + r the Hessian sum H(r, c) (full, symmetric:
 // the layout of Modality::gradient() / hessian()).  pose: 16 floats in LDS (column-major), updated in place.
 // scratch: 128 floats of LDS.  All 64 lanes of the wave must call this together.
-__device__ void rigid_solve_wave(float gh, float lambda_rot, float lambda_trans, float* pose, float* scratch) {
+typedef __attribute__((address_space(3))) float* LdsW;  // LDS pointers stay LDS pointers across the (non-inlined) call:
+                                                         // ds_read / ds_write instead of flat accesses in the solve
+__device__ __noinline__ void rigid_solve_wave(float gh, float lambda_rot, float lambda_trans, LdsW pose, LdsW scratch) {
   const int lane = threadIdx.x & (kWave - 1);
   PHASE_T0();
   if (lane < 42) scratch[lane] = gh;
@@ -1892,10 +1897,10 @@ __device__ void rigid_solve_wave(float gh, float lambda_rot, float lambda_trans,
 #pragma unroll
     for (int j = 0; j < 6; ++j) th[j] = rlf(mine, j);
   } else {
-    float* a = scratch + 48;
-    float* xs = scratch + 84;
-    int* trans = reinterpret_cast<int*>(scratch + 90);
-    float* temp = scratch + 96;
+    float* a = (float*)(scratch + 48);
+    float* xs = (float*)(scratch + 84);
+    int* trans = reinterpret_cast<int*>((float*)(scratch + 90));
+    float* temp = (float*)(scratch + 96);
     if (lane < 36) {
       const int c = lane / 6, r = lane - c * 6;
       float e = r >= c ? 0.0f - scratch[6 + lane] : 0.0f;
@@ -2773,7 +2778,7 @@ rigid_optimize_kernel(const RigidOptDev* opts, int n_opts, const RegionModDev* r
   }
   if (lane < 16) pose[lane] = body_poses[16 * o.body + lane];
   __builtin_amdgcn_wave_barrier();
-  rigid_solve_wave(gh, o.tikhonov_rotation, o.tikhonov_translation, pose, scratch);
+  rigid_solve_wave(gh, o.tikhonov_rotation, o.tikhonov_translation, (LdsW)pose, (LdsW)scratch);
   __builtin_amdgcn_wave_barrier();
   if (lane < 16) body_poses[16 * o.body + lane] = pose[lane];
 }
@@ -2787,7 +2792,8 @@ struct SplitParams {               // tracking_step_split_kernel: n_parts workgr
   unsigned long long* granules;    // [objects][2 slots][n_parts][32 fields][1 << lshift]
   unsigned* object_abort;          // [objects]
   unsigned* host_abort;            // mapped host word
-  unsigned seq;                    // launch sequence number
+  unsigned seq;                    // launch sequence number (restarts when the granule tags are cleared)
+  unsigned abort_id;               // what an aborting workgroup writes to *host_abort: unique per launch, never reset
   int n_parts, lshift;             // n_parts << lshift == 256
   int per_part_lines, per_part_points;
 };
@@ -2846,6 +2852,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     exchange.object_abort = (__attribute__((address_space(1))) unsigned*)split->object_abort + object;
     exchange.host_abort = split->host_abort;
     exchange.seq = split->seq;
+    exchange.abort_id = split->abort_id;
     exchange.part = part;
     exchange.n_parts = n_parts;
     exchange.lshift = split->lshift;
@@ -2860,12 +2867,13 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     {
       const Affine b2w = load_pose(pose);
       int region_view = -1;
+      bool vote_deferred = false;  // decided by region_correspondences (the one predicate for both sides)
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
         region_view = region_correspondences<HIST_LDS, SPLIT ? 2 : 8>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, line_lo,
-                                                                      line_hi);
+                                                                      line_hi, &vote_deferred);
       }
       if (dm) {
         PHASE_T0();
@@ -2879,7 +2887,6 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         PHASE_T0();
         // with occlusion handling on, the flags of the own lines (their occlusion results) travel too and the vote
         // over all lines follows the exchange (region_correspondences, defer_vote)
-        const bool vote_deferred = rm && rm->measure_occlusions && (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
         if (rm) {
           exchange.n_region_fields = rm->distribution_length + (vote_deferred ? 1 : 0);
           exchange.first_region_row = vote_deferred ? LS_VALID : LS_DIST0;
@@ -2936,7 +2943,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
           gh_depth[threadIdx.x] = sum_d;
         }
         PHASE_MARK(23);
-        rigid_solve_wave(gh, o.tikhonov_rotation, o.tikhonov_translation, pose, s.misc + kMiscSolve);
+        rigid_solve_wave(gh, o.tikhonov_rotation, o.tikhonov_translation, (LdsW)pose, (LdsW)(s.misc + kMiscSolve));
       }
       __syncthreads();
       PHASE_MARK(6);

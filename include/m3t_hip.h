@@ -260,20 +260,22 @@ int m3t_hip_execute_tracking_cycle(m3t_hip_context*, int iteration);
 int m3t_hip_set_fused_step(m3t_hip_context*, int mode);
 /* Batches that leave CUs idle run with several (4, 8 or 16) workgroups per object, which hand each other their
  * share of the line / point results inside the launch; that needs all of them resident at once, which holds while
- * this context has the GPU to itself.  If a workgroup waits in vain (another process occupies the CUs), the step
- * of that object is abandoned without writing its pose or histograms and the NEXT call of execute_tracking_step /
- * sync / a pose getter returns M3T_ERR_DEVICE: set the poses again and call start_modalities.  A process that
- * shares its GPU switches the split off.  enable: 0 = off, 1 = automatic (default), 2..16 = at most that many
+ * this context has the GPU to itself (the launch shape is chosen against the runtime's occupancy query for an
+ * otherwise idle device).  AUTOMATIC SPLIT THEREFORE ASSUMES EXCLUSIVE USE OF THE GPU: a second context or stream of
+ * the same process, or another process, that occupies CUs can keep a partner workgroup from starting.  If a workgroup
+ * waits in vain (about 5 ms), the step of that object is abandoned part-way -- workgroups that were already done may
+ * have written the new pose and their share of the histogram bins, so pose and histograms of that object are
+ * undefined -- and the NEXT call of execute_tracking_step / sync / a pose getter returns M3T_ERR_DEVICE: set the
+ * poses again and call start_modalities.  A process that shares its GPU switches the split off.  enable: 0 = off, 1 = automatic (default), 2..16 = at most that many
  * workgroups per object.  Results are bit-identical in every shape. */
 int m3t_hip_set_object_split(m3t_hip_context*, int enable);
 /* Refiner::RefinePoses (refiner.cpp:76-117): CalculateConsistentPoses, then n_corr_iterations x
  * (StartModalities + CalculateCorrespondences + n_update_iterations x (g/H + optimisation)), iteration index 0 */
 int m3t_hip_refine_poses(m3t_hip_context*, int n_corr_iterations, int n_update_iterations);
 int m3t_hip_sync(m3t_hip_context*);
-/* Kept for callers of the first release, no effect: the gradient / Hessian sums over lines / points are always
- * taken in the reference's sequential f32 order (region_modality.cpp:550-554, depth_modality.cpp:361-377), so
- * whole tracking sequences reproduce the CPU path bit for bit in every launch shape. */
-int m3t_hip_set_summation_mode(m3t_hip_context*, int mode);
+/* (The gradient / Hessian sums over lines / points are always taken in the reference's sequential f32 order,
+ * region_modality.cpp:550-554, depth_modality.cpp:361-377: whole tracking sequences reproduce the CPU path bit for
+ * bit in every launch shape; there is no summation-mode switch.) */
 /* measurement aid (bench.py roofline leg): HIP events on the context stream around
  * [0] the fused tracking kernel and [1] the histogram kernel; totals since enable */
 int m3t_hip_set_kernel_timing(m3t_hip_context*, int enable);

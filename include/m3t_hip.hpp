@@ -505,9 +505,8 @@ class Tracker {
     c_->Check(m3t_hip_get_stream(c_->get(), &s), "Tracker");
     return s;
   }
-  // launch shape and summation order (m3t_hip.h: set_fused_step, set_summation_mode, get_step_shape)
+  // launch shape (m3t_hip.h: set_fused_step, get_step_shape)
   void SetFusedStep(int mode) { c_->Check(m3t_hip_set_fused_step(c_->get(), mode), "Tracker"); }
-  void SetSummationMode(int mode) { c_->Check(m3t_hip_set_summation_mode(c_->get(), mode), "Tracker"); }
   std::array<int, 4> StepShape() const {
     std::array<int, 4> shape{};
     c_->Check(m3t_hip_get_step_shape(c_->get(), shape.data()), "Tracker");

@@ -178,7 +178,6 @@ int main(int argc, char** argv) {
     }
     if (mode == "track" && argc >= 3) {
       auto context = std::make_shared<Context>(0);
-      if (argc > 3) context->Check(m3t_hip_set_summation_mode(context->get(), std::atoi(argv[3])), "mode");
       auto tracker = cfg::GenerateConfiguredTracker(context, argv[2]);
       std::set<std::string> names;
       for (auto& o : tracker->optimizers) names.insert(o.first);
