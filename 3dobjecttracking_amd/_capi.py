@@ -312,6 +312,7 @@ _HIP_ONLY = {
     "set_kernel_timing": [C.c_int],
     "get_kernel_timing": [c_float_p, c_int_p],
     "get_step_shape": [c_int_p],
+    "get_step_kernel": [C.c_char_p, C.c_size_t],
     "set_object_split": [C.c_int],
 }
 

@@ -181,6 +181,27 @@ struct TrackLdsLayout {
   int total_floats;
 };
 
+// LDS carve-up of tracking_step_compact_kernel (m3t_compact.hip): what one object keeps between the phases of a
+// step when several objects share a CU -- no chain / segment buffers (a thread walks its whole line and keeps a
+// window of eight segments in registers), 8 + 1 factor rows per modality instead of 27 product rows.
+enum {
+  CS_CX = 0, CS_CY, CS_CZ, CS_CENTER_U, CS_CENTER_V, CS_NORMAL_U, CS_NORMAL_V, CS_DELTA_R, CS_NCTS, CS_MEAN, CS_VAR,
+  CS_VALID,   // int bits: bit 0 = the line is in data_lines_
+  CS_DIST0,   // distribution[12] (the raw products first, normalised in place)
+  CS_FIELDS = CS_DIST0 + 12
+};
+#define M3T_COMPACT_THREADS 256
+#define M3T_COMPACT_MISC_FLOATS 672
+#define M3T_COMPACT_ROWS 9      /* six Jacobian / direction entries, two weights, one row of constants */
+struct CompactLayout {
+  int nl, np;                 // lines (<= M3T_COMPACT_THREADS), depth points
+  int off_state;              // [CS_FIELDS][nl]
+  int off_rows_r, pitch_r;    // [M3T_COMPACT_ROWS][pitch_r]
+  int off_points;             // [PS_FIELDS][np]
+  int off_rows_d, pitch_d;    // [M3T_COMPACT_ROWS][pitch_d]
+  int total_floats;
+};
+
 #ifndef M3T_BLOCK_THREADS
 #define M3T_BLOCK_THREADS 512
 #endif

@@ -20,6 +20,7 @@
 #include "../../include/m3t_hip.h"
 #include "m3t_device.h"
 #include "m3t_kernels.hip"
+#include "m3t_compact.hip"
 #include "m3t_render.hip"
 #include "m3t_modelgen.hip"
 #include "m3t_links.hip"
@@ -211,6 +212,12 @@ struct m3t_hip_context {
   int last_step_shape[4] = {0, 0, 0, 0};  // m3t_hip_get_step_shape
   bool state_valid = false;  // line/point state + g/H on the device reflect the last step
   TrackLdsLayout layout{};
+  // tracking_step_compact_kernel (m3t_compact.hip): the launch shape of batches with two objects per CU and more
+  CompactLayout compact{};
+  size_t lds_compact = 0;
+  bool compact_possible = false;       // every modality fits the kernel's assumptions (UploadTables)
+  bool compact_fuses_histogram = false;  // ... and the count table fits next to the scratch block (<= 16 bins)
+  const char* last_step_kernel = "";   // m3t_hip_get_step_kernel
   int np_max = 0, off_points = 0;
   size_t lds_track = 0, lds_corr = 0, lds_hist = 0, lds_depth = 0;
   bool hist_counts_in_lds = true;
@@ -509,6 +516,26 @@ void ComputeLayout(Ctx* ctx) {
   size_t counts = size_t(bins3) * 4;
   ctx->hist_counts_in_lds = (M3T_MISC_FLOATS * 4 + counts) <= 160 * 1024;
   ctx->lds_hist = M3T_MISC_FLOATS * 4 + (ctx->hist_counts_in_lds ? counts : 0);
+  // the compact carve-up: scratch | line state | factor rows (+ point state | factor rows)
+  CompactLayout C{};
+  C.nl = nl;
+  C.np = np;
+  int o = M3T_COMPACT_MISC_FLOATS;
+  C.off_state = o; o += ctx->region_mods.empty() ? 0 : CS_FIELDS * nl;
+  o = (o + 3) / 4 * 4;
+  C.pitch_r = chain_pitch(nl);
+  C.off_rows_r = o; o += ctx->region_mods.empty() ? 0 : M3T_COMPACT_ROWS * C.pitch_r;
+  o = (o + 3) / 4 * 4;
+  C.off_points = o; o += ctx->depth_mods.empty() ? 0 : PS_FIELDS * np;
+  o = (o + 3) / 4 * 4;
+  C.pitch_d = chain_pitch(np);
+  C.off_rows_d = o; o += ctx->depth_mods.empty() ? 0 : M3T_COMPACT_ROWS * C.pitch_d;
+  C.total_floats = (o + 3) / 4 * 4;
+  // the histogram update rides along when the packed count table fits behind its 1024-float scratch block
+  ctx->compact_fuses_histogram = bins3 > 0 && size_t(M3T_MISC_FLOATS + bins3) * 4 <= 40 * 1024;
+  if (ctx->compact_fuses_histogram) C.total_floats = std::max(C.total_floats, M3T_MISC_FLOATS + bins3);
+  ctx->compact = C;
+  ctx->lds_compact = size_t(C.total_floats) * 4;
 }
 
 void DfsOrder(Ctx* ctx, int link, std::vector<int>* order) {
@@ -939,6 +966,16 @@ int UploadTables(Ctx* ctx) {
     REQUIRE(max_lds <= 160 * 1024, M3T_ERR_UNSUPPORTED,
             "per-object working set exceeds the 160 KB LDS of a CU");
     if (!ctx->hist_counts_in_lds) ctx->fuse_histogram_possible = false;
+    // the compact kernel: the reference's default function / distribution lengths, unrolled scales, a thread per line
+    ctx->compact_possible = ctx->fused_possible && ctx->lds_compact <= 80 * 1024;
+    for (auto& m : ctx->region_mods) {
+      if (m->p.function_length != 8 || m->p.distribution_length != 12 || m->p.n_lines_max > M3T_COMPACT_THREADS)
+        ctx->compact_possible = false;
+      for (int i = 0; i < m->p.n_scales; ++i)
+        if (m->p.scales[i] < 1 || m->p.scales[i] > 9) ctx->compact_possible = false;
+    }
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_compact_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_compact)));
     // the split kernel: free rigid bodies with their own histograms (the pair table is read from L2)
     ctx->split_possible = ctx->fused_possible;
     for (auto& m : ctx->region_mods)
@@ -2852,7 +2889,22 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       }
     }
     const bool split = parts >= 2;
-    if (split) {
+    // Two objects per CU and more: the compact kernel (<= 47 KB of LDS, <= 128 VGPRs per object: 3-5 workgroups
+    // per CU).  M3T_HIP_COMPACT=0 / 1: developer override (never / whenever possible).
+    bool compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && n >= 2 * ctx->prop.multiProcessorCount;
+    if (const char* e = std::getenv("M3T_HIP_COMPACT")) compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && std::atoi(e) != 0;
+    if (std::getenv("M3T_HIP_THREADS")) compact = false;
+    ctx->last_step_kernel = split ? "tracking_step_split_kernel"
+                                  : (compact ? "tracking_step_compact_kernel"
+                                             : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_kernel" : "tracking_step_kernel"));
+    if (compact) {
+      threads = M3T_COMPACT_THREADS;
+      histogram_fused = want_fused_histogram && ctx->compact_fuses_histogram;
+      hipLaunchKernelGGL(tracking_step_compact_kernel, dim3(n), dim3(threads), ctx->lds_compact, ctx->stream,
+                         ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                         ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->compact,
+                         iteration, ctx->n_corr_iterations, ctx->n_update_iterations, histogram_fused ? 1 : 0);
+    } else if (split) {
       const size_t per_object = size_t(2) * M3T_SPLIT_LANES * 32;  // granules
       if (!ctx->split_abort_host) {
         void* host = nullptr;
@@ -2966,6 +3018,12 @@ int m3t_hip_get_step_shape(m3t_hip_context* ctx, int shape[4]) {
   CHECK_CTX();
   REQUIRE(shape, M3T_ERR_INVALID_ARGUMENT, "null output");
   std::memcpy(shape, ctx->last_step_shape, sizeof(ctx->last_step_shape));
+  return M3T_OK;
+}
+int m3t_hip_get_step_kernel(m3t_hip_context* ctx, char* name, size_t capacity) {
+  CHECK_CTX();
+  REQUIRE(name && capacity > 0, M3T_ERR_INVALID_ARGUMENT, "null output");
+  std::snprintf(name, capacity, "%s", ctx->last_step_kernel);
   return M3T_OK;
 }
 int m3t_hip_get_kernel_timing(m3t_hip_context* ctx, float total_ms[2], int launches[2]) {

@@ -279,6 +279,8 @@ int m3t_hip_sync(m3t_hip_context*);
 /* measurement aid (bench.py roofline leg): HIP events on the context stream around
  * [0] the fused tracking kernel and [1] the histogram kernel; totals since enable */
 int m3t_hip_set_kernel_timing(m3t_hip_context*, int enable);
+/* name of the kernel the last execute_tracking_step launched for the tracking loop ("" = one launch per sub-step) */
+int m3t_hip_get_step_kernel(m3t_hip_context*, char* name, size_t capacity);
 int m3t_hip_get_kernel_timing(m3t_hip_context*, float total_ms[2], int launches[2]);
 /* launch shape of the last fused tracking step: [0] objects, [1] workgroups per object (1, or 4 / 8 / 16 =
  * tracking_step_split_kernel when the batch leaves CUs idle), [2] threads per workgroup,

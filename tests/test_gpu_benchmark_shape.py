@@ -40,8 +40,14 @@ def oracle_trajectory(inputs, use_depth=False):
     return ref, [r.histograms() for r in b.region]
 
 
-def hip_trajectory(inputs, use_depth=False, env=None):
-    for k in ("M3T_HIP_NO_SPLIT", "M3T_HIP_SPLIT_PARTS", "M3T_HIP_THREADS"):
+def kernel_of(api):
+    name = C.create_string_buffer(64)
+    api.call("get_step_kernel", name, 64)
+    return name.value.decode()
+
+
+def hip_trajectory(inputs, use_depth=False, env=None, want_kernel=None):
+    for k in ("M3T_HIP_NO_SPLIT", "M3T_HIP_SPLIT_PARTS", "M3T_HIP_THREADS", "M3T_HIP_COMPACT"):
         os.environ.pop(k, None)
     os.environ.update(env or {})
     try:
@@ -54,6 +60,8 @@ def hip_trajectory(inputs, use_depth=False, env=None):
             a.upload_frame(k)
             assert a.tracker.ExecuteTrackingStep(k)
             out.append(np.stack(a.poses()))
+        if want_kernel is not None:
+            assert kernel_of(api) == want_kernel
         return out, [r.histograms() for r in a.region], shape_of(api)
     finally:
         for k in (env or {}):
@@ -101,3 +109,31 @@ def test_ycb_batch_is_bit_identical_to_the_oracle():
         assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
     adds = [syn.add_s(inputs.vertices[i], got[-1][i], inputs.gt[i][-1]) for i in range(21)]
     assert max(adds) < 0.01  # tracked: ADD-S against the ground truth below 1 cm
+
+
+def test_compact_kernel_is_bit_identical_to_the_oracle(rbot64):
+    """tracking_step_compact_kernel (the launch shape of batches with two objects per CU and more: 256-thread
+    workgroups, a thread per correspondence line, factor rows instead of product rows), forced onto the headline
+    inputs: poses after every frame and histograms equal the oracle's"""
+    ref, ref_hist = oracle_trajectory(rbot64)
+    got, hist, shape = hip_trajectory(rbot64, env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1"},
+                                      want_kernel="tracking_step_compact_kernel")
+    assert shape[:3] == [64, 1, 256]
+    for k in range(rbot64.n_frames):
+        assert np.array_equal(got[k], ref[k]), k
+    for (fa, ba), (fb, bb) in zip(hist, ref_hist):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+
+
+def test_compact_kernel_region_and_depth():
+    """the same for Region + Depth objects with measured occlusions (YCB parameters, 16 bins: the histogram update
+    rides in the launch)"""
+    inputs = scenes.Inputs(21, 5, n_divides=4, n_models=6, with_depth=True)
+    ref, ref_hist = oracle_trajectory(inputs, use_depth=True)
+    got, hist, shape = hip_trajectory(inputs, use_depth=True, env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1"},
+                                      want_kernel="tracking_step_compact_kernel")
+    assert shape == [21, 1, 256, 1]
+    for k in range(inputs.n_frames):
+        assert np.array_equal(got[k], ref[k]), k
+    for (fa, ba), (fb, bb) in zip(hist, ref_hist):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
