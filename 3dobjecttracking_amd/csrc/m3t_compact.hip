@@ -36,6 +36,7 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
 #pragma unroll
   for (int i = 0; i < 8; ++i) { wf[i] = 0.0f; wb[i] = 0.0f; }
   float x = x0;
+  const unsigned long long rev_mask = __builtin_amdgcn_ballot_w64(reversed);  // lanes that fill from the far end
   // byte offset = minor * stride_minor + major * stride_major; minor < 2^16 and the strides < 2^24: the 24-bit
   // multiply is exact in its low 32 bits
   const uint32_t stride_minor = horiz ? pitch : 3u, stride_major = horiz ? 3u : pitch;
@@ -102,8 +103,11 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
             float value = 1.0f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const float sf = reversed ? wf[(s - k) & 7] : wf[(s + 1 + k) & 7];
-              const float sb = reversed ? wb[(s - k) & 7] : wb[(s + 1 + k) & 7];
+              // one v_cndmask each, spelled out: left to itself the compiler selects the ring INDEX per lane and
+              // emulates the indexed register read with a seven-deep compare / select chain
+              float sf, sb;
+              asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sf) : "v"(wf[(s + 1 + k) & 7]), "v"(wf[(s - k) & 7]), "s"(rev_mask));
+              asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sb) : "v"(wb[(s + 1 + k) & 7]), "v"(wb[(s - k) & 7]), "s"(rev_mask));
               value *= sf * lf[k] + sb * lb[k];
             }
             const int d = reversed ? 18 - t : t - 7;
@@ -223,8 +227,13 @@ __device__ __forceinline__ int compact_region_correspondences(CRegion& m, CCam& 
     switch (it.scale) {
 #define M3T_COMPACT_WALK(S) \
   case S: compact_walk<S>(image, pitch, hist, bitshift, bin_bits, start, step, x0, horiz, reversed, lf, lb, dist0, nl); break;
+#ifdef M3T_ABL_SCALES  /* developer ablation: only the scales of the RBOT configuration (code size) */
+      M3T_COMPACT_WALK(1) M3T_COMPACT_WALK(2) M3T_COMPACT_WALK(5)
+#elif defined(M3T_ABL_NOWALK)
+#else
       M3T_COMPACT_WALK(1) M3T_COMPACT_WALK(2) M3T_COMPACT_WALK(3) M3T_COMPACT_WALK(4) M3T_COMPACT_WALK(5)
       M3T_COMPACT_WALK(6) M3T_COMPACT_WALK(7) M3T_COMPACT_WALK(8) M3T_COMPACT_WALK(9)
+#endif
 #undef M3T_COMPACT_WALK
       default: break;  // (the host does not choose this kernel for larger scales)
     }
@@ -414,7 +423,10 @@ __device__ __forceinline__ void compact_chain(const float* rows_r, int pitch_r, 
 extern "C" {
 
 // One 256-thread workgroup per rigid optimizer, four or five per CU.
-__global__ void __launch_bounds__(M3T_COMPACT_THREADS, 4)
+#ifndef M3T_COMPACT_WAVES
+#define M3T_COMPACT_WAVES 4  /* waves per SIMD the register budget is held to (4 x 256-thread workgroups per CU) */
+#endif
+__global__ void __launch_bounds__(M3T_COMPACT_THREADS, M3T_COMPACT_WAVES)
 tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                              const CameraDev* cams, float* body_poses, CompactLayout L, int iteration,
                              int n_corr_iterations, int n_update_iterations, int fuse_histogram) {
@@ -470,28 +482,40 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
       __syncthreads();
       if (threadIdx.x < kWave) {  // one wave: the sums, Link::CalculateGradientAndHessian link.cpp:184-193, solve, pose
         float sum_r = 0.0f, sum_d = 0.0f;
+#ifndef M3T_ABL_NOCHAIN
         compact_chain(rm ? rows_r : nullptr, L.pitch_r, chain_slots(nl), dm ? rows_d : nullptr, L.pitch_d,
                       chain_slots(np), threadIdx.x, sum_r, sum_d);
+#endif
         float gh = 0.0f;
         if (rm) gh += sum_r;
         if (dm) gh += sum_d;
+#ifndef M3T_ABL_NOSOLVE
         rigid_solve_wave(gh, o.tikhonov_rotation, o.tikhonov_translation, (LdsW)pose, (LdsW)(misc + kMiscSolve));
+#else
+        if (threadIdx.x == 0) misc[kMiscSolve] = gh;
+#endif
       }
       __syncthreads();
     }
   }
   if (threadIdx.x < 16) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
   if (fuse_histogram && rm) {
-    // RegionModality::CalculateResults :572-583 in the same launch (count tables of <= 16 bins per channel fit: the
-    // whole carve-up is free now; first 1024 floats = the scratch block of region_histogram_update, then the counts)
+    // RegionModality::CalculateResults :572-583 in the same launch: the carve-up is free now (first 1024 floats =
+    // the scratch block of region_histogram_update).  While this workgroup streams its histograms through the blend,
+    // the CU's other workgroups walk their lines: HBM streaming beside L1-gather-bound work.
     const Affine b2w = load_pose(pose);
     __syncthreads();
     const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
     Affine b2dc = b2c;
     if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
     const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
-    region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
-                            (__attribute__((address_space(3))) uint32_t*)(lds_c + M3T_MISC_FLOATS), lds_c);
+    auto* counts = (__attribute__((address_space(3))) uint32_t*)(lds_c + L.off_tail_counts);
+    if (L.tail_pass_bins > 0)
+      region_histogram_update<false, true>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false, counts, lds_c, 0, -1,
+                                           reinterpret_cast<uint16_t*>(lds_c + L.off_tail_list), L.tail_list_row,
+                                           L.tail_pass_bins);
+    else
+      region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false, counts, lds_c);
   }
 }
 

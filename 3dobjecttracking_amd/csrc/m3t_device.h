@@ -199,6 +199,11 @@ struct CompactLayout {
   int off_rows_r, pitch_r;    // [M3T_COMPACT_ROWS][pitch_r]
   int off_points;             // [PS_FIELDS][np]
   int off_rows_d, pitch_d;    // [M3T_COMPACT_ROWS][pitch_d]
+  // histogram update in the tail of the launch (the carve-up above is dead by then): 1024 floats of scratch, then
+  // either a count word per bin (tail_pass_bins == 0) or a sample list + the count words of one pass over the bins
+  int tail_list_row;          // list entries per walker (>= the longest projected line), 0: no list
+  int tail_pass_bins;         // bins per pass
+  int off_tail_list, off_tail_counts;
   int total_floats;
 };
 

@@ -531,9 +531,34 @@ void ComputeLayout(Ctx* ctx) {
   C.pitch_d = chain_pitch(np);
   C.off_rows_d = o; o += ctx->depth_mods.empty() ? 0 : M3T_COMPACT_ROWS * C.pitch_d;
   C.total_floats = (o + 3) / 4 * 4;
-  // the histogram update rides along when the packed count table fits behind its 1024-float scratch block
-  ctx->compact_fuses_histogram = bins3 > 0 && size_t(M3T_MISC_FLOATS + bins3) * 4 <= 40 * 1024;
-  if (ctx->compact_fuses_histogram) C.total_floats = std::max(C.total_floats, M3T_MISC_FLOATS + bins3);
+  // The histogram update rides along in the tail of the launch.  Up to 16 bins per channel the packed count table
+  // (one word per bin) fits behind the 1024-float scratch block; with 32 bins the samples' bins go to a 16-bit list
+  // and the bins are counted and blended in passes (region_histogram_update<.., LIST>).  Budget: 40 KB per
+  // workgroup, so that four stay resident per CU.  (Counting by L2 atomics into a table in HBM instead was measured:
+  // 0.77 ms per step for 4096 objects x 8000 samples -- more than the whole separate histogram kernel.)
+  ctx->compact_fuses_histogram = false;
+  C.tail_list_row = C.tail_pass_bins = C.off_tail_list = C.off_tail_counts = 0;
+  const int budget = 40 * 1024 / 4;
+  if (bins3 > 0 && M3T_MISC_FLOATS + bins3 <= budget) {
+    ctx->compact_fuses_histogram = true;
+    C.off_tail_counts = M3T_MISC_FLOATS;
+    C.total_floats = std::max(C.total_floats, M3T_MISC_FLOATS + bins3);
+  } else if (bins3 > 0 && bins3 <= 32768) {
+    float longest = 0.0f;
+    for (auto& m : ctx->region_mods) longest = std::max(longest, m->p.max_considered_line_length);
+    const int row = int(longest + 0.5f) + 1;
+    const int list_words = nl * row;  // two walkers per line, two entries per word
+    int pass = bins3;
+    while (pass > 256 && M3T_MISC_FLOATS + list_words + pass > budget) pass /= 2;
+    if (M3T_MISC_FLOATS + list_words + pass <= budget) {
+      ctx->compact_fuses_histogram = true;
+      C.tail_list_row = row;
+      C.tail_pass_bins = pass;
+      C.off_tail_list = M3T_MISC_FLOATS;
+      C.off_tail_counts = M3T_MISC_FLOATS + list_words;
+      C.total_floats = std::max(C.total_floats, M3T_MISC_FLOATS + list_words + pass);
+    }
+  }
   ctx->compact = C;
   ctx->lds_compact = size_t(C.total_floats) * 4;
 }

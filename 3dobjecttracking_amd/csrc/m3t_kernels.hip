@@ -2265,11 +2265,17 @@ __device__ __forceinline__ void count_add(__attribute__((address_space(1))) unsi
 
 // SHARED: the modality adds into a ColorHistograms object it shares with others (64-bit words, foreground
 // count in the low half, background in the high half); shared_histogram_finish() turns them into histograms
-template <bool SHARED = false, typename CountPtr>
+// LIST: for a workgroup whose LDS cannot hold a count word per bin (tracking_step_compact_kernel: four objects per
+// CU).  The walk writes the bin of every sample into an LDS list (16 bits per sample: bin | background << 15, one
+// row of `list_row` entries per walker); then the bins are taken in passes of `pass_bins`: the pass's share of the
+// list is counted into the (small) table `counts`, its bins are blended and written.  Same sums, same blend
+// arithmetic, any number of passes.  Needs n_bins <= 32 (15-bit bin numbers).
+template <bool SHARED = false, bool LIST = false, typename CountPtr>
 __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                         const Affine& b2dc, bool handle_occlusions, bool initialize,
                                                         CountPtr counts, float* misc, int bin_lo = 0,
-                                                        int bin_hi = -1) {
+                                                        int bin_hi = -1, uint16_t* list = nullptr, int list_row = 0,
+                                                        int pass_bins = 0) {
   // [bin_lo, bin_hi): the bins this workgroup counts and blends (all of them unless it shares its object with
   // others: then every workgroup walks all lines, keeps the samples that fall into its bins, and no table
   // has to be merged); counts[0] is bin_lo's word
@@ -2277,7 +2283,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
   const int n_bins3 = m.n_bins * m.n_bins * m.n_bins;
   if (bin_hi < 0) bin_hi = n_bins3;
   const uint32_t n_own_bins = (uint32_t)(bin_hi - bin_lo);
-  if (!SHARED)
+  if (!SHARED && !LIST)
     for (int i = tid; i < (int)n_own_bins; i += nt) counts[i] = 0;
   unsigned sf = 0, sb = 0;  // this thread's foreground / background samples (all bins)
   PHASE_T0();
@@ -2343,6 +2349,11 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     __syncthreads();
   }
   PHASE_MARK(28);  // tail: occlusion windows
+  if constexpr (LIST) {  // 0xffff = no sample (two entries per word; rows of the walkers that end early stay empty)
+    uint32_t* words = reinterpret_cast<uint32_t*>(list);
+    for (int i = tid; i < n_lines * list_row; i += nt) words[i] = 0xffffffffu;  // 2 walkers x list_row / 2 words per line
+    __syncthreads();
+  }
   // two lanes per line: even lane = foreground walk (inwards), odd lane = background walk
   for (int item = tid; item < 2 * n_lines; item += nt) {
     const int line = item >> 1;
@@ -2447,7 +2458,12 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
       for (int j = 0; j < 8; ++j) {
         const uint32_t bin = ((px[j] & 0xffu) >> bitshift) * n_bins2 + (((px[j] >> 8) & 0xffu) >> bitshift) * n_bins +
                              (((px[j] >> 16) & 0xffu) >> bitshift) - (uint32_t)bin_lo;
-        if (((taken >> j) & 1u) && (SHARED || bin < n_own_bins)) count_add(&counts[bin], inc);
+        if constexpr (LIST) {
+          if (((taken >> j) & 1u) && k0 + j < list_row)
+            list[item * list_row + k0 + j] = (uint16_t)(bin | (background ? 0x8000u : 0u));
+        } else {
+          if (((taken >> j) & 1u) && (SHARED || bin < n_own_bins)) count_add(&counts[bin], inc);
+        }
       }
       n_valid += __builtin_popcount(taken);
     }
@@ -2477,6 +2493,26 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
   GW<v4f> norm4 = (GW<v4f>)m.histogram_norm;
   // (the old histograms of four trips are requested before the first is blended: one memory round trip for a
   // workgroup's 8192 bins at 512 threads instead of four)
+  const int n_passes = LIST ? (n_bins3 + pass_bins - 1) / pass_bins : 1;
+  for (int pass = 0; pass < n_passes; ++pass) {
+  if constexpr (LIST) {
+    bin_lo = pass * pass_bins;
+    bin_hi = min(bin_lo + pass_bins, n_bins3);
+    if (pass > 0) __syncthreads();  // the previous pass's blend has read its counts
+    for (int i = tid; i < pass_bins; i += nt) counts[i] = 0;
+    __syncthreads();
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(list);
+    for (int i = tid; i < n_lines * list_row; i += nt) {
+      const uint32_t w = words[i];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint32_t v = half ? w >> 16 : w & 0xffffu;
+        const uint32_t bin = (v & 0x7fffu) - (uint32_t)bin_lo;
+        if (v != 0xffffu && bin < (uint32_t)(bin_hi - bin_lo)) count_add(&counts[bin], (v & 0x8000u) ? 65536u : 1u);
+      }
+    }
+    __syncthreads();
+  }
   const int i4_end = bin_hi / 4;
   for (int i40 = bin_lo / 4 + tid; i40 < i4_end; i40 += 4 * nt) {
   v4f old_f[4], old_b[4];
@@ -2541,6 +2577,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     }
   }
   }
+  }  // passes
   }  // !SHARED
 }
 

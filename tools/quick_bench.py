@@ -43,7 +43,7 @@ def main():
         for n in counts:
             for env in env_sets:
                 sets = dict(kv.split("=") for kv in env.split(",") if kv)
-                for k in ("M3T_HIP_NO_SPLIT", "M3T_HIP_SPLIT_PARTS", "M3T_HIP_THREADS", "M3T_HIP_COMPACT"):
+                for k in [k for k in os.environ if k.startswith("M3T_HIP_")]:
                     os.environ.pop(k, None)
                 os.environ.update(sets)
                 hip = pkg.CApi(lib, "m3t_hip_")
