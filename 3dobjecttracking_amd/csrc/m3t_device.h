@@ -116,6 +116,8 @@ struct RegionModDev {
   float* histogram_f;     // [n_bins^3]
   float* histogram_b;     // [n_bins^3]
   float2* histogram_norm; // [n_bins^3] (pf/(pf+pb), pb/(pf+pb)) or (0.5,0.5): MultiplyPixelColorProbability hoisted per bin
+  uint8_t* occupancy;     // [n_bins^3 / 4] 1: the group of four bins holds a non-zero histogram value (the update only
+                          // streams those groups and the ones that received samples; a trained 32^3 table is ~85 % empty)
   uint32_t* count_scratch; // [n_bins^3] packed counts, only when they do not fit in LDS (n_bins = 64)
   unsigned long long* shared_counts;  // count table of the shared ColorHistograms object or nullptr
   float* line_state;      // [LS_FIELDS][n_lines_max]

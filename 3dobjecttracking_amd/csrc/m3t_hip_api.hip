@@ -110,7 +110,7 @@ struct RegionMod {
   int depth_renderer = -1, silhouette_renderer = -1;
   int shared_histograms = -1;
   int body, camera, depth_camera, model;
-  DevMem hist_f, hist_b, hist_norm, count_scratch, line_state, gh;
+  DevMem hist_f, hist_b, hist_norm, occupancy, count_scratch, line_state, gh;
   RegionModDev dev{};
 };
 struct DepthMod {
@@ -1743,6 +1743,8 @@ int m3t_hip_region_modality_create(m3t_hip_context* ctx, const m3t_region_modali
   HIPCHK(m->hist_f.alloc(bins3 * 4));
   HIPCHK(m->hist_b.alloc(bins3 * 4));
   HIPCHK(m->hist_norm.alloc(bins3 * 8));
+  HIPCHK(m->occupancy.alloc(bins3 / 4));
+  HIPCHK(hipMemset(m->occupancy.p, 1, bins3 / 4));  // (the uniform start histograms below: every group is non-zero)
   if (bins3 * 4 + M3T_MISC_FLOATS * 4 > 160 * 1024) HIPCHK(m->count_scratch.alloc(bins3 * 4));
   HIPCHK(m->line_state.alloc(size_t(LS_FIELDS) * d.n_lines_max * 4));
   HIPCHK(m->gh.alloc(42 * 4));
@@ -1758,6 +1760,7 @@ int m3t_hip_region_modality_create(m3t_hip_context* ctx, const m3t_region_modali
   d.histogram_f = m->hist_f.as<float>();
   d.histogram_b = m->hist_b.as<float>();
   d.histogram_norm = m->hist_norm.as<float2>();
+  d.occupancy = m->occupancy.as<uint8_t>();
   d.count_scratch = m->count_scratch.as<uint32_t>();
   d.line_state = m->line_state.as<float>();
   d.gradient_hessian = m->gh.as<float>();
@@ -2002,6 +2005,13 @@ int m3t_hip_region_modality_set_histograms(m3t_hip_context* ctx, int id, const f
   HIPCHK(hipMemcpy(m->dev.histogram_f, f, bins3 * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->dev.histogram_b, b, bins3 * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(m->dev.histogram_norm, nrm.data(), bins3 * 8, hipMemcpyHostToDevice));
+  std::vector<uint8_t> occupied(bins3 / 4);
+  for (size_t g = 0; g < bins3 / 4; ++g) {
+    bool any = false;
+    for (size_t k = 4 * g; k < 4 * g + 4; ++k) any = any || f[k] != 0.0f || b[k] != 0.0f;
+    occupied[g] = any ? 1 : 0;
+  }
+  HIPCHK(hipMemcpy(m->dev.occupancy, occupied.data(), occupied.size(), hipMemcpyHostToDevice));
   return M3T_OK;
 }
 

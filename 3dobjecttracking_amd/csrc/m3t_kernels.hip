@@ -2514,32 +2514,53 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     __syncthreads();
   }
   const int i4_end = bin_hi / 4;
+  // One byte per group of four bins says whether the group holds a non-zero value.  A group that is empty and got no
+  // sample stays as it is -- 0 * (1 - lr) + 0 * scale = 0, pair (0.5, 0.5) -- and is neither read nor written: most of
+  // a 32^3 table, frame after frame.  (Not while initialising, and not in the no-sample cases, which may set the
+  // uniform value.)  The occupancy bytes and the counts of four trips are looked at first, then the old histograms
+  // of the groups that need them are requested together.
+  GW<uint8_t> occupancy = as_global_w(m.occupancy);
+  const bool every_group = initialize || sf == 0 || sb == 0;
   for (int i40 = bin_lo / 4 + tid; i40 < i4_end; i40 += 4 * nt) {
+  uint32_t occupied[4];
+#pragma unroll
+  for (int trip = 0; trip < 4; ++trip) {
+    const int i4 = i40 + trip * nt;
+    occupied[trip] = 0u;
+    if (i4 < i4_end) occupied[trip] = every_group ? 1u : (uint32_t)occupancy[i4];
+  }
+  uint32_t c4s[4][4];
+  bool need[4];
+#pragma unroll
+  for (int trip = 0; trip < 4; ++trip) {
+    const int i4 = i40 + trip * nt;
+    need[trip] = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c4s[trip][k] = 0u;
+    if (i4 < i4_end) {
+      const int c0 = 4 * i4 - bin_lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c4s[trip][k] = counts[c0 + k];
+      need[trip] = occupied[trip] != 0u || (c4s[trip][0] | c4s[trip][1] | c4s[trip][2] | c4s[trip][3]) != 0u;
+    }
+  }
   v4f old_f[4], old_b[4];
 #pragma unroll
   for (int trip = 0; trip < 4; ++trip) {
     const int i4 = i40 + trip * nt;
-    if (i4 < i4_end) { old_f[trip] = hist_f4[i4]; old_b[trip] = hist_b4[i4]; }
+    if (need[trip]) { old_f[trip] = hist_f4[i4]; old_b[trip] = hist_b4[i4]; }
   }
 #pragma unroll
   for (int trip = 0; trip < 4; ++trip) {
     const int i4 = i40 + trip * nt;
-    if (i4 < i4_end) {  // (no `continue`: it would send the unrolled loop's arrays to scratch memory)
+    if (need[trip]) {  // (no `continue`: it would send the unrolled loop's arrays to scratch memory)
     v4f hf4 = old_f[trip], hb4 = old_b[trip];
-    const int c0 = 4 * i4 - bin_lo;
-    uint32_t c4[4] = {counts[c0], counts[c0 + 1], counts[c0 + 2], counts[c0 + 3]};
-    // Four bins that were empty and got no sample stay as they are -- 0 * (1 - lr) + 0 * scale = 0, pair (0.5, 0.5)
-    // -- and are not written back: most of a 32^3 table, frame after frame.  (Not while initialising, and not in
-    // the no-sample cases below, which may set the uniform value.)
-    if (!initialize && sf != 0 && sb != 0 && (c4[0] | c4[1] | c4[2] | c4[3]) == 0u &&
-        hf4.x == 0.0f && hf4.y == 0.0f && hf4.z == 0.0f && hf4.w == 0.0f &&
-        hb4.x == 0.0f && hb4.y == 0.0f && hb4.z == 0.0f && hb4.w == 0.0f) {
-    } else {
     v4f n0, n1;
+    bool any = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float hf = hf4[k], hb = hb4[k];
-      uint32_t c = c4[k];
+      uint32_t c = c4s[trip][k];
       if (sf == 0) {
         if (lr_f == 1.0f) hf = uniform_value;
       } else if (comp_f == 0.0f) {
@@ -2558,6 +2579,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
       }
       hf4[k] = hf;
       hb4[k] = hb;
+      any = any || hf != 0.0f || hb != 0.0f;
       // MultiplyPixelColorProbability :1585-1593 hoisted from per pixel to per bin
       float nx = 0.5f, ny = 0.5f;
       if (hf || hb) {
@@ -2573,7 +2595,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     hist_b4[i4] = hb4;
     norm4[2 * i4] = n0;
     norm4[2 * i4 + 1] = n1;
-    }
+    occupancy[i4] = any ? 1 : 0;
     }
   }
   }
