@@ -31,7 +31,7 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
                                              int start, float step, float x0, bool horiz, bool reversed,
                                              const float (&lf)[8], const float (&lb)[8], float* dist0, int nl) {
   // segments per batch: all pixel loads of a batch are issued before the first histogram gather
-  constexpr int GS = SCALE == 1 ? 8 : (SCALE == 2 ? 4 : (SCALE <= 5 ? 2 : 1));
+  constexpr int GS = SCALE <= 2 ? 8 : (SCALE <= 5 ? 4 : 2);  // 8 - 20 pixel loads in flight per lane (measured best)
   float wf[8], wb[8];  // ring: segment t of the walk sits in slot t & 7
 #pragma unroll
   for (int i = 0; i < 8; ++i) { wf[i] = 0.0f; wb[i] = 0.0f; }
@@ -227,13 +227,8 @@ __device__ __forceinline__ int compact_region_correspondences(CRegion& m, CCam& 
     switch (it.scale) {
 #define M3T_COMPACT_WALK(S) \
   case S: compact_walk<S>(image, pitch, hist, bitshift, bin_bits, start, step, x0, horiz, reversed, lf, lb, dist0, nl); break;
-#ifdef M3T_ABL_SCALES  /* developer ablation: only the scales of the RBOT configuration (code size) */
-      M3T_COMPACT_WALK(1) M3T_COMPACT_WALK(2) M3T_COMPACT_WALK(5)
-#elif defined(M3T_ABL_NOWALK)
-#else
       M3T_COMPACT_WALK(1) M3T_COMPACT_WALK(2) M3T_COMPACT_WALK(3) M3T_COMPACT_WALK(4) M3T_COMPACT_WALK(5)
       M3T_COMPACT_WALK(6) M3T_COMPACT_WALK(7) M3T_COMPACT_WALK(8) M3T_COMPACT_WALK(9)
-#endif
 #undef M3T_COMPACT_WALK
       default: break;  // (the host does not choose this kernel for larger scales)
     }
@@ -482,18 +477,12 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
       __syncthreads();
       if (threadIdx.x < kWave) {  // one wave: the sums, Link::CalculateGradientAndHessian link.cpp:184-193, solve, pose
         float sum_r = 0.0f, sum_d = 0.0f;
-#ifndef M3T_ABL_NOCHAIN
         compact_chain(rm ? rows_r : nullptr, L.pitch_r, chain_slots(nl), dm ? rows_d : nullptr, L.pitch_d,
                       chain_slots(np), threadIdx.x, sum_r, sum_d);
-#endif
         float gh = 0.0f;
         if (rm) gh += sum_r;
         if (dm) gh += sum_d;
-#ifndef M3T_ABL_NOSOLVE
         rigid_solve_wave(gh, o.tikhonov_rotation, o.tikhonov_translation, (LdsW)pose, (LdsW)(misc + kMiscSolve));
-#else
-        if (threadIdx.x == 0) misc[kMiscSolve] = gh;
-#endif
       }
       __syncthreads();
     }

@@ -212,3 +212,104 @@ def test_rigid_context_switches_to_general_path_for_begin_end():
             assert a.tracker.CalculateOptimization(0, 0, 0)
         poses.append(np.stack(a.poses()))
     assert np.array_equal(poses[0], poses[1])
+
+
+def chain_state(ch):
+    return [b.body2world_pose() for b in ch.bodies] + [l.joint2parent_pose() for l in ch.links[1:]]
+
+
+@gpu
+def test_eight_body_chain_matches_the_oracle():
+    """BASELINE configs[4] on ONE GPU: bench.py --config chain8's own structure (bench_chain.chain_inputs: a free root
+    and seven revolute joints, 13 dof, one RegionModality per body; optimizer.cpp:144-167, link.cpp:159-241) against
+    the oracle over 5 frames: all 8 body2world and all 7 joint2parent poses after every frame, bit for bit"""
+    import bench_chain
+    inputs, joints, gt = bench_chain.chain_inputs(scenes, syn, 8, 5, 2)
+    start_root = syn.perturb_pose(gt[0][0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
+    start_angles = gt[0][1] + 0.01
+    states = {}
+    for name, api in (("hip", util.open_hip()), ("oracle", util.open_oracle())):
+        ch = bench_chain.Chain(api, host, syn, inputs, joints, start_root, start_angles, range(8))
+        ch.upload(inputs, 0)
+        assert ch.tracker.StartModalities(0)
+        out = []
+        for k in range(len(gt)):
+            ch.upload(inputs, k)
+            assert ch.tracker.ExecuteTrackingStep(k)
+            out.append(chain_state(ch))
+        states[name] = out
+    for k, (sh, so) in enumerate(zip(states["hip"], states["oracle"])):
+        assert len(sh) == 15
+        for x, y in zip(sh, so):
+            assert np.array_equal(x, y), k
+    # the chain is tracked: every body within 5 cm / 5 degrees of the ground truth (rbot_evaluator.cpp:416-433)
+    for i in range(8):
+        e = syn.pose_errors(states["hip"][-1][i], gt[-1][0][i])
+        assert e[0] < np.deg2rad(5) and e[1] < 0.05
+
+
+@gpu
+def test_closed_chain_with_a_hard_constraint_matches_the_oracle():
+    """A -- revolute -- B -- revolute -- C with a Constraint (constraint.cpp:81-102, translation directions) that ties
+    a point of C back to A: a closed kinematic loop, three RegionModalities.  The constraint rows make the system an
+    indefinite KKT matrix; atan2f / tan of the constraint Jacobians differ in the last bit between ocml and glibc, so
+    the stated tolerance is 2e-5 (everywhere else it is zero)."""
+    inputs = scenes.Inputs(3, 1, n_divides=2)
+    rng = np.random.default_rng(3)
+    j1 = syn.make_pose(syn.rot_vec([0.2, -0.1, 0.3]), [0.05, 0.01, 0.0])
+    j2 = syn.make_pose(syn.rot_vec([-0.1, 0.25, 0.05]), [0.04, -0.02, 0.01])
+    th1, th2 = 0.3, -0.2
+    a_t_b = j1 @ syn.make_pose(syn.rot_vec([0, 0, th1]), [0, 0, 0])
+    b_t_c = j2 @ syn.make_pose(syn.rot_vec([0, 0, th2]), [0, 0, 0])
+    a_t_c = a_t_b @ b_t_c
+    c2joint = syn.make_pose(syn.rot_vec([0.1, 0.2, -0.3]), [0.02, 0.03, -0.01])  # the closing joint seen from C
+    a2joint = c2joint @ np.linalg.inv(a_t_c)                                      # ... and from A: closed at (th1, th2)
+    pose_a = inputs.gt[0][0].copy()
+    n_frames = 4
+    gt = []
+    inputs.color = [[], [], []]
+    for k in range(n_frames):
+        pose_a = syn.perturb_pose(pose_a, rng, rot_deg=0.7, trans=0.002)
+        poses = [pose_a, pose_a @ a_t_b, pose_a @ a_t_c]
+        gt.append([p.copy() for p in poses])
+        for i in range(3):
+            inputs.color[i].append(inputs.scenes[i].render(poses[i]))
+    start_a = syn.perturb_pose(gt[0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
+    states = {}
+    for name, api in (("hip", util.open_hip()), ("oracle", util.open_oracle())):
+        rp = dict(syn.RBOT_REGION_PARAMS, measure_occlusions=0)
+        models = [host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
+                  for m in inputs.region_models]
+        bodies = [host.Body(api, np.eye(4)) for _ in range(3)]
+        cams = [host.ColorCamera(api, **inputs.intr) for _ in range(3)]
+        mods = [host.RegionModality(api, bodies[i], cams[i], models[i], **rp) for i in range(3)]
+        la = host.Link(api, body=bodies[0])
+        lb = host.Link(api, body=bodies[1], parent=la, free_directions=(0, 0, 1, 0, 0, 0),
+                       joint2parent_pose=j1 @ syn.make_pose(syn.rot_vec([0, 0, th1 + 0.01]), [0, 0, 0]))
+        lc = host.Link(api, body=bodies[2], parent=lb, free_directions=(0, 0, 1, 0, 0, 0),
+                       joint2parent_pose=j2 @ syn.make_pose(syn.rot_vec([0, 0, th2 - 0.01]), [0, 0, 0]))
+        for link, mod in zip((la, lb, lc), mods):
+            link.AddModality(mod)
+        opt = host.Optimizer(api, root_link=la)
+        host.Constraint(api, opt, la, lc, body12joint1_pose=a2joint, body22joint2_pose=c2joint,
+                        constraint_directions=(0, 0, 0, 1, 1, 1))
+        tracker = host.Tracker(api, 7, 2)
+        bodies[0].set_body2world_pose(start_a)
+        assert tracker.CalculateConsistentPoses()
+        for i in range(3):
+            cams[i].UpdateImage(inputs.color[i][0])
+        assert tracker.StartModalities(0)
+        out = []
+        for k in range(n_frames):
+            for i in range(3):
+                cams[i].UpdateImage(inputs.color[i][k])
+            assert tracker.ExecuteTrackingStep(k)
+            out.append([b.body2world_pose() for b in bodies] + [lb.joint2parent_pose(), lc.joint2parent_pose()])
+        states[name] = out
+        # the loop stays closed: the closing joint's two images coincide in translation
+        a, b, c = [x.astype(np.float64) for x in out[-1][:3]]
+        gap = (a @ np.linalg.inv(a2joint))[:3, 3] - (c @ np.linalg.inv(c2joint))[:3, 3]
+        assert np.max(np.abs(gap)) < 1e-4
+    for sh, so in zip(states["hip"], states["oracle"]):
+        for x, y in zip(sh, so):
+            assert np.max(np.abs(x - y)) < 2e-5

@@ -12,6 +12,10 @@ CMD="python $REPO/tools/quick_bench.py --objects $N --steps 12 --warmup 2 $QB_FL
 declare -A PASS
 PASS[sq1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 PASS[sq2]="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE"
+PASS[ta]="TA_TA_BUSY_sum TA_BUSY_avr TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"
+PASS[tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"
+PASS[fetch]="FETCH_SIZE"
+PASS[write]="WRITE_SIZE"
 for p in ${PASSES:-sq1 sq2}; do
   timeout 300 rocprofv3 --kernel-trace --pmc ${PASS[$p]} --output-format csv -d "$OUT/$p" -- $CMD > "$OUT/$p.log" 2>&1
 done
@@ -47,6 +51,11 @@ for key, counters in sorted(per.items()):
             g("SQ_INSTS_VALU", 0) / key[1]))
     if g("SQ_BUSY_CYCLES") and g("SQ_WAVE_CYCLES"):
         print("  SQ_BUSY_CYCLES %.0f WAVE_CYCLES %.0f ACTIVE_INST_VALU %.0f" % (g("SQ_BUSY_CYCLES"), g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_VALU", 0)))
+    for name in ("TA_TA_BUSY_sum", "TA_BUSY_avr", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_TOTAL_CACHE_ACCESSES_sum",
+                 "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum",
+                 "FETCH_SIZE", "WRITE_SIZE"):
+        if g(name) is not None:
+            print("  %s %.0f" % (name, g(name)))
     if g("SQ_LDS_IDX_ACTIVE"):
         print("  LDS bank conflict frac %.3f" % (g("SQ_LDS_BANK_CONFLICT", 0) / g("SQ_LDS_IDX_ACTIVE")))
 PY
