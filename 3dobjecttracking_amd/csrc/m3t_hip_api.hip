@@ -2924,9 +2924,10 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       }
     }
     const bool split = parts >= 2;
-    // Two objects per CU and more: the compact kernel (<= 47 KB of LDS, <= 128 VGPRs per object: 3-5 workgroups
-    // per CU).  M3T_HIP_COMPACT=0 / 1: developer override (never / whenever possible).
-    bool compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && n >= 2 * ctx->prop.multiProcessorCount;
+    // More objects than CUs: the compact kernel (<= 47 KB of LDS, <= 128 VGPRs per object: 3-4 workgroups per CU;
+    // measured crossover on 256 CUs: 256 objects 0.249 vs 0.225 ms with one 512-thread workgroup per CU, 384 objects
+    // 0.309 vs 0.426 ms).  M3T_HIP_COMPACT=0 / 1: developer override (never / whenever possible).
+    bool compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && n > ctx->prop.multiProcessorCount;
     if (const char* e = std::getenv("M3T_HIP_COMPACT")) compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && std::atoi(e) != 0;
     if (std::getenv("M3T_HIP_THREADS")) compact = false;
     ctx->last_step_kernel = split ? "tracking_step_split_kernel"
