@@ -180,6 +180,12 @@ struct m3t_hip_context {
   bool tree_mode = false;          // any kinematic tree / constraint -> links_* kernels
   bool links_device_newer = false;  // joint poses on the device are ahead of the host mirror
   DevMem d_links, d_constraints, d_soft, d_treeopts, d_work, d_partial;
+  // tracking_step_tree_kernel: one workgroup per link that carries modalities
+  DevMem d_treesteps, d_tracked_links, d_tree_exchange;
+  int n_treesteps = 0;
+  bool tree_fused_possible = false;
+  size_t tree_block_floats = 0;  // LDS of the structure copy (link table, link sums, system, work arrays), largest structure
+  unsigned tree_seq = 0;
   size_t partial_count = 0;
   size_t tree_lds = 0;  // bytes of LDS per structure for the link kernels, 0: work arrays in global memory
   bool partial_ready = false;
@@ -705,6 +711,61 @@ int UploadTreeTables(Ctx* ctx) {
   if (!links.empty()) HIPCHK(hipMemcpy(ctx->d_links.p, links.data(), links.size() * sizeof(LinkDev), hipMemcpyHostToDevice));
   if (!cons.empty()) HIPCHK(hipMemcpy(ctx->d_constraints.p, cons.data(), cons.size() * sizeof(ConstraintDev), hipMemcpyHostToDevice));
   if (!soft.empty()) HIPCHK(hipMemcpy(ctx->d_soft.p, soft.data(), soft.size() * sizeof(SoftConstraintDev), hipMemcpyHostToDevice));
+  // tracking_step_tree_kernel: the links that carry modalities, one workgroup each (at most one region and one
+  // depth modality per link, every modality on a link), their exchange buffers, the LDS of a structure's copy
+  {
+    std::vector<TreeStepDev> steps;
+    std::vector<int> tracked;
+    std::vector<size_t> tracked_off(opts.size()), exchange_off(opts.size());
+    size_t exchange_total = 0, attached = 0;
+    bool possible = true;
+    ctx->tree_block_floats = 0;
+    for (size_t oi = 0; oi < opts.size(); ++oi) {
+      const Optimizer& o = ctx->optimizers[oi];
+      tracked_off[oi] = tracked.size();
+      int n_tracked = 0;
+      for (size_t k = 0; k < o.order.size(); ++k) {
+        const Link& l = ctx->links[o.order[k]];
+        if (l.modalities.empty()) continue;
+        TreeStepDev st{};
+        st.opt = int(oi);
+        st.link = int(k);
+        st.tracked = n_tracked++;
+        st.region_modality = st.depth_modality = -1;
+        st.region_first = 1;
+        for (size_t m = 0; m < l.modalities.size(); ++m) {
+          const ModalityRef& ref = ctx->modalities[l.modalities[m]];
+          int& slot = ref.region ? st.region_modality : st.depth_modality;
+          if (slot >= 0 || l.body < 0) possible = false;  // two of a kind on one link, or a modality without a body
+          slot = ref.index;
+          if (m == 0) st.region_first = ref.region ? 1 : 0;
+          ++attached;
+        }
+        steps.push_back(st);
+        tracked.push_back(int(k));
+      }
+      opts[oi].n_tracked = n_tracked;
+      exchange_off[oi] = exchange_total;
+      exchange_total += size_t(2) * n_tracked * M3T_TREE_GRANULES + 1;  // + the structure's abort word
+      const size_t block = (o.order.size() * sizeof(LinkDev) + 3) / 4 + o.order.size() * 42 + size_t(o.dof) * o.dof + o.dof +
+                           tree_work_floats(int(o.order.size()), o.dof, o.n_rows);
+      ctx->tree_block_floats = std::max(ctx->tree_block_floats, (block + 3) / 4 * 4);
+    }
+    if (attached != ctx->modalities.size() || steps.empty()) possible = false;
+    HIPCHK(ctx->d_treesteps.alloc(std::max<size_t>(1, steps.size()) * sizeof(TreeStepDev)));
+    HIPCHK(ctx->d_tracked_links.alloc(std::max<size_t>(1, tracked.size()) * sizeof(int)));
+    HIPCHK(ctx->d_tree_exchange.alloc(std::max<size_t>(1, exchange_total) * 8));
+    HIPCHK(hipMemset(ctx->d_tree_exchange.p, 0, ctx->d_tree_exchange.bytes));
+    ctx->tree_seq = 0;
+    if (!steps.empty()) HIPCHK(hipMemcpy(ctx->d_treesteps.p, steps.data(), steps.size() * sizeof(TreeStepDev), hipMemcpyHostToDevice));
+    if (!tracked.empty()) HIPCHK(hipMemcpy(ctx->d_tracked_links.p, tracked.data(), tracked.size() * sizeof(int), hipMemcpyHostToDevice));
+    for (size_t oi = 0; oi < opts.size(); ++oi) {
+      opts[oi].tracked_links = ctx->d_tracked_links.as<int>() + tracked_off[oi];
+      opts[oi].exchange = ctx->d_tree_exchange.as<unsigned long long>() + exchange_off[oi];
+    }
+    ctx->n_treesteps = int(steps.size());
+    ctx->tree_fused_possible = possible;
+  }
   if (!opts.empty()) HIPCHK(hipMemcpy(ctx->d_treeopts.p, opts.data(), opts.size() * sizeof(TreeOptDev), hipMemcpyHostToDevice));
   return M3T_OK;
 }
@@ -1190,6 +1251,40 @@ int LaunchOptimization(Ctx* ctx) {
                      ctx->d_depth.as<DepthModDev>(), ctx->d_poses.as<float>());
   HIPCHK(hipGetLastError());
   return M3T_OK;
+}
+
+// LDS of one workgroup of tracking_step_tree_kernel: the tracking carve-up (or the histogram update's count table,
+// whichever is larger) with the structure block behind it
+size_t TreeStepLds(Ctx* ctx, bool fused_histogram) {
+  const size_t front = fused_histogram ? std::max(ctx->lds_track, ctx->lds_hist) : ctx->lds_track;
+  return (front + 15) / 16 * 16 + ctx->tree_block_floats * 4;
+}
+// Can this step run as ONE launch of tracking_step_tree_kernel?  Needs: kinematic structures whose modalities sit on
+// links (at most one region and one depth modality per link), no renderer-fed branches, no communicator, no shared
+// histogram objects, line / point state not requested (fused mode 1), fewer than 63 Newton steps per frame, the
+// structure copy next to the tracking carve-up in LDS, and every workgroup of the grid resident at once.
+bool TreeStepFused(Ctx* ctx) {
+  if (!(ctx->tree_mode && ctx->tree_fused_possible && ctx->fused_mode == 1 && !ctx->comm && ctx->n_render_all == 0 &&
+        ctx->shared_histograms.empty() && ctx->n_treesteps > 0 && !std::getenv("M3T_HIP_NO_TREE_FUSION")))
+    return false;
+  if (ctx->layout.off_hist >= 0) return false;  // (the LDS-staged pair table belongs to tracking_step_lds_kernel)
+  if (ctx->n_corr_iterations * ctx->n_update_iterations >= 63) return false;
+  const bool fused_histogram = !ctx->region_mods.empty() && ctx->hist_counts_in_lds;
+  const size_t lds = TreeStepLds(ctx, fused_histogram);
+  if (lds > size_t(160) * 1024) return false;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_tree_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  int resident = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, tracking_step_tree_kernel, M3T_BLOCK_THREADS, lds) !=
+      hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  resident = std::min(resident, int(size_t(160) * 1024 / lds));
+  return resident >= 1 && ctx->n_treesteps <= ctx->prop.multiProcessorCount * resident;
 }
 
 int Prepare(Ctx* ctx, bool need_images) {
@@ -2992,7 +3087,48 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     ctx->last_step_shape[2] = threads;
     ctx->last_step_shape[3] = histogram_fused ? 1 : 0;
     ctx->state_valid = ctx->fused_mode == 2;
+  } else if (TreeStepFused(ctx)) {
+    // kinematic structures: the whole loop nest in one launch, one workgroup per link that carries modalities
+    ScopedKernelTimer timer(ctx, 0);
+    const bool want_fused_histogram = !ctx->region_mods.empty() && ctx->hist_counts_in_lds && ctx->shared_histograms.empty() &&
+                                      !std::getenv("M3T_HIP_NO_FUSED_HISTOGRAM");
+    const size_t lds = TreeStepLds(ctx, want_fused_histogram);
+    if (!ctx->split_abort_host) {
+      void* host = nullptr;
+      HIPCHK(hipHostMalloc(&host, 64, hipHostMallocMapped));
+      std::memset(host, 0, 64);
+      void* dev = nullptr;
+      HIPCHK(hipHostGetDevicePointer(&dev, host, 0));
+      ctx->split_abort_host = static_cast<unsigned*>(host);
+      ctx->split_abort_dev = static_cast<unsigned*>(dev);
+    }
+    if (ctx->tree_seq >= (1u << 26) - 1) {  // the tags restart: clear them first
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipMemset(ctx->d_tree_exchange.p, 0, ctx->d_tree_exchange.bytes));
+      ctx->tree_seq = 0;
+    }
+    TreeStepParams xp{};
+    xp.seq = ++ctx->tree_seq;
+    if (++ctx->split_launches == 0) ctx->split_launches = 1;
+    xp.abort_id = ctx->split_launches;
+    xp.host_abort = ctx->split_abort_dev;
+    const int off_tree = int((lds / 4 - ctx->tree_block_floats));
+    hipLaunchKernelGGL(tracking_step_tree_kernel, dim3(ctx->n_treesteps), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
+                       ctx->d_treesteps.as<TreeStepDev>(), ctx->d_treeopts.as<TreeOptDev>(),
+                       ctx->d_region.as<RegionModDev>(), ctx->d_depth.as<DepthModDev>(), ctx->cams_active,
+                       ctx->d_poses.as<float>(), ctx->layout, ctx->off_points, ctx->np_max, off_tree, iteration,
+                       ctx->n_corr_iterations, ctx->n_update_iterations, want_fused_histogram ? 1 : 0, xp);
+    HIPCHK(hipGetLastError());
+    histogram_fused = want_fused_histogram;
+    ctx->links_device_newer = true;
+    ctx->last_step_kernel = "tracking_step_tree_kernel";
+    ctx->last_step_shape[0] = ctx->n_treesteps;
+    ctx->last_step_shape[1] = 1;
+    ctx->last_step_shape[2] = M3T_BLOCK_THREADS;
+    ctx->last_step_shape[3] = histogram_fused ? 1 : 0;
+    ctx->state_valid = false;
   } else {
+    ctx->last_step_kernel = "";
     // Tracker::ExecuteTrackingStep tracker.cpp:344-364, one launch per sub-step
     for (int c = 0; c < ctx->n_corr_iterations; ++c) {
       if ((r = RenderForModalities(ctx, false))) return r;

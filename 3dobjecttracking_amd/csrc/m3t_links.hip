@@ -48,6 +48,28 @@ struct TreeOptDev {
   float tikhonov_rotation, tikhonov_translation;
   float* work;     // scratch, layout in tree_work_floats()
   float* partial;  // [dof*dof | dof]
+  // tracking_step_tree_kernel: the links that carry modalities ("tracked" links, one workgroup each) and the buffer
+  // through which their workgroups hand each other the link sums: [2 slots][n_tracked][64] {tag, value} granules,
+  // then one abort word
+  int n_tracked;
+  const int* tracked_links;     // [n_tracked] link index inside the structure
+  unsigned long long* exchange;
+};
+#define M3T_TREE_GRANULES 64  /* granules per tracked link and slot (42 used) */
+
+// one workgroup of tracking_step_tree_kernel
+struct TreeStepDev {
+  int opt;                 // structure (index into the TreeOptDev table)
+  int link;                // this workgroup's link inside the structure
+  int tracked;             // ... and its number among the structure's tracked links
+  int region_modality;     // index into the RegionModDev table or -1
+  int depth_modality;      // index into the DepthModDev table or -1
+  int region_first;        // order of the two in Link::modalities (Link::CalculateGradientAndHessian adds in that order)
+};
+struct TreeStepParams {
+  unsigned seq;            // launch sequence number inside the granule tags
+  unsigned abort_id;       // what a workgroup that waited in vain writes to *host_abort
+  unsigned* host_abort;    // mapped host word
 };
 
 namespace {
@@ -256,9 +278,31 @@ __device__ __forceinline__ TreeWork tree_carve(float* w, int n_links, int dof, i
   return t;
 }
 
+// The structure code below is executed by ONE wave.  As the 64-thread workgroup of links_project_kernel /
+// links_solve_kernel its phases are separated by __syncthreads() (the work arrays may live in global memory);
+// inside tracking_step_tree_kernel (WAVE: the first wave of a 512-thread workgroup, work arrays in LDS) a wave-level
+// barrier is enough: the LDS executes one wave's instructions in order.
+template <bool WAVE>
+__device__ __forceinline__ void tree_sync() {
+  if constexpr (WAVE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+// WAVE: every link's link2world in the (LDS) link table is current, body or not
+template <bool WAVE>
+__device__ __forceinline__ Affine tree_link_pose(const LinkDev& l, const float* body_poses) {
+  if constexpr (WAVE) return load_pose(l.link2world);
+  else return link_pose(l, body_poses);
+}
+
 // Eigen::LDLT<MatrixXf, Lower> + solve (optimizer.cpp:162-163) by one wave: the oracle's LdltSolve, its loops over
 // rows / columns spread over the lanes
-__device__ void ldlt_solve_wave(float* a, float* x, int n, float* temp, int* trans) {
+template <bool WAVE>
+__device__ __forceinline__ void ldlt_solve_wave(float* a, float* x, int n, float* temp, int* trans) {
 #define A_(r, c) a[(size_t)(c) * n + (r)]
   const int lane = threadIdx.x;
   bool degenerate = false;
@@ -280,16 +324,16 @@ __device__ void ldlt_solve_wave(float* a, float* x, int n, float* temp, int* tra
       if (lane == 0) { float t = A_(k, k); A_(k, k) = A_(piv, piv); A_(piv, piv) = t; }
       for (int i = k + 1 + lane; i < piv; i += kWave) { float t = A_(i, k); A_(i, k) = A_(piv, i); A_(piv, i) = t; }
     }
-    __syncthreads();
+    tree_sync<WAVE>();
     if (k > 0) {
       for (int c = lane; c < k; c += kWave) temp[c] = A_(c, c) * A_(k, c);
-      __syncthreads();
+      tree_sync<WAVE>();
       for (int i = k + lane; i < n; i += kWave) {  // i == k: the pivot; below: A21 -= A20 * temp
         float sacc = 0.0f;
         for (int c = 0; c < k; ++c) sacc += A_(i, c) * temp[c];
         A_(i, k) -= sacc;
       }
-      __syncthreads();
+      tree_sync<WAVE>();
     }
     const float akk = A_(k, k);
     const bool pivot_valid = fabsf(akk) > 0.0f;
@@ -299,57 +343,158 @@ __device__ void ldlt_solve_wave(float* a, float* x, int n, float* temp, int* tra
     } else if (pivot_valid) {
       for (int i = k + 1 + lane; i < n; i += kWave) A_(i, k) /= akk;
     }
-    __syncthreads();
+    tree_sync<WAVE>();
   }
   if (lane == 0)
     for (int k = 0; k < n; ++k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
-  __syncthreads();
+  tree_sync<WAVE>();
   for (int c = 0; c + 1 < n; ++c) {  // L y = P b, column sweep: row i sees its c in ascending order
     const float xc = x[c];
     for (int i = c + 1 + lane; i < n; i += kWave) x[i] -= A_(i, c) * xc;
-    __syncthreads();
+    tree_sync<WAVE>();
   }
   for (int i = lane; i < n; i += kWave) {
     if (fabsf(A_(i, i)) > 1.17549435e-38f) x[i] /= A_(i, i);
     else x[i] = 0.0f;
   }
-  __syncthreads();
+  tree_sync<WAVE>();
   for (int i = n - 1; i >= 0; --i) {  // L^T w = z: products by the lanes, the ordered subtraction by one
     for (int r = i + 1 + lane; r < n; r += kWave) temp[r] = A_(r, i) * x[r];
-    __syncthreads();
+    tree_sync<WAVE>();
     if (lane == 0) {
       float sacc = x[i];
       for (int r = i + 1; r < n; ++r) sacc -= temp[r];
       x[i] = sacc;
     }
-    __syncthreads();
+    tree_sync<WAVE>();
   }
   if (lane == 0)
     for (int k = n - 1; k >= 0; --k) { float t = x[k]; x[k] = x[trans[k]]; x[trans[k]] = t; }
-  __syncthreads();
+  tree_sync<WAVE>();
 #undef A_
 }
 
-extern "C" {
+// The same solve for systems of at most N unknowns with the matrix in REGISTERS: lane = row, one register per column
+// (the scheme of rigid_solve_wave for any size).  Eigen's LDLT<Lower> is the bordered variant -- step k writes column
+// k only -- so its diagonal pivoting looks at input diagonal entries only and the whole transposition sequence can be
+// found first, on the diagonal alone (a wave-wide "first largest" per step); P A P^T is then gathered from LDS and
+// factorised without pivoting: element for element the operations of the pivoted in-place algorithm, moved to where
+// the swaps would have carried them.  A zero or NaN diagonal (first pivot invalid, or a NaN that the reference's
+// comparisons treat specially) takes the general routine.  ~8 k cycles instead of ~50 k for the 13 x 13 system of an
+// 8-body chain, where every step of the general routine pays several LDS round trips and barriers.
+template <int N, bool WAVE>
+__device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float* temp, int* trans) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool row = lane < n;
+  float d = row ? fabsf(a[(size_t)lane * n + lane]) : 0.0f;
+  const bool bad = (d != d) || (__builtin_amdgcn_ballot_w64(row && d > 0.0f) == 0);
+  if (__builtin_amdgcn_ballot_w64(row && bad) != 0) {  // uniform
+    ldlt_solve_wave<WAVE>(a, x, n, temp, trans);
+    return;
+  }
+  // 1. the transposition sequence: position p holds input row src
+  int src = lane;
+#pragma nounroll
+  for (int k = 0; k < n; ++k) {
+    const float key = (lane >= k && row) ? d : -1.0f;
+    const float m = wave_max(key);
+    const unsigned long long hits = __builtin_amdgcn_ballot_w64(key == m);
+    const int piv = __builtin_ctzll(hits);  // the first position that holds the largest |A(i,i)|, i >= k
+    const float dk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), k));
+    const float dp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), piv));
+    const int sk = __builtin_amdgcn_readlane(src, k), sp = __builtin_amdgcn_readlane(src, piv);
+    if (lane == k) { d = dp; src = sp; }
+    else if (lane == piv) { d = dk; src = sk; }
+  }
+  // 2. row `lane` of P A P^T (lower triangle; the input holds its lower triangle) and the permuted right-hand side
+  float b[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    const int sc = __builtin_amdgcn_readlane(src, c);
+    const int hi = src > sc ? src : sc, lo = src > sc ? sc : src;
+    b[c] = (row && c <= lane && c < n) ? a[(size_t)lo * n + hi] : 0.0f;
+  }
+  float xp = row ? x[src] : 0.0f;
+  // 3. factorisation
+  float D[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    D[k] = 1.0f;
+    if (k < n) {  // uniform
+      if (k > 0) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < k; ++c) {
+          const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[c] * b[c]), k));  // temp = D * A10^T
+          acc += b[c] * t;
+        }
+        b[k] -= acc;  // row k: the pivot D_k; rows below: A21 -= A20 * temp
+      }
+      D[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[k]), k));
+      const bool pivot_valid = fabsf(D[k]) > 0.0f;
+      const float q = b[k] / D[k];
+      b[k] = (pivot_valid && lane > k) ? q : b[k];
+    }
+  }
+  // 4. L y = P b (column sweep), D z = y (pseudo-inverse), L^T w = z (ordered subtraction on broadcast values)
+#pragma unroll
+  for (int c = 0; c < N - 1; ++c) {
+    if (c < n - 1) {
+      const float xc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xp), c));
+      xp = lane > c ? xp - b[c] * xc : xp;
+    }
+  }
+  float dself = 1.0f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) dself = lane == k ? D[k] : dself;
+  xp = fabsf(dself) > 1.17549435e-38f ? xp / dself : 0.0f;
+  float X[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) X[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xp), i));
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    if (i < n) {
+      float sacc = X[i];
+#pragma unroll
+      for (int r = i + 1; r < N; ++r)
+        if (r < n) sacc -= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[i]), r)) * X[r];  // L(r, i) * w_r
+      X[i] = sacc;
+    }
+  }
+  // 5. un-permute: position p is input row src
+  float mine = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) mine = lane == i ? X[i] : mine;
+  if (row) x[src] = mine;
+  tree_sync<WAVE>();
+}
+template <bool WAVE>
+__device__ __forceinline__ void ldlt_solve_any(float* a, float* x, int n, float* temp, int* trans) {
+  if (n <= 16) ldlt_solve_rows<16, WAVE>(a, x, n, temp, trans);
+  else ldlt_solve_wave<WAVE>(a, x, n, temp, trans);
+}
 
-// Optimizer::CalculateDataLinks (:281-296) + AddProjectedGradientsAndHessians (:309-321)
-__global__ void __launch_bounds__(64)
-links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses, int work_in_lds) {
-  extern __shared__ __attribute__((aligned(16))) float tree_lds[];
-  const TreeOptDev& o = opts[blockIdx.x];
-  const int lane = threadIdx.x, dof = o.dof, n_links = o.n_links;
-  const TreeWork w = tree_carve(work_in_lds ? tree_lds : o.work, n_links, dof, o.n_rows);
+// Optimizer::CalculateDataLinks (:281-296) + AddProjectedGradientsAndHessians (:309-321).
+// links: the structure's link table (global, or its LDS copy); gh_links: nullptr = every link sums its modalities'
+// buffers (Link::CalculateGradientAndHessian), else [n_links][42] link sums already formed; A / b: where the
+// [dof x dof] (lower) and [dof] sums go.
+template <bool WAVE>
+__device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev* links, const TreeWork& w, const float* gh_links, float* A,
+                             float* b, const float* body_poses) {
+  const int lane = threadIdx.x & (kWave - 1), dof = o.dof, n_links = o.n_links;
+  PHASE_T0();
   // adjoints of every link, one lane per link (they depend on the link's own joint poses only)
   for (int li = lane; li < n_links; li += kWave) {
-    const LinkDev& l = o.links[li];
+    const LinkDev& l = links[li];
     if (l.parent >= 0)
       adjoint6(inverse_pose(mul_pose(load_pose(l.joint2parent), load_pose(l.body2joint))), w.AD + (size_t)li * 72);
     adjoint6(inverse_pose(load_pose(l.body2joint)), w.AD + (size_t)li * 72 + 36);
   }
-  __syncthreads();
+  tree_sync<WAVE>();
+  PHASE_MARK(17);
   // Link::CalculateJacobian link.cpp:159-182, parents before children
   for (int li = 0; li < n_links; ++li) {
-    const LinkDev& l = o.links[li];
+    const LinkDev& l = links[li];
     float* J = w.J + (size_t)li * 6 * dof;
     const float* ad = w.AD + (size_t)li * 72;
     const float* Jp = l.parent >= 0 ? w.J + (size_t)l.parent * 6 * dof : nullptr;
@@ -363,7 +508,7 @@ links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses
       }
       J[e] = v;
     }
-    __syncthreads();
+    tree_sync<WAVE>();
     if (lane < 36) {
       const int d = lane / 6, r = lane - d * 6;
       if (l.free_directions[d]) {
@@ -372,24 +517,28 @@ links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses
         J[(size_t)jidx * 6 + r] = ad[36 + d * 6 + r];
       }
     }
-    __syncthreads();
+    tree_sync<WAVE>();
   }
+
+  PHASE_MARK(18);
   // Link::CalculateGradientAndHessian link.cpp:184-193
   for (int e = lane; e < n_links * 42; e += kWave) {
     const int li = e / 42, i = e - li * 42;
-    const LinkDev& l = o.links[li];
+    const LinkDev& l = links[li];
     float sacc = 0.0f;
-    for (int m = 0; m < l.n_gh; ++m) sacc += l.gh[m][i];
+    if (gh_links) sacc = gh_links[e];
+    else
+      for (int m = 0; m < l.n_gh; ++m) sacc += l.gh[m][i];
     w.GH[e] = sacc;
   }
-  __syncthreads();
+  tree_sync<WAVE>();
   // SoftConstraint::AddGradientsAndHessiansToLinks soft_constraint.cpp:113-131 (optimizer.cpp:283-284)
   if (lane == 0) {
     for (int si = 0; si < o.n_soft; ++si) {
       const SoftConstraintDev& sc = o.soft[si];
       Affine b12j1 = load_pose(sc.joint.body12joint1);
-      Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(link_pose(o.links[sc.joint.link1], body_poses))),
-                                     link_pose(o.links[sc.joint.link2], body_poses));
+      Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(tree_link_pose<WAVE>(links[sc.joint.link1], body_poses))),
+                                     tree_link_pose<WAVE>(links[sc.joint.link2], body_poses));
       Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(sc.joint.body22joint2)));
       for (int which = 0; which < 2; ++which) {
         float g[6], h[36];
@@ -405,7 +554,7 @@ links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses
       }
     }
   }
-  __syncthreads();
+  tree_sync<WAVE>();
   // H J of every link, then b = sum J^T g and A = -sum J^T (H J) (lower), link after link per element
   for (int e = lane; e < n_links * 6 * dof; e += kWave) {
     const int li = e / (6 * dof), rem = e - li * 6 * dof, c = rem / 6, r = rem - c * 6;
@@ -415,9 +564,8 @@ links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses
     for (int k = 0; k < 6; ++k) sacc += H[k * 6 + r] * J[(size_t)c * 6 + k];
     w.HJ[e] = sacc;
   }
-  __syncthreads();
-  float* A = o.partial;
-  float* b = o.partial + (size_t)dof * dof;
+  tree_sync<WAVE>();
+  PHASE_MARK(19);
   for (int i = lane; i < dof; i += kWave) {
     float acc = 0.0f;
     for (int li = 0; li < n_links; ++li) {
@@ -443,27 +591,25 @@ links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses
     }
     A[e] = acc;
   }
-  if (work_in_lds)  // the Jacobians are needed again by the solve kernel (constraint rows)
-    for (int e = lane; e < n_links * 6 * dof; e += kWave) o.work[e] = w.J[e];
+  PHASE_MARK(20);
 }
 
-// the rest of Optimizer::CalculateOptimization + Optimizer::UpdatePoses (:335-346)
-__global__ void __launch_bounds__(64)
-links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int zero_theta, int work_in_lds) {
-  extern __shared__ __attribute__((aligned(16))) float tree_lds[];
-  const TreeOptDev& o = opts[blockIdx.x];
-  const int lane = threadIdx.x, dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
-  const TreeWork w = tree_carve(work_in_lds ? tree_lds : o.work, n_links, dof, o.n_rows);
+// the rest of Optimizer::CalculateOptimization + Optimizer::UpdatePoses (:335-346).  partial: [dof x dof | dof] sums
+// (after the all-reduce when the structure spans GPUs); w.J must hold the links' Jacobians.  Returns false when the
+// NaN guard skipped the update.
+template <bool WAVE>
+__device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, const TreeWork& w, const float* partial, float* body_poses,
+                           int zero_theta) {
+  const int lane = threadIdx.x & (kWave - 1), dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
+  PHASE_T0();
   float* A = w.A;
   float* b = w.b;
-  if (work_in_lds)
-    for (int e = lane; e < n_links * 6 * dof; e += kWave) w.J[e] = o.work[e];
   for (int e = lane; e < size * size; e += kWave) {
     const int c = e / size, r = e - c * size;
-    A[e] = (!zero_theta && c < dof && r < dof) ? o.partial[(size_t)c * dof + r] : 0.0f;
+    A[e] = (!zero_theta && c < dof && r < dof) ? partial[(size_t)c * dof + r] : 0.0f;
   }
-  for (int i = lane; i < size; i += kWave) b[i] = (!zero_theta && i < dof) ? o.partial[(size_t)dof * dof + i] : 0.0f;
-  __syncthreads();
+  for (int i = lane; i < size; i += kWave) b[i] = (!zero_theta && i < dof) ? partial[(size_t)dof * dof + i] : 0.0f;
+  tree_sync<WAVE>();
   if (!zero_theta) {  // zero_theta: Optimizer::CalculateConsistentPoses optimizer.cpp:135 (theta = 0)
     // constraints: Constraint::CalculateResidualAndConstraintJacobian constraint.cpp:81-102
     int idx = dof;
@@ -471,10 +617,10 @@ links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int ze
       const ConstraintDev& c = o.constraints[ci];
       const int n_c = c.n;
       if (lane == 0) {
-        const LinkDev& l1 = o.links[c.link1];
-        const LinkDev& l2 = o.links[c.link2];
+        const LinkDev& l1 = links[c.link1];
+        const LinkDev& l2 = links[c.link2];
         Affine b12j1 = load_pose(c.body12joint1);
-        Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(link_pose(l1, body_poses))), link_pose(l2, body_poses));
+        Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(tree_link_pose<WAVE>(l1, body_poses))), tree_link_pose<WAVE>(l2, body_poses));
         Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(c.body22joint2)));
         float angle, axis[3];
         angle_axis(joint22joint1.l, &angle, axis);
@@ -485,7 +631,7 @@ links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int ze
         constraint_unprojected_jacobian(c, joint22joint1, body22joint1, w.j2);
         constraint_unprojected_jacobian(c, joint22joint1, b12j1, w.j1);
       }
-      __syncthreads();
+      tree_sync<WAVE>();
       const float* J1 = w.J + (size_t)c.link1 * 6 * dof;
       const float* J2 = w.J + (size_t)c.link2 * 6 * dof;
       for (int e = lane; e < dof * n_c; e += kWave) {
@@ -499,12 +645,12 @@ links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int ze
         A[(size_t)col * size + idx + r] = -(s2 - s1);
       }
       if (lane < n_c) b[idx + lane] = w.cres[lane];
-      __syncthreads();
+      tree_sync<WAVE>();
       idx += n_c;
     }
     // Tikhonov vector optimizer.cpp:252-271 (free-direction order, rotation first)
     for (int li = lane; li < n_links; li += kWave) {
-      const LinkDev& l = o.links[li];
+      const LinkDev& l = links[li];
       int j = l.first_jacobian_index;
       for (int d = 0; d < 6; ++d)
         if (l.free_directions[d]) {
@@ -512,16 +658,23 @@ links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int ze
           j++;
         }
     }
-    __syncthreads();
-    ldlt_solve_wave(A, b, size, w.temp, w.trans);
+    tree_sync<WAVE>();
+    PHASE_MARK(12);
+    ldlt_solve_any<WAVE>(A, b, size, w.temp, w.trans);
+    PHASE_MARK(13);
     int has_nan = 0;
     for (int i = lane; i < size; i += kWave) has_nan |= (b[i] != b[i]) ? 1 : 0;
-    if (__syncthreads_or(has_nan)) return;  // NaN guard optimizer.cpp:165
+    // NaN guard optimizer.cpp:165
+    if constexpr (WAVE) {
+      if (__builtin_amdgcn_ballot_w64(has_nan != 0) != 0) return false;
+    } else {
+      if (__syncthreads_or(has_nan)) return false;
+    }
   }
   // Link::UpdatePoses link.cpp:205-241: the variations of all links at once (one lane per link) ...
   float* var_all = w.AD;  // [n_links][12]
   for (int li = lane; li < n_links; li += kWave) {
-    const LinkDev& l = o.links[li];
+    const LinkDev& l = links[li];
     float th[6];
     int j = l.first_jacobian_index;
     for (int d = 0; d < 6; ++d) th[d] = l.free_directions[d] ? b[j++] : 0.0f;
@@ -534,34 +687,271 @@ links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int ze
     for (int i = 0; i < 9; ++i) v[i] = R[i];
     v[9] = th[3]; v[10] = th[4]; v[11] = th[5];
   }
-  __syncthreads();
-  // ... then the poses, parents before children
-  if (lane == 0) {
-    for (int li = 0; li < n_links; ++li) {
-      LinkDev& l = o.links[li];
+  tree_sync<WAVE>();
+  PHASE_MARK(14);
+  // ... then the joints (all links at once, one lane per matrix element: mul_pose's expression per element) ...
+  // (results staged in w.HJ, dead here: every element of the old matrix is read before any is overwritten)
+  float* joint2body_chain = w.HJ;
+  for (int e = lane; e < n_links * 12; e += kWave) {
+    const int li = e / 12, q = e - li * 12;
+    LinkDev& l = links[li];
+    if (l.parent < 0) continue;
+    const float* v = var_all + (size_t)li * 12;  // variation: l[9] | t[3]
+    // joint2parent <- joint2parent * var (fixed body2joint), or body2joint <- var * body2joint
+    const float* A4 = l.fixed_body2joint_pose ? l.joint2parent : nullptr;  // 4 x 4 column-major
+    const float* B4 = l.fixed_body2joint_pose ? nullptr : l.body2joint;
+    float r;
+    if (q < 9) {
+      const int c = q / 3, k = q - c * 3;
+      if (A4) r = (A4[k] * v[c * 3] + A4[4 + k] * v[c * 3 + 1]) + A4[8 + k] * v[c * 3 + 2];
+      else r = (v[k] * B4[c * 4] + v[3 + k] * B4[c * 4 + 1]) + v[6 + k] * B4[c * 4 + 2];
+    } else {
+      const int k = q - 9;
+      if (A4) r = ((A4[k] * v[9] + A4[4 + k] * v[10]) + A4[8 + k] * v[11]) + A4[12 + k];
+      else r = ((v[k] * B4[12] + v[3 + k] * B4[13]) + v[6 + k] * B4[14]) + v[9 + k];
+    }
+    joint2body_chain[e] = r;
+  }
+  tree_sync<WAVE>();
+  for (int e = lane; e < n_links * 12; e += kWave) {
+    const int li = e / 12, q = e - li * 12;
+    LinkDev& l = links[li];
+    if (l.parent < 0) continue;
+    float* M = l.fixed_body2joint_pose ? l.joint2parent : l.body2joint;
+    if (q < 9) M[(q / 3) * 4 + (q % 3)] = joint2body_chain[e];
+    else M[12 + (q - 9)] = joint2body_chain[e];
+    if (q < 4) M[q * 4 + 3] = q == 3 ? 1.0f : 0.0f;
+  }
+  tree_sync<WAVE>();
+  // ... then link2world, parents before children: (parent's link2world * joint2parent) * body2joint, left to right
+  // like the reference (the products are not associative in floating point): twelve lanes form the first product,
+  // fetch its rows from each other and form the second.
+  for (int li = 0; li < n_links; ++li) {
+    LinkDev& l = links[li];
+    if (l.parent >= 0) {
+      const float* P4 = links[l.parent].link2world;
+      float first = 0.0f;
+      if (lane < 12) {
+        const float* B4 = l.joint2parent;
+        if (lane < 9) {
+          const int c = lane / 3, k = lane - c * 3;
+          first = (P4[k] * B4[c * 4] + P4[4 + k] * B4[c * 4 + 1]) + P4[8 + k] * B4[c * 4 + 2];
+        } else {
+          const int k = lane - 9;
+          first = ((P4[k] * B4[12] + P4[4 + k] * B4[13]) + P4[8 + k] * B4[14]) + P4[12 + k];
+        }
+      }
+      // first: element (k, c) of the intermediate product in lane c * 3 + k (t in lanes 9..11)
+      float second = 0.0f;
+      {
+        const float* B4 = l.body2joint;
+        const int c = lane < 9 ? lane / 3 : 3, k = lane < 9 ? lane - (lane / 3) * 3 : (lane - 9) % 3;
+        // the intermediate's row k sits in lanes k, 3 + k, 6 + k (and 9 + k for the translation)
+        const float fk0 = __shfl(first, k, kWave), fk1 = __shfl(first, 3 + k, kWave), fk2 = __shfl(first, 6 + k, kWave),
+                    ft = __shfl(first, 9 + k, kWave);
+        if (lane < 9) second = (fk0 * B4[c * 4] + fk1 * B4[c * 4 + 1]) + fk2 * B4[c * 4 + 2];
+        else second = ((fk0 * B4[12] + fk1 * B4[13]) + fk2 * B4[14]) + ft;
+      }
+      if (lane < 9) l.link2world[(lane / 3) * 4 + (lane % 3)] = second;
+      else if (lane < 12) l.link2world[12 + (lane - 9)] = second;
+      if (lane < 4) l.link2world[lane * 4 + 3] = lane == 3 ? 1.0f : 0.0f;
+    } else if (lane == 0) {
       const float* v = var_all + (size_t)li * 12;
       Affine var;
       for (int i = 0; i < 9; ++i) var.l[i] = v[i];
       var.t[0] = v[9]; var.t[1] = v[10]; var.t[2] = v[11];
-      Affine l2w;
-      if (l.parent >= 0) {
-        if (l.fixed_body2joint_pose) {
-          Affine j2p = mul_pose(load_pose(l.joint2parent), var);
-          affine_to_array(j2p, l.joint2parent);
-        } else {
-          Affine b2j = mul_pose(var, load_pose(l.body2joint));
-          affine_to_array(b2j, l.body2joint);
-        }
-        l2w = mul_pose(mul_pose(link_pose(o.links[l.parent], body_poses), load_pose(l.joint2parent)),
-                       load_pose(l.body2joint));
-      } else {
-        Affine b2j = load_pose(l.body2joint);
-        l2w = mul_pose(mul_pose(mul_pose(link_pose(l, body_poses), inverse_pose(b2j)), var), b2j);
-      }
+      Affine b2j = load_pose(l.body2joint);
+      Affine l2w = mul_pose(mul_pose(mul_pose(tree_link_pose<WAVE>(l, body_poses), inverse_pose(b2j)), var), b2j);
       affine_to_array(l2w, l.link2world);
-      if (l.body >= 0) affine_to_array(l2w, body_poses + 16 * l.body);
+    }
+    tree_sync<WAVE>();
+    if (!WAVE && l.body >= 0 && lane < 16) body_poses[16 * l.body + lane] = l.link2world[lane];  // (WAVE: the caller writes the bodies)
+  }
+  PHASE_MARK(15);
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// Tracker::ExecuteTrackingStep (tracker.cpp:344-364) for kinematic structures in ONE launch: one workgroup per link
+// that carries modalities runs that body's correspondence searches, products and reference-order sums (the device
+// functions of tracking_step_kernel); per Newton step the workgroups of a structure hand each other their link's 42
+// sums as {tag, value} granules (the exchange of tracking_step_split_kernel), after which EVERY workgroup holds all
+// link sums and its first wave runs Optimizer::CalculateOptimization on its own LDS copy of the structure -- same
+// inputs, same operations, same poses in all of them, so nothing has to be sent back.  Replaces 50 dependent
+// launches per frame (8-body chain, 7 x 2 iterations).  All workgroups of the grid must be resident (checked by the
+// host); a wait that runs out abandons the step and raises the context's abort word like the split kernel does.
+// ---------------------------------------------------------------------------
+extern "C" {
+
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
+                          const DepthModDev* dmods, const CameraDev* cams, float* body_poses, TrackLdsLayout layout,
+                          int off_points, int np, int off_tree, int iteration, int n_corr_iterations,
+                          int n_update_iterations, int fuse_histogram, TreeStepParams xp) {
+  extern __shared__ __attribute__((aligned(16))) float lds_tree[];
+  const TreeStepDev& st = steps[blockIdx.x];
+  const TreeOptDev& o = opts[st.opt];
+  CRegion* rm = st.region_modality >= 0 ? (CRegion*)(rmods + st.region_modality) : nullptr;
+  CDepth* dm = st.depth_modality >= 0 ? (CDepth*)(dmods + st.depth_modality) : nullptr;
+  const int tid = threadIdx.x, nt = blockDim.x, n_links = o.n_links, dof = o.dof;
+  Lds s = carve(lds_tree, layout);
+  float* ps = lds_tree + off_points;
+  float* rows_r = lds_tree + layout.off_rows_r;
+  float* rows_d = lds_tree + layout.off_rows_d;
+  // the structure: link table | link sums [n_links][42] | [dof x dof | dof] | work arrays
+  LinkDev* links = reinterpret_cast<LinkDev*>(lds_tree + off_tree);
+  float* gh_links = reinterpret_cast<float*>(links + n_links);
+  float* partial = gh_links + n_links * 42;
+  const TreeWork w = tree_carve(partial + dof * dof + dof, n_links, dof, o.n_rows);
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(o.links);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(links);
+    for (int i = tid; i < n_links * (int)(sizeof(LinkDev) / 4); i += nt) dst[i] = src[i];
+    for (int i = tid; i < n_links * 42; i += nt) gh_links[i] = 0.0f;  // links without modalities add nothing
+  }
+  if (rm) stage_log_table(s.misc);
+  __syncthreads();
+  for (int i = tid; i < n_links * 16; i += nt) {  // a link with a body stands where its body stands (link.cpp:296-301)
+    const int li = i >> 4;
+    if (links[li].body >= 0) links[li].link2world[i & 15] = body_poses[16 * links[li].body + (i & 15)];
+  }
+  __syncthreads();
+  float* pose = links[st.link].link2world;  // this workgroup's body2world, kept current by its own tree_solve
+  CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
+  CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
+  CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
+  auto* granules = (__attribute__((address_space(1))) unsigned long long*)o.exchange;
+  auto* abort_word = (__attribute__((address_space(1))) unsigned*)(o.exchange + 2 * (size_t)o.n_tracked * M3T_TREE_GRANULES);
+  int round = 0;
+  for (int c = 0; c < n_corr_iterations; ++c) {
+    {
+      const Affine b2w = load_pose(pose);
+      int region_view = -1;
+      if (rm) {
+        const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+        Affine b2dc = b2c;
+        if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
+        region_view = region_correspondences<false>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s);
+        region_moments(*rm, s);
+      }
+      if (dm) {
+        const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
+        depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, 0, 1 << 30,
+                                   (rm && dm->view_search_shared) ? region_view : -1);
+        depth_correspondences_vote(*dm, iteration, ps, np, s.misc);
+      } else {
+        __syncthreads();
+      }
+    }
+    for (int u = 0; u < n_update_iterations; ++u, ++round) {
+      const Affine b2w = load_pose(pose);
+      if (rm) {
+        const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+        region_products(*rm, *cam, b2c, c, u, s, rows_r, layout.pitch_r);
+      }
+      if (dm) {
+        const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
+        depth_products(*dm, b2c, c, ps, np, rows_d, layout.pitch_d);
+      }
+      __syncthreads();
+      const uint32_t tag = xp.seq * 64u + (uint32_t)round + 1u;
+      auto* slot = granules + (size_t)(round & 1) * o.n_tracked * M3T_TREE_GRANULES;
+      if (tid < kWave) {  // one wave: the sums in the reference's order, the link's sum, publish
+        float sum_r = 0.0f, sum_d = 0.0f;
+        chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
+                   chain_slots(np), gh_lane_row(tid < 42 ? tid : 0), sum_r, sum_d);
+        float gh = 0.0f;  // Link::CalculateGradientAndHessian link.cpp:184-193, in the order of Link::modalities
+        if (rm && dm && !st.region_first) { gh += sum_d; gh += sum_r; }
+        else { if (rm) gh += sum_r; if (dm) gh += sum_d; }
+        if (tid < 42) {
+          gh_links[st.link * 42 + tid] = gh;
+          __hip_atomic_store(slot + (size_t)st.tracked * M3T_TREE_GRANULES + tid,
+                             (static_cast<unsigned long long>(tag) << 32) | (unsigned)__float_as_int(gh),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // collect the other tracked links' sums (one granule per thread and trip, re-read until its tag matches)
+      bool timed_out = false;
+      for (int idx = tid; idx < o.n_tracked * 42; idx += nt) {
+        const int t = idx / 42, i = idx - t * 42;
+        if (t == st.tracked) continue;
+        auto* g = slot + (size_t)t * M3T_TREE_GRANULES + i;
+        unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (static_cast<uint32_t>(v >> 32) != tag) {
+          if (++spins > (1u << 12) ||
+              ((spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xp.seq)) {
+            timed_out = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        gh_links[o.tracked_links[t] * 42 + i] = __int_as_float(static_cast<int>(static_cast<uint32_t>(v)));
+      }
+      if (__syncthreads_or(timed_out ? 1 : 0)) {
+        if (tid == 0) {
+          __hip_atomic_store(abort_word, xp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(xp.host_abort, xp.abort_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+      }
+      if (tid < kWave) {  // Optimizer::CalculateOptimization + UpdatePoses on this workgroup's copy of the structure
+        PHASE_T0();
+        tree_project<true>(o, links, w, gh_links, partial, partial + dof * dof, nullptr);
+        tree_sync<true>();
+        PHASE_MARK(30);
+        (void)tree_solve<true>(o, links, w, partial, nullptr, 0);
+        PHASE_MARK(31);
+      }
+      __syncthreads();
     }
   }
+  // every workgroup of a structure holds the same link table: the first one writes it (and the bodies) back
+  if (st.tracked == 0) {
+    for (int i = tid; i < n_links * 48; i += nt) {
+      const int li = i / 48, k = i - li * 48;
+      float* dst = k < 16 ? o.links[li].body2joint : (k < 32 ? o.links[li].joint2parent : o.links[li].link2world);
+      const float* src = k < 16 ? links[li].body2joint : (k < 32 ? links[li].joint2parent : links[li].link2world);
+      dst[k & 15] = src[k & 15];
+    }
+    for (int i = tid; i < n_links * 16; i += nt) {
+      const int li = i >> 4;
+      if (links[li].body >= 0) body_poses[16 * links[li].body + (i & 15)] = links[li].link2world[i & 15];
+    }
+  }
+  if (fuse_histogram && rm) {  // RegionModality::CalculateResults :572-583 in the same launch
+    const Affine b2w = load_pose(pose);
+    __syncthreads();
+    const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+    Affine b2dc = b2c;
+    if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
+    const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
+    region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
+                            (__attribute__((address_space(3))) uint32_t*)(lds_tree + M3T_MISC_FLOATS), lds_tree);
+  }
+}
+
+__global__ void __launch_bounds__(64)
+links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses, int work_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) float tree_lds[];
+  const TreeOptDev& o = opts[blockIdx.x];
+  const TreeWork w = tree_carve(work_in_lds ? tree_lds : o.work, o.n_links, o.dof, o.n_rows);
+  tree_project<false>(o, o.links, w, nullptr, o.partial, o.partial + (size_t)o.dof * o.dof, body_poses);
+  if (work_in_lds)  // the Jacobians are needed again by the solve kernel (constraint rows)
+    for (int e = threadIdx.x; e < o.n_links * 6 * o.dof; e += kWave) o.work[e] = w.J[e];
+}
+
+__global__ void __launch_bounds__(64)
+links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int zero_theta, int work_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) float tree_lds[];
+  const TreeOptDev& o = opts[blockIdx.x];
+  const TreeWork w = tree_carve(work_in_lds ? tree_lds : o.work, o.n_links, o.dof, o.n_rows);
+  if (work_in_lds) {
+    for (int e = threadIdx.x; e < o.n_links * 6 * o.dof; e += kWave) w.J[e] = o.work[e];
+    __syncthreads();
+  }
+  (void)tree_solve<false>(o, o.links, w, o.partial, body_poses, zero_theta);
 }
 
 }  // extern "C"

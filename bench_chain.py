@@ -190,23 +190,32 @@ def run(args, pkg, rank, local_rank, world, dist, torch):
                       "gpu_us_per_structure": round(gpu_us / n_structures, 3), "cpu_port_us_per_structure": round(cpu_us, 2)})
     total = n_bodies * K
     rate = total / elapsed
+    name = C.create_string_buffer(64)
+    hip.call("get_step_kernel", name, 64)
+    kernel = name.value.decode()
+    fused = kernel == "tracking_step_tree_kernel"
     return {
         "metric": "pose-updates/sec (Mb-ICG kinematic chain, %d bodies, %d dof)" % (n_bodies, 6 + n_bodies - 1),
         "value": round(rate, 1), "unit": "pose-updates/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[4]: one kinematic chain of %d bodies (free root + %d revolute joints), one "
-                               "RegionModality per body (RBOT parameters, 200 lines x 7 x 2), link kernels: one wave per "
-                               "structure; body i on GPU i mod %d, ONE ncclAllReduce of %d floats per Newton step%s" %
-                               (n_bodies, n_bodies - 1, world, (6 + n_bodies - 1) ** 2 + 6 + n_bodies - 1,
-                                "" if world > 1 else " when N > 1"),
+                               "RegionModality per body (RBOT parameters, 200 lines x 7 x 2); %s; body i on GPU i mod %d, "
+                               "ONE ncclAllReduce of %d floats per Newton step%s" %
+                               (n_bodies, n_bodies - 1,
+                                "one launch per frame, one workgroup per body, the structure solved by every workgroup's "
+                                "first wave" if fused else "one launch per sub-step, link kernels: one wave per structure",
+                                world, (6 + n_bodies - 1) ** 2 + 6 + n_bodies - 1, "" if world > 1 else " when N > 1"),
                    "bodies": n_bodies, "parallelism": "bodies sharded over %d GPU(s)" % world,
                    "max_rotation_error_vs_ground_truth_rad": round(float(max(e[0] for e in gt_err)), 5),
                    "setup_s": round(setup_s, 1)},
-        "roofline": {"bound": "hbm", "kernel": "whole step: 7 x (correspondence + 2 x (g/H, project, solve)) + results launches",
+        "roofline": {"bound": "hbm",
+                     "kernel": kernel if fused else "whole step: 7 x (correspondence + 2 x (g/H, project, solve)) + results launches",
                      "achieved": round(rate * B_ALG / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(rate * B_ALG / 8e12, 6), "traffic": None,
-                     "note": "launch- and latency-bound by construction: 50 dependent launches per frame for one structure"},
+                     "note": ("latency-bound by construction: 14 dependent solves of one 13-dof structure per frame, each on "
+                              "one wave" if fused else
+                              "launch- and latency-bound by construction: 50 dependent launches per frame for one structure")},
         "cpu_baseline": cpu, "parity": parity,
         "repeats": {"n": len(times), "ms_per_step_min": round(min(times) / K * 1e3, 4),
                     "ms_per_step_median": round(elapsed / K * 1e3, 4)},

@@ -238,6 +238,10 @@ def test_eight_body_chain_matches_the_oracle():
             assert ch.tracker.ExecuteTrackingStep(k)
             out.append(chain_state(ch))
         states[name] = out
+        if name == "hip":  # the whole loop nest of the structure in one launch, one workgroup per body
+            kernel = C.create_string_buffer(64)
+            api.call("get_step_kernel", kernel, 64)
+            assert kernel.value.decode() == "tracking_step_tree_kernel"
     for k, (sh, so) in enumerate(zip(states["hip"], states["oracle"])):
         assert len(sh) == 15
         for x, y in zip(sh, so):
