@@ -1,0 +1,151 @@
+"""Batches of independent single-body trackers on seeded synthetic inputs: what bench.py times, what the
+parity tests compare, what __graft_entry__.smoke() runs.  `Inputs` holds the rendered frames, sparse viewpoint models
+and start poses; `Instance` is the object graph of those inputs behind ONE C-ABI context (the HIP library -- or, in
+the tests and bench.py's checker legs, the CPU oracle bound through the same ctypes layer), driven through identical
+Tracker calls."""
+import ctypes as C
+
+import numpy as np
+
+from . import host
+from . import synthetic as syn
+
+
+class Inputs:
+    """Seeded inputs for n_objects independent single-body trackers."""
+
+    def __init__(self, n_objects, n_frames, n_divides=2, n_points=200, intr=None, with_depth=False,
+                 depth_scale=1e-4, n_models=None, first_object=0):
+        self.n_objects = n_objects
+        self.n_frames = n_frames
+        self.with_depth = with_depth
+        self.intr = dict(intr or (syn.YCB_INTRINSICS if with_depth else syn.RBOT_INTRINSICS))
+        self.depth_scale = depth_scale
+        self.scenes = [syn.Scene(first_object + i, intr=self.intr, with_depth=with_depth, depth_scale=depth_scale)
+                       for i in range(n_objects)]
+        n_models = n_models or n_objects
+        # objects sharing a model share the body shape
+        for i, sc in enumerate(self.scenes):
+            if i >= n_models:
+                sc.body = self.scenes[i % n_models].body
+        self.model_of = [i % n_models for i in range(n_objects)]
+        self.region_models = [syn.make_region_model(self.scenes[m].body, n_divides=n_divides, n_points=n_points)
+                              for m in range(n_models)]
+        self.depth_models = ([syn.make_depth_model(self.scenes[m].body, n_divides=n_divides, n_points=n_points)
+                              for m in range(n_models)] if with_depth else None)
+        self.gt = [[None] * n_frames for _ in range(n_objects)]
+        self.color = [[None] * n_frames for _ in range(n_objects)]
+        self.depth = [[None] * n_frames for _ in range(n_objects)]
+        for i, sc in enumerate(self.scenes):
+            for k in range(n_frames):
+                if k:
+                    sc.step_pose()
+                self.gt[i][k] = sc.pose.copy()
+                r = sc.render()
+                if with_depth:
+                    self.color[i][k], self.depth[i][k] = r
+                else:
+                    self.color[i][k] = r
+        # the tracker starts from a slightly wrong pose
+        rng = np.random.default_rng(77 + first_object)
+        self.start = [syn.perturb_pose(self.gt[i][0], rng, rot_deg=1.0, trans=0.002) for i in range(n_objects)]
+        self.vertices = [sc.body.vertices(300, seed=i) for i, sc in enumerate(self.scenes)]
+
+
+class Instance:
+    """The object graph of `inputs` behind one C-ABI context (HIP or oracle)."""
+
+    def __init__(self, api, inputs, region_params=None, depth_params=None, tracker_params=None, use_region=True,
+                 use_depth=False):
+        self.api = api
+        self.inputs = inputs
+        rp = dict(region_params or (syn.YCB_REGION_PARAMS if inputs.with_depth else syn.RBOT_REGION_PARAMS))
+        dp = dict(depth_params or syn.YCB_DEPTH_PARAMS)
+        tp = dict(tracker_params or (syn.YCB_TRACKER if inputs.with_depth else syn.RBOT_TRACKER))
+        if not inputs.with_depth:
+            rp["measure_occlusions"] = 0
+        intr = inputs.intr
+        self.region_models = [host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
+                              for m in inputs.region_models] if use_region else []
+        self.depth_models = [host.DepthModel(api, data_points=m[0], orientations=m[1], surface_areas=m[2])
+                             for m in (inputs.depth_models or [])] if use_depth else []
+        self.bodies, self.color_cams, self.depth_cams, self.region, self.depth, self.optimizers = [], [], [], [], [], []
+        # inputs.camera_of (optional): objects that look at the same frame stream share one camera
+        camera_of = getattr(inputs, "camera_of", None)
+        shared = {}
+        for i in range(inputs.n_objects):
+            body = host.Body(api, inputs.start[i])
+            if camera_of is not None and camera_of[i] in shared:
+                cam, dcam = shared[camera_of[i]]
+            else:
+                cam = host.ColorCamera(api, **intr)
+                dcam = host.DepthCamera(api, depth_scale=inputs.depth_scale, **intr) if inputs.with_depth else None
+                if camera_of is not None:
+                    shared[camera_of[i]] = (cam, dcam)
+            mods = []
+            if use_region:
+                r = host.RegionModality(api, body, cam, self.region_models[inputs.model_of[i]], depth_camera=dcam, **rp)
+                self.region.append(r)
+                mods.append(r)
+            if use_depth:
+                d = host.DepthModality(api, body, dcam, self.depth_models[inputs.model_of[i]], **dp)
+                self.depth.append(d)
+                mods.append(d)
+            self.optimizers.append(host.Optimizer(
+                api, body=body, modalities=mods, tikhonov_parameter_rotation=tp["tikhonov_parameter_rotation"],
+                tikhonov_parameter_translation=tp["tikhonov_parameter_translation"]))
+            self.bodies.append(body)
+            self.color_cams.append(cam)
+            self.depth_cams.append(dcam)
+        self.tracker = host.Tracker(api, tp["n_corr_iterations"], tp["n_update_iterations"])
+
+    def upload_frame(self, k):
+        for i in range(self.inputs.n_objects):
+            self.color_cams[i].UpdateImage(self.inputs.color[i][k])
+            if self.depth_cams[i] is not None:
+                self.depth_cams[i].UpdateImage(self.inputs.depth[i][k])
+
+    def poses(self):
+        return [b.body2world_pose() for b in self.bodies]
+
+    def set_poses(self, poses):
+        for b, p in zip(self.bodies, poses):
+            b.set_body2world_pose(p)
+
+
+def replicate(inputs, n_obj):
+    """n_obj objects over the rendered streams of `inputs` (object i looks at stream i mod n_streams through its OWN
+    camera and frame ring: distinct device memory, identical content)"""
+    if n_obj == inputs.n_objects:
+        return inputs
+    rep = Inputs.__new__(Inputs)
+    rep.__dict__.update(inputs.__dict__)
+    idx = [i % inputs.n_objects for i in range(n_obj)]
+    rep.n_objects = n_obj
+    for name in ("scenes", "model_of", "gt", "color", "depth", "start", "vertices"):
+        rep.__dict__[name] = [inputs.__dict__[name][i] for i in idx]
+    return rep
+
+
+def subset(inputs, idx):
+    """the objects `idx` of a batch as a batch of their own"""
+    sub = Inputs.__new__(Inputs)
+    sub.__dict__.update(inputs.__dict__)
+    sub.n_objects = len(idx)
+    for name in ("scenes", "model_of", "gt", "color", "depth", "start", "vertices"):
+        sub.__dict__[name] = [inputs.__dict__[name][i] for i in idx]
+    return sub
+
+
+def stage_frames(api, inst, inputs, n_frames):
+    """all frames of all cameras into device-side rings (a new frame is then a pointer switch: cameras_select_slot)"""
+    for cams, frames in ((inst.color_cams, inputs.color), (inst.depth_cams, inputs.depth)):
+        done = set()
+        for i, cam in enumerate(cams):
+            if cam is None or cam.id in done:
+                continue
+            done.add(cam.id)
+            api.call("camera_set_ring", cam.id, n_frames)
+            for k in range(n_frames):
+                f = frames[i][k]
+                api.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])

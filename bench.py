@@ -29,7 +29,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+ORACLE_DIR = os.path.join(ROOT, "oracle")  # the checker / CPU baseline: never in the timed GPU path
 
 # algorithmic bytes per pose-update (Region only, RBOT parameters)
 B_PIXELS = 49400 * 3
@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 CONFIGS = {
     "rbot64": dict(metric="pose-updates/sec (64 objects, 200 lines, 7 it)", scaling="weak", with_depth=False,
-                   objects=64, models=8, alg=B_ALG, alg_track=B_ALG_TRACK_KERNEL, newton=14,
+                   objects=64, models=18, alg=B_ALG, alg_track=B_ALG_TRACK_KERNEL, newton=14,
                    workload="BASELINE configs[1]: %(n)d batched RBOT-geometry objects per GPU, RegionModality only, "
                             "200 lines x 7 corr-iterations x 2 updates, 640x512 BGR8, 32-bin histograms, "
                             "%(views)d views x 200 points models (%(models)d distinct)"),
@@ -79,7 +79,11 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (1 thread)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-cpu-parallel", action="store_true", help="skip the all-cores (OpenMP) CPU leg")
-    p.add_argument("--repeats", type=int, default=5, help="how often the timed region of K steps is repeated")
+    p.add_argument("--repeats", type=int, default=0,
+                   help="how often the timed region of K steps is repeated; 0 = until --busy-seconds of timed regions")
+    p.add_argument("--busy-seconds", type=float, default=6.0,
+                   help="with --repeats 0: keep repeating the K-step region until this much GPU time has been timed "
+                        "(at least 5 regions): a K = 20 region lasts ~3 ms, too short for device-level telemetry")
     p.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) legs")
     p.add_argument("--sweep", type=str, default="", help="comma separated object counts for a batch sweep (extra)")
     p.add_argument("--extras", action="store_true",
@@ -88,31 +92,19 @@ def parse():
     return p.parse_args()
 
 
-def replicate(scenes, inputs, n_obj):
-    """n_obj objects over the rendered streams of `inputs` (object i looks at stream i mod n_streams through its OWN
-    camera and frame ring: distinct device memory, identical content)"""
-    if n_obj == inputs.n_objects:
-        return inputs
-    rep = scenes.Inputs.__new__(scenes.Inputs)
-    rep.__dict__.update(inputs.__dict__)
-    idx = [i % inputs.n_objects for i in range(n_obj)]
-    rep.n_objects = n_obj
-    for name in ("scenes", "model_of", "gt", "color", "depth", "start", "vertices"):
-        rep.__dict__[name] = [inputs.__dict__[name][i] for i in idx]
-    return rep
-
-
-def stage_frames(hip, inst, inputs, n_frames):
-    for cams, frames in ((inst.color_cams, inputs.color), (inst.depth_cams, inputs.depth)):
-        done = set()
-        for i, cam in enumerate(cams):
-            if cam is None or cam.id in done:
-                continue
-            done.add(cam.id)
-            hip.call("camera_set_ring", cam.id, n_frames)
-            for k in range(n_frames):
-                f = frames[i][k]
-                hip.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+def open_oracle(native=False):
+    """oracle/libm3t_oracle.so (the bit-exact checker: x86-64-v3, no FMA contraction) or, native=True,
+    oracle/libm3t_oracle_native.so: the same source built the way the reference builds (-O3 -march=native, default
+    contraction, M3T/CMakeLists.txt:73-80) on THIS host -- faster, not bit-identical, used for timing only."""
+    import subprocess
+    pkg = importlib.import_module("3dobjecttracking_amd")
+    name = "libm3t_oracle_native.so" if native else "libm3t_oracle.so"
+    path = os.path.join(ORACLE_DIR, name)
+    if native:  # always rebuilt: -march=native belongs to the host that runs it
+        subprocess.check_call(["make", "-s", "-B", "-C", ORACLE_DIR, name])
+    elif not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, name])
+    return pkg.CApi(path, "m3t_oracle_")
 
 
 def main():
@@ -129,12 +121,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
 
     pkg = importlib.import_module("3dobjecttracking_amd")
-    import scenes
     if args.config == "chain8":
         import bench_chain
-        out = bench_chain.run(args, pkg, rank, local_rank, world, dist, torch)
+        out = bench_chain.run(args, pkg, rank, local_rank, world, dist, torch, open_oracle)
     else:
-        out = run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch)
+        out = run_objects(args, pkg, pkg.batch, rank, local_rank, world, dist, torch)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -162,9 +153,9 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
     n_models = min(args.models or cfg["models"], n_streams)
     base = scenes.Inputs(n_streams, n_frames, n_divides=args.n_divides, n_models=n_models, with_depth=use_depth,
                          first_object=first + (rank * 1000 if cfg["scaling"] == "strong" else 0))
-    inputs = replicate(scenes, base, n_obj)
+    inputs = scenes.replicate(base, n_obj)
     inst = scenes.Instance(hip, inputs, use_depth=use_depth)
-    stage_frames(hip, inst, inputs, n_frames)
+    scenes.stage_frames(hip, inst, inputs, n_frames)
     setup_s = time.time() - t0
 
     def barrier():
@@ -197,7 +188,13 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
     # trajectory checked below is the first one): min / median of the timed region, MAX over ranks each
     times = [elapsed]
     restart = np.stack([np.ascontiguousarray(inputs.gt[i][W].T, np.float32).reshape(16) for i in range(n_obj)])
-    for _ in range(max(0, args.repeats - 1)):
+    # (every rank repeats the same number of times: the count is fixed from rank 0's first region)
+    n_repeats = args.repeats if args.repeats > 0 else int(min(4000, max(5, args.busy_seconds / max(elapsed, 1e-6))))
+    if dist is not None:
+        tn = torch.tensor([n_repeats], device="cuda")
+        dist.broadcast(tn, 0)
+        n_repeats = int(tn.item())
+    for _ in range(max(0, n_repeats - 1)):
         hip.call("bodies_set_poses", restart.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
         barrier()
         t = time.perf_counter()
@@ -224,8 +221,9 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
         hip.call("set_kernel_timing", 0)
         shape = (C.c_int * 4)()
         hip.call("get_step_shape", shape)  # objects, workgroups per object, threads, histogram update fused
-        kernel = "tracking_step_split_kernel" if shape[1] > 1 else (
-            "tracking_step_lds_kernel" if use_depth else "tracking_step_kernel")
+        name = C.create_string_buffer(64)
+        hip.call("get_step_kernel", name, 64)
+        kernel = name.value.decode()
         track_ms = ms[0] / max(cnt[0], 1)
         fused_hist = cnt[1] == 0  # the histogram update rode in the tracking launch
         hist_ms = ms[1] / max(cnt[1], 1)
@@ -262,12 +260,9 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
     # the parity check of the benchmarked trajectory: the same objects, the same frames, free running ----
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only (the other ranks would idle)
-        import util
-        ora = util.open_oracle()
+        ora = open_oracle()
         n_cpu = min(8, n_obj)
-        sub = scenes.Inputs.__new__(scenes.Inputs)
-        sub.__dict__.update(inputs.__dict__)
-        sub.n_objects = n_cpu
+        sub = scenes.subset(inputs, list(range(n_cpu)))
         oinst = scenes.Instance(ora, sub, use_depth=use_depth)
         oinst.upload_frame(0)
         oinst.tracker.StartModalities(0)
@@ -297,10 +292,32 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
             oinst.set_poses([inputs.gt[i][0] for i in range(n_cpu)])
         cpu_parallel = None
         if not args.no_cpu_parallel:
-            cpu_parallel = cpu_all_cores(scenes, replicate(scenes, base, min(n_obj, 64)), min(n_obj, 64), n_frames,
+            cpu_parallel = cpu_all_cores(scenes, scenes.replicate(base, min(n_obj, 64)), min(n_obj, 64), n_frames,
                                          use_depth)
+        native = None
+        try:  # the same restatement built as the reference builds (M3T/CMakeLists.txt:73-80), on this host
+            nat = open_oracle(native=True)
+            ninst = scenes.Instance(nat, sub, use_depth=use_depth)
+            ninst.upload_frame(0)
+            ninst.tracker.StartModalities(0)
+            n_done, n_spent = 0, 0.0
+            while n_spent < min(args.cpu_seconds, 6.0):
+                for k in range(1, n_frames):
+                    ninst.upload_frame(k)
+                    tc = time.perf_counter()
+                    ninst.tracker.ExecuteTrackingStep(k)
+                    n_spent += time.perf_counter() - tc
+                    n_done += n_cpu
+                ninst.set_poses([inputs.gt[i][0] for i in range(n_cpu)])
+            native = {"value": round(n_done / n_spent, 1), "unit": "pose-updates/s", "cores": 1,
+                      "build": "g++ -O3 -march=native (FMA contraction on): timing only, not bit-identical"}
+            if not args.no_cpu_parallel:
+                native["all_cores"] = cpu_all_cores(scenes, scenes.replicate(base, min(n_obj, 64)), min(n_obj, 64),
+                                                    n_frames, use_depth, seconds=5.0, native=True)
+        except Exception as e:  # noqa: BLE001 (no compiler on the box: the baseline above stands alone)
+            native = {"error": str(e)[:200]}
         cpu = {"value": round(done / spent, 1), "unit": "pose-updates/s", "cores": 1, "kind": "port",
-               "all_cores": cpu_parallel,
+               "all_cores": cpu_parallel, "native_build": native,
                "sample": "%d pose-updates of %d of the same objects, same frames, oracle/libm3t_oracle.so "
                          "(g++ -O3 -march=x86-64-v3), 1 thread, host has %d cores" % (done, n_cpu, os.cpu_count())}
 
@@ -321,7 +338,9 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "repeats": {"n": len(times), "ms_per_step_min": round(min(times) / K * 1e3, 4),
                     "ms_per_step_median": round(elapsed / K * 1e3, 4),
-                    "ms_per_step_all": [round(x / K * 1e3, 4) for x in times]},
+                    "ms_per_step_p95": round(float(np.percentile(times, 95)) / K * 1e3, 4),
+                    "timed_seconds_total": round(float(np.sum(times)), 3),
+                    "ms_per_step_first_5": [round(x / K * 1e3, 4) for x in times[:5]]},
         "pcie_inclusive": pcie, "device_buckets_unfused": buckets,
         "frac_of_hbm_roofline_whole_step": round(total / elapsed * cfg["alg"] / (HBM_PEAK_GBS * 1e9 * world), 5),
         "newton_steps_per_s": round(total / elapsed * cfg["newton"], 1),  # corr-iterations x updates
@@ -438,13 +457,12 @@ def usable_cpus():
     return info
 
 
-def cpu_all_cores(scenes, inputs, n_obj, n_frames, use_depth, seconds=8.0):
+def cpu_all_cores(scenes, inputs, n_obj, n_frames, use_depth, seconds=8.0, native=False):
     """SURVEY 8(d) CPU baseline (ii): the batch (at most 64 objects) in ONE oracle context, stepped with an OpenMP
     `parallel for` over the objects at nproc threads (m3t_oracle_execute_tracking_step_parallel; what the
     reference's evaluators do over sequences, rbot_evaluator.cpp:144).  Also the evaluators' four time buckets
     (rbot_evaluator.cpp:354-414), summed over threads."""
-    import util
-    ora = util.open_oracle()
+    ora = open_oracle(native)
     f = ora.lib.m3t_oracle_execute_tracking_step_parallel
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -499,6 +517,7 @@ def extras_point(pkg):
     region + depth model of the triangle body (2 x 2562 views at 2000 x 2000) and of one tracking step of
     Region + Depth modality with region checking, silhouette checking and modelled occlusions behind the
     20 950-triangle bottle (4 focused renderers, refreshed before each of the 7 correspondence searches)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))  # (this extra leg runs on the reference's own test fixture)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import golden_scene as gs
     import util
@@ -550,11 +569,11 @@ def batch_point(pkg, scenes, base, n_obj, use_depth, cfg):
     hip = pkg.open_context(0)
     K, W = 6, 2
     n_frames = K + W + 1
-    rep = replicate(scenes, base, n_obj)
+    rep = scenes.replicate(base, n_obj)
     if n_obj > 4096:
         rep.camera_of = [i % base.n_objects for i in range(n_obj)]
     inst = scenes.Instance(hip, rep, use_depth=use_depth)
-    stage_frames(hip, inst, rep, n_frames)
+    scenes.stage_frames(hip, inst, rep, n_frames)
     hip.call("cameras_select_slot", 0)
     hip.call("start_modalities", 0)
     for k in range(1, 1 + W):

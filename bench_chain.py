@@ -84,10 +84,8 @@ def optimization_time_structures(api, host, n_bodies, n_structures):
     return host.Tracker(api, 1, 1)
 
 
-def run(args, pkg, rank, local_rank, world, dist, torch):
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import scenes
-    import util
+def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle):
+    scenes = pkg.batch
     syn, host = pkg.synthetic, pkg.host
     n_bodies, K, W = args.objects or 8, args.steps, args.warmup
     n_frames = K + W + 1
@@ -146,7 +144,7 @@ def run(args, pkg, rank, local_rank, world, dist, torch):
     # ---- CPU restatement of the same chain (all bodies in one process) + parity of the first timed trajectory ----
     cpu, parity = None, None
     if not args.no_cpu_baseline:
-        ora = util.open_oracle()
+        ora = open_oracle()
         oc = Chain(ora, host, syn, inputs, joints, start_root, start_angles, range(n_bodies))
         oc.upload(inputs, 0)
         assert oc.tracker.StartModalities(0)
@@ -179,7 +177,7 @@ def run(args, pkg, rank, local_rank, world, dist, torch):
             api.call("calculate_optimization", 0, 0, 0)
         api.call("sync")
         gpu_us = (time.perf_counter() - t) / reps * 1e6
-        ora = util.open_oracle()
+        ora = open_oracle()
         otr = optimization_time_structures(ora, host, nb, 1)
         assert otr.CalculateOptimization(0, 0, 0)
         t = time.perf_counter()

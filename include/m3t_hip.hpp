@@ -507,6 +507,11 @@ class Tracker {
   }
   // launch shape (m3t_hip.h: set_fused_step, get_step_shape)
   void SetFusedStep(int mode) { c_->Check(m3t_hip_set_fused_step(c_->get(), mode), "Tracker"); }
+  std::string StepKernel() const {  // name of the kernel the last ExecuteTrackingStep launched for the tracking loop
+    char name[64] = {0};
+    c_->Check(m3t_hip_get_step_kernel(c_->get(), name, sizeof(name)), "Tracker");
+    return name;
+  }
   std::array<int, 4> StepShape() const {
     std::array<int, 4> shape{};
     c_->Check(m3t_hip_get_step_shape(c_->get(), shape.data()), "Tracker");

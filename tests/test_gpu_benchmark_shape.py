@@ -9,7 +9,6 @@ import os
 import numpy as np
 import pytest
 
-import bench  # repo root: replicate() -- how bench.py spreads its 64 rendered streams over a larger batch
 import scenes
 import util
 from util import syn
@@ -140,15 +139,6 @@ def test_compact_kernel_region_and_depth():
         assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
 
 
-def subset(inputs, idx):
-    sub = scenes.Inputs.__new__(scenes.Inputs)
-    sub.__dict__.update(inputs.__dict__)
-    sub.n_objects = len(idx)
-    for name in ("scenes", "model_of", "gt", "color", "depth", "start", "vertices"):
-        sub.__dict__[name] = [inputs.__dict__[name][i] for i in idx]
-    return sub
-
-
 @pytest.mark.parametrize("env,kernel,shape", [
     ({}, "tracking_step_compact_kernel", [512, 1, 256, 1]),
     ({"M3T_HIP_COMPACT": "0"}, "tracking_step_lds_kernel", [512, 1, 512, 1])])
@@ -159,11 +149,11 @@ def test_synth512_batch_matches_the_oracle(env, kernel, shape):
     body2world after every frame and the histograms, bit for bit; and every object equals the other objects that look
     at the same stream (nothing leaks between the workgroups that share a CU)."""
     base = scenes.Inputs(64, 4, n_divides=4, n_models=16, with_depth=True)
-    inputs = bench.replicate(scenes, base, 512)
+    inputs = util.pkg.batch.replicate(base, 512)  # how bench.py spreads its 64 rendered streams over the batch
     got, hist, got_shape = hip_trajectory(inputs, use_depth=True, env=env, want_kernel=kernel)
     assert got_shape == shape
     sample = list(range(31)) + [511]
-    ref, ref_hist = oracle_trajectory(subset(inputs, sample), use_depth=True)
+    ref, ref_hist = oracle_trajectory(util.pkg.batch.subset(inputs, sample), use_depth=True)
     for k in range(inputs.n_frames):
         assert np.array_equal(got[k][sample], ref[k]), k
         for i in range(64, 512):

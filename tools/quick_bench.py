@@ -16,10 +16,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("3dobjecttracking_amd")
-import bench  # noqa: E402  (replicate, stage_frames)
-import scenes  # noqa: E402
+scenes = pkg.batch
 
 
 def main():
@@ -47,9 +45,9 @@ def main():
                     os.environ.pop(k, None)
                 os.environ.update(sets)
                 hip = pkg.CApi(lib, "m3t_hip_")
-                rep = bench.replicate(scenes, base, n)
+                rep = scenes.replicate(base, n)
                 inst = scenes.Instance(hip, rep, use_depth=a.ycb)
-                bench.stage_frames(hip, inst, rep, n_frames)
+                scenes.stage_frames(hip, inst, rep, n_frames)
                 hip.call("cameras_select_slot", 0)
                 hip.call("start_modalities", 0)
 

@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 pkg = importlib.import_module("3dobjecttracking_amd")
-import bench_chain, scenes
+import bench_chain
+scenes = pkg.batch
 lib = sys.argv[1]
 hip = pkg.CApi(lib, "m3t_hip_")
 f = hip.lib.m3t_hip_debug_phase_cycles
