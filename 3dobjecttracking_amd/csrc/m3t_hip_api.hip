@@ -3002,7 +3002,8 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       for (int p = M3T_SPLIT_MAX_PARTS; p >= 2; p >>= 1) {
         // 256-thread workgroups (developer override): two are resident per CU if their LDS fits twice
         const int per_cu = (threads == M3T_SPLIT_LANES && lds_split_for(p) * 2 <= size_t(160) * 1024) ? 2 : 1;
-        if (p > limit || n * p > ctx->prop.multiProcessorCount * per_cu) continue;
+        const int padded = (n + 7) / 8 * 8;  // grid blocks / p: every XCD gets the blocks of the fullest one
+        if (p > limit || padded * p > ctx->prop.multiProcessorCount * per_cu) continue;
         if ((elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;  // a part's elements fit its share of the lanes
         // the exchange needs every workgroup of the grid resident at once: ask the runtime how many of these
         // workgroups (registers, LDS) a CU takes, instead of assuming the LDS arithmetic above is the only limit
@@ -3013,7 +3014,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
           resident = 0;
         }
         if (resident > per_cu) resident = per_cu;  // (the query is known to over-report by one block for SGPR-heavy kernels)
-        if (resident < 1 || n * p > ctx->prop.multiProcessorCount * resident) continue;
+        if (resident < 1 || padded * p > ctx->prop.multiProcessorCount * resident) continue;
         parts = p;
         break;
       }
@@ -3063,6 +3064,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       sp.seq = ctx->split_seq;
       if (++ctx->split_launches == 0) ctx->split_launches = 1;  // (0 = the word's initial value)
       sp.abort_id = ctx->split_launches;
+      sp.n_objects = n;
       sp.n_parts = parts;
       sp.lshift = 0;
       while ((parts << sp.lshift) < M3T_SPLIT_LANES) ++sp.lshift;
@@ -3070,7 +3072,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       sp.per_part_points = (ctx->np_max + parts - 1) / parts;
       histogram_fused = want_fused_histogram;
       const size_t lds_split = lds_split_for(parts);
-      hipLaunchKernelGGL(tracking_step_split_kernel, dim3(n * parts), dim3(threads), lds_split, ctx->stream,
+      hipLaunchKernelGGL(tracking_step_split_kernel, dim3((n + 7) / 8 * 8 * parts), dim3(threads), lds_split, ctx->stream,
                          ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                          ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                          ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,

@@ -2853,6 +2853,7 @@ struct SplitParams {               // tracking_step_split_kernel: n_parts workgr
   unsigned* host_abort;            // mapped host word
   unsigned seq;                    // launch sequence number (restarts when the granule tags are cleared)
   unsigned abort_id;               // what an aborting workgroup writes to *host_abort: unique per launch, never reset
+  int n_objects;                   // objects of the launch (the grid is padded to a multiple of 8 x n_parts blocks)
   int n_parts, lshift;             // n_parts << lshift == 256
   int per_part_lines, per_part_points;
 };
@@ -2871,16 +2872,15 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   // XCD b % 8): a speed bonus, not a correctness condition.
   int object = blockIdx.x, part = 0, n_parts = 1;
   if constexpr (SPLIT) {
+    // All workgroups of an object on one XCD (block b runs on XCD b % 8: observed, a speed matter only), so that the
+    // object's image regions, model rows and histograms are fetched into ONE L2 and not into eight: XCD x hosts the
+    // objects x, x + 8, ...; its blocks b = x, x + 8, ... take them part after part.  The grid is padded to eight
+    // times the blocks of the fullest XCD (split->n_objects is the real count); surplus blocks leave at once.
     n_parts = split->n_parts;
-    const int b = blockIdx.x, n_objects = gridDim.x / n_parts;
-    if ((n_objects & 7) == 0) {
-      const int j = b >> 3;
-      object = (j / n_parts) * 8 + (b & 7);
-      part = j % n_parts;
-    } else {
-      object = b / n_parts;
-      part = b % n_parts;
-    }
+    const int b = blockIdx.x, j = b >> 3;
+    object = (j / n_parts) * 8 + (b & 7);
+    part = j % n_parts;
+    if (object >= split->n_objects) return;
   }
   COpt& o = *(COpt*)(opts + object);
   CRegion* rm = o.region_modality >= 0 ? (CRegion*)(rmods + o.region_modality) : nullptr;
