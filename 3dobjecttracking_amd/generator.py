@@ -48,17 +48,115 @@ class _LoaderCamera:
 
     def set_load_index(self, load_index):
         self.load_index = int(load_index)
+        self._drop_pipeline()
+
+    # ---- overlapped ingest (what replaces loader_camera.cpp:76-98's blocking imread + upload) ----
+    # Sequences are read in order, so while the tracker works on frame k a worker thread decodes frame k + 2 into a
+    # page-locked slab and the main thread has frame k + 1 crossing PCIe into the next slot of a three-slot device
+    # ring (m3t_hip_camera_upload_slot_async on the library's copy stream).  UpdateImage(k) then is a pointer switch.
+    # HIP contexts only; the arithmetic of the step never sees the difference (same pixels, same order).
+    _PIPELINE_SLOTS = 3
+
+    def enable_prefetch(self, enable=True):
+        """decode + upload ahead of UpdateImage (default for HIP contexts; switch off to get the blocking reference
+        behaviour, e.g. when frames are written while they are being tracked)"""
+        self._prefetch = bool(enable) and getattr(self.api, "is_hip", False)
+        self._drop_pipeline()
+
+    def _drop_pipeline(self):
+        for job in getattr(self, "_jobs", {}).values():
+            job["thread"].join()
+        if getattr(self, "_uploaded", None):
+            self.api.call("ingest_sync")  # the slabs must not be reused while a copy reads them
+        self._jobs, self._uploaded = {}, {}
+
+    def _slab(self, slot):
+        if not hasattr(self, "_slabs"):
+            import ctypes as C
+            shape = (self.height, self.width, 3) if self.bpp == 3 else (self.height, self.width)
+            self._slabs = [np.zeros(shape, np.uint8 if self.bpp == 3 else np.uint16)
+                           for _ in range(self._PIPELINE_SLOTS)]
+            for a in self._slabs:
+                self.api.call("host_register", a.ctypes.data_as(C.c_void_p), a.nbytes)
+            self.set_ring(self._PIPELINE_SLOTS)
+        return self._slabs[slot]
+
+    def _start_decode(self, index):
+        """worker thread: image `index` into its slab (no device call: the C-ABI belongs to the main thread)"""
+        import threading
+        if index in self._jobs or index in self._uploaded:
+            return
+        slab = self._slab(index % self._PIPELINE_SLOTS)
+        saved, self.load_index = self.load_index, index
+        path = self.image_path()
+        self.load_index = saved
+        job = {"ok": False, "path": path, "error": None}
+
+        def work():
+            try:
+                np.copyto(slab, self._decode(path))
+                job["ok"] = True
+            except (OSError, ValueError) as e:
+                job["error"] = e
+
+        job["thread"] = threading.Thread(target=work, daemon=True)
+        job["thread"].start()
+        self._jobs[index] = job
+
+    def _upload_when_decoded(self, index, wait):
+        """main thread: hand a decoded slab to the copy stream; returns False if it is not there (yet)"""
+        if index in self._uploaded:
+            return True
+        job = self._jobs.get(index)
+        if job is None:
+            return False
+        if not wait and job["thread"].is_alive():
+            return False
+        job["thread"].join()
+        del self._jobs[index]
+        if not job["ok"]:
+            self._failed = (job["path"], job["error"])
+            return False
+        slot = index % self._PIPELINE_SLOTS
+        self.upload_slot(slot, self._slabs[slot], asynchronous=True)
+        self._uploaded[index] = slot
+        return True
 
     def UpdateImage(self, synchronized=True):
-        path = self.image_path()
-        try:
-            image = self._decode(path)
-        except (OSError, ValueError) as e:
+        if getattr(self, "_prefetch", None) is None:
+            self.enable_prefetch(True)
+        if not self._prefetch:
+            path = self.image_path()
+            try:
+                image = self._decode(path)
+            except (OSError, ValueError) as e:
+                sys.stderr.write("Could not read image from %s (%s)\n" % (path, e))
+                return False
+            self.image = image
+            self.load_index += 1
+            return super().UpdateImage(image)
+        k = self.load_index
+        self._failed = None
+        self._start_decode(k)  # (already running or done unless this is the first frame / the index was set)
+        if not self._upload_when_decoded(k, wait=True):
+            path, e = self._failed or (self.image_path(), "not decoded")
             sys.stderr.write("Could not read image from %s (%s)\n" % (path, e))
+            self._drop_pipeline()
             return False
-        self.image = image
+        slot = self._uploaded.pop(k)
+        # every copy issued so far has left its slab (frame k's was started one step ago): the slab of frame k - 1,
+        # which frame k + 2 is about to be decoded into, is free
+        self.api.call("ingest_sync")
+        self.image = self._slabs[slot]
+        self.select_slot(slot)  # the step that follows waits for this slot's copy, and only for it
         self.load_index += 1
-        return super().UpdateImage(image)
+        # frame k + 1: decoded while the previous step ran -> its copy overlaps the coming step; frame k + 2: decode now
+        self._start_decode(k + 1)
+        self._upload_when_decoded(k + 1, wait=False)
+        # (slot (k + 2) % 3 is free: frame k - 1 was read by a step the main thread has already enqueued; the library
+        # orders an asynchronous upload behind the last step that read its slot)
+        self._start_decode(k + 2)
+        return True
 
 
 def _loader_meta(path):

@@ -20,6 +20,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -34,6 +36,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -621,6 +624,134 @@ inline LoaderSettings Loader(const Node& d, const std::string& path) {
 }
 }  // namespace detail
 
+// Overlapped ingest for loader cameras (replaces the blocking imread + upload of
+// loader_camera.cpp:76-98).  Sequences are read in order: while frame k is tracked, a worker thread decodes frame
+// k + 2 into a page-locked slab and frame k + 1 crosses PCIe on the library's copy stream into the next slot of a
+// three-slot device ring; UpdateImage(k) is then a pointer switch.  The worker never touches the C-ABI (a context
+// belongs to one host thread).  Where the asynchronous entry points do not exist (a host linked against the CPU
+// restatement) the camera falls back to the blocking path: same pixels, same order, same results.
+class FramePipeline {
+ public:
+  static constexpr int kSlots = 3;
+  using Check = std::function<std::string(const Image&)>;  // "" or why the image does not fit the camera
+  ~FramePipeline() { Drop(nullptr); }
+  bool enabled = true;
+  // returns false (and leaves `enabled` false) when the library has no asynchronous ingest
+  bool Prepare(m3t_hip_context* ctx, int camera_id, size_t frame_bytes) {
+    if (!enabled || ready_) return enabled;
+    for (auto& slab : slabs_) slab.assign(frame_bytes, 0);
+    if (m3t_hip_camera_set_ring(ctx, camera_id, kSlots) < 0) { enabled = false; return false; }
+    for (auto& slab : slabs_)
+      if (m3t_hip_host_register(ctx, slab.data(), slab.size()) < 0) { enabled = false; return false; }
+    ready_ = true;
+    return true;
+  }
+  void Drop(m3t_hip_context* ctx) {
+    for (auto& j : jobs_) if (j.second.thread.joinable()) j.second.thread.join();
+    jobs_.clear();
+    if (ctx && !uploaded_.empty()) (void)m3t_hip_ingest_sync(ctx);
+    uploaded_.clear();
+  }
+  void StartDecode(int index, const std::string& path, const Check& check) {
+    if (jobs_.count(index) || uploaded_.count(index)) return;
+    Job& job = jobs_[index];
+    job.path = path;
+    std::vector<uint8_t>* slab = &slabs_[size_t(index % kSlots)];
+    Job* j = &job;  // (std::map nodes do not move)
+    job.thread = std::thread([j, slab, path, check]() {
+      try {
+        Image image = DecodePng(path);
+        j->error = check(image);
+        if (j->error.empty() && image.pixels.size() == slab->size()) {
+          std::memcpy(slab->data(), image.pixels.data(), slab->size());
+          j->width = image.width; j->height = image.height; j->channels = image.channels;
+          j->bytes_per_channel = image.bytes_per_channel;
+          j->ok = true;
+        } else if (j->error.empty()) {
+          j->error = "Could not read image from " + path + " (unexpected size)";
+        }
+      } catch (const std::exception& e) {
+        j->error = e.what();
+      }
+      j->finished.store(true);
+    });
+  }
+  // main thread: hand a decoded slab to the copy stream; false if it is not there (yet) or could not be decoded
+  bool UploadWhenDecoded(m3t_hip_context* ctx, int camera_id, int index, bool wait, size_t row_step, std::string* error) {
+    if (uploaded_.count(index)) return true;
+    auto it = jobs_.find(index);
+    if (it == jobs_.end()) return false;
+    if (!wait && !it->second.done()) return false;
+    it->second.thread.join();
+    const bool ok = it->second.ok;
+    if (!ok && error) *error = it->second.error;
+    jobs_.erase(it);
+    if (!ok) return false;
+    const int slot = index % kSlots;
+    if (m3t_hip_camera_upload_slot_async(ctx, camera_id, slot, slabs_[size_t(slot)].data(), row_step) < 0) {
+      if (error) *error = m3t_hip_last_error(ctx);
+      return false;
+    }
+    uploaded_[index] = slot;
+    return true;
+  }
+  int TakeUploaded(int index) {
+    const int slot = uploaded_.at(index);
+    uploaded_.erase(index);
+    return slot;
+  }
+  const std::vector<uint8_t>& slab(int slot) const { return slabs_[size_t(slot)]; }
+  // One UpdateImage of a loader camera through the pipeline: frame `settings.load_index` becomes the camera's
+  // current frame (and `image`), the next two are on their way.  false + message when the frame cannot be read.
+  bool Update(m3t_hip_context* ctx, int camera_id, LoaderSettings* settings, const Check& check, size_t row_step,
+              Image* image, int width, int height, int channels, int bytes_per_channel) {
+    if (settings->load_index != expected_) Drop(ctx);  // the index was set from outside: start over
+    const int k = settings->load_index;
+    auto path_of = [&](int index) {
+      LoaderSettings t = *settings;
+      t.load_index = index;
+      return t.ImagePath();
+    };
+    StartDecode(k, path_of(k), check);
+    std::string error;
+    if (!UploadWhenDecoded(ctx, camera_id, k, true, row_step, &error)) {
+      std::cerr << error << std::endl;
+      Drop(ctx);
+      expected_ = -1;
+      return false;
+    }
+    const int slot = TakeUploaded(k);
+    // every copy issued so far has left its slab: the slab frame k + 2 is decoded into (frame k - 1's) is free
+    if (m3t_hip_ingest_sync(ctx) < 0 || m3t_hip_camera_select_slot(ctx, camera_id, slot) < 0) {
+      std::cerr << m3t_hip_last_error(ctx) << std::endl;
+      return false;
+    }
+    image->width = width; image->height = height; image->channels = channels; image->bytes_per_channel = bytes_per_channel;
+    image->pixels = slab(slot);
+    settings->load_index++;
+    expected_ = settings->load_index;
+    StartDecode(k + 1, path_of(k + 1), check);
+    (void)UploadWhenDecoded(ctx, camera_id, k + 1, false, row_step, nullptr);
+    StartDecode(k + 2, path_of(k + 2), check);
+    return true;
+  }
+
+ private:
+  int expected_ = -1;
+  struct Job {
+    std::thread thread;
+    std::string path, error;
+    bool ok = false;
+    int width = 0, height = 0, channels = 0, bytes_per_channel = 0;
+    bool done() const { return finished.load(); }
+    std::atomic<bool> finished{false};
+  };
+  std::map<int, Job> jobs_;
+  std::map<int, int> uploaded_;
+  std::array<std::vector<uint8_t>, kSlots> slabs_;
+  bool ready_ = false;
+};
+
 class LoaderColorCamera : public ColorCamera {
  public:
   LoaderColorCamera(ContextPtr c, const LoaderSettings& loader_settings, const m3t_intrinsics& intrinsics,
@@ -635,7 +766,16 @@ class LoaderColorCamera : public ColorCamera {
                                                detail::Intrinsics(d["intrinsics"], path),
                                                d.has("camera2world_pose") ? d["camera2world_pose"].pose() : IdentityPose());
   }
+  FramePipeline pipeline;  // pipeline.enabled = false: the blocking reference behaviour
   bool UpdateImage() {  // LoaderColorCamera::UpdateImage loader_camera.cpp:76-98
+    const size_t frame_bytes = size_t(intrinsics_.width) * size_t(intrinsics_.height) * 3;
+    if (pipeline.enabled && pipeline.Prepare(c_->get(), id_, frame_bytes)) {
+      const m3t_intrinsics in = intrinsics_;
+      return pipeline.Update(c_->get(), id_, &settings, [in](const Image& im) {
+        return (im.channels != 3 || im.width != in.width || im.height != in.height)
+                   ? std::string("Could not read image (not a colour image of the camera's size)") : std::string();
+      }, size_t(intrinsics_.width) * 3, &image, intrinsics_.width, intrinsics_.height, 3, 1);
+    }
     const std::string path = settings.ImagePath();
     try {
       image = DecodePng(path);
@@ -672,7 +812,16 @@ class LoaderDepthCamera : public DepthCamera {
                                                detail::Intrinsics(d["intrinsics"], path), float(d["depth_scale"].number()),
                                                d.has("camera2world_pose") ? d["camera2world_pose"].pose() : IdentityPose());
   }
+  FramePipeline pipeline;
   bool UpdateImage() {
+    const size_t frame_bytes = size_t(intrinsics_.width) * size_t(intrinsics_.height) * 2;
+    if (pipeline.enabled && pipeline.Prepare(c_->get(), id_, frame_bytes)) {
+      const m3t_intrinsics in = intrinsics_;
+      return pipeline.Update(c_->get(), id_, &settings, [in](const Image& im) {
+        return (im.channels != 1 || im.bytes_per_channel != 2 || im.width != in.width || im.height != in.height)
+                   ? std::string("Could not read image (not a 16-bit depth image of the camera's size)") : std::string();
+      }, size_t(intrinsics_.width) * 2, &image, intrinsics_.width, intrinsics_.height, 1, 2);
+    }
     const std::string path = settings.ImagePath();
     try {
       image = DecodePng(path);

@@ -50,3 +50,47 @@ def test_tracker_process_over_the_fixture_sequence(tmp_path):
     golden = util.read_golden_matrix("tracker_test/triangle_pose.txt")  # the pose after the first step
     pose = tracker.body_ptrs()[0].body2world_pose()
     assert np.linalg.norm(pose[:3, 3] - golden[:3, 3]) < 5e-3
+
+
+def test_loader_camera_overlapped_ingest(tmp_path):
+    """LoaderColorCamera with the decode / upload pipeline (frame k + 2 decoded on a worker thread into a page-locked
+    slab, frame k + 1 crossing PCIe on the copy stream while frame k is tracked; loader_camera.cpp:76-98 is the
+    blocking step it replaces) against the blocking loader: the same poses after every frame, bit for bit, and
+    UpdateImage fails the same way where the sequence ends"""
+    from PIL import Image
+    import scenes
+    from util import host, syn
+    n_frames = 9
+    inputs = scenes.Inputs(1, n_frames, n_divides=2)
+    for k in range(n_frames):
+        Image.fromarray(np.ascontiguousarray(inputs.color[0][k][:, :, ::-1])).save(str(tmp_path / ("color_%04d.png" % k)))
+    intr = inputs.intr
+    results = {}
+    for prefetch in (False, True):
+        api = util.open_hip()
+        cam = util.pkg.generator.LoaderColorCamera(
+            api, str(tmp_path), (intr["fu"], intr["fv"], intr["ppu"], intr["ppv"], intr["width"], intr["height"]),
+            "color_", 0, 4, "")
+        cam.enable_prefetch(prefetch)
+        body = host.Body(api, inputs.start[0])
+        m = inputs.region_models[0]
+        model = host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
+        region = host.RegionModality(api, body, cam, model, **dict(syn.RBOT_REGION_PARAMS, measure_occlusions=0))
+        host.Optimizer(api, body=body, modalities=[region], tikhonov_parameter_rotation=1000.0,
+                       tikhonov_parameter_translation=30000.0)
+        tracker = host.Tracker(api, 7, 2)
+        assert cam.UpdateImage(True)
+        assert tracker.StartModalities(0)
+        cam.set_load_index(0)
+        poses = []
+        for k in range(n_frames):
+            assert cam.UpdateImage(True)
+            assert np.array_equal(cam.image, inputs.color[0][k])
+            assert tracker.ExecuteTrackingStep(k)
+            poses.append(body.body2world_pose())
+        assert not cam.UpdateImage(True)  # frame 9 does not exist
+        results[prefetch] = poses
+    for a, b in zip(results[False], results[True]):
+        assert np.array_equal(a, b)
+    e = syn.pose_errors(results[True][-1], inputs.gt[0][-1])
+    assert e[0] < np.deg2rad(5) and e[1] < 0.05
