@@ -203,6 +203,7 @@ struct m3t_hip_context {
   size_t pose_capacity = 0;
   std::vector<RigidOptDev> opt_table;
   bool fused_possible = false;
+  bool fused_per_search_possible = false;  // ... if it were not for renderer-fed branches: one launch per correspondence search
   bool fuse_histogram_possible = false;  // ... and the histogram update can ride in the same launch
   // several workgroups per object (tracking_step_split_kernel) for batches that leave most CUs idle
   bool split_possible = false;
@@ -1033,6 +1034,7 @@ int UploadTables(Ctx* ctx) {
     for (auto& o : ctx->optimizers) attached += ctx->links[o.link].modalities.size();
     if (attached != ctx->modalities.size()) ctx->fused_possible = false;
     // renderer-fed branches read other bodies' poses between the sub-steps: one launch per sub-step
+    ctx->fused_per_search_possible = ctx->fused_possible && ctx->n_render_all > 0;
     if (ctx->n_render_all > 0) ctx->fused_possible = false;
     // the histogram update can ride in the tracking launch when every region modality sits alone on its
     // optimizer, owns its histograms, and the count table fits the LDS
@@ -3082,12 +3084,36 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
                        ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                        ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                        ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
-                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0);
+                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, 0);
     HIPCHK(hipGetLastError());
     ctx->last_step_shape[0] = n;
     ctx->last_step_shape[1] = split ? parts : 1;
     ctx->last_step_shape[2] = threads;
     ctx->last_step_shape[3] = histogram_fused ? 1 : 0;
+    ctx->state_valid = ctx->fused_mode == 2;
+  } else if (ctx->fused_mode >= 1 && ctx->fused_per_search_possible && !ctx->comm && !ctx->tree_mode &&
+             !std::getenv("M3T_HIP_NO_SEARCH_FUSION")) {
+    // Renderer-fed branches (modelled occlusions, region / silhouette checking): the focused renderings are redrawn
+    // before every correspondence search from the bodies' current poses (correspondence_renderer_ptrs,
+    // tracker.cpp:447-452), so the loop nest runs one search per launch -- the renderers, then ONE launch for the
+    // search and its Newton steps of all objects -- instead of one launch per sub-step: 4 instead of 11 per search.
+    ScopedKernelTimer timer(ctx, 0);
+    const int n = int(ctx->opt_table.size());
+    auto kernel = ctx->layout.off_hist >= 0 ? tracking_step_lds_kernel : tracking_step_kernel;
+    for (int c = 0; c < ctx->n_corr_iterations; ++c) {
+      if ((r = RenderForModalities(ctx, false))) return r;
+      hipLaunchKernelGGL(kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
+                         ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                         ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->layout,
+                         ctx->off_points, ctx->np_max, iteration, 1, ctx->n_update_iterations,
+                         ctx->fused_mode == 2 ? 1 : 0, 0, c);
+    }
+    HIPCHK(hipGetLastError());
+    ctx->last_step_kernel = ctx->layout.off_hist >= 0 ? "tracking_step_lds_kernel" : "tracking_step_kernel";
+    ctx->last_step_shape[0] = n;
+    ctx->last_step_shape[1] = 1;
+    ctx->last_step_shape[2] = M3T_BLOCK_THREADS;
+    ctx->last_step_shape[3] = 0;
     ctx->state_valid = ctx->fused_mode == 2;
   } else if (TreeStepFused(ctx)) {
     // kinematic structures: the whole loop nest in one launch, one workgroup per link that carries modalities

@@ -2863,7 +2863,7 @@ template <bool HIST_LDS, bool SPLIT = false>
 __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int fuse_histogram, const SplitParams* split = nullptr) {
+                     int fuse_histogram, const SplitParams* split = nullptr, int first_corr_iteration = 0) {
   extern __shared__ __attribute__((aligned(16))) float lds_t[];
   // SPLIT: n_parts workgroups share one object.  Each runs the whole step, but walks the pixels (and scans the depth
   // windows) of its own part of the lines (points) only; the line results are exchanged once per correspondence
@@ -2922,7 +2922,9 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     exchange.n_depth_fields = write_state ? PS_VALID + 1 - PS_CENTER_U : PS_VALID + 1 - PS_CORR_X;
     exchange.first_depth_row = write_state ? PS_CENTER_U : PS_CORR_X;
   }
-  for (int c = 0; c < n_corr_iterations; ++c) {
+  // (first_corr_iteration > 0: a host that refreshes renderer-fed inputs between the correspondence searches
+  // launches the loop one search at a time)
+  for (int c = first_corr_iteration; c < first_corr_iteration + n_corr_iterations; ++c) {
     {
       const Affine b2w = load_pose(pose);
       int region_view = -1;
@@ -3053,17 +3055,17 @@ __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int fuse_histogram) {
+                     int fuse_histogram, int first_corr_iteration) {
   tracking_step_body<false>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
-                            n_update_iterations, write_state, fuse_histogram);
+                            n_update_iterations, write_state, fuse_histogram, nullptr, first_corr_iteration);
 }
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_lds_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int fuse_histogram) {
+                     int fuse_histogram, int first_corr_iteration) {
   tracking_step_body<true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, n_corr_iterations,
-                            n_update_iterations, write_state, fuse_histogram);
+                            n_update_iterations, write_state, fuse_histogram, nullptr, first_corr_iteration);
 }
 // several workgroups per object: for batches that leave most CUs idle
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)

@@ -494,22 +494,22 @@ def cpu_all_cores(scenes, inputs, n_obj, n_frames, use_depth, seconds=8.0, nativ
 
 
 def measured_traffic(config, kernel, n_obj, fused_histogram=False):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/rNN_hbm_traffic*.json: FETCH_SIZE and WRITE_SIZE in separate runs of this same
-    command, read side doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).  The counters
-    cannot be collected from inside this process; null when no profile for this configuration exists."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_hbm_traffic_*.json:
+    FETCH_SIZE and WRITE_SIZE in separate runs of this same command, read side doubled as MI355X_MICROARCH.md §HBM
+    prescribes for gfx950).  The counters cannot be collected from inside this process; null when no profile of this
+    configuration, batch size, kernel and launch structure exists."""
     import glob
-    suffix = "" if config == "rbot64" else "_" + config
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic%s.json" % suffix)))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        if d.get("objects_per_launch") != n_obj or bool(d.get("histogram_update_fused", False)) != fused_histogram:
-            return None, None
-        return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("config", "rbot64") != config or d.get("objects_per_launch") != n_obj:
+                continue
+            if bool(d.get("histogram_update_fused", False)) != fused_histogram or kernel not in d["kernels"]:
+                continue
+            return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def extras_point(pkg):

@@ -53,8 +53,12 @@ def test_tracking_step_with_all_branches_matches_oracle():
     """Region + Depth modality with region checking, silhouette checking and modelled occlusions
     through a whole tracking step (renderings refreshed before every correspondence search and
     for the histogram update); reference summation order -> bit-identical poses and states"""
+    import ctypes as C
     res = []
-    for api in (util.open_hip(), util.open_oracle()):
+    hip_fused, hip_substep = util.open_hip(), util.open_hip()
+    hip_fused.call("set_fused_step", 2)    # one launch per correspondence search (+ the renderers), state written back
+    hip_substep.call("set_fused_step", 0)  # one launch per sub-step
+    for api in (hip_fused, hip_substep, util.open_oracle()):
         f, schauma, r = _scene(api, 200)
         f.region.ModelOcclusions(r["color_depth"])
         f.region.UseRegionChecking(r["color_sil"])
@@ -65,7 +69,13 @@ def test_tracking_step_with_all_branches_matches_oracle():
         lines = f.region.data_lines()
         points = f.depth.data_points()
         res.append((f.body.body2world_pose(), lines["valid"].copy(), points["valid"].copy(), f.region.histograms()))
-    (pa, la, qa, ha), (pb, lb, qb, hb) = res
+        if api is hip_fused:
+            name = C.create_string_buffer(64)
+            api.call("get_step_kernel", name, 64)
+            assert name.value.decode() in ("tracking_step_kernel", "tracking_step_lds_kernel")
+    (pa, la, qa, ha), (pc, lc, qc, hc), (pb, lb, qb, hb) = res
+    assert np.array_equal(lc, lb) and np.array_equal(qc, qb) and np.array_equal(pc, pb)
+    assert np.array_equal(hc[0], hb[0]) and np.array_equal(hc[1], hb[1])
     assert np.array_equal(la, lb) and np.array_equal(qa, qb)
     assert 0 < la.sum() < 179 and 0 < qa.sum() < 182  # the branches removed something
     assert np.array_equal(pa, pb)

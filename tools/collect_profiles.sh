@@ -1,24 +1,78 @@
 #!/bin/bash
-# Round profile set (outputs under gpurun_out/r02/; the ones to be judged are copied to profiles/r02_* by hand):
-# GPU test log, the bench lines of all four configurations, the batch sweep, rocprofv3 kernel stats of the default
-# bench command, the per-phase cycle breakdown of the developer build, the PMC passes (tools/collect_pmc.sh).
+# Round profile set, one script, one commit (outputs under gpurun_out/$ROUND/; tools/publish_profiles.py copies the
+# ones to be judged to profiles/${ROUND}_*):
+#   * GPU test log
+#   * the bench line of every configuration (bench.py --config ...), the large-batch line (4096 objects) and a sweep
+#   * rocprofv3 --kernel-trace --stats of every configuration's bench command
+#   * PMC passes (SQ x 2, TA, TCC, FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md -- 8 SQ / 4 TCC slots per pass, the two
+#     size counters in passes of their own, never together with the hip / hsa trace domains) of the same commands
+#   * per-phase cycles of the developer build (tools/phase_timing.py)
+# usage: tools/collect_profiles.sh [what ...]   what = tests bench stats pmc phases sweep (default: all)
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$REPO/gpurun_out/r02
+ROUND=${ROUND:-r03}
+OUT=$REPO/gpurun_out/$ROUND
+WHAT=${@:-tests bench stats pmc phases sweep}
+CONFIGS=${CONFIGS:-rbot64 rbot4096 ycb21 synth512 chain8}
 mkdir -p "$OUT"
 cd "$REPO"
-(nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; rocm-smi --showproductname 2>/dev/null | head -12) > "$OUT/host.log" 2>&1
-(cd tests && timeout 1500 python -m pytest -m gpu -q --timeout=900 2>&1 | grep -vE "^(RCCL|HIP|ROCm|Hostname|Librccl)" | tail -8) > "$OUT/gpu_tests.log" 2>&1
-(timeout 600 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err")
-(timeout 600 python bench.py --config ycb21 > "$OUT/bench_ycb21.json" 2> "$OUT/bench_ycb21.err")
-(timeout 900 python bench.py --config synth512 --steps 10 --warmup 3 > "$OUT/bench_synth512.json" 2> "$OUT/bench_synth512.err")
-(timeout 600 python bench.py --config chain8 > "$OUT/bench_chain8.json" 2> "$OUT/bench_chain8.err")
-(timeout 1200 python bench.py --no-pcie --no-cpu-baseline --sweep 1,8,32,256,512,1024,4096 --extras > "$OUT/bench_sweep.json" 2> "$OUT/bench_sweep.err")
-for v in "rbot64:64:" "ycb21:21:ycb"; do
-  IFS=: read name n ycb <<< "$v"
-  (timeout 300 python tools/phase_timing.py tools/libm3t_hip_timing.so $n $ycb 2>&1 | tail -34) > "$OUT/phase_timing_$name.txt" 2>&1
-done
-(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python "$REPO/bench.py" --no-cpu-baseline --no-pcie > "$OUT/prof.log" 2>&1)
-cp "$OUT"/prof/*/*kernel_stats.csv "$OUT/bench_kernel_stats.csv" 2>/dev/null
-bash tools/collect_pmc.sh rbot64 > "$OUT/pmc_rbot64.log" 2>&1
-bash tools/collect_pmc.sh ycb21 > "$OUT/pmc_ycb21.log" 2>&1
-tail -2 "$OUT/gpu_tests.log"; for f in default ycb21 synth512 chain8; do head -c 300 "$OUT/bench_$f.json"; echo; done; head -5 "$OUT/bench_kernel_stats.csv"; tail -25 "$OUT/pmc_rbot64.log"
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+args_of() {  # bench.py arguments of a profile configuration
+  case $1 in
+    rbot4096) echo "--config rbot64 --objects 4096" ;;
+    *) echo "--config $1" ;;
+  esac
+}
+(nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; rocm-smi --showproductname 2>/dev/null | head -12; git -C "$REPO" rev-parse HEAD 2>/dev/null) > "$OUT/host.log" 2>&1
+
+if has tests; then
+  (cd tests && timeout 1500 python -m pytest -m gpu -q --timeout=900 2>&1 | grep -vE "^(RCCL|HIP|ROCm|Hostname|Librccl)" | tail -8) > "$OUT/gpu_tests.log" 2>&1
+  tail -2 "$OUT/gpu_tests.log"
+fi
+if has bench; then
+  for c in $CONFIGS; do
+    extra=""
+    [ "$c" = rbot4096 ] && extra="--no-pcie --cpu-seconds 4 --no-cpu-parallel"
+    (timeout 900 python bench.py $(args_of $c) $extra > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err")
+    head -c 400 "$OUT/bench_$c.json"; echo
+  done
+fi
+if has sweep; then
+  (timeout 1200 python bench.py --no-pcie --no-cpu-baseline --repeats 3 --sweep 1,8,32,256,512,1024,4096 > "$OUT/bench_sweep.json" 2> "$OUT/bench_sweep.err")
+  python - "$OUT/bench_sweep.json" <<'PY'
+import json, sys
+for s in json.load(open(sys.argv[1])).get("batch_sweep", []):
+    print(s["objects"], s["pose_updates_per_s"], s["frac_of_hbm_roofline"], s.get("kernel"))
+PY
+fi
+PROF="--steps 10 --warmup 2 --no-cpu-baseline --no-pcie --repeats 1"
+if has stats; then
+  for c in $CONFIGS; do
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$c" -- python "$REPO/bench.py" $(args_of $c) $PROF > "$OUT/stats_$c.log" 2>&1)
+    cp "$OUT"/stats_$c/*/*kernel_stats.csv "$OUT/kernel_stats_$c.csv" 2>/dev/null
+    head -4 "$OUT/kernel_stats_$c.csv"
+  done
+fi
+if has pmc; then
+  declare -A PASS
+  PASS[sq1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
+  PASS[sq2]="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LEVEL_WAVES GRBM_GUI_ACTIVE"
+  PASS[ta]="TA_TA_BUSY_sum TA_BUSY_avr TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum"
+  PASS[tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+  PASS[fetch]="FETCH_SIZE"
+  PASS[write]="WRITE_SIZE"
+  for c in ${PMC_CONFIGS:-rbot64 rbot4096 ycb21 synth512}; do
+    mkdir -p "$OUT/pmc_$c"
+    for p in sq1 sq2 ta tcc fetch write; do
+      (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --pmc ${PASS[$p]} --output-format csv -d "$OUT/pmc_$c/$p" -- python "$REPO/bench.py" $(args_of $c) $PROF > "$OUT/pmc_$c/$p.log" 2>&1)
+    done
+    python tools/pmc_summary3.py "$OUT/pmc_$c" "$OUT/pmc_$c.json" "$c" "bench.py $(args_of $c) $PROF" | tail -24
+  done
+fi
+if has phases; then
+  for v in "rbot64:64:" "ycb21:21:ycb"; do
+    IFS=: read name n ycb <<< "$v"
+    (timeout 300 python tools/phase_timing.py tools/libm3t_hip_timing.so $n $ycb 2>&1 | tail -34) > "$OUT/phase_timing_$name.txt" 2>&1
+  done
+  (timeout 300 python tools/tree_timing.py tools/libm3t_hip_timing.so 2>&1 | grep -v amdgpu) > "$OUT/phase_timing_chain8.txt" 2>&1
+  head -12 "$OUT/phase_timing_rbot64.txt"
+fi

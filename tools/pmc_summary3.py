@@ -1,0 +1,100 @@
+"""Per-launch means of the PMC passes of tools/collect_profiles.sh for every kernel of the timed batch, the ratios the
+counters were collected for, and the HBM traffic block bench.py quotes (profiles/rNN_hbm_traffic_<profile>.json).
+SQ_* cycle counters are per-SE sums of quad-cycles as rocprofv3 reports them; GRBM_GUI_ACTIVE comes out once per XCD
+(summed here, divided by 8 below); FETCH_SIZE / WRITE_SIZE are in KB, the read side is doubled per
+MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request of a wide stream: an upper estimate for scattered gathers).
+
+  python tools/pmc_summary3.py <dir with one sub-directory per pass> <out.json> <profile name> "<command>"
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+OBJECTS = {"rbot64": 64, "rbot4096": 4096, "ycb21": 21, "synth512": 512}
+CONFIG = {"rbot64": "rbot64", "rbot4096": "rbot64", "ycb21": "ycb21", "synth512": "synth512"}
+
+
+def per_kernel(folder):
+    per = {}
+    for path in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            name = row["Kernel_Name"].split("(")[0].split("::")[-1]
+            if not (name.startswith("tracking_step") or name == "region_histogram_kernel"):
+                continue
+            key = (name, int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1), int(row["Workgroup_Size"]),
+                   int(row.get("VGPR_Count", 0) or 0) + int(row.get("Accum_VGPR_Count", 0) or 0),
+                   int(row.get("LDS_Block_Size", 0) or 0), int(row.get("Scratch_Size", 0) or 0))
+            d = per.setdefault(key, {}).setdefault(row["Counter_Name"], {})
+            d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+    out = {}
+    for key, counters in per.items():
+        n = max(len(v) for v in counters.values())
+        if n < 5:  # the timed batch, not one-off set-up launches
+            continue
+        out[key] = {c: sum(v.values()) / len(v) for c, v in counters.items()}
+        out[key]["_launches"] = n
+    return out
+
+
+def ratios_of(m):
+    g = m.get
+    r = {}
+    if g("SQ_WAVE_CYCLES"):
+        r["wave_cycles_parked_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES)"] = g("SQ_WAIT_ANY", 0) / g("SQ_WAVE_CYCLES")
+        r["wave_cycles_issue_stall_frac (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)"] = g("SQ_WAIT_INST_ANY", 0) / g("SQ_WAVE_CYCLES")
+        r["wave_cycles_issuing_frac (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)"] = g("SQ_ACTIVE_INST_ANY", 0) / g("SQ_WAVE_CYCLES")
+    gui = g("GRBM_GUI_ACTIVE", 0) / 8.0
+    if gui:
+        r["kernel_cycles (GRBM_GUI_ACTIVE / 8 XCDs)"] = gui
+    if g("SQ_ACTIVE_INST_VALU") and gui:
+        r["valu_busy_pct (100 x SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / kernel cycles)"] = \
+            100.0 * g("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / gui
+    if g("SQ_WAVE_CYCLES") and gui:
+        r["mean_resident_waves_per_cu (SQ_WAVE_CYCLES x 4 / kernel cycles / 256)"] = g("SQ_WAVE_CYCLES") * 4.0 / gui / 256.0
+    if g("SQ_WAVES") and g("SQ_INSTS_VALU") is not None:
+        r["valu_instructions_per_wave"] = g("SQ_INSTS_VALU") / g("SQ_WAVES")
+    if g("SQ_LDS_IDX_ACTIVE"):
+        r["lds_bank_conflict_frac (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)"] = g("SQ_LDS_BANK_CONFLICT", 0) / g("SQ_LDS_IDX_ACTIVE")
+    if g("TCC_HIT_sum") is not None and (g("TCC_HIT_sum", 0) + g("TCC_MISS_sum", 0)):
+        r["l2_hit_frac (TCC_HIT / (TCC_HIT + TCC_MISS))"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    if g("TA_TA_BUSY_sum") and gui:
+        r["ta_busy_frac_per_cu (TA_TA_BUSY_sum / (256 x kernel cycles))"] = g("TA_TA_BUSY_sum") / (256.0 * gui)
+    if g("TCP_TOTAL_CACHE_ACCESSES_sum") and gui:
+        r["l1_accesses_per_cycle_per_cu"] = g("TCP_TOTAL_CACHE_ACCESSES_sum") / (256.0 * gui)
+    if g("TCP_PENDING_STALL_CYCLES_sum") and gui:
+        r["l1_pending_stall_frac_per_cu"] = g("TCP_PENDING_STALL_CYCLES_sum") / (256.0 * gui)
+    return r
+
+
+def main(out_dir, target, profile, command):
+    kernels = {}
+    for p in ("sq1", "sq2", "ta", "tcc", "fetch", "write"):
+        for key, c in per_kernel(os.path.join(out_dir, p)).items():
+            k = kernels.setdefault(key[0], {"workgroups": key[1], "threads": key[2], "vgprs": key[3],
+                                            "lds_bytes": key[4], "scratch_bytes": key[5], "per_launch_means": {}})
+            k["per_launch_means"].update({n: v for n, v in c.items()})
+    traffic = {"command": command, "profile": profile, "config": CONFIG.get(profile, profile),
+               "objects_per_launch": OBJECTS.get(profile), "kernels": {},
+               "note": "FETCH_SIZE and WRITE_SIZE (KB) in separate rocprofv3 --pmc passes, mean over the launches of the "
+                       "timed region; read side doubled per MI355X_MICROARCH.md HBM section"}
+    for name, k in kernels.items():
+        m = k["per_launch_means"]
+        k["ratios"] = ratios_of(m)
+        if m.get("FETCH_SIZE") is not None and m.get("WRITE_SIZE") is not None:
+            k["hbm"] = {"FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
+                        "hbm_bytes_per_launch_raw": int((m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024),
+                        "hbm_bytes_per_launch_corrected": int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)}
+            traffic["kernels"][name] = dict(k["hbm"])
+    traffic["histogram_update_fused"] = "region_histogram_kernel" not in kernels
+    json.dump({"command": command, "profile": profile, "kernels": kernels}, open(target, "w"), indent=1)
+    json.dump(traffic, open(os.path.join(os.path.dirname(target), "hbm_traffic_%s.json" % profile), "w"), indent=1)
+    for name, k in kernels.items():
+        print(name, k["workgroups"], "x", k["threads"], "vgprs", k["vgprs"], "lds", k["lds_bytes"])
+        print(json.dumps(k["ratios"], indent=1))
+        print(json.dumps(k.get("hbm")))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
