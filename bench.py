@@ -589,7 +589,10 @@ def batch_point(pkg, scenes, base, n_obj, use_depth, cfg):
     rate = n_obj * K / el
     shape = (C.c_int * 4)()
     hip.call("get_step_shape", shape)
+    name = C.create_string_buffer(64)
+    hip.call("get_step_kernel", name, 64)
     return {"objects": n_obj, "pose_updates_per_s": round(rate, 1), "ms_per_step": round(el / K * 1e3, 4),
+            "kernel": name.value.decode(), "histogram_update_in_the_launch": bool(shape[3]),
             "frac_of_hbm_roofline": round(rate * cfg["alg"] / (HBM_PEAK_GBS * 1e9), 5),
             "workgroups_per_object": shape[1], "threads_per_workgroup": shape[2],
             "distinct_frame_rings": len({c.id for c in inst.color_cams})}
