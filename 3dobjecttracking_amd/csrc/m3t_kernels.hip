@@ -909,8 +909,10 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
             (roundf(cmaj - it.line_length_minus_1_half) + it.line_length_minus_1_half - cmaj) / ndom;
         s.state[LS_WALK_START * nl + line] = i2f_bits(start);
         s.state[LS_WALK_STEP * nl + line] = step;
-        // sequential chain: x_{k+1} = x_k + step, recorded at every segment start
+        // sequential chain: x_{k+1} = x_k + step, recorded at every segment start (only the lines this workgroup
+        // walks need it: up to 19 x scale dependent additions per line)
         float* chain = s.chain + line * s.ns;
+        if (line >= line_lo && line < line_hi)
         switch (it.scale) {
           case 1: chain_fill<1>(chain, x0, step, n_seg); break;
           case 2: chain_fill<2>(chain, x0, step, n_seg); break;
