@@ -49,6 +49,7 @@ if has stats; then
   for c in $CONFIGS; do
     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$c" -- python "$REPO/bench.py" $(args_of $c) $PROF > "$OUT/stats_$c.log" 2>&1)
     cp "$OUT"/stats_$c/*/*kernel_stats.csv "$OUT/kernel_stats_$c.csv" 2>/dev/null
+    rm -rf "$OUT/stats_$c"  # (the raw traces of a 4096-object run are tens of MB; gpurun merges at most 64 MB back)
     head -4 "$OUT/kernel_stats_$c.csv"
   done
 fi
@@ -62,10 +63,11 @@ if has pmc; then
   PASS[write]="WRITE_SIZE"
   for c in ${PMC_CONFIGS:-rbot64 rbot4096 ycb21 synth512}; do
     mkdir -p "$OUT/pmc_$c"
-    for p in sq1 sq2 ta tcc fetch write; do
+    for p in ${PMC_PASSES:-sq1 sq2 ta tcc fetch write}; do
       (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --pmc ${PASS[$p]} --output-format csv -d "$OUT/pmc_$c/$p" -- python "$REPO/bench.py" $(args_of $c) $PROF > "$OUT/pmc_$c/$p.log" 2>&1)
     done
     python tools/pmc_summary3.py "$OUT/pmc_$c" "$OUT/pmc_$c.json" "$c" "bench.py $(args_of $c) $PROF" | tail -24
+    rm -rf "$OUT/pmc_$c"
   done
 fi
 if has phases; then

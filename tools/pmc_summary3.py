@@ -89,7 +89,7 @@ def main(out_dir, target, profile, command):
             traffic["kernels"][name] = dict(k["hbm"])
     traffic["histogram_update_fused"] = "region_histogram_kernel" not in kernels
     json.dump({"command": command, "profile": profile, "kernels": kernels}, open(target, "w"), indent=1)
-    json.dump(traffic, open(os.path.join(os.path.dirname(target), "hbm_traffic_%s.json" % profile), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(os.path.dirname(os.path.abspath(target)), "hbm_traffic_%s.json" % profile), "w"), indent=1)
     for name, k in kernels.items():
         print(name, k["workgroups"], "x", k["threads"], "vgprs", k["vgprs"], "lds", k["lds_bytes"])
         print(json.dumps(k["ratios"], indent=1))
