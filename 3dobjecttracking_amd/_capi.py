@@ -335,6 +335,9 @@ def pose_ret(buf):
     return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
 
 
+_NEWER_ENTRY_POINTS = ("get_step_kernel",)
+
+
 class CApi:
     """One loaded library + one context."""
 
@@ -348,7 +351,12 @@ class CApi:
         if self.is_hip:
             sigs.update(_HIP_ONLY)
         for name, args in sigs.items():
-            f = getattr(self.lib, prefix + name)
+            try:
+                f = getattr(self.lib, prefix + name)
+            except AttributeError:
+                if name in _NEWER_ENTRY_POINTS:  # an older build of the library (developer comparisons)
+                    continue
+                raise
             f.restype = C.c_int
             f.argtypes = [_CTX] + args
             self._fn[name] = f

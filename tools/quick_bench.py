@@ -73,12 +73,17 @@ def main():
                 hip.call("set_kernel_timing", 0)
                 shape = (C.c_int * 4)()
                 hip.call("get_step_shape", shape)
+                kernel = ""
+                if "get_step_kernel" in hip._fn:
+                    nb = C.create_string_buffer(64)
+                    hip.call("get_step_kernel", nb, 64)
+                    kernel = nb.value.decode()
                 poses = np.zeros((n, 16), np.float32)
                 hip.call("bodies_get_poses", poses.ctypes.data_as(C.POINTER(C.c_float)), n)
                 print("%-28s %-26s n=%5d  %.4f ms/step  %9.0f pose-updates/s  shape %s  track %.4f ms  hist %.4f ms  "
-                      "pose-sum %.9g" % (os.path.basename(os.path.dirname(lib)) + "/" + os.path.basename(lib), env, n,
-                                         el / K * 1e3, n * K / el, list(shape), ms[0] / max(cnt[0], 1),
-                                         ms[1] / max(cnt[1], 1), float(np.abs(poses[:8]).sum())), flush=True)
+                      "pose-sum %.9g %s" % (os.path.basename(os.path.dirname(lib)) + "/" + os.path.basename(lib), env, n,
+                                            el / K * 1e3, n * K / el, list(shape), ms[0] / max(cnt[0], 1),
+                                            ms[1] / max(cnt[1], 1), float(np.abs(poses[:8]).sum()), kernel), flush=True)
                 del inst, hip
 
 
