@@ -15,10 +15,14 @@
 
 #include <m3t/body.h>
 #include <m3t/camera.h>
+#include <m3t/depth_model.h>
 #include <m3t/modality.h>
+#include <m3t/region_model.h>
 
 #include <algorithm>
+#include <cstring>
 #include <filesystem>
+#include <fstream>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -160,6 +164,46 @@ struct HipBatch {
   std::vector<float> gh_cache;     // [n_modalities][6 + 36] of the last gradient / Hessian round
 };
 
+// Is `path` the sparse viewpoint model file of THIS model object and THIS body?  The acceptance test of
+// Model::LoadModelParameters / LoadBodyData (model.cpp:218-284): type letter and version, the seven generation
+// parameters (a file with MORE points per view passes, as in the reference), then the main body's geometry record.
+// A .bin generated for another body or with other parameters would otherwise load silently.
+inline bool ModelFileMatches(const std::filesystem::path& path, char model_type, int version_id, const m3t::Model& model) {
+  std::ifstream ifs{path, std::ios::binary};
+  if (!ifs.is_open()) return false;
+  auto get = [&](auto* v) { ifs.read(reinterpret_cast<char*>(v), sizeof(*v)); return bool(ifs); };
+  char type = 0;
+  int version = 0, n_divides = 0, n_points = 0, image_size = 0;
+  float sphere_radius = 0, max_radius_depth_offset = 0, stride_depth_offset = 0;
+  bool use_random_seed = false;
+  if (!(get(&type) && get(&version) && get(&sphere_radius) && get(&n_divides) && get(&n_points) &&
+        get(&max_radius_depth_offset) && get(&stride_depth_offset) && get(&use_random_seed) && get(&image_size)))
+    return false;
+  if (type != model_type || version != version_id || sphere_radius != model.sphere_radius() ||
+      n_divides != model.n_divides() || n_points < model.n_points() ||
+      max_radius_depth_offset != model.max_radius_depth_offset() ||
+      stride_depth_offset != model.stride_depth_offset() || use_random_seed != model.use_random_seed() ||
+      image_size != model.image_size())
+    return false;
+  const m3t::Body& body = *model.body_ptr();
+  std::string::size_type length = 0;
+  if (!get(&length) || length > 4096) return false;
+  std::string geometry_path(length, '\0');
+  ifs.read(geometry_path.data(), std::streamsize(length));
+  float unit = 0, diameter = 0;
+  bool ccw = false, culling = false;
+  float pose[16];
+  if (!(ifs && get(&unit) && get(&ccw) && get(&culling) && get(&diameter))) return false;
+  ifs.read(reinterpret_cast<char*>(pose), sizeof(pose));
+  if (!ifs) return false;
+  std::error_code ec;
+  const bool same_file = std::filesystem::equivalent(geometry_path, body.geometry_path(), ec) ||
+                         std::filesystem::path{geometry_path}.lexically_normal() == body.geometry_path().lexically_normal();
+  return same_file && unit == body.geometry_unit_in_meter() && ccw == body.geometry_counterclockwise() &&
+         culling == body.geometry_enable_culling() && diameter == body.maximum_body_diameter() &&
+         std::memcmp(pose, body.geometry2body_pose().data(), sizeof(pose)) == 0;
+}
+
 // what both adapters do the same way
 class HipModality : public m3t::Modality {
  public:
@@ -225,10 +269,35 @@ class HipRegionModality : public HipModality {
         depth_camera_{std::move(depth_camera)},
         model_path_{std::move(region_model_path)},
         params_{params} {}
+  // The reference's signature (region_modality.h:169-172) with the batch and the parameter block appended: the host's
+  // own RegionModel object.  Its views are private, so the adapter reads the file that model wrote or loaded in
+  // its SetUp (model_path()), after checking that the file belongs to this model and body (ModelFileMatches).
+  HipRegionModality(const std::string& name, const std::shared_ptr<m3t::Body>& body,
+                    std::shared_ptr<m3t::ColorCamera> color_camera, std::shared_ptr<m3t::RegionModel> region_model,
+                    std::shared_ptr<HipBatch> batch, const m3t_region_modality_params& params,
+                    std::shared_ptr<m3t::DepthCamera> depth_camera = nullptr)
+      : HipModality{name, body, std::move(batch)},
+        color_camera_{std::move(color_camera)},
+        depth_camera_{std::move(depth_camera)},
+        region_model_{std::move(region_model)},
+        params_{params} {}
+  std::shared_ptr<m3t::Model> model_ptr() const { return region_model_; }
 
   bool SetUp() override {
     set_up_ = false;
     if (!batch_ || !batch_->ctx) return false;
+    if (region_model_) {
+      if (!region_model_->set_up()) {  // region_modality.cpp:37-40
+        std::cerr << "Region model " << region_model_->name() << " was not set up" << std::endl;
+        return false;
+      }
+      model_path_ = region_model_->model_path();
+      if (!ModelFileMatches(model_path_, 'r', 10, *region_model_)) {
+        std::cerr << "Model file " << model_path_ << " was not generated for region model " << region_model_->name()
+                  << " and body " << region_model_->body_ptr()->name() << std::endl;
+        return false;
+      }
+    }
     color_id_ = batch_->ColorCameraId(color_camera_);
     if (depth_camera_) {
       depth_id_ = batch_->DepthCameraId(depth_camera_);
@@ -251,6 +320,7 @@ class HipRegionModality : public HipModality {
  private:
   std::shared_ptr<m3t::ColorCamera> color_camera_;
   std::shared_ptr<m3t::DepthCamera> depth_camera_;
+  std::shared_ptr<m3t::RegionModel> region_model_;
   std::filesystem::path model_path_;
   m3t_region_modality_params params_;
   int color_id_ = -1, depth_id_ = -1, model_id_ = -1;
@@ -265,10 +335,31 @@ class HipDepthModality : public HipModality {
         depth_camera_{std::move(depth_camera)},
         model_path_{std::move(depth_model_path)},
         params_{params} {}
+  // depth_modality.h:110-113 with the batch and the parameter block appended (see HipRegionModality)
+  HipDepthModality(const std::string& name, const std::shared_ptr<m3t::Body>& body,
+                   std::shared_ptr<m3t::DepthCamera> depth_camera, std::shared_ptr<m3t::DepthModel> depth_model,
+                   std::shared_ptr<HipBatch> batch, const m3t_depth_modality_params& params)
+      : HipModality{name, body, std::move(batch)},
+        depth_camera_{std::move(depth_camera)},
+        depth_model_{std::move(depth_model)},
+        params_{params} {}
+  std::shared_ptr<m3t::Model> model_ptr() const { return depth_model_; }
 
   bool SetUp() override {
     set_up_ = false;
     if (!batch_ || !batch_->ctx) return false;
+    if (depth_model_) {
+      if (!depth_model_->set_up()) {
+        std::cerr << "Depth model " << depth_model_->name() << " was not set up" << std::endl;
+        return false;
+      }
+      model_path_ = depth_model_->model_path();
+      if (!ModelFileMatches(model_path_, 'd', 9, *depth_model_)) {
+        std::cerr << "Model file " << model_path_ << " was not generated for depth model " << depth_model_->name()
+                  << " and body " << depth_model_->body_ptr()->name() << std::endl;
+        return false;
+      }
+    }
     depth_id_ = batch_->DepthCameraId(depth_camera_);
     model_id_ = m3t_hip_depth_model_load(batch_->ctx, model_path_.string().c_str());
     body_id_ = batch_->BodyId(body_ptr_);
@@ -283,6 +374,7 @@ class HipDepthModality : public HipModality {
 
  private:
   std::shared_ptr<m3t::DepthCamera> depth_camera_;
+  std::shared_ptr<m3t::DepthModel> depth_model_;
   std::filesystem::path model_path_;
   m3t_depth_modality_params params_;
   int depth_id_ = -1, model_id_ = -1;

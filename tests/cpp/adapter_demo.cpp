@@ -129,13 +129,36 @@ int main(int argc, char** argv) {
 
   if (argc > 2 && std::string(argv[2]) == "adapter-only") return 0;
   // fast mode on a second batch: the library optimises, the host Body receives the pose
-  auto fast_body = std::make_shared<m3t::Body>("triangle");
+  // ... built the way a maintainer's code builds it (region_modality.h:169-172, depth_modality.h:110-113): the host's
+  // own model objects go into the constructors; the adapter reads the files they wrote / loaded after checking that
+  // the files belong to these models and this body (Model::LoadModelParameters / LoadBodyData, model.cpp:218-284)
+  auto fast_body = std::make_shared<m3t::Body>("triangle", "triangle.obj", 1.0f, true, true, m3t::Transform3fA{});
+  fast_body->set_maximum_body_diameter(0.1f);
   fast_body->set_body2world_pose(body2world);
   auto fast = std::make_shared<HipBatch>(0);
   if (!fast->ctx) return 13;
-  auto region = std::make_shared<HipRegionModality>("region", fast_body, color, dir + "/region.bin", fast, rp, depth);
-  auto depth_modality = std::make_shared<HipDepthModality>("depth", fast_body, depth, dir + "/depth.bin", fast, dp);
+  auto region_model = std::make_shared<m3t::RegionModel>("triangle_region_model", fast_body, dir + "/region.bin");
+  auto depth_model = std::make_shared<m3t::DepthModel>("triangle_depth_model", fast_body, dir + "/depth.bin");
+  {
+    auto not_set_up = std::make_shared<HipRegionModality>("region", fast_body, color, region_model, fast, rp, depth);
+    if (not_set_up->SetUp()) return 20;  // "Region model ... was not set up" (region_modality.cpp:37-40)
+  }
+  if (!region_model->SetUp() || !depth_model->SetUp()) return 21;
+  {
+    // a model object with other generation parameters, or for another body: the file on disk is not its file
+    auto other = std::make_shared<m3t::RegionModel>("other", fast_body, dir + "/region.bin", 0.8f, 3);
+    other->SetUp();
+    if (std::make_shared<HipRegionModality>("region", fast_body, color, other, fast, rp, depth)->SetUp()) return 22;
+    auto other_body = std::make_shared<m3t::Body>("bottle", "schauma.obj", 1.0f, true, true, m3t::Transform3fA{});
+    other_body->set_maximum_body_diameter(0.1f);
+    auto stale = std::make_shared<m3t::DepthModel>("stale", other_body, dir + "/depth.bin");
+    stale->SetUp();
+    if (std::make_shared<HipDepthModality>("depth", other_body, depth, stale, fast, dp)->SetUp()) return 23;
+  }
+  auto region = std::make_shared<HipRegionModality>("region", fast_body, color, region_model, fast, rp, depth);
+  auto depth_modality = std::make_shared<HipDepthModality>("depth", fast_body, depth, depth_model, fast, dp);
   if (!region->SetUp() || !depth_modality->SetUp()) return 14;
+  if (region->model_ptr() != region_model) return 24;
   if (!fast->AddRigidOptimizer(fast_body, {region->device_id(), depth_modality->device_id()})) return 15;
   if (!fast->StartModalities(0) || !fast->ExecuteTrackingStep(0, 7, 2)) return 16;
   std::printf("fast");
