@@ -73,7 +73,7 @@ fi
 if has phases; then
   for v in "rbot64:64:" "ycb21:21:ycb"; do
     IFS=: read name n ycb <<< "$v"
-    (timeout 300 python tools/phase_timing.py tools/libm3t_hip_timing.so $n $ycb 2>&1 | tail -34) > "$OUT/phase_timing_$name.txt" 2>&1
+    (timeout 300 python tools/phase_timing.py tools/libm3t_hip_timing.so $n $ycb 2>&1 | grep -v amdgpu | tail -44) > "$OUT/phase_timing_$name.txt" 2>&1
   done
   (timeout 300 python tools/tree_timing.py tools/libm3t_hip_timing.so 2>&1 | grep -v amdgpu) > "$OUT/phase_timing_chain8.txt" 2>&1
   head -12 "$OUT/phase_timing_rbot64.txt"
