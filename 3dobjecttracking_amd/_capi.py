@@ -305,6 +305,7 @@ _HIP_ONLY = {
     "comm_set": [C.c_void_p],
     "comm_destroy": [],
     "calculate_optimization_allreduce": [],
+    "comm_get_allreduce_count": [C.POINTER(C.c_longlong)],
     "cameras_set_ring": [c_int_p, C.c_int, C.c_int],
     "cameras_upload_batch_async": [c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t],
     "camera_select_slot": [C.c_int, C.c_int],
@@ -313,6 +314,7 @@ _HIP_ONLY = {
     "get_kernel_timing": [c_float_p, c_int_p],
     "get_step_shape": [c_int_p],
     "get_step_kernel": [C.c_char_p, C.c_size_t],
+    "debug_log_checksum": [C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong)],
     "set_object_split": [C.c_int],
 }
 
@@ -335,7 +337,7 @@ def pose_ret(buf):
     return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
 
 
-_NEWER_ENTRY_POINTS = ("get_step_kernel",)
+_NEWER_ENTRY_POINTS = ("get_step_kernel", "comm_get_allreduce_count", "debug_log_checksum")
 
 
 class CApi:

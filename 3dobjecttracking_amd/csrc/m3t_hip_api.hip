@@ -191,6 +191,7 @@ struct m3t_hip_context {
   bool partial_ready = false;
   // a kinematic structure spread over GPUs: this rank's RCCL communicator (m3t_hip_comm_init_rank) or the host's
   ncclComm_t comm = nullptr;
+  long long allreduce_calls = 0;  // ncclAllReduce calls issued since the context was created (m3t_hip_comm_get_allreduce_count)
   bool comm_owned = false;
   int n_corr_iterations = 5, n_update_iterations = 2;
   int fused_mode = 1;
@@ -1222,6 +1223,7 @@ int AllReducePartial(Ctx* ctx) {
   if (rc != ncclSuccess)
     return Fail(ctx, M3T_ERR_DEVICE,
                 std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+  ++ctx->allreduce_calls;
   return M3T_OK;
 }
 
@@ -3218,6 +3220,31 @@ int m3t_hip_get_step_shape(m3t_hip_context* ctx, int shape[4]) {
   CHECK_CTX();
   REQUIRE(shape, M3T_ERR_INVALID_ARGUMENT, "null output");
   std::memcpy(shape, ctx->last_step_shape, sizeof(ctx->last_step_shape));
+  return M3T_OK;
+}
+int m3t_hip_debug_log_checksum(m3t_hip_context* ctx, unsigned first_bits, unsigned last_bits,
+                               unsigned long long out[3]) {
+  CHECK_CTX();
+  REQUIRE(out && first_bits <= last_bits, M3T_ERR_INVALID_ARGUMENT, "bad range");
+  HIPCHK(hipSetDevice(ctx->device));
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), 24));
+  hipError_t e = hipMemsetAsync(d, 0, 24, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(log_checksum_kernel, dim3(ctx->prop.multiProcessorCount * 8), dim3(256), 0, ctx->stream,
+                       first_bits, last_bits, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, 24, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  HIPCHK(e);
+  return M3T_OK;
+}
+int m3t_hip_comm_get_allreduce_count(m3t_hip_context* ctx, long long* count) {
+  CHECK_CTX();
+  REQUIRE(count, M3T_ERR_INVALID_ARGUMENT, "null output");
+  *count = ctx->allreduce_calls;
   return M3T_OK;
 }
 int m3t_hip_get_step_kernel(m3t_hip_context* ctx, char* name, size_t capacity) {

@@ -3081,4 +3081,38 @@ tracking_step_split_kernel(const RigidOptDev* opts, const RegionModDev* rmods, c
                                   n_corr_iterations, n_update_iterations, write_state, fuse_histogram, &split);
 }
 
+// Test hook (m3t_hip_debug_log_checksum): the logarithm exactly as region_products takes it -- m3t_log_fast on the
+// table in LDS, the general double logarithm where the fast path does not vouch -- for every float whose bit pattern
+// lies in [first_bits, last_bits].  out[0] += sum of result_bits * (input_bits | 1) mod 2^64, out[1] += calls that
+// took the general logarithm, out[2] += the same sum over those calls alone (ocml's logarithm by itself).
+// tests/cpp/log_check.cpp forms the same sums from float(std::log(double(x))) on the host.
+__global__ void __launch_bounds__(256)
+log_checksum_kernel(unsigned first_bits, unsigned last_bits, unsigned long long* out) {
+  __shared__ double table[M3T_LOG_TABLE_DOUBLES];
+  if (threadIdx.x < M3T_LOG_TABLE_DOUBLES)
+    reinterpret_cast<uint64_t*>(table)[threadIdx.x] = g_log_table_bits[threadIdx.x];
+  __syncthreads();
+  typedef const __attribute__((address_space(3))) double* LdsDoubles;
+  LdsDoubles log_table = (LdsDoubles)table;
+  unsigned long long sum = 0ull, fallbacks = 0ull, fallback_sum = 0ull;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long b = (unsigned long long)first_bits + blockIdx.x * blockDim.x + threadIdx.x; b <= last_bits;
+       b += stride) {
+    const unsigned ix = (unsigned)b;
+    const float x = __uint_as_float(ix);
+    float y = 0.0f;
+    const bool vouched = m3t_log_fast(x, log_table, &y);
+    if (!vouched) y = (float)log((double)x);
+    const unsigned long long term = (unsigned long long)__float_as_uint(y) * (unsigned long long)(ix | 1u);
+    sum += term;
+    if (!vouched) {
+      ++fallbacks;
+      fallback_sum += term;
+    }
+  }
+  atomicAdd(&out[0], sum);
+  atomicAdd(&out[1], fallbacks);
+  atomicAdd(&out[2], fallback_sum);
+}
+
 }  // extern "C"

@@ -248,6 +248,9 @@ int m3t_hip_comm_init_rank(m3t_hip_context*, const void* id, size_t id_bytes, in
 int m3t_hip_comm_set(m3t_hip_context*, void* nccl_comm /* ncclComm_t or NULL */);
 int m3t_hip_comm_destroy(m3t_hip_context*);
 int m3t_hip_calculate_optimization_allreduce(m3t_hip_context*);
+/* number of ncclAllReduce calls the context has issued so far (one per Newton step of a tracking step while a
+ * communicator is set: the observable a host or a test checks the distributed path with) */
+int m3t_hip_comm_get_allreduce_count(m3t_hip_context*, long long* count);
 int m3t_hip_calculate_consistent_poses(m3t_hip_context*); /* tracker.cpp:423, optimizer.cpp:135 */
 int m3t_hip_calculate_results(m3t_hip_context*, int iteration);                    /* :503 */
 /* Tracker::ExecuteTrackingStep (M3T tracker.cpp:344) == Tracker::ExecuteTrackingCycle
@@ -276,6 +279,13 @@ int m3t_hip_sync(m3t_hip_context*);
 /* (The gradient / Hessian sums over lines / points are always taken in the reference's sequential f32 order,
  * region_modality.cpp:550-554, depth_modality.cpp:361-377: whole tracking sequences reproduce the CPU path bit for
  * bit in every launch shape; there is no summation-mode switch.) */
+/* Test hook: the logarithm of RegionModality::CalculateGradientAndHessian (region_modality.cpp:520-523) exactly as
+ * the kernels take it (csrc/m3t_log.h, with the general double logarithm where the table path does not vouch for its
+ * rounding), evaluated on the device for every float with a bit pattern in [first_bits, last_bits]:
+ * out[0] = sum of result_bits * (input_bits | 1) mod 2^64, out[1] = evaluations that took the general logarithm,
+ * out[2] = the sum over those evaluations alone.  tests/test_gpu_log.py compares all three with
+ * float(std::log(double(x))) on the host over all of [FLT_MIN, 1]. */
+int m3t_hip_debug_log_checksum(m3t_hip_context*, unsigned first_bits, unsigned last_bits, unsigned long long out[3]);
 /* measurement aid (bench.py roofline leg): HIP events on the context stream around
  * [0] the fused tracking kernel and [1] the histogram kernel; totals since enable */
 int m3t_hip_set_kernel_timing(m3t_hip_context*, int enable);

@@ -505,6 +505,17 @@ class Tracker {
     c_->Check(m3t_hip_get_stream(c_->get(), &s), "Tracker");
     return s;
   }
+  long long AllReduceCount() const {  // ncclAllReduce calls issued so far (one per Newton step with a communicator set)
+    long long n = 0;
+    c_->Check(m3t_hip_comm_get_allreduce_count(c_->get(), &n), "Tracker");
+    return n;
+  }
+  // test hook: checksum and general-logarithm count of the device's logarithm over a range of float bit patterns
+  std::array<unsigned long long, 3> DebugLogChecksum(unsigned first_bits, unsigned last_bits) const {
+    std::array<unsigned long long, 3> out{};
+    c_->Check(m3t_hip_debug_log_checksum(c_->get(), first_bits, last_bits, out.data()), "Tracker");
+    return out;
+  }
   // launch shape (m3t_hip.h: set_fused_step, get_step_shape)
   void SetFusedStep(int mode) { c_->Check(m3t_hip_set_fused_step(c_->get(), mode), "Tracker"); }
   std::string StepKernel() const {  // name of the kernel the last ExecuteTrackingStep launched for the tracking loop

@@ -192,6 +192,43 @@ def test_native_rccl_allreduce_world1():
 
 
 @gpu
+def test_tracking_step_all_reduces_with_a_communicator_set():
+    """ExecuteTrackingStep of a kinematic structure while a communicator is set (m3t_hip.h: the step runs
+    project -> ONE ncclAllReduce -> solve per Newton step by itself, optimizer.cpp:309-321 being the distributed sum):
+    the library's own RCCL communicator at world size 1 on the 2-body chain.  The collective is really issued --
+    7 x 2 calls per frame -- the launch is the one split at the all-reduce, not the one-launch tree kernel, and the
+    poses equal the oracle's (= the single-GPU path's) bit for bit: a sum over one rank changes nothing."""
+    inputs, joint2parent, gt = chain_inputs(3)
+    start_a = syn.perturb_pose(gt[0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
+    results = {}
+    for name, api in (("hip", util.open_hip()), ("oracle", util.open_oracle())):
+        ch = Chain(api, inputs, joint2parent, start_a, gt[0][2] + 0.01)
+        if name == "hip":
+            uid = C.create_string_buffer(128)
+            api.call("comm_get_unique_id", uid, 128)
+            api.call("comm_init_rank", uid, 128, 1, 0)
+        ch.upload(inputs, 0)
+        assert ch.tracker.StartModalities(0)
+        states = []
+        for k in range(len(gt)):
+            ch.upload(inputs, k)
+            assert ch.tracker.ExecuteTrackingStep(k)
+            states.append(ch.state())
+        results[name] = states
+        if name == "hip":
+            count = C.c_longlong(-1)
+            api.call("comm_get_allreduce_count", C.byref(count))
+            assert count.value == len(gt) * 7 * 2
+            kernel = C.create_string_buffer(64)
+            api.call("get_step_kernel", kernel, 64)
+            assert kernel.value.decode() != "tracking_step_tree_kernel"
+            api.call("comm_destroy")
+    for sh, so in zip(results["hip"], results["oracle"]):
+        for x, y in zip(sh, so):
+            assert np.array_equal(x, y)
+
+
+@gpu
 def test_rigid_context_switches_to_general_path_for_begin_end():
     """begin/end on a rigid-only context == the rigid fast path within one Newton-step tolerance"""
     inputs = scenes.Inputs(2, 2, n_divides=2)
