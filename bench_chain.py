@@ -188,6 +188,9 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle):
                       "gpu_us_per_structure": round(gpu_us / n_structures, 3), "cpu_port_us_per_structure": round(cpu_us, 2)})
     total = n_bodies * K
     rate = total / elapsed
+    collectives = C.c_longlong(0)  # ncclAllReduce calls this rank's context issued (start to here: W + repeats x K steps)
+    hip.call("comm_get_allreduce_count", C.byref(collectives))
+    steps_run = W + max(1, args.repeats) * K
     name = C.create_string_buffer(64)
     hip.call("get_step_kernel", name, 64)
     kernel = name.value.decode()
@@ -205,6 +208,8 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle):
                                 "first wave" if fused else "one launch per sub-step, link kernels: one wave per structure",
                                 world, (6 + n_bodies - 1) ** 2 + 6 + n_bodies - 1, "" if world > 1 else " when N > 1"),
                    "bodies": n_bodies, "parallelism": "bodies sharded over %d GPU(s)" % world,
+                   "rccl_ranks": world if world > 1 else 0,
+                   "allreduce_calls_per_step": round(collectives.value / steps_run, 3),
                    "max_rotation_error_vs_ground_truth_rad": round(float(max(e[0] for e in gt_err)), 5),
                    "setup_s": round(setup_s, 1)},
         "roofline": {"bound": "hbm",
