@@ -1,0 +1,104 @@
+// tools/ubench_ingest.hip — developer micro-benchmark for ROI ingest: three ways to bring the part of
+// 64 camera frames (640 x 512 BGR8, one page-locked block) that the trackers read into the frame ring:
+//   full     one hipMemcpyAsync of the whole block (what m3t_hip_cameras_upload_batch_async does today)
+//   2d       one hipMemcpy2DAsync per camera for its rectangle
+//   pull     ONE kernel that reads the rectangles straight from the mapped host block over PCIe and writes the ring
+// for rectangles of 128^2 ... 512^2 pixels.  Prints ms per batch-frame and the frames/s x 64 objects they allow.
+//   hipcc --offload-arch=gfx950 -O3 -o ubench_ingest tools/ubench_ingest.hip && ./ubench_ingest
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+constexpr int W = 640, H = 512, BPP = 3, PITCH = W * BPP, N = 64;
+constexpr size_t FRAME = (size_t)PITCH * H;
+
+struct Rect { int x0, y0, x1, y1; };
+
+// grid: (rows of 16-byte chunks) -- one workgroup per (camera, 8 rows); a thread moves 16 bytes at a time
+__global__ void __launch_bounds__(256)
+pull_kernel(const unsigned char* __restrict__ host_block, unsigned char* __restrict__ ring, const Rect* rects) {
+  const int cam = blockIdx.y;
+  const Rect r = rects[cam];
+  const int row0 = r.y0 + blockIdx.x * 8;
+  // widen the span to 16-byte boundaries of the row (rows start 16-byte aligned: 1920 = 120 x 16)
+  const int b0 = (r.x0 * BPP) & ~15, b1 = (r.x1 * BPP + 15) & ~15;
+  const int chunks = (b1 - b0) >> 4;
+  for (int i = threadIdx.x; i < 8 * chunks; i += 256) {
+    const int row = row0 + i / chunks, c = i - (i / chunks) * chunks;
+    if (row >= r.y1) break;
+    const size_t at = (size_t)cam * FRAME + (size_t)row * PITCH + b0 + ((size_t)c << 4);
+    *reinterpret_cast<uint4*>(ring + at) = *reinterpret_cast<const uint4*>(host_block + at);
+  }
+}
+
+int main() {
+  unsigned char *host, *host_dev, *ring;
+  Rect* d_rects;
+  CHECK(hipHostMalloc(reinterpret_cast<void**>(&host), N * FRAME, hipHostMallocMapped));
+  memset(host, 7, N * FRAME);
+  CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), host, 0));
+  CHECK(hipMalloc(&ring, N * FRAME));
+  CHECK(hipMalloc(&d_rects, N * sizeof(Rect)));
+  hipStream_t s;
+  CHECK(hipStreamCreate(&s));
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(now() - t).count();
+  };
+  const int reps = 20;
+  {
+    CHECK(hipMemcpyAsync(ring, host, N * FRAME, hipMemcpyHostToDevice, s));
+    CHECK(hipStreamSynchronize(s));
+    auto t = now();
+    for (int k = 0; k < reps; ++k) CHECK(hipMemcpyAsync(ring, host, N * FRAME, hipMemcpyHostToDevice, s));
+    CHECK(hipStreamSynchronize(s));
+    const double ms = ms_since(t) / reps;
+    printf("full frames             %7.3f ms per batch-frame  %6.1f GB/s  -> %8.0f pose-updates/s\n", ms, N * FRAME / ms * 1e-6,
+           N / ms * 1e3);
+  }
+  for (int side : {128, 192, 256, 320, 384, 512}) {
+    Rect rects[N];
+    for (int i = 0; i < N; ++i) {
+      const int x0 = (i * 37) % (W - (side < W ? side : W) + 1), y0 = (i * 53) % (H - (side < H ? side : H) + 1);
+      rects[i] = {x0, y0, x0 + (side < W ? side : W), y0 + (side < H ? side : H)};
+    }
+    CHECK(hipMemcpy(d_rects, rects, sizeof rects, hipMemcpyHostToDevice));
+    size_t bytes = 0;
+    for (int i = 0; i < N; ++i) bytes += (size_t)(rects[i].x1 - rects[i].x0) * BPP * (rects[i].y1 - rects[i].y0);
+    double ms2d, mspull;
+    {
+      auto run = [&] {
+        for (int i = 0; i < N; ++i) {
+          const Rect& r = rects[i];
+          const size_t at = (size_t)i * FRAME + (size_t)r.y0 * PITCH + (size_t)r.x0 * BPP;
+          CHECK(hipMemcpy2DAsync(ring + at, PITCH, host + at, PITCH, (size_t)(r.x1 - r.x0) * BPP, r.y1 - r.y0,
+                                 hipMemcpyHostToDevice, s));
+        }
+      };
+      run();
+      CHECK(hipStreamSynchronize(s));
+      auto t = now();
+      for (int k = 0; k < reps; ++k) run();
+      CHECK(hipStreamSynchronize(s));
+      ms2d = ms_since(t) / reps;
+    }
+    {
+      const int rows = rects[0].y1 - rects[0].y0;
+      auto run = [&] { hipLaunchKernelGGL(pull_kernel, dim3((rows + 7) / 8, N), dim3(256), 0, s, host_dev, ring, d_rects); };
+      run();
+      CHECK(hipStreamSynchronize(s));
+      auto t = now();
+      for (int k = 0; k < reps; ++k) run();
+      CHECK(hipStreamSynchronize(s));
+      mspull = ms_since(t) / reps;
+    }
+    printf("rect %3d^2 (%5.1f %% of the frames)  2d x 64: %7.3f ms (%5.1f GB/s, %8.0f pose-updates/s)   pull kernel: %7.3f ms (%5.1f GB/s, "
+           "%8.0f pose-updates/s)\n", side, 100.0 * bytes / (N * FRAME), ms2d, bytes / ms2d * 1e-6, N / ms2d * 1e3, mspull,
+           bytes / mspull * 1e-6, N / mspull * 1e3);
+  }
+  return 0;
+}
