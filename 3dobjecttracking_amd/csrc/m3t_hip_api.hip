@@ -874,7 +874,10 @@ int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int /*largest_image
   if (n_which == 0) return M3T_OK;
   hipLaunchKernelGGL(focused_clear_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                      ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
-  hipLaunchKernelGGL(focused_raster_kernel, dim3(32, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+#ifndef M3T_RASTER_SLICES
+#define M3T_RASTER_SLICES 32
+#endif
+  hipLaunchKernelGGL(focused_raster_kernel, dim3(M3T_RASTER_SLICES, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                      ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
   hipLaunchKernelGGL(focused_unpack_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                      ctx->d_renderers.as<RendererDev>(), which);

@@ -181,6 +181,9 @@ __device__ __forceinline__ void raster_pixel(const RasterTriangle& t, int px, in
     inside = inside && (e[k] > 0.0 || (e[k] == 0.0 && owns));
   }
   if (!inside) return;
+#if M3T_RASTER_PROBE == 5
+  if (t.area > 0.0) { atomicMin(&z_buffer[py * S + px], 0xfffffffeu); return; }
+#endif
   const double z = (e[1] / t.area) * t.z[0] + (e[2] / t.area) * t.z[1] + (e[0] / t.area) * t.z[2];
   if (!(z >= 0.0 && z <= 1.0)) return;
   const uint32_t d16 = (uint32_t)floor(z * 65535.0 + 0.46);  // see the oracle / gl_model.py
@@ -192,13 +195,22 @@ __device__ __forceinline__ void raster_pixel(const RasterTriangle& t, int px, in
 // LDS and rasterised by the whole workgroup.
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 focused_raster_kernel(const RendererDev* renderers, const int* which, const CameraDev* cams, const float* body_poses) {
-  constexpr int kQueue = 64;
+#ifndef M3T_RASTER_QUEUE
+#define M3T_RASTER_QUEUE 64
+#endif
+#ifndef M3T_RASTER_SERIAL_MAX
+#define M3T_RASTER_SERIAL_MAX 192
+#endif
+  constexpr int kQueue = M3T_RASTER_QUEUE;
   __shared__ RasterTriangle queue[kQueue];
   __shared__ int n_queued;
   const RendererDev& r = renderers[which[blockIdx.y]];
   const CameraDev& cam = cams[r.camera];
   const FocusedProjection f = focused_projection(r, cam, body_poses);
   if (f.n_visible == 0) return;  // block-uniform
+#if M3T_RASTER_PROBE == 1
+  if (f.n_visible > 0) return;
+#endif
   const int S = r.image_size;
   uint32_t* z_buffer = r.packed;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -209,6 +221,11 @@ focused_raster_kernel(const RendererDev* renderers, const int* which, const Came
     const float* vertices = r.vertices[order];
     const int* triangles = r.triangles[order];
     const bool culling = r.culling[order] != 0;
+#if M3T_RASTER_PROBE == 3
+    if (r.n_triangles[order] > 64) continue;   // few-triangle bodies only
+#elif M3T_RASTER_PROBE == 4
+    if (r.n_triangles[order] <= 64) continue;  // many-triangle bodies only
+#endif
     const int per_slice = (r.n_triangles[order] + gridDim.x - 1) / gridDim.x;
     const int t_begin = blockIdx.x * per_slice;
     const int t_end = min(t_begin + per_slice, r.n_triangles[order]);
@@ -220,7 +237,11 @@ focused_raster_kernel(const RendererDev* renderers, const int* which, const Came
       if (t < t_end && raster_setup(trans, vertices, triangles, t, culling, S, tri)) {
         const int pixels = (tri.x1 - tri.x0 + 1) * (tri.y1 - tri.y0 + 1);
         int slot = kQueue;
-        if (pixels > 192) slot = atomicAdd(&n_queued, 1);
+#if M3T_RASTER_PROBE == 2
+        atomicMin(&z_buffer[tri.y0 * S + tri.x0], 0xfffffffeu);
+        continue;
+#endif
+        if (pixels > M3T_RASTER_SERIAL_MAX) slot = atomicAdd(&n_queued, 1);
         if (slot < kQueue) {
           queue[slot] = tri;
         } else {
