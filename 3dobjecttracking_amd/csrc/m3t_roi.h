@@ -1,0 +1,119 @@
+// m3t_roi.h -- which part of a camera frame a tracking step can read for one body (ROI ingest): a
+// conservative rectangle from the pose a search runs at, a box around the model's points and the modality's parameters.
+// Every pixel the path reads lies within a bounded distance of the projection of a point of the body:
+//   RegionModality, colour frame   correspondence line of (function_length + distribution_length - 1) x scale pixels
+//                                  centred on a projected contour point (region_modality.cpp:1433-1508); histogram
+//                                  lines of unconsidered + max_considered_line_length along the normal (:1640-1780)
+//   RegionModality, depth frame    the <= 6 x 6 window of IsLineUnoccludedMeasured around the projected point, diameter
+//                                  2 x measured_occlusion_radius x fu / z (:1343-1389)
+//   DepthModality, depth frame     the window of FindCorrespondence, diameter 2 x considered_distance x fu / z
+//                                  (x z with depth scaling; depth_modality.cpp:826-884), and the measured-occlusion
+//                                  window (:736-776)
+// and those points are data points of the modality's sparse viewpoint model moved by the pose: the rectangle is the
+// bounding rectangle of the projected box around the model's points, widened by a reach in pixels plus a reach in
+// metres at the box's near side.
+// Host and device code (plain C functions); tests/test_roi_bound.py checks the rectangles against the oracle: frames
+// scrambled outside them leave every pose and histogram of a tracked sequence unchanged.
+#pragma once
+#include <math.h>
+
+#include "../../include/m3t_types.h"
+
+#if defined(__HIPCC__)
+#define M3T_ROI_FN __device__ __forceinline__
+#else
+#define M3T_ROI_FN static inline
+#endif
+
+typedef struct m3t_roi_rect {
+  int x0, y0, x1, y1;  // inclusive pixel bounds; empty when x1 < x0
+} m3t_roi_rect;
+
+M3T_ROI_FN m3t_roi_rect m3t_roi_empty(void) {
+  m3t_roi_rect r = {1 << 30, 1 << 30, -(1 << 30), -(1 << 30)};
+  return r;
+}
+M3T_ROI_FN m3t_roi_rect m3t_roi_union(m3t_roi_rect a, m3t_roi_rect b) {
+  m3t_roi_rect r;
+  r.x0 = a.x0 < b.x0 ? a.x0 : b.x0;
+  r.y0 = a.y0 < b.y0 ? a.y0 : b.y0;
+  r.x1 = a.x1 > b.x1 ? a.x1 : b.x1;
+  r.y1 = a.y1 > b.y1 ? a.y1 : b.y1;
+  return r;
+}
+M3T_ROI_FN int m3t_roi_contains(m3t_roi_rect outer, m3t_roi_rect inner) {
+  return inner.x1 < inner.x0 || (outer.x0 <= inner.x0 && outer.y0 <= inner.y0 && outer.x1 >= inner.x1 && outer.y1 >= inner.y1);
+}
+
+// a window of the reference's strided scans around a centre: rounded_radius + the roundings of its corners
+M3T_ROI_FN float m3t_roi_window_reach(float diameter) { return 0.55f * diameter + 2.0f; }
+
+// reach in pixels of the colour frame for a RegionModality: the correspondence lines of search corr_iteration
+// (scale of that iteration, region_modality.cpp:1011-1023), and the histogram lines (StartModality, CalculateResults)
+M3T_ROI_FN float m3t_roi_region_line_reach(const m3t_region_modality_params* p, int corr_iteration) {
+  const int last = p->n_scales - 1;
+  const int scale = p->n_scales > 0 ? p->scales[corr_iteration < last ? corr_iteration : last] : 1;
+  return 0.5f * (float)((p->function_length + p->distribution_length - 1) * scale) + 2.0f;
+}
+M3T_ROI_FN float m3t_roi_region_histogram_reach(const m3t_region_modality_params* p) {
+  return p->unconsidered_line_length + p->max_considered_line_length + 2.0f;
+}
+// reach of a RegionModality in its depth frame (measured occlusions): metres at the point's depth, plus pixels
+M3T_ROI_FN void m3t_roi_region_depth_reach(const m3t_region_modality_params* p, float* reach_m, float* reach_px) {
+  *reach_m = p->measure_occlusions ? 1.1f * p->measured_occlusion_radius : 0.0f;
+  *reach_px = 2.0f;
+}
+// reach of a DepthModality in its depth frame
+M3T_ROI_FN void m3t_roi_depth_reach(const m3t_depth_modality_params* p, float fu, float* reach_m, float* reach_px) {
+  float distance = 0.0f;
+  for (int i = 0; i < p->n_considered_distances; ++i)
+    distance = p->considered_distances[i] > distance ? p->considered_distances[i] : distance;
+  if (p->measure_occlusions && p->measured_occlusion_radius > distance) distance = p->measured_occlusion_radius;
+  if (p->use_depth_scaling) {  // distances are multiples of the point's depth: a fixed number of pixels
+    *reach_m = 0.0f;
+    *reach_px = 1.1f * distance * fu + 2.0f;
+  } else {
+    *reach_m = 1.1f * distance;
+    *reach_px = 2.0f;
+  }
+}
+
+// The rectangle of one body in one camera.  body2camera = 4 x 4 column-major pose of the body frame in the camera
+// frame; box_min / box_max = a box in the body frame that holds every point the modality works with (the data points
+// of its sparse viewpoint model: line and point centres are model points moved by the pose).  A perspective
+// projection maps the box into the convex hull of its projected corners as long as the box lies in front of the
+// camera; a box that reaches the camera plane gives the whole frame.  reach_px + reach_m (metres, taken at the box's
+// nearest depth) widen the hull's bounding rectangle.
+M3T_ROI_FN m3t_roi_rect m3t_roi_body(const float* body2camera, const float* box_min, const float* box_max,
+                                     const m3t_intrinsics* intr, float reach_px, float reach_m) {
+  m3t_roi_rect full = {0, 0, intr->width - 1, intr->height - 1};
+  float u_min = 3.0e38f, u_max = -3.0e38f, v_min = 3.0e38f, v_max = -3.0e38f, z_min = 3.0e38f;
+  for (int corner = 0; corner < 8; ++corner) {
+    const float bx = (corner & 1) ? box_max[0] : box_min[0];
+    const float by = (corner & 2) ? box_max[1] : box_min[1];
+    const float bz = (corner & 4) ? box_max[2] : box_min[2];
+    const float x = body2camera[0] * bx + body2camera[4] * by + body2camera[8] * bz + body2camera[12];
+    const float y = body2camera[1] * bx + body2camera[5] * by + body2camera[9] * bz + body2camera[13];
+    const float z = body2camera[2] * bx + body2camera[6] * by + body2camera[10] * bz + body2camera[14];
+    if (!(z > 1e-3f)) return full;
+    const float u = x * intr->fu / z + intr->ppu, v = y * intr->fv / z + intr->ppv;
+    u_min = u < u_min ? u : u_min;
+    u_max = u > u_max ? u : u_max;
+    v_min = v < v_min ? v : v_min;
+    v_max = v > v_max ? v : v_max;
+    z_min = z < z_min ? z : z_min;
+  }
+  const float f = intr->fu > intr->fv ? intr->fu : intr->fv;
+  const float reach = reach_px + reach_m * f / z_min + 1.0f;
+  if (!(u_min > -1.0e7f && u_max < 1.0e7f && v_min > -1.0e7f && v_max < 1.0e7f && reach < 1.0e7f)) return full;
+  m3t_roi_rect r;
+  r.x0 = (int)floorf(u_min - reach);
+  r.y0 = (int)floorf(v_min - reach);
+  r.x1 = (int)ceilf(u_max + reach);
+  r.y1 = (int)ceilf(v_max + reach);
+  if (r.x0 < 0) r.x0 = 0;
+  if (r.y0 < 0) r.y0 = 0;
+  if (r.x1 > intr->width - 1) r.x1 = intr->width - 1;
+  if (r.y1 > intr->height - 1) r.y1 = intr->height - 1;
+  return r;
+}

@@ -1,0 +1,143 @@
+"""3dobjecttracking_amd/csrc/m3t_roi.h against the oracle (CPU): the rectangle of a frame that a tracking step can read
+for a body -- the bounding box of the projected bounding sphere at the poses the step's searches run at, widened by the
+modality's reach -- really contains every pixel the path reads.  A Region + Depth sequence with measured occlusions
+(YCB parameters) is tracked twice: on the frames as rendered, and on frames whose pixels OUTSIDE the rectangles are
+replaced by noise.  Poses after every frame and the histograms at the end must be identical, bit for bit; and the
+rectangles are small enough for the statement to mean something (ROI ingest)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import scenes
+import util
+from util import syn
+
+capi = util.pkg._capi
+
+
+def roi_lib(tmp_path):
+    so = str(tmp_path / "libroi_bound.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so,
+                    os.path.join(util.ROOT, "tests", "cpp", "roi_bound.cpp")], check=True)
+    return C.CDLL(so)
+
+
+def rect(fn, pose, box, intr, params, *extra):
+    out = (C.c_int * 4)()
+    p = np.ascontiguousarray(np.asarray(pose, np.float32).T).reshape(16)  # column-major
+    lo, hi = (np.ascontiguousarray(b, np.float32) for b in box)
+    f = C.POINTER(C.c_float)
+    fn(p.ctypes.data_as(f), lo.ctypes.data_as(f), hi.ctypes.data_as(f), C.byref(intr), C.byref(params), *extra, out)
+    return list(out)
+
+
+def box_of(points):
+    """box around the centres of a sparse viewpoint model's data points ([views][points][>= 3])"""
+    c = np.asarray(points, np.float32)[..., :3].reshape(-1, 3)
+    return c.min(axis=0), c.max(axis=0)
+
+
+def union(a, b):
+    return b if a is None else [min(a[0], b[0]), min(a[1], b[1]), max(a[2], b[2]), max(a[3], b[3])]
+
+
+def track_recording_search_poses(inst, inputs, n_corr, n_update):
+    """the tracking loop of Tracker::ExecuteTrackingStep (tracker.cpp:344-364) sub-step by sub-step; returns, per frame
+    and object, the poses at which the frame was read, and the poses after every frame"""
+    read_at, after = [], []
+    inst.upload_frame(0)
+    start_poses = inst.poses()
+    assert inst.tracker.StartModalities(0)
+    for k in range(inputs.n_frames):
+        inst.upload_frame(k)
+        poses = [[p] for p in (start_poses if k == 0 else inst.poses())]
+        for c in range(n_corr):
+            for i, p in enumerate(inst.poses()):
+                poses[i].append(p)
+            assert inst.tracker.CalculateCorrespondences(k, c)
+            for u in range(n_update):
+                assert inst.tracker.CalculateGradientAndHessian(k, c, u)
+                assert inst.tracker.CalculateOptimization(k, c, u)
+        for i, p in enumerate(inst.poses()):
+            poses[i].append(p)  # CalculateResults: the histogram lines at the final pose
+        assert inst.tracker.CalculateResults(k)
+        read_at.append(poses)
+        after.append(np.stack(inst.poses()))
+    return read_at, after
+
+
+@pytest.mark.parametrize("with_depth,limit", [(False, 0.35), (True, 1.0)])
+def test_frames_scrambled_outside_the_rectangles_track_identically(tmp_path, with_depth, limit):
+    """RBOT parameters (Region, 7 x 2 iterations, scales 5 2 2 1) and YCB parameters (Region + Depth with measured
+    occlusions, considered distances up to 7 cm at fu = 1067: rectangles that nearly fill these frames)"""
+    lib = roi_lib(tmp_path)
+    inputs = scenes.Inputs(3, 5, n_divides=2, with_depth=with_depth)
+    rp = capi.RegionModalityParams(**(syn.YCB_REGION_PARAMS if with_depth else syn.RBOT_REGION_PARAMS))
+    dp = capi.DepthModalityParams(**syn.YCB_DEPTH_PARAMS)
+    intr = capi.Intrinsics(*[inputs.intr[k] for k in ("fu", "fv", "ppu", "ppv", "width", "height")])
+    tp = syn.YCB_TRACKER if with_depth else syn.RBOT_TRACKER
+    n_corr = tp["n_corr_iterations"]
+    a = scenes.Instance(util.open_oracle(), inputs, use_depth=with_depth)
+    read_at, ref = track_recording_search_poses(a, inputs, n_corr, tp["n_update_iterations"])
+    ref_hist = [r.histograms() for r in a.region]
+    # the same trajectory through the one-call step (what the scrambled run uses)
+    b = scenes.Instance(util.open_oracle(), inputs, use_depth=with_depth)
+    b.upload_frame(0)
+    assert b.tracker.StartModalities(0)
+    for k in range(inputs.n_frames):
+        b.upload_frame(k)
+        assert b.tracker.ExecuteTrackingStep(k)
+        assert np.array_equal(np.stack(b.poses()), ref[k])
+    # frames with noise outside the rectangles
+    rng = np.random.default_rng(5)
+    scrambled = scenes.Inputs.__new__(scenes.Inputs)
+    scrambled.__dict__.update(inputs.__dict__)
+    scrambled.color = [[None] * inputs.n_frames for _ in range(inputs.n_objects)]
+    scrambled.depth = [[None] * inputs.n_frames for _ in range(inputs.n_objects)]
+    fractions = []
+    area = inputs.intr["width"] * inputs.intr["height"]
+    for i in range(inputs.n_objects):
+        region_box = box_of(inputs.region_models[inputs.model_of[i]][0])
+        depth_box = box_of(inputs.depth_models[inputs.model_of[i]][0]) if with_depth else None
+        for k in range(inputs.n_frames):
+            rc, rd = None, None
+            # read_at: [pose the frame is first looked at (histogram lines of StartModality on frame 0), the pose of
+            # every correspondence search, the final pose (histogram lines of CalculateResults)]
+            for j, pose in enumerate(read_at[k][i]):
+                c = j - 1 if 1 <= j <= n_corr else -1
+                rc = union(rc, rect(lib.roi_region_color, pose, region_box, intr, rp, C.c_int(c)))
+                if with_depth:
+                    rd = union(rd, rect(lib.roi_region_depth, pose, region_box, intr, rp))
+                    rd = union(rd, rect(lib.roi_depth, pose, depth_box, intr, dp))
+            color = rng.integers(0, 256, inputs.color[i][k].shape, dtype=np.uint8)
+            color[rc[1]:rc[3] + 1, rc[0]:rc[2] + 1] = inputs.color[i][k][rc[1]:rc[3] + 1, rc[0]:rc[2] + 1]
+            scrambled.color[i][k] = color
+            fractions.append((rc[2] - rc[0] + 1) * (rc[3] - rc[1] + 1) / area)
+            if with_depth:
+                depth = rng.integers(1, 20000, inputs.depth[i][k].shape).astype(inputs.depth[i][k].dtype)
+                depth[rd[1]:rd[3] + 1, rd[0]:rd[2] + 1] = inputs.depth[i][k][rd[1]:rd[3] + 1, rd[0]:rd[2] + 1]
+                scrambled.depth[i][k] = depth
+    c = scenes.Instance(util.open_oracle(), scrambled, use_depth=with_depth)
+    c.upload_frame(0)
+    assert c.tracker.StartModalities(0)
+    for k in range(inputs.n_frames):
+        c.upload_frame(k)
+        assert c.tracker.ExecuteTrackingStep(k)
+        assert np.array_equal(np.stack(c.poses()), ref[k]), k
+    for (fa, ba), (fb, bb) in zip([r.histograms() for r in c.region], ref_hist):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+    # the rectangles are a fraction of the frame (and a frame of noise does change the result: the check has teeth)
+    print("colour rectangles: %.3f .. %.3f of the frame" % (min(fractions), max(fractions)))
+    assert max(fractions) < limit, fractions
+    noise = scenes.Inputs.__new__(scenes.Inputs)
+    noise.__dict__.update(scrambled.__dict__)
+    noise.color = [[rng.integers(0, 256, f.shape, dtype=np.uint8) for f in row] for row in inputs.color]
+    d = scenes.Instance(util.open_oracle(), noise, use_depth=with_depth)
+    d.upload_frame(0)
+    assert d.tracker.StartModalities(0)
+    d.upload_frame(1)
+    assert d.tracker.ExecuteTrackingStep(1)
+    assert not np.array_equal(np.stack(d.poses()), ref[1])
