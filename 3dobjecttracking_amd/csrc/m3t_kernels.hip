@@ -2844,7 +2844,12 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   }
   // (first_corr_iteration > 0: a host that refreshes renderer-fed inputs between the correspondence searches
   // launches the loop one search at a time)
+  // ROI ingest: the poses this step reads its frames at (m3t_ingest.hip checks them against what was uploaded)
+  GW<float> search_poses = as_global_w(o.search_poses);
+  const bool record_poses = o.search_poses != nullptr && part == 0 && threadIdx.x < 16;
+  if (record_poses && first_corr_iteration == 0) search_poses[threadIdx.x] = pose[threadIdx.x];
   for (int c = first_corr_iteration; c < first_corr_iteration + n_corr_iterations; ++c) {
+    if (record_poses) search_poses[(c + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
     {
       const Affine b2w = load_pose(pose);
       int region_view = -1;
@@ -2933,6 +2938,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   // (every workgroup of a split object holds the same pose: the first one writes it; no other workgroup can
   // still be waiting to read the old one, it had to publish its first results before this one got here)
   if (threadIdx.x < 16 && part == 0) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
+  if (record_poses) search_poses[(first_corr_iteration + n_corr_iterations + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
   if (write_state && part == 0) {
     if (rm) {
       for (int i = threadIdx.x; i < LS_FIELDS * rm->n_lines_max; i += blockDim.x) {

@@ -20,7 +20,7 @@
 #include "../../include/m3t_types.h"
 
 #if defined(__HIPCC__)
-#define M3T_ROI_FN __device__ __forceinline__
+#define M3T_ROI_FN __host__ __device__ __forceinline__
 #else
 #define M3T_ROI_FN static inline
 #endif
