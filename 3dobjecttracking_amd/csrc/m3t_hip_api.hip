@@ -1639,6 +1639,7 @@ int m3t_hip_camera_set_ring(m3t_hip_context* ctx, int id, int n_slots) {
   c.has_image.assign(n_slots, false);
   c.last_read_step.assign(n_slots, -1);
   c.slot_is_roi.assign(n_slots, false);
+  if (ctx->roi_enabled) ctx->tables_dirty = true;  // (the rectangle table has a row per ring slot)
   ctx->cams_dirty = true;
   return M3T_OK;
 }
@@ -1738,6 +1739,7 @@ int m3t_hip_cameras_set_ring(m3t_hip_context* ctx, const int* ids, int n, int n_
     c.has_image.assign(n_slots, false);
     c.last_read_step.assign(n_slots, -1);
     c.slot_is_roi.assign(n_slots, false);
+    if (ctx->roi_enabled) ctx->tables_dirty = true;  // (the rectangle table has a row per ring slot)
   }
   ctx->slabs.push_back(std::move(slab));
   ctx->cams_dirty = true;
@@ -3431,7 +3433,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     hipLaunchKernelGGL(roi_check_kernel, dim3((ctx->n_roi_items + 63) / 64), dim3(64), 0, ctx->stream,
                        ctx->d_roi_items.as<RoiItemDev>(), ctx->n_roi_items, ctx->cams_active, int(ctx->cameras.size()),
                        ctx->d_opts.as<RigidOptDev>(), ctx->roi_n_poses, ctx->d_roi_rects.as<m3t_roi_rect>(),
-                       ctx->roi_miss_dev, int(Ctx::kRoiMissCapacity));
+                       ctx->roi_rect_slots, ctx->roi_miss_dev, int(Ctx::kRoiMissCapacity));
     HIPCHK(hipGetLastError());
   }
   if (ctx->async_ingest) {

@@ -82,7 +82,7 @@ roi_pull_kernel(const RoiItemDev* items, const int* item_first, const int* cam_i
 // which slot the step read; misses[0] = count, misses[1 ..] = body ids
 __global__ void __launch_bounds__(64)
 roi_check_kernel(const RoiItemDev* items, int n_items, const CameraDev* cams, int n_cams, const RigidOptDev* opts,
-                 int n_poses, const m3t_roi_rect* rects, int* misses, int capacity) {
+                 int n_poses, const m3t_roi_rect* rects, int n_rect_slots, int* misses, int capacity) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const RoiItemDev& it = items[i];
@@ -90,6 +90,7 @@ roi_check_kernel(const RoiItemDev* items, int n_items, const CameraDev* cams, in
   const float* poses = opts[it.opt].search_poses;
   if (!poses) return;
   const CameraDev& cam = cams[it.camera];
+  if (cam.slot >= n_rect_slots) return;  // (a ring slot added since the tables were built: whole frames only)
   const m3t_roi_rect have = rects[(size_t)cam.slot * n_cams + it.camera];
   if (have.x0 <= 0 && have.y0 <= 0 && have.x1 >= cam.width - 1 && have.y1 >= cam.height - 1) return;  // a whole frame
   const m3t_intrinsics k = roi_intrinsics(cam);
