@@ -401,10 +401,29 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
     ldlt_solve_wave<WAVE>(a, x, n, temp, trans);
     return;
   }
-  // 1. the transposition sequence: position p holds input row src
+  // 1. the transposition sequence: position p holds input row src.  Eigen's selection (the first largest of the
+  // rest, swapped to the front) leaves DISTINCT values in descending order whatever the swaps were: position p holds
+  // the row of rank p, and the ranks take N broadcasts instead of n dependent wave-wide maxima.  Equal values are
+  // reordered by the swaps themselves: those take the selection step by step.
   int src = lane;
+  int rank = 0;
+  bool tie = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (j < n) {  // uniform
+      const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), j));
+      rank += dj > d ? 1 : 0;
+      tie = tie || (dj == d && j != lane);
+    }
+  }
+  const bool distinct = __builtin_amdgcn_ballot_w64(row && tie) == 0;
+  if (distinct) {
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (j < n && __builtin_amdgcn_readlane(rank, j) == lane) src = j;
+  }
 #pragma nounroll
-  for (int k = 0; k < n; ++k) {
+  for (int k = 0; k < (distinct ? 0 : n); ++k) {
     const float key = (lane >= k && row) ? d : -1.0f;
     const float m = wave_max(key);
     const unsigned long long hits = __builtin_amdgcn_ballot_w64(key == m);
