@@ -69,7 +69,13 @@ struct RendererDev {
   uint8_t* silhouette_image;    // [image_size^2] ids (0 = nothing)
   uint32_t* packed;             // z-buffer scratch when image_size^2 words do not fit in LDS
   float* state;                 // [RS_FLOATS]
+  // triangles that survive set-up (culling, clipping against the crop), appended by focused_setup_kernel and
+  // rasterised into an LDS z-buffer by focused_resolve_kernel: [survivor_capacity] x M3T_SURVIVOR_BYTES, and their count
+  void* survivors;
+  int* n_survivors;
+  int survivor_capacity;
 };
+#define M3T_SURVIVOR_BYTES 104  /* RasterTriangle (m3t_raster.h: 10 doubles + 4 ints) + the low bits of its words */
 
 // a ColorHistograms object shared by several RegionModalities (region_modality.cpp:168-173)
 struct SharedHistogramsDev {

@@ -101,6 +101,8 @@ struct RendererH {  // FocusedBasicDepthRenderer / FocusedSilhouetteRenderer
   float z_min = 0.02f, z_max = 10.0f;
   std::vector<int> referenced;
   DevMem depth, sil, packed, state;
+  DevMem survivors, n_survivors;  // focused_setup_kernel -> focused_resolve_kernel (m3t_render.hip)
+  int survivor_capacity = 0;
   bool rendered = false;
 };
 struct SharedHistogramsH {  // a ColorHistograms object used by several RegionModalities
@@ -175,6 +177,7 @@ struct m3t_hip_context {
   std::vector<std::unique_ptr<RendererH>> renderers;
   DevMem d_renderers, d_render_region, d_render_all;  // RendererDev table; which renderers to run when
   int n_render_region = 0, n_render_all = 0;
+  int lds_raster = -1;  // focused_resolve_kernel (z-buffer in LDS) usable on this device: -1 not tried yet
   std::vector<Link> links;
   std::vector<ConstraintH> constraints;
   std::vector<SoftConstraintH> soft_constraints;
@@ -855,6 +858,18 @@ int UploadRendererTables(Ctx* ctx) {
     d.silhouette_image = h.sil.as<uint8_t>();
     d.packed = h.packed.as<uint32_t>();
     d.state = h.state.as<float>();
+    int n_triangles = 0;
+    for (int k = 0; k < d.n_bodies; ++k) n_triangles += d.n_triangles[k];
+    if (h.survivor_capacity < n_triangles || !h.n_survivors.p) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(h.survivors.alloc(std::max<size_t>(1, size_t(n_triangles)) * M3T_SURVIVOR_BYTES));
+      HIPCHK(h.n_survivors.alloc(64));
+      HIPCHK(hipMemset(h.n_survivors.p, 0, 64));
+      h.survivor_capacity = n_triangles;
+    }
+    d.survivors = h.survivors.p;
+    d.n_survivors = h.n_survivors.as<int>();
+    d.survivor_capacity = h.survivor_capacity;
   }
   HIPCHK(ctx->d_renderers.alloc(std::max<size_t>(1, n) * sizeof(RendererDev)));
   if (n) HIPCHK(hipMemcpy(ctx->d_renderers.p, table.data(), n * sizeof(RendererDev), hipMemcpyHostToDevice));
@@ -900,14 +915,34 @@ int UploadRendererTables(Ctx* ctx) {
   return M3T_OK;
 }
 
-// clear + crop, rasterise (32 slices of the triangle lists per renderer), unpack
-int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int /*largest_image_size*/) {
+// Renderings whose z-buffer fits the LDS of a CU: set-up + survivor list (32 slices of the triangle lists per renderer),
+// then one workgroup per renderer that rasterises the survivors in LDS and writes the images.  Larger ones: clear + crop,
+// rasterise into a z-buffer in memory, unpack.
+int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int largest_image_size) {
   if (n_which == 0) return M3T_OK;
-  hipLaunchKernelGGL(focused_clear_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
-                     ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
 #ifndef M3T_RASTER_SLICES
 #define M3T_RASTER_SLICES 32
 #endif
+  const size_t lds = size_t(largest_image_size) * largest_image_size * 4 + 65 * 4;
+  if (ctx->lds_raster < 0) {  // once per context (= per device)
+    ctx->lds_raster = 1;
+    if (std::getenv("M3T_HIP_NO_LDS_RASTER")) ctx->lds_raster = 0;
+    else if (hipFuncSetAttribute(reinterpret_cast<const void*>(focused_resolve_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->lds_raster = 0;
+    }
+  }
+  if (ctx->lds_raster == 1 && largest_image_size > 0 && lds <= size_t(160) * 1024) {
+    hipLaunchKernelGGL(focused_setup_kernel, dim3(M3T_RASTER_SLICES, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                       ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
+    hipLaunchKernelGGL(focused_resolve_kernel, dim3(n_which), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
+                       ctx->d_renderers.as<RendererDev>(), which);
+    HIPCHK(hipGetLastError());
+    return M3T_OK;
+  }
+  hipLaunchKernelGGL(focused_clear_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                     ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
   hipLaunchKernelGGL(focused_raster_kernel, dim3(M3T_RASTER_SLICES, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                      ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
   hipLaunchKernelGGL(focused_unpack_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,

@@ -174,6 +174,117 @@ focused_raster_kernel(const RendererDev* renderers, const int* which, const Came
   }
 }
 
+// ---- the two-launch form, used when the z-buffer of a rendering fits the LDS of a CU (image_size <= 200) ----
+// Of a finely tessellated body most triangles never reach a pixel (tools/raster_stats.py: 1 000 - 1 300 of 20 950 on
+// the probe scene; the rest face away or lie outside the crop), and the survivors' boxes hold ~55 000 pixels in all:
+// little work, spread thin.  focused_setup_kernel (grid: slices x renderers) does the set-up and APPENDS the survivors
+// to a list; focused_resolve_kernel (one workgroup per renderer) clears a z-buffer in LDS, rasterises the list into it
+// with LDS atomics, and writes the depth and id images: no clear launch, no global atomics, no unpack launch.  The
+// words and their minimum are those of the three-launch form.
+struct RasterSurvivor {
+  RasterTriangle tri;
+  uint32_t low_bits, pad;
+};
+static_assert(sizeof(RasterSurvivor) == M3T_SURVIVOR_BYTES, "M3T_SURVIVOR_BYTES");
+
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+focused_setup_kernel(const RendererDev* renderers, const int* which, const CameraDev* cams, const float* body_poses) {
+  const RendererDev& r = renderers[which[blockIdx.y]];
+  const CameraDev& cam = cams[r.camera];
+  const FocusedProjection f = focused_projection(r, cam, body_poses);
+  if (threadIdx.x == 0 && blockIdx.x == 0) {  // the crop, for the modalities that read the rendering
+    r.state[RS_CORNER_U] = f.corner_u;
+    r.state[RS_CORNER_V] = f.corner_v;
+    r.state[RS_SCALE] = f.scale;
+    r.state[RS_TERM_A] = r.z_max * r.z_min * 65535.0f / (r.z_max - r.z_min);  // renderer.cpp:567-570
+    r.state[RS_TERM_B] = r.z_max * 65535.0f / (r.z_max - r.z_min);
+    r.state[RS_N_VISIBLE] = (float)f.n_visible;
+    for (int k = 0; k < M3T_MAX_RENDERER_BODIES; ++k)
+      r.state[RS_VISIBLE0 + k] = (f.visible_mask >> k & 1u) ? 1.0f : 0.0f;
+  }
+  if (f.n_visible == 0) return;  // block-uniform
+  const int S = r.image_size;
+  RasterSurvivor* list = static_cast<RasterSurvivor*>(r.survivors);
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & (kWave - 1);
+  for (int order = 0; order < r.n_bodies; ++order) {
+    const M44 trans = mul44(f.P, mul44(load44(cam.world2camera),
+                                       mul44(load44(body_poses + 16 * r.body[order]), load44(r.geometry2body[order]))));
+    const uint32_t low_bits = ((uint32_t)order << 8) | (r.silhouette ? (uint32_t)r.id[order] : 0u);
+    const float* vertices = r.vertices[order];
+    const int* triangles = r.triangles[order];
+    const bool culling = r.culling[order] != 0;
+    const int per_slice = (r.n_triangles[order] + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per_slice;
+    const int t_end = min(t_begin + per_slice, r.n_triangles[order]);
+    for (int base = t_begin; base < t_end; base += nt) {
+      const int t = base + tid;
+      RasterSurvivor sv;
+      const bool ok = t < t_end && raster_setup(trans, vertices, triangles, t, culling, S, sv.tri);
+      // one atomic per wave: the lanes with a survivor take consecutive entries
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+      if (mask == 0) continue;  // wave-uniform
+      int first = 0;
+      if (lane == 0) first = atomicAdd(r.n_survivors, __builtin_popcountll(mask));
+      first = __builtin_amdgcn_readfirstlane(first);
+      if (ok) {
+        const int at = first + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (at < r.survivor_capacity) {
+          sv.low_bits = low_bits;
+          sv.pad = 0;
+          list[at] = sv;
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+focused_resolve_kernel(const RendererDev* renderers, const int* which) {
+  extern __shared__ uint32_t lds_z[];  // [S * S] packed words, then the queue of large triangles
+  constexpr int kQueue = 64, kPiece = 32;
+  const RendererDev& r = renderers[which[blockIdx.x]];
+  const int S = r.image_size, n_px = S * S;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int* queue = reinterpret_cast<int*>(lds_z + n_px);
+  int* n_queued = queue + kQueue;
+  for (int i = tid; i < n_px; i += nt) lds_z[i] = 0xffffffffu;
+  const int n = min(*r.n_survivors, r.survivor_capacity);
+  const RasterSurvivor* list = static_cast<const RasterSurvivor*>(r.survivors);
+  auto sink = [S](int px, int py, uint32_t word) { atomicMin(&lds_z[py * S + px], word); };
+  for (int base = 0; base < n; base += nt) {  // block-uniform trip count
+    if (tid == 0) *n_queued = 0;
+    __syncthreads();  // (also: the cleared z-buffer, the first time)
+    const int i = base + tid;
+    if (i < n) {
+      const RasterSurvivor sv = list[i];
+      const int pixels = (sv.tri.x1 - sv.tri.x0 + 1) * (sv.tri.y1 - sv.tri.y0 + 1);
+      int slot = kQueue;
+      if (pixels > 192) slot = atomicAdd(n_queued, 1);
+      if (slot < kQueue) queue[slot] = i;
+      else
+        for (int py = sv.tri.y0; py <= sv.tri.y1; ++py) raster_row(sv.tri, py, sv.tri.x0, sv.tri.x1, sv.low_bits, sink);
+    }
+    __syncthreads();
+    const int nq = min(*n_queued, kQueue);
+    for (int q = 0; q < nq; ++q) {  // a large box: 32-pixel pieces of its rows over the whole workgroup
+      const RasterSurvivor big = list[queue[q]];
+      const int pieces = (big.tri.x1 - big.tri.x0 + kPiece) / kPiece, total = pieces * (big.tri.y1 - big.tri.y0 + 1);
+      for (int k = tid; k < total; k += nt) {
+        const int row = k / pieces, xa = big.tri.x0 + (k - row * pieces) * kPiece;
+        raster_row(big.tri, big.tri.y0 + row, xa, min(xa + kPiece - 1, big.tri.x1), big.low_bits, sink);
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = tid; i < n_px; i += nt) {
+    const uint32_t v = lds_z[i];
+    r.depth_image[i] = v == 0xffffffffu ? (uint16_t)65535 : (uint16_t)(v >> 16);
+    r.silhouette_image[i] = v == 0xffffffffu ? (uint8_t)0 : (uint8_t)(v & 0xffu);
+  }
+  if (tid == 0) *r.n_survivors = 0;  // for the next rendering
+}
+
 // 3/3: unpack into the u16 depth image and the u8 id image (grid: 16 x renderers)
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 focused_unpack_kernel(const RendererDev* renderers, const int* which) {
