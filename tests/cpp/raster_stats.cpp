@@ -33,3 +33,32 @@ void raster_stats(const float* trans16, const float* vertices, const int* triang
   }
 }
 }
+
+// The whole rendering of one body list into a z-buffer the way focused_setup_kernel + focused_resolve_kernel do it
+// (set-up, survivors, row scan, minimum of the packed words, unpack), for tests/test_raster_scene.py: against the
+// oracle's focused renderer on the same scene.  packed: [S * S] words, 0xffffffff = nothing (the caller clears it).
+extern "C" void raster_body(const float* trans16, const float* vertices, const int* triangles, int n_triangles, int culling,
+                            int S, unsigned low_bits, unsigned* packed) {
+  RasterM44 trans;
+  for (int i = 0; i < 16; ++i) trans.m[i] = trans16[i];
+  std::vector<RasterTriangle> survivors;
+  for (int t = 0; t < n_triangles; ++t) {
+    RasterTriangle tri;
+    if (raster_setup(trans, vertices, triangles, t, culling != 0, S, tri)) survivors.push_back(tri);
+  }
+  auto sink = [&](int px, int py, uint32_t word) {
+    if (word < packed[py * S + px]) packed[py * S + px] = word;
+  };
+  for (const RasterTriangle& tri : survivors) {
+    const int pixels = (tri.x1 - tri.x0 + 1) * (tri.y1 - tri.y0 + 1);
+    if (pixels <= 192) {
+      for (int py = tri.y0; py <= tri.y1; ++py) raster_row(tri, py, tri.x0, tri.x1, low_bits, sink);
+    } else {  // the workgroup path: 32-pixel pieces of the rows
+      const int pieces = (tri.x1 - tri.x0 + 32) / 32, total = pieces * (tri.y1 - tri.y0 + 1);
+      for (int k = 0; k < total; ++k) {
+        const int row = k / pieces, xa = tri.x0 + (k - row * pieces) * 32;
+        raster_row(tri, tri.y0 + row, xa, xa + 31 < tri.x1 ? xa + 31 : tri.x1, low_bits, sink);
+      }
+    }
+  }
+}
