@@ -308,6 +308,9 @@ _HIP_ONLY = {
     "comm_get_allreduce_count": [C.POINTER(C.c_longlong)],
     "cameras_set_ring": [c_int_p, C.c_int, C.c_int],
     "cameras_upload_batch_async": [c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t],
+    "set_roi_ingest": [C.c_int, C.c_float],
+    "cameras_upload_batch_roi_async": [c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t],
+    "roi_get_status": [c_int_p, C.c_int, c_int_p, C.POINTER(C.c_longlong)],
     "camera_select_slot": [C.c_int, C.c_int],
     "cameras_select_slot": [C.c_int],
     "set_kernel_timing": [C.c_int],
@@ -337,7 +340,8 @@ def pose_ret(buf):
     return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
 
 
-_NEWER_ENTRY_POINTS = ("get_step_kernel", "comm_get_allreduce_count", "debug_log_checksum")
+_NEWER_ENTRY_POINTS = ("get_step_kernel", "comm_get_allreduce_count", "debug_log_checksum", "set_roi_ingest",
+                       "cameras_upload_batch_roi_async", "roi_get_status")
 
 
 class CApi:

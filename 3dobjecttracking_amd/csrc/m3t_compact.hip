@@ -454,7 +454,12 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
   CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
   CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
   CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
+  // ROI ingest: the poses this step reads its frames at (m3t_ingest.hip checks them against what was uploaded)
+  GW<float> search_poses = as_global_w(o.search_poses);
+  const bool record_poses = o.search_poses != nullptr && threadIdx.x < 16;
+  if (record_poses) search_poses[threadIdx.x] = pose[threadIdx.x];
   for (int c = 0; c < n_corr_iterations; ++c) {
+    if (record_poses) search_poses[(c + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
     {
       const Affine b2w = load_pose(pose);
       int region_view = -1;
@@ -495,6 +500,7 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
     }
   }
   if (threadIdx.x < 16) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
+  if (record_poses) search_poses[(n_corr_iterations + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
   if (fuse_histogram && rm) {
     // RegionModality::CalculateResults :572-583 in the same launch: the carve-up is free now (first 1024 floats =
     // the scratch block of region_histogram_update).  While this workgroup streams its histograms through the blend,

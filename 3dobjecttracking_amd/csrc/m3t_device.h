@@ -44,6 +44,7 @@ struct CameraDev {
   float fu, fv, ppu, ppv;
   float depth_scale;
   float world2camera[16];  // column-major
+  int slot;                // which slot of the camera's frame ring `image` is (ROI ingest: whose rectangle applies)
 };
 
 // FocusedBasicDepthRenderer / FocusedSilhouetteRenderer (renderer.h:180-330) on the device
@@ -68,7 +69,13 @@ struct RendererDev {
   uint8_t* silhouette_image;    // [image_size^2] ids (0 = nothing)
   uint32_t* packed;             // z-buffer scratch when image_size^2 words do not fit in LDS
   float* state;                 // [RS_FLOATS]
+  // triangles that survive set-up (culling, clipping against the crop), appended by focused_setup_kernel and
+  // rasterised into an LDS z-buffer by focused_resolve_kernel: [survivor_capacity] x M3T_SURVIVOR_BYTES, and their count
+  void* survivors;
+  int* n_survivors;
+  int survivor_capacity;
 };
+#define M3T_SURVIVOR_BYTES 104  /* RasterTriangle (m3t_raster.h: 10 doubles + 4 ints) + the low bits of its words */
 
 // a ColorHistograms object shared by several RegionModalities (region_modality.cpp:168-173)
 struct SharedHistogramsDev {
@@ -163,6 +170,17 @@ struct RigidOptDev {
   int region_modality;  // index into RegionModDev table or -1
   int depth_modality;   // index into DepthModDev table or -1
   float tikhonov_rotation, tikhonov_translation;
+  // ROI ingest (m3t_ingest.hip): where the fused kernels leave the poses a step read its frames at --
+  // [n_corr_iterations + 2][16]: start of the step, every correspondence search, the final pose -- or null
+  float* search_poses;
+};
+
+// ROI ingest: one reader of a camera's frames = one modality of one body (m3t_roi.h)
+struct RoiItemDev {
+  int camera, body;
+  int opt;                       // the rigid optimizer whose search poses apply (-1: none recorded)
+  float box_min[3], box_max[3];  // around the data points of the modality's model, body frame
+  float reach_px, reach_m;       // the modality's reach (m3t_roi.h), without the caller's margin
 };
 
 // LDS carve-up of the tracking kernels, computed on the host from the maxima

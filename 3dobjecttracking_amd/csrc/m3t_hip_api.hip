@@ -24,6 +24,7 @@
 #include "m3t_render.hip"
 #include "m3t_modelgen.hip"
 #include "m3t_links.hip"
+#include "m3t_ingest.hip"
 
 namespace {
 
@@ -59,6 +60,7 @@ struct Model {
   DevMem points, orientations, extents;
   DevMem points8, orientations4;  // device-only compact copies of the hot fields
   std::vector<float> h_orientations;  // host copy: modalities whose models share their view table share the view search
+  float box_min[3] = {0, 0, 0}, box_max[3] = {0, 0, 0};  // around the centres of all data points (ROI ingest, m3t_roi.h)
 };
 
 struct Camera {
@@ -71,6 +73,7 @@ struct Camera {
   int n_slots = 1, current = 0;
   std::vector<bool> has_image;
   std::vector<long> last_read_step;  // per slot: the last streaming step that read it (-1: none)
+  std::vector<bool> slot_is_roi;     // per slot: only the trackers' rectangle of the frame was uploaded (m3t_ingest.hip)
   DevMem ring;          // this camera's own frame ring, or empty when it lives in a shared slab
   int slab = -1, slab_index = 0;  // shared slab (m3t_hip_cameras_set_ring): [slot][camera of the group][frame]
   uint8_t* frames = nullptr;      // slot 0 of this camera
@@ -98,6 +101,8 @@ struct RendererH {  // FocusedBasicDepthRenderer / FocusedSilhouetteRenderer
   float z_min = 0.02f, z_max = 10.0f;
   std::vector<int> referenced;
   DevMem depth, sil, packed, state;
+  DevMem survivors, n_survivors;  // focused_setup_kernel -> focused_resolve_kernel (m3t_render.hip)
+  int survivor_capacity = 0;
   bool rendered = false;
 };
 struct SharedHistogramsH {  // a ColorHistograms object used by several RegionModalities
@@ -172,6 +177,7 @@ struct m3t_hip_context {
   std::vector<std::unique_ptr<RendererH>> renderers;
   DevMem d_renderers, d_render_region, d_render_all;  // RendererDev table; which renderers to run when
   int n_render_region = 0, n_render_all = 0;
+  int lds_raster = -1;  // focused_resolve_kernel (z-buffer in LDS) usable on this device: -1 not tried yet
   std::vector<Link> links;
   std::vector<ConstraintH> constraints;
   std::vector<SoftConstraintH> soft_constraints;
@@ -226,6 +232,21 @@ struct m3t_hip_context {
   bool compact_possible = false;       // every modality fits the kernel's assumptions (UploadTables)
   bool compact_fuses_histogram = false;  // ... and the count table fits next to the scratch block (<= 16 bins)
   const char* last_step_kernel = "";   // m3t_hip_get_step_kernel
+  // ROI ingest (m3t_ingest.hip): rectangles instead of whole frames
+  bool roi_enabled = false;        // m3t_hip_set_roi_ingest
+  float roi_margin_px = 0.0f;
+  bool roi_recorded = false;       // the last step left its search poses (a fused rigid launch): the next pull may use them
+  int roi_n_poses = 0;             // n_corr_iterations + 2
+  int n_roi_items = 0;
+  long long roi_pulls = 0;         // batch-frames uploaded as rectangles so far
+  DevMem d_search_poses, d_roi_items, d_roi_item_first, d_roi_cam_ids, d_roi_rects, d_roi_pose_snapshot;
+  std::vector<int> roi_cam_ids;    // what d_roi_cam_ids holds
+  int roi_rect_slots = 0;          // d_roi_rects: [slot][camera id]
+  hipEvent_t roi_snapshot_done = nullptr;
+  bool roi_snapshot_valid = false;
+  int* roi_miss_host = nullptr;             // mapped: [0] count, [1 ..] body ids
+  int* roi_miss_dev = nullptr;
+  static constexpr int kRoiMissCapacity = 255;
   int np_max = 0, off_points = 0;
   size_t lds_track = 0, lds_corr = 0, lds_hist = 0, lds_depth = 0;
   bool hist_counts_in_lds = true;
@@ -380,6 +401,15 @@ int CreateModel(Ctx* ctx, bool region, int n_views, int n_points, const float* p
   m->max_radius_depth_offset = max_radius;
   for (int v = 0; v < n_views; ++v) m->max_extent = std::max(m->max_extent, ext[v]);
   m->h_orientations.assign(ori, ori + size_t(n_views) * 3);
+  for (int k = 0; k < 3; ++k) {
+    m->box_min[k] = 3.0e38f;
+    m->box_max[k] = -3.0e38f;
+  }
+  for (size_t i = 0; i < size_t(n_views) * n_points; ++i)
+    for (int k = 0; k < 3; ++k) {
+      m->box_min[k] = std::min(m->box_min[k], pts[i * m->point_floats + k]);
+      m->box_max[k] = std::max(m->box_max[k], pts[i * m->point_floats + k]);
+    }
   size_t pb = size_t(n_views) * n_points * m->point_floats * 4;
   HIPCHK(m->points.alloc(pb));
   HIPCHK(m->orientations.alloc(size_t(n_views) * 12));
@@ -426,6 +456,7 @@ int CreateCamera(Ctx* ctx, const m3t_intrinsics* intr, const float* w2c, bool de
   c->n_slots = 1;
   c->has_image.assign(1, false);
   c->last_read_step.assign(1, -1);
+  c->slot_is_roi.assign(1, false);
   HIPCHK(c->ring.alloc(c->frame_bytes + 64));  // +64: pixels are fetched as one 4-byte load (B,G,R,+1)
   c->frames = c->ring.as<uint8_t>();
   c->slot_stride = c->frame_bytes;
@@ -433,6 +464,8 @@ int CreateCamera(Ctx* ctx, const m3t_intrinsics* intr, const float* w2c, bool de
   ctx->cams_dirty = true;
   return int(ctx->cameras.size()) - 1;
 }
+
+void RoiMarkWholeFrame(Ctx* ctx, int camera, int slot, hipStream_t stream);  // (ROI ingest, below)
 
 int UploadFrame(Ctx* ctx, int id, int slot, const void* pixels, size_t row_step) {
   REQUIRE(id >= 0 && id < int(ctx->cameras.size()) && pixels, M3T_ERR_INVALID_ARGUMENT, "bad camera id");
@@ -443,6 +476,7 @@ int UploadFrame(Ctx* ctx, int id, int slot, const void* pixels, size_t row_step)
   uint8_t* dst = c.frame(slot);
   HIPCHK(hipMemcpy2DAsync(dst, c.pitch, pixels, row_step, row, c.intr.height, hipMemcpyHostToDevice, ctx->stream));
   // the host buffer is only borrowed for the duration of the call
+  RoiMarkWholeFrame(ctx, id, slot, ctx->stream);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   c.has_image[slot] = true;
   return M3T_OK;
@@ -824,6 +858,18 @@ int UploadRendererTables(Ctx* ctx) {
     d.silhouette_image = h.sil.as<uint8_t>();
     d.packed = h.packed.as<uint32_t>();
     d.state = h.state.as<float>();
+    int n_triangles = 0;
+    for (int k = 0; k < d.n_bodies; ++k) n_triangles += d.n_triangles[k];
+    if (h.survivor_capacity < n_triangles || !h.n_survivors.p) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(h.survivors.alloc(std::max<size_t>(1, size_t(n_triangles)) * M3T_SURVIVOR_BYTES));
+      HIPCHK(h.n_survivors.alloc(64));
+      HIPCHK(hipMemset(h.n_survivors.p, 0, 64));
+      h.survivor_capacity = n_triangles;
+    }
+    d.survivors = h.survivors.p;
+    d.n_survivors = h.n_survivors.as<int>();
+    d.survivor_capacity = h.survivor_capacity;
   }
   HIPCHK(ctx->d_renderers.alloc(std::max<size_t>(1, n) * sizeof(RendererDev)));
   if (n) HIPCHK(hipMemcpy(ctx->d_renderers.p, table.data(), n * sizeof(RendererDev), hipMemcpyHostToDevice));
@@ -869,12 +915,35 @@ int UploadRendererTables(Ctx* ctx) {
   return M3T_OK;
 }
 
-// clear + crop, rasterise (32 slices of the triangle lists per renderer), unpack
-int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int /*largest_image_size*/) {
+// Renderings whose z-buffer fits the LDS of a CU: set-up + survivor list (32 slices of the triangle lists per renderer),
+// then one workgroup per renderer that rasterises the survivors in LDS and writes the images.  Larger ones: clear + crop,
+// rasterise into a z-buffer in memory, unpack.
+int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int largest_image_size) {
   if (n_which == 0) return M3T_OK;
+#ifndef M3T_RASTER_SLICES
+#define M3T_RASTER_SLICES 32
+#endif
+  const size_t lds = size_t(largest_image_size) * largest_image_size * 4 + 65 * 4;
+  if (ctx->lds_raster < 0) {  // once per context (= per device)
+    ctx->lds_raster = 1;
+    if (std::getenv("M3T_HIP_NO_LDS_RASTER")) ctx->lds_raster = 0;
+    else if (hipFuncSetAttribute(reinterpret_cast<const void*>(focused_resolve_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->lds_raster = 0;
+    }
+  }
+  if (ctx->lds_raster == 1 && largest_image_size > 0 && lds <= size_t(160) * 1024) {
+    hipLaunchKernelGGL(focused_setup_kernel, dim3(M3T_RASTER_SLICES, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                       ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
+    hipLaunchKernelGGL(focused_resolve_kernel, dim3(n_which), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
+                       ctx->d_renderers.as<RendererDev>(), which);
+    HIPCHK(hipGetLastError());
+    return M3T_OK;
+  }
   hipLaunchKernelGGL(focused_clear_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                      ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
-  hipLaunchKernelGGL(focused_raster_kernel, dim3(32, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+  hipLaunchKernelGGL(focused_raster_kernel, dim3(M3T_RASTER_SLICES, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                      ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
   hipLaunchKernelGGL(focused_unpack_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                      ctx->d_renderers.as<RendererDev>(), which);
@@ -890,6 +959,101 @@ int RenderForModalities(Ctx* ctx, bool region_only) {
   for (auto& r : ctx->renderers) r->rendered = true;
   return LaunchRenderers(ctx, region_only ? ctx->d_render_region.as<int>() : ctx->d_render_all.as<int>(),
                          region_only ? ctx->n_render_region : ctx->n_render_all, LargestRendererImage(ctx));
+}
+
+// ROI ingest: the readers of every camera (one per modality of a rigid optimizer: which body, which box of model
+// points, which reach -- m3t_roi.h) sorted by camera, and where the fused kernels leave their search poses.
+// Called while the optimizer table is being rebuilt.
+int BuildRoiTables(Ctx* ctx) {
+  ctx->n_roi_items = 0;
+  ctx->roi_recorded = false;
+  ctx->roi_snapshot_valid = false;
+  for (auto& od : ctx->opt_table) od.search_poses = nullptr;
+  if (!ctx->roi_enabled || ctx->tree_mode || ctx->opt_table.empty()) return M3T_OK;
+  ctx->roi_n_poses = ctx->n_corr_iterations + 2;
+  const size_t per_object = size_t(ctx->roi_n_poses) * 16;
+  HIPCHK(ctx->d_search_poses.alloc(ctx->opt_table.size() * per_object * 4));
+  HIPCHK(hipMemset(ctx->d_search_poses.p, 0, ctx->opt_table.size() * per_object * 4));
+  std::vector<RoiItemDev> items;
+  auto add = [&](int camera, int body, int opt, const Model& model, float reach_px, float reach_m) {
+    RoiItemDev it{};
+    it.camera = camera;
+    it.body = body;
+    it.opt = opt;
+    for (int k = 0; k < 3; ++k) {
+      it.box_min[k] = model.box_min[k];
+      it.box_max[k] = model.box_max[k];
+    }
+    it.reach_px = reach_px;
+    it.reach_m = reach_m;
+    items.push_back(it);
+  };
+  for (size_t oi = 0; oi < ctx->opt_table.size(); ++oi) {
+    RigidOptDev& od = ctx->opt_table[oi];
+    od.search_poses = ctx->d_search_poses.as<float>() + oi * per_object;
+    if (od.region_modality >= 0) {
+      const RegionMod& m = *ctx->region_mods[od.region_modality];
+      const Model& model = *ctx->region_models[m.model];
+      float reach = m3t_roi_region_histogram_reach(&m.p);
+      for (int c = 0; c < ctx->n_corr_iterations; ++c) reach = std::max(reach, m3t_roi_region_line_reach(&m.p, c));
+      add(m.camera, od.body, int(oi), model, reach, 0.0f);
+      if (m.p.measure_occlusions) {
+        float reach_m = 0.0f, reach_px = 0.0f;
+        m3t_roi_region_depth_reach(&m.p, &reach_m, &reach_px);
+        add(m.depth_camera, od.body, int(oi), model, reach_px, reach_m);
+      }
+    }
+    if (od.depth_modality >= 0) {
+      const DepthMod& m = *ctx->depth_mods[od.depth_modality];
+      float reach_m = 0.0f, reach_px = 0.0f;
+      m3t_roi_depth_reach(&m.p, ctx->cameras[m.camera]->intr.fu, &reach_m, &reach_px);
+      add(m.camera, od.body, int(oi), *ctx->depth_models[m.model], reach_px, reach_m);
+    }
+  }
+  std::stable_sort(items.begin(), items.end(), [](const RoiItemDev& a, const RoiItemDev& b) { return a.camera < b.camera; });
+  const size_t n_cams = ctx->cameras.size();
+  std::vector<int> first(n_cams + 1, 0);
+  for (auto& it : items) ++first[size_t(it.camera) + 1];
+  for (size_t c = 0; c < n_cams; ++c) first[c + 1] += first[c];
+  HIPCHK(ctx->d_roi_items.alloc(std::max<size_t>(1, items.size()) * sizeof(RoiItemDev)));
+  HIPCHK(ctx->d_roi_item_first.alloc(first.size() * sizeof(int)));
+  if (!items.empty())
+    HIPCHK(hipMemcpy(ctx->d_roi_items.p, items.data(), items.size() * sizeof(RoiItemDev), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_roi_item_first.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+  ctx->n_roi_items = int(items.size());
+  int slots = 1;
+  for (auto& c : ctx->cameras) slots = std::max(slots, c->n_slots);
+  ctx->roi_rect_slots = slots;
+  HIPCHK(ctx->d_roi_rects.alloc(size_t(slots) * n_cams * sizeof(m3t_roi_rect)));
+  HIPCHK(ctx->d_roi_pose_snapshot.alloc(std::max<size_t>(64, ctx->body_poses.size() * 4)));
+  if (!ctx->roi_snapshot_done) HIPCHK(hipEventCreateWithFlags(&ctx->roi_snapshot_done, hipEventDisableTiming));
+  {  // what every slot holds now: a whole frame, or (a rectangle from before the rebuild) nothing that can be vouched for
+    std::vector<m3t_roi_rect> rects(size_t(slots) * n_cams, m3t_roi_empty());
+    for (size_t c = 0; c < n_cams; ++c)
+      for (int sl = 0; sl < ctx->cameras[c]->n_slots; ++sl)
+        if (!ctx->cameras[c]->slot_is_roi[sl])
+          rects[size_t(sl) * n_cams + c] = m3t_roi_rect{0, 0, ctx->cameras[c]->intr.width - 1, ctx->cameras[c]->intr.height - 1};
+    HIPCHK(hipMemcpy(ctx->d_roi_rects.p, rects.data(), rects.size() * sizeof(m3t_roi_rect), hipMemcpyHostToDevice));
+  }
+  if (!ctx->roi_miss_host) {
+    void *host = nullptr, *dev = nullptr;
+    HIPCHK(hipHostMalloc(&host, (Ctx::kRoiMissCapacity + 1) * sizeof(int), hipHostMallocMapped));
+    std::memset(host, 0, (Ctx::kRoiMissCapacity + 1) * sizeof(int));
+    HIPCHK(hipHostGetDevicePointer(&dev, host, 0));
+    ctx->roi_miss_host = static_cast<int*>(host);
+    ctx->roi_miss_dev = static_cast<int*>(dev);
+  }
+  return M3T_OK;
+}
+
+// a whole frame was (or is being, on `stream`) written into (camera, slot)
+void RoiMarkWholeFrame(Ctx* ctx, int camera, int slot, hipStream_t stream) {
+  Camera& c = *ctx->cameras[camera];
+  c.slot_is_roi[slot] = false;
+  if (!ctx->roi_enabled || ctx->n_roi_items == 0 || slot >= ctx->roi_rect_slots || ctx->tables_dirty) return;
+  hipLaunchKernelGGL(roi_set_rect_kernel, dim3(1), dim3(1), 0, stream,
+                     ctx->d_roi_rects.as<m3t_roi_rect>() + size_t(slot) * ctx->cameras.size() + camera, 0, 0,
+                     c.intr.width - 1, c.intr.height - 1);
 }
 
 int UploadTables(Ctx* ctx) {
@@ -926,6 +1090,7 @@ int UploadTables(Ctx* ctx) {
         d.height = c.intr.height;
         d.fu = c.intr.fu; d.fv = c.intr.fv; d.ppu = c.intr.ppu; d.ppv = c.intr.ppv;
         d.depth_scale = c.depth_scale;
+        d.slot = slot < 0 ? c.current : slot;
         std::memcpy(d.world2camera, c.world2camera, 64);
       }
     };
@@ -1045,6 +1210,10 @@ int UploadTables(Ctx* ctx) {
     if (depth_table_changed) {
       for (size_t i = 0; i < d.size(); ++i) d[i] = ctx->depth_mods[i]->dev;
       HIPCHK(hipMemcpy(ctx->d_depth.p, d.data(), d.size() * sizeof(DepthModDev), hipMemcpyHostToDevice));
+    }
+    {
+      int r = BuildRoiTables(ctx);  // (sets RigidOptDev::search_poses)
+      if (r) return r;
     }
     HIPCHK(ctx->d_opts.alloc(std::max<size_t>(1, ctx->opt_table.size()) * sizeof(RigidOptDev)));
     if (!ctx->opt_table.empty())
@@ -1362,6 +1531,8 @@ void m3t_hip_destroy(m3t_hip_context* ctx) {
     if (ctx->cam_stage_done[i]) (void)hipEventDestroy(ctx->cam_stage_done[i]);
   }
   if (ctx->split_abort_host) (void)hipHostFree(ctx->split_abort_host);
+  if (ctx->roi_miss_host) (void)hipHostFree(ctx->roi_miss_host);
+  if (ctx->roi_snapshot_done) (void)hipEventDestroy(ctx->roi_snapshot_done);
   if (ctx->comm && ctx->comm_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
   delete ctx;
 }
@@ -1502,6 +1673,8 @@ int m3t_hip_camera_set_ring(m3t_hip_context* ctx, int id, int n_slots) {
   c.current = 0;
   c.has_image.assign(n_slots, false);
   c.last_read_step.assign(n_slots, -1);
+  c.slot_is_roi.assign(n_slots, false);
+  if (ctx->roi_enabled) ctx->tables_dirty = true;  // (the rectangle table has a row per ring slot)
   ctx->cams_dirty = true;
   return M3T_OK;
 }
@@ -1562,6 +1735,7 @@ int m3t_hip_camera_upload_slot_async(m3t_hip_context* ctx, int id, int slot, con
     HIPCHK(hipMemcpy2DAsync(dst, c.pitch, pixels, row_step, row, c.intr.height, hipMemcpyHostToDevice,
                             ctx->copy_stream[cs]));
   c.has_image[slot] = true;
+  RoiMarkWholeFrame(ctx, id, slot, ctx->copy_stream[cs]);
   ctx->copies_pending |= 1u << cs;
   return M3T_OK;
 }
@@ -1599,6 +1773,8 @@ int m3t_hip_cameras_set_ring(m3t_hip_context* ctx, const int* ids, int n, int n_
     c.current = 0;
     c.has_image.assign(n_slots, false);
     c.last_read_step.assign(n_slots, -1);
+    c.slot_is_roi.assign(n_slots, false);
+    if (ctx->roi_enabled) ctx->tables_dirty = true;  // (the rectangle table has a row per ring slot)
   }
   ctx->slabs.push_back(std::move(slab));
   ctx->cams_dirty = true;
@@ -1656,8 +1832,108 @@ int m3t_hip_cameras_upload_batch_async(m3t_hip_context* ctx, const int* ids, int
   else
     HIPCHK(hipMemcpy2DAsync(dst, c0.pitch, base, row_step, row, size_t(c0.intr.height) * size_t(n), hipMemcpyHostToDevice,
                             ctx->copy_stream[cs]));
-  for (int i = 0; i < n; ++i) ctx->cameras[ids[i]]->has_image[slot] = true;
+  for (int i = 0; i < n; ++i) {
+    ctx->cameras[ids[i]]->has_image[slot] = true;
+    RoiMarkWholeFrame(ctx, ids[i], slot, ctx->copy_stream[cs]);
+  }
   ctx->copies_pending |= 1u << cs;
+  return M3T_OK;
+}
+// ROI ingest (m3t_ingest.hip).  enable: the fused rigid launches record the poses their searches run at,
+// and m3t_hip_cameras_upload_batch_roi_async may upload rectangles instead of frames; margin_px: how far (in pixels,
+// in every direction) the trackers' rectangle may move between the pose it is computed from and the last pose of
+// the step that reads the frame, i.e. two frames of motion.
+int m3t_hip_set_roi_ingest(m3t_hip_context* ctx, int enable, float margin_px) {
+  CHECK_CTX();
+  REQUIRE(margin_px >= 0.0f && margin_px < 1.0e6f, M3T_ERR_INVALID_ARGUMENT, "bad margin");
+  if ((enable != 0) != ctx->roi_enabled) ctx->tables_dirty = true;
+  ctx->roi_enabled = enable != 0;
+  ctx->roi_margin_px = margin_px;
+  return M3T_OK;
+}
+// m3t_hip_cameras_upload_batch_async for the trackers' rectangles only: ONE kernel on the copy stream computes every
+// camera's rectangle from the bodies' poses as of the start of the step enqueued last, and pulls its rows out of the
+// mapped, page-locked host block.  Whole frames are uploaded instead (same result, more bytes) whenever the
+// conditions are not met: ROI ingest off, no recorded step yet, cameras not in one slab in this order, a host block
+// that is not registered, or strides that are not multiples of 16 bytes.
+int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context* ctx, const int* ids, int n, int slot, const void* base,
+                                           size_t camera_stride, size_t row_step) {
+  CHECK_CTX();
+  REQUIRE(ids && n >= 1 && base, M3T_ERR_INVALID_ARGUMENT, "bad arguments");
+  bool pull = ctx->roi_enabled && ctx->roi_recorded && ctx->roi_snapshot_valid && ctx->n_roi_items > 0 &&
+              !ctx->tables_dirty && !ctx->cams_dirty && ctx->async_ingest;
+  for (int i = 0; i < n && pull; ++i) {
+    if (ids[i] < 0 || ids[i] >= int(ctx->cameras.size())) { pull = false; break; }
+    const Camera& c = *ctx->cameras[ids[i]];
+    const Camera& c0 = *ctx->cameras[ids[0]];
+    if (slot < 0 || slot >= c.n_slots || slot >= ctx->roi_rect_slots) pull = false;
+    if (c.slab < 0 || c.slab != c0.slab || c.slab_index != c0.slab_index + i) pull = false;
+  }
+  const uint8_t* src = nullptr;
+  if (pull) {
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, const_cast<void*>(base), 0) != hipSuccess) {
+      (void)hipGetLastError();
+      pull = false;
+    }
+    src = static_cast<const uint8_t*>(dev);
+  }
+  if (pull) {
+    const Camera& c0 = *ctx->cameras[ids[0]];
+    const size_t row = size_t(c0.intr.width) * (c0.is_depth ? 2 : 3), row16 = (row + 15) / 16 * 16;
+    if (reinterpret_cast<uintptr_t>(src) % 16 || camera_stride % 16 || row_step % 16 || c0.pitch % 16 ||
+        c0.frame_bytes % 16 || reinterpret_cast<uintptr_t>(c0.frame(slot)) % 16 || row16 > row_step || row16 > c0.pitch)
+      pull = false;
+  }
+  if (!pull) return m3t_hip_cameras_upload_batch_async(ctx, ids, n, slot, base, camera_stride, row_step);
+  HIPCHK(hipSetDevice(ctx->device));
+  const int cs = 0;
+  if (ctx->roi_cam_ids != std::vector<int>(ids, ids + n)) {  // (rare: the batch's camera list changed)
+    HIPCHK(hipStreamSynchronize(ctx->copy_stream[cs]));
+    ctx->roi_cam_ids.assign(ids, ids + n);
+    HIPCHK(ctx->d_roi_cam_ids.alloc(size_t(n) * sizeof(int)));
+    HIPCHK(hipMemcpy(ctx->d_roi_cam_ids.p, ids, size_t(n) * sizeof(int), hipMemcpyHostToDevice));
+  }
+  long last_read = -1;
+  for (int i = 0; i < n; ++i) last_read = std::max(last_read, ctx->cameras[ids[i]]->last_read_step[slot]);
+  if (ctx->untracked_launches) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->untracked_launches = false;
+  } else if (last_read > ctx->copy_waited_step[cs]) {  // overwrite only after the last step that read this slot
+    HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->step_done[last_read % Ctx::kStepEvents], 0));
+    ctx->copy_waited_step[cs] = last_read;
+  }
+  HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->roi_snapshot_done, 0));  // the poses the rectangles come from
+  const Camera& c0 = *ctx->cameras[ids[0]];
+  // the camera table is only read for intrinsics and world2camera here: any slot version will do (the first one)
+  hipLaunchKernelGGL(roi_pull_kernel, dim3((c0.intr.height + 7) / 8, n), dim3(256), 0, ctx->copy_stream[cs],
+                     ctx->d_roi_items.as<RoiItemDev>(), ctx->d_roi_item_first.as<int>(), ctx->d_roi_cam_ids.as<int>(),
+                     ctx->d_cams.as<CameraDev>(), ctx->d_roi_pose_snapshot.as<float>(), src, camera_stride, uint32_t(row_step),
+                     c0.frame(slot), c0.frame_bytes, c0.pitch, c0.is_depth ? 2 : 3, ctx->roi_margin_px,
+                     ctx->d_roi_rects.as<m3t_roi_rect>() + size_t(slot) * ctx->cameras.size());
+  HIPCHK(hipGetLastError());
+  ++ctx->roi_pulls;
+  for (int i = 0; i < n; ++i) {
+    ctx->cameras[ids[i]]->has_image[slot] = true;
+    ctx->cameras[ids[i]]->slot_is_roi[slot] = true;
+  }
+  ctx->copies_pending |= 1u << cs;
+  return M3T_OK;
+}
+// Bodies whose last checked steps needed pixels outside the rectangle that had been uploaded (their poses since then
+// are not the whole-frame poses): up to `capacity` body ids, *n = how many there were; the list is cleared.
+int m3t_hip_roi_get_status(m3t_hip_context* ctx, int* bodies, int capacity, int* n, long long* n_rectangle_uploads) {
+  CHECK_CTX();
+  REQUIRE(n && capacity >= 0 && (bodies || capacity == 0), M3T_ERR_INVALID_ARGUMENT, "null output");
+  *n = 0;
+  if (n_rectangle_uploads) *n_rectangle_uploads = ctx->roi_pulls;
+  if (!ctx->roi_miss_host) return M3T_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int count = __atomic_load_n(&ctx->roi_miss_host[0], __ATOMIC_ACQUIRE);
+  *n = count;
+  for (int i = 0; i < std::min(std::min(count, capacity), int(Ctx::kRoiMissCapacity)); ++i) bodies[i] = ctx->roi_miss_host[1 + i];
+  std::memset(ctx->roi_miss_host, 0, (Ctx::kRoiMissCapacity + 1) * sizeof(int));
   return M3T_OK;
 }
 int m3t_hip_ingest_sync(m3t_hip_context* ctx) {
@@ -2802,6 +3078,7 @@ int m3t_hip_link_get_joint_poses(m3t_hip_context* ctx, int link, float body2join
 int m3t_hip_tracker_set_iterations(m3t_hip_context* ctx, int n_corr, int n_update) {
   CHECK_CTX();
   REQUIRE(n_corr >= 0 && n_update >= 0, M3T_ERR_INVALID_ARGUMENT, "bad iteration counts");
+  if (ctx->roi_enabled && n_corr != ctx->n_corr_iterations) ctx->tables_dirty = true;  // (the search-pose slots per object)
   ctx->n_corr_iterations = n_corr;
   ctx->n_update_iterations = n_update;
   return M3T_OK;
@@ -2970,7 +3247,20 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   ctx->untracked_launches = untracked_before;  // a whole step is tracked by its step_done event below
   if ((r = CheckSplitExchange(ctx))) return r;  // an earlier step that was abandoned on the device
   bool histogram_fused = false;
-  if (ctx->fused_mode >= 1 && ctx->fused_possible && !ctx->comm) {  // (a communicator: the structures span GPUs)
+  const bool rigid_fused = ctx->fused_mode >= 1 && ctx->fused_possible && !ctx->comm;
+  bool roi_frames = false;  // does this step read a slot that holds a rectangle only
+  for (auto& cam : ctx->cameras) roi_frames = roi_frames || cam->slot_is_roi[cam->current];
+  REQUIRE(!roi_frames || (rigid_fused && ctx->n_roi_items > 0), M3T_ERR_UNSUPPORTED,
+          "a frame slot holds the trackers' rectangle only (ROI ingest): that needs the fused step of rigid objects");
+  if (ctx->roi_enabled && ctx->n_roi_items > 0 && rigid_fused) {
+    // the poses the NEXT frame's rectangles are computed from (m3t_hip_cameras_upload_batch_roi_async, copy stream)
+    HIPCHK(hipMemcpyAsync(ctx->d_roi_pose_snapshot.p, ctx->d_poses.p, ctx->body_poses.size() * 4, hipMemcpyDeviceToDevice,
+                          ctx->stream));
+    HIPCHK(hipEventRecord(ctx->roi_snapshot_done, ctx->stream));
+    ctx->roi_snapshot_valid = true;
+  }
+  ctx->roi_recorded = ctx->roi_enabled && ctx->n_roi_items > 0 && rigid_fused;
+  if (rigid_fused) {  // (a communicator: the structures span GPUs)
     int n = int(ctx->opt_table.size());
     ScopedKernelTimer timer(ctx, 0);
     // From two objects per CU on (and if two working sets fit the CU's LDS) the kernel runs with 256-thread
@@ -3173,6 +3463,13 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   if (!histogram_fused) {
     if ((r = RenderForModalities(ctx, true))) return r;
     if ((r = LaunchHistogram(ctx, iteration, false))) return r;
+  }
+  if (roi_frames) {  // did the step stay inside the rectangles it was given?
+    hipLaunchKernelGGL(roi_check_kernel, dim3((ctx->n_roi_items + 63) / 64), dim3(64), 0, ctx->stream,
+                       ctx->d_roi_items.as<RoiItemDev>(), ctx->n_roi_items, ctx->cams_active, int(ctx->cameras.size()),
+                       ctx->d_opts.as<RigidOptDev>(), ctx->roi_n_poses, ctx->d_roi_rects.as<m3t_roi_rect>(),
+                       ctx->roi_rect_slots, ctx->roi_miss_dev, int(Ctx::kRoiMissCapacity));
+    HIPCHK(hipGetLastError());
   }
   if (ctx->async_ingest) {
     // remember which frame slots this step reads, so that a later asynchronous upload into one of

@@ -28,6 +28,7 @@
 
 #include "m3t_device.h"
 #include "m3t_log.h"
+#include "m3t_renderer_read.h"
 
 #ifdef M3T_PHASE_TIMING
 // developer instrumentation: accumulated s_memtime cycles per phase, block 0 thread 0
@@ -411,117 +412,32 @@ __device__ __forceinline__ bool renderer_body_visible(const RendererDev* r, int 
 __device__ __forceinline__ float renderer_depth(const RendererDev& r, unsigned short value) {
   return r.state[RS_TERM_A] / (r.state[RS_TERM_B] - (float)value);
 }
-// the minimum of the <= 6 x 6 strided samples of IsLineUnoccludedModeled :1391-1431 /
-// IsPointUnoccludedModeled depth_modality.cpp:778-824
-__device__ unsigned short modeled_window_min(const RendererDev& r, float center_u, float center_v, float diameter) {
-  const int size_minus_1 = r.image_size - 1;
-  int stride = f2i(diameter / M3T_MAX_N_OCCLUSION_STRIDES + 1.0f);
-  int n_strides = f2i(diameter / stride + 0.5f);
-  int rounded_diameter = n_strides * stride;
-  float rounded_radius = 0.5f * (float)rounded_diameter;
-  float focused_center_u = (center_u - r.state[RS_CORNER_U]) * r.state[RS_SCALE];
-  float focused_center_v = (center_v - r.state[RS_CORNER_V]) * r.state[RS_SCALE];
-  int u_min = f2i(focused_center_u - rounded_radius + 0.5f);
-  int v_min = f2i(focused_center_v - rounded_radius + 0.5f);
-  int u_max = u_min + rounded_diameter;
-  int v_max = v_min + rounded_diameter;
-  u_min = max(u_min, 0);
-  v_min = max(v_min, 0);
-  u_max = min(u_max, size_minus_1);
-  v_max = min(v_max, size_minus_1);
-  unsigned short min_value = 65535;
-  for (int v = v_min; v <= v_max; v += stride)
-    for (int u = u_min; u <= u_max; u += stride) {
-      unsigned short d = r.depth_image[(size_t)v * r.image_size + u];
-      min_value = d < min_value ? d : min_value;
-    }
-  return min_value;
+// The sampling loops themselves live in m3t_renderer_read.h (host-checkable): all samples of a loop are requested
+// at once, the reference's decisions follow in the reference's order.  These wrappers hand them the rendering through
+// address-space-1 pointers (global loads, not flat ones).
+__device__ __forceinline__ FocusedCrop renderer_crop(const RendererDev& r) {
+  FocusedCrop c;
+  c.corner_u = r.state[RS_CORNER_U];
+  c.corner_v = r.state[RS_CORNER_V];
+  c.scale = r.state[RS_SCALE];
+  c.image_size = r.image_size;
+  return c;
 }
-__device__ __forceinline__ int silhouette_at(const RendererDev& r, float u, float v) {  // -1: off the image
-  const float size = (float)r.image_size;
-  if (u >= size || u < 0.0f || v >= size || v < 0.0f) return -1;
-  return r.silhouette_image[(size_t)f2i(v) * r.image_size + f2i(u)];
+__device__ __forceinline__ unsigned short modeled_window_min(const RendererDev& r, float center_u, float center_v,
+                                                             float diameter) {
+  return modeled_window_min(as_global(r.depth_image), renderer_crop(r), center_u, center_v, diameter);
 }
-// IsDynamicLineRegionSufficient :1293-1341 (an off-image coordinate in the foreground loop, which the
-// reference reads unchecked, counts as another region)
-__device__ bool dynamic_line_region_sufficient(const RendererDev& r, int region_id, float min_continuous_distance,
-                                               float fscale, float center_u, float center_v, float normal_u,
-                                               float normal_v) {
-  const float scale = r.state[RS_SCALE];
-  float focused_min_continuous_distance = min_continuous_distance * fscale * scale;
-  float focused_stride = fmaxf((focused_min_continuous_distance - M3T_REGION_OFFSET) / (float)M3T_N_REGION_STRIDE, 0.0f);
-  float stride_u = focused_stride * normal_u;
-  float stride_v = focused_stride * normal_v;
-  float offset_u = M3T_REGION_OFFSET * normal_u;
-  float offset_v = M3T_REGION_OFFSET * normal_v;
-  float focused_center_u = 0.5f + (center_u - r.state[RS_CORNER_U]) * scale;
-  float focused_center_v = 0.5f + (center_v - r.state[RS_CORNER_V]) * scale;
-  float u = focused_center_u - offset_u;
-  float v = focused_center_v - offset_v;
-  for (int i = 0; i <= M3T_N_REGION_STRIDE; ++i) {
-    if (silhouette_at(r, u, v) != region_id) return false;
-    u -= stride_u;
-    v -= stride_v;
-  }
-  u = focused_center_u + offset_u;
-  v = focused_center_v + offset_v;
-  for (int i = 0; i <= M3T_N_REGION_STRIDE; ++i) {
-    int id = silhouette_at(r, u, v);
-    if (id < 0) break;
-    if (id == region_id) return false;
-    u += stride_u;
-    v += stride_v;
-  }
-  return true;
+__device__ __forceinline__ bool dynamic_line_region_sufficient(const RendererDev& r, int region_id,
+                                                               float min_continuous_distance, float fscale, float center_u,
+                                                               float center_v, float normal_u, float normal_v) {
+  return dynamic_line_region_sufficient(as_global(r.silhouette_image), renderer_crop(r), region_id, min_continuous_distance,
+                                        fscale, center_u, center_v, normal_u, normal_v);
 }
-// DynamicRegionDistance :1157-1229 (with the assignment to the *foreground* distance in the background loop)
-__device__ void dynamic_region_distance(const RendererDev& r, int region_id, float max_considered_line_length,
-                                        float unconsidered_line_length, float center_u, float center_v,
-                                        float normal_u, float normal_v, float* foreground, float* background) {
-  const float scale = r.state[RS_SCALE];
-  float stride = max_considered_line_length / (float)M3T_N_REGION_STRIDE;
-  float focused_stride = stride * scale;
-  float focused_stride_u = focused_stride * normal_u;
-  float focused_stride_v = focused_stride * normal_v;
-  float delta_start = M3T_REGION_OFFSET / scale - unconsidered_line_length;
-  int i_start = max(f2i(delta_start / stride + 1.0f), 0);
-  float offset = unconsidered_line_length + (float)i_start * stride;
-  float focused_offset = offset * scale;
-  float focused_offset_u = focused_offset * normal_u;
-  float focused_offset_v = focused_offset * normal_v;
-  float focused_center_u = 0.5f + (center_u - r.state[RS_CORNER_U]) * scale;
-  float focused_center_v = 0.5f + (center_v - r.state[RS_CORNER_V]) * scale;
-  float u = focused_center_u - focused_offset_u;
-  float v = focused_center_v - focused_offset_v;
-  for (int i = i_start; i <= M3T_N_REGION_STRIDE; ++i) {
-    int id = silhouette_at(r, u, v);
-    if (id < 0) {
-      *foreground = stride * (float)i;
-      break;
-    }
-    if (id != region_id) {
-      *foreground = i == i_start ? 0.0f : stride * (float)i;
-      break;
-    }
-    u -= focused_stride_u;
-    v -= focused_stride_v;
-  }
-  u = focused_center_u + focused_offset_u;
-  v = focused_center_v + focused_offset_v;
-  for (int i = i_start; i <= M3T_N_REGION_STRIDE; ++i) {
-    int id = silhouette_at(r, u, v);
-    if (id < 0) {
-      *background = max_considered_line_length;
-      break;
-    }
-    if (id == region_id) {
-      if (i == i_start) *background = 0.0f;
-      else *foreground = stride * (float)i;
-      break;
-    }
-    u += focused_stride_u;
-    v += focused_stride_v;
-  }
+__device__ __forceinline__ void dynamic_region_distance(const RendererDev& r, int region_id, float max_considered_line_length,
+                                                        float unconsidered_line_length, float center_u, float center_v,
+                                                        float normal_u, float normal_v, float* foreground, float* background) {
+  dynamic_region_distance(as_global(r.silhouette_image), renderer_crop(r), region_id, max_considered_line_length,
+                          unconsidered_line_length, center_u, center_v, normal_u, normal_v, foreground, background);
 }
 
 
@@ -2928,7 +2844,12 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   }
   // (first_corr_iteration > 0: a host that refreshes renderer-fed inputs between the correspondence searches
   // launches the loop one search at a time)
+  // ROI ingest: the poses this step reads its frames at (m3t_ingest.hip checks them against what was uploaded)
+  GW<float> search_poses = as_global_w(o.search_poses);
+  const bool record_poses = o.search_poses != nullptr && part == 0 && threadIdx.x < 16;
+  if (record_poses && first_corr_iteration == 0) search_poses[threadIdx.x] = pose[threadIdx.x];
   for (int c = first_corr_iteration; c < first_corr_iteration + n_corr_iterations; ++c) {
+    if (record_poses) search_poses[(c + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
     {
       const Affine b2w = load_pose(pose);
       int region_view = -1;
@@ -3017,6 +2938,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   // (every workgroup of a split object holds the same pose: the first one writes it; no other workgroup can
   // still be waiting to read the old one, it had to publish its first results before this one got here)
   if (threadIdx.x < 16 && part == 0) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
+  if (record_poses) search_poses[(first_corr_iteration + n_corr_iterations + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
   if (write_state && part == 0) {
     if (rm) {
       for (int i = threadIdx.x; i < LS_FIELDS * rm->n_lines_max; i += blockDim.x) {

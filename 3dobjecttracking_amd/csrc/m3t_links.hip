@@ -282,9 +282,16 @@ __device__ __forceinline__ TreeWork tree_carve(float* w, int n_links, int dof, i
 // links_solve_kernel its phases are separated by __syncthreads() (the work arrays may live in global memory);
 // inside tracking_step_tree_kernel (WAVE: the first wave of a 512-thread workgroup, work arrays in LDS) a wave-level
 // barrier is enough: the LDS executes one wave's instructions in order.
-template <bool WAVE>
-__device__ __forceinline__ void tree_sync() {
-  if constexpr (WAVE) {
+// MODE of the structure code: 0 = the 64-thread workgroup of links_project_kernel / links_solve_kernel, 1 = ONE wave of
+// a larger workgroup (work arrays in LDS), 2 = the WHOLE workgroup of tracking_step_tree_kernel (every loop over
+// matrix elements / links spread over all its threads; the wave-level factorisation stays on the first wave).
+template <int MODE>
+__device__ __forceinline__ int tree_lane() { return MODE == 2 ? (int)threadIdx.x : (int)(threadIdx.x & (kWave - 1)); }
+template <int MODE>
+__device__ __forceinline__ int tree_width() { return MODE == 2 ? (int)blockDim.x : kWave; }
+template <int MODE>
+__device__ __forceinline__ void tree_sync_mode() {
+  if constexpr (MODE == 1) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -292,10 +299,12 @@ __device__ __forceinline__ void tree_sync() {
     __syncthreads();
   }
 }
-// WAVE: every link's link2world in the (LDS) link table is current, body or not
 template <bool WAVE>
+__device__ __forceinline__ void tree_sync() { tree_sync_mode<WAVE ? 1 : 0>(); }
+// MODE != 0: every link's link2world in the (LDS) link table is current, body or not
+template <int MODE>
 __device__ __forceinline__ Affine tree_link_pose(const LinkDev& l, const float* body_poses) {
-  if constexpr (WAVE) return load_pose(l.link2world);
+  if constexpr (MODE != 0) return load_pose(l.link2world);
   else return link_pose(l, body_poses);
 }
 
@@ -392,10 +401,29 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
     ldlt_solve_wave<WAVE>(a, x, n, temp, trans);
     return;
   }
-  // 1. the transposition sequence: position p holds input row src
+  // 1. the transposition sequence: position p holds input row src.  Eigen's selection (the first largest of the
+  // rest, swapped to the front) leaves DISTINCT values in descending order whatever the swaps were: position p holds
+  // the row of rank p, and the ranks take N broadcasts instead of n dependent wave-wide maxima.  Equal values are
+  // reordered by the swaps themselves: those take the selection step by step.
   int src = lane;
+  int rank = 0;
+  bool tie = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (j < n) {  // uniform
+      const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), j));
+      rank += dj > d ? 1 : 0;
+      tie = tie || (dj == d && j != lane);
+    }
+  }
+  const bool distinct = __builtin_amdgcn_ballot_w64(row && tie) == 0;
+  if (distinct) {
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (j < n && __builtin_amdgcn_readlane(rank, j) == lane) src = j;
+  }
 #pragma nounroll
-  for (int k = 0; k < n; ++k) {
+  for (int k = 0; k < (distinct ? 0 : n); ++k) {
     const float key = (lane >= k && row) ? d : -1.0f;
     const float m = wave_max(key);
     const unsigned long long hits = __builtin_amdgcn_ballot_w64(key == m);
@@ -478,19 +506,19 @@ __device__ __forceinline__ void ldlt_solve_any(float* a, float* x, int n, float*
 // links: the structure's link table (global, or its LDS copy); gh_links: nullptr = every link sums its modalities'
 // buffers (Link::CalculateGradientAndHessian), else [n_links][42] link sums already formed; A / b: where the
 // [dof x dof] (lower) and [dof] sums go.
-template <bool WAVE>
+template <int MODE>
 __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev* links, const TreeWork& w, const float* gh_links, float* A,
                              float* b, const float* body_poses) {
-  const int lane = threadIdx.x & (kWave - 1), dof = o.dof, n_links = o.n_links;
+  const int lane = tree_lane<MODE>(), width = tree_width<MODE>(), dof = o.dof, n_links = o.n_links;
   PHASE_T0();
   // adjoints of every link, one lane per link (they depend on the link's own joint poses only)
-  for (int li = lane; li < n_links; li += kWave) {
+  for (int li = lane; li < n_links; li += width) {
     const LinkDev& l = links[li];
     if (l.parent >= 0)
       adjoint6(inverse_pose(mul_pose(load_pose(l.joint2parent), load_pose(l.body2joint))), w.AD + (size_t)li * 72);
     adjoint6(inverse_pose(load_pose(l.body2joint)), w.AD + (size_t)li * 72 + 36);
   }
-  tree_sync<WAVE>();
+  tree_sync_mode<MODE>();
   PHASE_MARK(17);
   // Link::CalculateJacobian link.cpp:159-182, parents before children
   for (int li = 0; li < n_links; ++li) {
@@ -498,7 +526,7 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
     float* J = w.J + (size_t)li * 6 * dof;
     const float* ad = w.AD + (size_t)li * 72;
     const float* Jp = l.parent >= 0 ? w.J + (size_t)l.parent * 6 * dof : nullptr;
-    for (int e = lane; e < 6 * dof; e += kWave) {
+    for (int e = lane; e < 6 * dof; e += width) {
       const int c = e / 6, r = e - c * 6;
       float v = 0.0f;
       if (Jp) {
@@ -508,7 +536,7 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
       }
       J[e] = v;
     }
-    tree_sync<WAVE>();
+    tree_sync_mode<MODE>();
     if (lane < 36) {
       const int d = lane / 6, r = lane - d * 6;
       if (l.free_directions[d]) {
@@ -517,12 +545,12 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
         J[(size_t)jidx * 6 + r] = ad[36 + d * 6 + r];
       }
     }
-    tree_sync<WAVE>();
+    tree_sync_mode<MODE>();
   }
 
   PHASE_MARK(18);
   // Link::CalculateGradientAndHessian link.cpp:184-193
-  for (int e = lane; e < n_links * 42; e += kWave) {
+  for (int e = lane; e < n_links * 42; e += width) {
     const int li = e / 42, i = e - li * 42;
     const LinkDev& l = links[li];
     float sacc = 0.0f;
@@ -531,14 +559,14 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
       for (int m = 0; m < l.n_gh; ++m) sacc += l.gh[m][i];
     w.GH[e] = sacc;
   }
-  tree_sync<WAVE>();
+  tree_sync_mode<MODE>();
   // SoftConstraint::AddGradientsAndHessiansToLinks soft_constraint.cpp:113-131 (optimizer.cpp:283-284)
   if (lane == 0) {
     for (int si = 0; si < o.n_soft; ++si) {
       const SoftConstraintDev& sc = o.soft[si];
       Affine b12j1 = load_pose(sc.joint.body12joint1);
-      Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(tree_link_pose<WAVE>(links[sc.joint.link1], body_poses))),
-                                     tree_link_pose<WAVE>(links[sc.joint.link2], body_poses));
+      Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(tree_link_pose<MODE>(links[sc.joint.link1], body_poses))),
+                                     tree_link_pose<MODE>(links[sc.joint.link2], body_poses));
       Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(sc.joint.body22joint2)));
       for (int which = 0; which < 2; ++which) {
         float g[6], h[36];
@@ -554,9 +582,9 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
       }
     }
   }
-  tree_sync<WAVE>();
+  tree_sync_mode<MODE>();
   // H J of every link, then b = sum J^T g and A = -sum J^T (H J) (lower), link after link per element
-  for (int e = lane; e < n_links * 6 * dof; e += kWave) {
+  for (int e = lane; e < n_links * 6 * dof; e += width) {
     const int li = e / (6 * dof), rem = e - li * 6 * dof, c = rem / 6, r = rem - c * 6;
     const float* H = w.GH + (size_t)li * 42 + 6;
     const float* J = w.J + (size_t)li * 6 * dof;
@@ -564,9 +592,9 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
     for (int k = 0; k < 6; ++k) sacc += H[k * 6 + r] * J[(size_t)c * 6 + k];
     w.HJ[e] = sacc;
   }
-  tree_sync<WAVE>();
+  tree_sync_mode<MODE>();
   PHASE_MARK(19);
-  for (int i = lane; i < dof; i += kWave) {
+  for (int i = lane; i < dof; i += width) {
     float acc = 0.0f;
     for (int li = 0; li < n_links; ++li) {
       const float* J = w.J + (size_t)li * 6 * dof;
@@ -577,7 +605,7 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
     }
     b[i] = acc;
   }
-  for (int e = lane; e < dof * dof; e += kWave) {
+  for (int e = lane; e < dof * dof; e += width) {
     const int c = e / dof, r = e - c * dof;
     float acc = 0.0f;
     if (r >= c) {
@@ -597,19 +625,19 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
 // the rest of Optimizer::CalculateOptimization + Optimizer::UpdatePoses (:335-346).  partial: [dof x dof | dof] sums
 // (after the all-reduce when the structure spans GPUs); w.J must hold the links' Jacobians.  Returns false when the
 // NaN guard skipped the update.
-template <bool WAVE>
+template <int MODE>
 __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, const TreeWork& w, const float* partial, float* body_poses,
                            int zero_theta) {
-  const int lane = threadIdx.x & (kWave - 1), dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
+  const int lane = tree_lane<MODE>(), width = tree_width<MODE>(), dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
   PHASE_T0();
   float* A = w.A;
   float* b = w.b;
-  for (int e = lane; e < size * size; e += kWave) {
+  for (int e = lane; e < size * size; e += width) {
     const int c = e / size, r = e - c * size;
     A[e] = (!zero_theta && c < dof && r < dof) ? partial[(size_t)c * dof + r] : 0.0f;
   }
-  for (int i = lane; i < size; i += kWave) b[i] = (!zero_theta && i < dof) ? partial[(size_t)dof * dof + i] : 0.0f;
-  tree_sync<WAVE>();
+  for (int i = lane; i < size; i += width) b[i] = (!zero_theta && i < dof) ? partial[(size_t)dof * dof + i] : 0.0f;
+  tree_sync_mode<MODE>();
   if (!zero_theta) {  // zero_theta: Optimizer::CalculateConsistentPoses optimizer.cpp:135 (theta = 0)
     // constraints: Constraint::CalculateResidualAndConstraintJacobian constraint.cpp:81-102
     int idx = dof;
@@ -620,7 +648,7 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
         const LinkDev& l1 = links[c.link1];
         const LinkDev& l2 = links[c.link2];
         Affine b12j1 = load_pose(c.body12joint1);
-        Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(tree_link_pose<WAVE>(l1, body_poses))), tree_link_pose<WAVE>(l2, body_poses));
+        Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(tree_link_pose<MODE>(l1, body_poses))), tree_link_pose<MODE>(l2, body_poses));
         Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(c.body22joint2)));
         float angle, axis[3];
         angle_axis(joint22joint1.l, &angle, axis);
@@ -631,10 +659,10 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
         constraint_unprojected_jacobian(c, joint22joint1, body22joint1, w.j2);
         constraint_unprojected_jacobian(c, joint22joint1, b12j1, w.j1);
       }
-      tree_sync<WAVE>();
+      tree_sync_mode<MODE>();
       const float* J1 = w.J + (size_t)c.link1 * 6 * dof;
       const float* J2 = w.J + (size_t)c.link2 * 6 * dof;
-      for (int e = lane; e < dof * n_c; e += kWave) {
+      for (int e = lane; e < dof * n_c; e += width) {
         const int col = e / n_c, r = e - col * n_c;
         float s2 = 0.0f, s1 = 0.0f;
         for (int k = 0; k < 6; ++k) {
@@ -645,11 +673,11 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
         A[(size_t)col * size + idx + r] = -(s2 - s1);
       }
       if (lane < n_c) b[idx + lane] = w.cres[lane];
-      tree_sync<WAVE>();
+      tree_sync_mode<MODE>();
       idx += n_c;
     }
     // Tikhonov vector optimizer.cpp:252-271 (free-direction order, rotation first)
-    for (int li = lane; li < n_links; li += kWave) {
+    for (int li = lane; li < n_links; li += width) {
       const LinkDev& l = links[li];
       int j = l.first_jacobian_index;
       for (int d = 0; d < 6; ++d)
@@ -658,14 +686,16 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
           j++;
         }
     }
-    tree_sync<WAVE>();
+    tree_sync_mode<MODE>();
     PHASE_MARK(12);
-    ldlt_solve_any<WAVE>(A, b, size, w.temp, w.trans);
+    // the factorisation is wave-level code: in the whole-workgroup mode the first wave runs it, the others wait
+    if (MODE != 2 || threadIdx.x < kWave) ldlt_solve_any<MODE != 0>(A, b, size, w.temp, w.trans);
+    if constexpr (MODE == 2) __syncthreads();
     PHASE_MARK(13);
     int has_nan = 0;
-    for (int i = lane; i < size; i += kWave) has_nan |= (b[i] != b[i]) ? 1 : 0;
+    for (int i = lane; i < size; i += width) has_nan |= (b[i] != b[i]) ? 1 : 0;
     // NaN guard optimizer.cpp:165
-    if constexpr (WAVE) {
+    if constexpr (MODE == 1) {
       if (__builtin_amdgcn_ballot_w64(has_nan != 0) != 0) return false;
     } else {
       if (__syncthreads_or(has_nan)) return false;
@@ -673,7 +703,7 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
   }
   // Link::UpdatePoses link.cpp:205-241: the variations of all links at once (one lane per link) ...
   float* var_all = w.AD;  // [n_links][12]
-  for (int li = lane; li < n_links; li += kWave) {
+  for (int li = lane; li < n_links; li += width) {
     const LinkDev& l = links[li];
     float th[6];
     int j = l.first_jacobian_index;
@@ -687,12 +717,12 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
     for (int i = 0; i < 9; ++i) v[i] = R[i];
     v[9] = th[3]; v[10] = th[4]; v[11] = th[5];
   }
-  tree_sync<WAVE>();
+  tree_sync_mode<MODE>();
   PHASE_MARK(14);
   // ... then the joints (all links at once, one lane per matrix element: mul_pose's expression per element) ...
   // (results staged in w.HJ, dead here: every element of the old matrix is read before any is overwritten)
   float* joint2body_chain = w.HJ;
-  for (int e = lane; e < n_links * 12; e += kWave) {
+  for (int e = lane; e < n_links * 12; e += width) {
     const int li = e / 12, q = e - li * 12;
     LinkDev& l = links[li];
     if (l.parent < 0) continue;
@@ -712,8 +742,8 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
     }
     joint2body_chain[e] = r;
   }
-  tree_sync<WAVE>();
-  for (int e = lane; e < n_links * 12; e += kWave) {
+  tree_sync_mode<MODE>();
+  for (int e = lane; e < n_links * 12; e += width) {
     const int li = e / 12, q = e - li * 12;
     LinkDev& l = links[li];
     if (l.parent < 0) continue;
@@ -722,50 +752,100 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
     else M[12 + (q - 9)] = joint2body_chain[e];
     if (q < 4) M[q * 4 + 3] = q == 3 ? 1.0f : 0.0f;
   }
-  tree_sync<WAVE>();
-  // ... then link2world, parents before children: (parent's link2world * joint2parent) * body2joint, left to right
-  // like the reference (the products are not associative in floating point): twelve lanes form the first product,
-  // fetch its rows from each other and form the second.
-  for (int li = 0; li < n_links; ++li) {
-    LinkDev& l = links[li];
-    if (l.parent >= 0) {
-      const float* P4 = links[l.parent].link2world;
-      float first = 0.0f;
-      if (lane < 12) {
-        const float* B4 = l.joint2parent;
-        if (lane < 9) {
-          const int c = lane / 3, k = lane - c * 3;
-          first = (P4[k] * B4[c * 4] + P4[4 + k] * B4[c * 4 + 1]) + P4[8 + k] * B4[c * 4 + 2];
-        } else {
-          const int k = lane - 9;
-          first = ((P4[k] * B4[12] + P4[4 + k] * B4[13]) + P4[8 + k] * B4[14]) + P4[12 + k];
-        }
-      }
-      // first: element (k, c) of the intermediate product in lane c * 3 + k (t in lanes 9..11)
-      float second = 0.0f;
-      {
-        const float* B4 = l.body2joint;
-        const int c = lane < 9 ? lane / 3 : 3, k = lane < 9 ? lane - (lane / 3) * 3 : (lane - 9) % 3;
-        // the intermediate's row k sits in lanes k, 3 + k, 6 + k (and 9 + k for the translation)
-        const float fk0 = __shfl(first, k, kWave), fk1 = __shfl(first, 3 + k, kWave), fk2 = __shfl(first, 6 + k, kWave),
-                    ft = __shfl(first, 9 + k, kWave);
-        if (lane < 9) second = (fk0 * B4[c * 4] + fk1 * B4[c * 4 + 1]) + fk2 * B4[c * 4 + 2];
-        else second = ((fk0 * B4[12] + fk1 * B4[13]) + fk2 * B4[14]) + ft;
-      }
-      if (lane < 9) l.link2world[(lane / 3) * 4 + (lane % 3)] = second;
-      else if (lane < 12) l.link2world[12 + (lane - 9)] = second;
-      if (lane < 4) l.link2world[lane * 4 + 3] = lane == 3 ? 1.0f : 0.0f;
-    } else if (lane == 0) {
+  tree_sync_mode<MODE>();
+  if constexpr (MODE == 2) {
+    // ... then link2world.  The root links first (each by its own thread) ...
+    for (int li = lane; li < n_links; li += width) {
+      LinkDev& l = links[li];
+      if (l.parent >= 0) continue;
       const float* v = var_all + (size_t)li * 12;
       Affine var;
       for (int i = 0; i < 9; ++i) var.l[i] = v[i];
       var.t[0] = v[9]; var.t[1] = v[10]; var.t[2] = v[11];
       Affine b2j = load_pose(l.body2joint);
-      Affine l2w = mul_pose(mul_pose(mul_pose(tree_link_pose<WAVE>(l, body_poses), inverse_pose(b2j)), var), b2j);
+      Affine l2w = mul_pose(mul_pose(mul_pose(tree_link_pose<MODE>(l, body_poses), inverse_pose(b2j)), var), b2j);
       affine_to_array(l2w, l.link2world);
     }
-    tree_sync<WAVE>();
-    if (!WAVE && l.body >= 0 && lane < 16) body_poses[16 * l.body + lane] = l.link2world[lane];  // (WAVE: the caller writes the bodies)
+    tree_sync_mode<MODE>();
+    // ... then every other link by ITS OWN thread, which walks down from the link's root: link2world of a link is
+    // (parent's link2world * joint2parent) * body2joint, left to right like the reference (the products are not
+    // associative in floating point).  A thread forms the products of all links on its path itself -- the same
+    // operations on the same values as the threads of those links, so the same bits -- and needs no barrier on the way.
+    for (int li = lane; li < n_links; li += width) {
+      if (links[li].parent < 0) continue;
+      int depth = 0, root = li;
+      while (links[root].parent >= 0) { root = links[root].parent; ++depth; }
+      float P[12];  // 3 x 4: element (k, c) at P[c * 3 + k], the translation in P[9 .. 11]
+      {
+        const float* R4 = links[root].link2world;
+        for (int c = 0; c < 4; ++c)
+          for (int k = 0; k < 3; ++k) P[c * 3 + k] = R4[c * 4 + k];
+      }
+      for (int step = depth - 1; step >= 0; --step) {
+        int a = li;  // the ancestor `step` levels above li (step == 0: li itself)
+        for (int up = 0; up < step; ++up) a = links[a].parent;
+        const LinkDev& la = links[a];
+        for (int pass = 0; pass < 2; ++pass) {
+          const float* B4 = pass == 0 ? la.joint2parent : la.body2joint;
+          float Q[12];
+          for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < 3; ++k) Q[c * 3 + k] = (P[k] * B4[c * 4] + P[3 + k] * B4[c * 4 + 1]) + P[6 + k] * B4[c * 4 + 2];
+          for (int k = 0; k < 3; ++k) Q[9 + k] = ((P[k] * B4[12] + P[3 + k] * B4[13]) + P[6 + k] * B4[14]) + P[9 + k];
+          for (int i = 0; i < 12; ++i) P[i] = Q[i];
+        }
+      }
+      float* out = links[li].link2world;
+      for (int c = 0; c < 4; ++c) {
+        for (int k = 0; k < 3; ++k) out[c * 4 + k] = P[c * 3 + k];
+        out[c * 4 + 3] = c == 3 ? 1.0f : 0.0f;
+      }
+    }
+    tree_sync_mode<MODE>();
+  } else {
+    // ... then link2world, parents before children: (parent's link2world * joint2parent) * body2joint, left to right
+    // like the reference (the products are not associative in floating point): twelve lanes form the first product,
+    // fetch its rows from each other and form the second.
+    for (int li = 0; li < n_links; ++li) {
+      LinkDev& l = links[li];
+      if (l.parent >= 0) {
+        const float* P4 = links[l.parent].link2world;
+        float first = 0.0f;
+        if (lane < 12) {
+          const float* B4 = l.joint2parent;
+          if (lane < 9) {
+            const int c = lane / 3, k = lane - c * 3;
+            first = (P4[k] * B4[c * 4] + P4[4 + k] * B4[c * 4 + 1]) + P4[8 + k] * B4[c * 4 + 2];
+          } else {
+            const int k = lane - 9;
+            first = ((P4[k] * B4[12] + P4[4 + k] * B4[13]) + P4[8 + k] * B4[14]) + P4[12 + k];
+          }
+        }
+        // first: element (k, c) of the intermediate product in lane c * 3 + k (t in lanes 9..11)
+        float second = 0.0f;
+        {
+          const float* B4 = l.body2joint;
+          const int c = lane < 9 ? lane / 3 : 3, k = lane < 9 ? lane - (lane / 3) * 3 : (lane - 9) % 3;
+          // the intermediate's row k sits in lanes k, 3 + k, 6 + k (and 9 + k for the translation)
+          const float fk0 = __shfl(first, k, kWave), fk1 = __shfl(first, 3 + k, kWave), fk2 = __shfl(first, 6 + k, kWave),
+                      ft = __shfl(first, 9 + k, kWave);
+          if (lane < 9) second = (fk0 * B4[c * 4] + fk1 * B4[c * 4 + 1]) + fk2 * B4[c * 4 + 2];
+          else second = ((fk0 * B4[12] + fk1 * B4[13]) + fk2 * B4[14]) + ft;
+        }
+        if (lane < 9) l.link2world[(lane / 3) * 4 + (lane % 3)] = second;
+        else if (lane < 12) l.link2world[12 + (lane - 9)] = second;
+        if (lane < 4) l.link2world[lane * 4 + 3] = lane == 3 ? 1.0f : 0.0f;
+      } else if (lane == 0) {
+        const float* v = var_all + (size_t)li * 12;
+        Affine var;
+        for (int i = 0; i < 9; ++i) var.l[i] = v[i];
+        var.t[0] = v[9]; var.t[1] = v[10]; var.t[2] = v[11];
+        Affine b2j = load_pose(l.body2joint);
+        Affine l2w = mul_pose(mul_pose(mul_pose(tree_link_pose<MODE>(l, body_poses), inverse_pose(b2j)), var), b2j);
+        affine_to_array(l2w, l.link2world);
+      }
+      tree_sync_mode<MODE>();
+      if (MODE == 0 && l.body >= 0 && lane < 16) body_poses[16 * l.body + lane] = l.link2world[lane];  // (otherwise the caller writes the bodies)
+    }
   }
   PHASE_MARK(15);
   return true;
@@ -896,12 +976,12 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
         }
         return;
       }
-      if (tid < kWave) {  // Optimizer::CalculateOptimization + UpdatePoses on this workgroup's copy of the structure
+      {  // Optimizer::CalculateOptimization + UpdatePoses on this workgroup's copy of the structure, by all its threads
         PHASE_T0();
-        tree_project<true>(o, links, w, gh_links, partial, partial + dof * dof, nullptr);
-        tree_sync<true>();
+        tree_project<2>(o, links, w, gh_links, partial, partial + dof * dof, nullptr);
+        __syncthreads();
         PHASE_MARK(30);
-        (void)tree_solve<true>(o, links, w, partial, nullptr, 0);
+        (void)tree_solve<2>(o, links, w, partial, nullptr, 0);
         PHASE_MARK(31);
       }
       __syncthreads();
@@ -937,7 +1017,7 @@ links_project_kernel(const TreeOptDev* opts, int n_opts, const float* body_poses
   extern __shared__ __attribute__((aligned(16))) float tree_lds[];
   const TreeOptDev& o = opts[blockIdx.x];
   const TreeWork w = tree_carve(work_in_lds ? tree_lds : o.work, o.n_links, o.dof, o.n_rows);
-  tree_project<false>(o, o.links, w, nullptr, o.partial, o.partial + (size_t)o.dof * o.dof, body_poses);
+  tree_project<0>(o, o.links, w, nullptr, o.partial, o.partial + (size_t)o.dof * o.dof, body_poses);
   if (work_in_lds)  // the Jacobians are needed again by the solve kernel (constraint rows)
     for (int e = threadIdx.x; e < o.n_links * 6 * o.dof; e += kWave) o.work[e] = w.J[e];
 }
@@ -951,7 +1031,7 @@ links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int ze
     for (int e = threadIdx.x; e < o.n_links * 6 * o.dof; e += kWave) w.J[e] = o.work[e];
     __syncthreads();
   }
-  (void)tree_solve<false>(o, o.links, w, o.partial, body_poses, zero_theta);
+  (void)tree_solve<0>(o, o.links, w, o.partial, body_poses, zero_theta);
 }
 
 }  // extern "C"

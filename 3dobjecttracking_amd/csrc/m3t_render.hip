@@ -11,13 +11,11 @@
 #ifndef M3T_RENDER_HIP_
 #define M3T_RENDER_HIP_
 
+#include "m3t_raster.h"
+
 namespace {
 
-struct M44 {
-  float m[16];  // column-major
-  __device__ float operator()(int r, int c) const { return m[c * 4 + r]; }
-  __device__ float& operator()(int r, int c) { return m[c * 4 + r]; }
-};
+using M44 = RasterM44;
 __device__ M44 mul44(const M44& a, const M44& b) {
   M44 o;
   for (int c = 0; c < 4; ++c)
@@ -118,81 +116,14 @@ focused_clear_kernel(const RendererDev* renderers, const int* which, const Camer
   }
 }
 
-// One triangle after projection, snapping, culling: vertices re-ordered to positive area
-struct RasterTriangle {
-  double ax[3], ay[3], z[3], area;
-  int x0, x1, y0, y1;
-};
-__device__ bool raster_setup(const M44& trans, const float* vertices, const int* triangles, int t, bool culling,
-                             int S, RasterTriangle& o) {
-  const float half_s = 0.5f * (float)S;
-  double sx[3], sy[3];
-  float wz[3];
-  bool behind = false;
-  for (int k = 0; k < 3; ++k) {
-    const float* p = vertices + (size_t)triangles[t * 3 + k] * 3;
-    float cx = ((trans(0, 0) * p[0] + trans(0, 1) * p[1]) + trans(0, 2) * p[2]) + trans(0, 3);
-    float cy = ((trans(1, 0) * p[0] + trans(1, 1) * p[1]) + trans(1, 2) * p[2]) + trans(1, 3);
-    float cz = ((trans(2, 0) * p[0] + trans(2, 1) * p[1]) + trans(2, 2) * p[2]) + trans(2, 3);
-    float cw = ((trans(3, 0) * p[0] + trans(3, 1) * p[1]) + trans(3, 2) * p[2]) + trans(3, 3);
-    if (!(cw > 0.0f)) behind = true;  // no near-plane clipping: such triangles are dropped
-    float wx = (cx / cw + 1.0f) * half_s;
-    float wy = (cy / cw + 1.0f) * half_s;
-    wz[k] = (cz / cw + 1.0f) * 0.5f;
-    sx[k] = floor((double)wx * 256.0 + 0.5);
-    sy[k] = floor((double)wy * 256.0 + 0.5);
-  }
-  if (behind) return false;
-  // anything this far off the image cannot touch it and would leave the exact-integer range
-  if (!(fabs(sx[0]) < 3.0e7 && fabs(sx[1]) < 3.0e7 && fabs(sx[2]) < 3.0e7 && fabs(sy[0]) < 3.0e7 &&
-        fabs(sy[1]) < 3.0e7 && fabs(sy[2]) < 3.0e7))
-    return false;
-  double area = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sy[1] - sy[0]) * (sx[2] - sx[0]);
-  if (area == 0.0) return false;
-  // counter-clockwise meshes seen from outside have negative area in the y-down image
-  if (area > 0.0 && culling) return false;
-  int i1 = 1, i2 = 2;
-  if (area < 0.0) { i1 = 2; i2 = 1; area = -area; }
-  o.ax[0] = sx[0]; o.ax[1] = sx[i1]; o.ax[2] = sx[i2];
-  o.ay[0] = sy[0]; o.ay[1] = sy[i1]; o.ay[2] = sy[i2];
-  o.z[0] = (double)wz[0]; o.z[1] = (double)wz[i1]; o.z[2] = (double)wz[i2];
-  o.area = area;
-  const double min_x = fmin(o.ax[0], fmin(o.ax[1], o.ax[2])), max_x = fmax(o.ax[0], fmax(o.ax[1], o.ax[2]));
-  const double min_y = fmin(o.ay[0], fmin(o.ay[1], o.ay[2])), max_y = fmax(o.ay[0], fmax(o.ay[1], o.ay[2]));
-  // pixels whose centre (256 p + 128) lies inside the bounding box: nothing else can pass the edge tests
-  o.x0 = (int)fmax(ceil((min_x - 128.0) / 256.0), 0.0);
-  o.x1 = (int)fmin(floor((max_x - 128.0) / 256.0), (double)(S - 1));
-  o.y0 = (int)fmax(ceil((min_y - 128.0) / 256.0), 0.0);
-  o.y1 = (int)fmin(floor((max_y - 128.0) / 256.0), (double)(S - 1));
-  return o.x1 >= o.x0 && o.y1 >= o.y0;
-}
-// edge functions in f64: the snapped coordinates are integers below 2^26, products and their differences are
-// exact, so the coverage is the integer result of the oracle
-__device__ __forceinline__ void raster_pixel(const RasterTriangle& t, int px, int py, uint32_t low_bits, int S,
-                                             uint32_t* z_buffer) {
-  const double cx = (double)px * 256.0 + 128.0, cy = (double)py * 256.0 + 128.0;
-  double e[3];
-  bool inside = true;
-  for (int k = 0; k < 3; ++k) {
-    const int k1 = (k + 1) % 3;
-    const double ex = t.ax[k1] - t.ax[k], ey = t.ay[k1] - t.ay[k];
-    e[k] = ex * (cy - t.ay[k]) - ey * (cx - t.ax[k]);
-    const bool owns = ey < 0.0 || (ey == 0.0 && ex > 0.0);  // top-left rule, y down
-    inside = inside && (e[k] > 0.0 || (e[k] == 0.0 && owns));
-  }
-  if (!inside) return;
-  const double z = (e[1] / t.area) * t.z[0] + (e[2] / t.area) * t.z[1] + (e[0] / t.area) * t.z[2];
-  if (!(z >= 0.0 && z <= 1.0)) return;
-  const uint32_t d16 = (uint32_t)floor(z * 65535.0 + 0.46);  // see the oracle / gl_model.py
-  atomicMin(&z_buffer[py * S + px], (d16 << 16) | low_bits);
-}
-
 // 2/3: rasterise (grid: slices x renderers; a slice is a contiguous part of every body's triangle list).
-// A triangle with a small bounding box is finished by the thread that owns it; larger ones are queued in
-// LDS and rasterised by the whole workgroup.
+// A triangle with a small bounding box is finished by the thread that owns it, row after row (raster_row: three
+// additions per pixel, and a row is left behind its covered span -- the slivers of a finely tessellated body have
+// boxes that are mostly empty); larger ones are queued in LDS and rasterised by the whole workgroup, a thread taking
+// 32-pixel pieces of rows.
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 focused_raster_kernel(const RendererDev* renderers, const int* which, const CameraDev* cams, const float* body_poses) {
-  constexpr int kQueue = 64;
+  constexpr int kQueue = 64, kPiece = 32;
   __shared__ RasterTriangle queue[kQueue];
   __shared__ int n_queued;
   const RendererDev& r = renderers[which[blockIdx.y]];
@@ -201,6 +132,7 @@ focused_raster_kernel(const RendererDev* renderers, const int* which, const Came
   if (f.n_visible == 0) return;  // block-uniform
   const int S = r.image_size;
   uint32_t* z_buffer = r.packed;
+  auto sink = [z_buffer, S](int px, int py, uint32_t word) { atomicMin(&z_buffer[py * S + px], word); };
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int order = 0; order < r.n_bodies; ++order) {
     const M44 trans = mul44(f.P, mul44(load44(cam.world2camera),
@@ -224,20 +156,133 @@ focused_raster_kernel(const RendererDev* renderers, const int* which, const Came
         if (slot < kQueue) {
           queue[slot] = tri;
         } else {
-          for (int py = tri.y0; py <= tri.y1; ++py)
-            for (int px = tri.x0; px <= tri.x1; ++px) raster_pixel(tri, px, py, low_bits, S, z_buffer);
+          for (int py = tri.y0; py <= tri.y1; ++py) raster_row(tri, py, tri.x0, tri.x1, low_bits, sink);
         }
       }
       __syncthreads();
       const int nq = min(n_queued, kQueue);
       for (int q = 0; q < nq; ++q) {
         const RasterTriangle big = queue[q];
-        const int w = big.x1 - big.x0 + 1, total = w * (big.y1 - big.y0 + 1);
-        for (int i = tid; i < total; i += nt) raster_pixel(big, big.x0 + i % w, big.y0 + i / w, low_bits, S, z_buffer);
+        const int pieces = (big.x1 - big.x0 + kPiece) / kPiece, total = pieces * (big.y1 - big.y0 + 1);
+        for (int i = tid; i < total; i += nt) {
+          const int row = i / pieces, xa = big.x0 + (i - row * pieces) * kPiece;
+          raster_row(big, big.y0 + row, xa, min(xa + kPiece - 1, big.x1), low_bits, sink);
+        }
       }
       __syncthreads();
     }
   }
+}
+
+// ---- the two-launch form, used when the z-buffer of a rendering fits the LDS of a CU (image_size <= 200) ----
+// Of a finely tessellated body most triangles never reach a pixel (tools/raster_stats.py: 1 000 - 1 300 of 20 950 on
+// the probe scene; the rest face away or lie outside the crop), and the survivors' boxes hold ~55 000 pixels in all:
+// little work, spread thin.  focused_setup_kernel (grid: slices x renderers) does the set-up and APPENDS the survivors
+// to a list; focused_resolve_kernel (one workgroup per renderer) clears a z-buffer in LDS, rasterises the list into it
+// with LDS atomics, and writes the depth and id images: no clear launch, no global atomics, no unpack launch.  The
+// words and their minimum are those of the three-launch form.
+struct RasterSurvivor {
+  RasterTriangle tri;
+  uint32_t low_bits, pad;
+};
+static_assert(sizeof(RasterSurvivor) == M3T_SURVIVOR_BYTES, "M3T_SURVIVOR_BYTES");
+
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+focused_setup_kernel(const RendererDev* renderers, const int* which, const CameraDev* cams, const float* body_poses) {
+  const RendererDev& r = renderers[which[blockIdx.y]];
+  const CameraDev& cam = cams[r.camera];
+  const FocusedProjection f = focused_projection(r, cam, body_poses);
+  if (threadIdx.x == 0 && blockIdx.x == 0) {  // the crop, for the modalities that read the rendering
+    r.state[RS_CORNER_U] = f.corner_u;
+    r.state[RS_CORNER_V] = f.corner_v;
+    r.state[RS_SCALE] = f.scale;
+    r.state[RS_TERM_A] = r.z_max * r.z_min * 65535.0f / (r.z_max - r.z_min);  // renderer.cpp:567-570
+    r.state[RS_TERM_B] = r.z_max * 65535.0f / (r.z_max - r.z_min);
+    r.state[RS_N_VISIBLE] = (float)f.n_visible;
+    for (int k = 0; k < M3T_MAX_RENDERER_BODIES; ++k)
+      r.state[RS_VISIBLE0 + k] = (f.visible_mask >> k & 1u) ? 1.0f : 0.0f;
+  }
+  if (f.n_visible == 0) return;  // block-uniform
+  const int S = r.image_size;
+  RasterSurvivor* list = static_cast<RasterSurvivor*>(r.survivors);
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & (kWave - 1);
+  for (int order = 0; order < r.n_bodies; ++order) {
+    const M44 trans = mul44(f.P, mul44(load44(cam.world2camera),
+                                       mul44(load44(body_poses + 16 * r.body[order]), load44(r.geometry2body[order]))));
+    const uint32_t low_bits = ((uint32_t)order << 8) | (r.silhouette ? (uint32_t)r.id[order] : 0u);
+    const float* vertices = r.vertices[order];
+    const int* triangles = r.triangles[order];
+    const bool culling = r.culling[order] != 0;
+    const int per_slice = (r.n_triangles[order] + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per_slice;
+    const int t_end = min(t_begin + per_slice, r.n_triangles[order]);
+    for (int base = t_begin; base < t_end; base += nt) {
+      const int t = base + tid;
+      RasterSurvivor sv;
+      const bool ok = t < t_end && raster_setup(trans, vertices, triangles, t, culling, S, sv.tri);
+      // one atomic per wave: the lanes with a survivor take consecutive entries
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+      if (mask == 0) continue;  // wave-uniform
+      int first = 0;
+      if (lane == 0) first = atomicAdd(r.n_survivors, __builtin_popcountll(mask));
+      first = __builtin_amdgcn_readfirstlane(first);
+      if (ok) {
+        const int at = first + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (at < r.survivor_capacity) {
+          sv.low_bits = low_bits;
+          sv.pad = 0;
+          list[at] = sv;
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+focused_resolve_kernel(const RendererDev* renderers, const int* which) {
+  extern __shared__ uint32_t lds_z[];  // [S * S] packed words, then the queue of large triangles
+  constexpr int kQueue = 64, kPiece = 32;
+  const RendererDev& r = renderers[which[blockIdx.x]];
+  const int S = r.image_size, n_px = S * S;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int* queue = reinterpret_cast<int*>(lds_z + n_px);
+  int* n_queued = queue + kQueue;
+  for (int i = tid; i < n_px; i += nt) lds_z[i] = 0xffffffffu;
+  const int n = min(*r.n_survivors, r.survivor_capacity);
+  const RasterSurvivor* list = static_cast<const RasterSurvivor*>(r.survivors);
+  auto sink = [S](int px, int py, uint32_t word) { atomicMin(&lds_z[py * S + px], word); };
+  for (int base = 0; base < n; base += nt) {  // block-uniform trip count
+    if (tid == 0) *n_queued = 0;
+    __syncthreads();  // (also: the cleared z-buffer, the first time)
+    const int i = base + tid;
+    if (i < n) {
+      const RasterSurvivor sv = list[i];
+      const int pixels = (sv.tri.x1 - sv.tri.x0 + 1) * (sv.tri.y1 - sv.tri.y0 + 1);
+      int slot = kQueue;
+      if (pixels > 192) slot = atomicAdd(n_queued, 1);
+      if (slot < kQueue) queue[slot] = i;
+      else
+        for (int py = sv.tri.y0; py <= sv.tri.y1; ++py) raster_row(sv.tri, py, sv.tri.x0, sv.tri.x1, sv.low_bits, sink);
+    }
+    __syncthreads();
+    const int nq = min(*n_queued, kQueue);
+    for (int q = 0; q < nq; ++q) {  // a large box: 32-pixel pieces of its rows over the whole workgroup
+      const RasterSurvivor big = list[queue[q]];
+      const int pieces = (big.tri.x1 - big.tri.x0 + kPiece) / kPiece, total = pieces * (big.tri.y1 - big.tri.y0 + 1);
+      for (int k = tid; k < total; k += nt) {
+        const int row = k / pieces, xa = big.tri.x0 + (k - row * pieces) * kPiece;
+        raster_row(big.tri, big.tri.y0 + row, xa, min(xa + kPiece - 1, big.tri.x1), big.low_bits, sink);
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = tid; i < n_px; i += nt) {
+    const uint32_t v = lds_z[i];
+    r.depth_image[i] = v == 0xffffffffu ? (uint16_t)65535 : (uint16_t)(v >> 16);
+    r.silhouette_image[i] = v == 0xffffffffu ? (uint8_t)0 : (uint8_t)(v & 0xffu);
+  }
+  if (tid == 0) *r.n_survivors = 0;  // for the next rendering
 }
 
 // 3/3: unpack into the u16 depth image and the u8 id image (grid: 16 x renderers)

@@ -70,6 +70,24 @@ class _LoaderCamera:
             self.api.call("ingest_sync")  # the slabs must not be reused while a copy reads them
         self._jobs, self._uploaded = {}, {}
 
+    def release(self):
+        """before the camera (or its arrays) go away: no copy in flight, the slabs no longer page-locked"""
+        self._drop_pipeline()
+        if hasattr(self, "_slabs"):
+            import ctypes as C
+            for a in self._slabs:
+                try:
+                    self.api.call("host_unregister", a.ctypes.data_as(C.c_void_p))
+                except Exception:  # (the context may be gone already: it unregisters what is left itself)
+                    pass
+            del self._slabs
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
     def _slab(self, slot):
         if not hasattr(self, "_slabs"):
             import ctypes as C

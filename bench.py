@@ -422,8 +422,52 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
     hip.call("ingest_sync")
     hip.call("sync")
     el = time.perf_counter() - tu
+    el_full = el
+    # the same again with ROI ingest: only the trackers' rectangle of every frame is pulled out of the slab (one kernel
+    # per batch-frame on the copy stream, m3t_hip_cameras_upload_batch_roi_async); poses must not change, and the
+    # device-side check must not report a body that left its rectangle
+    roi = None
+    if "set_roi_ingest" in hip._fn:
+        ref = (C.c_float * (16 * n_obj))()
+        hip.call("bodies_get_poses", ref, n_obj)
+        ref = np.array(ref)
+        restart = np.stack([np.ascontiguousarray(inputs.gt[i][W].T, np.float32).reshape(16) for i in range(n_obj)])
+
+        def timed(roi_on):
+            hip.call("set_roi_ingest", 1 if roi_on else 0, C.c_float(32.0))
+            hip.call("bodies_set_poses", restart.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+            upload(0, blocks[0])  # (whole frames: no step recorded yet)
+            hip.call("ingest_sync")
+            hip.call("sync")
+            fn = "cameras_upload_batch_roi_async" if roi_on else "cameras_upload_batch_async"
+            t0 = time.perf_counter()
+            for j in range(n_up):
+                hip.call("cameras_select_slot", j % 2)
+                hip.call("execute_tracking_step", 1 + W + j)
+                b = blocks[j + 1]
+                hip.call(fn, ids, n_obj, (j + 1) % 2, b.ctypes.data_as(C.c_void_p), b.strides[0], b.strides[1])
+            hip.call("ingest_sync")
+            hip.call("sync")
+            dt = time.perf_counter() - t0
+            out = (C.c_float * (16 * n_obj))()
+            hip.call("bodies_get_poses", out, n_obj)
+            return dt, np.array(out)
+
+        dt_full, poses_full = timed(False)
+        dt_roi, poses_roi = timed(True)
+        bodies = (C.c_int * 64)()
+        n_miss, pulls = C.c_int(0), C.c_longlong(0)
+        hip.call("roi_get_status", bodies, 64, C.byref(n_miss), C.byref(pulls))
+        hip.call("set_roi_ingest", 0, C.c_float(0.0))
+        roi = {"pose_updates_per_s": round(n_obj * n_up / dt_roi, 1), "ms_per_step": round(dt_roi / n_up * 1e3, 3),
+               "whole_frames_same_loop_ms_per_step": round(dt_full / n_up * 1e3, 3),
+               "rectangle_uploads": int(pulls.value), "bodies_outside_their_rectangle": int(n_miss.value),
+               "bit_identical_to_whole_frames": bool(np.array_equal(poses_roi, poses_full)), "margin_px": 32.0,
+               "note": "m3t_hip_cameras_upload_batch_roi_async: one pull kernel per batch-frame over the mapped slab"}
     for b in blocks:
         inst.tracker.unregister_host_buffer(b)
+    el = el_full
+    pcie["roi_rectangles"] = roi
     pcie["async_pinned"] = {"pose_updates_per_s": round(n_obj * n_up / el, 1),
                             "ms_per_step": round(el / n_up * 1e3, 3),
                             "upload_GBs": round(frame_bytes * n_up / el / 1e9, 2),

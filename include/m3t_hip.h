@@ -117,6 +117,24 @@ int m3t_hip_cameras_set_ring(m3t_hip_context*, const int* camera_ids, int n_came
 int m3t_hip_cameras_upload_batch_async(m3t_hip_context*, const int* camera_ids, int n_cameras, int slot, const void* base,
                                        size_t camera_stride, size_t row_step);
 int m3t_hip_ingest_sync(m3t_hip_context*); /* wait until all enqueued frame copies have landed */
+/* ROI ingest: only the part of a frame the trackers can read crosses PCIe.  set_roi_ingest(enable, margin_px) makes
+ * the fused step of rigid objects record the poses its searches run at; cameras_upload_batch_roi_async is
+ * cameras_upload_batch_async for rectangles: one kernel on the copy stream computes every camera's rectangle -- the
+ * projected box around the model points of the bodies tracked through it, widened by the modalities' reach
+ * (region_modality.cpp:1433-1508, 1640-1780, 1343-1389; depth_modality.cpp:736-776, 826-884) and by margin_px for the
+ * motion until the frame has been used (two frames: the rectangle comes from the pose at the start of the step
+ * enqueued last) -- and pulls its rows out of the host block, which has to be page-locked and mapped
+ * (host_register).  Where that is not possible (ROI ingest off, no step recorded yet, cameras not in one ring in this
+ * order, strides that are not multiples of 16 bytes) the whole frames are uploaded.  After every step that read a
+ * rectangle the library checks, on the device, that the poses the step went through stayed inside it;
+ * roi_get_status returns (and clears) the bodies for which they did not -- their poses since then are not the
+ * whole-frame poses: re-upload the frame in full, set the pose again and repeat the step.  Results of steps without
+ * misses equal the whole-frame results bit for bit. */
+int m3t_hip_set_roi_ingest(m3t_hip_context*, int enable, float margin_px);
+int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context*, const int* camera_ids, int n_cameras, int slot, const void* base,
+                                           size_t camera_stride, size_t row_step);
+int m3t_hip_roi_get_status(m3t_hip_context*, int* body_ids, int capacity, int* n_misses,
+                            long long* n_rectangle_uploads /* batch-frames that went as rectangles so far; may be NULL */);
 
 /* ---- Bodies (body.h:46: only body2world_pose crosses the boundary) ------------ */
 int m3t_hip_body_create(m3t_hip_context*, const float body2world[16]);

@@ -479,6 +479,22 @@ class Tracker {
     return c_->Step(m3t_hip_cameras_upload_batch_async(c_->get(), camera_ids.data(), int(camera_ids.size()), slot, base,
                                                        camera_stride, row_step));
   }
+  // ROI ingest: rectangles instead of frames (m3t_hip.h)
+  void SetRoiIngest(bool enable, float margin_px) {
+    c_->Check(m3t_hip_set_roi_ingest(c_->get(), enable ? 1 : 0, margin_px), "Tracker");
+  }
+  bool UploadBatchRoiAsync(const std::vector<int>& camera_ids, int slot, const void* base, size_t camera_stride,
+                           size_t row_step) {
+    return c_->Step(m3t_hip_cameras_upload_batch_roi_async(c_->get(), camera_ids.data(), int(camera_ids.size()), slot,
+                                                           base, camera_stride, row_step));
+  }
+  std::vector<int> RoiMisses() {  // bodies whose last checked steps left their rectangle (cleared by the call)
+    std::vector<int> bodies(256);
+    int n = 0;
+    c_->Check(m3t_hip_roi_get_status(c_->get(), bodies.data(), int(bodies.size()), &n, nullptr), "Tracker");
+    bodies.resize(size_t(n < int(bodies.size()) ? n : int(bodies.size())));
+    return bodies;
+  }
   // a kinematic structure spread over GPUs: begin -> all-reduce(sum) of `count` floats at `partial` on stream() -> end
   bool CalculateOptimizationBegin(float** partial, size_t* count) {
     return c_->Step(m3t_hip_calculate_optimization_begin(c_->get(), partial, count));

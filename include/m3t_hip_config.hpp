@@ -652,6 +652,13 @@ class FramePipeline {
     if (ctx && !uploaded_.empty()) (void)m3t_hip_ingest_sync(ctx);
     uploaded_.clear();
   }
+  // the owner goes away before its context: the slabs must not stay page-locked behind freed memory
+  void Release(m3t_hip_context* ctx) {
+    Drop(ctx);
+    if (ready_ && ctx)
+      for (auto& slab : slabs_) (void)m3t_hip_host_unregister(ctx, slab.data());
+    ready_ = false;
+  }
   void StartDecode(int index, const std::string& path, const Check& check) {
     if (jobs_.count(index) || uploaded_.count(index)) return;
     Job& job = jobs_[index];
@@ -767,6 +774,7 @@ class LoaderColorCamera : public ColorCamera {
                                                d.has("camera2world_pose") ? d["camera2world_pose"].pose() : IdentityPose());
   }
   FramePipeline pipeline;  // pipeline.enabled = false: the blocking reference behaviour
+  ~LoaderColorCamera() { pipeline.Release(c_->get()); }
   bool UpdateImage() {  // LoaderColorCamera::UpdateImage loader_camera.cpp:76-98
     const size_t frame_bytes = size_t(intrinsics_.width) * size_t(intrinsics_.height) * 3;
     if (pipeline.enabled && pipeline.Prepare(c_->get(), id_, frame_bytes)) {
@@ -813,6 +821,7 @@ class LoaderDepthCamera : public DepthCamera {
                                                d.has("camera2world_pose") ? d["camera2world_pose"].pose() : IdentityPose());
   }
   FramePipeline pipeline;
+  ~LoaderDepthCamera() { pipeline.Release(c_->get()); }
   bool UpdateImage() {
     const size_t frame_bytes = size_t(intrinsics_.width) * size_t(intrinsics_.height) * 2;
     if (pipeline.enabled && pipeline.Prepare(c_->get(), id_, frame_bytes)) {

@@ -1,0 +1,69 @@
+// Host check of 3dobjecttracking_amd/csrc/m3t_renderer_read.h: the forms the kernels call (all samples requested first,
+// decisions afterwards) against the reference's loops (sample, decide, next sample) on random renderings, crops, points
+// and line directions.  Prints "cases N mismatches M".
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../3dobjecttracking_amd/csrc/m3t_renderer_read.h"
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? std::atoi(argv[1]) : 2000000;
+  std::mt19937 rng(4711);
+  std::uniform_real_distribution<float> uni(0.0f, 1.0f);
+  long long mismatches = 0, cases = 0, insufficient = 0, sufficient = 0, windows_hit = 0;
+  const int S = 200;
+  std::vector<uint16_t> depth(S * S);
+  std::vector<uint8_t> sil(S * S);
+  for (int image = 0; image < 40; ++image) {
+    // a blob of region 150 (with holes of region 50 and background 0) in a rendering with three depth levels
+    const float bx = 60.0f + 80.0f * uni(rng), by = 60.0f + 80.0f * uni(rng), br = 20.0f + 50.0f * uni(rng);
+    for (int v = 0; v < S; ++v)
+      for (int u = 0; u < S; ++u) {
+        const float d2 = (u - bx) * (u - bx) + (v - by) * (v - by);
+        uint8_t id = d2 < br * br ? 150 : 0;
+        const float noise = (image & 3) == 0 ? 0.03f : 0.002f;
+        if (uni(rng) < noise) id = uni(rng) < 0.5f ? 50 : 0;
+        if (d2 > br * br && uni(rng) < noise) id = 150;
+        sil[v * S + u] = id;
+        depth[v * S + u] = id ? (uint16_t)(20000 + 3000 * uni(rng)) : (uni(rng) < 0.1f ? (uint16_t)(15000 * uni(rng)) : 65535);
+      }
+    FocusedCrop c;
+    c.corner_u = 100.0f + 200.0f * uni(rng);
+    c.corner_v = 80.0f + 200.0f * uni(rng);
+    c.scale = 0.4f + 2.0f * uni(rng);
+    c.image_size = S;
+    for (int k = 0; k < n / 40; ++k) {
+      ++cases;
+      // a point in or around the crop (sometimes well outside)
+      float cu = c.corner_u + (uni(rng) * 1.4f - 0.2f) * S / c.scale, cv = c.corner_v + (uni(rng) * 1.4f - 0.2f) * S / c.scale;
+      const float a = 6.2831853f * uni(rng), nu = cosf(a), nv = sinf(a);
+      if (k & 1) {  // on the blob's contour, the normal pointing out of it (a correspondence line of that region)
+        const float rr = br + 3.0f * (uni(rng) - 0.5f);
+        cu = c.corner_u + (bx + rr * nu - 0.5f) / c.scale;
+        cv = c.corner_v + (by + rr * nv - 0.5f) / c.scale;
+      }
+      const float diameter = uni(rng) < 0.1f ? 200.0f * uni(rng) : 40.0f * uni(rng);
+      const unsigned short m0 = modeled_window_min_reference(depth.data(), c, cu, cv, diameter);
+      const unsigned short m1 = modeled_window_min(depth.data(), c, cu, cv, diameter);
+      mismatches += m0 != m1;
+      windows_hit += m0 != 65535;
+      const float min_cont = 12.0f * uni(rng), fscale = (float)(1 + (int)(6 * uni(rng)));
+      const bool s0 = dynamic_line_region_sufficient_reference(sil.data(), c, 150, min_cont, fscale, cu, cv, nu, nv);
+      const bool s1 = dynamic_line_region_sufficient(sil.data(), c, 150, min_cont, fscale, cu, cv, nu, nv);
+      mismatches += s0 != s1;
+      (s0 ? sufficient : insufficient)++;
+      const float max_len = 5.0f + 40.0f * uni(rng), unconsidered = 3.0f * uni(rng);
+      float f0 = -1.0f, b0 = -2.0f, f1 = -1.0f, b1 = -2.0f;
+      dynamic_region_distance_reference(sil.data(), c, 150, max_len, unconsidered, cu, cv, nu, nv, &f0, &b0);
+      dynamic_region_distance(sil.data(), c, 150, max_len, unconsidered, cu, cv, nu, nv, &f1, &b1);
+      mismatches += std::memcmp(&f0, &f1, 4) != 0;
+      mismatches += std::memcmp(&b0, &b1, 4) != 0;
+    }
+  }
+  std::printf("cases %lld mismatches %lld (windows with a rendered sample %lld, lines sufficient %lld insufficient %lld)\n", cases,
+              mismatches, windows_hit, sufficient, insufficient);
+  return mismatches == 0 ? 0 : 1;
+}

@@ -1,0 +1,105 @@
+"""ROI ingest (m3t_hip_set_roi_ingest, m3t_hip_cameras_upload_batch_roi_async): only the rectangle of
+every frame that the trackers can read is pulled out of the page-locked host block, overlapped with the previous
+tracking step; the poses of the sequence equal those of the blocking whole-frame hand-over bit for bit, the device-side
+check reports no body that left its rectangle -- and does report it when the margin is too small for the motion."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenes
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def status(hip):
+    bodies = (C.c_int * 64)()
+    n = C.c_int(0)
+    pulls = C.c_longlong(0)
+    hip.call("roi_get_status", bodies, 64, C.byref(n), C.byref(pulls))
+    return n.value, list(bodies[:min(n.value, 64)]), pulls.value
+
+
+def run(inputs, mode, margin=24.0, n_frames=None, with_depth=False):
+    n_frames = n_frames or inputs.n_frames
+    hip = util.open_hip()
+    inst = scenes.Instance(hip, inputs, use_depth=with_depth)
+    if mode != "blocking":
+        hip.call("set_roi_ingest", 1, C.c_float(margin))
+    inst.upload_frame(0)
+    assert inst.tracker.StartModalities(0)
+    out = []
+    if mode == "blocking":
+        for k in range(1, n_frames):
+            inst.upload_frame(k)
+            assert inst.tracker.ExecuteTrackingStep(k)
+            out.append(np.stack(inst.poses()))
+        return out, (0, [], 0)
+    n = inputs.n_objects
+    groups = [(inst.color_cams, inputs.color, 3, np.uint8)]
+    if with_depth:
+        groups.append((inst.depth_cams, inputs.depth, 1, np.uint16))
+    rings = []
+    for cams, frames, channels, dtype in groups:
+        h, w = frames[0][0].shape[:2]
+        blocks = []
+        for k in range(n_frames):
+            b = np.zeros((n, h, w * channels), dtype)
+            for i in range(n):
+                b[i] = frames[i][k].reshape(h, w * channels)
+            inst.tracker.register_host_buffer(b)
+            blocks.append(b)
+        ids = (C.c_int * n)(*[cam.id for cam in cams])
+        hip.call("cameras_set_ring", ids, n, 2)
+        rings.append((ids, blocks))
+
+    def upload(slot, k):
+        for ids, blocks in rings:
+            b = blocks[k]
+            hip.call("cameras_upload_batch_roi_async", ids, n, slot, b.ctypes.data_as(C.c_void_p), b.strides[0], b.strides[1])
+
+    upload(1, 1)  # (no step recorded yet: goes as whole frames)
+    for k in range(1, n_frames):
+        inst.tracker.select_slot(k % 2)
+        assert inst.tracker.ExecuteTrackingStep(k)
+        if k + 1 < n_frames:
+            upload((k + 1) % 2, k + 1)
+        out.append(np.stack(inst.poses()))  # (synchronises: the next upload is not overlapped here, the path is the same)
+    inst.tracker.ingest_sync()
+    return out, status(hip)
+
+
+def test_rectangles_track_like_whole_frames():
+    inputs = scenes.Inputs(6, 7, n_divides=2)
+    ref, _ = run(inputs, "blocking")
+    got, (misses, bodies, pulls) = run(inputs, "roi")
+    assert pulls >= inputs.n_frames - 3  # all but the first uploads went as rectangles
+    assert misses == 0, bodies
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(a, b), k
+
+
+def test_rectangles_region_and_depth():
+    inputs = scenes.Inputs(3, 6, n_divides=2, with_depth=True)
+    ref, _ = run(inputs, "blocking", with_depth=True)
+    got, (misses, bodies, pulls) = run(inputs, "roi", with_depth=True)
+    assert pulls >= 2 * (inputs.n_frames - 3) and misses == 0, (pulls, bodies)
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(a, b), k
+
+
+def test_a_body_that_outruns_its_rectangle_is_reported():
+    """object 1 jumps by ~60 pixels between two frames; with a margin of 2 pixels its rectangle (computed from the pose
+    two frames back) does not hold what the step needs: roi_get_status names that body, and only that one"""
+    inputs = scenes.Inputs(3, 6, n_divides=2)
+    jump = inputs.scenes[1]
+    for k in range(3, inputs.n_frames):
+        pose = inputs.gt[1][k].copy()
+        pose[0, 3] += 0.06
+        inputs.gt[1][k] = pose
+        inputs.color[1][k] = jump.render(pose)
+    _, (misses, bodies, pulls) = run(inputs, "roi", margin=2.0)
+    assert pulls > 0 and misses >= 1
+    # body ids are creation order: object 1 is body 1
+    assert set(bodies) == {1}, bodies
