@@ -30,6 +30,7 @@ def open_context(device_id=0):
     the GPU to itself.  A process that shares the GPU with other contexts, streams
     or processes calls ``ctx.call("set_object_split", 0)`` (include/m3t_hip.h,
     m3t_hip_set_object_split)."""
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("%s missing: build it with `python __graft_entry__.py`" % LIB_PATH)
-    return CApi(LIB_PATH, "m3t_hip_", device_id)
+    path = os.environ.get("M3T_HIP_LIBRARY", LIB_PATH)  # another build of the same HIP library (A/B measurements)
+    if not os.path.exists(path):
+        raise RuntimeError("%s missing: build it with `python __graft_entry__.py`" % path)
+    return CApi(path, "m3t_hip_", device_id)

@@ -107,18 +107,73 @@ def open_oracle(native=False):
     return pkg.CApi(path, "m3t_oracle_")
 
 
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_gpus, argv, n_visible=None):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks, one per GPU, under
+    torch.distributed.run on 127.0.0.1 (what the driver does itself for its scaling runs).  Fails loudly when fewer
+    than N devices are visible -- a run that asked for N GPUs never reports a smaller n_gpus.  Returns the launcher's
+    command line (the caller execs it)."""
+    n_visible = visible_gpus() if n_visible is None else n_visible
+    if n_visible < n_gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node; refusing to run fewer ranks than "
+                         "asked for" % (n_gpus, n_visible))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def rank_plan(config, rank, world, objects=0, models=0):
+    """Which objects and how many distinct models rank `rank` of `world` holds: weak scaling (rbot64) =
+    `objects` per GPU, rank r owns the global objects [r n, (r + 1) n); strong scaling (ycb21, synth512) = a fixed
+    total, object i -> GPU i mod G.  A rank builds and uploads only the models its own objects use."""
+    pkg = importlib.import_module("3dobjecttracking_amd")
+    cfg = CONFIGS[config]
+    total = objects or cfg["objects"]
+    if cfg["scaling"] == "weak":
+        n_obj = total
+        ids = pkg.sharding.shard_objects(n_obj * world, rank, world, mode="block")
+        total = n_obj * world
+        first = int(ids[0])
+    else:
+        ids = pkg.sharding.shard_objects(total, rank, world, mode="round_robin")
+        n_obj = len(ids)
+        first = rank * 1000  # seeds of this rank's rendered streams
+    n_streams = min(n_obj, 64)
+    n_models = min(models or cfg["models"], n_streams)
+    return {"global_ids": [int(i) for i in ids], "n_obj": n_obj, "total_objects": total, "first_object": first,
+            "n_streams": n_streams, "n_models": n_models,
+            "model_of": [(i % n_streams) % n_models for i in range(n_obj)] if n_obj else []}
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        cmd = launch_ranks(args.gpus, sys.argv[1:])
+        os.execv(cmd[0], cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     import torch
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
 
     pkg = importlib.import_module("3dobjecttracking_amd")
     if args.config == "chain8":
@@ -141,18 +196,10 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
     n_frames = K + W + 1
     use_depth = cfg["with_depth"]
     t0 = time.time()
-    total_objects = args.objects or cfg["objects"]
-    if cfg["scaling"] == "weak":  # rank r owns the global objects [r * n, (r + 1) * n)
-        n_obj = total_objects
-        first = int(pkg.sharding.shard_objects(n_obj * world, rank, world, mode="block")[0])
-        total_objects = n_obj * world
-    else:                         # fixed total, object i -> GPU i mod G
-        mine = pkg.sharding.shard_objects(total_objects, rank, world, mode="round_robin")
-        n_obj, first = len(mine), 0
-    n_streams = min(n_obj, 64)
-    n_models = min(args.models or cfg["models"], n_streams)
+    plan = rank_plan(args.config, rank, world, args.objects, args.models)
+    n_obj, total_objects, n_streams, n_models = plan["n_obj"], plan["total_objects"], plan["n_streams"], plan["n_models"]
     base = scenes.Inputs(n_streams, n_frames, n_divides=args.n_divides, n_models=n_models, with_depth=use_depth,
-                         first_object=first + (rank * 1000 if cfg["scaling"] == "strong" else 0))
+                         first_object=plan["first_object"])
     inputs = scenes.replicate(base, n_obj)
     inst = scenes.Instance(hip, inputs, use_depth=use_depth)
     scenes.stage_frames(hip, inst, inputs, n_frames)
@@ -259,7 +306,11 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
     # ---- CPU baseline: the oracle restatement, bounded sample (rank 0); its first pass over the frames is also
     # the parity check of the benchmarked trajectory: the same objects, the same frames, free running ----
     cpu, parity = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only (the other ranks would idle)
+    if rank == 0 and not args.no_cpu_baseline:
+        # N > 1: rank 0 still checks its own first objects against the oracle and times a short 1-thread sample (the
+        # other ranks wait at the final barrier); the all-cores and native-build legs run at N = 1 only
+        if world > 1:
+            args.cpu_seconds, args.no_cpu_parallel = min(args.cpu_seconds, 4.0), True
         ora = open_oracle()
         n_cpu = min(8, n_obj)
         sub = scenes.subset(inputs, list(range(n_cpu)))
@@ -296,6 +347,8 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
                                          use_depth)
         native = None
         try:  # the same restatement built as the reference builds (M3T/CMakeLists.txt:73-80), on this host
+            if world > 1:
+                raise RuntimeError("N = 1 only")
             nat = open_oracle(native=True)
             ninst = scenes.Instance(nat, sub, use_depth=use_depth)
             ninst.upload_frame(0)
@@ -332,7 +385,10 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["workload"] % dict(n=n_obj, views=n_views, models=len(inputs.region_models)),
                    "objects_per_gpu": n_obj,
-                   "parallelism": "objects sharded over %d GPU(s), no collective" % world,
+                   "parallelism": "objects sharded over %d GPU(s) (%s), no collective on the data path" %
+                                  (world, "rank r owns objects [r n, (r + 1) n)" if cfg["scaling"] == "weak"
+                                   else "object i on GPU i mod %d" % world),
+                   "ranks": world, "rccl_ranks": world if world > 1 else 0,
                    "tracked_within_5cm_5deg": "%d/%d" % (tracked, n_obj),
                    "mean_add_s_vs_ground_truth_m": round(float(np.mean(adds_gt)), 6), "setup_s": round(setup_s, 1)},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
