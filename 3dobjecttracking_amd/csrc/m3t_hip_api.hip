@@ -12,9 +12,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/m3t_hip.h"
@@ -215,6 +217,8 @@ struct m3t_hip_context {
   // several workgroups per object (tracking_step_split_kernel) for batches that leave most CUs idle
   bool split_possible = false;
   bool split_enabled = true;  // m3t_hip_set_object_split
+  std::map<std::tuple<const void*, int, size_t>, int> occupancy_cache;  // ResidentBlocks
+  size_t tree_lds_attribute = 0;  // dynamic LDS limit last set on tracking_step_tree_kernel
   DevMem d_split;            // [objects][2 slots][parts][32 fields][256 / parts] granules, then one abort word per object
   size_t split_objects = 0;  // capacity of d_split
   unsigned split_seq = 0;    // launch counter inside the granule tags
@@ -483,6 +487,22 @@ int UploadFrame(Ctx* ctx, int id, int slot, const void* pixels, size_t row_step)
 }
 
 // ---- device tables -----------------------------------------------------------
+// Workgroups of `kernel` (threads, dynamic LDS bytes) a CU keeps resident: asked once per (kernel, shape) and kept --
+// the per-frame launch decision must not call into the driver (round-3 advisor).  0 = the query failed.
+template <typename K>
+int ResidentBlocks(Ctx* ctx, K kernel, int threads, size_t lds) {
+  const auto key = std::make_tuple(reinterpret_cast<const void*>(kernel), threads, lds);
+  auto it = ctx->occupancy_cache.find(key);
+  if (it != ctx->occupancy_cache.end()) return it->second;
+  int resident = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kernel, threads, lds) != hipSuccess) {
+    (void)hipGetLastError();
+    resident = 0;
+  }
+  ctx->occupancy_cache[key] = resident;
+  return resident;
+}
+
 // After a synchronisation: did the workgroups of a split object ever give up waiting for each other?  (They
 // are all resident by construction; the bounded wait exists so that a surprise cannot hang the device.)
 int CheckSplitExchange(Ctx* ctx) {
@@ -491,12 +511,16 @@ int CheckSplitExchange(Ctx* ctx) {
   const unsigned value = __atomic_load_n(ctx->split_abort_host, __ATOMIC_ACQUIRE);
   if (value != ctx->split_abort_seen) {
     ctx->split_abort_seen = value;
-    return Fail(ctx, M3T_ERR_DEVICE,
-                "tracking_step_split_kernel: a workgroup waited in vain for its object's other workgroups (is another "
-                "process or stream using this GPU?); the object's step was abandoned part-way: workgroups that had "
-                "already finished may have written the new pose and blended their share of the histogram bins, so "
-                "the object's pose and histograms are undefined; set the poses again and call start_modalities "
-                "(m3t_hip_set_object_split(ctx, 0) avoids the kernel)");
+    const bool tree = std::strcmp(ctx->last_step_kernel, "tracking_step_tree_kernel") == 0;
+    const std::string msg =
+        std::string(tree ? "tracking_step_tree_kernel" : "tracking_step_split_kernel") +
+        ": a workgroup waited in vain for the other workgroups of its " + (tree ? "kinematic structure" : "object") +
+        " (is another process or stream using this GPU?); the step was abandoned part-way: workgroups that had "
+        "already finished may have written the new pose" + (tree ? "s and joints" : "") +
+        " and blended their share of the histogram bins, so the poses and histograms involved are undefined; set the "
+        "poses again and call start_modalities.  m3t_hip_set_object_split(ctx, 0) keeps both kernels out: one "
+        "workgroup per rigid object, per-sub-step launches for kinematic structures";
+    return Fail(ctx, M3T_ERR_DEVICE, msg.c_str());
   }
   return M3T_OK;
 }
@@ -1437,25 +1461,25 @@ size_t TreeStepLds(Ctx* ctx, bool fused_histogram) {
 // histogram objects, line / point state not requested (fused mode 1), fewer than 63 Newton steps per frame, the
 // structure copy next to the tracking carve-up in LDS, and every workgroup of the grid resident at once.
 bool TreeStepFused(Ctx* ctx) {
+  // (m3t_hip_set_object_split(ctx, 0) = "this context shares its GPU": no launch whose workgroups wait for each other)
   if (!(ctx->tree_mode && ctx->tree_fused_possible && ctx->fused_mode == 1 && !ctx->comm && ctx->n_render_all == 0 &&
-        ctx->shared_histograms.empty() && ctx->n_treesteps > 0 && !std::getenv("M3T_HIP_NO_TREE_FUSION")))
+        ctx->shared_histograms.empty() && ctx->n_treesteps > 0 && ctx->split_enabled &&
+        !std::getenv("M3T_HIP_NO_TREE_FUSION")))
     return false;
   if (ctx->layout.off_hist >= 0) return false;  // (the LDS-staged pair table belongs to tracking_step_lds_kernel)
   if (ctx->n_corr_iterations * ctx->n_update_iterations >= 63) return false;
   const bool fused_histogram = !ctx->region_mods.empty() && ctx->hist_counts_in_lds;
   const size_t lds = TreeStepLds(ctx, fused_histogram);
   if (lds > size_t(160) * 1024) return false;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_tree_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
+  if (ctx->tree_lds_attribute != lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_tree_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    ctx->tree_lds_attribute = lds;
   }
-  int resident = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, tracking_step_tree_kernel, M3T_BLOCK_THREADS, lds) !=
-      hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
+  int resident = ResidentBlocks(ctx, tracking_step_tree_kernel, M3T_BLOCK_THREADS, lds);
   resident = std::min(resident, int(size_t(160) * 1024 / lds));
   return resident >= 1 && ctx->n_treesteps <= ctx->prop.multiProcessorCount * resident;
 }
@@ -3301,12 +3325,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
         if ((elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;  // a part's elements fit its share of the lanes
         // the exchange needs every workgroup of the grid resident at once: ask the runtime how many of these
         // workgroups (registers, LDS) a CU takes, instead of assuming the LDS arithmetic above is the only limit
-        int resident = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, tracking_step_split_kernel, threads,
-                                                         lds_split_for(p)) != hipSuccess) {
-          (void)hipGetLastError();
-          resident = 0;
-        }
+        int resident = ResidentBlocks(ctx, tracking_step_split_kernel, threads, lds_split_for(p));
         if (resident > per_cu) resident = per_cu;  // (the query is known to over-report by one block for SGPR-heavy kernels)
         if (resident < 1 || padded * p > ctx->prop.multiProcessorCount * resident) continue;
         parts = p;

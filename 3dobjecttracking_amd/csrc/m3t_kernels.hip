@@ -2184,10 +2184,12 @@ __device__ __forceinline__ void count_add(__attribute__((address_space(1))) unsi
 // SHARED: the modality adds into a ColorHistograms object it shares with others (64-bit words, foreground
 // count in the low half, background in the high half); shared_histogram_finish() turns them into histograms
 // LIST: for a workgroup whose LDS cannot hold a count word per bin (tracking_step_compact_kernel: four objects per
-// CU).  The walk writes the bin of every sample into an LDS list (16 bits per sample: bin | background << 15, one
-// row of `list_row` entries per walker); then the bins are taken in passes of `pass_bins`: the pass's share of the
-// list is counted into the (small) table `counts`, its bins are blended and written.  Same sums, same blend
-// arithmetic, any number of passes.  Needs n_bins <= 32 (15-bit bin numbers).
+// CU).  The walk writes the bin of every sample into an LDS list (16 bits per sample = the bin, 0xffff = no sample;
+// one row of `list_row` entries per walker, the rows of the foreground walkers first, then those of the background
+// walkers: which half an entry sits in says what it counts for -- a flag inside the entry would make a background
+// sample of bin 0x7fff, a saturated white pixel at 32 bins, look like the sentinel); then the bins are taken in passes
+// of `pass_bins`: the pass's share of the list is counted into the (small) table `counts`, its bins are blended and
+// written.  Same sums, same blend arithmetic, any number of passes.  Needs n_bins <= 32 (15-bit bin numbers).
 template <bool SHARED = false, bool LIST = false, typename CountPtr>
 __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                         const Affine& b2dc, bool handle_occlusions, bool initialize,
@@ -2378,7 +2380,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
                              (((px[j] >> 16) & 0xffu) >> bitshift) - (uint32_t)bin_lo;
         if constexpr (LIST) {
           if (((taken >> j) & 1u) && k0 + j < list_row)
-            list[item * list_row + k0 + j] = (uint16_t)(bin | (background ? 0x8000u : 0u));
+            list[(background ? n_lines * list_row : 0) + line * list_row + k0 + j] = (uint16_t)bin;
         } else {
           if (((taken >> j) & 1u) && (SHARED || bin < n_own_bins)) count_add(&counts[bin], inc);
         }
@@ -2420,13 +2422,15 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     for (int i = tid; i < pass_bins; i += nt) counts[i] = 0;
     __syncthreads();
     const uint32_t* words = reinterpret_cast<const uint32_t*>(list);
+    const uint32_t first_background = (uint32_t)(n_lines * list_row);  // entry index
     for (int i = tid; i < n_lines * list_row; i += nt) {
       const uint32_t w = words[i];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const uint32_t v = half ? w >> 16 : w & 0xffffu;
-        const uint32_t bin = (v & 0x7fffu) - (uint32_t)bin_lo;
-        if (v != 0xffffu && bin < (uint32_t)(bin_hi - bin_lo)) count_add(&counts[bin], (v & 0x8000u) ? 65536u : 1u);
+        const uint32_t bin = v - (uint32_t)bin_lo;
+        if (v != 0xffffu && bin < (uint32_t)(bin_hi - bin_lo))
+          count_add(&counts[bin], 2u * (uint32_t)i + (uint32_t)half >= first_background ? 65536u : 1u);
       }
     }
     __syncthreads();

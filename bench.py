@@ -489,9 +489,18 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
         ref = np.array(ref)
         restart = np.stack([np.ascontiguousarray(inputs.gt[i][W].T, np.float32).reshape(16) for i in range(n_obj)])
 
+        start_block = np.stack([inputs.color[i][W] for i in range(n_obj)])
+        inst.tracker.register_host_buffer(start_block)
+        margin = 24.0  # pixels: two frames of this workload's motion (the rectangle comes from the pose two frames back)
+
         def timed(roi_on):
-            hip.call("set_roi_ingest", 1 if roi_on else 0, C.c_float(32.0))
+            # both runs from the same state: poses of frame W, histograms initialised on frame W (whole frames)
+            hip.call("set_roi_ingest", 1 if roi_on else 0, C.c_float(margin))
             hip.call("bodies_set_poses", restart.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+            upload(1, start_block)
+            hip.call("ingest_sync")
+            hip.call("cameras_select_slot", 1)
+            hip.call("start_modalities", W)
             upload(0, blocks[0])  # (whole frames: no step recorded yet)
             hip.call("ingest_sync")
             hip.call("sync")
@@ -518,7 +527,7 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
         roi = {"pose_updates_per_s": round(n_obj * n_up / dt_roi, 1), "ms_per_step": round(dt_roi / n_up * 1e3, 3),
                "whole_frames_same_loop_ms_per_step": round(dt_full / n_up * 1e3, 3),
                "rectangle_uploads": int(pulls.value), "bodies_outside_their_rectangle": int(n_miss.value),
-               "bit_identical_to_whole_frames": bool(np.array_equal(poses_roi, poses_full)), "margin_px": 32.0,
+               "bit_identical_to_whole_frames": bool(np.array_equal(poses_roi, poses_full)), "margin_px": margin,
                "note": "m3t_hip_cameras_upload_batch_roi_async: one pull kernel per batch-frame over the mapped slab"}
     for b in blocks:
         inst.tracker.unregister_host_buffer(b)

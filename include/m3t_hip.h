@@ -287,7 +287,10 @@ int m3t_hip_set_fused_step(m3t_hip_context*, int mode);
  * waits in vain (about 5 ms), the step of that object is abandoned part-way -- workgroups that were already done may
  * have written the new pose and their share of the histogram bins, so pose and histograms of that object are
  * undefined -- and the NEXT call of execute_tracking_step / sync / a pose getter returns M3T_ERR_DEVICE: set the
- * poses again and call start_modalities.  A process that shares its GPU switches the split off.  enable: 0 = off, 1 = automatic (default), 2..16 = at most that many
+ * poses again and call start_modalities.  A process that shares its GPU switches the split off.  The same holds for
+ * kinematic structures: their one-launch step (tracking_step_tree_kernel, a workgroup per tracked link, the link sums
+ * handed over inside the launch) is chosen under the same assumption and fails the same way; enable = 0 switches it
+ * off as well (per-sub-step launches instead).  enable: 0 = off, 1 = automatic (default), 2..16 = at most that many
  * workgroups per object.  Results are bit-identical in every shape. */
 int m3t_hip_set_object_split(m3t_hip_context*, int enable);
 /* Refiner::RefinePoses (refiner.cpp:76-117): CalculateConsistentPoses, then n_corr_iterations x

@@ -162,3 +162,24 @@ def test_synth512_batch_matches_the_oracle(env, kernel, shape):
         assert np.array_equal(hist[i][0], ref_hist[j][0]) and np.array_equal(hist[i][1], ref_hist[j][1])
     adds = [syn.add_s(inputs.vertices[i], got[-1][i], inputs.gt[i][-1]) for i in sample]
     assert max(adds) < 0.01  # tracked
+
+
+def test_compact_kernel_counts_saturated_background_pixels():
+    """32 bins, histogram update from the 16-bit sample list (tracking_step_compact_kernel): white pixels fall into bin
+    0x7fff, which as a background sample must not be taken for the list's empty-slot word 0xffff (round-3 advisor).
+    Frames with every 8th pixel of every 8th row saturated: foreground and background walks both meet bin 32767."""
+    base = scenes.Inputs(8, 4, n_divides=2, n_models=4)
+    inputs = util.pkg.batch.subset(base, list(range(8)))
+    inputs.color = [[f.copy() for f in frames] for frames in base.color]
+    for frames in inputs.color:
+        for f in frames:
+            f[::8, ::8, :] = 255
+    ref, ref_hist = oracle_trajectory(inputs)
+    assert all(fb[1].reshape(-1)[32767] > 0 and fb[0].reshape(-1)[32767] > 0 for fb in ref_hist)
+    got, hist, shape = hip_trajectory(inputs, env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1"},
+                                      want_kernel="tracking_step_compact_kernel")
+    assert shape == [8, 1, 256, 1]
+    for (fa, ba), (fb, bb) in zip(hist, ref_hist):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+    for k in range(inputs.n_frames):
+        assert np.array_equal(got[k], ref[k]), k

@@ -290,6 +290,35 @@ def test_eight_body_chain_matches_the_oracle():
 
 
 @gpu
+def test_object_split_off_keeps_the_tree_kernel_out():
+    """m3t_hip_set_object_split(ctx, 0) -- the switch of a context that shares its GPU -- also keeps
+    tracking_step_tree_kernel (workgroups that wait for each other) out: per-sub-step launches, the same bits"""
+    import bench_chain
+    inputs, joints, gt = bench_chain.chain_inputs(scenes, syn, 4, 3, 2)
+    start_root = syn.perturb_pose(gt[0][0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
+    states = {}
+    for name in ("tree", "unfused"):
+        api = util.open_hip()
+        if name == "unfused":
+            api.call("set_object_split", 0)
+        ch = bench_chain.Chain(api, host, syn, inputs, joints, start_root, gt[0][1] + 0.01, range(4))
+        ch.upload(inputs, 0)
+        assert ch.tracker.StartModalities(0)
+        out = []
+        for k in range(len(gt)):
+            ch.upload(inputs, k)
+            assert ch.tracker.ExecuteTrackingStep(k)
+            out.append(chain_state(ch))
+        states[name] = out
+        kernel = C.create_string_buffer(64)
+        api.call("get_step_kernel", kernel, 64)
+        assert (kernel.value.decode() == "tracking_step_tree_kernel") == (name == "tree")
+    for sa, sb in zip(states["tree"], states["unfused"]):
+        for x, y in zip(sa, sb):
+            assert np.array_equal(x, y)
+
+
+@gpu
 def test_closed_chain_with_a_hard_constraint_matches_the_oracle():
     """A -- revolute -- B -- revolute -- C with a Constraint (constraint.cpp:81-102, translation directions) that ties
     a point of C back to A: a closed kinematic loop, three RegionModalities.  The constraint rows make the system an
