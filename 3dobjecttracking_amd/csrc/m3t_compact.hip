@@ -513,7 +513,7 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
     const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
     auto* counts = (__attribute__((address_space(3))) uint32_t*)(lds_c + L.off_tail_counts);
     if (L.tail_pass_bins > 0)
-      region_histogram_update<false, true>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false, counts, lds_c, 0, -1,
+      region_histogram_update<false, true, false>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false, counts, lds_c, 0, -1,
                                            reinterpret_cast<uint16_t*>(lds_c + L.off_tail_list), L.tail_list_row,
                                            L.tail_pass_bins);
     else

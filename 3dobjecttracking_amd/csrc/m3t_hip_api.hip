@@ -947,7 +947,13 @@ int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int largest_image_s
 #ifndef M3T_RASTER_SLICES
 #define M3T_RASTER_SLICES 32
 #endif
-  const size_t lds = size_t(largest_image_size) * largest_image_size * 4 + 65 * 4;
+#ifndef M3T_RASTER_BANDS
+#define M3T_RASTER_BANDS 16
+#endif
+  int bands = M3T_RASTER_BANDS;
+  if (const char* e = std::getenv("M3T_HIP_RASTER_BANDS")) bands = std::max(1, std::atoi(e));  // developer override
+  const size_t band_rows = (size_t(largest_image_size) + bands - 1) / bands;
+  const size_t lds = band_rows * largest_image_size * 4 + 65 * 4;
   if (ctx->lds_raster < 0) {  // once per context (= per device)
     ctx->lds_raster = 1;
     if (std::getenv("M3T_HIP_NO_LDS_RASTER")) ctx->lds_raster = 0;
@@ -960,7 +966,7 @@ int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int largest_image_s
   if (ctx->lds_raster == 1 && largest_image_size > 0 && lds <= size_t(160) * 1024) {
     hipLaunchKernelGGL(focused_setup_kernel, dim3(M3T_RASTER_SLICES, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                        ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
-    hipLaunchKernelGGL(focused_resolve_kernel, dim3(n_which), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
+    hipLaunchKernelGGL(focused_resolve_kernel, dim3(bands, n_which), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
                        ctx->d_renderers.as<RendererDev>(), which);
     HIPCHK(hipGetLastError());
     return M3T_OK;
@@ -1930,11 +1936,13 @@ int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context* ctx, const int* ids,
   HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->roi_snapshot_done, 0));  // the poses the rectangles come from
   const Camera& c0 = *ctx->cameras[ids[0]];
   // the camera table is only read for intrinsics and world2camera here: any slot version will do (the first one)
+  m3t_roi_rect* rects = ctx->d_roi_rects.as<m3t_roi_rect>() + size_t(slot) * ctx->cameras.size();
+  hipLaunchKernelGGL(roi_rect_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->copy_stream[cs],
+                     ctx->d_roi_items.as<RoiItemDev>(), ctx->d_roi_item_first.as<int>(), ctx->d_roi_cam_ids.as<int>(), n,
+                     ctx->d_cams.as<CameraDev>(), ctx->d_roi_pose_snapshot.as<float>(), ctx->roi_margin_px, rects);
   hipLaunchKernelGGL(roi_pull_kernel, dim3((c0.intr.height + 7) / 8, n), dim3(256), 0, ctx->copy_stream[cs],
-                     ctx->d_roi_items.as<RoiItemDev>(), ctx->d_roi_item_first.as<int>(), ctx->d_roi_cam_ids.as<int>(),
-                     ctx->d_cams.as<CameraDev>(), ctx->d_roi_pose_snapshot.as<float>(), src, camera_stride, uint32_t(row_step),
-                     c0.frame(slot), c0.frame_bytes, c0.pitch, c0.is_depth ? 2 : 3, ctx->roi_margin_px,
-                     ctx->d_roi_rects.as<m3t_roi_rect>() + size_t(slot) * ctx->cameras.size());
+                     ctx->d_roi_cam_ids.as<int>(), rects, src, camera_stride, uint32_t(row_step), c0.frame(slot),
+                     c0.frame_bytes, c0.pitch, c0.is_depth ? 2 : 3);
   HIPCHK(hipGetLastError());
   ++ctx->roi_pulls;
   for (int i = 0; i < n; ++i) {

@@ -1,10 +1,10 @@
 // m3t_ingest.hip — ROI ingest: instead of whole frames, only the rectangle of every
 // camera frame that the trackers can read crosses PCIe.
-//   roi_pull_kernel   ONE launch per batch-frame on the copy stream: every camera's rectangle from the bodies' poses
-//                     (m3t_roi.h: projected box around the model's points + the modality's reach + the caller's
-//                     margin for the motion until the frame is used), then the rectangle's rows straight from the
-//                     mapped, page-locked host block into the ring slot, 16 bytes per thread and trip (measured:
-//                     33-51 GB/s, against 2.8-6.4 GB/s for one 2-D DMA per camera: tools/ubench_ingest.hip)
+//   roi_rect_kernel   every camera's rectangle from the bodies' poses (m3t_roi.h: projected box around the model's
+//                     points + the modality's reach + the caller's margin for the motion until the frame is used)
+//   roi_pull_kernel   ONE launch per batch-frame on the copy stream: the rectangles' rows straight from the mapped,
+//                     page-locked host block into the ring slot, 16 bytes per thread and trip (measured: 33-51 GB/s,
+//                     against 2.8-6.4 GB/s for one 2-D DMA per camera: tools/ubench_ingest.hip)
 //   roi_check_kernel  after a tracking step: the rectangle the step really needed -- the union over the poses its
 //                     searches ran at (the tracking kernels store them) -- against the rectangle that was in the
 //                     slot; a body whose needs stick out is reported (m3t_hip_roi_get_status), its pose of this step
@@ -37,43 +37,52 @@ __device__ __forceinline__ m3t_intrinsics roi_intrinsics(const CameraDev& cam) {
 
 extern "C" {
 
-// grid: (ceil(height / 8), cameras of the batch); cam_ids[blockIdx.y] = camera id; item_first[camera id .. + 1] = its
-// readers in `items`.  src / dst: camera blockIdx.y of the batch at + blockIdx.y * stride (one host block, one slab).
-__global__ void __launch_bounds__(256)
-roi_pull_kernel(const RoiItemDev* items, const int* item_first, const int* cam_ids, const CameraDev* cams,
-                const float* body_poses, const uint8_t* src0, size_t src_camera_stride, uint32_t src_row_step,
-                uint8_t* dst0, size_t dst_camera_stride, uint32_t dst_pitch, int bytes_per_pixel, float margin_px,
-                m3t_roi_rect* rects /* of this slot, by camera id */) {
-  __shared__ m3t_roi_rect rect_s;
-  const int cam_id = cam_ids[blockIdx.y];
+// one thread per camera of the batch: cam_ids[i] = camera id; item_first[camera id .. + 1] = its readers in `items`;
+// rects: the rectangle table of the slot, by camera id
+__global__ void __launch_bounds__(64)
+roi_rect_kernel(const RoiItemDev* items, const int* item_first, const int* cam_ids, int n_batch, const CameraDev* cams,
+                const float* body_poses, float margin_px, m3t_roi_rect* rects) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_batch) return;
+  const int cam_id = cam_ids[i];
   const CameraDev& cam = cams[cam_id];
-  if (threadIdx.x == 0) {
-    const m3t_intrinsics k = roi_intrinsics(cam);
-    m3t_roi_rect r = m3t_roi_empty();
-    for (int i = item_first[cam_id]; i < item_first[cam_id + 1]; ++i) {
-      const RoiItemDev& it = items[i];
-      float b2c[16];
-      roi_body2camera(cam.world2camera, body_poses + 16 * it.body, b2c);
-      r = m3t_roi_union(r, m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px + margin_px, it.reach_m));
-    }
-    rect_s = r;
-    if (blockIdx.x == 0) rects[cam_id] = r;
+  const m3t_intrinsics k = roi_intrinsics(cam);
+  m3t_roi_rect r = m3t_roi_empty();
+  for (int j = item_first[cam_id]; j < item_first[cam_id + 1]; ++j) {
+    const RoiItemDev& it = items[j];
+    float b2c[16];
+    roi_body2camera(cam.world2camera, body_poses + 16 * it.body, b2c);
+    r = m3t_roi_union(r, m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px + margin_px, it.reach_m));
   }
-  __syncthreads();
-  const m3t_roi_rect r = rect_s;
+  rects[cam_id] = r;
+}
+
+// grid: (ceil(height / 8), cameras of the batch).  src / dst: camera blockIdx.y of the batch at + blockIdx.y * stride
+// (one host block, one slab).  At most 32 VGPRs: a wave of this kernel fits next to the two 240-VGPR waves per SIMD of
+// tracking_step_split_kernel, so the rectangles of frame k + 1 cross PCIe WHILE step k runs on all CUs.
+__global__ void __launch_bounds__(256)
+roi_pull_kernel(const int* cam_ids, const m3t_roi_rect* rects /* of this slot, by camera id */, const uint8_t* src0,
+                size_t src_camera_stride, uint32_t src_row_step, uint8_t* dst0, size_t dst_camera_stride,
+                uint32_t dst_pitch, int bytes_per_pixel) {
+  const m3t_roi_rect r = rects[cam_ids[blockIdx.y]];
   if (r.x1 < r.x0) return;
   const int row0 = r.y0 + (int)blockIdx.x * 8;
   if (row0 > r.y1) return;
   // the span widened to 16-byte boundaries of the row (rows start 16-byte aligned on both sides: checked by the host)
   const int b0 = (r.x0 * bytes_per_pixel) & ~15, b1 = ((r.x1 + 1) * bytes_per_pixel + 15) & ~15;
   const int chunks = (b1 - b0) >> 4;
-  const uint8_t* src = src0 + (size_t)blockIdx.y * src_camera_stride;
-  uint8_t* dst = dst0 + (size_t)blockIdx.y * dst_camera_stride;
-  for (int i = threadIdx.x; i < 8 * chunks; i += 256) {
-    const int dr = i / chunks, c = i - dr * chunks, row = row0 + dr;
-    if (row > r.y1) break;
-    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)row * src_row_step + b0 + ((size_t)c << 4));
-    *reinterpret_cast<uint4*>(dst + (size_t)row * dst_pitch + b0 + ((size_t)c << 4)) = v;
+  const uint8_t* src = src0 + (size_t)blockIdx.y * src_camera_stride + b0;
+  uint8_t* dst = dst0 + (size_t)blockIdx.y * dst_camera_stride + b0;
+  const int rows = min(8, r.y1 - row0 + 1), total = rows * chunks;
+  for (int i = threadIdx.x; i < total; i += 512) {  // two reads over PCIe in flight per thread
+    const int j = i + 256;
+    const int dr0 = i / chunks, c0 = i - dr0 * chunks;
+    const int dr1 = j / chunks, c1 = j - dr1 * chunks;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(src + (size_t)(row0 + dr0) * src_row_step + ((size_t)c0 << 4));
+    uint4 v1 = v0;
+    if (j < total) v1 = *reinterpret_cast<const uint4*>(src + (size_t)(row0 + dr1) * src_row_step + ((size_t)c1 << 4));
+    *reinterpret_cast<uint4*>(dst + (size_t)(row0 + dr0) * dst_pitch + ((size_t)c0 << 4)) = v0;
+    if (j < total) *reinterpret_cast<uint4*>(dst + (size_t)(row0 + dr1) * dst_pitch + ((size_t)c1 << 4)) = v1;
   }
 }
 

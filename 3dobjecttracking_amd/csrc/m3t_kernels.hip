@@ -699,7 +699,9 @@ __device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> 
 // Phase C  one thread per (line, d): CalculateDistribution :1600 products; then one
 //          thread per line: normalisation + CalculateDistributionMoments :1639.
 // ---------------------------------------------------------------------------
-template <bool HIST_LDS, int BMAX = 8>
+// RENDER = false: a launch shape that never runs with renderer-fed branches (the split kernel: m3t_hip_api.hip takes
+// the per-search launches of tracking_step_kernel as soon as a modality reads a rendering) leaves their code out
+template <bool HIST_LDS, int BMAX = 8, bool RENDER = true>
 __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                        const Affine& b2dc, int iteration, int corr_iteration,
                                                        const Lds& s, int line_lo = 0, int line_hi = 1 << 30,
@@ -719,10 +721,10 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
                       m.max_extent, m.n_points);
   const bool handle_occlusions = (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
   const bool measured_pass = m.measure_occlusions && handle_occlusions;
-  const bool modeled_pass = m.model_occlusions && handle_occlusions &&
+  const bool modeled_pass = RENDER && m.model_occlusions && handle_occlusions &&
                             renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
   const bool region_checking =
-      m.use_region_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
+      RENDER && m.use_region_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
   const bool occlusion_pass = measured_pass || modeled_pass;
   // A workgroup that shares its object with others (line_hi set) runs the occlusion tests -- up to 36 depth samples per
   // line -- for its own lines only and defers the two-pass vote :435-463 until the flags of all lines have been
@@ -1874,6 +1876,7 @@ __device__ __noinline__ void rigid_solve_wave(float gh, float lambda_rot, float 
 // points [pt_lo, pt_hi); a workgroup that shares its object with others (tracking_step_split_kernel) also loads the
 // model data of the other parts' points, whose correspondences arrive through split_exchange_state().
 // Part 2 (depth_correspondences_vote): the two-pass fallback :282-313 over all points.
+template <bool RENDER = true>
 __device__ __forceinline__ void depth_correspondences_scan(CDepth& m, CCam& cam, const Affine& b2c, int iteration,
                                            int corr_iteration, float* ps, int np, float* misc, int pt_lo = 0,
                                            int pt_hi = 1 << 30, int known_view = -1) {
@@ -1893,10 +1896,10 @@ __device__ __forceinline__ void depth_correspondences_scan(CDepth& m, CCam& cam,
   const int max_n_strides = f2i(considered_distance0 / m.stride_length + 0.5f);
   const bool handle_occlusions = (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
   const bool measured_pass = m.measure_occlusions && handle_occlusions;
-  const bool modeled_pass = m.model_occlusions && handle_occlusions &&
+  const bool modeled_pass = RENDER && m.model_occlusions && handle_occlusions &&
                             renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
   const bool silhouette_checking =
-      m.use_silhouette_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
+      RENDER && m.use_silhouette_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
   const bool occlusion_pass = measured_pass || modeled_pass;
   G<uint8_t> image = as_global(cam.image);
   const int own_hi = pt_hi < np ? pt_hi : np;
@@ -2095,11 +2098,12 @@ __device__ __forceinline__ void depth_correspondences_scan(CDepth& m, CCam& cam,
   __syncthreads();
 }
 
+template <bool RENDER = true>
 __device__ __forceinline__ void depth_correspondences_vote(CDepth& m, int iteration, float* ps, int np, float* misc) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const bool handle_occlusions = (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
   const bool measured_pass = m.measure_occlusions && handle_occlusions;
-  const bool modeled_pass = m.model_occlusions && handle_occlusions &&
+  const bool modeled_pass = RENDER && m.model_occlusions && handle_occlusions &&
                             renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
   bool use_occ = false;
   if (measured_pass || modeled_pass) {
@@ -2190,7 +2194,7 @@ __device__ __forceinline__ void count_add(__attribute__((address_space(1))) unsi
 // sample of bin 0x7fff, a saturated white pixel at 32 bins, look like the sentinel); then the bins are taken in passes
 // of `pass_bins`: the pass's share of the list is counted into the (small) table `counts`, its bins are blended and
 // written.  Same sums, same blend arithmetic, any number of passes.  Needs n_bins <= 32 (15-bit bin numbers).
-template <bool SHARED = false, bool LIST = false, typename CountPtr>
+template <bool SHARED = false, bool LIST = false, bool RENDER = true, typename CountPtr>
 __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                         const Affine& b2dc, bool handle_occlusions, bool initialize,
                                                         CountPtr counts, float* misc, int bin_lo = 0,
@@ -2212,9 +2216,9 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
                                       as_global(m.extents), view, m.max_extent, m.n_points);
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = n_bins * n_bins;
   const int w1 = cam.width - 1, h1 = cam.height - 1;
-  const bool visible_depth = m.model_occlusions && renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
+  const bool visible_depth = RENDER && m.model_occlusions && renderer_body_visible(m.depth_renderer, m.depth_renderer_slot);
   const bool visible_silhouette =
-      m.use_region_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
+      RENDER && m.use_region_checking && renderer_body_visible(m.silhouette_renderer, m.silhouette_renderer_slot);
   // IsLineUnoccludedMeasured at the final pose :1084-1087: the windows of all lines first -- their limits by one thread
   // per line, the samples by 16 lanes per line (three words per line in the misc block, which holds 256 lines; the
   // verdict replaces the first word; longer models test inside the walk)
@@ -2862,15 +2866,15 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_view = region_correspondences<HIST_LDS, SPLIT ? 2 : 8>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, line_lo,
-                                                                      line_hi, &vote_deferred);
+        region_view = region_correspondences<HIST_LDS, SPLIT ? 2 : 8, !SPLIT>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s,
+                                                                              line_lo, line_hi, &vote_deferred);
       }
       if (dm) {
         PHASE_T0();
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
         // (same view table and same camera pose as the region modality of this body: its search is this one's)
-        depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, pt_lo, pt_hi,
-                                   (rm && dm->view_search_shared) ? region_view : -1);
+        depth_correspondences_scan<!SPLIT>(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, pt_lo, pt_hi,
+                                           (rm && dm->view_search_shared) ? region_view : -1);
         PHASE_MARK(16);
       }
       if constexpr (SPLIT) {
@@ -2901,7 +2905,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       }
       {
         PHASE_T0();
-        if (dm) depth_correspondences_vote(*dm, iteration, ps, np, s.misc);
+        if (dm) depth_correspondences_vote<!SPLIT>(*dm, iteration, ps, np, s.misc);
         else __syncthreads();
         PHASE_MARK(25);
       }
@@ -2973,9 +2977,9 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     const int n_bins3 = rm->n_bins * rm->n_bins * rm->n_bins;
     const int bin_lo = SPLIT ? part * (n_bins3 / n_parts) : 0;
     const int bin_hi = SPLIT ? bin_lo + n_bins3 / n_parts : n_bins3;
-    region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
-                            (__attribute__((address_space(3))) uint32_t*)(lds_t + M3T_MISC_FLOATS), lds_t, bin_lo,
-                            bin_hi);
+    region_histogram_update<false, false, !SPLIT>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
+                                                  (__attribute__((address_space(3))) uint32_t*)(lds_t + M3T_MISC_FLOATS),
+                                                  lds_t, bin_lo, bin_hi);
   }
   PHASE_MARK(26);
 }

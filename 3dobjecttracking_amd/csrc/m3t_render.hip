@@ -178,9 +178,9 @@ focused_raster_kernel(const RendererDev* renderers, const int* which, const Came
 // Of a finely tessellated body most triangles never reach a pixel (tools/raster_stats.py: 1 000 - 1 300 of 20 950 on
 // the probe scene; the rest face away or lie outside the crop), and the survivors' boxes hold ~55 000 pixels in all:
 // little work, spread thin.  focused_setup_kernel (grid: slices x renderers) does the set-up and APPENDS the survivors
-// to a list; focused_resolve_kernel (one workgroup per renderer) clears a z-buffer in LDS, rasterises the list into it
-// with LDS atomics, and writes the depth and id images: no clear launch, no global atomics, no unpack launch.  The
-// words and their minimum are those of the three-launch form.
+// to a list; focused_resolve_kernel (a workgroup per band of rows of every renderer) clears its band of the z-buffer in
+// LDS, rasterises the list into it with LDS atomics, and writes the depth and id images: no clear launch, no global
+// atomics, no unpack launch.  The words and their minimum are those of the three-launch form.
 struct RasterSurvivor {
   RasterTriangle tri;
   uint32_t low_bits, pad;
@@ -238,51 +238,69 @@ focused_setup_kernel(const RendererDev* renderers, const int* which, const Camer
   }
 }
 
+// grid: (bands, renderers).  A workgroup owns a band of image rows: its z-buffer band lives in LDS, it looks at every
+// survivor and rasterises the rows that fall into its band (round 4: ONE workgroup per renderer took 166 us for the
+// probe scene's ~1 200 survivors, the three-launch form 98 us).  The workgroup that finishes last resets the counters.
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 focused_resolve_kernel(const RendererDev* renderers, const int* which) {
-  extern __shared__ uint32_t lds_z[];  // [S * S] packed words, then the queue of large triangles
+  extern __shared__ uint32_t lds_z[];  // [band rows * S] packed words, then the queue of large triangles
   constexpr int kQueue = 64, kPiece = 32;
-  const RendererDev& r = renderers[which[blockIdx.x]];
-  const int S = r.image_size, n_px = S * S;
+  const RendererDev& r = renderers[which[blockIdx.y]];
+  const int S = r.image_size;
+  const int band_rows = (S + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int row_lo = (int)blockIdx.x * band_rows, row_hi = min(row_lo + band_rows, S) - 1;  // inclusive
+  const int n_px = band_rows * S;
   const int tid = threadIdx.x, nt = blockDim.x;
   int* queue = reinterpret_cast<int*>(lds_z + n_px);
   int* n_queued = queue + kQueue;
   for (int i = tid; i < n_px; i += nt) lds_z[i] = 0xffffffffu;
-  const int n = min(*r.n_survivors, r.survivor_capacity);
+  const int n = min(__hip_atomic_load(r.n_survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), r.survivor_capacity);
   const RasterSurvivor* list = static_cast<const RasterSurvivor*>(r.survivors);
-  auto sink = [S](int px, int py, uint32_t word) { atomicMin(&lds_z[py * S + px], word); };
-  for (int base = 0; base < n; base += nt) {  // block-uniform trip count
+  auto sink = [S, row_lo](int px, int py, uint32_t word) { atomicMin(&lds_z[(py - row_lo) * S + px], word); };
+  for (int base = 0; base < n && row_lo <= row_hi; base += nt) {  // block-uniform trip count
     if (tid == 0) *n_queued = 0;
     __syncthreads();  // (also: the cleared z-buffer, the first time)
     const int i = base + tid;
     if (i < n) {
-      const RasterSurvivor sv = list[i];
-      const int pixels = (sv.tri.x1 - sv.tri.x0 + 1) * (sv.tri.y1 - sv.tri.y0 + 1);
-      int slot = kQueue;
-      if (pixels > 192) slot = atomicAdd(n_queued, 1);
-      if (slot < kQueue) queue[slot] = i;
-      else
-        for (int py = sv.tri.y0; py <= sv.tri.y1; ++py) raster_row(sv.tri, py, sv.tri.x0, sv.tri.x1, sv.low_bits, sink);
+      const RasterTriangle& tri = list[i].tri;
+      const int ya = max(tri.y0, row_lo), yb = min(tri.y1, row_hi);
+      if (ya <= yb) {
+        const RasterSurvivor sv = list[i];
+        const int pixels = (sv.tri.x1 - sv.tri.x0 + 1) * (yb - ya + 1);
+        int slot = kQueue;
+        if (pixels > 192) slot = atomicAdd(n_queued, 1);
+        if (slot < kQueue) queue[slot] = i;
+        else
+          for (int py = ya; py <= yb; ++py) raster_row(sv.tri, py, sv.tri.x0, sv.tri.x1, sv.low_bits, sink);
+      }
     }
     __syncthreads();
     const int nq = min(*n_queued, kQueue);
     for (int q = 0; q < nq; ++q) {  // a large box: 32-pixel pieces of its rows over the whole workgroup
       const RasterSurvivor big = list[queue[q]];
-      const int pieces = (big.tri.x1 - big.tri.x0 + kPiece) / kPiece, total = pieces * (big.tri.y1 - big.tri.y0 + 1);
+      const int ya = max(big.tri.y0, row_lo), yb = min(big.tri.y1, row_hi);
+      const int pieces = (big.tri.x1 - big.tri.x0 + kPiece) / kPiece, total = pieces * (yb - ya + 1);
       for (int k = tid; k < total; k += nt) {
         const int row = k / pieces, xa = big.tri.x0 + (k - row * pieces) * kPiece;
-        raster_row(big.tri, big.tri.y0 + row, xa, min(xa + kPiece - 1, big.tri.x1), big.low_bits, sink);
+        raster_row(big.tri, ya + row, xa, min(xa + kPiece - 1, big.tri.x1), big.low_bits, sink);
       }
     }
     __syncthreads();
   }
   __syncthreads();
-  for (int i = tid; i < n_px; i += nt) {
+  const int n_out = (row_hi - row_lo + 1) * S;
+  for (int i = tid; i < n_out; i += nt) {
     const uint32_t v = lds_z[i];
-    r.depth_image[i] = v == 0xffffffffu ? (uint16_t)65535 : (uint16_t)(v >> 16);
-    r.silhouette_image[i] = v == 0xffffffffu ? (uint8_t)0 : (uint8_t)(v & 0xffu);
+    r.depth_image[row_lo * S + i] = v == 0xffffffffu ? (uint16_t)65535 : (uint16_t)(v >> 16);
+    r.silhouette_image[row_lo * S + i] = v == 0xffffffffu ? (uint8_t)0 : (uint8_t)(v & 0xffu);
   }
-  if (tid == 0) *r.n_survivors = 0;  // for the next rendering
+  // every band has read the count by now once it says it is done: the last one clears the list for the next rendering
+  if (tid == 0) {
+    if (atomicAdd(r.n_survivors + 1, 1) == (int)gridDim.x - 1) {
+      __hip_atomic_store(r.n_survivors, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(r.n_survivors + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // 3/3: unpack into the u16 depth image and the u8 id image (grid: 16 x renderers)

@@ -8,6 +8,15 @@
 // pushes the host Bodies' poses (PrecalculatePoseVariables reads Body every time, region_modality.cpp:1000) and
 // launches the step for ALL registered modalities, the later calls of the round only fetch their own result.
 //
+// Two modes.  Adapter mode (default): the device computes correspondences and g/H, the host's Optimizer solves (one
+// launch per sub-step, one read-back per g/H round).  Device-optimisation mode (HipBatch::UseDeviceOptimization,
+// SURVEY 8(b) row 1): the UNMODIFIED Tracker::ExecuteTrackingStep loop (tracker.cpp:344-364) still calls every
+// sub-step, but the first CalculateCorrespondences(iteration, 0) of a step runs the whole loop nest as ONE launch
+// (m3t_hip_execute_tracking_step) and writes the resulting poses into the host Bodies; every
+// CalculateGradientAndHessian of that step then leaves gradient_ / hessian_ zero, so the host's Optimizer solves
+// (0 + lambda) theta = 0 -> theta = 0 and its pose update is the identity (optimizer.cpp:144-167, link.cpp:205-241);
+// CalculateResults writes the device pose into Body once more (the histogram update already rode in the launch).
+//
 // Needs the M3T headers (and through them Eigen / OpenCV); links -lm3t_hip.  In this repository it is compiled
 // against the interface stubs under tests/cpp/m3t_stub/ (tests/test_cpp_adapter.py).
 #ifndef M3T_HIP_MODALITY_H_
@@ -116,6 +125,19 @@ struct HipBatch {
     if (rc < 0) std::cerr << m3t_hip_last_error(ctx) << std::endl;
     return rc >= 0;
   }
+  // Device-optimisation mode for a host whose Tracker is left untouched (see the head of this file).  Every body needs
+  // its AddRigidOptimizer first; n_corr_iterations / n_update_iterations are the Tracker's (tracker.h:231-232): the
+  // device runs that many inside its one launch while the host's loop of the same length idles through.
+  bool device_optimization = false;
+  bool UseDeviceOptimization(int n_corr_iterations, int n_update_iterations) {
+    device_optimization = Status(m3t_hip_set_fused_step(ctx, 1)) &&
+                          Status(m3t_hip_tracker_set_iterations(ctx, n_corr_iterations, n_update_iterations));
+    return device_optimization;
+  }
+  bool DoNotUseDeviceOptimization() {
+    device_optimization = false;
+    return Status(m3t_hip_set_fused_step(ctx, 0));
+  }
   // StartModalities / ExecuteTrackingStep of tracker.cpp:344-364,430-445 for every registered body at once:
   // images up, poses up, the whole loop nest on the device, poses back into the host Bodies
   bool StartModalities(int iteration) {
@@ -159,7 +181,7 @@ struct HipBatch {
     round->served[size_t(modality_id)] = 1;
     return round->ok;
   }
-  Round start_round, corr_round, gh_round, res_round;
+  Round start_round, corr_round, gh_round, res_round, step_round;
   int n_modalities = 0;            // device modality ids are 0 .. n_modalities - 1
   std::vector<float> gh_cache;     // [n_modalities][6 + 36] of the last gradient / Hessian round
 };
@@ -214,6 +236,16 @@ class HipModality : public m3t::Modality {
   }
   bool CalculateCorrespondences(int iteration, int corr_iteration) override {
     if (!CheckSetUp()) return false;
+    if (batch_->device_optimization) {
+      // the first search of a step: the whole step on the device, poses into the host Bodies; the later searches
+      // of the host's loop have nothing left to do
+      if (corr_iteration > 0) return batch_->step_round.open && batch_->step_round.ok;
+      return batch_->Once(&batch_->step_round, id_, iteration, true, [&] {
+        const int rc = m3t_hip_execute_tracking_step(batch_->ctx, iteration);
+        if (rc < 0) return rc;
+        return batch_->PullPoses() ? 0 : -1;
+      });
+    }
     // (Tracker::UpdateCameras ran before the first search of a step: its images go up with that round)
     return batch_->Once(&batch_->corr_round, id_, iteration * 4096L + corr_iteration, corr_iteration == 0, [&] {
       return m3t_hip_calculate_correspondences(batch_->ctx, iteration, corr_iteration);
@@ -221,6 +253,11 @@ class HipModality : public m3t::Modality {
   }
   bool CalculateGradientAndHessian(int iteration, int corr_iteration, int opt_iteration) override {
     if (!CheckSetUp()) return false;
+    if (batch_->device_optimization) {  // g = 0, H = 0: the host's Optimizer finds theta = 0 (lambda > 0)
+      std::fill(gradient_.data(), gradient_.data() + 6, 0.0f);
+      std::fill(hessian_.data(), hessian_.data() + 36, 0.0f);
+      return batch_->step_round.open && batch_->step_round.ok;
+    }
     const bool ok = batch_->Once(&batch_->gh_round, id_, (iteration * 4096L + corr_iteration) * 4096L + opt_iteration, false, [&] {
       int rc = m3t_hip_calculate_gradient_and_hessian(batch_->ctx, iteration, corr_iteration, opt_iteration);
       if (rc < 0) return rc;
@@ -237,9 +274,19 @@ class HipModality : public m3t::Modality {
   }
   bool CalculateResults(int iteration) override {
     if (!CheckSetUp()) return false;
+    if (batch_->device_optimization)  // (the histogram update rode in the step's launch) the device pose, exactly
+      return batch_->step_round.open && batch_->step_round.ok && batch_->PullPoses();
     return batch_->Once(&batch_->res_round, id_, iteration, false,
                         [&] { return m3t_hip_calculate_results(batch_->ctx, iteration); });
   }
+  // modality.h:96-103.  Renderers and ColorHistograms of these modalities live in the library (C-ABI ids): it starts
+  // the renderings before the sub-steps that read them and clears / initialises / updates shared histograms around
+  // its modalities itself, so the host Tracker, which collects the objects to start and to clear from these getters
+  // (tracker.cpp:738-800; AddPtrIfNameNotExists skips null), must find none.
+  std::vector<std::shared_ptr<m3t::Renderer>> start_modality_renderer_ptrs() const override { return {}; }
+  std::vector<std::shared_ptr<m3t::Renderer>> correspondence_renderer_ptrs() const override { return {}; }
+  std::vector<std::shared_ptr<m3t::Renderer>> results_renderer_ptrs() const override { return {}; }
+  std::shared_ptr<m3t::ColorHistograms> color_histograms_ptr() const override { return nullptr; }
   bool VisualizeCorrespondences(int) override { return true; }
   bool VisualizeOptimization(int) override { return true; }
   bool VisualizeResults(int) override { return true; }
@@ -281,7 +328,18 @@ class HipRegionModality : public HipModality {
         depth_camera_{std::move(depth_camera)},
         region_model_{std::move(region_model)},
         params_{params} {}
-  std::shared_ptr<m3t::Model> model_ptr() const { return region_model_; }
+  std::shared_ptr<m3t::Model> model_ptr() const override { return region_model_; }
+
+  // RegionModality::ModelOcclusions / UseRegionChecking / UseSharedColorHistograms and their DoNot... twins
+  // (region_modality.cpp:168-179, 230-267) with the library's object ids in place of the host's OpenGL renderers and
+  // ColorHistograms: m3t_hip_focused_depth_renderer_create / m3t_hip_focused_silhouette_renderer_create /
+  // m3t_hip_color_histograms_create on batch->ctx.  Like the reference's setters they take effect with the next SetUp.
+  void ModelOcclusions(int depth_renderer_id) { depth_renderer_id_ = depth_renderer_id; set_up_ = false; }
+  void DoNotModelOcclusions() { depth_renderer_id_ = -1; set_up_ = false; }
+  void UseRegionChecking(int silhouette_renderer_id) { silhouette_renderer_id_ = silhouette_renderer_id; set_up_ = false; }
+  void DoNotUseRegionChecking() { silhouette_renderer_id_ = -1; set_up_ = false; }
+  void UseSharedColorHistograms(int color_histograms_id) { color_histograms_id_ = color_histograms_id; set_up_ = false; }
+  void DoNotUseSharedColorHistograms() { color_histograms_id_ = -1; set_up_ = false; }
 
   bool SetUp() override {
     set_up_ = false;
@@ -308,6 +366,12 @@ class HipRegionModality : public HipModality {
     if (color_id_ >= 0 && model_id_ >= 0 && body_id_ >= 0 && (!depth_camera_ || depth_id_ >= 0))
       id_ = m3t_hip_region_modality_create(batch_->ctx, &params_, body_id_, color_id_, model_id_, depth_id_);
     set_up_ = id_ >= 0;
+    if (set_up_ && depth_renderer_id_ >= 0)
+      set_up_ = m3t_hip_region_modality_model_occlusions(batch_->ctx, id_, depth_renderer_id_) >= 0;
+    if (set_up_ && silhouette_renderer_id_ >= 0)
+      set_up_ = m3t_hip_region_modality_use_region_checking(batch_->ctx, id_, silhouette_renderer_id_) >= 0;
+    if (set_up_ && color_histograms_id_ >= 0)
+      set_up_ = m3t_hip_region_modality_use_shared_color_histograms(batch_->ctx, id_, color_histograms_id_) >= 0;
     if (set_up_) batch_->n_modalities = std::max(batch_->n_modalities, id_ + 1);
     if (!set_up_) std::cerr << m3t_hip_last_error(batch_->ctx) << std::endl;
     return set_up_;
@@ -324,6 +388,7 @@ class HipRegionModality : public HipModality {
   std::filesystem::path model_path_;
   m3t_region_modality_params params_;
   int color_id_ = -1, depth_id_ = -1, model_id_ = -1;
+  int depth_renderer_id_ = -1, silhouette_renderer_id_ = -1, color_histograms_id_ = -1;
 };
 
 class HipDepthModality : public HipModality {
@@ -343,7 +408,13 @@ class HipDepthModality : public HipModality {
         depth_camera_{std::move(depth_camera)},
         depth_model_{std::move(depth_model)},
         params_{params} {}
-  std::shared_ptr<m3t::Model> model_ptr() const { return depth_model_; }
+  std::shared_ptr<m3t::Model> model_ptr() const override { return depth_model_; }
+
+  // DepthModality::ModelOcclusions / UseSilhouetteChecking (depth_modality.cpp:128-161) with the library's renderer ids
+  void ModelOcclusions(int depth_renderer_id) { depth_renderer_id_ = depth_renderer_id; set_up_ = false; }
+  void DoNotModelOcclusions() { depth_renderer_id_ = -1; set_up_ = false; }
+  void UseSilhouetteChecking(int silhouette_renderer_id) { silhouette_renderer_id_ = silhouette_renderer_id; set_up_ = false; }
+  void DoNotUseSilhouetteChecking() { silhouette_renderer_id_ = -1; set_up_ = false; }
 
   bool SetUp() override {
     set_up_ = false;
@@ -366,6 +437,10 @@ class HipDepthModality : public HipModality {
     if (depth_id_ >= 0 && model_id_ >= 0 && body_id_ >= 0)
       id_ = m3t_hip_depth_modality_create(batch_->ctx, &params_, body_id_, depth_id_, model_id_);
     set_up_ = id_ >= 0;
+    if (set_up_ && depth_renderer_id_ >= 0)
+      set_up_ = m3t_hip_depth_modality_model_occlusions(batch_->ctx, id_, depth_renderer_id_) >= 0;
+    if (set_up_ && silhouette_renderer_id_ >= 0)
+      set_up_ = m3t_hip_depth_modality_use_silhouette_checking(batch_->ctx, id_, silhouette_renderer_id_) >= 0;
     if (set_up_) batch_->n_modalities = std::max(batch_->n_modalities, id_ + 1);
     if (!set_up_) std::cerr << m3t_hip_last_error(batch_->ctx) << std::endl;
     return set_up_;
@@ -378,6 +453,7 @@ class HipDepthModality : public HipModality {
   std::filesystem::path model_path_;
   m3t_depth_modality_params params_;
   int depth_id_ = -1, model_id_ = -1;
+  int depth_renderer_id_ = -1, silhouette_renderer_id_ = -1;
 };
 
 }  // namespace m3t_hip_adapter

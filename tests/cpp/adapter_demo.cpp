@@ -49,6 +49,85 @@ class RawFileCamera : public BASE {
   int bytes_per_pixel_;
   std::vector<unsigned char> pixels_;
 };
+
+// The reference's host side above the modalities, reduced to one free body, for the device-optimisation mode: the
+// loop nest is tracker.cpp:344-364 / :447-517 as written there; the optimizer is Link::CalculateGradientAndHessian
+// (link.cpp:184-193: sum over the modalities), Optimizer::CalculateOptimization (optimizer.cpp:144-167: b = g,
+// A = -H + diag(lambda), solve, NaN guard) and Link::UpdatePoses (link.cpp:205-241: T <- T [R(theta_r) | theta_t]).
+struct HostOptimizer {
+  std::shared_ptr<m3t::Body> body;
+  std::vector<std::shared_ptr<m3t::Modality>> modalities;
+  float tikhonov_rotation = 1000.0f, tikhonov_translation = 30000.0f;
+  double largest_theta = 0.0;  // what the test looks at: the host's own solve found nothing left to do
+  bool CalculateOptimization(int, int, int) {
+    double a[6][7] = {};
+    for (auto& m : modalities) {
+      for (int i = 0; i < 6; ++i) {
+        a[i][6] += double(m->gradient().v[size_t(i)]);
+        for (int j = 0; j < 6; ++j) a[i][j] -= double(m->hessian().v[size_t(j) * 6 + size_t(i)]);
+      }
+    }
+    for (int i = 0; i < 6; ++i) a[i][i] += double(i < 3 ? tikhonov_rotation : tikhonov_translation);
+    for (int k = 0; k < 6; ++k) {  // (symmetric positive definite: no pivoting needed for this check)
+      for (int i = k + 1; i < 6; ++i) {
+        const double f = a[i][k] / a[k][k];
+        for (int j = k; j < 7; ++j) a[i][j] -= f * a[k][j];
+      }
+    }
+    double theta[6];
+    for (int i = 5; i >= 0; --i) {
+      double v = a[i][6];
+      for (int j = i + 1; j < 6; ++j) v -= a[i][j] * theta[j];
+      theta[i] = v / a[i][i];
+    }
+    for (double v : theta) {
+      if (v != v) return true;  // optimizer.cpp:165-166
+      largest_theta = std::max(largest_theta, v < 0 ? -v : v);
+    }
+    // T <- T * [expm(skew(theta_r)) | theta_t]; first-order rotation is enough for a test that expects theta = 0
+    const m3t::Transform3fA t = body->body2world_pose();
+    const float r[3][3] = {{1.0f, float(-theta[2]), float(theta[1])},
+                           {float(theta[2]), 1.0f, float(-theta[0])},
+                           {float(-theta[1]), float(theta[0]), 1.0f}};
+    m3t::Transform3fA out = t;
+    for (int c = 0; c < 3; ++c)
+      for (int row = 0; row < 3; ++row)
+        out.m[size_t(c) * 4 + size_t(row)] = t.m[size_t(row)] * r[0][c] + t.m[4 + size_t(row)] * r[1][c] + t.m[8 + size_t(row)] * r[2][c];
+    for (int row = 0; row < 3; ++row)
+      out.m[12 + size_t(row)] = t.m[size_t(row)] * float(theta[3]) + t.m[4 + size_t(row)] * float(theta[4]) +
+                                t.m[8 + size_t(row)] * float(theta[5]) + t.m[12 + size_t(row)];
+    body->set_body2world_pose(out);
+    return true;
+  }
+};
+struct HostTracker {  // tracker.cpp:344-364 with the sub-steps of :447-517 (no renderers, no shared histograms here)
+  std::vector<std::shared_ptr<m3t::Modality>> modalities;
+  std::vector<HostOptimizer*> optimizers;
+  int n_corr_iterations = 7, n_update_iterations = 2;
+  bool ExecuteTrackingStep(int iteration) {
+    for (int corr_iteration = 0; corr_iteration < n_corr_iterations; ++corr_iteration) {
+      int corr_save_idx = iteration * n_corr_iterations + corr_iteration;
+      for (auto& m : modalities)
+        if (!m->CalculateCorrespondences(iteration, corr_iteration)) return false;
+      for (auto& m : modalities)
+        if (!m->VisualizeCorrespondences(corr_save_idx)) return false;
+      for (int update_iteration = 0; update_iteration < n_update_iterations; ++update_iteration) {
+        int update_save_idx = corr_save_idx * n_update_iterations + update_iteration;
+        for (auto& m : modalities)
+          if (!m->CalculateGradientAndHessian(iteration, corr_iteration, update_iteration)) return false;
+        for (auto* o : optimizers)
+          if (!o->CalculateOptimization(iteration, corr_iteration, update_iteration)) return false;
+        for (auto& m : modalities)
+          if (!m->VisualizeOptimization(update_save_idx)) return false;
+      }
+    }
+    for (auto& m : modalities)
+      if (!m->CalculateResults(iteration)) return false;
+    for (auto& m : modalities)
+      if (!m->VisualizeResults(iteration)) return false;
+    return true;
+  }
+};
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -164,5 +243,50 @@ int main(int argc, char** argv) {
   std::printf("fast");
   for (float v : fast_body->body2world_pose().m) std::printf(" %a", double(v));
   std::printf("\n");
+
+  // device-optimisation mode: the UNMODIFIED host loop (HostTracker = tracker.cpp:344-364) over the adapters; the
+  // first correspondence search of the step runs the whole step on the device, the host's optimizer finds theta = 0
+  auto fused_body = std::make_shared<m3t::Body>("triangle", "triangle.obj", 1.0f, true, true, m3t::Transform3fA{});
+  fused_body->set_maximum_body_diameter(0.1f);
+  fused_body->set_body2world_pose(body2world);
+  auto fused = std::make_shared<HipBatch>(0);
+  if (!fused->ctx) return 30;
+  auto fused_region = std::make_shared<HipRegionModality>("region", fused_body, color, region_model, fused, rp, depth);
+  auto fused_depth = std::make_shared<HipDepthModality>("depth", fused_body, depth, depth_model, fused, dp);
+  if (!fused_region->SetUp() || !fused_depth->SetUp()) return 31;
+  // the getters Tracker assembles its renderer / histogram lists from (tracker.cpp:738-800): nothing for the host to run
+  if (!fused_region->start_modality_renderer_ptrs().empty() || !fused_region->correspondence_renderer_ptrs().empty() ||
+      !fused_region->results_renderer_ptrs().empty() || fused_region->color_histograms_ptr() ||
+      fused_depth->color_histograms_ptr())
+    return 32;
+  if (!fused->AddRigidOptimizer(fused_body, {fused_region->device_id(), fused_depth->device_id()})) return 33;
+  HostOptimizer host_optimizer;
+  host_optimizer.body = fused_body;
+  host_optimizer.modalities = {fused_region, fused_depth};
+  HostTracker host_tracker;
+  host_tracker.modalities = {fused_region, fused_depth};
+  host_tracker.optimizers = {&host_optimizer};
+  if (!fused->UseDeviceOptimization(host_tracker.n_corr_iterations, host_tracker.n_update_iterations)) return 34;
+  for (auto& m : host_tracker.modalities)
+    if (!m->StartModality(0, 0)) return 35;
+  if (!host_tracker.ExecuteTrackingStep(0)) return 36;
+  if (host_optimizer.largest_theta != 0.0) return 37;  // 14 host solves, all of them no-ops
+  for (float v : fused_region->hessian().v)
+    if (v != 0.0f) return 38;
+  m3t::Transform3fA device_pose;
+  if (m3t_hip_body_get_body2world_pose(fused->ctx, fused->BodyId(fused_body), device_pose.data()) < 0) return 39;
+  if (device_pose.m != fused_body->body2world_pose().m) return 40;
+  std::printf("fused");
+  for (float v : fused_body->body2world_pose().m) std::printf(" %a", double(v));
+  std::printf("\n");
+  // a region modality that names renderers / shared histograms the context does not have: SetUp fails loudly
+  {
+    auto bad = std::make_shared<HipRegionModality>("region", fused_body, color, region_model, fused, rp, depth);
+    bad->UseRegionChecking(12345);
+    if (bad->SetUp()) return 41;
+    bad->DoNotUseRegionChecking();
+    bad->UseSharedColorHistograms(m3t_hip_color_histograms_create(fused->ctx, 16, 0.2f, 0.2f));
+    if (!bad->SetUp()) return 42;
+  }
   return 0;
 }

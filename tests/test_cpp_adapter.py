@@ -90,6 +90,10 @@ def run_demo(exe, directory, *args):
     rows = {line.split()[0]: np.array([float.fromhex(x) for x in line.split()[1:]], np.float32)
             for line in out.stdout.strip().splitlines()}
     fast = rows["fast"].reshape(4, 4).T if "fast" in rows else None
+    if fast is not None:
+        # device-optimisation mode: the unmodified host loop (tracker.cpp:344-364) over the adapters ends on the same pose
+        # as the library's own ExecuteTrackingStep, bit for bit
+        assert np.array_equal(rows["fused"].reshape(4, 4).T, fast)
     # a repeated round (same iteration indices after a reset) ran again and reproduced the first result
     assert np.array_equal(rows["again"], rows["triangle_region_modality"])
     return [rows["triangle_region_modality"], rows["triangle_depth_modality"]], rows["moved"], fast
@@ -134,8 +138,13 @@ def test_adapter_over_the_hip_library(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall"] + INCLUDES + [SRC, "-o", exe, "-L", libdir, "-lm3t_hip",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     world2camera, body2world = write_scene(tmp_path)
-    got, got_moved, _ = run_demo(exe, tmp_path, "adapter-only")
+    got, got_moved, fast_pose = run_demo(exe, tmp_path)
     want, want_moved = expected(util.open_hip(), tmp_path, world2camera, body2world)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
     assert np.array_equal(got_moved, want_moved)
+    # fast mode and device-optimisation mode (run_demo checks that the two agree): the pose of the Python-driven
+    # tracker on the same library, which meets the reference's TrackerTest golden
+    assert np.array_equal(fast_pose, expected_fast_pose(util.open_hip(), tmp_path, world2camera, body2world))
+    golden = util.read_golden_matrix("tracker_test/triangle_pose.txt")
+    assert np.max(np.abs((fast_pose - golden)[:3] / golden[:3])) < 1e-5
