@@ -75,6 +75,10 @@ struct RendererDev {
   int* n_survivors;
   int survivor_capacity;
 };
+// closest_view_local: per view a row of M3T_VIEW_ROW float4: entry 0 the view itself, entries 1 .. M3T_VIEW_NEIGHBORS
+// its nearest views ({x, y, z, id bits}), the last entry {threshold, 0, 0, 0}
+#define M3T_VIEW_NEIGHBORS 18
+#define M3T_VIEW_ROW (M3T_VIEW_NEIGHBORS + 2)
 #define M3T_SURVIVOR_BYTES 104  /* RasterTriangle (m3t_raster.h: 10 doubles + 4 ints) + the low bits of its words */
 
 // a ColorHistograms object shared by several RegionModalities (region_modality.cpp:168-173)
@@ -93,6 +97,8 @@ struct RegionModDev {
   const float* points;        // [n_views][n_points][38]  the .bin layout (depth_offsets are read from here)
   const float4* points8;      // [n_views][n_points][2]: {cx,cy,cz,nx},{ny,nz,foreground_distance,background_distance}
   const float4* orientations4;  // [n_views] xyz + pad
+  const float4* view_neighbors; // [n_views][M3T_VIEW_ROW]: closest_view_local (m3t_kernels.hip), or nullptr
+  int* last_view;             // the view the last correspondence search of this modality used (-1: none yet)
   const float* extents;       // contour_length [n_views]
   int n_views, n_points;
   float max_extent;

@@ -61,6 +61,7 @@ struct Model {
   float stride_depth_offset = 0.002f, max_radius_depth_offset = 0.05f, max_extent = 0.0f;
   DevMem points, orientations, extents;
   DevMem points8, orientations4;  // device-only compact copies of the hot fields
+  DevMem view_neighbors;          // [n_views][M3T_VIEW_ROW] float4 (closest_view_local), empty for tiny view sets
   std::vector<float> h_orientations;  // host copy: modalities whose models share their view table share the view search
   float box_min[3] = {0, 0, 0}, box_max[3] = {0, 0, 0};  // around the centres of all data points (ROI ingest, m3t_roi.h)
 };
@@ -432,6 +433,36 @@ int CreateModel(Ctx* ctx, bool region, int n_views, int n_points, const float* p
     HIPCHK(m->orientations4.alloc(o4.size() * 4));
     HIPCHK(hipMemcpy(m->points8.p, p8.data(), p8.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m->orientations4.p, o4.data(), o4.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (n_views > M3T_VIEW_ROW) {
+    // closest_view_local: the M3T_VIEW_NEIGHBORS nearest views of every view and how far a viewing direction may be
+    // from the view for the argmax over ALL views to lie among them: with R = the angle to the nearest view that is
+    // NOT in the row, a direction closer to the view than R / 2 is closer to it than to any view outside the row.
+    // The threshold stored is cos(R / 2 - 2e-3 rad): the slack dwarfs every rounding error of the f32 dot products.
+    std::vector<float> rows(size_t(n_views) * M3T_VIEW_ROW * 4, 0.0f);
+    std::vector<std::pair<float, int>> by_dot(static_cast<size_t>(n_views));
+    for (int v = 0; v < n_views; ++v) {
+      const float* a = ori + size_t(v) * 3;
+      for (int w = 0; w < n_views; ++w) {
+        const float* b = ori + size_t(w) * 3;
+        by_dot[size_t(w)] = {w == v ? 4.0f : float(double(a[0]) * b[0] + double(a[1]) * b[1] + double(a[2]) * b[2]), w};
+      }
+      std::partial_sort(by_dot.begin(), by_dot.begin() + M3T_VIEW_NEIGHBORS + 2, by_dot.end(),
+                        [](const std::pair<float, int>& x, const std::pair<float, int>& y) {
+                          return x.first > y.first || (x.first == y.first && x.second < y.second);
+                        });
+      float* row = rows.data() + size_t(v) * M3T_VIEW_ROW * 4;
+      for (int k = 0; k <= M3T_VIEW_NEIGHBORS; ++k) {  // by_dot[0] is the view itself
+        const int w = by_dot[size_t(k)].second;
+        std::memcpy(row + k * 4, ori + size_t(w) * 3, 12);
+        std::memcpy(row + k * 4 + 3, &w, 4);
+      }
+      const double first_outside = std::min(1.0, std::max(-1.0, double(by_dot[M3T_VIEW_NEIGHBORS + 1].first)));
+      const double half = 0.5 * std::acos(first_outside) - 2.0e-3;
+      row[(M3T_VIEW_ROW - 1) * 4] = half > 0.0 ? float(std::cos(half)) : 2.0f;  // 2: never met
+    }
+    HIPCHK(m->view_neighbors.alloc(rows.size() * 4));
+    HIPCHK(hipMemcpy(m->view_neighbors.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
   }
   auto& vec = region ? ctx->region_models : ctx->depth_models;
   vec.push_back(std::move(m));
@@ -2154,9 +2185,10 @@ int m3t_hip_region_modality_create(m3t_hip_context* ctx, const m3t_region_modali
   HIPCHK(hipMemset(m->occupancy.p, 1, bins3 / 4));  // (the uniform start histograms below: every group is non-zero)
   if (bins3 * 4 + M3T_MISC_FLOATS * 4 > 160 * 1024) HIPCHK(m->count_scratch.alloc(bins3 * 4));
   HIPCHK(m->line_state.alloc(size_t(LS_FIELDS) * d.n_lines_max * 4));
-  HIPCHK(m->gh.alloc(42 * 4));
+  HIPCHK(m->gh.alloc(48 * 4));  // 42 floats g / H, then (at [44]) the view of the last search (int, -1: none yet)
   HIPCHK(hipMemset(m->line_state.p, 0, m->line_state.bytes));
   HIPCHK(hipMemset(m->gh.p, 0, m->gh.bytes));
+  HIPCHK(hipMemset(m->gh.as<int>() + 44, 0xff, 4));
   {  // SetUpHistograms color_histograms.cpp:160-172: uniform 1/n^3
     std::vector<float> u(bins3, 1.0f / float(bins3));
     std::vector<float> nrm(bins3 * 2, 0.5f);
@@ -2171,6 +2203,8 @@ int m3t_hip_region_modality_create(m3t_hip_context* ctx, const m3t_region_modali
   d.count_scratch = m->count_scratch.as<uint32_t>();
   d.line_state = m->line_state.as<float>();
   d.gradient_hessian = m->gh.as<float>();
+  d.view_neighbors = mdl.view_neighbors.as<float4>();
+  d.last_view = m->gh.as<int>() + 44;
   ctx->region_mods.push_back(std::move(m));
   ctx->modalities.push_back({true, int(ctx->region_mods.size()) - 1});
   ctx->tables_dirty = true;

@@ -204,6 +204,39 @@ __device__ __forceinline__ int wave_min_i(int v) {  // broadcast result
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// The viewing direction of RegionModel::GetClosestView (region_model.cpp:113-119): o = R^-1 t / |t|; false when t = 0
+// (the reference then returns the first view)
+__device__ __forceinline__ bool view_direction(const Affine& b2c, float& o0, float& o1, float& o2) {
+  const float tn = sqrtf((b2c.t[0] * b2c.t[0] + b2c.t[1] * b2c.t[1]) + b2c.t[2] * b2c.t[2]);
+  if (tn == 0.0f) return false;
+  const float tx = b2c.t[0] / tn, ty = b2c.t[1] / tn, tz = b2c.t[2] / tn;
+  float ri[9];
+  inverse3(b2c.l, ri);
+  o0 = (ri[0] * tx + ri[3] * ty) + ri[6] * tz;
+  o1 = (ri[1] * tx + ri[4] * ty) + ri[7] * tz;
+  o2 = (ri[2] * tx + ri[5] * ty) + ri[8] * tz;
+  return true;
+}
+
+// GetClosestView from the view of the previous search (round 4).  Between two searches the pose moves by a Newton
+// step, so the closest view is the previous one or one next to it.  `neighbors` holds for every view its
+// M3T_VIEW_NEIGHBORS nearest views and the cosine of the angle within which a direction is provably closer to the
+// view than to any view outside that row (m3t_hip_api.hip, CreateModel).  Inside that angle the argmax over all views
+// is the argmax over the row: the same dot products (same expression, same operands), the largest, the lowest index
+// among equals -- the result of the full scan, bit for bit.  Outside it: -1, the caller scans all views.  Every wave
+// works the row out for itself (19 lanes): no LDS, no barrier.
+__device__ __forceinline__ int closest_view_local(G<v4f> neighbors, int prev, float o0, float o1, float o2) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const v4f e = neighbors[(uint32_t)prev * M3T_VIEW_ROW + (lane < M3T_VIEW_ROW ? lane : 0)];
+  float d = (o0 * e.x + o1 * e.y) + o2 * e.z;
+  const float d_prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 0));
+  const float threshold = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.x), M3T_VIEW_ROW - 1));
+  if (!(d_prev > threshold)) return -1;  // wave-uniform (and the same in every wave: same inputs)
+  d = lane <= M3T_VIEW_NEIGHBORS ? d : -2.0f;
+  const float best = wave_max(d);
+  return wave_min_i(d == best ? __float_as_int(e.w) : INT_MAX);
+}
+
 // ---------------------------------------------------------------------------
 // RegionModel::GetClosestView (region_model.cpp:105-130), whole block.
 // First maximum wins == (max dot, lowest index); result broadcast to all threads.
@@ -705,16 +738,37 @@ template <bool HIST_LDS, int BMAX = 8, bool RENDER = true>
 __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                        const Affine& b2dc, int iteration, int corr_iteration,
                                                        const Lds& s, int line_lo = 0, int line_hi = 1 << 30,
-                                                       bool* vote_deferred = nullptr) {
+                                                       bool* vote_deferred = nullptr, int prev_view = -1) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const RegionIter it = region_iter(m, corr_iteration);
   const int nl = s.nl;
   PHASE_T0();
-  if (tid < M3T_MAX_FUNCTION_LENGTH) {
+  if (tid < M3T_MAX_FUNCTION_LENGTH) {  // (read in phase C: the barrier behind phase A publishes them)
     s.misc[kMiscLookup + tid] = m.function_lookup_f[tid];
     s.misc[kMiscLookup + M3T_MAX_FUNCTION_LENGTH + tid] = m.function_lookup_b[tid];
   }
-  const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, s.misc);  // (syncs publish the lookups)
+  // the view of the previous search first (closest_view_local); while that is worked out, the previous view's data
+  // point of this thread's first line is already on its way: most searches stay on the view
+  int view = -1;
+  v4f guess_a = {0.0f, 0.0f, 0.0f, 0.0f}, guess_b = guess_a;
+  const bool try_local = prev_view >= 0 && m.view_neighbors != nullptr;
+  if (try_local) {
+#ifndef M3T_NO_VIEW_GUESS
+    if (tid < nl) {
+      G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)prev_view * m.n_points + (tid < m.n_points ? tid : 0)) * 2;
+      guess_a = p8[0];
+      guess_b = p8[1];
+    }
+#endif
+    float o0, o1, o2;
+    if (view_direction(b2c, o0, o1, o2)) view = closest_view_local((G<v4f>)m.view_neighbors, prev_view, o0, o1, o2);
+  }
+  if (view < 0) view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, s.misc);  // block-uniform; two barriers
+#ifndef M3T_NO_VIEW_GUESS
+  const bool guessed = try_local && view == prev_view;
+#else
+  const bool guessed = false;
+#endif
   PHASE_MARK(0);
   const int n_lines =
       number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length, as_global(m.extents), view,
@@ -743,7 +797,8 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
     if (measured_pass) reinterpret_cast<uint32_t*>(s.seg_f)[line * 3 + 1] = 0u;  // no occlusion window to scan (yet)
     if (line < n_lines) {
       G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
-      const v4f pa = p8[0], pb4 = p8[1];
+      v4f pa = guess_a, pb4 = guess_b;
+      if (!(guessed && line == tid)) { pa = p8[0]; pb4 = p8[1]; }
       float cx = pa.x, cy = pa.y, cz = pa.z;
       float nx = pa.w, ny = pb4.x, nz = pb4.y;
       float fg = pb4.z, bg = pb4.w;
@@ -2199,7 +2254,7 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
                                                         const Affine& b2dc, bool handle_occlusions, bool initialize,
                                                         CountPtr counts, float* misc, int bin_lo = 0,
                                                         int bin_hi = -1, uint16_t* list = nullptr, int list_row = 0,
-                                                        int pass_bins = 0) {
+                                                        int pass_bins = 0, int prev_view = -1) {
   // [bin_lo, bin_hi): the bins this workgroup counts and blends (all of them unless it shares its object with
   // others: then every workgroup walks all lines, keeps the samples that fall into its bins, and no table
   // has to be merged); counts[0] is bin_lo's word
@@ -2211,7 +2266,13 @@ __device__ __forceinline__ void region_histogram_update(CRegion& m, CCam& cam, C
     for (int i = tid; i < (int)n_own_bins; i += nt) counts[i] = 0;
   unsigned sf = 0, sb = 0;  // this thread's foreground / background samples (all bins)
   PHASE_T0();
-  const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
+  int view = -1;
+  if (prev_view >= 0 && m.view_neighbors != nullptr) {
+    float o0, o1, o2;
+    if (view_direction(b2c, o0, o1, o2)) view = closest_view_local((G<v4f>)m.view_neighbors, prev_view, o0, o1, o2);
+    if (view >= 0) __syncthreads();  // (the counts are zeroed behind this)
+  }
+  if (view < 0) view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);  // syncs: counts are zeroed after this
   const int n_lines = number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length,
                                       as_global(m.extents), view, m.max_extent, m.n_points);
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = n_bins * n_bins;
@@ -2856,18 +2917,19 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   GW<float> search_poses = as_global_w(o.search_poses);
   const bool record_poses = o.search_poses != nullptr && part == 0 && threadIdx.x < 16;
   if (record_poses && first_corr_iteration == 0) search_poses[threadIdx.x] = pose[threadIdx.x];
+  // the view of the modality's previous search (of the previous frame for the first one): closest_view_local
+  int region_view = rm ? *as_global(rm->last_view) : -1;
   for (int c = first_corr_iteration; c < first_corr_iteration + n_corr_iterations; ++c) {
     if (record_poses) search_poses[(c + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
     {
       const Affine b2w = load_pose(pose);
-      int region_view = -1;
       bool vote_deferred = false;  // decided by region_correspondences (the one predicate for both sides)
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
         region_view = region_correspondences<HIST_LDS, SPLIT ? 2 : 8, !SPLIT>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s,
-                                                                              line_lo, line_hi, &vote_deferred);
+                                                                              line_lo, line_hi, &vote_deferred, region_view);
       }
       if (dm) {
         PHASE_T0();
@@ -2946,6 +3008,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   // (every workgroup of a split object holds the same pose: the first one writes it; no other workgroup can
   // still be waiting to read the old one, it had to publish its first results before this one got here)
   if (threadIdx.x < 16 && part == 0) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
+  if (rm && threadIdx.x == 0 && part == 0) *as_global_w(rm->last_view) = region_view;
   if (record_poses) search_poses[(first_corr_iteration + n_corr_iterations + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
   if (write_state && part == 0) {
     if (rm) {
@@ -2979,7 +3042,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     const int bin_hi = SPLIT ? bin_lo + n_bins3 / n_parts : n_bins3;
     region_histogram_update<false, false, !SPLIT>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
                                                   (__attribute__((address_space(3))) uint32_t*)(lds_t + M3T_MISC_FLOATS),
-                                                  lds_t, bin_lo, bin_hi);
+                                                  lds_t, bin_lo, bin_hi, nullptr, 0, 0, region_view);
   }
   PHASE_MARK(26);
 }
