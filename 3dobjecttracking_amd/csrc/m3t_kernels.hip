@@ -747,28 +747,15 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
     s.misc[kMiscLookup + tid] = m.function_lookup_f[tid];
     s.misc[kMiscLookup + M3T_MAX_FUNCTION_LENGTH + tid] = m.function_lookup_b[tid];
   }
-  // the view of the previous search first (closest_view_local); while that is worked out, the previous view's data
-  // point of this thread's first line is already on its way: most searches stay on the view
+  // the view of the previous search first (closest_view_local: no barrier), the scan over all views if that cannot
+  // vouch for its answer.  (Fetching this thread's data point of the previous view ahead of the search -- most
+  // searches stay on their view -- was measured: no gain, 9 VGPRs.)
   int view = -1;
-  v4f guess_a = {0.0f, 0.0f, 0.0f, 0.0f}, guess_b = guess_a;
-  const bool try_local = prev_view >= 0 && m.view_neighbors != nullptr;
-  if (try_local) {
-#ifndef M3T_NO_VIEW_GUESS
-    if (tid < nl) {
-      G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)prev_view * m.n_points + (tid < m.n_points ? tid : 0)) * 2;
-      guess_a = p8[0];
-      guess_b = p8[1];
-    }
-#endif
+  if (prev_view >= 0 && m.view_neighbors != nullptr) {
     float o0, o1, o2;
     if (view_direction(b2c, o0, o1, o2)) view = closest_view_local((G<v4f>)m.view_neighbors, prev_view, o0, o1, o2);
   }
   if (view < 0) view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, s.misc);  // block-uniform; two barriers
-#ifndef M3T_NO_VIEW_GUESS
-  const bool guessed = try_local && view == prev_view;
-#else
-  const bool guessed = false;
-#endif
   PHASE_MARK(0);
   const int n_lines =
       number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length, as_global(m.extents), view,
@@ -797,8 +784,7 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
     if (measured_pass) reinterpret_cast<uint32_t*>(s.seg_f)[line * 3 + 1] = 0u;  // no occlusion window to scan (yet)
     if (line < n_lines) {
       G<v4f> p8 = (G<v4f>)m.points8 + ((uint32_t)view * m.n_points + line) * 2;
-      v4f pa = guess_a, pb4 = guess_b;
-      if (!(guessed && line == tid)) { pa = p8[0]; pb4 = p8[1]; }
+      const v4f pa = p8[0], pb4 = p8[1];
       float cx = pa.x, cy = pa.y, cz = pa.z;
       float nx = pa.w, ny = pb4.x, nz = pb4.y;
       float fg = pb4.z, bg = pb4.w;
