@@ -79,7 +79,7 @@ struct RendererDev {
 // its nearest views ({x, y, z, id bits}), the last entry {threshold, 0, 0, 0}
 #define M3T_VIEW_NEIGHBORS 18
 #define M3T_VIEW_ROW (M3T_VIEW_NEIGHBORS + 2)
-#define M3T_SURVIVOR_BYTES 104  /* RasterTriangle (m3t_raster.h: 10 doubles + 4 ints) + the low bits of its words */
+#define M3T_SURVIVOR_BYTES 112  /* RasterTriangle (m3t_raster.h: 11 doubles + 4 ints) + the low bits of its words */
 
 // a ColorHistograms object shared by several RegionModalities (region_modality.cpp:168-173)
 struct SharedHistogramsDev {

@@ -291,6 +291,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
@@ -302,6 +303,7 @@ struct Rccl {
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+    CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(handle, "ncclCommUserRank"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce) { error = "librccl.so.1 lacks the nccl* entry points"; AllReduce = nullptr; return false; }
@@ -984,7 +986,7 @@ int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int largest_image_s
   int bands = M3T_RASTER_BANDS;
   if (const char* e = std::getenv("M3T_HIP_RASTER_BANDS")) bands = std::max(1, std::atoi(e));  // developer override
   const size_t band_rows = (size_t(largest_image_size) + bands - 1) / bands;
-  const size_t lds = band_rows * largest_image_size * 4 + 65 * 4;
+  const size_t lds = band_rows * largest_image_size * 4 + (M3T_BLOCK_THREADS + 1 + 16) * 4;  // z-buffer band | prefix sums | wave totals
   if (ctx->lds_raster < 0) {  // once per context (= per device)
     ctx->lds_raster = 1;
     if (std::getenv("M3T_HIP_NO_LDS_RASTER")) ctx->lds_raster = 0;
@@ -3259,6 +3261,12 @@ int m3t_hip_comm_init_rank(m3t_hip_context* ctx, const void* id, size_t bytes, i
   RCCLCHK(g_rccl.CommInitRank(&comm, n_ranks, u, rank));
   ctx->comm = comm;
   ctx->comm_owned = true;
+  // every rank holds the whole structure, soft constraints included, and tree_project adds their g / H to the link
+  // sums BEFORE the all-reduce: they must enter the summed system once, so only rank 0 keeps them (round-3 advisor)
+  if ((rank == 0) != ctx->soft_constraints_active) {
+    ctx->soft_constraints_active = rank == 0;
+    ctx->tables_dirty = true;
+  }
   return M3T_OK;
 }
 int m3t_hip_comm_set(m3t_hip_context* ctx, void* nccl_comm) {
@@ -3267,6 +3275,14 @@ int m3t_hip_comm_set(m3t_hip_context* ctx, void* nccl_comm) {
   if (ctx->comm && ctx->comm_owned) RCCLCHK(g_rccl.CommDestroy(ctx->comm));
   ctx->comm = static_cast<ncclComm_t>(nccl_comm);
   ctx->comm_owned = false;
+  if (ctx->comm && g_rccl.CommUserRank) {  // soft constraints on one rank only (see m3t_hip_comm_init_rank)
+    int rank = 0;
+    RCCLCHK(g_rccl.CommUserRank(ctx->comm, &rank));
+    if ((rank == 0) != ctx->soft_constraints_active) {
+      ctx->soft_constraints_active = rank == 0;
+      ctx->tables_dirty = true;
+    }
+  }
   return M3T_OK;
 }
 int m3t_hip_comm_destroy(m3t_hip_context* ctx) {

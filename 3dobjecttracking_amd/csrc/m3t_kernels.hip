@@ -1640,11 +1640,26 @@ __device__ __forceinline__ void colmul(const float (&u)[9], const float (&col)[3
 #pragma unroll
   for (int k = 0; k < 3; ++k) r[k] = (u[k] * col[0] + u[3 + k] * col[1]) + u[6 + k] * col[2];
 }
+// QUAD: the three columns live in lanes 0..2 of every group of four lanes (a matrix per group), not in lanes 0..2 of
+// the wave (one matrix per wave): the gather is a DPP quad broadcast instead of a v_readlane
+template <int C>
+__device__ __forceinline__ float quad_lane(float v) {  // lane C of the caller's group of four
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), C * 0x55, 0xf, 0xf, false));
+}
+template <bool QUAD = false>
 __device__ __forceinline__ void colgather(const float (&col)[3], float (&u)[9]) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) u[c * 3 + r] = rlf(col[r], c);
+  for (int r = 0; r < 3; ++r) {
+    if constexpr (QUAD) {
+      u[r] = quad_lane<0>(col[r]);
+      u[3 + r] = quad_lane<1>(col[r]);
+      u[6 + r] = quad_lane<2>(col[r]);
+    } else {
+      u[r] = rlf(col[r], 0);
+      u[3 + r] = rlf(col[r], 1);
+      u[6 + r] = rlf(col[r], 2);
+    }
+  }
 }
 __device__ __forceinline__ void coladd(const float (&a)[3], float sa, const float (&b)[3], float sb, float (&r)[3]) {
 #pragma unroll
@@ -1690,6 +1705,7 @@ __device__ __forceinline__ void colsolve3(float (&a)[9], float (&b)[3], float (&
 
 // exp(skew(theta_r)): Pade approximant with scaling and squaring like Eigen's MatrixFunctions (link.cpp:224),
 // operation for operation the oracle's Expm3; the result's column c is returned in lane c (c < 3).
+template <bool QUAD = false>
 __device__ __forceinline__ void colexpm3(const float (&K)[9], int c, float (&R)[3]) {
   float l1 = 0.0f;
 #pragma unroll
@@ -1722,7 +1738,7 @@ __device__ __forceinline__ void colexpm3(const float (&K)[9], int c, float (&R)[
     coladd(a2c, 12.0f, Ic, 120.0f, V);
   } else {
     float a2[9], a4c[3], t2[3];
-    colgather(a2c, a2);
+    colgather<QUAD>(a2c, a2);
     colmul(a2, a2c, a4c);  // a4 = a2 * a2
     if (l1 < 1.880152677804762e+000f) {
       coladd(a4c, 1.0f, a2c, 420.0f, t2);
@@ -1732,7 +1748,7 @@ __device__ __forceinline__ void colexpm3(const float (&K)[9], int c, float (&R)[
       coladd(t2, 1.0f, Ic, 30240.0f, V);
     } else {
       float a4[9], a6c[3], t3[3];
-      colgather(a4c, a4);
+      colgather<QUAD>(a4c, a4);
       colmul(a4, a2c, a6c);  // a6 = a4 * a2
       coladd(a6c, 1.0f, a4c, 1512.0f, t2);
       coladd(t2, 1.0f, a2c, 277200.0f, t3);
@@ -1746,12 +1762,12 @@ __device__ __forceinline__ void colexpm3(const float (&K)[9], int c, float (&R)[
   float num[3], denc[3], den[9];
   coladd(U, 1.0f, V, 1.0f, num);
   coladd(U, -1.0f, V, 1.0f, denc);
-  colgather(denc, den);
+  colgather<QUAD>(denc, den);
   colsolve3(den, num, R);
 #pragma nounroll
   for (int i = 0; i < squarings; ++i) {
     float r9[9], t[3];
-    colgather(R, r9);
+    colgather<QUAD>(R, r9);
     colmul(r9, R, t);
 #pragma unroll
     for (int j = 0; j < 3; ++j) R[j] = t[j];

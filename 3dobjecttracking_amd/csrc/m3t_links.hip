@@ -76,7 +76,8 @@ namespace {
 
 __host__ __device__ inline size_t tree_work_floats(int n_links, int dof, int n_rows) {
   size_t size = size_t(dof) + n_rows;
-  return size_t(n_links) * (12 * dof + 42 + 72) + size * size + 4 * size + size_t(n_rows) * (dof + 1) + 2 * 6 * 6 + 64;
+  return size_t(n_links) * (12 * dof + 42 + 72) + size * size + 4 * size + size_t(n_rows) * (dof + 1) + 2 * 6 * 6 + 64 +
+         size_t(n_links) * (size_t(dof) * dof + dof) + dof;  // tree_system_block: per-link terms of A and b, Tikhonov vector
 }
 
 __device__ inline void affine_to_array(const Affine& a, float* p) {
@@ -259,6 +260,7 @@ __device__ void soft_constraint_add_group(const SoftConstraintDev& sc, bool rota
 // ---------------------------------------------------------------------------
 struct TreeWork {
   float *J, *GH, *AD, *HJ, *A, *b, *temp, *cres, *j1, *j2;
+  float *terms, *tikhonov;  // [n_links][dof * dof + dof], [dof] (tree_system_block)
   int* trans;
 };
 __device__ __forceinline__ TreeWork tree_carve(float* w, int n_links, int dof, int n_rows) {
@@ -275,6 +277,8 @@ __device__ __forceinline__ TreeWork tree_carve(float* w, int n_links, int dof, i
   t.cres = t.temp + 2 * size + size;        // [n_rows]
   t.j1 = t.cres + n_rows + (size_t)n_rows * dof;
   t.j2 = t.j1 + 36;
+  t.terms = t.j2 + 36 + 64;
+  t.tikhonov = t.terms + (size_t)n_links * ((size_t)dof * dof + dof);
   return t;
 }
 
@@ -443,34 +447,34 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
     b[c] = (row && c <= lane && c < n) ? a[(size_t)lo * n + hi] : 0.0f;
   }
   float xp = row ? x[src] : 0.0f;
-  // 3. factorisation
-  float D[N];
+  // 3. factorisation, right-looking: as soon as column c is final, its term enters the running sums acc[k] of all
+  // later columns -- the same terms in the same order (c = 0, 1, ...) as the bordered algorithm's dot product
+  // sum_c A(i, c) * (D_c * A(k, c)) taken when column k's turn comes, but only the LAST term of a column's sum sits
+  // on the dependent path (broadcast, division, broadcast) instead of the whole dot product.  Padded rows / columns
+  // (lane, c >= n) hold zeros and a unit pivot: they add +-0 and are never read; one basic block, no branches.
+  float D[N], acc[N];
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    D[k] = 1.0f;
-    if (k < n) {  // uniform
-      if (k > 0) {
-        float acc = 0.0f;
+  for (int k = 0; k < N; ++k) acc[k] = 0.0f;
 #pragma unroll
-        for (int c = 0; c < k; ++c) {
-          const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(D[c] * b[c]), k));  // temp = D * A10^T
-          acc += b[c] * t;
-        }
-        b[k] -= acc;  // row k: the pivot D_k; rows below: A21 -= A20 * temp
-      }
-      D[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[k]), k));
-      const bool pivot_valid = fabsf(D[k]) > 0.0f;
-      const float q = b[k] / D[k];
-      b[k] = (pivot_valid && lane > k) ? q : b[k];
+  for (int c = 0; c < N; ++c) {
+    b[c] -= acc[c];  // row c: the pivot D_c; rows below: A21 -= A20 * temp  (c = 0: minus +0)
+    const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[c]), c));
+    D[c] = c < n ? dc : 1.0f;
+    const bool pivot_valid = fabsf(D[c]) > 0.0f;
+    const float q = b[c] / D[c];
+    b[c] = (pivot_valid && lane > c) ? q : b[c];
+    const float tv = D[c] * b[c];  // lane k: temp_k[c] = D_c * L(k, c)
+#pragma unroll
+    for (int k = c + 1; k < N; ++k) {
+      const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tv), k));
+      acc[k] += b[c] * t;
     }
   }
   // 4. L y = P b (column sweep), D z = y (pseudo-inverse), L^T w = z (ordered subtraction on broadcast values)
 #pragma unroll
   for (int c = 0; c < N - 1; ++c) {
-    if (c < n - 1) {
-      const float xc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xp), c));
-      xp = lane > c ? xp - b[c] * xc : xp;
-    }
+    const float xc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xp), c));
+    xp = lane > c ? xp - b[c] * xc : xp;
   }
   float dself = 1.0f;
 #pragma unroll
@@ -481,13 +485,11 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
   for (int i = 0; i < N; ++i) X[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xp), i));
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
-    if (i < n) {
-      float sacc = X[i];
+    float sacc = X[i];
 #pragma unroll
-      for (int r = i + 1; r < N; ++r)
-        if (r < n) sacc -= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[i]), r)) * X[r];  // L(r, i) * w_r
-      X[i] = sacc;
-    }
+    for (int r = i + 1; r < N; ++r)
+      sacc -= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[i]), r)) * X[r];  // L(r, i) * w_r
+    X[i] = sacc;
   }
   // 5. un-permute: position p is input row src
   float mine = 0.0f;
@@ -498,7 +500,9 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
 }
 template <bool WAVE>
 __device__ __forceinline__ void ldlt_solve_any(float* a, float* x, int n, float* temp, int* trans) {
-  if (n <= 16) ldlt_solve_rows<16, WAVE>(a, x, n, temp, trans);
+  if (n <= 8) ldlt_solve_rows<8, WAVE>(a, x, n, temp, trans);
+  else if (n <= 13) ldlt_solve_rows<13, WAVE>(a, x, n, temp, trans);  // (13: a free root and seven one-dof joints)
+  else if (n <= 16) ldlt_solve_rows<16, WAVE>(a, x, n, temp, trans);
   else ldlt_solve_wave<WAVE>(a, x, n, temp, trans);
 }
 
@@ -506,9 +510,11 @@ __device__ __forceinline__ void ldlt_solve_any(float* a, float* x, int n, float*
 // links: the structure's link table (global, or its LDS copy); gh_links: nullptr = every link sums its modalities'
 // buffers (Link::CalculateGradientAndHessian), else [n_links][42] link sums already formed; A / b: where the
 // [dof x dof] (lower) and [dof] sums go.
+// The part of the projection that depends on the joint poses only: the adjoints and Jacobians of all links
+// (Link::CalculateJacobian link.cpp:159-182).  tracking_step_tree_kernel runs it on an otherwise idle wave (MODE 1)
+// while the first wave forms the link's sums and the other links' sums are on their way.
 template <int MODE>
-__device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev* links, const TreeWork& w, const float* gh_links, float* A,
-                             float* b, const float* body_poses) {
+__device__ __forceinline__ void tree_kinematics(const TreeOptDev& o, const LinkDev* links, const TreeWork& w) {
   const int lane = tree_lane<MODE>(), width = tree_width<MODE>(), dof = o.dof, n_links = o.n_links;
   PHASE_T0();
   // adjoints of every link, one lane per link (they depend on the link's own joint poses only)
@@ -547,8 +553,21 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
     }
     tree_sync_mode<MODE>();
   }
-
+  for (int li = lane; li < n_links; li += width) {  // Tikhonov vector optimizer.cpp:252-271 (free-direction order)
+    const LinkDev& l = links[li];
+    int j = l.first_jacobian_index;
+    for (int d = 0; d < 6; ++d)
+      if (l.free_directions[d]) w.tikhonov[j++] = d < 3 ? o.tikhonov_rotation : o.tikhonov_translation;
+  }
   PHASE_MARK(18);
+}
+
+template <int MODE>
+__device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev* links, const TreeWork& w, const float* gh_links, float* A,
+                             float* b, const float* body_poses, bool kinematics_done = false) {
+  const int lane = tree_lane<MODE>(), width = tree_width<MODE>(), dof = o.dof, n_links = o.n_links;
+  if (!kinematics_done) tree_kinematics<MODE>(o, links, w);
+  PHASE_T0();
   // Link::CalculateGradientAndHessian link.cpp:184-193
   for (int e = lane; e < n_links * 42; e += width) {
     const int li = e / 42, i = e - li * 42;
@@ -622,22 +641,116 @@ __device__ __forceinline__ void tree_project(const TreeOptDev& o, const LinkDev*
   PHASE_MARK(20);
 }
 
+// tracking_step_tree_kernel's form of the sums of tree_project (the kinematics are done: tree_kinematics), by the WHOLE
+// workgroup, straight into the system of tree_solve (w.A: [size x size], w.b): the dof x dof block -sum J^T H J (lower
+// triangle) with the Tikhonov diagonal, b = sum J^T g, zeros elsewhere (constraint rows are added by tree_solve).
+// Every number is formed by the operations of tree_project in their order -- a 6-term dot per (element, link), the
+// links added one after the other -- only that the dots of all links are taken side by side first (w.terms) instead
+// of inside the element's loop over the links: 3 short rounds over 512 threads instead of a 48-term serial loop.
+__device__ __forceinline__ void tree_system_block(const TreeOptDev& o, const LinkDev* links, const TreeWork& w,
+                                                  const float* gh_links) {
+  const int tid = threadIdx.x, nt = blockDim.x, dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
+  const int per_link = dof * dof + dof;
+  PHASE_T0();
+  // Link::CalculateGradientAndHessian link.cpp:184-193: the link sums as they were collected (gh_links), unless soft
+  // constraints add to them: then a copy (w.GH)
+  const float* GH = gh_links;
+  if (o.n_soft > 0) {  // SoftConstraint::AddGradientsAndHessiansToLinks soft_constraint.cpp:113-131 (optimizer.cpp:283-284)
+    GH = w.GH;
+    for (int e = tid; e < n_links * 42; e += nt) w.GH[e] = gh_links[e];
+    __syncthreads();
+    if (tid == 0) {
+      for (int si = 0; si < o.n_soft; ++si) {
+        const SoftConstraintDev& sc = o.soft[si];
+        Affine b12j1 = load_pose(sc.joint.body12joint1);
+        Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(load_pose(links[sc.joint.link1].link2world))),
+                                       load_pose(links[sc.joint.link2].link2world));
+        Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(sc.joint.body22joint2)));
+        for (int which = 0; which < 2; ++which) {
+          float g[6], h[36];
+          for (int i = 0; i < 6; ++i) g[i] = 0.0f;
+          for (int i = 0; i < 36; ++i) h[i] = 0.0f;
+          const Affine& body2joint1 = which == 0 ? b12j1 : body22joint1;
+          const float sign = which == 0 ? -1.0f : 1.0f;
+          soft_constraint_add_group(sc, true, joint22joint1, body2joint1, sign, g, h);
+          soft_constraint_add_group(sc, false, joint22joint1, body2joint1, sign, g, h);
+          float* gh = w.GH + (size_t)(which == 0 ? sc.joint.link1 : sc.joint.link2) * 42;
+          for (int i = 0; i < 6; ++i) gh[i] += g[i];
+          for (int i = 0; i < 36; ++i) gh[6 + i] += h[i];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // H J of every link
+  for (int e = tid; e < n_links * 6 * dof; e += nt) {
+    const int li = e / (6 * dof), rem = e - li * 6 * dof, c = rem / 6, r = rem - c * 6;
+    const float* H = GH + (size_t)li * 42 + 6;
+    const float* J = w.J + (size_t)li * 6 * dof;
+    float sacc = 0.0f;
+    for (int k = 0; k < 6; ++k) sacc += H[k * 6 + r] * J[(size_t)c * 6 + k];
+    w.HJ[e] = sacc;
+  }
+  __syncthreads();
+  PHASE_MARK(19);
+  // the terms of every link: J^T g (dof) and, for the lower triangle, J^T (H J) (dof x dof)
+  for (int x = tid; x < n_links * per_link; x += nt) {
+    const int li = x / per_link, e = x - li * per_link;
+    const float* J = w.J + (size_t)li * 6 * dof;
+    float sacc = 0.0f;
+    if (e < dof) {
+      const float* g = GH + (size_t)li * 42;
+      for (int k = 0; k < 6; ++k) sacc += J[(size_t)e * 6 + k] * g[k];
+    } else {
+      const int a = e - dof, c = a / dof, r = a - c * dof;
+      if (r >= c) {
+        const float* hj = w.HJ + (size_t)li * 6 * dof;
+        for (int k = 0; k < 6; ++k) sacc += J[(size_t)r * 6 + k] * hj[(size_t)c * 6 + k];
+      }
+    }
+    w.terms[x] = sacc;
+  }
+  __syncthreads();
+  // the links one after the other, then the Tikhonov term of the diagonal (tree_solve adds it after the sums too)
+  for (int i = tid; i < size; i += nt) {
+    float acc = 0.0f;
+    if (i < dof)
+      for (int li = 0; li < n_links; ++li) acc += w.terms[(size_t)li * per_link + i];
+    w.b[i] = acc;
+  }
+  for (int e = tid; e < size * size; e += nt) {
+    const int c = e / size, r = e - c * size;
+    float acc = 0.0f;
+    if (c < dof && r < dof && r >= c) {
+      for (int li = 0; li < n_links; ++li) acc -= w.terms[(size_t)li * per_link + dof + c * dof + r];
+      if (r == c) acc += w.tikhonov[c];
+    }
+    w.A[e] = acc;
+  }
+  __syncthreads();
+  PHASE_MARK(20);
+}
+
 // the rest of Optimizer::CalculateOptimization + Optimizer::UpdatePoses (:335-346).  partial: [dof x dof | dof] sums
 // (after the all-reduce when the structure spans GPUs); w.J must hold the links' Jacobians.  Returns false when the
 // NaN guard skipped the update.
 template <int MODE>
 __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, const TreeWork& w, const float* partial, float* body_poses,
-                           int zero_theta) {
+                           int zero_theta, bool assembled = false) {
+  // assembled: w.A / w.b already hold the sums and the Tikhonov diagonal (tree_system_block); only the constraint
+  // rows are still to be added
   const int lane = tree_lane<MODE>(), width = tree_width<MODE>(), dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
   PHASE_T0();
   float* A = w.A;
   float* b = w.b;
-  for (int e = lane; e < size * size; e += width) {
-    const int c = e / size, r = e - c * size;
-    A[e] = (!zero_theta && c < dof && r < dof) ? partial[(size_t)c * dof + r] : 0.0f;
+  if (!assembled) {
+    for (int e = lane; e < size * size; e += width) {
+      const int c = e / size, r = e - c * size;
+      A[e] = (!zero_theta && c < dof && r < dof) ? partial[(size_t)c * dof + r] : 0.0f;
+    }
+    for (int i = lane; i < size; i += width) b[i] = (!zero_theta && i < dof) ? partial[(size_t)dof * dof + i] : 0.0f;
+    tree_sync_mode<MODE>();
   }
-  for (int i = lane; i < size; i += width) b[i] = (!zero_theta && i < dof) ? partial[(size_t)dof * dof + i] : 0.0f;
-  tree_sync_mode<MODE>();
   if (!zero_theta) {  // zero_theta: Optimizer::CalculateConsistentPoses optimizer.cpp:135 (theta = 0)
     // constraints: Constraint::CalculateResidualAndConstraintJacobian constraint.cpp:81-102
     int idx = dof;
@@ -677,16 +790,18 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
       idx += n_c;
     }
     // Tikhonov vector optimizer.cpp:252-271 (free-direction order, rotation first)
-    for (int li = lane; li < n_links; li += width) {
-      const LinkDev& l = links[li];
-      int j = l.first_jacobian_index;
-      for (int d = 0; d < 6; ++d)
-        if (l.free_directions[d]) {
-          A[(size_t)j * size + j] += d < 3 ? o.tikhonov_rotation : o.tikhonov_translation;
-          j++;
-        }
+    if (!assembled) {
+      for (int li = lane; li < n_links; li += width) {
+        const LinkDev& l = links[li];
+        int j = l.first_jacobian_index;
+        for (int d = 0; d < 6; ++d)
+          if (l.free_directions[d]) {
+            A[(size_t)j * size + j] += d < 3 ? o.tikhonov_rotation : o.tikhonov_translation;
+            j++;
+          }
+      }
+      tree_sync_mode<MODE>();
     }
-    tree_sync_mode<MODE>();
     PHASE_MARK(12);
     // the factorisation is wave-level code: in the whole-workgroup mode the first wave runs it, the others wait
     if (MODE != 2 || threadIdx.x < kWave) ldlt_solve_any<MODE != 0>(A, b, size, w.temp, w.trans);
@@ -703,19 +818,42 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
   }
   // Link::UpdatePoses link.cpp:205-241: the variations of all links at once (one lane per link) ...
   float* var_all = w.AD;  // [n_links][12]
-  for (int li = lane; li < n_links; li += width) {
-    const LinkDev& l = links[li];
-    float th[6];
-    int j = l.first_jacobian_index;
-    for (int d = 0; d < 6; ++d) th[d] = l.free_directions[d] ? b[j++] : 0.0f;
-    float K[9], R[9];
-    K[0] = 0.0f;   K[3] = -th[2]; K[6] = th[1];
-    K[1] = th[2];  K[4] = 0.0f;   K[7] = -th[0];
-    K[2] = -th[1]; K[5] = th[0];  K[8] = 0.0f;
-    expm3(K, R);
-    float* v = var_all + (size_t)li * 12;
-    for (int i = 0; i < 9; ++i) v[i] = R[i];
-    v[9] = th[3]; v[10] = th[4]; v[11] = th[5];
+  if constexpr (MODE == 2) {
+    for (int li = lane; li < n_links; li += width) {
+      const LinkDev& l = links[li];
+      float th[6];
+      int j = l.first_jacobian_index;
+      for (int d = 0; d < 6; ++d) th[d] = l.free_directions[d] ? b[j++] : 0.0f;
+      float K[9], R[9];
+      K[0] = 0.0f;   K[3] = -th[2]; K[6] = th[1];
+      K[1] = th[2];  K[4] = 0.0f;   K[7] = -th[0];
+      K[2] = -th[1]; K[5] = th[0];  K[8] = 0.0f;
+      expm3(K, R);
+      float* v = var_all + (size_t)li * 12;
+      for (int i = 0; i < 9; ++i) v[i] = R[i];
+      v[9] = th[3]; v[10] = th[4]; v[11] = th[5];
+    }
+  } else {
+    // four lanes per link: lane c < 3 of the group works out column c of exp(skew(theta_r)) (colexpm3: the oracle's
+    // Expm3 operation for operation, a third of its serial length), lane 3 carries the translation
+    for (int base = 0; base < n_links; base += kWave / 4) {
+      const int li = base + (lane >> 2), c = lane & 3;
+      if (li < n_links) {
+        const LinkDev& l = links[li];
+        float th[6];
+        int j = l.first_jacobian_index;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) th[d] = l.free_directions[d] ? b[j++] : 0.0f;
+        float K[9], col[3];
+        K[0] = 0.0f;   K[3] = -th[2]; K[6] = th[1];
+        K[1] = th[2];  K[4] = 0.0f;   K[7] = -th[0];
+        K[2] = -th[1]; K[5] = th[0];  K[8] = 0.0f;
+        colexpm3<true>(K, c, col);
+        float* v = var_all + (size_t)li * 12;
+        if (c == 3) { col[0] = th[3]; col[1] = th[4]; col[2] = th[5]; }
+        v[c * 3] = col[0]; v[c * 3 + 1] = col[1]; v[c * 3 + 2] = col[2];
+      }
+    }
   }
   tree_sync_mode<MODE>();
   PHASE_MARK(14);
@@ -936,6 +1074,11 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
       __syncthreads();
       const uint32_t tag = xp.seq * 64u + (uint32_t)round + 1u;
       auto* slot = granules + (size_t)(round & 1) * o.n_tracked * M3T_TREE_GRANULES;
+      if (tid >= kWave && tid < 2 * kWave) {
+        // the second wave: adjoints and Jacobians of the structure (they depend on the joint poses only) while the
+        // first wave runs down this link's sums and the other links' sums are on their way
+        tree_kinematics<1>(o, links, w);
+      }
       if (tid < kWave) {  // one wave: the sums in the reference's order, the link's sum, publish
         float sum_r = 0.0f, sum_d = 0.0f;
         chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
@@ -976,12 +1119,13 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
         }
         return;
       }
-      {  // Optimizer::CalculateOptimization + UpdatePoses on this workgroup's copy of the structure, by all its threads
+      {  // Optimizer::CalculateOptimization + UpdatePoses on this workgroup's copy of the structure: the sums by all
+         // threads (the barrier above also says that the second wave's Jacobians are there), the solve and the pose
+         // updates -- short dependent stages -- by the first wave
         PHASE_T0();
-        tree_project<2>(o, links, w, gh_links, partial, partial + dof * dof, nullptr);
-        __syncthreads();
+        tree_system_block(o, links, w, gh_links);
         PHASE_MARK(30);
-        (void)tree_solve<2>(o, links, w, partial, nullptr, 0);
+        if (tid < kWave) (void)tree_solve<1>(o, links, w, nullptr, nullptr, 0, true);
         PHASE_MARK(31);
       }
       __syncthreads();

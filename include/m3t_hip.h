@@ -222,7 +222,9 @@ int m3t_hip_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, 
 /* SoftConstraint (include/m3t/soft_constraint.h:52-62; soft_constraint.cpp:113-131,220-272): a joint that only
  * pulls once its rotation / translation error exceeds max_distance_*, weighted with 1/standard_deviation^2;
  * it adds to the g/H of both links before the projection.  A structure spread over several processes
- * (begin -> all-reduce -> end) keeps them active on one rank only: set_soft_constraints_active(0) elsewhere. */
+ * (begin -> all-reduce -> end) keeps them active on one rank only: m3t_hip_comm_init_rank / m3t_hip_comm_set switch
+ * them off on every rank but 0 (their terms would otherwise enter the summed system once per rank); a host that
+ * all-reduces the partial buffers itself calls set_soft_constraints_active(0) on the other ranks. */
 int m3t_hip_soft_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, int link2_id,
                                    const float body12joint1[16], const float body22joint2[16],
                                    const int constraint_directions[6], float max_distance_rotation,

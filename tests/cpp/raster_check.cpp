@@ -65,6 +65,17 @@ int main(int argc, char** argv) {
       for (int xa = t.x0; xa <= t.x1; xa += 32) raster_row(t, py, xa, xa + 31 < t.x1 ? xa + 31 : t.x1, low, sink_c);
     for (int i = 0; i < S * S; ++i) mismatches += (a[i] != b[i]) + (a[i] != c[i]);
   }
+  // raster_quotient against the division it replaces: integer operands as the edge functions and areas are
+  {
+    std::mt19937_64 r64(99);
+    for (int bits = 2; bits <= 52; ++bits)
+      for (int i = 0; i < 1000000; ++i) {
+        const unsigned long long area = (r64() >> (64 - bits)) | 1ull;
+        const unsigned long long e = (i & 1) ? r64() % (area + 1) : r64() >> (64 - bits);
+        const double b = (double)area, a = (double)e;
+        mismatches += raster_quotient(a, b, 1.0 / b) != a / b;
+      }
+  }
   std::printf("triangles %lld covered %lld mismatches %lld\n", accepted, covered, mismatches);
   return mismatches == 0 ? 0 : 1;
 }

@@ -3,6 +3,8 @@
 //   full     one hipMemcpyAsync of the whole block (what m3t_hip_cameras_upload_batch_async does today)
 //   2d       one hipMemcpy2DAsync per camera for its rectangle
 //   pull     ONE kernel that reads the rectangles straight from the mapped host block over PCIe and writes the ring
+//   2d/8     the per-camera 2-D copies spread over 8 streams (do several SDMA queues run them side by side?)
+//   graph    the 64 2-D copies as memcpy nodes of ONE hipGraph without edges between them
 // for rectangles of 128^2 ... 512^2 pixels.  Prints ms per batch-frame and the frames/s x 64 objects they allow.
 //   hipcc --offload-arch=gfx950 -O3 -o ubench_ingest tools/ubench_ingest.hip && ./ubench_ingest
 #include <hip/hip_runtime.h>
@@ -86,6 +88,51 @@ int main() {
       CHECK(hipStreamSynchronize(s));
       ms2d = ms_since(t) / reps;
     }
+    double ms2d8 = 0.0, msgraph = 0.0;
+    {
+      static hipStream_t many[8];
+      static bool made = false;
+      if (!made) { for (auto& st : many) CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); made = true; }
+      auto run = [&] {
+        for (int i = 0; i < N; ++i) {
+          const Rect& r = rects[i];
+          const size_t at = (size_t)i * FRAME + (size_t)r.y0 * PITCH + (size_t)r.x0 * BPP;
+          CHECK(hipMemcpy2DAsync(ring + at, PITCH, host + at, PITCH, (size_t)(r.x1 - r.x0) * BPP, r.y1 - r.y0,
+                                 hipMemcpyHostToDevice, many[i & 7]));
+        }
+      };
+      run();
+      for (auto& st : many) CHECK(hipStreamSynchronize(st));
+      auto t = now();
+      for (int k = 0; k < reps; ++k) run();
+      for (auto& st : many) CHECK(hipStreamSynchronize(st));
+      ms2d8 = ms_since(t) / reps;
+    }
+    {
+      hipGraph_t graph;
+      CHECK(hipGraphCreate(&graph, 0));
+      for (int i = 0; i < N; ++i) {
+        const Rect& r = rects[i];
+        const size_t at = (size_t)i * FRAME + (size_t)r.y0 * PITCH + (size_t)r.x0 * BPP;
+        hipMemcpy3DParms p{};
+        p.srcPtr = make_hipPitchedPtr(host + at, PITCH, W, H);
+        p.dstPtr = make_hipPitchedPtr(ring + at, PITCH, W, H);
+        p.extent = make_hipExtent((size_t)(r.x1 - r.x0) * BPP, r.y1 - r.y0, 1);
+        p.kind = hipMemcpyHostToDevice;
+        hipGraphNode_t node;
+        CHECK(hipGraphAddMemcpyNode(&node, graph, nullptr, 0, &p));
+      }
+      hipGraphExec_t exec;
+      CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      CHECK(hipGraphLaunch(exec, s));
+      CHECK(hipStreamSynchronize(s));
+      auto t = now();
+      for (int k = 0; k < reps; ++k) CHECK(hipGraphLaunch(exec, s));
+      CHECK(hipStreamSynchronize(s));
+      msgraph = ms_since(t) / reps;
+      CHECK(hipGraphExecDestroy(exec));
+      CHECK(hipGraphDestroy(graph));
+    }
     {
       const int rows = rects[0].y1 - rects[0].y0;
       auto run = [&] { hipLaunchKernelGGL(pull_kernel, dim3((rows + 7) / 8, N), dim3(256), 0, s, host_dev, ring, d_rects); };
@@ -99,6 +146,8 @@ int main() {
     printf("rect %3d^2 (%5.1f %% of the frames)  2d x 64: %7.3f ms (%5.1f GB/s, %8.0f pose-updates/s)   pull kernel: %7.3f ms (%5.1f GB/s, "
            "%8.0f pose-updates/s)\n", side, 100.0 * bytes / (N * FRAME), ms2d, bytes / ms2d * 1e-6, N / ms2d * 1e3, mspull,
            bytes / mspull * 1e-6, N / mspull * 1e3);
+    printf("               2d x 64 over 8 streams: %7.3f ms (%5.1f GB/s)   64 memcpy nodes in one graph: %7.3f ms (%5.1f GB/s)\n",
+           ms2d8, bytes / ms2d8 * 1e-6, msgraph, bytes / msgraph * 1e-6);
   }
   return 0;
 }
