@@ -272,7 +272,9 @@ struct m3t_hip_context {
   unsigned copies_pending = 0;  // bit s: copy stream s has frames not yet ordered before the compute stream
   long step_counter = 0, copy_waited_step[kCopyStreams] = {-1, -1, -1, -1};
   std::vector<void*> registered;
-  bool timing = false;
+  bool timing = false;        // m3t_hip_set_kernel_timing(1): an event pair around every launch
+  bool timing_region = false; // m3t_hip_set_kernel_timing(2): ONE pair around all launches until the query
+  hipEvent_t region_a = nullptr, region_b = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   struct Pending { hipEvent_t a, b; int which; };
   std::vector<Pending> pending;
@@ -545,8 +547,9 @@ int CheckSplitExchange(Ctx* ctx) {
   if (value != ctx->split_abort_seen) {
     ctx->split_abort_seen = value;
     const bool tree = std::strcmp(ctx->last_step_kernel, "tracking_step_tree_kernel") == 0;
+    const bool render = std::strcmp(ctx->last_step_kernel, "tracking_step_split_render_kernel") == 0;
     const std::string msg =
-        std::string(tree ? "tracking_step_tree_kernel" : "tracking_step_split_kernel") +
+        std::string(tree ? "tracking_step_tree_kernel" : (render ? "tracking_step_split_render_kernel" : "tracking_step_split_kernel")) +
         ": a workgroup waited in vain for the other workgroups of its " + (tree ? "kinematic structure" : "object") +
         " (is another process or stream using this GPU?); the step was abandoned part-way: workgroups that had "
         "already finished may have written the new pose" + (tree ? "s and joints" : "") +
@@ -1303,6 +1306,8 @@ int UploadTables(Ctx* ctx) {
       if (m->shared_histograms >= 0 || m->p.n_histogram_bins < 4) ctx->split_possible = false;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_split_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_split_render_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_lds_kernel),
@@ -1362,6 +1367,7 @@ struct ScopedKernelTimer {
   int which;
   hipEvent_t a = nullptr, b = nullptr;
   ScopedKernelTimer(Ctx* c, int w) : ctx(c), which(w) {
+    if (ctx->timing_region) ctx->kernel_launches[w] += 1;  // (no event between the launches)
     if (!ctx->timing) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
     (void)hipEventRecord(a, ctx->stream);
@@ -1596,6 +1602,8 @@ void m3t_hip_destroy(m3t_hip_context* ctx) {
   if (ctx->split_abort_host) (void)hipHostFree(ctx->split_abort_host);
   if (ctx->roi_miss_host) (void)hipHostFree(ctx->roi_miss_host);
   if (ctx->roi_snapshot_done) (void)hipEventDestroy(ctx->roi_snapshot_done);
+  if (ctx->region_a) (void)hipEventDestroy(ctx->region_a);
+  if (ctx->region_b) (void)hipEventDestroy(ctx->region_b);
   if (ctx->comm && ctx->comm_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
   delete ctx;
 }
@@ -3320,6 +3328,78 @@ int m3t_hip_calculate_results(m3t_hip_context* ctx, int iteration) {
   return LaunchHistogram(ctx, iteration, false);
 }
 
+// tracking_step_split_kernel / _split_render_kernel: how many workgroups per object (0: none) for a batch of n.
+// parts x padded elements per part = 256 (the collecting threads of split_exchange_state); the grid must fit the GPU
+// with every workgroup resident at once (their in-kernel exchange needs that).
+extern "C++" {
+template <typename K>
+int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_histogram, size_t* lds_out) {
+  const size_t lds_tracking = size_t(ctx->layout.off_hist >= 0 ? ctx->layout.off_hist : ctx->layout.total_floats) * 4;
+  // (each workgroup counts its share of the histogram bins: that share of the count table; the pair table is
+  // read from L2, never staged)
+  auto lds_split_for = [&](int p) {
+    return want_fused_histogram ? std::max(lds_tracking, M3T_MISC_FLOATS * 4 + (ctx->lds_hist - M3T_MISC_FLOATS * 4) / p)
+                                : lds_tracking;
+  };
+  int limit = ctx->split_parts_override > 1 ? ctx->split_parts_override : 8;
+  if (const char* e = std::getenv("M3T_HIP_SPLIT_PARTS")) limit = std::atoi(e);  // developer override
+  const int elements = std::max(ctx->layout.nl, ctx->depth_mods.empty() ? 1 : ctx->np_max);
+  for (int p = M3T_SPLIT_MAX_PARTS; p >= 2; p >>= 1) {
+    // 256-thread workgroups (developer override): two are resident per CU if their LDS fits twice
+    const int per_cu = (threads == M3T_SPLIT_LANES && lds_split_for(p) * 2 <= size_t(160) * 1024) ? 2 : 1;
+    const int padded = (n + 7) / 8 * 8;  // grid blocks / p: every XCD gets the blocks of the fullest one
+    if (p > limit || padded * p > ctx->prop.multiProcessorCount * per_cu) continue;
+    if ((elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;  // a part's elements fit its share of the lanes
+    // the exchange needs every workgroup of the grid resident at once: ask the runtime how many of these
+    // workgroups (registers, LDS) a CU takes, instead of assuming the LDS arithmetic above is the only limit
+    int resident = ResidentBlocks(ctx, kernel, threads, lds_split_for(p));
+    if (resident > per_cu) resident = per_cu;  // (the query is known to over-report by one block for SGPR-heavy kernels)
+    if (resident < 1 || padded * p > ctx->prop.multiProcessorCount * resident) continue;
+    *lds_out = lds_split_for(p);
+    return p;
+  }
+  return 0;
+}
+}  // extern "C++"
+// the exchange buffers and the per-launch descriptor of a split launch
+int PrepareSplit(Ctx* ctx, int n, int parts, SplitParams* out) {
+  const size_t per_object = size_t(2) * M3T_SPLIT_LANES * 32;  // granules
+  if (!ctx->split_abort_host) {
+    void* host = nullptr;
+    HIPCHK(hipHostMalloc(&host, 64, hipHostMallocMapped));
+    std::memset(host, 0, 64);
+    void* dev = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dev, host, 0));
+    ctx->split_abort_host = static_cast<unsigned*>(host);
+    ctx->split_abort_dev = static_cast<unsigned*>(dev);
+  }
+  if (ctx->split_objects < size_t(n) || ctx->split_seq >= (1u << 26) - 1) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->split_objects < size_t(n)) {
+      HIPCHK(ctx->d_split.alloc(size_t(n) * per_object * sizeof(unsigned long long) + size_t(n) * sizeof(unsigned)));
+      ctx->split_objects = size_t(n);
+    }
+    HIPCHK(hipMemset(ctx->d_split.p, 0, ctx->d_split.bytes));
+    ctx->split_seq = 0;
+  }
+  ++ctx->split_seq;
+  SplitParams sp{};
+  sp.granules = ctx->d_split.as<unsigned long long>();
+  sp.object_abort = reinterpret_cast<unsigned*>(sp.granules + ctx->split_objects * per_object);
+  sp.host_abort = ctx->split_abort_dev;
+  sp.seq = ctx->split_seq;
+  if (++ctx->split_launches == 0) ctx->split_launches = 1;  // (0 = the word's initial value)
+  sp.abort_id = ctx->split_launches;
+  sp.n_objects = n;
+  sp.n_parts = parts;
+  sp.lshift = 0;
+  while ((parts << sp.lshift) < M3T_SPLIT_LANES) ++sp.lshift;
+  sp.per_part_lines = (ctx->layout.nl + parts - 1) / parts;
+  sp.per_part_points = (ctx->np_max + parts - 1) / parts;
+  *out = sp;
+  return M3T_OK;
+}
+
 int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));
@@ -3363,33 +3443,10 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // their in-kernel exchange needs; a wait that runs out abandons the object's step, see CheckSplitExchange).
     // parts x padded elements per part = 256 (the collecting threads of split_exchange_state).
     int parts = 0;
-    const size_t lds_tracking = size_t(ctx->layout.off_hist >= 0 ? ctx->layout.off_hist : ctx->layout.total_floats) * 4;
-    // (each workgroup counts its share of the histogram bins: that share of the count table; the pair table is
-    // read from L2, never staged)
-    auto lds_split_for = [&](int p) {
-      return want_fused_histogram ? std::max(lds_tracking, M3T_MISC_FLOATS * 4 + (ctx->lds_hist - M3T_MISC_FLOATS * 4) / p)
-                                  : lds_tracking;
-    };
+    size_t lds_split = 0;
     if (ctx->split_possible && ctx->split_enabled && threads % M3T_SPLIT_LANES == 0 &&
-        ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT")) {
-      int limit = ctx->split_parts_override > 1 ? ctx->split_parts_override : 8;
-      if (const char* e = std::getenv("M3T_HIP_SPLIT_PARTS")) limit = std::atoi(e);  // developer override
-      const int elements = std::max(ctx->layout.nl, ctx->depth_mods.empty() ? 1 : ctx->np_max);
-      for (int p = M3T_SPLIT_MAX_PARTS; p >= 2; p >>= 1) {
-        // 256-thread workgroups (developer override): two are resident per CU if their LDS fits twice
-        const int per_cu = (threads == M3T_SPLIT_LANES && lds_split_for(p) * 2 <= size_t(160) * 1024) ? 2 : 1;
-        const int padded = (n + 7) / 8 * 8;  // grid blocks / p: every XCD gets the blocks of the fullest one
-        if (p > limit || padded * p > ctx->prop.multiProcessorCount * per_cu) continue;
-        if ((elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;  // a part's elements fit its share of the lanes
-        // the exchange needs every workgroup of the grid resident at once: ask the runtime how many of these
-        // workgroups (registers, LDS) a CU takes, instead of assuming the LDS arithmetic above is the only limit
-        int resident = ResidentBlocks(ctx, tracking_step_split_kernel, threads, lds_split_for(p));
-        if (resident > per_cu) resident = per_cu;  // (the query is known to over-report by one block for SGPR-heavy kernels)
-        if (resident < 1 || padded * p > ctx->prop.multiProcessorCount * resident) continue;
-        parts = p;
-        break;
-      }
-    }
+        ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT"))
+      parts = ChooseSplitParts(ctx, tracking_step_split_kernel, n, threads, want_fused_histogram, &lds_split);
     const bool split = parts >= 2;
     // More objects than CUs: the compact kernel (<= 47 KB of LDS, <= 128 VGPRs per object: 3-4 workgroups per CU;
     // measured crossover on 256 CUs: 256 objects 0.249 vs 0.225 ms with one 512-thread workgroup per CU, 384 objects
@@ -3408,41 +3465,9 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
                          ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->compact,
                          iteration, ctx->n_corr_iterations, ctx->n_update_iterations, histogram_fused ? 1 : 0);
     } else if (split) {
-      const size_t per_object = size_t(2) * M3T_SPLIT_LANES * 32;  // granules
-      if (!ctx->split_abort_host) {
-        void* host = nullptr;
-        HIPCHK(hipHostMalloc(&host, 64, hipHostMallocMapped));
-        std::memset(host, 0, 64);
-        void* dev = nullptr;
-        HIPCHK(hipHostGetDevicePointer(&dev, host, 0));
-        ctx->split_abort_host = static_cast<unsigned*>(host);
-        ctx->split_abort_dev = static_cast<unsigned*>(dev);
-      }
-      if (ctx->split_objects < size_t(n) || ctx->split_seq >= (1u << 26) - 1) {
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (ctx->split_objects < size_t(n)) {
-          HIPCHK(ctx->d_split.alloc(size_t(n) * per_object * sizeof(unsigned long long) + size_t(n) * sizeof(unsigned)));
-          ctx->split_objects = size_t(n);
-        }
-        HIPCHK(hipMemset(ctx->d_split.p, 0, ctx->d_split.bytes));
-        ctx->split_seq = 0;
-      }
-      ++ctx->split_seq;
       SplitParams sp{};
-      sp.granules = ctx->d_split.as<unsigned long long>();
-      sp.object_abort = reinterpret_cast<unsigned*>(sp.granules + ctx->split_objects * per_object);
-      sp.host_abort = ctx->split_abort_dev;
-      sp.seq = ctx->split_seq;
-      if (++ctx->split_launches == 0) ctx->split_launches = 1;  // (0 = the word's initial value)
-      sp.abort_id = ctx->split_launches;
-      sp.n_objects = n;
-      sp.n_parts = parts;
-      sp.lshift = 0;
-      while ((parts << sp.lshift) < M3T_SPLIT_LANES) ++sp.lshift;
-      sp.per_part_lines = (ctx->layout.nl + parts - 1) / parts;
-      sp.per_part_points = (ctx->np_max + parts - 1) / parts;
+      if ((r = PrepareSplit(ctx, n, parts, &sp))) return r;
       histogram_fused = want_fused_histogram;
-      const size_t lds_split = lds_split_for(parts);
       hipLaunchKernelGGL(tracking_step_split_kernel, dim3((n + 7) / 8 * 8 * parts), dim3(threads), lds_split, ctx->stream,
                          ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                          ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
@@ -3469,18 +3494,37 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     ScopedKernelTimer timer(ctx, 0);
     const int n = int(ctx->opt_table.size());
     auto kernel = ctx->layout.off_hist >= 0 ? tracking_step_lds_kernel : tracking_step_kernel;
+    // a batch that leaves CUs idle: several workgroups per object here too (tracking_step_split_render_kernel: the
+    // split kernel with the renderer-fed branches compiled in, one search per launch)
+    int parts = 0;
+    size_t lds_split = 0;
+    bool shared = false;
+    for (auto& m : ctx->region_mods) shared = shared || m->shared_histograms >= 0 || m->p.n_histogram_bins < 4;
+    if (!shared && ctx->split_enabled && ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT"))
+      parts = ChooseSplitParts(ctx, tracking_step_split_render_kernel, n, M3T_BLOCK_THREADS, false, &lds_split);
     for (int c = 0; c < ctx->n_corr_iterations; ++c) {
       if ((r = RenderForModalities(ctx, false))) return r;
-      hipLaunchKernelGGL(kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
-                         ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
-                         ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->layout,
-                         ctx->off_points, ctx->np_max, iteration, 1, ctx->n_update_iterations,
-                         ctx->fused_mode == 2 ? 1 : 0, 0, c);
+      if (parts >= 2) {
+        SplitParams sp{};
+        if ((r = PrepareSplit(ctx, n, parts, &sp))) return r;
+        hipLaunchKernelGGL(tracking_step_split_render_kernel, dim3((n + 7) / 8 * 8 * parts), dim3(M3T_BLOCK_THREADS),
+                           lds_split, ctx->stream, ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                           ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->layout,
+                           ctx->off_points, ctx->np_max, iteration, ctx->n_update_iterations,
+                           ctx->fused_mode == 2 ? 1 : 0, c, sp);
+      } else {
+        hipLaunchKernelGGL(kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_track, ctx->stream,
+                           ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                           ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->layout,
+                           ctx->off_points, ctx->np_max, iteration, 1, ctx->n_update_iterations,
+                           ctx->fused_mode == 2 ? 1 : 0, 0, c);
+      }
     }
     HIPCHK(hipGetLastError());
-    ctx->last_step_kernel = ctx->layout.off_hist >= 0 ? "tracking_step_lds_kernel" : "tracking_step_kernel";
+    ctx->last_step_kernel = parts >= 2 ? "tracking_step_split_render_kernel"
+                                       : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_kernel" : "tracking_step_kernel");
     ctx->last_step_shape[0] = n;
-    ctx->last_step_shape[1] = 1;
+    ctx->last_step_shape[1] = parts >= 2 ? parts : 1;
     ctx->last_step_shape[2] = M3T_BLOCK_THREADS;
     ctx->last_step_shape[3] = 0;
     ctx->state_valid = ctx->fused_mode == 2;
@@ -3585,9 +3629,17 @@ int m3t_hip_set_kernel_timing(m3t_hip_context* ctx, int enable) {
     (void)hipEventDestroy(p.b);
   }
   ctx->pending.clear();
-  ctx->timing = enable != 0;
+  ctx->timing = enable == 1;
+  ctx->timing_region = enable == 2;
   ctx->kernel_ms[0] = ctx->kernel_ms[1] = 0.0;
   ctx->kernel_launches[0] = ctx->kernel_launches[1] = 0;
+  if (ctx->timing_region) {  // the stream is idle (synchronised above): the region starts here
+    if (!ctx->region_a) {
+      HIPCHK(hipEventCreate(&ctx->region_a));
+      HIPCHK(hipEventCreate(&ctx->region_b));
+    }
+    HIPCHK(hipEventRecord(ctx->region_a, ctx->stream));
+  }
   return M3T_OK;
 }
 int m3t_hip_get_step_shape(m3t_hip_context* ctx, int shape[4]) {
@@ -3630,6 +3682,15 @@ int m3t_hip_get_step_kernel(m3t_hip_context* ctx, char* name, size_t capacity) {
 int m3t_hip_get_kernel_timing(m3t_hip_context* ctx, float total_ms[2], int launches[2]) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->timing_region) {  // device time from the enabling call to here, all of it booked on the tracking launches
+    HIPCHK(hipEventRecord(ctx->region_b, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->region_a, ctx->region_b));
+    if (total_ms) { total_ms[0] = ms; total_ms[1] = 0.0f; }
+    if (launches) { launches[0] = ctx->kernel_launches[0]; launches[1] = ctx->kernel_launches[1]; }
+    return M3T_OK;
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (auto& p : ctx->pending) {
     float ms = 0.0f;

@@ -732,13 +732,32 @@ __device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> 
 // Phase C  one thread per (line, d): CalculateDistribution :1600 products; then one
 //          thread per line: normalisation + CalculateDistributionMoments :1639.
 // ---------------------------------------------------------------------------
+// (tracking_step_split_kernel: what the workgroups of one object need to hand each other their lines' results; the
+// exchange itself follows further down -- split_exchange_publish / split_exchange_collect)
+struct SplitExchange {
+  __attribute__((address_space(1))) unsigned long long* granules;  // this object's [2 slots][parts][32 fields][1 << lshift]
+  __attribute__((address_space(1))) unsigned* object_abort;        // launch sequence number of an aborted step
+  unsigned* host_abort;                                            // mapped host word, set to the sequence number
+  uint32_t seq;    // launch sequence number (> 0)
+  uint32_t abort_id;
+  int part, n_parts, lshift;
+  int per_part_lines, per_part_points;
+  int n_region_fields, first_region_row;    // rows LS_DIST0 .. (from LS_VALID on while the occlusion vote is deferred)
+  int n_depth_fields, first_depth_row;      // rows first_depth_row .. PS_VALID of the point state
+};
+constexpr int kExchangeFieldBits = 5;
+
 // RENDER = false: a launch shape that never runs with renderer-fed branches (the split kernel: m3t_hip_api.hip takes
 // the per-search launches of tracking_step_kernel as soon as a modality reads a rendering) leaves their code out
 template <bool HIST_LDS, int BMAX = 8, bool RENDER = true>
 __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                        const Affine& b2dc, int iteration, int corr_iteration,
                                                        const Lds& s, int line_lo = 0, int line_hi = 1 << 30,
-                                                       bool* vote_deferred = nullptr, int prev_view = -1) {
+                                                       bool* vote_deferred = nullptr, int prev_view = -1,
+                                                       const SplitExchange* early = nullptr) {
+  // early: the thread that normalises a distribution value (phase C2) also sends it to the object's other workgroups
+  // (the granule split_exchange_publish would write after the phase: same slot, same tag, same value), unless the
+  // occlusion vote is deferred -- then the rows travel with the flags after the phase
   const int tid = threadIdx.x, nt = blockDim.x;
   const RegionIter it = region_iter(m, corr_iteration);
   const int nl = s.nl;
@@ -998,12 +1017,23 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   // ---- phase C2: normalisation, one thread per (line, d): every thread adds up the line's raw values in the
   // reference's order (the same area in all of them) and divides its own (the moments follow in region_moments) ----
   {
+    const bool send = early != nullptr && !defer_vote;
+    __attribute__((address_space(1))) unsigned long long* mine = nullptr;
+    unsigned long long tag_bits = 0;
+    int lshift = 0;
+    if (send) {
+      lshift = early->lshift;
+      mine = early->granules + ((size_t)(corr_iteration & 1) * early->n_parts << (kExchangeFieldBits + lshift)) +
+             ((size_t)early->part << (kExchangeFieldBits + lshift));
+      tag_bits = static_cast<unsigned long long>(early->seq * 64u + (uint32_t)corr_iteration + 1u) << 32;
+    }
     const int q = nt / dl, r = nt - q * dl;
     int line = tid / dl, d = tid - line * dl;
     line += line_lo;
     const int n_items_c = (n_lines_b - line_lo) * dl;
     for (int item = tid; item < n_items_c; item += nt) {
       const int flags = f2i_bits(s.state[LS_VALID * nl + line]);
+      float value = 0.0f;
       if (flags & valid_mask) {
         const float* rr = raw + line * s.ns;
         float area = 0.0f;
@@ -1015,11 +1045,26 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
         } else {
           for (int k = 0; k < dl; ++k) area += rr[k];
         }
-        s.state[(LS_DIST0 + d) * nl + line] = rr[d] / area;
+        value = rr[d] / area;
+        s.state[(LS_DIST0 + d) * nl + line] = value;
+      } else if (send) {
+        value = s.state[(LS_DIST0 + d) * nl + line];  // (a line that is not walked: what the row holds, as the publish loop sends it)
       }
+      if (send)
+        __hip_atomic_store(mine + ((d << lshift) | (line - line_lo)), tag_bits | (unsigned)__float_as_int(value),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       line += q;
       d += r;
       if (d >= dl) { d -= dl; ++line; }
+    }
+    if (send) {  // the rows' entries of this part beyond the view's lines (the other workgroups wait for every granule)
+      const int first = n_lines_b > line_lo ? n_lines_b : line_lo, last = line_hi < nl ? line_hi : nl;
+      for (int item = tid; item < (last - first) * dl; item += nt) {
+        const int l2 = first + item / dl, d2 = item - (item / dl) * dl;
+        __hip_atomic_store(mine + ((d2 << lshift) | (l2 - line_lo)),
+                           tag_bits | (unsigned)__float_as_int(s.state[(LS_DIST0 + d2) * nl + l2]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   // the final flag (bit 0 = line is in data_lines_), for the lines of all parts: it follows from phase A, which every
@@ -1123,6 +1168,8 @@ typedef const volatile __attribute__((address_space(3))) v4f* LdsV4;
 // two register sets take turns (no copies), a scheduling barrier keeps each set's reads ahead of the other set's sums
 template <int Q>
 __device__ __forceinline__ float chain_walk(LdsV4 p, int n_quads, float s) {
+  // (round 4: a third register set -- the reads of the next TWO steps in flight, no full drain at the loop head -- was
+  // measured: no change, 38.0 k vs 37.2 k cycles per frame; the chain is bound by its dependent subtractions)
   v4f a[Q], b[Q];
 #pragma unroll
   for (int i = 0; i < Q; ++i) a[i] = p[i];
@@ -1305,18 +1352,6 @@ __device__ __forceinline__ void region_products(CRegion& m, CCam& cam, const Aff
 // A wait that runs out (a partner that is not resident: another process on the GPU) ends the whole object's step
 // without writing anything and raises the context's abort flag, which the host reads at its next call.
 // ---------------------------------------------------------------------------
-struct SplitExchange {
-  __attribute__((address_space(1))) unsigned long long* granules;  // this object's [2 slots][parts][32 fields][1 << lshift]
-  __attribute__((address_space(1))) unsigned* object_abort;        // launch sequence number of an aborted step
-  unsigned* host_abort;                                            // mapped host word, set to the sequence number
-  uint32_t seq;    // launch sequence number (> 0)
-  uint32_t abort_id;
-  int part, n_parts, lshift;
-  int per_part_lines, per_part_points;
-  int n_region_fields, first_region_row;    // rows LS_DIST0 .. (from LS_VALID on while the occlusion vote is deferred)
-  int n_depth_fields, first_depth_row;      // rows first_depth_row .. PS_VALID of the point state
-};
-constexpr int kExchangeFieldBits = 5;
 
 struct SplitExchangeView {  // what publish and collect derive from the descriptor
   uint32_t tag;
@@ -1340,14 +1375,15 @@ __device__ __forceinline__ SplitExchangeView split_exchange_view(const SplitExch
   return v;
 }
 __device__ __forceinline__ void split_exchange_publish(const SplitExchange& x, int round, const Lds& s, bool with_region,
-                                                       float* ps, int np, bool with_depth) {
+                                                       float* ps, int np, bool with_depth, int first_field = 0) {
+  // first_field: the fields below it have been sent already (region_correspondences, early)
   const int tid = threadIdx.x, nt = blockDim.x;
   const SplitExchangeView v = split_exchange_view(x, round, s, with_region, ps, np, with_depth);
   const uint32_t tag = v.tag;
   const int lmask = v.lmask, nfr = v.nfr, nf = v.nf, region_row0 = v.region_row0, depth_row0 = v.depth_row0;
   float* const lds0 = v.lds0;
   auto* mine = v.slot + ((size_t)x.part << (kExchangeFieldBits + x.lshift));
-  for (int idx = tid; idx < (nf << x.lshift); idx += nt) {
+  for (int idx = tid + (first_field << x.lshift); idx < (nf << x.lshift); idx += nt) {
     const int f = idx >> x.lshift, l = idx & lmask;
     const bool region = f < nfr;
     const int per_part = region ? x.per_part_lines : x.per_part_points, count = region ? s.nl : np;
@@ -2848,7 +2884,7 @@ struct SplitParams {               // tracking_step_split_kernel: n_parts workgr
 };
 
 extern "C++" {
-template <bool HIST_LDS, bool SPLIT = false>
+template <bool HIST_LDS, bool SPLIT = false, bool RENDER = !SPLIT>
 __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
@@ -2930,14 +2966,15 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_view = region_correspondences<HIST_LDS, SPLIT ? 2 : 8, !SPLIT>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s,
-                                                                              line_lo, line_hi, &vote_deferred, region_view);
+        region_view = region_correspondences<HIST_LDS, SPLIT ? 2 : 8, RENDER>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s,
+                                                                              line_lo, line_hi, &vote_deferred, region_view,
+                                                                              SPLIT ? &exchange : nullptr);
       }
       if (dm) {
         PHASE_T0();
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
         // (same view table and same camera pose as the region modality of this body: its search is this one's)
-        depth_correspondences_scan<!SPLIT>(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, pt_lo, pt_hi,
+        depth_correspondences_scan<RENDER>(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, pt_lo, pt_hi,
                                            (rm && dm->view_search_shared) ? region_view : -1);
         PHASE_MARK(16);
       }
@@ -2952,7 +2989,9 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         // publish the own part's results, take the moments of the own lines while the other parts' results are on
         // their way, collect them, then the moments of the received lines
         EXCHANGE_STAMP(0, c, part, object);
-        split_exchange_publish(exchange, c, s, rm != nullptr, ps, np, dm != nullptr);
+        // (the distribution rows left with phase C2 unless the vote is deferred)
+        split_exchange_publish(exchange, c, s, rm != nullptr, ps, np, dm != nullptr,
+                               (rm && !vote_deferred) ? rm->distribution_length : 0);
         EXCHANGE_STAMP(1, c, part, object);
         if (rm && !vote_deferred) region_moments(*rm, s, line_lo, line_hi, true);
         if (!split_exchange_collect(exchange, c, s, rm != nullptr, ps, np, dm != nullptr)) return;
@@ -2969,7 +3008,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       }
       {
         PHASE_T0();
-        if (dm) depth_correspondences_vote<!SPLIT>(*dm, iteration, ps, np, s.misc);
+        if (dm) depth_correspondences_vote<RENDER>(*dm, iteration, ps, np, s.misc);
         else __syncthreads();
         PHASE_MARK(25);
       }
@@ -3042,7 +3081,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     const int n_bins3 = rm->n_bins * rm->n_bins * rm->n_bins;
     const int bin_lo = SPLIT ? part * (n_bins3 / n_parts) : 0;
     const int bin_hi = SPLIT ? bin_lo + n_bins3 / n_parts : n_bins3;
-    region_histogram_update<false, false, !SPLIT>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
+    region_histogram_update<false, false, RENDER>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
                                                   (__attribute__((address_space(3))) uint32_t*)(lds_t + M3T_MISC_FLOATS),
                                                   lds_t, bin_lo, bin_hi, nullptr, 0, 0, region_view);
   }
@@ -3074,6 +3113,18 @@ tracking_step_split_kernel(const RigidOptDev* opts, const RegionModDev* rmods, c
                      int fuse_histogram, SplitParams split) {
   tracking_step_body<false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
                                   n_corr_iterations, n_update_iterations, write_state, fuse_histogram, &split);
+}
+
+// the same with the renderer-fed branches compiled in, one correspondence search per launch (the host redraws the
+// focused renderings between the searches): round 4 -- the renderer-fed step of a small batch was ONE workgroup per
+// object (87 us per search for the reference's test scene)
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_split_render_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_update_iterations, int write_state, int first_corr_iteration,
+                     SplitParams split) {
+  tracking_step_body<false, true, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, 1,
+                                        n_update_iterations, write_state, 0, &split, first_corr_iteration);
 }
 
 // Test hook (m3t_hip_debug_log_checksum): the logarithm exactly as region_products takes it -- m3t_log_fast on the

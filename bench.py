@@ -85,6 +85,8 @@ def parse():
                    help="with --repeats 0: keep repeating the K-step region until this much GPU time has been timed "
                         "(at least 5 regions): a K = 20 region lasts ~3 ms, too short for device-level telemetry")
     p.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) legs")
+    p.add_argument("--no-buckets", action="store_true",
+                   help="skip the one-launch-per-sub-step leg (profiling runs: only the timed kernels are launched)")
     p.add_argument("--sweep", type=str, default="", help="comma separated object counts for a batch sweep (extra)")
     p.add_argument("--extras", action="store_true",
                    help="extra legs (never the headline): model generation without OpenGL and a tracking step with "
@@ -178,7 +180,7 @@ def main():
     pkg = importlib.import_module("3dobjecttracking_amd")
     if args.config == "chain8":
         import bench_chain
-        out = bench_chain.run(args, pkg, rank, local_rank, world, dist, torch, open_oracle)
+        out = bench_chain.run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_traffic)
     else:
         out = run_objects(args, pkg, pkg.batch, rank, local_rank, world, dist, torch)
     if rank == 0:
@@ -259,11 +261,21 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
     # ---- roofline leg: HIP events around the kernels on the context stream (rank 0) ----
     roofline = None
     if rank == 0:
+        # (a) ONE event pair around the K launches of a timed region (nothing between the launches): the device time
+        # per launch, which is what `achieved` is computed from; (b) an event pair around every launch, as round 3
+        # measured it: each pair also times the launch gap in front of its kernel and the markers slow the stream, so
+        # its mean comes out above (a) -- and above the host-clocked ms_per_step -- by the marker overhead reported
+        hip.call("bodies_set_poses", restart.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
+        ms = (C.c_float * 2)()
+        cnt = (C.c_int * 2)()
+        hip.call("set_kernel_timing", 2)
+        run(1 + W, K)
+        hip.call("get_kernel_timing", ms, cnt)
+        region_ms, region_launches = float(ms[0]), int(cnt[0]) + int(cnt[1])
+        fused_hist = cnt[1] == 0  # the histogram update rode in the tracking launch
         hip.call("bodies_set_poses", restart.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
         hip.call("set_kernel_timing", 1)
         run(1 + W, K)
-        ms = (C.c_float * 2)()
-        cnt = (C.c_int * 2)()
         hip.call("get_kernel_timing", ms, cnt)
         hip.call("set_kernel_timing", 0)
         shape = (C.c_int * 4)()
@@ -271,9 +283,11 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
         name = C.create_string_buffer(64)
         hip.call("get_step_kernel", name, 64)
         kernel = name.value.decode()
-        track_ms = ms[0] / max(cnt[0], 1)
-        fused_hist = cnt[1] == 0  # the histogram update rode in the tracking launch
+        pair_ms = ms[0] / max(cnt[0], 1)
         hist_ms = ms[1] / max(cnt[1], 1)
+        # one launch per step when the histogram update is fused: the region mean IS the kernel's mean duration (plus
+        # the launch gap); with a separate histogram kernel the pairs' split of the region is used
+        track_ms = region_ms / max(region_launches, 1) if fused_hist else region_ms / K * pair_ms / max(pair_ms + hist_ms, 1e-9)
         alg = cfg["alg"] if fused_hist else cfg["alg_track"]
         achieved = alg * n_obj / (track_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(args.config, kernel, n_obj, fused_hist)
@@ -282,14 +296,18 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
                     "workgroups_per_object": shape[1], "threads_per_workgroup": shape[2],
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel_ms": round(track_ms, 4), "algorithmic_bytes_per_launch": alg * n_obj}
+                    "kernel_ms": round(track_ms, 4), "algorithmic_bytes_per_launch": alg * n_obj,
+                    "kernel_ms_how": "HIP events on the context's stream: one pair around the %d launches of a timed "
+                                     "region / %d" % (region_launches, region_launches),
+                    "kernel_ms_event_pair_per_launch": round(pair_ms, 4),
+                    "event_pair_overhead_ms": round(pair_ms - track_ms, 4)}
         if not fused_hist:
             roofline["histogram_kernel_ms"] = round(hist_ms, 4)
 
     # ---- the evaluators' four time buckets (rbot_evaluator.cpp:354-414) on the device, one launch per sub-step
     # (m3t_hip_set_fused_step(0)), each bucket synchronised and timed on the host: what the fused launch replaces ----
     buckets = None
-    if rank == 0 and world == 1 and args.config in ("rbot64", "ycb21"):
+    if rank == 0 and world == 1 and args.config in ("rbot64", "ycb21") and not args.no_buckets:
         buckets = device_buckets(hip, restart, n_obj, W, min(K, 5), cfg)
 
     # ---- host-buffer (PCIe-inclusive) rate: every step first receives its frames from host memory; never `value` ----

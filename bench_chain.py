@@ -84,7 +84,7 @@ def optimization_time_structures(api, host, n_bodies, n_structures):
     return host.Tracker(api, 1, 1)
 
 
-def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle):
+def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_traffic=None):
     scenes = pkg.batch
     syn, host = pkg.synthetic, pkg.host
     n_bodies, K, W = args.objects or 8, args.steps, args.warmup
@@ -141,6 +141,13 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle):
     elapsed = float(np.median(times))
     if rank != 0:
         return None
+    # roofline leg: ONE HIP event pair on the context's stream around the K launches of one more region
+    ms, cnt = (C.c_float * 2)(), (C.c_int * 2)()
+    hip.call("set_kernel_timing", 2)
+    run_steps(1 + W, K)
+    hip.call("get_kernel_timing", ms, cnt)
+    hip.call("set_kernel_timing", 0)
+    kernel_ms = float(ms[0]) / max(int(cnt[0]), 1) if cnt[0] else None
     # ---- CPU restatement of the same chain (all bodies in one process) + parity of the first timed trajectory ----
     cpu, parity = None, None
     if not args.no_cpu_baseline:
@@ -195,6 +202,7 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle):
     hip.call("get_step_kernel", name, 64)
     kernel = name.value.decode()
     fused = kernel == "tracking_step_tree_kernel"
+    traffic, traffic_src = (measured_traffic("chain8", kernel, n_bodies, True) if (measured_traffic and fused) else (None, None))
     return {
         "metric": "pose-updates/sec (Mb-ICG kinematic chain, %d bodies, %d dof)" % (n_bodies, 6 + n_bodies - 1),
         "value": round(rate, 1), "unit": "pose-updates/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -214,8 +222,12 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle):
                    "setup_s": round(setup_s, 1)},
         "roofline": {"bound": "hbm",
                      "kernel": kernel if fused else "whole step: 7 x (correspondence + 2 x (g/H, project, solve)) + results launches",
-                     "achieved": round(rate * B_ALG / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(rate * B_ALG / 8e12, 6), "traffic": None,
+                     "achieved": round((n_bodies * B_ALG / (kernel_ms * 1e-3) / 1e9) if (fused and kernel_ms) else rate * B_ALG / 1e9, 3),
+                     "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(((n_bodies * B_ALG / (kernel_ms * 1e-3)) if (fused and kernel_ms) else rate * B_ALG) / 8e12, 6),
+                     "kernel_ms": round(kernel_ms, 4) if (fused and kernel_ms) else None,
+                     "algorithmic_bytes_per_launch": n_bodies * B_ALG,
+                     "traffic": traffic, "traffic_source": traffic_src,
                      "note": ("latency-bound by construction: 14 dependent solves of one 13-dof structure per frame, each on "
                               "one wave" if fused else
                               "launch- and latency-bound by construction: 50 dependent launches per frame for one structure")},

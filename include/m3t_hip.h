@@ -309,8 +309,12 @@ int m3t_hip_sync(m3t_hip_context*);
  * out[2] = the sum over those evaluations alone.  tests/test_gpu_log.py compares all three with
  * float(std::log(double(x))) on the host over all of [FLT_MIN, 1]. */
 int m3t_hip_debug_log_checksum(m3t_hip_context*, unsigned first_bits, unsigned last_bits, unsigned long long out[3]);
-/* measurement aid (bench.py roofline leg): HIP events on the context stream around
- * [0] the fused tracking kernel and [1] the histogram kernel; totals since enable */
+/* measurement aid (bench.py roofline leg): HIP events on the context stream.  enable = 1: a pair around every launch
+ * of [0] the fused tracking kernel and [1] the histogram kernel, totals since enable (each pair also times the
+ * launch gap in front of its kernel and the markers slow the stream a little: the sum exceeds the device time of the
+ * undisturbed loop by a few per cent).  enable = 2: ONE pair -- the first event where timing is switched on, the second
+ * when get_kernel_timing asks -- and launch counts in between: total_ms[0] = device time of the whole region, nothing
+ * is inserted between the launches.  0: off */
 int m3t_hip_set_kernel_timing(m3t_hip_context*, int enable);
 /* name of the kernel the last execute_tracking_step launched for the tracking loop ("" = one launch per sub-step) */
 int m3t_hip_get_step_kernel(m3t_hip_context*, char* name, size_t capacity);

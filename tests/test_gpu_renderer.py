@@ -54,26 +54,37 @@ def test_tracking_step_with_all_branches_matches_oracle():
     through a whole tracking step (renderings refreshed before every correspondence search and
     for the histogram update); reference summation order -> bit-identical poses and states"""
     import ctypes as C
+    import os
     res = []
-    hip_fused, hip_substep = util.open_hip(), util.open_hip()
+    hip_fused, hip_one, hip_substep = util.open_hip(), util.open_hip(), util.open_hip()
     hip_fused.call("set_fused_step", 2)    # one launch per correspondence search (+ the renderers), state written back
+    hip_one.call("set_fused_step", 2)      # the same with ONE workgroup for the object (M3T_HIP_NO_SPLIT)
     hip_substep.call("set_fused_step", 0)  # one launch per sub-step
-    for api in (hip_fused, hip_substep, util.open_oracle()):
+    for api in (hip_fused, hip_one, hip_substep, util.open_oracle()):
         f, schauma, r = _scene(api, 200)
         f.region.ModelOcclusions(r["color_depth"])
         f.region.UseRegionChecking(r["color_sil"])
         f.depth.ModelOcclusions(r["depth_depth"])
         f.depth.UseSilhouetteChecking(r["depth_sil"])
         assert f.tracker.StartModalities(0)
-        assert f.tracker.ExecuteTrackingStep(0)
+        if api is hip_one:
+            os.environ["M3T_HIP_NO_SPLIT"] = "1"
+        try:
+            assert f.tracker.ExecuteTrackingStep(0)
+        finally:
+            os.environ.pop("M3T_HIP_NO_SPLIT", None)
         lines = f.region.data_lines()
         points = f.depth.data_points()
         res.append((f.body.body2world_pose(), lines["valid"].copy(), points["valid"].copy(), f.region.histograms()))
-        if api is hip_fused:
+        if api in (hip_fused, hip_one):
             name = C.create_string_buffer(64)
             api.call("get_step_kernel", name, 64)
-            assert name.value.decode() in ("tracking_step_kernel", "tracking_step_lds_kernel")
-    (pa, la, qa, ha), (pc, lc, qc, hc), (pb, lb, qb, hb) = res
+            # one object: several workgroups share it (the split kernel with the renderer-fed branches compiled in)
+            assert name.value.decode() == ("tracking_step_split_render_kernel" if api is hip_fused else "tracking_step_kernel") \
+                or (api is hip_one and name.value.decode() == "tracking_step_lds_kernel")
+    (pa, la, qa, ha), one, (pc, lc, qc, hc), (pb, lb, qb, hb) = res
+    assert np.array_equal(one[0], pb) and np.array_equal(one[1], lb) and np.array_equal(one[2], qb)
+    assert np.array_equal(one[3][0], hb[0]) and np.array_equal(one[3][1], hb[1])
     assert np.array_equal(lc, lb) and np.array_equal(qc, qb) and np.array_equal(pc, pb)
     assert np.array_equal(hc[0], hb[0]) and np.array_equal(hc[1], hb[1])
     assert np.array_equal(la, lb) and np.array_equal(qa, qb)

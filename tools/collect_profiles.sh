@@ -9,7 +9,7 @@
 #   * per-phase cycles of the developer build (tools/phase_timing.py)
 # usage: tools/collect_profiles.sh [what ...]   what = tests bench stats pmc phases sweep (default: all)
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=$REPO/gpurun_out/$ROUND
 WHAT=${@:-tests bench stats pmc phases sweep}
 CONFIGS=${CONFIGS:-rbot64 rbot4096 ycb21 synth512 chain8}
@@ -44,7 +44,7 @@ for s in json.load(open(sys.argv[1])).get("batch_sweep", []):
     print(s["objects"], s["pose_updates_per_s"], s["frac_of_hbm_roofline"], s.get("kernel"))
 PY
 fi
-PROF="--steps 10 --warmup 2 --no-cpu-baseline --no-pcie --repeats 1"
+PROF="--steps 10 --warmup 2 --no-cpu-baseline --no-pcie --no-buckets --repeats 1"
 if has stats; then
   for c in $CONFIGS; do
     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$c" -- python "$REPO/bench.py" $(args_of $c) $PROF > "$OUT/stats_$c.log" 2>&1)
@@ -61,9 +61,13 @@ if has pmc; then
   PASS[tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
   PASS[fetch]="FETCH_SIZE"
   PASS[write]="WRITE_SIZE"
-  for c in ${PMC_CONFIGS:-rbot64 rbot4096 ycb21 synth512}; do
+  for c in ${PMC_CONFIGS:-rbot64 rbot4096 ycb21 synth512 chain8}; do
     mkdir -p "$OUT/pmc_$c"
-    for p in ${PMC_PASSES:-sq1 sq2 ta tcc fetch write}; do
+    # all passes for the configurations in PMC_FULL (default: the headline), FETCH_SIZE / WRITE_SIZE only for the
+    # others (every bench line gets its roofline.traffic; a pass is one more run of the bench command)
+    passes="fetch write"
+    [[ " ${PMC_FULL:-rbot64} " == *" $c "* ]] && passes="sq1 sq2 ta tcc fetch write"
+    for p in ${PMC_PASSES:-$passes}; do
       (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --pmc ${PASS[$p]} --output-format csv -d "$OUT/pmc_$c/$p" -- python "$REPO/bench.py" $(args_of $c) $PROF > "$OUT/pmc_$c/$p.log" 2>&1)
     done
     python tools/pmc_summary3.py "$OUT/pmc_$c" "$OUT/pmc_$c.json" "$c" "bench.py $(args_of $c) $PROF" | tail -24
@@ -73,7 +77,7 @@ fi
 if has phases; then
   for v in "rbot64:64:" "ycb21:21:ycb"; do
     IFS=: read name n ycb <<< "$v"
-    (timeout 300 python tools/phase_timing.py tools/libm3t_hip_timing.so $n $ycb 2>&1 | grep -v amdgpu | tail -44) > "$OUT/phase_timing_$name.txt" 2>&1
+    (timeout 300 python tools/phase_timing.py tools/libm3t_hip_timing.so $n $ycb 2>&1 | grep -v amdgpu) > "$OUT/phase_timing_$name.txt" 2>&1
   done
   (timeout 300 python tools/tree_timing.py tools/libm3t_hip_timing.so 2>&1 | grep -v amdgpu) > "$OUT/phase_timing_chain8.txt" 2>&1
   head -12 "$OUT/phase_timing_rbot64.txt"

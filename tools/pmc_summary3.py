@@ -12,8 +12,8 @@ import json
 import os
 import sys
 
-OBJECTS = {"rbot64": 64, "rbot4096": 4096, "ycb21": 21, "synth512": 512}
-CONFIG = {"rbot64": "rbot64", "rbot4096": "rbot64", "ycb21": "ycb21", "synth512": "synth512"}
+OBJECTS = {"rbot64": 64, "rbot4096": 4096, "ycb21": 21, "synth512": 512, "chain8": 8}
+CONFIG = {"rbot64": "rbot64", "rbot4096": "rbot64", "ycb21": "ycb21", "synth512": "synth512", "chain8": "chain8"}
 
 
 def per_kernel(folder):
@@ -87,7 +87,14 @@ def main(out_dir, target, profile, command):
                         "hbm_bytes_per_launch_raw": int((m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024),
                         "hbm_bytes_per_launch_corrected": int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)}
             traffic["kernels"][name] = dict(k["hbm"])
-    traffic["histogram_update_fused"] = "region_histogram_kernel" not in kernels
+    # fused = the histogram update rides in the tracking launch: then region_histogram_kernel only runs for
+    # StartModalities (and in bench.py's unfused-buckets leg, which profiling runs skip: --no-buckets), i.e. far less
+    # often than the tracking kernel
+    tracking = max((k["per_launch_means"].get("_launches", 0) for n, k in kernels.items() if n.startswith("tracking_step")),
+                   default=0)
+    hist = kernels.get("region_histogram_kernel", {}).get("per_launch_means", {}).get("_launches", 0)
+    traffic["histogram_update_fused"] = hist < 0.5 * tracking
+    traffic["launches"] = {"tracking": tracking, "region_histogram_kernel": hist}
     json.dump({"command": command, "profile": profile, "kernels": kernels}, open(target, "w"), indent=1)
     json.dump(traffic, open(os.path.join(os.path.dirname(os.path.abspath(target)), "hbm_traffic_%s.json" % profile), "w"), indent=1)
     for name, k in kernels.items():
