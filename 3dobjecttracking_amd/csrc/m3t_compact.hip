@@ -132,10 +132,16 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
 // line needs in between stays in the thread's registers.  Ends with a barrier.  Returns the closest view.
 __device__ __forceinline__ int compact_region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                               const Affine& b2dc, int iteration, int corr_iteration,
-                                                              float* misc, float* state, int nl) {
+                                                              float* misc, float* state, int nl, int prev_view = -1) {
   const int tid = threadIdx.x;
   const RegionIter it = region_iter(m, corr_iteration);
-  const int view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);
+  // the view of the previous search first (closest_view_local: 20 loads, no barrier), else the scan over all views
+  int view = -1;
+  if (prev_view >= 0 && m.view_neighbors != nullptr) {
+    float o0, o1, o2;
+    if (view_direction(b2c, o0, o1, o2)) view = closest_view_local((G<v4f>)m.view_neighbors, prev_view, o0, o1, o2);
+  }
+  if (view < 0) view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, misc);
   const int n_lines =
       number_of_lines(m.n_lines_max, m.use_adaptive_coverage, m.reference_contour_length, as_global(m.extents), view,
                       m.max_extent, m.n_points);
@@ -458,16 +464,16 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
   GW<float> search_poses = as_global_w(o.search_poses);
   const bool record_poses = o.search_poses != nullptr && threadIdx.x < 16;
   if (record_poses) search_poses[threadIdx.x] = pose[threadIdx.x];
+  int region_view = rm ? *as_global(rm->last_view) : -1;  // the view of the modality's previous search
   for (int c = 0; c < n_corr_iterations; ++c) {
     if (record_poses) search_poses[(c + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
     {
       const Affine b2w = load_pose(pose);
-      int region_view = -1;
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_view = compact_region_correspondences(*rm, *cam, rdcam, b2c, b2dc, iteration, c, misc, state, nl);
+        region_view = compact_region_correspondences(*rm, *cam, rdcam, b2c, b2dc, iteration, c, misc, state, nl, region_view);
       }
       if (dm) {
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
@@ -500,6 +506,7 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
     }
   }
   if (threadIdx.x < 16) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
+  if (rm && threadIdx.x == 0) *as_global_w(rm->last_view) = region_view;
   if (record_poses) search_poses[(n_corr_iterations + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
   if (fuse_histogram && rm) {
     // RegionModality::CalculateResults :572-583 in the same launch: the carve-up is free now (first 1024 floats =
@@ -515,9 +522,10 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
     if (L.tail_pass_bins > 0)
       region_histogram_update<false, true, false>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false, counts, lds_c, 0, -1,
                                            reinterpret_cast<uint16_t*>(lds_c + L.off_tail_list), L.tail_list_row,
-                                           L.tail_pass_bins);
+                                           L.tail_pass_bins, region_view);
     else
-      region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false, counts, lds_c);
+      region_histogram_update<false, false, false>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false, counts, lds_c, 0, -1,
+                                                   nullptr, 0, 0, region_view);
   }
 }
 

@@ -179,6 +179,8 @@ struct m3t_hip_context {
   std::vector<std::vector<int>> renderer_geometries;
   std::vector<std::unique_ptr<RendererH>> renderers;
   DevMem d_renderers, d_render_region, d_render_all;  // RendererDev table; which renderers to run when
+  DevMem d_render_region_pairs, d_render_all_pairs;   // the same lists as {renderer, twin or -1} (LaunchRenderers)
+  int n_render_region_pairs = 0, n_render_all_pairs = 0;
   int n_render_region = 0, n_render_all = 0;
   int lds_raster = -1;  // focused_resolve_kernel (z-buffer in LDS) usable on this device: -1 not tried yet
   std::vector<Link> links;
@@ -964,6 +966,38 @@ int UploadRendererTables(Ctx* ctx) {
     if (for_region[i]) list_region.push_back(int(i));
     if (for_all[i]) list_all.push_back(int(i));
   }
+  // twins: two renderers of a list that differ in nothing but the id written (focused_setup_kernel) are drawn once
+  auto same_rendering = [&](int a, int b) {
+    const RendererH& x = *ctx->renderers[a];
+    const RendererH& y = *ctx->renderers[b];
+    return x.camera == y.camera && x.geometry == y.geometry && x.image_size == y.image_size && x.z_min == y.z_min &&
+           x.z_max == y.z_max && x.referenced == y.referenced;
+  };
+  auto pairs_of = [&](const std::vector<int>& list) {
+    std::vector<int> pairs;
+    std::vector<char> taken(list.size(), 0);
+    for (size_t i = 0; i < list.size(); ++i) {
+      if (taken[i]) continue;
+      int twin = -1;
+      for (size_t j = i + 1; j < list.size() && twin < 0; ++j)
+        if (!taken[j] && same_rendering(list[i], list[j])) {
+          twin = list[j];
+          taken[j] = 1;
+        }
+      pairs.push_back(list[i]);
+      pairs.push_back(twin);
+    }
+    return pairs;
+  };
+  const std::vector<int> pairs_region = pairs_of(list_region), pairs_all = pairs_of(list_all);
+  ctx->n_render_region_pairs = int(pairs_region.size() / 2);
+  ctx->n_render_all_pairs = int(pairs_all.size() / 2);
+  HIPCHK(ctx->d_render_region_pairs.alloc(std::max<size_t>(1, pairs_region.size()) * 4));
+  HIPCHK(ctx->d_render_all_pairs.alloc(std::max<size_t>(1, pairs_all.size()) * 4));
+  if (!pairs_region.empty())
+    HIPCHK(hipMemcpy(ctx->d_render_region_pairs.p, pairs_region.data(), pairs_region.size() * 4, hipMemcpyHostToDevice));
+  if (!pairs_all.empty())
+    HIPCHK(hipMemcpy(ctx->d_render_all_pairs.p, pairs_all.data(), pairs_all.size() * 4, hipMemcpyHostToDevice));
   ctx->n_render_region = int(list_region.size());
   ctx->n_render_all = int(list_all.size());
   HIPCHK(ctx->d_render_region.alloc(std::max<size_t>(1, list_region.size()) * 4));
@@ -978,15 +1012,13 @@ int UploadRendererTables(Ctx* ctx) {
 // Renderings whose z-buffer fits the LDS of a CU: set-up + survivor list (32 slices of the triangle lists per renderer),
 // then one workgroup per renderer that rasterises the survivors in LDS and writes the images.  Larger ones: clear + crop,
 // rasterise into a z-buffer in memory, unpack.
-int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int largest_image_size) {
+int LaunchRenderers(Ctx* ctx, const int* which, int n_which, const int* pairs, int n_pairs, int largest_image_size) {
   if (n_which == 0) return M3T_OK;
-#ifndef M3T_RASTER_SLICES
-#define M3T_RASTER_SLICES 32
-#endif
-#ifndef M3T_RASTER_BANDS
-#define M3T_RASTER_BANDS 16
-#endif
-  int bands = M3T_RASTER_BANDS;
+  // work spread: ~128 set-up workgroups (slices of the triangle lists) and ~64 resolve workgroups (bands of image
+  // rows) per launch, whatever the number of renderings (measured on the reference's test scene, two pairs of twins:
+  // 16 -> 32 bands 87 -> 75 us per rendering; 32 -> 64 slices with four renderings: no change)
+  int slices = std::min(128, std::max(32, 128 / std::max(1, n_pairs)));
+  int bands = std::min(32, std::max(8, 64 / std::max(1, n_pairs)));
   if (const char* e = std::getenv("M3T_HIP_RASTER_BANDS")) bands = std::max(1, std::atoi(e));  // developer override
   const size_t band_rows = (size_t(largest_image_size) + bands - 1) / bands;
   const size_t lds = band_rows * largest_image_size * 4 + (M3T_BLOCK_THREADS + 1 + 16) * 4;  // z-buffer band | prefix sums | wave totals
@@ -1000,13 +1032,16 @@ int LaunchRenderers(Ctx* ctx, const int* which, int n_which, int largest_image_s
     }
   }
   if (ctx->lds_raster == 1 && largest_image_size > 0 && lds <= size_t(160) * 1024) {
-    hipLaunchKernelGGL(focused_setup_kernel, dim3(M3T_RASTER_SLICES, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
-                       ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
-    hipLaunchKernelGGL(focused_resolve_kernel, dim3(bands, n_which), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
-                       ctx->d_renderers.as<RendererDev>(), which);
+    hipLaunchKernelGGL(focused_setup_kernel, dim3(slices, n_pairs), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
+                       ctx->d_renderers.as<RendererDev>(), pairs, ctx->cams_active, ctx->d_poses.as<float>());
+    hipLaunchKernelGGL(focused_resolve_kernel, dim3(bands, n_pairs), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
+                       ctx->d_renderers.as<RendererDev>(), pairs);
     HIPCHK(hipGetLastError());
     return M3T_OK;
   }
+#ifndef M3T_RASTER_SLICES
+#define M3T_RASTER_SLICES 32
+#endif
   hipLaunchKernelGGL(focused_clear_kernel, dim3(16, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                      ctx->d_renderers.as<RendererDev>(), which, ctx->cams_active, ctx->d_poses.as<float>());
   hipLaunchKernelGGL(focused_raster_kernel, dim3(M3T_RASTER_SLICES, n_which), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
@@ -1024,7 +1059,9 @@ int LargestRendererImage(Ctx* ctx) {
 int RenderForModalities(Ctx* ctx, bool region_only) {
   for (auto& r : ctx->renderers) r->rendered = true;
   return LaunchRenderers(ctx, region_only ? ctx->d_render_region.as<int>() : ctx->d_render_all.as<int>(),
-                         region_only ? ctx->n_render_region : ctx->n_render_all, LargestRendererImage(ctx));
+                         region_only ? ctx->n_render_region : ctx->n_render_all,
+                         region_only ? ctx->d_render_region_pairs.as<int>() : ctx->d_render_all_pairs.as<int>(),
+                         region_only ? ctx->n_render_region_pairs : ctx->n_render_all_pairs, LargestRendererImage(ctx));
 }
 
 // ROI ingest: the readers of every camera (one per modality of a rigid optimizer: which body, which box of model
@@ -2592,9 +2629,10 @@ int m3t_hip_renderer_start_rendering(m3t_hip_context* ctx, int renderer) {
   int r = Prepare(ctx, false);
   if (r) return r;
   DevMem which;  // freed after the synchronisation below
-  HIPCHK(which.alloc(4));
-  HIPCHK(hipMemcpy(which.p, &renderer, 4, hipMemcpyHostToDevice));
-  if ((r = LaunchRenderers(ctx, which.as<int>(), 1, ctx->renderers[renderer]->image_size))) return r;
+  const int pair[2] = {renderer, -1};
+  HIPCHK(which.alloc(8));
+  HIPCHK(hipMemcpy(which.p, pair, 8, hipMemcpyHostToDevice));
+  if ((r = LaunchRenderers(ctx, which.as<int>(), 1, which.as<int>(), 1, ctx->renderers[renderer]->image_size))) return r;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->renderers[renderer]->rendered = true;
   return M3T_OK;

@@ -148,6 +148,7 @@ __device__ __forceinline__ Affine inverse_pose(const Affine& a) {
 }
 
 __device__ __forceinline__ int f2i(float v) { return (int)v; }  // truncation like C int(float)
+
 __device__ __forceinline__ float i2f_bits(int v) { return __int_as_float(v); }
 __device__ __forceinline__ int f2i_bits(float v) { return __float_as_int(v); }
 

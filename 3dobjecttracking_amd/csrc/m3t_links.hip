@@ -307,6 +307,11 @@ template <bool WAVE>
 __device__ __forceinline__ void tree_sync() { tree_sync_mode<WAVE ? 1 : 0>(); }
 // MODE != 0: every link's link2world in the (LDS) link table is current, body or not
 template <int MODE>
+__device__ __forceinline__ float tree_link_pose_element(const LinkDev& l, const float* body_poses, int e) {
+  if constexpr (MODE != 0) return l.link2world[e];
+  else return l.body >= 0 ? body_poses[16 * l.body + e] : l.link2world[e];
+}
+template <int MODE>
 __device__ __forceinline__ Affine tree_link_pose(const LinkDev& l, const float* body_poses) {
   if constexpr (MODE != 0) return load_pose(l.link2world);
   else return link_pose(l, body_poses);
@@ -941,48 +946,51 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
     tree_sync_mode<MODE>();
   } else {
     // ... then link2world, parents before children: (parent's link2world * joint2parent) * body2joint, left to right
-    // like the reference (the products are not associative in floating point): twelve lanes form the first product,
-    // fetch its rows from each other and form the second.
-    for (int li = 0; li < n_links; ++li) {
-      LinkDev& l = links[li];
-      if (l.parent >= 0) {
-        const float* P4 = links[l.parent].link2world;
-        float first = 0.0f;
-        if (lane < 12) {
-          const float* B4 = l.joint2parent;
-          if (lane < 9) {
-            const int c = lane / 3, k = lane - c * 3;
-            first = (P4[k] * B4[c * 4] + P4[4 + k] * B4[c * 4 + 1]) + P4[8 + k] * B4[c * 4 + 2];
-          } else {
-            const int k = lane - 9;
-            first = ((P4[k] * B4[12] + P4[4 + k] * B4[13]) + P4[8 + k] * B4[14]) + P4[12 + k];
-          }
+    // like the reference (the products are not associative in floating point).  Twelve lanes hold a pose, element
+    // (k, c) of its 3 x 4 block in lane 4 k + c: a row sits in one group of four lanes, so the four values of row k
+    // that mul_pose's expression for element (k, c) needs come by DPP quad broadcasts -- no LDS round trip inside a
+    // product -- and a child whose parent was the previous link takes the parent's pose from the registers it was just
+    // formed in.  Same operations on the same values as mul_pose, element for element.
+    {
+      const int k = (lane >> 2) < 3 ? (lane >> 2) : 0, c = lane & 3;
+      const bool holds = lane < 12;
+      // out(k, c) = (P(k,0) b0 + P(k,1) b1) + P(k,2) b2 [+ P(k,3) for the translation column]; b = column c of B
+      auto quadmul = [&](float P, float b0, float b1, float b2) {
+        const float p0 = quad_lane<0>(P), p1 = quad_lane<1>(P), p2 = quad_lane<2>(P), p3 = quad_lane<3>(P);
+        const float v = (p0 * b0 + p1 * b1) + p2 * b2;
+        return c == 3 ? v + p3 : v;
+      };
+      float cur = 0.0f;
+      int cur_link = -2;
+      for (int li = 0; li < n_links; ++li) {
+        LinkDev& l = links[li];
+        const float* B1 = l.joint2parent;
+        const float* B2 = l.body2joint;
+        const float e0 = B2[c * 4], e1 = B2[c * 4 + 1], e2 = B2[c * 4 + 2];  // column c of body2joint
+        float result;
+        if (l.parent >= 0) {
+          const float d0 = B1[c * 4], d1 = B1[c * 4 + 1], d2 = B1[c * 4 + 2];  // column c of joint2parent
+          const float P = l.parent == cur_link ? cur : links[l.parent].link2world[c * 4 + k];
+          result = quadmul(quadmul(P, d0, d1, d2), e0, e1, e2);
+        } else {
+          // a root: link2world <- ((link2world * body2joint^-1) * variation) * body2joint (link.cpp:226-230)
+          const float* v = var_all + (size_t)li * 12;  // variation: l[9] | t[3], column c at v[3 c ..]
+          const Affine inv = inverse_pose(load_pose(B2));
+          const float i0 = c < 3 ? inv.l[c * 3] : inv.t[0], i1 = c < 3 ? inv.l[c * 3 + 1] : inv.t[1],
+                      i2 = c < 3 ? inv.l[c * 3 + 2] : inv.t[2];
+          const float T = tree_link_pose_element<MODE>(l, body_poses, c * 4 + k);
+          result = quadmul(quadmul(quadmul(T, i0, i1, i2), v[c * 3], v[c * 3 + 1], v[c * 3 + 2]), e0, e1, e2);
         }
-        // first: element (k, c) of the intermediate product in lane c * 3 + k (t in lanes 9..11)
-        float second = 0.0f;
-        {
-          const float* B4 = l.body2joint;
-          const int c = lane < 9 ? lane / 3 : 3, k = lane < 9 ? lane - (lane / 3) * 3 : (lane - 9) % 3;
-          // the intermediate's row k sits in lanes k, 3 + k, 6 + k (and 9 + k for the translation)
-          const float fk0 = __shfl(first, k, kWave), fk1 = __shfl(first, 3 + k, kWave), fk2 = __shfl(first, 6 + k, kWave),
-                      ft = __shfl(first, 9 + k, kWave);
-          if (lane < 9) second = (fk0 * B4[c * 4] + fk1 * B4[c * 4 + 1]) + fk2 * B4[c * 4 + 2];
-          else second = ((fk0 * B4[12] + fk1 * B4[13]) + fk2 * B4[14]) + ft;
-        }
-        if (lane < 9) l.link2world[(lane / 3) * 4 + (lane % 3)] = second;
-        else if (lane < 12) l.link2world[12 + (lane - 9)] = second;
+        if (holds) l.link2world[c * 4 + k] = result;
         if (lane < 4) l.link2world[lane * 4 + 3] = lane == 3 ? 1.0f : 0.0f;
-      } else if (lane == 0) {
-        const float* v = var_all + (size_t)li * 12;
-        Affine var;
-        for (int i = 0; i < 9; ++i) var.l[i] = v[i];
-        var.t[0] = v[9]; var.t[1] = v[10]; var.t[2] = v[11];
-        Affine b2j = load_pose(l.body2joint);
-        Affine l2w = mul_pose(mul_pose(mul_pose(tree_link_pose<MODE>(l, body_poses), inverse_pose(b2j)), var), b2j);
-        affine_to_array(l2w, l.link2world);
+        cur = result;
+        cur_link = li;
+        if constexpr (MODE == 0) {  // (the fused kernel's caller writes the bodies)
+          tree_sync_mode<MODE>();
+          if (l.body >= 0 && lane < 16) body_poses[16 * l.body + lane] = l.link2world[lane];
+        }
       }
       tree_sync_mode<MODE>();
-      if (MODE == 0 && l.body >= 0 && lane < 16) body_poses[16 * l.body + lane] = l.link2world[lane];  // (otherwise the caller writes the bodies)
     }
   }
   PHASE_MARK(15);
@@ -1041,15 +1049,16 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
   auto* granules = (__attribute__((address_space(1))) unsigned long long*)o.exchange;
   auto* abort_word = (__attribute__((address_space(1))) unsigned*)(o.exchange + 2 * (size_t)o.n_tracked * M3T_TREE_GRANULES);
   int round = 0;
+  int region_view = rm ? *as_global(rm->last_view) : -1;  // the view of the modality's previous search (closest_view_local)
   for (int c = 0; c < n_corr_iterations; ++c) {
     {
       const Affine b2w = load_pose(pose);
-      int region_view = -1;
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_view = region_correspondences<false>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s);
+        region_view = region_correspondences<false>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, 0, 1 << 30, nullptr,
+                                                    region_view);
         region_moments(*rm, s);
       }
       if (dm) {
@@ -1131,6 +1140,7 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
       __syncthreads();
     }
   }
+  if (rm && tid == 0) *as_global_w(rm->last_view) = region_view;
   // every workgroup of a structure holds the same link table: the first one writes it (and the bodies) back
   if (st.tracked == 0) {
     for (int i = tid; i < n_links * 48; i += nt) {
@@ -1152,7 +1162,8 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
     if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
     const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
     region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
-                            (__attribute__((address_space(3))) uint32_t*)(lds_tree + M3T_MISC_FLOATS), lds_tree);
+                            (__attribute__((address_space(3))) uint32_t*)(lds_tree + M3T_MISC_FLOATS), lds_tree, 0, -1,
+                            nullptr, 0, 0, region_view);
   }
 }
 

@@ -187,20 +187,28 @@ struct RasterSurvivor {
 };
 static_assert(sizeof(RasterSurvivor) == M3T_SURVIVOR_BYTES, "M3T_SURVIVOR_BYTES");
 
+// which: pairs {renderer, twin or -1}.  A twin is a second renderer of the same camera, geometry, referenced bodies,
+// depth range and image size (a FocusedBasicDepthRenderer and a FocusedSilhouetteRenderer of one camera, say): its
+// rendering is this one -- the z-buffer word orders by depth and draw order, the id byte follows from the draw order --
+// so one set-up and one rasterisation serve both; the resolve kernel writes the twin's images with the twin's ids.
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 focused_setup_kernel(const RendererDev* renderers, const int* which, const CameraDev* cams, const float* body_poses) {
-  const RendererDev& r = renderers[which[blockIdx.y]];
+  const RendererDev& r = renderers[which[2 * blockIdx.y]];
+  const int twin = which[2 * blockIdx.y + 1];
   const CameraDev& cam = cams[r.camera];
   const FocusedProjection f = focused_projection(r, cam, body_poses);
   if (threadIdx.x == 0 && blockIdx.x == 0) {  // the crop, for the modalities that read the rendering
-    r.state[RS_CORNER_U] = f.corner_u;
-    r.state[RS_CORNER_V] = f.corner_v;
-    r.state[RS_SCALE] = f.scale;
-    r.state[RS_TERM_A] = r.z_max * r.z_min * 65535.0f / (r.z_max - r.z_min);  // renderer.cpp:567-570
-    r.state[RS_TERM_B] = r.z_max * 65535.0f / (r.z_max - r.z_min);
-    r.state[RS_N_VISIBLE] = (float)f.n_visible;
-    for (int k = 0; k < M3T_MAX_RENDERER_BODIES; ++k)
-      r.state[RS_VISIBLE0 + k] = (f.visible_mask >> k & 1u) ? 1.0f : 0.0f;
+    for (int w = 0; w < (twin >= 0 ? 2 : 1); ++w) {
+      float* state = w == 0 ? r.state : renderers[twin].state;
+      state[RS_CORNER_U] = f.corner_u;
+      state[RS_CORNER_V] = f.corner_v;
+      state[RS_SCALE] = f.scale;
+      state[RS_TERM_A] = r.z_max * r.z_min * 65535.0f / (r.z_max - r.z_min);  // renderer.cpp:567-570
+      state[RS_TERM_B] = r.z_max * 65535.0f / (r.z_max - r.z_min);
+      state[RS_N_VISIBLE] = (float)f.n_visible;
+      for (int k = 0; k < M3T_MAX_RENDERER_BODIES; ++k)
+        state[RS_VISIBLE0 + k] = (f.visible_mask >> k & 1u) ? 1.0f : 0.0f;
+    }
   }
   if (f.n_visible == 0) return;  // block-uniform
   const int S = r.image_size;
@@ -248,7 +256,8 @@ focused_resolve_kernel(const RendererDev* renderers, const int* which) {
   // are numbered through (block-wide prefix sum) and dealt out evenly: a covered pixel costs ~30 f64 operations, and a
   // thread that finished a 100-pixel box by itself kept its whole wave waiting (measured: 54 us per resolve).
   constexpr int kPiece = 8;
-  const RendererDev& r = renderers[which[blockIdx.y]];
+  const RendererDev& r = renderers[which[2 * blockIdx.y]];
+  const int twin = which[2 * blockIdx.y + 1];  // a renderer whose rendering is this one (focused_setup_kernel), or -1
   const int S = r.image_size;
   const int band_rows = (S + (int)gridDim.x - 1) / (int)gridDim.x;
   const int row_lo = (int)blockIdx.x * band_rows, row_hi = min(row_lo + band_rows, S) - 1;  // inclusive
@@ -303,6 +312,15 @@ focused_resolve_kernel(const RendererDev* renderers, const int* which) {
     const uint32_t v = lds_z[i];
     r.depth_image[row_lo * S + i] = v == 0xffffffffu ? (uint16_t)65535 : (uint16_t)(v >> 16);
     r.silhouette_image[row_lo * S + i] = v == 0xffffffffu ? (uint8_t)0 : (uint8_t)(v & 0xffu);
+  }
+  if (twin >= 0) {  // the same rendering with the twin's id byte: the winner's draw order sits in bits 8..15
+    const RendererDev& t = renderers[twin];
+    for (int i = tid; i < n_out; i += nt) {
+      const uint32_t v = lds_z[i];
+      t.depth_image[row_lo * S + i] = v == 0xffffffffu ? (uint16_t)65535 : (uint16_t)(v >> 16);
+      t.silhouette_image[row_lo * S + i] =
+          (v == 0xffffffffu || !t.silhouette) ? (uint8_t)0 : (uint8_t)t.id[(v >> 8) & 0xffu];
+    }
   }
   // every band has read the count by now once it says it is done: the last one clears the list for the next rendering
   if (tid == 0) {

@@ -683,7 +683,55 @@ def extras_point(pkg):
         f.tracker.ExecuteTrackingStep(0)
     api.call("sync")
     t4 = time.perf_counter()
+    name = C.create_string_buffer(64)
+    api.call("get_step_kernel", name, 64)
+    shape1 = (C.c_int * 4)()
+    api.call("get_step_shape", shape1)
+    # the same scene 64 times in one context (64 bodies behind 64 bottles, 256 focused renderers = 128 pairs of twins
+    # drawn once each, refreshed before each of the 7 searches): the renderer-fed step of a batch
+    api64 = pkg.open_context(0)
+    fixtures = []
+    for _ in range(64):
+        g = gs.TrackerFixture(api64, measure_occlusions=False, region_params=dict(n_unoccluded_iterations=0),
+                              depth_params=dict(n_unoccluded_iterations=0))
+        geo, _ = gs.fixture_renderer_geometry(api64, g.body)
+        rs = (host.FocusedBasicDepthRenderer(api64, geo, g.color_camera),
+              host.FocusedSilhouetteRenderer(api64, geo, g.color_camera, id_type=1),
+              host.FocusedBasicDepthRenderer(api64, geo, g.depth_camera),
+              host.FocusedSilhouetteRenderer(api64, geo, g.depth_camera, id_type=0))
+        for r in rs:
+            r.AddReferencedBody(g.body)
+        g.region.ModelOcclusions(rs[0])
+        g.region.UseRegionChecking(rs[1])
+        g.depth.ModelOcclusions(rs[2])
+        g.depth.UseSilhouetteChecking(rs[3])
+        fixtures.append((g, rs))
+    tracker64 = fixtures[0][0].tracker
+    tracker64.StartModalities(0)
+    tracker64.ExecuteTrackingStep(0)
+    api64.call("sync")
+    poses64 = np.stack([g.body.body2world_pose() for g, _ in fixtures])
+    n64 = 5
+    t5 = time.perf_counter()
+    for _ in range(n64):
+        for g, _ in fixtures:
+            g.body.set_body2world_pose(start)
+        tracker64.ExecuteTrackingStep(0)
+    api64.call("sync")
+    t6 = time.perf_counter()
+    name64 = C.create_string_buffer(64)
+    api64.call("get_step_kernel", name64, 64)
+    shape64 = (C.c_int * 4)()
+    api64.call("get_step_shape", shape64)
     return {"region_model_generation_s": round(t1 - t0, 2), "depth_model_generation_s": round(t2 - t1, 2),
+            "renderer_fed_kernel": name.value.decode(), "renderer_fed_shape": list(shape1),
+            "renderer_fed_64_objects": {
+                "ms_per_step": round((t6 - t5) / n64 * 1e3, 3),
+                "pose_updates_per_s": round(64 * n64 / (t6 - t5), 1),
+                "kernel": name64.value.decode(), "shape": list(shape64),
+                "all_objects_end_on_the_single_object_pose": bool(all(np.array_equal(p, poses64[0]) for p in poses64)),
+                "note": "64 x (Region + Depth with region / silhouette checking + modelled occlusions, 4 focused renderers "
+                        "of 20 958 triangles at 200 x 200), one context, 7 x 2 iterations"},
             "model": "2562 views x 200 points, 2000 x 2000 renderings, data/_body/triangle.obj",
             "renderer_fed_tracking_step_ms": round((t4 - t3) / n * 1e3, 3),
             "renderer_fed_config": "Region + Depth, region / silhouette checking + modelled occlusions, 4 focused "
