@@ -3107,6 +3107,8 @@ tracking_step_lds_kernel(const RigidOptDev* opts, const RegionModDev* rmods, con
                             n_update_iterations, write_state, fuse_histogram, nullptr, first_corr_iteration);
 }
 // several workgroups per object: for batches that leave most CUs idle
+// (round 4: a 128-VGPR build -- two of these workgroups per CU, so 8 instead of 4 per object at 64 objects -- spills
+// 496 bytes per lane: 0.194 ms with 4 and 0.232 ms with 8 workgroups per object against 0.150 ms)
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 tracking_step_split_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
