@@ -40,6 +40,19 @@ class _LoaderCamera:
         self.load_index, self.n_leading_zeros = int(load_index), int(n_leading_zeros)
         self.load_image_type = load_image_type
 
+    @property
+    def image(self):
+        """Camera::image() (camera.h): the frame of the last UpdateImage.  With prefetch on, the pixels live in a
+        page-locked slab that a worker thread overwrites two frames later: callers get their own copy, valid as long
+        as they keep it (viewers, recorders)."""
+        slab = getattr(self, "_image_slab", None)
+        return slab.copy() if slab is not None else getattr(self, "_image", None)
+
+    @image.setter
+    def image(self, value):
+        self._image_slab = None
+        self._image = value
+
     def image_path(self):
         s = str(self.load_index)
         n_zeros = max(self.n_leading_zeros - len(s), 0)  # loader_camera.cpp:83-88
@@ -150,7 +163,8 @@ class _LoaderCamera:
             except (OSError, ValueError) as e:
                 sys.stderr.write("Could not read image from %s (%s)\n" % (path, e))
                 return False
-            self.image = image
+            self._image_slab = None
+            self._image = image
             self.load_index += 1
             return super().UpdateImage(image)
         k = self.load_index
@@ -165,7 +179,7 @@ class _LoaderCamera:
         # every copy issued so far has left its slab (frame k's was started one step ago): the slab of frame k - 1,
         # which frame k + 2 is about to be decoded into, is free
         self.api.call("ingest_sync")
-        self.image = self._slabs[slot]
+        self._image_slab = self._slabs[slot]  # (`image` hands out a copy: the slab is decoded into again two frames on)
         self.select_slot(slot)  # the step that follows waits for this slot's copy, and only for it
         self.load_index += 1
         # frame k + 1: decoded while the previous step ran -> its copy overlaps the coming step; frame k + 2: decode now
