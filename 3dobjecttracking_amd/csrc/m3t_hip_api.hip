@@ -1014,14 +1014,16 @@ int UploadRendererTables(Ctx* ctx) {
 // rasterise into a z-buffer in memory, unpack.
 int LaunchRenderers(Ctx* ctx, const int* which, int n_which, const int* pairs, int n_pairs, int largest_image_size) {
   if (n_which == 0) return M3T_OK;
-  // work spread: ~128 set-up workgroups (slices of the triangle lists) and ~64 resolve workgroups (bands of image
-  // rows) per launch, whatever the number of renderings (measured on the reference's test scene, two pairs of twins:
-  // 16 -> 32 bands 87 -> 75 us per rendering; 32 -> 64 slices with four renderings: no change)
+  // work spread: ~128 set-up workgroups (slices of the triangle lists) and ~256 resolve workgroups (bands of image
+  // rows, at least two rows each) per launch, whatever the number of renderings (measured on the reference's test
+  // scene, two pairs of twins, renderer-fed step: 32 bands 0.633 ms, 64: 0.624, 100: 0.611; 64 -> 128 slices: no
+  // change, 256: slower)
   int slices = std::min(128, std::max(32, 128 / std::max(1, n_pairs)));
-  int bands = std::min(32, std::max(8, 64 / std::max(1, n_pairs)));
-  if (const char* e = std::getenv("M3T_HIP_RASTER_BANDS")) bands = std::max(1, std::atoi(e));  // developer override
+  int bands = std::min(std::max(8, largest_image_size / 2), std::max(8, 256 / std::max(1, n_pairs)));
+  if (const char* e = std::getenv("M3T_HIP_RASTER_BANDS")) bands = std::max(1, std::atoi(e));    // developer overrides
+  if (const char* e = std::getenv("M3T_HIP_RASTER_SLICES")) slices = std::max(1, std::atoi(e));
   const size_t band_rows = (size_t(largest_image_size) + bands - 1) / bands;
-  const size_t lds = band_rows * largest_image_size * 4 + (M3T_BLOCK_THREADS + 1 + 16) * 4;  // z-buffer band | prefix sums | wave totals
+  const size_t lds = band_rows * largest_image_size * 4 + (M3T_BLOCK_THREADS + 1 + 16 + 4 * M3T_BLOCK_THREADS) * 4;  // z-buffer band | prefix sums | wave totals | per-thread counts
   if (ctx->lds_raster < 0) {  // once per context (= per device)
     ctx->lds_raster = 1;
     if (std::getenv("M3T_HIP_NO_LDS_RASTER")) ctx->lds_raster = 0;
@@ -3371,7 +3373,8 @@ int m3t_hip_calculate_results(m3t_hip_context* ctx, int iteration) {
 // with every workgroup resident at once (their in-kernel exchange needs that).
 extern "C++" {
 template <typename K>
-int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_histogram, size_t* lds_out) {
+int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_histogram, size_t* lds_out,
+                     int default_limit = 8) {
   const size_t lds_tracking = size_t(ctx->layout.off_hist >= 0 ? ctx->layout.off_hist : ctx->layout.total_floats) * 4;
   // (each workgroup counts its share of the histogram bins: that share of the count table; the pair table is
   // read from L2, never staged)
@@ -3379,7 +3382,9 @@ int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_his
     return want_fused_histogram ? std::max(lds_tracking, M3T_MISC_FLOATS * 4 + (ctx->lds_hist - M3T_MISC_FLOATS * 4) / p)
                                 : lds_tracking;
   };
-  int limit = ctx->split_parts_override > 1 ? ctx->split_parts_override : 8;
+  // (default_limit: 8 for the one-launch step -- 16 was not faster there in round 2; 16 for the per-search launches of
+  // renderer-fed steps, measured 0.643 -> 0.635 ms for one object)
+  int limit = ctx->split_parts_override > 1 ? ctx->split_parts_override : default_limit;
   if (const char* e = std::getenv("M3T_HIP_SPLIT_PARTS")) limit = std::atoi(e);  // developer override
   const int elements = std::max(ctx->layout.nl, ctx->depth_mods.empty() ? 1 : ctx->np_max);
   for (int p = M3T_SPLIT_MAX_PARTS; p >= 2; p >>= 1) {
@@ -3539,7 +3544,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     bool shared = false;
     for (auto& m : ctx->region_mods) shared = shared || m->shared_histograms >= 0 || m->p.n_histogram_bins < 4;
     if (!shared && ctx->split_enabled && ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT"))
-      parts = ChooseSplitParts(ctx, tracking_step_split_render_kernel, n, M3T_BLOCK_THREADS, false, &lds_split);
+      parts = ChooseSplitParts(ctx, tracking_step_split_render_kernel, n, M3T_BLOCK_THREADS, false, &lds_split, 16);
     for (int c = 0; c < ctx->n_corr_iterations; ++c) {
       if ((r = RenderForModalities(ctx, false))) return r;
       if (parts >= 2) {

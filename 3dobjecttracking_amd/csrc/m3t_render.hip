@@ -255,7 +255,7 @@ focused_resolve_kernel(const RendererDev* renderers, const int* which) {
   // Every survivor's rows inside the band are cut into pieces of kPiece pixels; the pieces of ALL survivors of a trip
   // are numbered through (block-wide prefix sum) and dealt out evenly: a covered pixel costs ~30 f64 operations, and a
   // thread that finished a 100-pixel box by itself kept its whole wave waiting (measured: 54 us per resolve).
-  constexpr int kPiece = 8;
+  constexpr int kPiece = 8, kPer = 4;  // survivors a thread looks at per trip: one trip up to 2048 survivors
   const RendererDev& r = renderers[which[2 * blockIdx.y]];
   const int twin = which[2 * blockIdx.y + 1];  // a renderer whose rendering is this one (focused_setup_kernel), or -1
   const int S = r.image_size;
@@ -263,18 +263,25 @@ focused_resolve_kernel(const RendererDev* renderers, const int* which) {
   const int row_lo = (int)blockIdx.x * band_rows, row_hi = min(row_lo + band_rows, S) - 1;  // inclusive
   const int n_px = band_rows * S;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  int* first_item = reinterpret_cast<int*>(lds_z + n_px);  // [nt + 1]: pieces before survivor base + t
-  int* wave_total = first_item + nt + 1;                   // [nt / kWave]
+  int* first_item = reinterpret_cast<int*>(lds_z + n_px);  // [nt + 1]: pieces before thread t's survivors
+  int* wave_total = first_item + nt + 1;                   // [16]
+  int* own_count = wave_total + 16;                        // [kPer][nt]: pieces of thread t's j-th survivor
   for (int i = tid; i < n_px; i += nt) lds_z[i] = 0xffffffffu;
   const int n = min(__hip_atomic_load(r.n_survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), r.survivor_capacity);
   const RasterSurvivor* list = static_cast<const RasterSurvivor*>(r.survivors);
   auto sink = [S, row_lo](int px, int py, uint32_t word) { atomicMin(&lds_z[(py - row_lo) * S + px], word); };
-  for (int base = 0; base < n && row_lo <= row_hi; base += nt) {  // block-uniform trip count
-    int mine = 0;
-    if (base + tid < n) {
-      const RasterTriangle& tri = list[base + tid].tri;
-      const int ya = max(tri.y0, row_lo), yb = min(tri.y1, row_hi);
-      if (ya <= yb) mine = ((tri.x1 - tri.x0 + kPiece) / kPiece) * (yb - ya + 1);
+  for (int base = 0; base < n && row_lo <= row_hi; base += nt * kPer) {  // block-uniform trip count
+    int mine = 0, cnt[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int i = base + j * nt + tid;
+      cnt[j] = 0;
+      if (i < n) {
+        const RasterTriangle& tri = list[i].tri;
+        const int ya = max(tri.y0, row_lo), yb = min(tri.y1, row_hi);
+        if (ya <= yb) cnt[j] = ((tri.x1 - tri.x0 + kPiece) / kPiece) * (yb - ya + 1);
+      }
+      mine += cnt[j];
     }
     // inclusive prefix sum over the wave (DPP: row_shr 1 2 4 8, row_bcast 15 / 31), then over the waves
     int incl = mine;
@@ -284,8 +291,10 @@ focused_resolve_kernel(const RendererDev* renderers, const int* which) {
     incl += dpp_zero_i<0x118, 0xf>(incl);
     incl += dpp_zero_i<0x142, 0xa>(incl);
     incl += dpp_zero_i<0x143, 0xc>(incl);
-    __syncthreads();  // (the previous trip's pieces are done with first_item; the first time: the cleared z-buffer)
+    __syncthreads();  // (the previous trip's pieces are done with the tables; the first time: the cleared z-buffer)
     if (lane == kWave - 1) wave_total[wave] = incl;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) own_count[j * nt + tid] = cnt[j];
     __syncthreads();
     int before = 0;
     for (int wv = 0; wv < wave; ++wv) before += wave_total[wv];
@@ -294,14 +303,16 @@ focused_resolve_kernel(const RendererDev* renderers, const int* which) {
     __syncthreads();
     const int total = first_item[nt];
     for (int k = tid; k < total; k += nt) {
-      int lo = 0, hi = nt - 1;  // the last survivor whose first piece is <= k (survivors without pieces repeat the value:
+      int lo = 0, hi = nt - 1;  // the last thread whose first piece is <= k (threads without pieces repeat the value:
       while (lo < hi) {         // the last of equals is the one that owns the piece)
         const int mid = (lo + hi + 1) >> 1;
         if (first_item[mid] <= k) lo = mid; else hi = mid - 1;
       }
-      const RasterSurvivor& sv = list[base + lo];
+      int local = k - first_item[lo], j = 0;
+      while (j < kPer - 1 && local >= own_count[j * nt + lo]) { local -= own_count[j * nt + lo]; ++j; }
+      const RasterSurvivor& sv = list[base + j * nt + lo];
       const int ya = max(sv.tri.y0, row_lo);
-      const int pieces = (sv.tri.x1 - sv.tri.x0 + kPiece) / kPiece, local = k - first_item[lo];
+      const int pieces = (sv.tri.x1 - sv.tri.x0 + kPiece) / kPiece;
       const int row = local / pieces, xa = sv.tri.x0 + (local - row * pieces) * kPiece;
       raster_row(sv.tri, ya + row, xa, min(xa + kPiece - 1, sv.tri.x1), sv.low_bits, sink);
     }

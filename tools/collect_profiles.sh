@@ -7,11 +7,13 @@
 #   * PMC passes (SQ x 2, TA, TCC, FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md -- 8 SQ / 4 TCC slots per pass, the two
 #     size counters in passes of their own, never together with the hip / hsa trace domains) of the same commands
 #   * per-phase cycles of the developer build (tools/phase_timing.py)
-# usage: tools/collect_profiles.sh [what ...]   what = tests bench stats pmc phases sweep (default: all)
+# Order: the PMC passes first -- their HBM traffic blocks go into profiles/ on the box, so the bench lines taken after
+# them quote this run's traffic (roofline.traffic_source).
+# usage: tools/collect_profiles.sh [what ...]   what = tests pmc bench extras stats phases sweep (default: all)
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 ROUND=${ROUND:-r04}
 OUT=$REPO/gpurun_out/$ROUND
-WHAT=${@:-tests bench stats pmc phases sweep}
+WHAT=${@:-tests pmc bench extras stats phases sweep}
 CONFIGS=${CONFIGS:-rbot64 rbot4096 ycb21 synth512 chain8}
 mkdir -p "$OUT"
 cd "$REPO"
@@ -28,31 +30,7 @@ if has tests; then
   (cd tests && timeout 1500 python -m pytest -m gpu -q --timeout=900 2>&1 | grep -vE "^(RCCL|HIP|ROCm|Hostname|Librccl)" | tail -8) > "$OUT/gpu_tests.log" 2>&1
   tail -2 "$OUT/gpu_tests.log"
 fi
-if has bench; then
-  for c in $CONFIGS; do
-    extra=""
-    [ "$c" = rbot4096 ] && extra="--no-pcie --cpu-seconds 4 --no-cpu-parallel"
-    (timeout 900 python bench.py $(args_of $c) $extra > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err")
-    head -c 400 "$OUT/bench_$c.json"; echo
-  done
-fi
-if has sweep; then
-  (timeout 1200 python bench.py --no-pcie --no-cpu-baseline --repeats 3 --sweep 1,8,32,256,512,1024,4096 > "$OUT/bench_sweep.json" 2> "$OUT/bench_sweep.err")
-  python - "$OUT/bench_sweep.json" <<'PY'
-import json, sys
-for s in json.load(open(sys.argv[1])).get("batch_sweep", []):
-    print(s["objects"], s["pose_updates_per_s"], s["frac_of_hbm_roofline"], s.get("kernel"))
-PY
-fi
 PROF="--steps 10 --warmup 2 --no-cpu-baseline --no-pcie --no-buckets --repeats 1"
-if has stats; then
-  for c in $CONFIGS; do
-    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$c" -- python "$REPO/bench.py" $(args_of $c) $PROF > "$OUT/stats_$c.log" 2>&1)
-    cp "$OUT"/stats_$c/*/*kernel_stats.csv "$OUT/kernel_stats_$c.csv" 2>/dev/null
-    rm -rf "$OUT/stats_$c"  # (the raw traces of a 4096-object run are tens of MB; gpurun merges at most 64 MB back)
-    head -4 "$OUT/kernel_stats_$c.csv"
-  done
-fi
 if has pmc; then
   declare -A PASS
   PASS[sq1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
@@ -74,6 +52,32 @@ if has pmc; then
     rm -rf "$OUT/pmc_$c"
   done
 fi
+
+# the bench lines below quote this run's traffic blocks (bench.py looks them up under profiles/)
+for f in "$OUT"/hbm_traffic_*.json; do [ -f "$f" ] && cp "$f" "$REPO/profiles/${ROUND}_$(basename "$f")"; done
+if has bench; then
+  for c in $CONFIGS; do
+    extra=""
+    [ "$c" = rbot4096 ] && extra="--no-pcie --cpu-seconds 4 --no-cpu-parallel"
+    (timeout 900 python bench.py $(args_of $c) $extra > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err")
+    head -c 400 "$OUT/bench_$c.json"; echo
+  done
+fi
+if has extras; then
+  (timeout 900 python bench.py --extras --no-pcie --no-cpu-baseline --no-buckets --busy-seconds 1 > "$OUT/bench_extras.json" 2> "$OUT/bench_extras.err")
+  python - "$OUT/bench_extras.json" <<'PY'
+import json, sys
+print(json.dumps(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]).get("extras"))[:600])
+PY
+fi
+if has stats; then
+  for c in $CONFIGS; do
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$c" -- python "$REPO/bench.py" $(args_of $c) $PROF > "$OUT/stats_$c.log" 2>&1)
+    cp "$OUT"/stats_$c/*/*kernel_stats.csv "$OUT/kernel_stats_$c.csv" 2>/dev/null
+    rm -rf "$OUT/stats_$c"  # (the raw traces of a 4096-object run are tens of MB; gpurun merges at most 64 MB back)
+    head -4 "$OUT/kernel_stats_$c.csv"
+  done
+fi
 if has phases; then
   for v in "rbot64:64:" "ycb21:21:ycb"; do
     IFS=: read name n ycb <<< "$v"
@@ -81,4 +85,17 @@ if has phases; then
   done
   (timeout 300 python tools/tree_timing.py tools/libm3t_hip_timing.so 2>&1 | grep -v amdgpu) > "$OUT/phase_timing_chain8.txt" 2>&1
   head -12 "$OUT/phase_timing_rbot64.txt"
+fi
+if has sweep; then
+  (timeout 1200 python bench.py --no-pcie --no-cpu-baseline --no-buckets --repeats 3 --sweep 1,8,32,256,512,1024,4096 > "$OUT/bench_sweep.json" 2> "$OUT/bench_sweep.err")
+  # SURVEY 8(d) also names 32768 objects (shared cameras above 4096: batch_point): its own run and time limit
+  (timeout 700 python bench.py --no-pcie --no-cpu-baseline --no-buckets --repeats 1 --busy-seconds 1 --sweep 32768 > "$OUT/bench_sweep_32768.json" 2> "$OUT/bench_sweep_32768.err")
+  python - "$OUT/bench_sweep.json" <<'PY'
+import json, sys
+import os
+for path in (sys.argv[1], sys.argv[1].replace(".json", "_32768.json")):
+    if os.path.exists(path) and os.path.getsize(path):
+        for s in json.load(open(path)).get("batch_sweep", []):
+            print(s["objects"], s["pose_updates_per_s"], s["frac_of_hbm_roofline"], s.get("kernel"))
+PY
 fi

@@ -49,4 +49,4 @@ def main(rounds):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["r03"])
+    main(sys.argv[1:] or ["r04"])
