@@ -21,6 +21,7 @@
 
 #include "../../include/m3t_hip.h"
 #include "m3t_device.h"
+#include "m3t_view_rows.h"
 #include "m3t_kernels.hip"
 #include "m3t_compact.hip"
 #include "m3t_render.hip"
@@ -441,32 +442,7 @@ int CreateModel(Ctx* ctx, bool region, int n_views, int n_points, const float* p
     HIPCHK(hipMemcpy(m->orientations4.p, o4.data(), o4.size() * 4, hipMemcpyHostToDevice));
   }
   if (n_views > M3T_VIEW_ROW) {
-    // closest_view_local: the M3T_VIEW_NEIGHBORS nearest views of every view and how far a viewing direction may be
-    // from the view for the argmax over ALL views to lie among them: with R = the angle to the nearest view that is
-    // NOT in the row, a direction closer to the view than R / 2 is closer to it than to any view outside the row.
-    // The threshold stored is cos(R / 2 - 2e-3 rad): the slack dwarfs every rounding error of the f32 dot products.
-    std::vector<float> rows(size_t(n_views) * M3T_VIEW_ROW * 4, 0.0f);
-    std::vector<std::pair<float, int>> by_dot(static_cast<size_t>(n_views));
-    for (int v = 0; v < n_views; ++v) {
-      const float* a = ori + size_t(v) * 3;
-      for (int w = 0; w < n_views; ++w) {
-        const float* b = ori + size_t(w) * 3;
-        by_dot[size_t(w)] = {w == v ? 4.0f : float(double(a[0]) * b[0] + double(a[1]) * b[1] + double(a[2]) * b[2]), w};
-      }
-      std::partial_sort(by_dot.begin(), by_dot.begin() + M3T_VIEW_NEIGHBORS + 2, by_dot.end(),
-                        [](const std::pair<float, int>& x, const std::pair<float, int>& y) {
-                          return x.first > y.first || (x.first == y.first && x.second < y.second);
-                        });
-      float* row = rows.data() + size_t(v) * M3T_VIEW_ROW * 4;
-      for (int k = 0; k <= M3T_VIEW_NEIGHBORS; ++k) {  // by_dot[0] is the view itself
-        const int w = by_dot[size_t(k)].second;
-        std::memcpy(row + k * 4, ori + size_t(w) * 3, 12);
-        std::memcpy(row + k * 4 + 3, &w, 4);
-      }
-      const double first_outside = std::min(1.0, std::max(-1.0, double(by_dot[M3T_VIEW_NEIGHBORS + 1].first)));
-      const double half = 0.5 * std::acos(first_outside) - 2.0e-3;
-      row[(M3T_VIEW_ROW - 1) * 4] = half > 0.0 ? float(std::cos(half)) : 2.0f;  // 2: never met
-    }
+    const std::vector<float> rows = m3t_view_rows(ori, n_views);  // closest_view_local's table (m3t_view_rows.h)
     HIPCHK(m->view_neighbors.alloc(rows.size() * 4));
     HIPCHK(hipMemcpy(m->view_neighbors.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
   }

@@ -1,5 +1,5 @@
 // Host check of 3dobjecttracking_amd/csrc/m3t_raster.h: the row scan of the focused renderers' kernels (raster_row,
-// serial over a bounding box and in 32-pixel pieces as the workgroup path cuts it) against the per-pixel definition
+// serial over a bounding box and in the 8- / 32-pixel pieces the workgroup paths cut it into) against the per-pixel definition
 // (raster_pixel) on random triangles -- slivers, triangles with vertices on pixel centres and on pixel edges,
 // axis-parallel edges, triangles that leave the image -- word for word.  Prints "triangles N covered P mismatches M".
 #include <cstdio>
@@ -61,8 +61,11 @@ int main(int argc, char** argv) {
     for (int py = t.y0; py <= t.y1; ++py)
       for (int px = t.x0; px <= t.x1; ++px) raster_pixel(t, px, py, low, sink_a);
     for (int py = t.y0; py <= t.y1; ++py) raster_row(t, py, t.x0, t.x1, low, sink_b);
+    // (the pieces of the kernels: 8 pixels in focused_resolve_kernel, 32 in focused_raster_kernel)
+    const int piece = (it & 1) ? 8 : 32;
     for (int py = t.y0; py <= t.y1; ++py)
-      for (int xa = t.x0; xa <= t.x1; xa += 32) raster_row(t, py, xa, xa + 31 < t.x1 ? xa + 31 : t.x1, low, sink_c);
+      for (int xa = t.x0; xa <= t.x1; xa += piece)
+        raster_row(t, py, xa, xa + piece - 1 < t.x1 ? xa + piece - 1 : t.x1, low, sink_c);
     for (int i = 0; i < S * S; ++i) mismatches += (a[i] != b[i]) + (a[i] != c[i]);
   }
   // raster_quotient against the division it replaces: integer operands as the edge functions and areas are
