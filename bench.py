@@ -176,6 +176,13 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # N ranks build their inputs (rendering, model sampling: numpy) side by side on one host: every rank keeps to
+        # its share of the usable cores instead of N thread pools of full width fighting over the container's quota
+        try:
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(limits=max(1, int(usable_cpus()["usable"]) // world))
+        except Exception:  # noqa: BLE001 (a convenience, not a requirement)
+            pass
 
     pkg = importlib.import_module("3dobjecttracking_amd")
     if args.config == "chain8":
