@@ -300,6 +300,7 @@ _HIP_ONLY = {
     "host_register": [C.c_void_p, C.c_size_t],
     "host_unregister": [C.c_void_p],
     "ingest_sync": [],
+    "camera_slot_sync": [C.c_int, C.c_int],
     "comm_get_unique_id": [C.c_void_p, C.c_size_t],
     "comm_init_rank": [C.c_void_p, C.c_size_t, C.c_int, C.c_int],
     "comm_set": [C.c_void_p],

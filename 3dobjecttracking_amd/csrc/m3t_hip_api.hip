@@ -78,6 +78,7 @@ struct Camera {
   std::vector<bool> has_image;
   std::vector<long> last_read_step;  // per slot: the last streaming step that read it (-1: none)
   std::vector<bool> slot_is_roi;     // per slot: only the trackers' rectangle of the frame was uploaded (m3t_ingest.hip)
+  std::vector<hipEvent_t> slot_copied;  // per slot: behind its last camera_upload_slot_async (m3t_hip_camera_slot_sync); lazily made
   DevMem ring;          // this camera's own frame ring, or empty when it lives in a shared slab
   int slab = -1, slab_index = 0;  // shared slab (m3t_hip_cameras_set_ring): [slot][camera of the group][frame]
   uint8_t* frames = nullptr;      // slot 0 of this camera
@@ -1614,6 +1615,9 @@ void m3t_hip_destroy(m3t_hip_context* ctx) {
     if (ctx->cam_stage[i]) (void)hipHostFree(ctx->cam_stage[i]);
     if (ctx->cam_stage_done[i]) (void)hipEventDestroy(ctx->cam_stage_done[i]);
   }
+  for (auto& c : ctx->cameras)
+    for (auto& e : c->slot_copied)
+      if (e) (void)hipEventDestroy(e);
   if (ctx->split_abort_host) (void)hipHostFree(ctx->split_abort_host);
   if (ctx->roi_miss_host) (void)hipHostFree(ctx->roi_miss_host);
   if (ctx->roi_snapshot_done) (void)hipEventDestroy(ctx->roi_snapshot_done);
@@ -1822,7 +1826,22 @@ int m3t_hip_camera_upload_slot_async(m3t_hip_context* ctx, int id, int slot, con
                             ctx->copy_stream[cs]));
   c.has_image[slot] = true;
   RoiMarkWholeFrame(ctx, id, slot, ctx->copy_stream[cs]);
+  if (c.slot_copied.size() < size_t(c.n_slots)) c.slot_copied.resize(size_t(c.n_slots), nullptr);
+  if (!c.slot_copied[slot]) HIPCHK(hipEventCreateWithFlags(&c.slot_copied[slot], hipEventDisableTiming));
+  HIPCHK(hipEventRecord(c.slot_copied[slot], ctx->copy_stream[cs]));
   ctx->copies_pending |= 1u << cs;
+  return M3T_OK;
+}
+// Wait until the last camera_upload_slot_async into (camera, slot) has left its host buffer -- and for nothing else:
+// the copies of other cameras and of this camera's other slots stay in flight (m3t_hip_ingest_sync waits for all).
+int m3t_hip_camera_slot_sync(m3t_hip_context* ctx, int id, int slot) {
+  CHECK_CTX();
+  REQUIRE(id >= 0 && id < int(ctx->cameras.size()), M3T_ERR_INVALID_ARGUMENT, "bad camera id");
+  Camera& c = *ctx->cameras[id];
+  REQUIRE(slot >= 0 && slot < c.n_slots, M3T_ERR_INVALID_ARGUMENT, "bad frame slot");
+  if (size_t(slot) >= c.slot_copied.size() || !c.slot_copied[slot]) return M3T_OK;  // nothing was enqueued
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipEventSynchronize(c.slot_copied[slot]));
   return M3T_OK;
 }
 // One frame ring for a group of cameras of equal geometry: [slot][camera][frame], so that slot s of the whole group is
@@ -3306,6 +3325,9 @@ int m3t_hip_comm_set(m3t_hip_context* ctx, void* nccl_comm) {
       ctx->soft_constraints_active = rank == 0;
       ctx->tables_dirty = true;
     }
+  } else if (!ctx->comm && !ctx->soft_constraints_active) {  // back to one process: the whole structure is here again
+    ctx->soft_constraints_active = true;
+    ctx->tables_dirty = true;
   }
   return M3T_OK;
 }
@@ -3314,6 +3336,10 @@ int m3t_hip_comm_destroy(m3t_hip_context* ctx) {
   if (ctx->comm && ctx->comm_owned) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     RCCLCHK(g_rccl.CommDestroy(ctx->comm));
+  }
+  if (ctx->comm && !ctx->soft_constraints_active) {  // (see m3t_hip_comm_set)
+    ctx->soft_constraints_active = true;
+    ctx->tables_dirty = true;
   }
   ctx->comm = nullptr;
   ctx->comm_owned = false;

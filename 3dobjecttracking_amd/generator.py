@@ -176,9 +176,10 @@ class _LoaderCamera:
             self._drop_pipeline()
             return False
         slot = self._uploaded.pop(k)
-        # every copy issued so far has left its slab (frame k's was started one step ago): the slab of frame k - 1,
-        # which frame k + 2 is about to be decoded into, is free
-        self.api.call("ingest_sync")
+        # the slab frame k + 2 is about to be decoded into is the one frame k - 1 was copied out of, three uploads of
+        # THIS camera ago: wait for that copy and for no other (the other cameras' copies of frame k + 1, enqueued a
+        # moment ago by their UpdateImage, stay in flight next to the coming step)
+        self.slot_sync((k + 2) % self._PIPELINE_SLOTS)
         self._image_slab = self._slabs[slot]  # (`image` hands out a copy: the slab is decoded into again two frames on)
         self.select_slot(slot)  # the step that follows waits for this slot's copy, and only for it
         self.load_index += 1

@@ -66,6 +66,12 @@ class Tracker:
     def CalculateOptimizationEnd(self):
         return self._step("calculate_optimization_end")
 
+    def SetSoftConstraintsActive(self, active):
+        """a structure spread over processes whose host sums the begin() buffers itself: the soft constraints'
+        terms enter the summed system once, i.e. they stay active on ONE process (m3t_hip.h; with a communicator set
+        the library does this by rank)"""
+        self.api.call("set_soft_constraints_active", 1 if active else 0)
+
     def ExecuteTrackingStep(self, iteration):
         return self._step("execute_tracking_step", iteration)
 
@@ -206,7 +212,7 @@ class _Camera:
 
     def upload_slot(self, slot, image, asynchronous=False):
         """Stage `image` into ring slot `slot`.  With asynchronous=True the call returns at once and
-        the array must stay alive and unchanged until Tracker.ingest_sync() (page-lock it once with
+        the array must stay alive and unchanged until slot_sync(slot) / Tracker.ingest_sync() (page-lock it once with
         Tracker.register_host_buffer for a true overlapped copy)."""
         a = np.asarray(image)
         assert a.shape[0] == self.height and a.shape[1] == self.width
@@ -216,6 +222,11 @@ class _Camera:
 
     def select_slot(self, slot):
         self.api.call("camera_select_slot", self.id, slot)
+
+    def slot_sync(self, slot):
+        """wait until this camera's last asynchronous upload into `slot` has left its host buffer (and for no other
+        copy: Tracker.ingest_sync waits for all cameras)"""
+        self.api.call("camera_slot_sync", self.id, slot)
 
     def set_world2camera_pose(self, pose):
         self.api.call("camera_set_world2camera_pose", self.id, fptr(pose_arg(pose)))

@@ -117,6 +117,9 @@ int m3t_hip_cameras_set_ring(m3t_hip_context*, const int* camera_ids, int n_came
 int m3t_hip_cameras_upload_batch_async(m3t_hip_context*, const int* camera_ids, int n_cameras, int slot, const void* base,
                                        size_t camera_stride, size_t row_step);
 int m3t_hip_ingest_sync(m3t_hip_context*); /* wait until all enqueued frame copies have landed */
+/* wait until the last camera_upload_slot_async into (camera, slot) has left its host buffer, and for nothing else: a
+ * loader that recycles one camera's page-locked buffers does not hold up the copies of the other cameras */
+int m3t_hip_camera_slot_sync(m3t_hip_context*, int camera_id, int slot);
 /* ROI ingest: only the part of a frame the trackers can read crosses PCIe.  set_roi_ingest(enable, margin_px) makes
  * the fused step of rigid objects record the poses its searches run at; cameras_upload_batch_roi_async is
  * cameras_upload_batch_async for rectangles: one kernel on the copy stream computes every camera's rectangle -- the
@@ -223,8 +226,9 @@ int m3t_hip_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, 
  * pulls once its rotation / translation error exceeds max_distance_*, weighted with 1/standard_deviation^2;
  * it adds to the g/H of both links before the projection.  A structure spread over several processes
  * (begin -> all-reduce -> end) keeps them active on one rank only: m3t_hip_comm_init_rank / m3t_hip_comm_set switch
- * them off on every rank but 0 (their terms would otherwise enter the summed system once per rank); a host that
- * all-reduces the partial buffers itself calls set_soft_constraints_active(0) on the other ranks. */
+ * them off on every rank but 0 (their terms would otherwise enter the summed system once per rank) and
+ * m3t_hip_comm_destroy / comm_set(ctx, NULL) switch them on again; a host that all-reduces the partial buffers
+ * itself calls set_soft_constraints_active(0) on the other ranks. */
 int m3t_hip_soft_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, int link2_id,
                                    const float body12joint1[16], const float body22joint2[16],
                                    const int constraint_directions[6], float max_distance_rotation,

@@ -106,6 +106,7 @@ class Camera {
                                  : m3t_hip_camera_upload_slot(c_->get(), id_, slot, pixels, row_step));
   }
   bool SelectSlot(int slot) { return c_->Step(m3t_hip_camera_select_slot(c_->get(), id_, slot)); }
+  bool SlotSync(int slot) { return c_->Step(m3t_hip_camera_slot_sync(c_->get(), id_, slot)); }  // this camera's copy only
   int id() const { return id_; }
 
  protected:

@@ -66,12 +66,12 @@ def test_loader_camera_overlapped_ingest(tmp_path):
         Image.fromarray(np.ascontiguousarray(inputs.color[0][k][:, :, ::-1])).save(str(tmp_path / ("color_%04d.png" % k)))
     intr = inputs.intr
     results = {}
-    for prefetch in (False, True):
-        api = util.open_hip()
+    for prefetch in (False, True, "no read-back"):  # (the last: nothing waits for a step until the sequence ends, the
+        api = util.open_hip()                        #  slabs are recycled on the strength of camera_slot_sync alone)
         cam = util.pkg.generator.LoaderColorCamera(
             api, str(tmp_path), (intr["fu"], intr["fv"], intr["ppu"], intr["ppv"], intr["width"], intr["height"]),
             "color_", 0, 4, "")
-        cam.enable_prefetch(prefetch)
+        cam.enable_prefetch(bool(prefetch))
         body = host.Body(api, inputs.start[0])
         m = inputs.region_models[0]
         model = host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
@@ -87,10 +87,12 @@ def test_loader_camera_overlapped_ingest(tmp_path):
             assert cam.UpdateImage(True)
             assert np.array_equal(cam.image, inputs.color[0][k])
             assert tracker.ExecuteTrackingStep(k)
-            poses.append(body.body2world_pose())
+            if prefetch != "no read-back":
+                poses.append(body.body2world_pose())
         assert not cam.UpdateImage(True)  # frame 9 does not exist
-        results[prefetch] = poses
+        results[prefetch] = poses or [body.body2world_pose()]
     for a, b in zip(results[False], results[True]):
         assert np.array_equal(a, b)
+    assert np.array_equal(results["no read-back"][-1], results[True][-1])
     e = syn.pose_errors(results[True][-1], inputs.gt[0][-1])
     assert e[0] < np.deg2rad(5) and e[1] < 0.05

@@ -229,6 +229,63 @@ def test_tracking_step_all_reduces_with_a_communicator_set():
 
 
 @gpu
+def test_soft_constraints_count_once_when_the_host_sums_the_buffers():
+    """two contexts on this GPU stand in for two ranks that hold the same structure: the host adds their begin()
+    buffers (what an all-reduce does) and hands the sum to both; with the soft constraints active in one context only
+    (m3t_hip_set_soft_constraints_active; comm_init_rank / comm_set do it by rank) both replicas equal the
+    single-context run bit for bit -- the other context adds exact zeros.  Active in both they count twice."""
+    import torch
+    from test_multibody_oracle import build_soft
+
+    def structure(api):
+        rng = np.random.default_rng(7)
+        b1, b2 = random_pose(rng), random_pose(rng)
+        link1, link2, opt = build_soft(api, b1, b2)
+        d = random_pose(rng)
+        d[:3, :3] = syn.rot_vec(rng.normal(size=3) * 0.3)
+        d[:3, 3] *= 0.05
+        link2.set_joint2parent_pose(np.linalg.inv(b1) @ d)
+        tracker = host.Tracker(api, 1, 1)
+        return tracker, (link1, link2)
+
+    def state(links):
+        return np.stack([links[0].link2world_pose(), links[1].link2world_pose(), links[1].joint2parent_pose()])
+
+    def view(ptr, n):
+        addr = C.cast(ptr, C.c_void_p).value
+
+        class _Buf:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (addr, False), "version": 2}
+        return torch.as_tensor(_Buf(), device="cuda")
+
+    tracker, links = structure(util.open_hip())
+    assert tracker.CalculateConsistentPoses()
+    for it in range(5):
+        assert tracker.CalculateOptimization(0, 0, 0)
+    single = state(links)
+    results = {}
+    for all_active in (False, True):
+        ranks = [structure(util.open_hip()) for _ in range(2)]
+        if not all_active:
+            ranks[1][0].SetSoftConstraintsActive(False)
+        for tr, _ in ranks:
+            assert tr.CalculateConsistentPoses()
+        for it in range(5):
+            bufs = [view(*tr.CalculateOptimizationBegin()) for tr, _ in ranks]
+            torch.cuda.synchronize()
+            total = bufs[0] + bufs[1]
+            for b in bufs:
+                b.copy_(total)
+            torch.cuda.synchronize()
+            for tr, _ in ranks:
+                assert tr.CalculateOptimizationEnd()
+        results[all_active] = [state(l) for _, l in ranks]
+    assert np.array_equal(results[False][0], results[False][1])
+    assert np.array_equal(results[False][0], single)
+    assert np.max(np.abs(results[True][0] - single)) > 1e-4
+
+
+@gpu
 def test_rigid_context_switches_to_general_path_for_begin_end():
     """begin/end on a rigid-only context == the rigid fast path within one Newton-step tolerance"""
     inputs = scenes.Inputs(2, 2, n_divides=2)

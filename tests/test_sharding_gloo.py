@@ -125,6 +125,57 @@ def test_kinematic_structure_over_two_ranks(tmp_path):
     assert np.array_equal(r0, ref)      # and equal the single-process run
 
 
+# ---- soft constraints of a structure spread over ranks enter the summed system once ----
+def _soft_worker(rank, world, port, out_dir, all_active):
+    import torch
+    import torch.distributed as dist
+    from test_multibody_oracle import build_soft, random_pose
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    api = util.open_oracle()
+    b1, b2 = random_pose(rng), random_pose(rng)
+    link1, link2, opt = build_soft(api, b1, b2)
+    d = random_pose(rng)
+    d[:3, :3] = util.syn.rot_vec(rng.normal(size=3) * 0.3)
+    d[:3, 3] *= 0.05
+    link2.set_joint2parent_pose(np.linalg.inv(b1) @ d)
+    tracker = util.host.Tracker(api, 1, 1)
+    if world > 1 and not all_active:
+        tracker.SetSoftConstraintsActive(rank == 0)
+    assert tracker.CalculateConsistentPoses()
+    for it in range(5):
+        ptr, n = tracker.CalculateOptimizationBegin()
+        if world > 1:
+            dist.all_reduce(torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(n,))))
+        assert tracker.CalculateOptimizationEnd()
+    state = np.stack([link1.link2world_pose(), link2.link2world_pose(), link2.joint2parent_pose()])
+    np.save(os.path.join(out_dir, "soft_%d_%d_%d.npy" % (world, rank, int(all_active))), state)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_soft_constraints_over_two_ranks_count_once(tmp_path):
+    """every rank holds the whole structure, its soft constraints included; their g / H are added before the sums are
+    stacked for the all-reduce, so they stay active on one rank (Tracker.SetSoftConstraintsActive; the HIP library
+    does it by rank when it owns the communicator): replicas identical and equal to the single process, bit for bit
+    (the other rank adds exact zeros).  Left active everywhere they count twice -- the control"""
+    import torch.multiprocessing as mp
+    port = 29900 + os.getpid() % 90
+    mp.spawn(_soft_worker, args=(2, port, str(tmp_path), False), nprocs=2, join=True)
+    mp.spawn(_soft_worker, args=(2, port + 1, str(tmp_path), True), nprocs=2, join=True)
+    _soft_worker(0, 1, port + 2, str(tmp_path), False)
+    ref = np.load(os.path.join(str(tmp_path), "soft_1_0_0.npy"))
+    r0 = np.load(os.path.join(str(tmp_path), "soft_2_0_0.npy"))
+    r1 = np.load(os.path.join(str(tmp_path), "soft_2_1_0.npy"))
+    assert np.array_equal(r0, r1) and np.array_equal(r0, ref)
+    twice = np.load(os.path.join(str(tmp_path), "soft_2_0_1.npy"))
+    assert np.max(np.abs(twice - ref)) > 1e-4
+
+
 def test_bodies_that_share_color_histograms_stay_on_one_rank():
     import importlib
     sh = importlib.import_module("3dobjecttracking_amd.sharding")
