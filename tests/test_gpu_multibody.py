@@ -286,6 +286,62 @@ def test_soft_constraints_count_once_when_the_host_sums_the_buffers():
 
 
 @gpu
+def test_chain_spread_over_two_contexts_equals_one_context():
+    """SURVEY 8e's exchange step on the hardware, minus the transport: the 2-body chain held by two contexts of this
+    GPU (each keeps the whole link tree and ONE body's modality -- what two ranks hold), the stacked [dof*dof | dof]
+    sums of begin() added by the host (what ncclAllReduce does) and handed to both.  links_project_kernel /
+    links_solve_kernel run on partial sums exactly as on two GPUs; replicas identical and equal to one context that
+    owns both modalities, bit for bit (each rank adds exact zeros for the body it does not own), which in turn equals
+    the oracle (test_kinematic_chain_tracking_matches_oracle)"""
+    import torch
+
+    def view(ptr, n):
+        addr = C.cast(ptr, C.c_void_p).value
+
+        class _Buf:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (addr, False), "version": 2}
+        return torch.as_tensor(_Buf(), device="cuda")
+
+    inputs, joint2parent, gt = chain_inputs(3)
+    start_a = syn.perturb_pose(gt[0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
+
+    def run(owners):
+        chains = [Chain(util.open_hip(), inputs, joint2parent, start_a, gt[0][2] + 0.01, owned=o) for o in owners]
+        for ch, o in zip(chains, owners):
+            for i in o:
+                ch.cams[i].UpdateImage(inputs.color[i][0])
+            assert ch.tracker.StartModalities(0)
+        for k in range(len(gt)):
+            for ch, o in zip(chains, owners):
+                for i in o:
+                    ch.cams[i].UpdateImage(inputs.color[i][k])
+            for c in range(7):
+                for ch in chains:
+                    assert ch.tracker.CalculateCorrespondences(k, c)
+                for u in range(2):
+                    bufs = []
+                    for ch in chains:
+                        assert ch.tracker.CalculateGradientAndHessian(k, c, u)
+                        bufs.append(view(*ch.tracker.CalculateOptimizationBegin()))
+                    if len(chains) > 1:
+                        torch.cuda.synchronize()
+                        total = bufs[0] + bufs[1]
+                        for b in bufs:
+                            b.copy_(total)
+                        torch.cuda.synchronize()
+                    for ch in chains:
+                        assert ch.tracker.CalculateOptimizationEnd()
+            for ch in chains:
+                assert ch.tracker.CalculateResults(k)
+        return [np.stack(ch.state()) for ch in chains]
+
+    one = run([[0, 1]])[0]
+    two = run([[0], [1]])
+    assert np.array_equal(two[0], two[1])
+    assert np.array_equal(two[0], one)
+
+
+@gpu
 def test_rigid_context_switches_to_general_path_for_begin_end():
     """begin/end on a rigid-only context == the rigid fast path within one Newton-step tolerance"""
     inputs = scenes.Inputs(2, 2, n_divides=2)
