@@ -256,7 +256,6 @@ _SIGNATURES = {
     "refine_poses": [C.c_int, C.c_int],
     "soft_constraint_create": [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p, C.c_float, C.c_float,
                                C.c_float, C.c_float],
-    "set_soft_constraints_active": [C.c_int],
     "link_get_link2world_pose": [C.c_int, c_float_p],
     "link_set_link2world_pose": [C.c_int, c_float_p],
     "link_set_joint_poses": [C.c_int, c_float_p, c_float_p],

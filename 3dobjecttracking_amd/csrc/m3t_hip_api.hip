@@ -188,11 +188,12 @@ struct m3t_hip_context {
   std::vector<Link> links;
   std::vector<ConstraintH> constraints;
   std::vector<SoftConstraintH> soft_constraints;
-  bool soft_constraints_active = true;
   std::vector<Optimizer> optimizers;
   bool tree_mode = false;          // any kinematic tree / constraint -> links_* kernels
   bool links_device_newer = false;  // joint poses on the device are ahead of the host mirror
   DevMem d_links, d_constraints, d_soft, d_treeopts, d_work, d_partial;
+  DevMem d_link_sums, d_link_first;  // what a structure spread over processes exchanges (links_gather_kernel): [links][42], first link per structure
+  size_t link_sums_count = 0;
   // tracking_step_tree_kernel: one workgroup per link that carries modalities
   DevMem d_treesteps, d_tracked_links, d_tree_exchange;
   int n_treesteps = 0;
@@ -297,7 +298,6 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
@@ -309,7 +309,6 @@ struct Rccl {
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
-    CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(handle, "ncclCommUserRank"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce) { error = "librccl.so.1 lacks the nccl* entry points"; AllReduce = nullptr; return false; }
@@ -764,6 +763,17 @@ int UploadTreeTables(Ctx* ctx) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->tree_lds)));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(links_solve_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->tree_lds)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(links_solve_sums_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->tree_lds)));
+  {
+    std::vector<int> first(std::max<size_t>(1, opts.size()), 0);
+    for (size_t oi = 0; oi < opts.size(); ++oi) first[oi] = int(link_off[oi]);
+    HIPCHK(ctx->d_link_first.alloc(first.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(ctx->d_link_first.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+    ctx->link_sums_count = links.size() * 42;
+    HIPCHK(ctx->d_link_sums.alloc(std::max<size_t>(1, ctx->link_sums_count) * 4));
+    HIPCHK(hipMemset(ctx->d_link_sums.p, 0, ctx->d_link_sums.bytes));
+  }
   HIPCHK(ctx->d_partial.alloc(std::max<size_t>(1, partial_total) * 4));
   HIPCHK(hipMemset(ctx->d_partial.p, 0, ctx->d_partial.bytes));
   ctx->partial_count = partial_total;
@@ -776,7 +786,7 @@ int UploadTreeTables(Ctx* ctx) {
     d.n_constraints = int(o.constraints.size());
     d.constraints = ctx->d_constraints.as<ConstraintDev>() + con_off[oi];
     d.n_rows = o.n_rows;
-    d.n_soft = ctx->soft_constraints_active ? int(o.soft_constraints.size()) : 0;
+    d.n_soft = int(o.soft_constraints.size());
     d.soft = ctx->d_soft.as<SoftConstraintDev>() + soft_off[oi];
     d.tikhonov_rotation = o.tr;
     d.tikhonov_translation = o.tt;
@@ -1466,14 +1476,38 @@ int LaunchSolve(Ctx* ctx, bool zero_theta) {
   return M3T_OK;
 }
 
-// sum of the stacked [dof x dof | dof] buffers of all structures over the ranks of the communicator: ONE
-// ncclAllReduce on the context's stream, in place (optimizer.cpp:309-321 is the sum being distributed)
+// The two halves around the exchange of a structure spread over processes (m3t_links.hip): the link sums of this
+// process's modalities, and everything else of Optimizer::CalculateOptimization from the summed link sums
+int LaunchGather(Ctx* ctx) {
+  int n = int(ctx->optimizers.size());
+  if (n == 0) return M3T_OK;
+  hipLaunchKernelGGL(links_gather_kernel, dim3(n), dim3(64), 0, ctx->stream, ctx->d_treeopts.as<TreeOptDev>(), n,
+                     ctx->d_link_sums.as<float>(), ctx->d_link_first.as<int>());
+  HIPCHK(hipGetLastError());
+  ctx->partial_ready = true;
+  return M3T_OK;
+}
+int LaunchSolveSums(Ctx* ctx) {
+  int n = int(ctx->optimizers.size());
+  if (n == 0) return M3T_OK;
+  hipLaunchKernelGGL(links_solve_sums_kernel, dim3(n), dim3(64), ctx->tree_lds, ctx->stream,
+                     ctx->d_treeopts.as<TreeOptDev>(), n, ctx->d_poses.as<float>(), 0, ctx->tree_lds ? 1 : 0,
+                     ctx->d_link_sums.as<float>(), ctx->d_link_first.as<int>());
+  HIPCHK(hipGetLastError());
+  ctx->links_device_newer = true;
+  ctx->partial_ready = false;
+  return M3T_OK;
+}
+
+// sum of the stacked link sums ([links of all structures][6 + 36]) over the ranks of the communicator: ONE
+// ncclAllReduce on the context's stream, in place.  Exact: every link's modalities live on one rank, the others add
+// +0.0 (m3t_links.hip, links_gather_kernel)
 int AllReducePartial(Ctx* ctx) {
   REQUIRE(ctx->partial_ready, M3T_ERR_NOT_SET_UP, "calculate_optimization_begin has to be called first");
   REQUIRE(ctx->comm != nullptr, M3T_ERR_NOT_SET_UP, "no communicator: m3t_hip_comm_init_rank / m3t_hip_comm_set first");
-  float* buffer = ctx->d_partial.as<float>();
+  float* buffer = ctx->d_link_sums.as<float>();
   const ncclResult_t rc =
-      g_rccl.AllReduce(buffer, buffer, ctx->partial_count, ncclFloat, ncclSum, ctx->comm, ctx->stream);
+      g_rccl.AllReduce(buffer, buffer, ctx->link_sums_count, ncclFloat, ncclSum, ctx->comm, ctx->stream);
   if (rc != ncclSuccess)
     return Fail(ctx, M3T_ERR_DEVICE,
                 std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
@@ -1482,7 +1516,7 @@ int AllReducePartial(Ctx* ctx) {
 }
 
 // Optimizer::CalculateOptimization for every optimizer.  With a communicator set the structures span GPUs
-// (SURVEY 8e): project -> ONE all-reduce of the stacked sums -> solve, on every path that reaches this function
+// (SURVEY 8e): link sums -> ONE all-reduce of them -> project + solve, on every path that reaches this function
 // (m3t_hip_calculate_optimization and the sub-step loop of m3t_hip_execute_tracking_step alike).
 int LaunchOptimization(Ctx* ctx) {
   if (ctx->comm) {
@@ -1492,10 +1526,10 @@ int LaunchOptimization(Ctx* ctx) {
       int r = UploadTreeTables(ctx);
       if (r) return r;
     }
-    int r = LaunchProject(ctx);
+    int r = LaunchGather(ctx);
     if (r) return r;
     if ((r = AllReducePartial(ctx))) return r;
-    return LaunchSolve(ctx, false);
+    return LaunchSolveSums(ctx);
   }
   if (ctx->tree_mode) {
     int r = LaunchProject(ctx);
@@ -3131,14 +3165,6 @@ int m3t_hip_soft_constraint_create(m3t_hip_context* ctx, int optimizer, int link
   ctx->tables_dirty = true;
   return int(ctx->soft_constraints.size()) - 1;
 }
-int m3t_hip_set_soft_constraints_active(m3t_hip_context* ctx, int active) {
-  CHECK_CTX();
-  if (ctx->soft_constraints_active != (active != 0)) {
-    ctx->soft_constraints_active = active != 0;
-    ctx->tables_dirty = true;
-  }
-  return M3T_OK;
-}
 int m3t_hip_link_get_link2world_pose(m3t_hip_context* ctx, int link, float pose[16]) {
   CHECK_CTX();
   REQUIRE(link >= 0 && link < int(ctx->links.size()) && pose, M3T_ERR_INVALID_ARGUMENT, "bad link id");
@@ -3245,11 +3271,12 @@ int m3t_hip_calculate_optimization(m3t_hip_context* ctx, int, int, int) {
   HIPCHK(hipSetDevice(ctx->device));
   int r = Prepare(ctx, false);
   if (r) return r;
-  return LaunchOptimization(ctx);  // (with a communicator: project, ONE all-reduce, solve)
+  return LaunchOptimization(ctx);  // (with a communicator: link sums, ONE all-reduce, project + solve)
 }
 // Optimizer::CalculateOptimization split at the multi-GPU exchange point: *partial is a
-// DEVICE pointer to `count` floats (the stacked [dof*dof | dof] sums of every structure); sum it over the
-// ranks that hold bodies of the structures (one RCCL all-reduce on the context stream), then call _end.
+// DEVICE pointer to `count` floats (the 6 + 36 gradient / Hessian sums of every link of every structure, zero for
+// links whose modalities live in another process); sum it over the ranks that hold bodies of the structures (one
+// RCCL all-reduce on the context stream), then call _end.
 int m3t_hip_calculate_optimization_begin(m3t_hip_context* ctx, float** partial, size_t* count) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));
@@ -3261,17 +3288,17 @@ int m3t_hip_calculate_optimization_begin(m3t_hip_context* ctx, float** partial, 
     r = UploadTreeTables(ctx);
     if (r) return r;
   }
-  r = LaunchProject(ctx);
+  r = LaunchGather(ctx);
   if (r) return r;
-  if (partial) *partial = ctx->d_partial.as<float>();
-  if (count) *count = ctx->partial_count;
+  if (partial) *partial = ctx->d_link_sums.as<float>();
+  if (count) *count = ctx->link_sums_count;
   return M3T_OK;
 }
 int m3t_hip_calculate_optimization_end(m3t_hip_context* ctx) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));
   REQUIRE(ctx->partial_ready, M3T_ERR_NOT_SET_UP, "calculate_optimization_begin has to be called first");
-  return LaunchSolve(ctx, false);
+  return LaunchSolveSums(ctx);
 }
 // ---- RCCL: the one collective of the path (a kinematic structure spread over GPUs) ----
 #define RCCLCHK(expr)                                                                                      \
@@ -3304,12 +3331,8 @@ int m3t_hip_comm_init_rank(m3t_hip_context* ctx, const void* id, size_t bytes, i
   RCCLCHK(g_rccl.CommInitRank(&comm, n_ranks, u, rank));
   ctx->comm = comm;
   ctx->comm_owned = true;
-  // every rank holds the whole structure, soft constraints included, and tree_project adds their g / H to the link
-  // sums BEFORE the all-reduce: they must enter the summed system once, so only rank 0 keeps them (round-3 advisor)
-  if ((rank == 0) != ctx->soft_constraints_active) {
-    ctx->soft_constraints_active = rank == 0;
-    ctx->tables_dirty = true;
-  }
+  // (soft constraints need no care here: every rank adds them AFTER the all-reduce of the link sums, as one process
+  // does -- links_solve_sums_kernel)
   return M3T_OK;
 }
 int m3t_hip_comm_set(m3t_hip_context* ctx, void* nccl_comm) {
@@ -3318,17 +3341,6 @@ int m3t_hip_comm_set(m3t_hip_context* ctx, void* nccl_comm) {
   if (ctx->comm && ctx->comm_owned) RCCLCHK(g_rccl.CommDestroy(ctx->comm));
   ctx->comm = static_cast<ncclComm_t>(nccl_comm);
   ctx->comm_owned = false;
-  if (ctx->comm && g_rccl.CommUserRank) {  // soft constraints on one rank only (see m3t_hip_comm_init_rank)
-    int rank = 0;
-    RCCLCHK(g_rccl.CommUserRank(ctx->comm, &rank));
-    if ((rank == 0) != ctx->soft_constraints_active) {
-      ctx->soft_constraints_active = rank == 0;
-      ctx->tables_dirty = true;
-    }
-  } else if (!ctx->comm && !ctx->soft_constraints_active) {  // back to one process: the whole structure is here again
-    ctx->soft_constraints_active = true;
-    ctx->tables_dirty = true;
-  }
   return M3T_OK;
 }
 int m3t_hip_comm_destroy(m3t_hip_context* ctx) {
@@ -3337,16 +3349,12 @@ int m3t_hip_comm_destroy(m3t_hip_context* ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     RCCLCHK(g_rccl.CommDestroy(ctx->comm));
   }
-  if (ctx->comm && !ctx->soft_constraints_active) {  // (see m3t_hip_comm_set)
-    ctx->soft_constraints_active = true;
-    ctx->tables_dirty = true;
-  }
   ctx->comm = nullptr;
   ctx->comm_owned = false;
   return M3T_OK;
 }
-// sum of the stacked [dof x dof | dof] buffers of all structures over the ranks of the communicator: ONE
-// ncclAllReduce on the context's stream, in place (optimizer.cpp:309-321 is the sum being distributed)
+// sum of the stacked link sums of all structures over the ranks of the communicator: ONE ncclAllReduce on the
+// context's stream, in place (Link::CalculateGradientAndHessian link.cpp:184-193 is the sum being distributed)
 int m3t_hip_calculate_optimization_allreduce(m3t_hip_context* ctx) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));

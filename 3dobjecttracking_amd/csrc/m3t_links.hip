@@ -43,7 +43,7 @@ struct TreeOptDev {
   int n_constraints;
   ConstraintDev* constraints;
   int n_rows;  // sum of constraint rows
-  int n_soft;  // soft constraints (0 while they are switched off for this process)
+  int n_soft;  // soft constraints
   SoftConstraintDev* soft;
   float tikhonov_rotation, tikhonov_translation;
   float* work;     // scratch, layout in tree_work_floats()
@@ -1186,6 +1186,43 @@ links_solve_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int ze
     for (int e = threadIdx.x; e < o.n_links * 6 * o.dof; e += kWave) w.J[e] = o.work[e];
     __syncthreads();
   }
+  (void)tree_solve<0>(o, o.links, w, o.partial, body_poses, zero_theta);
+}
+
+// A structure spread over processes.  What crosses between the ranks is the LINK SUMS themselves --
+// Link::CalculateGradientAndHessian's 6 + 36 floats per link (link.cpp:184-193), stacked over all links of all
+// structures: link_sums[first_link[structure] + link][42] -- and not the projected system: a link's modalities live on
+// one rank, every other rank contributes +0.0 to its 42 numbers, so the all-reduce returns on every rank exactly the
+// floats one process has (x + 0 + ... + 0 = x in any order; the sums are never -0: they start from +0).  Soft
+// constraints, projection, constraint rows, Tikhonov and the solve then run on every rank as they run in one process:
+// the poses are the single-process poses bit for bit for any number of ranks.  (Summing the projected [dof x dof | dof]
+// blocks instead is a reassociation of the sum over the links, and the tracker's discrete decisions amplify it: the
+// 8-body chain on two ranks ends 6e-3 away from one process after ONE frame.)
+__global__ void __launch_bounds__(64)
+links_gather_kernel(const TreeOptDev* opts, int n_opts, float* link_sums, const int* first_link) {
+  const TreeOptDev& o = opts[blockIdx.x];
+  float* out = link_sums + (size_t)first_link[blockIdx.x] * 42;
+  for (int e = threadIdx.x; e < o.n_links * 42; e += kWave) {
+    const int li = e / 42, i = e - li * 42;
+    const LinkDev& l = o.links[li];
+    float sacc = 0.0f;  // (the expression of tree_project)
+    for (int m = 0; m < l.n_gh; ++m) sacc += l.gh[m][i];
+    out[e] = sacc;
+  }
+}
+
+// ... and the rest of Optimizer::CalculateOptimization from the (all-reduced) link sums: links_project_kernel and
+// links_solve_kernel in one launch
+__global__ void __launch_bounds__(64)
+links_solve_sums_kernel(const TreeOptDev* opts, int n_opts, float* body_poses, int zero_theta, int work_in_lds,
+                        const float* link_sums, const int* first_link) {
+  extern __shared__ __attribute__((aligned(16))) float tree_lds[];
+  const TreeOptDev& o = opts[blockIdx.x];
+  const TreeWork w = tree_carve(work_in_lds ? tree_lds : o.work, o.n_links, o.dof, o.n_rows);
+  tree_project<0>(o, o.links, w, link_sums + (size_t)first_link[blockIdx.x] * 42, o.partial,
+                  o.partial + (size_t)o.dof * o.dof, body_poses);
+  __threadfence_block();
+  __syncthreads();  // (o.partial is read back by other lanes)
   (void)tree_solve<0>(o, o.links, w, o.partial, body_poses, zero_theta);
 }
 

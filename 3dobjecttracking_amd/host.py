@@ -56,7 +56,7 @@ class Tracker:
         return self._step("calculate_consistent_poses")
 
     def CalculateOptimizationBegin(self):
-        """first half of CalculateOptimization: this process's stacked [dof*dof | dof] sums.
+        """first half of CalculateOptimization: the link sums of this process's modalities, 6 + 36 floats per link.
         Returns (pointer, count); device pointer for the HIP library, host pointer for the oracle."""
         ptr = _capi.c_float_p()
         n = C.c_size_t()
@@ -65,12 +65,6 @@ class Tracker:
 
     def CalculateOptimizationEnd(self):
         return self._step("calculate_optimization_end")
-
-    def SetSoftConstraintsActive(self, active):
-        """a structure spread over processes whose host sums the begin() buffers itself: the soft constraints'
-        terms enter the summed system once, i.e. they stay active on ONE process (m3t_hip.h; with a communicator set
-        the library does this by rank)"""
-        self.api.call("set_soft_constraints_active", 1 if active else 0)
 
     def ExecuteTrackingStep(self, iteration):
         return self._step("execute_tracking_step", iteration)

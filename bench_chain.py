@@ -1,8 +1,9 @@
 """bench.py --config chain8 (BASELINE configs[4]): one kinematic structure -- a chain of 8 bodies, a free root and seven
 1-dof revolute joints (13 dof) -- tracked by one RegionModality per body; with N GPUs every rank holds the whole link
-tree but only the modalities of its own bodies (body i -> rank i mod N), and each Newton step sums the stacked
-[dof x dof | dof] buffers with ONE ncclAllReduce inside the library (m3t_hip_comm_init_rank: while a communicator is
-set, ExecuteTrackingStep runs project -> all-reduce -> solve by itself).  Also the sweep of
+tree but only the modalities of its own bodies (body i -> rank i mod N), and each Newton step sums the stacked link
+sums (6 + 36 floats per link) with ONE ncclAllReduce inside the library (m3t_hip_comm_init_rank: while a communicator
+is set, ExecuteTrackingStep runs link sums -> all-reduce -> project + solve by itself; the sum is exact, N ranks
+compute the poses of one process bit for bit).  Also the sweep of
 examples/optimization_time.cpp:14-79: Optimizer::CalculateOptimization for chains of 1..50 one-dof links."""
 import ctypes as C
 import os
@@ -210,11 +211,11 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[4]: one kinematic chain of %d bodies (free root + %d revolute joints), one "
                                "RegionModality per body (RBOT parameters, 200 lines x 7 x 2); %s; body i on GPU i mod %d, "
-                               "ONE ncclAllReduce of %d floats per Newton step%s" %
+                               "ONE ncclAllReduce of %d floats (the link sums) per Newton step%s" %
                                (n_bodies, n_bodies - 1,
                                 "one launch per frame, one workgroup per body, the structure solved by every workgroup's "
                                 "first wave" if fused else "one launch per sub-step, link kernels: one wave per structure",
-                                world, (6 + n_bodies - 1) ** 2 + 6 + n_bodies - 1, "" if world > 1 else " when N > 1"),
+                                world, 42 * n_bodies, "" if world > 1 else " when N > 1"),
                    "bodies": n_bodies, "parallelism": "bodies sharded over %d GPU(s)" % world,
                    "rccl_ranks": world if world > 1 else 0,
                    "allreduce_calls_per_step": round(collectives.value / steps_run, 3),

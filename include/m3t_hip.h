@@ -224,17 +224,13 @@ int m3t_hip_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, 
                               const int constraint_directions[6]);
 /* SoftConstraint (include/m3t/soft_constraint.h:52-62; soft_constraint.cpp:113-131,220-272): a joint that only
  * pulls once its rotation / translation error exceeds max_distance_*, weighted with 1/standard_deviation^2;
- * it adds to the g/H of both links before the projection.  A structure spread over several processes
- * (begin -> all-reduce -> end) keeps them active on one rank only: m3t_hip_comm_init_rank / m3t_hip_comm_set switch
- * them off on every rank but 0 (their terms would otherwise enter the summed system once per rank) and
- * m3t_hip_comm_destroy / comm_set(ctx, NULL) switch them on again; a host that all-reduces the partial buffers
- * itself calls set_soft_constraints_active(0) on the other ranks. */
+ * it adds to the g/H of both links before the projection.  In a structure spread over several processes
+ * (begin -> all-reduce -> end) every process adds them after the all-reduce, as one process does. */
 int m3t_hip_soft_constraint_create(m3t_hip_context*, int optimizer_id, int link1_id, int link2_id,
                                    const float body12joint1[16], const float body22joint2[16],
                                    const int constraint_directions[6], float max_distance_rotation,
                                    float max_distance_translation, float standard_deviation_rotation,
                                    float standard_deviation_translation);
-int m3t_hip_set_soft_constraints_active(m3t_hip_context*, int active);
 int m3t_hip_link_get_link2world_pose(m3t_hip_context*, int link_id, float pose[16]);
 /* Link::set_link2world_pose (link.cpp:138-140; what Detector::UpdatePoses writes, detector.cpp:42-53):
  * the body's pose for a link with a body, the link's own frame for a body-less root */
@@ -254,11 +250,17 @@ int m3t_hip_calculate_gradient_and_hessian(m3t_hip_context*, int iteration, int 
 int m3t_hip_calculate_optimization(m3t_hip_context*, int iteration, int corr_iteration,
                                    int opt_iteration);                            /* :481 */
 /* Optimizer::CalculateOptimization split where a kinematic structure spread over several GPUs
- * exchanges data: begin() leaves this process's stacked sums  [J^T H J (dof x dof) | J^T g (dof)]
- * of every structure in ONE contiguous device buffer (*partial, `count` floats); the host sums that
- * buffer over the participating ranks with a single all-reduce (ncclAllReduce / torch.distributed
- * on RCCL, on the stream of m3t_hip_get_stream) and calls end(), which adds constraint rows and the
- * Tikhonov diagonal, solves and updates the poses identically on every rank. */
+ * exchanges data: begin() leaves the link sums of this process's modalities -- gradient (6) and Hessian (36)
+ * of every link of every structure, Link::CalculateGradientAndHessian link.cpp:184-193, zero for links whose
+ * modalities live in another process -- in ONE contiguous device buffer (*partial, `count` = 42 x links floats);
+ * the host sums that buffer over the participating ranks with a single all-reduce (ncclAllReduce /
+ * torch.distributed on RCCL, on the stream of m3t_hip_get_stream) and calls end(), which adds the soft
+ * constraints, projects with the Jacobians (optimizer.cpp:309-321), adds constraint rows and the Tikhonov
+ * diagonal, solves and updates the poses identically on every rank.  Keep all modalities of a link in one process
+ * (3dobjecttracking_amd/sharding.py place_bodies does): every other process then adds +0.0 to that link's 42
+ * numbers, the all-reduce is exact whatever its order, and the poses of N processes are the poses of one process
+ * bit for bit.  (The projected [dof x dof | dof] blocks would be a smaller message for long chains, but their sum
+ * over the ranks is a reassociation of the sum over the links, which the tracker's discrete decisions amplify.) */
 int m3t_hip_calculate_optimization_begin(m3t_hip_context*, float** partial, size_t* count);
 int m3t_hip_calculate_optimization_end(m3t_hip_context*);
 /* The collective itself, inside the library: one ncclAllReduce(sum, float, count) on the context's stream, in place on

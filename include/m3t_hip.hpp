@@ -514,9 +514,6 @@ class Tracker {
   void CommSet(void* nccl_comm) { c_->Check(m3t_hip_comm_set(c_->get(), nccl_comm), "Tracker"); }
   void CommDestroy() { c_->Check(m3t_hip_comm_destroy(c_->get()), "Tracker"); }
   bool CalculateOptimizationAllReduce() { return c_->Step(m3t_hip_calculate_optimization_allreduce(c_->get())); }
-  void SetSoftConstraintsActive(bool active) {
-    c_->Check(m3t_hip_set_soft_constraints_active(c_->get(), active ? 1 : 0), "Tracker");
-  }
   void* stream() const {
     void* s = nullptr;
     c_->Check(m3t_hip_get_stream(c_->get(), &s), "Tracker");

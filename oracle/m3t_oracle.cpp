@@ -735,7 +735,7 @@ struct Optimizer {
   int degrees_of_freedom = 0;
   std::vector<float> tikhonov_vector;
   std::vector<int> constraints, soft_constraints;
-  std::vector<float> partial;  // [dof*dof | dof] of the last Begin
+  std::vector<float> partial;  // the link sums of the last Begin: [links, parents first][6 + 36]
 };
 
 struct Context {
@@ -751,9 +751,8 @@ struct Context {
   std::vector<Link> links;
   std::vector<Constraint> constraints;
   std::vector<SoftConstraint> soft_constraints;
-  bool soft_constraints_active = true;  // a structure spread over processes adds them on one rank only
   std::vector<Optimizer> optimizers;
-  std::vector<float> partial_all;  // concatenated partial sums of all optimizers
+  std::vector<float> partial_all;  // concatenated link sums of all optimizers
   int n_corr_iterations = 5, n_update_iterations = 2;  // tracker.h:231-232
 
   const Mat4& LinkPose(const Link& l) const {  // Link::link2world_pose() link.cpp:296-301
@@ -2110,31 +2109,47 @@ void AddProjected(Context* ctx, int link_id, int dof, int size, std::vector<floa
   for (int c : l.children) AddProjected(ctx, c, dof, size, b, a);
 }
 
+void PackLinkSums(Context* ctx, int link_id, std::vector<float>* out) {  // parents first, as the links are visited
+  const Link& l = ctx->links[link_id];
+  out->insert(out->end(), l.gradient, l.gradient + 6);
+  out->insert(out->end(), l.hessian, l.hessian + 36);
+  for (int c : l.children) PackLinkSums(ctx, c, out);
+}
+void UnpackLinkSums(Context* ctx, int link_id, const float** in) {
+  Link& l = ctx->links[link_id];
+  std::copy(*in, *in + 6, l.gradient);
+  std::copy(*in + 6, *in + 42, l.hessian);
+  *in += 42;
+  for (int c : l.children) UnpackLinkSums(ctx, c, in);
+}
+
 // Optimizer::CalculateOptimization src/optimizer.cpp:144-167, split at the point where a
-// kinematic structure spread over several GPUs exchanges data: Begin computes
-// this process's projected sums  A_p = sum J^T H J (dof x dof, lower), b_p = sum J^T g;
-// End adds the constraint rows and the Tikhonov diagonal, solves and updates the poses.
+// kinematic structure spread over several processes exchanges data.  Begin computes the
+// Jacobians and the link sums of this process's modalities (Link::CalculateGradientAndHessian
+// link.cpp:184-193: 6 + 36 floats per link, zero for links whose modalities live elsewhere) -- THAT
+// is what the processes add up: a link's modalities live in one process, the others add +0.0, so the
+// sum is exact in any order and N processes compute what one computes, bit for bit.  End adds the soft
+// constraints to the link sums, projects (AddProjected), adds the constraint rows and the Tikhonov
+// diagonal, solves and updates the poses.
 // Single process: Begin + End == the reference function, operation for operation.
 void OptimizerBegin(Context* ctx, Optimizer& o) {
-  int dof = o.degrees_of_freedom;
-  o.partial.assign(size_t(dof) * dof + dof, 0.0f);
-  std::vector<float> b(dof, 0.0f), a(size_t(dof) * dof, 0.0f);
   CalculateDataLinks(ctx, o.root_link);
-  if (ctx->soft_constraints_active)  // Optimizer::CalculateDataLinks optimizer.cpp:281-286
-    for (int sid : o.soft_constraints) SoftConstraintAdd(ctx, ctx->soft_constraints[sid]);
-  AddProjected(ctx, o.root_link, dof, dof, &b, &a);
-  std::copy(a.begin(), a.end(), o.partial.begin());
-  std::copy(b.begin(), b.end(), o.partial.begin() + size_t(dof) * dof);
+  o.partial.clear();
+  PackLinkSums(ctx, o.root_link, &o.partial);
 }
 bool OptimizerEnd(Context* ctx, Optimizer& o) {
   int dof = o.degrees_of_freedom;
+  {
+    const float* in = o.partial.data();
+    UnpackLinkSums(ctx, o.root_link, &in);
+  }
+  // Optimizer::CalculateDataLinks optimizer.cpp:281-286
+  for (int sid : o.soft_constraints) SoftConstraintAdd(ctx, ctx->soft_constraints[sid]);
   int n_constraints = 0;
   for (int cid : o.constraints) n_constraints += ctx->constraints[cid].NumberOfConstraints();
   int size = dof + n_constraints;
   std::vector<float> b(size, 0.0f), a(size_t(size) * size, 0.0f);
-  for (int c = 0; c < dof; ++c)
-    for (int r = 0; r < dof; ++r) a[size_t(c) * size + r] = o.partial[size_t(c) * dof + r];
-  for (int i = 0; i < dof; ++i) b[i] = o.partial[size_t(dof) * dof + i];
+  AddProjected(ctx, o.root_link, dof, size, &b, &a);
   for (int cid : o.constraints) ConstraintCalculate(ctx, ctx->constraints[cid], dof);
   int idx = dof;  // AddResidualsAndConstraintJacobians :323-333
   for (int cid : o.constraints) {
@@ -2667,11 +2682,6 @@ int m3t_oracle_soft_constraint_create(m3t_oracle_context* ctx, int optimizer, in
   CTX->soft_constraints.push_back(sc);
   CTX->optimizers[optimizer].soft_constraints.push_back(int(CTX->soft_constraints.size()) - 1);
   return int(CTX->soft_constraints.size()) - 1;
-}
-int m3t_oracle_set_soft_constraints_active(m3t_oracle_context* ctx, int active) {
-  CHECK_CTX();
-  CTX->soft_constraints_active = active != 0;
-  return M3T_OK;
 }
 int m3t_oracle_link_get_link2world_pose(m3t_oracle_context* ctx, int link, float pose[16]) {
   CHECK_CTX();

@@ -126,7 +126,6 @@ int m3t_oracle_soft_constraint_create(m3t_oracle_context*, int optimizer_id, int
                                       const int constraint_directions[6], float max_distance_rotation,
                                       float max_distance_translation, float standard_deviation_rotation,
                                       float standard_deviation_translation);
-int m3t_oracle_set_soft_constraints_active(m3t_oracle_context*, int active);
 int m3t_oracle_link_get_link2world_pose(m3t_oracle_context*, int link_id, float pose[16]);
 /* Link::set_link2world_pose (link.cpp:138-140; what Detector::UpdatePoses writes, detector.cpp:42-53):
  * the body's pose for a link with a body, the link's own frame for a body-less root */

@@ -72,7 +72,7 @@ def test_begin_end_equals_single_call():
         for it in range(3):
             if split:
                 ptr, n = tracker.CalculateOptimizationBegin()
-                assert n == 12 * 12 + 12
+                assert n == 2 * 42  # the link sums of both links
                 assert tracker.CalculateOptimizationEnd()
             else:
                 assert tracker.CalculateOptimization(0, 0, 0)
