@@ -157,6 +157,14 @@ def rank_plan(config, rank, world, objects=0, models=0):
             "model_of": [(i % n_streams) % n_models for i in range(n_obj)] if n_obj else []}
 
 
+def flush_stdio():
+    sys.stdout.flush()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -190,11 +198,16 @@ def main():
         out = bench_chain.run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_traffic)
     else:
         out = run_objects(args, pkg, pkg.batch, rank, local_rank, world, dist, torch)
-    if rank == 0:
-        print(json.dumps(out))
+    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio when a communicator is
+    # made, which a redirected stdout holds back until the process ends -- behind the line.  Push it out first (every
+    # rank, before the last barrier), take the process group down, then print.
+    flush_stdio()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    flush_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):

@@ -171,6 +171,45 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
         cpu = {"value": round(n_bodies * (W + K) / spent, 1), "unit": "pose-updates/s", "cores": 1, "kind": "port",
                "sample": "%d tracking steps of the same %d-body chain, oracle/libm3t_oracle.so, 1 thread" % (W + K, n_bodies)}
     gt_err = [syn.pose_errors(first_poses[i], gt[W + K][0][i]) for i in range(n_bodies)]
+    # ---- the path a rank runs when the structure spans GPUs, at world size 1: per Newton step link sums -> the
+    # library's ncclAllReduce -> project + solve, one launch per sub-step (what N > 1 costs per rank before the
+    # transport's latency is added); the poses must be the fused launch's
+    distributed = None
+    if world == 1:
+        try:
+            ctx2 = pkg.open_context(local_rank)
+            ch2 = Chain(ctx2, host, syn, inputs, joints, start_root, start_angles, range(n_bodies))
+            buf = C.create_string_buffer(128)
+            ctx2.call("comm_get_unique_id", buf, 128)
+            ctx2.call("comm_init_rank", buf, 128, 1, 0)
+            for cam in ch2.cams:
+                ctx2.call("camera_set_ring", cam.id, n_frames)
+                for k in range(n_frames):
+                    f = inputs.color[ch2.cams.index(cam)][k]
+                    ctx2.call("camera_upload_slot", cam.id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+            ctx2.call("cameras_select_slot", 0)
+            ctx2.call("start_modalities", 0)
+
+            def steps2(first, count):
+                for k in range(first, first + count):
+                    ctx2.call("cameras_select_slot", k)
+                    ctx2.call("execute_tracking_step", k)
+            steps2(1, W)
+            ctx2.call("sync")
+            t = time.perf_counter()
+            steps2(1 + W, K)
+            ctx2.call("sync")
+            dt = time.perf_counter() - t
+            calls = C.c_longlong(0)
+            ctx2.call("comm_get_allreduce_count", C.byref(calls))
+            distributed = {"ms_per_step": round(dt / K * 1e3, 4), "allreduce_calls_per_step": round(calls.value / (W + K), 2),
+                           "floats_per_allreduce": 42 * n_bodies,
+                           "bit_identical_to_the_one_launch_step": bool(np.array_equal(ch2.poses(), first_poses)),
+                           "note": "library communicator at world size 1: links_gather_kernel -> ncclAllReduce -> "
+                                   "links_solve_sums_kernel per Newton step, sub-step launches around them"}
+            ctx2.call("comm_destroy")
+        except Exception as e:  # (no RCCL on the box: the leg is reported as missing, the bench line stands)
+            distributed = {"error": str(e)[:200]}
     # ---- examples/optimization_time.cpp: CalculateOptimization for chains of 1..50 one-dof links ----
     sweep = []
     n_structures = 256
@@ -236,4 +275,5 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
         "repeats": {"n": len(times), "ms_per_step_min": round(min(times) / K * 1e3, 4),
                     "ms_per_step_median": round(elapsed / K * 1e3, 4)},
         "optimization_time_sweep": sweep,
+        "distributed_path_world1": distributed,
     }
