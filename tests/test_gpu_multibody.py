@@ -514,7 +514,11 @@ def test_closed_chain_with_a_hard_constraint_matches_the_oracle():
             inputs.color[i].append(inputs.scenes[i].render(poses[i]))
     start_a = syn.perturb_pose(gt[0][0], np.random.default_rng(5), rot_deg=0.5, trans=0.001)
     states = {}
-    for name, api in (("hip", util.open_hip()), ("oracle", util.open_oracle())):
+    for name, api in (("hip", util.open_hip()), ("hip_comm", util.open_hip()), ("oracle", util.open_oracle())):
+        if name == "hip_comm":  # the multi-GPU form of the step at world size 1: link sums -> ncclAllReduce ->
+            uid = C.create_string_buffer(128)  # links_solve_sums_kernel (constraint rows included)
+            api.call("comm_get_unique_id", uid, 128)
+            api.call("comm_init_rank", uid, 128, 1, 0)
         rp = dict(syn.RBOT_REGION_PARAMS, measure_occlusions=0)
         models = [host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
                   for m in inputs.region_models]
@@ -548,6 +552,11 @@ def test_closed_chain_with_a_hard_constraint_matches_the_oracle():
         a, b, c = [x.astype(np.float64) for x in out[-1][:3]]
         gap = (a @ np.linalg.inv(a2joint))[:3, 3] - (c @ np.linalg.inv(c2joint))[:3, 3]
         assert np.max(np.abs(gap)) < 1e-4
+        if name == "hip_comm":
+            api.call("comm_destroy")
     for sh, so in zip(states["hip"], states["oracle"]):
         for x, y in zip(sh, so):
             assert np.max(np.abs(x - y)) < 2e-5
+    for sh, sc in zip(states["hip"], states["hip_comm"]):  # same device arithmetic on both paths: no tolerance
+        for x, y in zip(sh, sc):
+            assert np.array_equal(x, y)
