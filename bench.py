@@ -109,6 +109,13 @@ def open_oracle(native=False):
     return pkg.CApi(path, "m3t_oracle_")
 
 
+def share_one_gpu():
+    """Developer switch M3T_BENCH_SHARE_ONE_GPU=1: a DRY RUN of the N-rank code path on a box with one GPU -- every
+    rank uses device 0, the process group runs on gloo, one workgroup per object (co-resident split launches of two
+    processes on one GPU could wait for each other).  The line says so (`dry_run`) and its value measures nothing."""
+    return os.environ.get("M3T_BENCH_SHARE_ONE_GPU") == "1"
+
+
 def visible_gpus():
     import torch
     return torch.cuda.device_count() if torch.cuda.is_available() else 0
@@ -127,6 +134,8 @@ def launch_ranks(n_gpus, argv, n_visible=None):
     than N devices are visible -- a run that asked for N GPUs never reports a smaller n_gpus.  Returns the launcher's
     command line (the caller execs it)."""
     n_visible = visible_gpus() if n_visible is None else n_visible
+    if share_one_gpu() and n_visible >= 1:
+        n_visible = n_gpus
     if n_visible < n_gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node; refusing to run fewer ranks than "
                          "asked for" % (n_gpus, n_visible))
@@ -177,13 +186,21 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dry_run = share_one_gpu() and world > 1
+    if dry_run:
+        if args.config == "chain8":
+            raise SystemExit("bench.py: the one-GPU dry run covers the sharded configurations (RCCL refuses two ranks on one device)")
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry_run:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         # N ranks build their inputs (rendering, model sampling: numpy) side by side on one host: every rank keeps to
         # its share of the usable cores instead of N thread pools of full width fighting over the container's quota
         try:
@@ -197,7 +214,10 @@ def main():
         import bench_chain
         out = bench_chain.run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_traffic)
     else:
-        out = run_objects(args, pkg, pkg.batch, rank, local_rank, world, dist, torch)
+        out = run_objects(args, pkg, pkg.batch, rank, local_rank, world, dist, torch, dry_run)
+        if out is not None and dry_run:
+            out["dry_run"] = "M3T_BENCH_SHARE_ONE_GPU=1: %d ranks on ONE GPU over gloo, one workgroup per object -- the N-rank code path, not a measurement" % world
+            out["metric"] = "[DRY RUN, not a measurement] " + out["metric"]
     # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio when a communicator is
     # made, which a redirected stdout holds back until the process ends -- behind the line.  Push it out first (every
     # rank, before the last barrier), take the process group down, then print.
@@ -210,10 +230,12 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch):
+def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch, dry_run=False):
     cfg = CONFIGS[args.config]
     syn = pkg.synthetic
     hip = pkg.open_context(local_rank)
+    if dry_run:
+        hip.call("set_object_split", 0)
     K, W = args.steps, args.warmup
     n_frames = K + W + 1
     use_depth = cfg["with_depth"]

@@ -33,6 +33,17 @@ def test_launcher_command_line():
         bench.launch_ranks(8, [], n_visible=4)
 
 
+def test_dry_run_switch_lets_n_ranks_share_one_gpu(monkeypatch):
+    monkeypatch.setenv("M3T_BENCH_SHARE_ONE_GPU", "1")
+    cmd = bench.launch_ranks(2, ["--gpus", "2"], n_visible=1)
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    with pytest.raises(SystemExit):
+        bench.launch_ranks(2, ["--gpus", "2"], n_visible=0)  # (still needs a GPU)
+    monkeypatch.delenv("M3T_BENCH_SHARE_ONE_GPU")
+    with pytest.raises(SystemExit):
+        bench.launch_ranks(2, ["--gpus", "2"], n_visible=1)
+
+
 def test_world_size_must_match_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "4"],

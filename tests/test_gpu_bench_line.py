@@ -26,3 +26,23 @@ def test_chain_bench_line_is_the_last_line_of_stdout():
     assert line["parity"]["bit_identical"] is True
     d = line["distributed_path_world1"]
     assert d["bit_identical_to_the_one_launch_step"] is True and d["allreduce_calls_per_step"] == 14.0
+
+
+def test_two_rank_code_path_dry_run_on_one_gpu():
+    """`bench.py --gpus 2` end to end on a one-GPU box (M3T_BENCH_SHARE_ONE_GPU=1: both ranks on device 0, gloo
+    instead of RCCL, one workgroup per object): launcher, sharding, barriers, max over ranks, rank 0's parity check and
+    its JSON line -- everything of the N-rank path but the transport.  The line carries the dry-run mark."""
+    env = dict(os.environ, M3T_BENCH_SHARE_ONE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--objects", "8",
+                          "--steps", "3", "--warmup", "1", "--repeats", "2", "--cpu-seconds", "0.5", "--n-divides", "2"],
+                         capture_output=True, text=True, timeout=900, cwd=util.ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "dry_run" in line and line["metric"].startswith("[DRY RUN")
+    assert line["scaling"] == "weak" and line["config"]["objects_per_gpu"] == 8 and line["config"]["ranks"] == 2
+    assert line["parity"]["bit_identical"] is True
+    assert line["roofline"]["workgroups_per_object"] == 1
+    # weak scaling: value = the objects of both ranks over the slower rank's time
+    assert abs(line["value"] - 2 * 8 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 0.01
