@@ -224,6 +224,8 @@ struct m3t_hip_context {
   bool split_possible = false;
   bool split_enabled = true;  // m3t_hip_set_object_split
   std::map<std::tuple<const void*, int, size_t>, int> occupancy_cache;  // ResidentBlocks
+  int ingest_cus = 0;   // m3t_hip_reserve_ingest_cus: CUs kept free of the tracking kernels for the ROI pull kernel
+  int compute_cus = 0;  // what the tracking launches may count on (set with the device properties)
   size_t tree_lds_attribute = 0;  // dynamic LDS limit last set on tracking_step_tree_kernel
   DevMem d_split;            // [objects][2 slots][parts][32 fields][256 / parts] granules, then one abort word per object
   size_t split_objects = 0;  // capacity of d_split
@@ -1576,7 +1578,7 @@ bool TreeStepFused(Ctx* ctx) {
   }
   int resident = ResidentBlocks(ctx, tracking_step_tree_kernel, M3T_BLOCK_THREADS, lds);
   resident = std::min(resident, int(size_t(160) * 1024 / lds));
-  return resident >= 1 && ctx->n_treesteps <= ctx->prop.multiProcessorCount * resident;
+  return resident >= 1 && ctx->n_treesteps <= ctx->compute_cus * resident;
 }
 
 int Prepare(Ctx* ctx, bool need_images) {
@@ -1595,6 +1597,26 @@ RegionMod* GetRegion(Ctx* ctx, int id) {
 DepthMod* GetDepth(Ctx* ctx, int id) {
   if (id < 0 || id >= int(ctx->modalities.size()) || ctx->modalities[id].region) return nullptr;
   return ctx->depth_mods[ctx->modalities[id].index].get();
+}
+
+// The context's streams.  With CUs reserved for ingest (m3t_hip_reserve_ingest_cus) the compute stream runs on the
+// CUs of mask bits [0, CUs - n) and copy stream 0 -- the one the ROI pull kernel is launched on -- on bits
+// [CUs - n, CUs).  Bit i of a mask belongs to XCD i mod 8 (amdkfd deals the bits round-robin; tools/ubench_cumask.hip
+// counts 30 / 2 CUs per XCD for 240 / 16 bits), inside an XCD the highest bits are the last CU of each shader engine.
+hipError_t CreateMaskedStream(Ctx* ctx, hipStream_t* stream, bool ingest_side) {
+  if (ctx->ingest_cus <= 0) return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+  const int cus = ctx->prop.multiProcessorCount, split = cus - ctx->ingest_cus;
+  std::vector<uint32_t> mask(size_t(cus + 31) / 32, 0u);
+  for (int i = ingest_side ? split : 0; i < (ingest_side ? cus : split); ++i) mask[size_t(i) / 32] |= 1u << (i % 32);
+  return hipExtStreamCreateWithCUMask(stream, uint32_t(mask.size()), mask.data());
+}
+hipError_t CreateCopyStreams(Ctx* ctx) {
+  for (int i = 0; i < Ctx::kCopyStreams; ++i) {
+    const hipError_t e = i == 0 ? CreateMaskedStream(ctx, &ctx->copy_stream[i], true)
+                                : hipStreamCreateWithFlags(&ctx->copy_stream[i], hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace
@@ -1624,6 +1646,7 @@ int m3t_hip_create(m3t_hip_context** out, int device_id) {
     g_create_error = std::string("device initialisation failed: ") + hipGetErrorString(e);
     return M3T_ERR_DEVICE;
   }
+  ctx->compute_cus = ctx->prop.multiProcessorCount;
   *out = ctx.release();
   return M3T_OK;
 }
@@ -1835,7 +1858,7 @@ int m3t_hip_camera_upload_slot_async(m3t_hip_context* ctx, int id, int slot, con
   REQUIRE(row_step >= row, M3T_ERR_INVALID_ARGUMENT, "row_step smaller than one image row");
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->async_ingest) {
-    for (auto& cs : ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    HIPCHK(CreateCopyStreams(ctx));
     for (auto& e : ctx->copies_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ctx->step_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->async_ingest = true;
@@ -1948,7 +1971,7 @@ int m3t_hip_cameras_upload_batch_async(m3t_hip_context* ctx, const int* ids, int
   }
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->async_ingest) {
-    for (auto& cs : ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    HIPCHK(CreateCopyStreams(ctx));
     for (auto& e : ctx->copies_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ctx->step_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->async_ingest = true;
@@ -1988,6 +2011,44 @@ int m3t_hip_set_roi_ingest(m3t_hip_context* ctx, int enable, float margin_px) {
   if ((enable != 0) != ctx->roi_enabled) ctx->tables_dirty = true;
   ctx->roi_enabled = enable != 0;
   ctx->roi_margin_px = margin_px;
+  return M3T_OK;
+}
+// Keep n_cus CUs free of the tracking kernels and run the ROI pull kernel there (CU masks on the context's streams).
+// Why: the pull kernel's PCIe reads (~2 us each) sit in the memory pipelines of the CUs it runs on; a tracking
+// workgroup that shares its CU takes 3-4 x longer, and since an object's workgroups wait for each other so does the
+// step.  On CUs of its own the pull costs the step ~14 % (tools/ubench_cumask.hip) and frame k + 1 crosses PCIe while
+// step k runs.  n_cus should take the same number of CUs from every shader engine -- on MI355X a multiple of 32
+// (8 XCDs x 4 shader engines): 16 leaves the engines unequal and a one-workgroup-per-CU launch 1.5 x slower, 64 gives
+// the pull more lanes than PCIe can feed and costs the step more.  0 = off.  The call synchronises and REPLACES the
+// context's streams: fetch m3t_hip_get_stream again afterwards.
+int m3t_hip_reserve_ingest_cus(m3t_hip_context* ctx, int n_cus) {
+  CHECK_CTX();
+  REQUIRE(n_cus >= 0 && n_cus <= ctx->prop.multiProcessorCount / 2, M3T_ERR_INVALID_ARGUMENT,
+          "n_cus must lie in [0, CUs / 2]");
+  if (n_cus == ctx->ingest_cus) return M3T_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& cs : ctx->copy_stream)
+    if (cs) HIPCHK(hipStreamSynchronize(cs));
+  const int before = ctx->ingest_cus;
+  ctx->ingest_cus = n_cus;
+  hipStream_t compute = nullptr;
+  if (CreateMaskedStream(ctx, &compute, false) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->ingest_cus = before;
+    return Fail(ctx, M3T_ERR_UNSUPPORTED, "this device / runtime does not create CU-masked streams");
+  }
+  HIPCHK(hipStreamDestroy(ctx->stream));
+  ctx->stream = compute;
+  if (ctx->async_ingest) {
+    for (auto& cs : ctx->copy_stream) {
+      if (cs) HIPCHK(hipStreamDestroy(cs));
+      cs = nullptr;
+    }
+    HIPCHK(CreateCopyStreams(ctx));
+  }
+  ctx->compute_cus = ctx->prop.multiProcessorCount - n_cus;
+  ctx->copies_pending = 0;
   return M3T_OK;
 }
 // m3t_hip_cameras_upload_batch_async for the trackers' rectangles only: ONE kernel on the copy stream computes every
@@ -3401,13 +3462,13 @@ int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_his
     // 256-thread workgroups (developer override): two are resident per CU if their LDS fits twice
     const int per_cu = (threads == M3T_SPLIT_LANES && lds_split_for(p) * 2 <= size_t(160) * 1024) ? 2 : 1;
     const int padded = (n + 7) / 8 * 8;  // grid blocks / p: every XCD gets the blocks of the fullest one
-    if (p > limit || padded * p > ctx->prop.multiProcessorCount * per_cu) continue;
+    if (p > limit || padded * p > ctx->compute_cus * per_cu) continue;
     if ((elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;  // a part's elements fit its share of the lanes
     // the exchange needs every workgroup of the grid resident at once: ask the runtime how many of these
     // workgroups (registers, LDS) a CU takes, instead of assuming the LDS arithmetic above is the only limit
     int resident = ResidentBlocks(ctx, kernel, threads, lds_split_for(p));
     if (resident > per_cu) resident = per_cu;  // (the query is known to over-report by one block for SGPR-heavy kernels)
-    if (resident < 1 || padded * p > ctx->prop.multiProcessorCount * resident) continue;
+    if (resident < 1 || padded * p > ctx->compute_cus * resident) continue;
     *lds_out = lds_split_for(p);
     return p;
   }
@@ -3483,7 +3544,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // spilled (measured, pose-updates/s: 512 objects 1.11 M vs 0.87 M with 512 threads, 4096: 1.24 M vs 0.91 M;
     // 128-VGPR variants of the 512-thread kernel reached 1.03 M / 1.11 M)
     int threads = M3T_BLOCK_THREADS;
-    if (n >= 2 * ctx->prop.multiProcessorCount && ctx->lds_track * 2 <= 160 * 1024) threads = M3T_BLOCK_THREADS / 2;
+    if (n >= 2 * ctx->compute_cus && ctx->lds_track * 2 <= 160 * 1024) threads = M3T_BLOCK_THREADS / 2;
     if (const char* e = std::getenv("M3T_HIP_THREADS")) threads = std::atoi(e);  // developer override
     auto kernel = ctx->layout.off_hist >= 0 ? tracking_step_lds_kernel : tracking_step_kernel;
     // One workgroup per CU: the histogram update (CalculateResults) runs at the end of the same launch, its
@@ -3504,7 +3565,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // More objects than CUs: the compact kernel (<= 47 KB of LDS, <= 128 VGPRs per object: 3-4 workgroups per CU;
     // measured crossover on 256 CUs: 256 objects 0.249 vs 0.225 ms with one 512-thread workgroup per CU, 384 objects
     // 0.309 vs 0.426 ms).  M3T_HIP_COMPACT=0 / 1: developer override (never / whenever possible).
-    bool compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && n > ctx->prop.multiProcessorCount;
+    bool compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && n > ctx->compute_cus;
     if (const char* e = std::getenv("M3T_HIP_COMPACT")) compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && std::atoi(e) != 0;
     if (std::getenv("M3T_HIP_THREADS")) compact = false;
     ctx->last_step_kernel = split ? "tracking_step_split_kernel"

@@ -59,7 +59,9 @@ roi_rect_kernel(const RoiItemDev* items, const int* item_first, const int* cam_i
 
 // grid: (ceil(height / 8), cameras of the batch).  src / dst: camera blockIdx.y of the batch at + blockIdx.y * stride
 // (one host block, one slab).  At most 32 VGPRs: a wave of this kernel fits next to the two 240-VGPR waves per SIMD of
-// tracking_step_split_kernel, so the rectangles of frame k + 1 cross PCIe WHILE step k runs on all CUs.
+// tracking_step_split_kernel, so the rectangles of frame k + 1 CAN cross PCIe while step k runs on all CUs -- measured
+// (profiles/r04_roi_trace.txt): the step kernel then runs 2.3-3 x longer (the CUs' memory pipelines hold the ~2 us PCIe
+// reads), and the loop takes what step + pull take one after the other.
 __global__ void __launch_bounds__(256)
 roi_pull_kernel(const int* cam_ids, const m3t_roi_rect* rects /* of this slot, by camera id */, const uint8_t* src0,
                 size_t src_camera_stride, uint32_t src_row_step, uint8_t* dst0, size_t dst_camera_stride,

@@ -583,17 +583,39 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
             hip.call("bodies_get_poses", out, n_obj)
             return dt, np.array(out)
 
-        dt_full, poses_full = timed(False)
-        dt_roi, poses_roi = timed(True)
+        def median_of(roi_on, n=5):
+            runs = [timed(roi_on) for _ in range(n)]
+            assert all(np.array_equal(r[1], runs[0][1]) for r in runs)
+            return float(np.median([r[0] for r in runs])), runs[0][1]
+
+        dt_full, poses_full = median_of(False)
+        dt_roi, poses_roi = median_of(True)
         bodies = (C.c_int * 64)()
         n_miss, pulls = C.c_int(0), C.c_longlong(0)
         hip.call("roi_get_status", bodies, 64, C.byref(n_miss), C.byref(pulls))
-        hip.call("set_roi_ingest", 0, C.c_float(0.0))
         roi = {"pose_updates_per_s": round(n_obj * n_up / dt_roi, 1), "ms_per_step": round(dt_roi / n_up * 1e3, 3),
                "whole_frames_same_loop_ms_per_step": round(dt_full / n_up * 1e3, 3),
                "rectangle_uploads": int(pulls.value), "bodies_outside_their_rectangle": int(n_miss.value),
                "bit_identical_to_whole_frames": bool(np.array_equal(poses_roi, poses_full)), "margin_px": margin,
+               "timed": "median of 5 runs of %d steps" % n_up,
                "note": "m3t_hip_cameras_upload_batch_roi_async: one pull kernel per batch-frame over the mapped slab"}
+        # ... and with CUs of its own for the pull kernel (m3t_hip_reserve_ingest_cus: CU-masked streams): frame k + 1
+        # crosses PCIe WHILE step k runs on the other CUs
+        if "reserve_ingest_cus" in hip._fn:
+            roi["reserved_cus"] = []
+            for n_cus in [int(x) for x in os.environ.get("M3T_BENCH_RESERVE_CUS", "32").split(",")]:  # (developer: other counts)
+                hip.call("reserve_ingest_cus", n_cus)
+                dt_res, poses_res = median_of(True)
+                shape = (C.c_int * 4)()
+                hip.call("get_step_shape", shape)
+                hip.call("roi_get_status", bodies, 64, C.byref(n_miss), C.byref(pulls))
+                roi["reserved_cus"].append(
+                    {"cus_for_the_pull": n_cus, "pose_updates_per_s": round(n_obj * n_up / dt_res, 1),
+                     "ms_per_step": round(dt_res / n_up * 1e3, 3), "workgroups_per_object": int(shape[1]),
+                     "bodies_outside_their_rectangle": int(n_miss.value),
+                     "bit_identical_to_whole_frames": bool(np.array_equal(poses_res, poses_full))})
+            hip.call("reserve_ingest_cus", 0)
+        hip.call("set_roi_ingest", 0, C.c_float(0.0))
     for b in blocks:
         inst.tracker.unregister_host_buffer(b)
     el = el_full

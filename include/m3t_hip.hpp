@@ -484,6 +484,8 @@ class Tracker {
   void SetRoiIngest(bool enable, float margin_px) {
     c_->Check(m3t_hip_set_roi_ingest(c_->get(), enable ? 1 : 0, margin_px), "Tracker");
   }
+  // ... pulled by a kernel on CUs of its own while the step runs on the others (replaces the streams: stream() again)
+  void ReserveIngestCus(int n_cus) { c_->Check(m3t_hip_reserve_ingest_cus(c_->get(), n_cus), "Tracker"); }
   bool UploadBatchRoiAsync(const std::vector<int>& camera_ids, int slot, const void* base, size_t camera_stride,
                            size_t row_step) {
     return c_->Step(m3t_hip_cameras_upload_batch_roi_async(c_->get(), camera_ids.data(), int(camera_ids.size()), slot,
