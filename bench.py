@@ -603,7 +603,7 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
         # crosses PCIe WHILE step k runs on the other CUs
         if "reserve_ingest_cus" in hip._fn:
             roi["reserved_cus"] = []
-            for n_cus in [int(x) for x in os.environ.get("M3T_BENCH_RESERVE_CUS", "32").split(",")]:  # (developer: other counts)
+            for n_cus in [int(x) for x in os.environ.get("M3T_BENCH_RESERVE_CUS", "32,64").split(",")]:  # (developer: other counts)
                 hip.call("reserve_ingest_cus", n_cus)
                 dt_res, poses_res = median_of(True)
                 shape = (C.c_int * 4)()

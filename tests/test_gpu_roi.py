@@ -21,9 +21,11 @@ def status(hip):
     return n.value, list(bodies[:min(n.value, 64)]), pulls.value
 
 
-def run(inputs, mode, margin=24.0, n_frames=None, with_depth=False):
+def run(inputs, mode, margin=24.0, n_frames=None, with_depth=False, reserve_cus=0):
     n_frames = n_frames or inputs.n_frames
     hip = util.open_hip()
+    if reserve_cus:
+        hip.call("reserve_ingest_cus", reserve_cus)
     inst = scenes.Instance(hip, inputs, use_depth=with_depth)
     if mode != "blocking":
         hip.call("set_roi_ingest", 1, C.c_float(margin))
@@ -104,3 +106,47 @@ def test_a_body_that_outruns_its_rectangle_is_reported():
     assert pulls > 0 and misses >= 1
     # body ids are creation order: object 1 is body 1
     assert set(bodies) == {1}, bodies
+
+
+def test_pull_kernel_on_reserved_cus():
+    """m3t_hip_reserve_ingest_cus: the tracking step on the CUs of one mask, the ROI pull kernel on the others (frame
+    k + 1 crosses PCIe while step k runs).  Which CUs run what changes nothing in the results: the poses of the
+    sequence equal the blocking whole-frame hand-over bit for bit, region + depth, no body outside its rectangle"""
+    inputs = scenes.Inputs(3, 6, n_divides=2, with_depth=True)
+    ref, _ = run(inputs, "blocking", with_depth=True)
+    got, (misses, bodies, pulls) = run(inputs, "roi", with_depth=True, reserve_cus=32)
+    assert pulls >= 2 * (inputs.n_frames - 3) and misses == 0, (pulls, bodies)
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(a, b), k
+
+
+def test_reserving_cus_replans_the_launch_and_replaces_the_stream():
+    """64 objects x 4 workgroups need all 256 CUs; with 32 of them reserved the launch is planned for 224 (2 workgroups
+    per object), the context's stream is a new one, the poses stay what they were; 0 gives everything back"""
+    inputs = scenes.Inputs(64, 3, n_divides=2, n_models=4)
+    poses, shapes, streams = [], [], []
+    for reserve in (0, 32, -1):  # -1: reserve, then give back
+        hip = util.open_hip()
+        s0 = C.c_void_p()
+        hip.call("get_stream", C.byref(s0))
+        if reserve:
+            hip.call("reserve_ingest_cus", 32)
+        if reserve < 0:
+            hip.call("reserve_ingest_cus", 0)
+        s1 = C.c_void_p()
+        hip.call("get_stream", C.byref(s1))
+        streams.append((s0.value, s1.value))
+        inst = scenes.Instance(hip, inputs)
+        inst.upload_frame(0)
+        assert inst.tracker.StartModalities(0)
+        for k in range(1, inputs.n_frames):
+            inst.upload_frame(k)
+            assert inst.tracker.ExecuteTrackingStep(k)
+        shape = (C.c_int * 4)()
+        hip.call("get_step_shape", shape)
+        shapes.append(list(shape))
+        poses.append(np.stack(inst.poses()))
+        assert hip.raw("reserve_ingest_cus", -8) < 0 and hip.raw("reserve_ingest_cus", 1 << 20) < 0
+    assert shapes[0][1] == 4 and shapes[1][1] == 2 and shapes[2][1] == 4, shapes
+    assert streams[0][0] == streams[0][1] and streams[1][0] != streams[1][1]
+    assert np.array_equal(poses[0], poses[1]) and np.array_equal(poses[0], poses[2])
