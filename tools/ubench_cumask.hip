@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(h.data(), d_where, n_where * 8, hipMemcpyDeviceToHost));
     std::set<unsigned> per_xcc[16];
     for (int b = 0; b < n_where; ++b) per_xcc[h[2 * b]].insert(h[2 * b + 1]);
-    printf("%-34s distinct CUs per XCD:", which == 0 ? "mask bits 0..239" : (which == 1 ? "mask bits 240..255" : "no mask"));
+    printf("%-34s distinct CUs per XCD:", which == 0 ? "compute mask (low bits)" : (which == 1 ? "ingest mask (high bits)" : "no mask"));
     int total = 0;
     for (int x = 0; x < 8; ++x) { printf(" %2zu", per_xcc[x].size()); total += (int)per_xcc[x].size(); }
     printf("  (%d)\n", total);
@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(pull, dim3(64, N), dim3(256), 0, s, host_dev, ring, side);
     CHECK(hipStreamSynchronize(s));
     const double ms = ms_since(t) / 20;
-    printf("pull of 64 x %d^2 px (%.1f MB) on %-12s %7.3f ms  %5.1f GB/s\n", side, pull_bytes * 1e-6, which == 0 ? "all CUs:" : "16 CUs:", ms,
+    printf("pull of 64 x %d^2 px (%.1f MB) on %-12s %7.3f ms  %5.1f GB/s\n", side, pull_bytes * 1e-6, which == 0 ? "all CUs:" : "reserved:", ms,
            pull_bytes / ms * 1e-6);
   }
   // ---- the victim alone, beside the pull on its own CUs, beside the pull on reserved CUs ----
@@ -153,7 +153,7 @@ int main(int argc, char** argv) {
       if (rep >= 2) { best = ms < best ? ms : best; sum += ms; }
     }
     static const char* what[4] = {"victim alone, 256 workgroups, no mask", "victim + pull, both on all CUs",
-                                  "victim alone, 240 workgroups on the 240-CU stream", "victim on 240 CUs + pull on the 16 reserved CUs"};
+                                  "victim alone on the compute mask, one workgroup per CU", "victim on the compute mask + pull on the reserved CUs"};
     printf("%-52s %7.3f ms (min %7.3f)\n", what[mode], sum / 10, best);
   }
   // ---- is the masked stream's extra time a constant per launch or a factor?  (rounds 100 / 400 / 1600) ----
@@ -174,7 +174,7 @@ int main(int argc, char** argv) {
       }
       t[which] = sum / 6;
     }
-    printf("victim, %4d rounds: no mask 256 wgs %7.3f ms | no mask 240 wgs %7.3f ms | 240-CU mask 240 wgs %7.3f ms\n", r, t[0], t[1], t[2]);
+    printf("victim, %4d rounds: no mask 256 wgs %7.3f ms | no mask, fewer wgs %7.3f ms | compute mask %7.3f ms\n", r, t[0], t[1], t[2]);
   }
   // ---- variations: a mask that masks nothing; the victim on all CUs beside a pull confined to 16 of them ----
   {
@@ -198,8 +198,8 @@ int main(int argc, char** argv) {
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (rep >= 2) sum += ms;
       }
-      static const char* what[3] = {"victim on a stream whose mask has all 256 bits set", "victim unmasked (256 wgs) + pull confined to 16 CUs",
-                                    "victim unmasked (240 wgs) + pull confined to 16 CUs"};
+      static const char* what[3] = {"victim on a stream whose mask has all 256 bits set", "victim unmasked (all CUs) + pull confined to the reserved CUs",
+                                    "victim unmasked (fewer wgs) + pull confined to the reserved CUs"};
       printf("%-52s %7.3f ms\n", what[mode], sum / 8);
     }
   }
