@@ -2025,6 +2025,11 @@ int m3t_hip_reserve_ingest_cus(m3t_hip_context* ctx, int n_cus) {
   CHECK_CTX();
   REQUIRE(n_cus >= 0 && n_cus <= ctx->prop.multiProcessorCount / 2, M3T_ERR_INVALID_ARGUMENT,
           "n_cus must lie in [0, CUs / 2]");
+  // unequal shader engines are not only slow: the hardware deals workgroups to engines, so a launch planned with one
+  // workgroup per remaining CU may find two of its workgroups queued behind each other -- and the split / tree launches
+  // need all of theirs resident at once
+  REQUIRE(n_cus % 32 == 0, M3T_ERR_INVALID_ARGUMENT,
+          "n_cus must be a multiple of 32 (one CU from each of the 4 shader engines of each of the 8 XCDs)");
   if (n_cus == ctx->ingest_cus) return M3T_OK;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));

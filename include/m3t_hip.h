@@ -140,9 +140,9 @@ int m3t_hip_roi_get_status(m3t_hip_context*, int* body_ids, int capacity, int* n
                             long long* n_rectangle_uploads /* batch-frames that went as rectangles so far; may be NULL */);
 /* Keep n_cus compute units free of the tracking kernels and run the ROI pull kernel on them (CU-masked streams), so
  * that the rectangles of frame k + 1 cross PCIe WHILE step k runs: on shared CUs the pull's PCIe reads hold the CUs'
- * memory pipelines and the step takes 2.3-3 x longer, on CUs of its own the pull costs the step little.  Take the same
- * number of CUs from every shader engine: a multiple of 32 on MI355X (8 XCDs x 4 engines); 32 is the measured sweet
- * spot (tools/ubench_cumask.hip).  The tracking launches plan with the remaining CUs (fewer workgroups per object
+ * memory pipelines and the step takes 2.3-3 x longer, on CUs of its own the pull costs the step little.  n_cus has to
+ * take the same number of CUs from every shader engine: a multiple of 32 on MI355X (8 XCDs x 4 engines; anything else
+ * is refused); 32 and 64 were measured (tools/ubench_cumask.hip, bench.py's ROI leg).  The tracking launches plan with the remaining CUs (fewer workgroups per object
  * where the batch no longer fits).  0 = off (default).  The call synchronises and REPLACES the context's streams:
  * fetch m3t_hip_get_stream again afterwards.  Results do not depend on it. */
 int m3t_hip_reserve_ingest_cus(m3t_hip_context*, int n_cus);
