@@ -4,7 +4,7 @@ page-locked block per batch-frame while the previous step runs), for a kernel tr
   rocprofv3 --kernel-trace --output-format csv -d DIR -- python tools/roi_trace.py     then
   python tools/roi_trace.py --report DIR    prints when the tracking kernel and the pull kernel of the last rounds ran
 
-Without rocprofv3 it prints the loop's ms per step."""
+Without rocprofv3 it prints the loop's ms per step.  ROI_RESERVE_CUS=32: with m3t_hip_reserve_ingest_cus(32).  ROI_MARGIN: pixels."""
 import csv
 import ctypes as C
 import glob
@@ -41,6 +41,8 @@ def main():
     n_obj, n_frames = 64, 8
     margin = float(os.environ.get("ROI_MARGIN", "24"))
     hip = pkg.open_context(0)
+    if os.environ.get("ROI_RESERVE_CUS"):  # the pull kernel on CUs of its own (m3t_hip_reserve_ingest_cus)
+        hip.call("reserve_ingest_cus", int(os.environ["ROI_RESERVE_CUS"]))
     inputs = scenes.Inputs(n_obj, n_frames, n_divides=2, n_models=8)
     inst = scenes.Instance(hip, inputs)
     blocks = [np.stack([inputs.color[i][k] for i in range(n_obj)]) for k in range(n_frames)]
