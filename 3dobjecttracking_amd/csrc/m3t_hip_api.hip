@@ -1642,7 +1642,7 @@ int m3t_hip_create(m3t_hip_context** out, int device_id) {
   auto ctx = std::make_unique<m3t_hip_context>();
   ctx->device = device_id;
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device_id)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+      (e = CreateMaskedStream(ctx.get(), &ctx->stream, false)) != hipSuccess) {
     g_create_error = std::string("device initialisation failed: ") + hipGetErrorString(e);
     return M3T_ERR_DEVICE;
   }
