@@ -254,8 +254,14 @@ struct m3t_hip_context {
   DevMem d_search_poses, d_roi_items, d_roi_item_first, d_roi_cam_ids, d_roi_rects, d_roi_pose_snapshot;
   std::vector<int> roi_cam_ids;    // what d_roi_cam_ids holds
   int roi_rect_slots = 0;          // d_roi_rects: [slot][camera id]
-  hipEvent_t roi_snapshot_done = nullptr;
+  // two snapshots of the bodies' poses, alternating: taken at the END of every fused rigid step (= the poses the next
+  // step starts from, available a whole pull earlier than a snapshot at that step's start), or at a step's start when
+  // the previous step's end does not vouch for them (first step, poses set by the host, other launches in between)
+  hipEvent_t roi_snapshot_done[2] = {nullptr, nullptr};
   bool roi_snapshot_valid = false;
+  int roi_use = 0;              // the snapshot the next rectangle upload reads: the poses at the start of the step enqueued last
+  int roi_end_index = 0;        // where the last step's end-of-step snapshot went
+  bool roi_end_valid = false;   // ... and whether it still describes the device poses
   int* roi_miss_host = nullptr;             // mapped: [0] count, [1 ..] body ids
   int* roi_miss_dev = nullptr;
   static constexpr int kRoiMissCapacity = 255;
@@ -1062,6 +1068,7 @@ int BuildRoiTables(Ctx* ctx) {
   ctx->n_roi_items = 0;
   ctx->roi_recorded = false;
   ctx->roi_snapshot_valid = false;
+  ctx->roi_end_valid = false;
   for (auto& od : ctx->opt_table) od.search_poses = nullptr;
   if (!ctx->roi_enabled || ctx->tree_mode || ctx->opt_table.empty()) return M3T_OK;
   ctx->roi_n_poses = ctx->n_corr_iterations + 2;
@@ -1119,8 +1126,9 @@ int BuildRoiTables(Ctx* ctx) {
   for (auto& c : ctx->cameras) slots = std::max(slots, c->n_slots);
   ctx->roi_rect_slots = slots;
   HIPCHK(ctx->d_roi_rects.alloc(size_t(slots) * n_cams * sizeof(m3t_roi_rect)));
-  HIPCHK(ctx->d_roi_pose_snapshot.alloc(std::max<size_t>(64, ctx->body_poses.size() * 4)));
-  if (!ctx->roi_snapshot_done) HIPCHK(hipEventCreateWithFlags(&ctx->roi_snapshot_done, hipEventDisableTiming));
+  HIPCHK(ctx->d_roi_pose_snapshot.alloc(2 * std::max<size_t>(64, ctx->body_poses.size() * 4)));  // two snapshots
+  for (auto& e : ctx->roi_snapshot_done)
+    if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   {  // what every slot holds now: a whole frame, or (a rectangle from before the rebuild) nothing that can be vouched for
     std::vector<m3t_roi_rect> rects(size_t(slots) * n_cams, m3t_roi_empty());
     for (size_t c = 0; c < n_cams; ++c)
@@ -1677,7 +1685,8 @@ void m3t_hip_destroy(m3t_hip_context* ctx) {
       if (e) (void)hipEventDestroy(e);
   if (ctx->split_abort_host) (void)hipHostFree(ctx->split_abort_host);
   if (ctx->roi_miss_host) (void)hipHostFree(ctx->roi_miss_host);
-  if (ctx->roi_snapshot_done) (void)hipEventDestroy(ctx->roi_snapshot_done);
+  for (auto& e : ctx->roi_snapshot_done)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->region_a) (void)hipEventDestroy(ctx->region_a);
   if (ctx->region_b) (void)hipEventDestroy(ctx->region_b);
   if (ctx->comm && ctx->comm_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
@@ -2108,13 +2117,15 @@ int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context* ctx, const int* ids,
     HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->step_done[last_read % Ctx::kStepEvents], 0));
     ctx->copy_waited_step[cs] = last_read;
   }
-  HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->roi_snapshot_done, 0));  // the poses the rectangles come from
+  HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->roi_snapshot_done[ctx->roi_use], 0));  // the poses the rectangles come from
   const Camera& c0 = *ctx->cameras[ids[0]];
   // the camera table is only read for intrinsics and world2camera here: any slot version will do (the first one)
   m3t_roi_rect* rects = ctx->d_roi_rects.as<m3t_roi_rect>() + size_t(slot) * ctx->cameras.size();
   hipLaunchKernelGGL(roi_rect_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->copy_stream[cs],
                      ctx->d_roi_items.as<RoiItemDev>(), ctx->d_roi_item_first.as<int>(), ctx->d_roi_cam_ids.as<int>(), n,
-                     ctx->d_cams.as<CameraDev>(), ctx->d_roi_pose_snapshot.as<float>(), ctx->roi_margin_px, rects);
+                     ctx->d_cams.as<CameraDev>(),
+                     ctx->d_roi_pose_snapshot.as<float>() + size_t(ctx->roi_use) * (ctx->d_roi_pose_snapshot.bytes / 8),
+                     ctx->roi_margin_px, rects);
   hipLaunchKernelGGL(roi_pull_kernel, dim3((c0.intr.height + 7) / 8, n), dim3(256), 0, ctx->copy_stream[cs],
                      ctx->d_roi_cam_ids.as<int>(), rects, src, camera_stride, uint32_t(row_step), c0.frame(slot),
                      c0.frame_bytes, c0.pitch, c0.is_depth ? 2 : 3);
@@ -3523,6 +3534,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   CHECK_CTX();
   HIPCHK(hipSetDevice(ctx->device));
   const bool untracked_before = ctx->untracked_launches;
+  const bool host_poses_before = ctx->poses_dirty_host;  // (Prepare uploads them)
   int r = Prepare(ctx, true);
   if (r) return r;
   ctx->untracked_launches = untracked_before;  // a whole step is tracked by its step_done event below
@@ -3533,14 +3545,25 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   for (auto& cam : ctx->cameras) roi_frames = roi_frames || cam->slot_is_roi[cam->current];
   REQUIRE(!roi_frames || (rigid_fused && ctx->n_roi_items > 0), M3T_ERR_UNSUPPORTED,
           "a frame slot holds the trackers' rectangle only (ROI ingest): that needs the fused step of rigid objects");
-  if (ctx->roi_enabled && ctx->n_roi_items > 0 && rigid_fused) {
-    // the poses the NEXT frame's rectangles are computed from (m3t_hip_cameras_upload_batch_roi_async, copy stream)
-    HIPCHK(hipMemcpyAsync(ctx->d_roi_pose_snapshot.p, ctx->d_poses.p, ctx->body_poses.size() * 4, hipMemcpyDeviceToDevice,
-                          ctx->stream));
-    HIPCHK(hipEventRecord(ctx->roi_snapshot_done, ctx->stream));
+  const bool roi_active = ctx->roi_enabled && ctx->n_roi_items > 0 && rigid_fused;
+  float* const roi_snapshots = ctx->d_roi_pose_snapshot.as<float>();
+  const size_t roi_snapshot_floats = ctx->d_roi_pose_snapshot.bytes / 8;
+  if (roi_active) {
+    // the poses the NEXT frame's rectangles are computed from (m3t_hip_cameras_upload_batch_roi_async, copy stream):
+    // the poses this step starts from.  The previous step's end-of-step snapshot holds exactly those -- and was ready
+    // before this step had to wait for its own frame, so the next pull can follow the current one at once -- unless
+    // something else touched the poses in between
+    if (ctx->roi_end_valid && !host_poses_before && !untracked_before) {
+      ctx->roi_use = ctx->roi_end_index;
+    } else {
+      ctx->roi_use = 0;
+      HIPCHK(hipMemcpyAsync(roi_snapshots, ctx->d_poses.p, ctx->body_poses.size() * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipEventRecord(ctx->roi_snapshot_done[0], ctx->stream));
+    }
     ctx->roi_snapshot_valid = true;
   }
-  ctx->roi_recorded = ctx->roi_enabled && ctx->n_roi_items > 0 && rigid_fused;
+  ctx->roi_end_valid = false;
+  ctx->roi_recorded = roi_active;
   if (rigid_fused) {  // (a communicator: the structures span GPUs)
     int n = int(ctx->opt_table.size());
     ScopedKernelTimer timer(ctx, 0);
@@ -3703,6 +3726,13 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   if (!histogram_fused) {
     if ((r = RenderForModalities(ctx, true))) return r;
     if ((r = LaunchHistogram(ctx, iteration, false))) return r;
+  }
+  if (roi_active) {  // the poses the step ends on = the poses the next one starts from
+    ctx->roi_end_index = 1 - ctx->roi_use;
+    HIPCHK(hipMemcpyAsync(roi_snapshots + size_t(ctx->roi_end_index) * roi_snapshot_floats, ctx->d_poses.p,
+                          ctx->body_poses.size() * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->roi_snapshot_done[ctx->roi_end_index], ctx->stream));
+    ctx->roi_end_valid = true;
   }
   if (roi_frames) {  // did the step stay inside the rectangles it was given?
     hipLaunchKernelGGL(roi_check_kernel, dim3((ctx->n_roi_items + 63) / 64), dim3(64), 0, ctx->stream,

@@ -519,9 +519,12 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
     frame_bytes = sum(inputs.color[i][0].nbytes for i in range(n_obj))
     pcie = {"pose_updates_per_s": round(n_obj * n_up / el, 1), "ms_per_step": round(el / n_up * 1e3, 3),
             "host_bytes_per_step": frame_bytes, "upload_GBs": round(frame_bytes * n_up / el / 1e9, 2),
-            "note": "pageable host frames, synchronous m3t_hip_camera_upload per camera, then the step"}
+            "note": "pageable host frames, synchronous m3t_hip_camera_upload per camera, then the step (%d steps)" % n_up}
     # the same with ONE page-locked slab per batch-frame and the double-buffered asynchronous ingest: the 64 frames of
     # step k+1 cross PCIe as one DMA on the copy stream while step k runs (m3t_hip_cameras_upload_batch_async)
+    # (the streaming legs run longer than the pageable one: their pipelines -- the copy of frame k + 1 beside step k --
+    # take a step to fill, which a 5-step loop would charge with a fifth of a step)
+    n_up = max(1, min(12, K - 1))
     blocks = [np.stack([inputs.color[i][k] for i in range(n_obj)]) for k in range(1 + W, 2 + W + n_up)]
     ids = (C.c_int * n_obj)(*[cam.id for cam in inst.color_cams])
     for b in blocks:
@@ -624,7 +627,7 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
                             "ms_per_step": round(el / n_up * 1e3, 3),
                             "upload_GBs": round(frame_bytes * n_up / el / 1e9, 2),
                             "note": "one page-locked slab per batch-frame, m3t_hip_cameras_upload_batch_async on the "
-                                    "copy stream, two ring slots; the copy of frame k+1 overlaps step k"}
+                                    "copy stream, two ring slots; the copy of frame k+1 overlaps step k (%d steps)" % n_up}
     return pcie
 
 
