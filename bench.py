@@ -355,12 +355,18 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch, dry_run
     # (m3t_hip_set_fused_step(0)), each bucket synchronised and timed on the host: what the fused launch replaces ----
     buckets = None
     if rank == 0 and world == 1 and args.config in ("rbot64", "ycb21") and not args.no_buckets:
-        buckets = device_buckets(hip, restart, n_obj, W, min(K, 5), cfg)
+        try:  # (extra legs never cost the line: the headline above is already measured)
+            buckets = device_buckets(hip, restart, n_obj, W, min(K, 5), cfg)
+        except Exception as e:  # noqa: BLE001
+            buckets = {"error": str(e)[:300]}
 
     # ---- host-buffer (PCIe-inclusive) rate: every step first receives its frames from host memory; never `value` ----
     pcie = None
     if rank == 0 and world == 1 and args.config == "rbot64" and not args.no_pcie:
-        pcie = pcie_legs(hip, inst, inputs, n_obj, W, K)
+        try:
+            pcie = pcie_legs(hip, inst, inputs, n_obj, W, K)
+        except Exception as e:  # noqa: BLE001
+            pcie = {"error": str(e)[:300]}
 
     # ---- optional batch sweep (extra, not the headline) ----
     sweep = []
