@@ -4,6 +4,9 @@ and start poses; `Instance` is the object graph of those inputs behind ONE C-ABI
 the tests and bench.py's checker legs, the CPU oracle bound through the same ctypes layer), driven through identical
 Tracker calls."""
 import ctypes as C
+import hashlib
+import os
+import pickle
 
 import numpy as np
 
@@ -11,11 +14,62 @@ from . import host
 from . import synthetic as syn
 
 
+def _cache_file(kind, key):
+    """M3T_INPUT_CACHE=<dir>: generated inputs are kept there between processes (the models of an 18-model RBOT batch
+    take a minute of numpy, its frames another 20 s -- per bench.py invocation, and a profile collection makes dozens).
+    The key holds every argument and the generator's own source: a changed generator never meets an old file."""
+    root = os.environ.get("M3T_INPUT_CACHE")
+    if not root:
+        return None
+    h = hashlib.sha1(repr(key).encode())
+    for path in (syn.__file__, __file__):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    os.makedirs(root, exist_ok=True)
+    return os.path.join(root, "%s_%s.pkl" % (kind, h.hexdigest()[:20]))
+
+
+def _cache_load(path):
+    if path and os.path.exists(path):
+        try:
+            with open(path, "rb") as f:
+                return pickle.load(f)
+        except Exception:  # noqa: BLE001 (a torn file from a killed writer: rebuild)
+            return None
+    return None
+
+
+def _cache_store(path, obj):
+    if not path:
+        return
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    try:
+        with open(tmp, "wb") as f:
+            pickle.dump(obj, f, protocol=5)
+        os.replace(tmp, path)
+    except OSError:  # (disk full, read-only: the cache is a convenience)
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+
+
 class Inputs:
     """Seeded inputs for n_objects independent single-body trackers."""
 
     def __init__(self, n_objects, n_frames, n_divides=2, n_points=200, intr=None, with_depth=False,
                  depth_scale=1e-4, n_models=None, first_object=0):
+        key = (n_objects, n_frames, n_divides, n_points, sorted((intr or {}).items()), with_depth, depth_scale, n_models,
+               first_object)
+        whole = _cache_file("inputs", key)
+        cached = _cache_load(whole)
+        if cached is not None:
+            self.__dict__.update(cached)
+            return
+        self._build(n_objects, n_frames, n_divides, n_points, intr, with_depth, depth_scale, n_models, first_object)
+        _cache_store(whole, self.__dict__)
+
+    def _build(self, n_objects, n_frames, n_divides, n_points, intr, with_depth, depth_scale, n_models, first_object):
         self.n_objects = n_objects
         self.n_frames = n_frames
         self.with_depth = with_depth
@@ -29,10 +83,17 @@ class Inputs:
             if i >= n_models:
                 sc.body = self.scenes[i % n_models].body
         self.model_of = [i % n_models for i in range(n_objects)]
-        self.region_models = [syn.make_region_model(self.scenes[m].body, n_divides=n_divides, n_points=n_points)
-                              for m in range(n_models)]
-        self.depth_models = ([syn.make_depth_model(self.scenes[m].body, n_divides=n_divides, n_points=n_points)
-                              for m in range(n_models)] if with_depth else None)
+        # (the models depend on the bodies' shapes only: their own cache entry serves every frame count)
+        models_file = _cache_file("models", (first_object, n_models, n_divides, n_points, with_depth,
+                                             sorted(self.intr.items()), depth_scale))
+        models = _cache_load(models_file)
+        if models is None:
+            models = ([syn.make_region_model(self.scenes[m].body, n_divides=n_divides, n_points=n_points)
+                       for m in range(n_models)],
+                      [syn.make_depth_model(self.scenes[m].body, n_divides=n_divides, n_points=n_points)
+                       for m in range(n_models)] if with_depth else None)
+            _cache_store(models_file, models)
+        self.region_models, self.depth_models = models
         self.gt = [[None] * n_frames for _ in range(n_objects)]
         self.color = [[None] * n_frames for _ in range(n_objects)]
         self.depth = [[None] * n_frames for _ in range(n_objects)]
