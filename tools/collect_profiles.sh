@@ -18,7 +18,7 @@ CONFIGS=${CONFIGS:-rbot64 rbot4096 ycb21 synth512 chain8}
 mkdir -p "$OUT"
 cd "$REPO"
 # every bench.py invocation below would regenerate its configuration's inputs (rbot64: 39 s of numpy on the box's CPU,
-# synth512: 66 s -- 14 of the 23.5 minutes of round 4's collection): generate once per (configuration, frame count)
+# synth512: 66 s -- about 14 of the 23.5 minutes of round 4's collection): generate once per (configuration, frame count)
 export M3T_INPUT_CACHE=${M3T_INPUT_CACHE:-/tmp/m3t_inputs}
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 args_of() {  # bench.py arguments of a profile configuration
