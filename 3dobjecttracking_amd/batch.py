@@ -54,6 +54,76 @@ def _cache_store(path, obj):
             pass
 
 
+def _workers(n_tasks, heavy):
+    """Processes to generate inputs with.  Opt-in: M3T_INPUT_WORKERS=<n> forces n (1 = in this process),
+    M3T_INPUT_WORKERS=auto takes the cores this process may use (affinity, cgroup quota) for inputs that are worth the
+    start of a pool; unset = in this process (what bench.py does when the driver runs it)."""
+    env = os.environ.get("M3T_INPUT_WORKERS")
+    if env is None:
+        return 1
+    if env != "auto":
+        return max(1, min(int(env), n_tasks))
+    if not heavy:
+        return 1
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, n_tasks))
+
+
+def _model_task(args):
+    body, n_divides, n_points, with_depth = args
+    return (syn.make_region_model(body, n_divides=n_divides, n_points=n_points),
+            syn.make_depth_model(body, n_divides=n_divides, n_points=n_points) if with_depth else None)
+
+
+def _scene_task(args):
+    """one object's stream: its scene (random state after the last frame included), poses and frames"""
+    index, body_index, intr, with_depth, depth_scale, n_frames = args
+    sc = syn.Scene(index, intr=intr, with_depth=with_depth, depth_scale=depth_scale)
+    if body_index != index:  # an object that shares its model: the other object's shape
+        sc.body = syn.Scene(body_index, intr=intr, with_depth=with_depth, depth_scale=depth_scale).body
+    gt, color, depth = [], [], []
+    for k in range(n_frames):
+        if k:
+            sc.step_pose()
+        gt.append(sc.pose.copy())
+        r = sc.render()
+        if with_depth:
+            color.append(r[0])
+            depth.append(r[1])
+        else:
+            color.append(r)
+            depth.append(None)
+    return sc, gt, color, depth
+
+
+def _map(fn, tasks, heavy):
+    """fn over tasks, in order; with worker processes where that pays (spawned: the caller may hold a HIP runtime,
+    which must not be forked).  Every task is computed by the same code either way: the results are the same bits."""
+    import multiprocessing as mp
+    import sys
+    n = _workers(len(tasks), heavy)
+    # a spawned worker imports the parent's __main__ again: that needs a script file (not `python -`, not a prompt),
+    # and a worker of somebody else's pool cannot have children
+    main_file = getattr(sys.modules.get("__main__"), "__file__", None)
+    if not (main_file and os.path.exists(main_file)) or mp.current_process().daemon:
+        n = 1
+    if n <= 1 or len(tasks) <= 1:
+        return [fn(t) for t in tasks]
+    from concurrent.futures import ProcessPoolExecutor
+    try:
+        with ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("spawn")) as pool:
+            return list(pool.map(fn, tasks))
+    except Exception as e:  # noqa: BLE001 (a worker that died, a box without /dev/shm: the serial path always works)
+        sys.stderr.write("input generation: worker processes failed (%s), continuing in this process\n" % (e,))
+        return [fn(t) for t in tasks]
+
+
 class Inputs:
     """Seeded inputs for n_objects independent single-body trackers."""
 
@@ -75,38 +145,29 @@ class Inputs:
         self.with_depth = with_depth
         self.intr = dict(intr or (syn.YCB_INTRINSICS if with_depth else syn.RBOT_INTRINSICS))
         self.depth_scale = depth_scale
-        self.scenes = [syn.Scene(first_object + i, intr=self.intr, with_depth=with_depth, depth_scale=depth_scale)
-                       for i in range(n_objects)]
         n_models = n_models or n_objects
+        self.model_of = [i % n_models for i in range(n_objects)]
+        # every object's stream: its scene, ground-truth poses and frames (objects are independent: one task each)
+        streams = _map(_scene_task, [(first_object + i, first_object + i % n_models, self.intr, with_depth, depth_scale,
+                                      n_frames) for i in range(n_objects)], heavy=n_objects * n_frames >= 256)
+        self.scenes = [st[0] for st in streams]
         # objects sharing a model share the body shape
         for i, sc in enumerate(self.scenes):
             if i >= n_models:
                 sc.body = self.scenes[i % n_models].body
-        self.model_of = [i % n_models for i in range(n_objects)]
         # (the models depend on the bodies' shapes only: their own cache entry serves every frame count)
         models_file = _cache_file("models", (first_object, n_models, n_divides, n_points, with_depth,
                                              sorted(self.intr.items()), depth_scale))
         models = _cache_load(models_file)
         if models is None:
-            models = ([syn.make_region_model(self.scenes[m].body, n_divides=n_divides, n_points=n_points)
-                       for m in range(n_models)],
-                      [syn.make_depth_model(self.scenes[m].body, n_divides=n_divides, n_points=n_points)
-                       for m in range(n_models)] if with_depth else None)
+            made = _map(_model_task, [(self.scenes[m].body, n_divides, n_points, with_depth) for m in range(n_models)],
+                        heavy=n_divides >= 3 and n_models > 1)
+            models = ([m[0] for m in made], [m[1] for m in made] if with_depth else None)
             _cache_store(models_file, models)
         self.region_models, self.depth_models = models
-        self.gt = [[None] * n_frames for _ in range(n_objects)]
-        self.color = [[None] * n_frames for _ in range(n_objects)]
-        self.depth = [[None] * n_frames for _ in range(n_objects)]
-        for i, sc in enumerate(self.scenes):
-            for k in range(n_frames):
-                if k:
-                    sc.step_pose()
-                self.gt[i][k] = sc.pose.copy()
-                r = sc.render()
-                if with_depth:
-                    self.color[i][k], self.depth[i][k] = r
-                else:
-                    self.color[i][k] = r
+        self.gt = [list(st[1]) for st in streams]
+        self.color = [list(st[2]) for st in streams]
+        self.depth = [list(st[3]) for st in streams]
         # the tracker starts from a slightly wrong pose
         rng = np.random.default_rng(77 + first_object)
         self.start = [syn.perturb_pose(self.gt[i][0], rng, rot_deg=1.0, trans=0.002) for i in range(n_objects)]
