@@ -209,6 +209,9 @@ def main():
         except Exception:  # noqa: BLE001 (a convenience, not a requirement)
             pass
 
+    # the synthetic inputs are generated on worker processes (3dobjecttracking_amd/batch.py: one task per model / per
+    # object stream, the same bits as in one process, serial fallback; at N > 1 every rank keeps to its share of the cores)
+    os.environ.setdefault("M3T_INPUT_WORKERS", "auto" if world == 1 else str(max(1, int(usable_cpus()["usable"]) // world)))
     pkg = importlib.import_module("3dobjecttracking_amd")
     if args.config == "chain8":
         import bench_chain
