@@ -108,20 +108,27 @@ def _map(fn, tasks, heavy):
     import multiprocessing as mp
     import sys
     n = _workers(len(tasks), heavy)
-    # a spawned worker imports the parent's __main__ again: that needs a script file (not `python -`, not a prompt),
-    # and a worker of somebody else's pool cannot have children
-    main_file = getattr(sys.modules.get("__main__"), "__file__", None)
-    if not (main_file and os.path.exists(main_file)) or mp.current_process().daemon:
+    if mp.current_process().daemon:  # (a worker of somebody else's pool cannot have children)
         n = 1
     if n <= 1 or len(tasks) <= 1:
         return [fn(t) for t in tasks]
     from concurrent.futures import ProcessPoolExecutor
+    # the workers need this module only, found by name: keep multiprocessing from running the parent's script again
+    # in every worker (spawn does that whenever __main__ has a file or a spec -- a script without a __main__ guard
+    # would open its GPU context in each of them)
+    main = sys.modules["__main__"]
+    hidden = {k: getattr(main, k) for k in ("__file__", "__spec__") if hasattr(main, k)}
     try:
+        for k in hidden:
+            setattr(main, k, None)
         with ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("spawn")) as pool:
             return list(pool.map(fn, tasks))
     except Exception as e:  # noqa: BLE001 (a worker that died, a box without /dev/shm: the serial path always works)
         sys.stderr.write("input generation: worker processes failed (%s), continuing in this process\n" % (e,))
         return [fn(t) for t in tasks]
+    finally:
+        for k, v in hidden.items():
+            setattr(main, k, v)
 
 
 class Inputs:

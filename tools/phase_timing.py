@@ -1,10 +1,13 @@
 """Developer tool: per-phase s_memtime cycles of the fused tracking kernel (block 0),
 using a -DM3T_PHASE_TIMING build of the library (gpurun_out/libm3t_hip_timing.so)."""
 import ctypes as C, importlib, os, sys
+
+os.environ.setdefault("M3T_INPUT_WORKERS", "auto")  # inputs on worker processes (same bits; batch.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 pkg = importlib.import_module("3dobjecttracking_amd")
+import os
 import scenes
 lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "libm3t_hip_timing.so")
 n_obj = int(sys.argv[2]) if len(sys.argv) > 2 else 64

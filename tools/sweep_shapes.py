@@ -1,10 +1,13 @@
 """Developer tool: ms per tracking step for several launch shapes on the same inputs (built once), with a check
 that every shape ends on the same poses bit for bit.  usage: sweep_shapes.py [rbot|ycb] ..."""
 import ctypes as C, importlib, json, os, sys, time
+
+os.environ.setdefault("M3T_INPUT_WORKERS", "auto")  # inputs on worker processes (same bits; batch.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 pkg = importlib.import_module("3dobjecttracking_amd")
+import os
 import scenes
 
 

@@ -1,9 +1,12 @@
 """Developer tool: s_memtime cycles of the structure phases of tracking_step_tree_kernel (-DM3T_PHASE_TIMING build)."""
 import ctypes as C, importlib, os, sys
+
+os.environ.setdefault("M3T_INPUT_WORKERS", "auto")  # inputs on worker processes (same bits; batch.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 pkg = importlib.import_module("3dobjecttracking_amd")
+import os
 import bench_chain
 scenes = pkg.batch
 lib = sys.argv[1]
