@@ -57,7 +57,7 @@ def _cache_store(path, obj):
 def _workers(n_tasks, heavy):
     """Processes to generate inputs with.  Opt-in: M3T_INPUT_WORKERS=<n> forces n (1 = in this process),
     M3T_INPUT_WORKERS=auto takes the cores this process may use (affinity, cgroup quota) for inputs that are worth the
-    start of a pool; unset = in this process (what bench.py does when the driver runs it)."""
+    start of a pool; unset = in this process.  (bench.py and the developer tools set `auto` unless told otherwise.)"""
     env = os.environ.get("M3T_INPUT_WORKERS")
     if env is None:
         return 1
