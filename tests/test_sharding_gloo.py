@@ -13,6 +13,14 @@ ROOT = util.ROOT
 N_OBJECTS, N_FRAMES = 6, 3
 
 
+def _free_port():
+    """a port nobody listens on right now (the rendezvous of a test must not depend on what else runs on the box)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _track(ids):
     import scenes
     ora = util.open_oracle()
@@ -54,7 +62,7 @@ def test_two_rank_sharding_matches_single_process(tmp_path, mode):
     sh = importlib.import_module("3dobjecttracking_amd.sharding")
     ids0, ids1 = sh.shard_objects(N_OBJECTS, 0, 2, mode), sh.shard_objects(N_OBJECTS, 1, 2, mode)
     assert sorted(list(ids0) + list(ids1)) == list(range(N_OBJECTS))
-    port = 29500 + os.getpid() % 2000 + (0 if mode == "block" else 1)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
     ref = _track(range(N_OBJECTS))
     for rank in range(2):
@@ -114,7 +122,7 @@ def test_kinematic_structure_over_two_ranks(tmp_path):
     """every rank keeps the whole link tree but only its own bodies' modalities; one all-reduce of
     the stacked link sums per Newton step keeps all replicas identical and equal to the single-process result"""
     import torch.multiprocessing as mp
-    port = 29700 + os.getpid() % 200
+    port = _free_port()
     mp.spawn(_chain_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     _chain_worker(0, 1, port + 1, str(tmp_path))
     ref = np.load(os.path.join(str(tmp_path), "chain_1_0.npy"))
@@ -168,7 +176,7 @@ def test_four_ranks_equal_one_process_bit_for_bit(tmp_path):
     bit.  (With the projected [dof x dof | dof] sums of round 3 the sum over the ranks was a reassociation of the sum
     over the links; the tracker's discrete decisions amplified it to 6e-3 on the poses within one frame.)"""
     import torch.multiprocessing as mp
-    port = 29990 + os.getpid() % 9
+    port = _free_port()
     mp.spawn(_four_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
     _four_worker(0, 1, port + 1, str(tmp_path))
     ref = np.load(os.path.join(str(tmp_path), "four_1_0.npy"))
@@ -215,7 +223,7 @@ def test_soft_constraints_over_two_ranks_count_once(tmp_path):
     they enter the system once, replicas identical and equal to the single process bit for bit.  (Round 3 summed the
     projected system, soft terms included: once per rank -- its advisor's finding.)"""
     import torch.multiprocessing as mp
-    port = 29900 + os.getpid() % 90
+    port = _free_port()
     mp.spawn(_soft_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     _soft_worker(0, 1, port + 2, str(tmp_path))
     ref = np.load(os.path.join(str(tmp_path), "soft_1_0.npy"))
