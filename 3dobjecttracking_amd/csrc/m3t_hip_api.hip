@@ -198,6 +198,7 @@ struct m3t_hip_context {
   DevMem d_treesteps, d_tracked_links, d_tree_exchange;
   int n_treesteps = 0;
   bool tree_fused_possible = false;
+  bool tree_constrained = false;  // some structure has Constraint / SoftConstraint objects: tracking_step_tree_constrained_kernel
   size_t tree_block_floats = 0;  // LDS of the structure copy (link table, link sums, system, work arrays), largest structure
   unsigned tree_seq = 0;
   size_t partial_count = 0;
@@ -226,7 +227,8 @@ struct m3t_hip_context {
   std::map<std::tuple<const void*, int, size_t>, int> occupancy_cache;  // ResidentBlocks
   int ingest_cus = 0;   // m3t_hip_reserve_ingest_cus: CUs kept free of the tracking kernels for the ROI pull kernel
   int compute_cus = 0;  // what the tracking launches may count on (set with the device properties)
-  size_t tree_lds_attribute = 0;  // dynamic LDS limit last set on tracking_step_tree_kernel
+  size_t tree_lds_attribute = 0;  // dynamic LDS limit last set on the one-launch tree kernel ...
+  const void* tree_lds_kernel = nullptr;  // ... and which of the two it was
   DevMem d_split;            // [objects][2 slots][parts][32 fields][256 / parts] granules, then one abort word per object
   size_t split_objects = 0;  // capacity of d_split
   unsigned split_seq = 0;    // launch counter inside the granule tags
@@ -532,10 +534,10 @@ int CheckSplitExchange(Ctx* ctx) {
   const unsigned value = __atomic_load_n(ctx->split_abort_host, __ATOMIC_ACQUIRE);
   if (value != ctx->split_abort_seen) {
     ctx->split_abort_seen = value;
-    const bool tree = std::strcmp(ctx->last_step_kernel, "tracking_step_tree_kernel") == 0;
+    const bool tree = std::strncmp(ctx->last_step_kernel, "tracking_step_tree_", 19) == 0;
     const bool render = std::strcmp(ctx->last_step_kernel, "tracking_step_split_render_kernel") == 0;
     const std::string msg =
-        std::string(tree ? "tracking_step_tree_kernel" : (render ? "tracking_step_split_render_kernel" : "tracking_step_split_kernel")) +
+        std::string(tree ? ctx->last_step_kernel : (render ? "tracking_step_split_render_kernel" : "tracking_step_split_kernel")) +
         ": a workgroup waited in vain for the other workgroups of its " + (tree ? "kinematic structure" : "object") +
         " (is another process or stream using this GPU?); the step was abandoned part-way: workgroups that had "
         "already finished may have written the new pose" + (tree ? "s and joints" : "") +
@@ -845,6 +847,14 @@ int UploadTreeTables(Ctx* ctx) {
       ctx->tree_block_floats = std::max(ctx->tree_block_floats, (block + 3) / 4 * 4);
     }
     if (attached != ctx->modalities.size() || steps.empty()) possible = false;
+    // what the one-launch step's structure code is laid out for (m3t_links.hip, round 5); larger structures take the
+    // per-sub-step launches.  Structures with Constraint / SoftConstraint objects run the kernel that has their code.
+    ctx->tree_constrained = false;
+    for (size_t oi = 0; oi < opts.size(); ++oi) {
+      const Optimizer& o = ctx->optimizers[oi];
+      if (int(o.order.size()) > M3T_TREE_FUSED_MAX_LINKS || o.dof + o.n_rows > M3T_TREE_FUSED_MAX_SIZE) possible = false;
+      if (!o.constraints.empty() || !o.soft_constraints.empty()) ctx->tree_constrained = true;
+    }
     HIPCHK(ctx->d_treesteps.alloc(std::max<size_t>(1, steps.size()) * sizeof(TreeStepDev)));
     HIPCHK(ctx->d_tracked_links.alloc(std::max<size_t>(1, tracked.size()) * sizeof(int)));
     HIPCHK(ctx->d_tree_exchange.alloc(std::max<size_t>(1, exchange_total) * 8));
@@ -1576,15 +1586,17 @@ bool TreeStepFused(Ctx* ctx) {
   const bool fused_histogram = !ctx->region_mods.empty() && ctx->hist_counts_in_lds;
   const size_t lds = TreeStepLds(ctx, fused_histogram);
   if (lds > size_t(160) * 1024) return false;
-  if (ctx->tree_lds_attribute != lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_tree_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
+  auto kernel = ctx->tree_constrained ? tracking_step_tree_constrained_kernel : tracking_step_tree_kernel;
+  if (ctx->tree_lds_attribute != lds || ctx->tree_lds_kernel != reinterpret_cast<const void*>(kernel)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(lds)) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
     ctx->tree_lds_attribute = lds;
+    ctx->tree_lds_kernel = reinterpret_cast<const void*>(kernel);
   }
-  int resident = ResidentBlocks(ctx, tracking_step_tree_kernel, M3T_BLOCK_THREADS, lds);
+  int resident = ResidentBlocks(ctx, kernel, M3T_BLOCK_THREADS, lds);
   resident = std::min(resident, int(size_t(160) * 1024 / lds));
   return resident >= 1 && ctx->n_treesteps <= ctx->compute_cus * resident;
 }
@@ -3696,7 +3708,8 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     xp.abort_id = ctx->split_launches;
     xp.host_abort = ctx->split_abort_dev;
     const int off_tree = int((lds / 4 - ctx->tree_block_floats));
-    hipLaunchKernelGGL(tracking_step_tree_kernel, dim3(ctx->n_treesteps), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
+    hipLaunchKernelGGL(ctx->tree_constrained ? tracking_step_tree_constrained_kernel : tracking_step_tree_kernel,
+                       dim3(ctx->n_treesteps), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
                        ctx->d_treesteps.as<TreeStepDev>(), ctx->d_treeopts.as<TreeOptDev>(),
                        ctx->d_region.as<RegionModDev>(), ctx->d_depth.as<DepthModDev>(), ctx->cams_active,
                        ctx->d_poses.as<float>(), ctx->layout, ctx->off_points, ctx->np_max, off_tree, iteration,
@@ -3704,7 +3717,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     HIPCHK(hipGetLastError());
     histogram_fused = want_fused_histogram;
     ctx->links_device_newer = true;
-    ctx->last_step_kernel = "tracking_step_tree_kernel";
+    ctx->last_step_kernel = ctx->tree_constrained ? "tracking_step_tree_constrained_kernel" : "tracking_step_tree_kernel";
     ctx->last_step_shape[0] = ctx->n_treesteps;
     ctx->last_step_shape[1] = 1;
     ctx->last_step_shape[2] = M3T_BLOCK_THREADS;

@@ -46,10 +46,18 @@ __device__ unsigned long long g_exchange_times[3 * 16 * 16];  // [kind][round][p
     if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_cycles[i] += _n - _pt;   \
     _pt = _n;                                                                 \
   } while (0)
+// (a phase that runs on another wave than the first: `thread` records it)
+#define PHASE_MARK_BY(i, thread)                                                        \
+  do {                                                                                  \
+    unsigned long long _n = clock64();                                                  \
+    if (blockIdx.x == 0 && (int)threadIdx.x == (thread)) g_phase_cycles[i] += _n - _pt; \
+    _pt = _n;                                                                           \
+  } while (0)
 #else
 #define EXCHANGE_STAMP(kind, round, part, object) do {} while (0)
 #define PHASE_T0() do {} while (0)
 #define PHASE_MARK(i) do {} while (0)
+#define PHASE_MARK_BY(i, thread) do {} while (0)
 #endif
 
 namespace {
@@ -227,7 +235,8 @@ __device__ __forceinline__ bool view_direction(const Affine& b2c, float& o0, flo
 // among equals -- the result of the full scan, bit for bit.  Outside it: -1, the caller scans all views.  Every wave
 // works the row out for itself (19 lanes): no LDS, no barrier.
 __device__ __forceinline__ int closest_view_local(G<v4f> neighbors, int prev, float o0, float o1, float o2) {
-  const int lane = threadIdx.x & (kWave - 1);
+  int lane = threadIdx.x & (kWave - 1);
+  asm volatile("" : "+v"(lane));  // (the row offset is worked out here, not in front of the caller's loops: one VGPR pair less alive across them)
   const v4f e = neighbors[(uint32_t)prev * M3T_VIEW_ROW + (lane < M3T_VIEW_ROW ? lane : 0)];
   float d = (o0 * e.x + o1 * e.y) + o2 * e.z;
   const float d_prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 0));
@@ -935,6 +944,7 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
     }
     __syncthreads();
     my_valid_occ = 0;  // counted from the flags now
+#pragma nounroll
     for (int line = tid; line < nl; line += nt) my_valid_occ += f2i_bits(s.state[LS_VALID * nl + line]) & 1;
   }
   // two-pass fallback :435-463: use the occlusion-handled set only if it has enough lines
@@ -1071,6 +1081,7 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   // the final flag (bit 0 = line is in data_lines_), for the lines of all parts: it follows from phase A, which every
   // workgroup ran in full.  (Threads above may still test `flags & valid_mask`: bit 0 only ever takes that test's value.)
   if (!defer_vote)
+#pragma nounroll
     for (int line = tid; line < nl; line += nt) {
       const int flags = f2i_bits(s.state[LS_VALID * nl + line]);
       s.state[LS_VALID * nl + line] = i2f_bits((flags & ~1) | ((flags & valid_mask) ? 1 : 0));
@@ -2194,7 +2205,9 @@ __device__ __forceinline__ void depth_correspondences_scan(CDepth& m, CCam& cam,
 
 template <bool RENDER = true>
 __device__ __forceinline__ void depth_correspondences_vote(CDepth& m, int iteration, float* ps, int np, float* misc) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // (the flag addresses are formed here, not once in front of the caller's loops)
+  const int nt = blockDim.x;
   const bool handle_occlusions = (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
   const bool measured_pass = m.measure_occlusions && handle_occlusions;
   const bool modeled_pass = RENDER && m.model_occlusions && handle_occlusions &&
@@ -2202,6 +2215,7 @@ __device__ __forceinline__ void depth_correspondences_vote(CDepth& m, int iterat
   bool use_occ = false;
   if (measured_pass || modeled_pass) {
     int mine = 0;
+#pragma nounroll
     for (int i = tid; i < np; i += nt) mine += f2i_bits(ps[PS_VALID * np + i]) & 1;
     int cnt = wave_sum_i(mine);
     int* imisc = reinterpret_cast<int*>(misc);
@@ -2212,6 +2226,7 @@ __device__ __forceinline__ void depth_correspondences_vote(CDepth& m, int iterat
     use_occ = total >= m.min_n_unoccluded_points;
   }
   const int valid_mask = use_occ ? 1 : 2;
+#pragma nounroll
   for (int i = tid; i < np; i += nt) {
     int flags = f2i_bits(ps[PS_VALID * np + i]);
     ps[PS_VALID * np + i] = i2f_bits((flags & ~1) | ((flags & valid_mask) ? 1 : 0));

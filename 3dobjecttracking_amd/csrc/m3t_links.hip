@@ -56,6 +56,11 @@ struct TreeOptDev {
   unsigned long long* exchange;
 };
 #define M3T_TREE_GRANULES 64  /* granules per tracked link and slot (42 used) */
+#define M3T_TREE_LANE_FIELDS 5 /* per-lane constants of a structure (tree_tables) */
+// what the one-launch step's structure code (tracking_step_tree_kernel) is laid out for: a link per wave in the
+// system assembly, two lanes per link for the adjoints, four per link for exp(), a Jacobian column per lane
+#define M3T_TREE_FUSED_MAX_LINKS 16
+#define M3T_TREE_FUSED_MAX_SIZE 64
 
 // one workgroup of tracking_step_tree_kernel
 struct TreeStepDev {
@@ -77,7 +82,8 @@ namespace {
 __host__ __device__ inline size_t tree_work_floats(int n_links, int dof, int n_rows) {
   size_t size = size_t(dof) + n_rows;
   return size_t(n_links) * (12 * dof + 42 + 72) + size * size + 4 * size + size_t(n_rows) * (dof + 1) + 2 * 6 * 6 + 64 +
-         size_t(n_links) * (size_t(dof) * dof + dof) + dof;  // tree_system_block: per-link terms of A and b, Tikhonov vector
+         size_t(n_links) * (size_t(dof) * dof + dof) + dof +  // tree_system_block: per-link terms of A and b, Tikhonov vector
+         size_t(dof) * (dof + 1) / 2 + M3T_TREE_LANE_FIELDS * 64;  // tree_tables: (row, column) of the lower triangle's elements, per-lane constants
 }
 
 __device__ inline void affine_to_array(const Affine& a, float* p) {
@@ -262,6 +268,7 @@ struct TreeWork {
   float *J, *GH, *AD, *HJ, *A, *b, *temp, *cres, *j1, *j2;
   float *terms, *tikhonov;  // [n_links][dof * dof + dof], [dof] (tree_system_block)
   int* trans;
+  int *lower, *lanes;       // [dof (dof + 1) / 2], [M3T_TREE_LANE_FIELDS][64] (tree_tables)
 };
 __device__ __forceinline__ TreeWork tree_carve(float* w, int n_links, int dof, int n_rows) {
   const int size = dof + n_rows;
@@ -279,6 +286,8 @@ __device__ __forceinline__ TreeWork tree_carve(float* w, int n_links, int dof, i
   t.j2 = t.j1 + 36;
   t.terms = t.j2 + 36 + 64;
   t.tikhonov = t.terms + (size_t)n_links * ((size_t)dof * dof + dof);
+  t.lower = reinterpret_cast<int*>(t.tikhonov + dof);
+  t.lanes = t.lower + (size_t)dof * (dof + 1) / 2;
   return t;
 }
 
@@ -320,9 +329,8 @@ __device__ __forceinline__ Affine tree_link_pose(const LinkDev& l, const float* 
 // Eigen::LDLT<MatrixXf, Lower> + solve (optimizer.cpp:162-163) by one wave: the oracle's LdltSolve, its loops over
 // rows / columns spread over the lanes
 template <bool WAVE>
-__device__ __forceinline__ void ldlt_solve_wave(float* a, float* x, int n, float* temp, int* trans) {
+__device__ __forceinline__ void ldlt_solve_wave(float* a, float* x, int n, float* temp, int* trans, int lane) {
 #define A_(r, c) a[(size_t)(c) * n + (r)]
-  const int lane = threadIdx.x;
   bool degenerate = false;
   for (int k = 0; k < n && !degenerate; ++k) {
     // first largest |A(i,i)|, i >= k (a NaN never beats `best`; a NaN at k keeps piv = k)
@@ -401,13 +409,12 @@ __device__ __forceinline__ void ldlt_solve_wave(float* a, float* x, int n, float
 // comparisons treat specially) takes the general routine.  ~8 k cycles instead of ~50 k for the 13 x 13 system of an
 // 8-body chain, where every step of the general routine pays several LDS round trips and barriers.
 template <int N, bool WAVE>
-__device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float* temp, int* trans) {
-  const int lane = threadIdx.x & (kWave - 1);
+__device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float* temp, int* trans, int lane) {
   const bool row = lane < n;
   float d = row ? fabsf(a[(size_t)lane * n + lane]) : 0.0f;
   const bool bad = (d != d) || (__builtin_amdgcn_ballot_w64(row && d > 0.0f) == 0);
   if (__builtin_amdgcn_ballot_w64(row && bad) != 0) {  // uniform
-    ldlt_solve_wave<WAVE>(a, x, n, temp, trans);
+    ldlt_solve_wave<WAVE>(a, x, n, temp, trans, lane);
     return;
   }
   // 1. the transposition sequence: position p holds input row src.  Eigen's selection (the first largest of the
@@ -504,11 +511,13 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
   tree_sync<WAVE>();
 }
 template <bool WAVE>
-__device__ __forceinline__ void ldlt_solve_any(float* a, float* x, int n, float* temp, int* trans) {
-  if (n <= 8) ldlt_solve_rows<8, WAVE>(a, x, n, temp, trans);
-  else if (n <= 13) ldlt_solve_rows<13, WAVE>(a, x, n, temp, trans);  // (13: a free root and seven one-dof joints)
-  else if (n <= 16) ldlt_solve_rows<16, WAVE>(a, x, n, temp, trans);
-  else ldlt_solve_wave<WAVE>(a, x, n, temp, trans);
+__device__ __forceinline__ void ldlt_solve_any(float* a, float* x, int n, float* temp, int* trans, int lane) {
+  // lane: the caller's lane inside the wave that runs the solve (a parameter so that a caller can keep the compiler
+  // from working its addresses out far ahead: tree_step_body)
+  if (n <= 8) ldlt_solve_rows<8, WAVE>(a, x, n, temp, trans, lane);
+  else if (n <= 13) ldlt_solve_rows<13, WAVE>(a, x, n, temp, trans, lane);  // (13: a free root and seven one-dof joints)
+  else if (n <= 16) ldlt_solve_rows<16, WAVE>(a, x, n, temp, trans, lane);
+  else ldlt_solve_wave<WAVE>(a, x, n, temp, trans, lane);
 }
 
 // Optimizer::CalculateDataLinks (:281-296) + AddProjectedGradientsAndHessians (:309-321).
@@ -809,7 +818,7 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
     }
     PHASE_MARK(12);
     // the factorisation is wave-level code: in the whole-workgroup mode the first wave runs it, the others wait
-    if (MODE != 2 || threadIdx.x < kWave) ldlt_solve_any<MODE != 0>(A, b, size, w.temp, w.trans);
+    if (MODE != 2 || threadIdx.x < kWave) ldlt_solve_any<MODE != 0>(A, b, size, w.temp, w.trans, threadIdx.x & (kWave - 1));
     if constexpr (MODE == 2) __syncthreads();
     PHASE_MARK(13);
     int has_nan = 0;
@@ -998,6 +1007,411 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
 }
 
 // ---------------------------------------------------------------------------
+// Round 5: the structure code of tracking_step_tree_kernel, laid out for the wavefront.  The same numbers as
+// tree_kinematics / tree_project / tree_solve above, operation for operation (the 8-body chain's poses stay equal to
+// the oracle's bit for bit), but
+//   * the adjoints by two lanes per link, kept in registers; the Jacobians by ONE LANE PER COLUMN, which carries its
+//     column down the tree in registers (the adjoint of the link in turn broadcast by v_readlane): no barrier and no LDS
+//     round trip between two links, 8 x ~80 instructions instead of 8 x two barriers -- and on the workgroup's LAST wave,
+//     which has no correspondence line to form products for: it runs beside the products, the chain and the exchange;
+//   * the system -sum J^T H J | sum J^T g by a wave per link (H J and the link's terms need no workgroup barrier in
+//     between), the (row, column) of a lower-triangle element from a table instead of integer divisions;
+//   * the joint update by twelve lanes per link, four links at a time, and the link2world chain with the next link's
+//     joint poses already loaded: DPP quad broadcasts only on the dependent path.
+// CONSTRAINED = false leaves Constraint / SoftConstraint code out of the kernel altogether (a chain never runs it; in
+// round 4 its private arrays were 40 % of the kernel's scratch instructions).
+// ---------------------------------------------------------------------------
+enum { TL_COL_OWNER = 0, TL_COL_DIR = 1, TL_PARENT = 2, TL_QUAD_FIRST = 3, TL_QUAD_MASK = 4 };
+
+__device__ __forceinline__ void tree_wave_sync() { tree_sync_mode<1>(); }
+
+// Constants of the structure, once per launch (the link table keeps its shape while a kernel runs): per lane L the link
+// and direction that own Jacobian column L (optimizer.cpp:237-250: free directions in link order), the parent of link
+// L, first Jacobian index and free-direction bits of link L / 4; the (row | column << 8) of the elements of the lower
+// triangle, column after column.  Ends without a barrier.
+__device__ __forceinline__ void tree_tables(const TreeOptDev& o, const LinkDev* links, const TreeWork& w) {
+  const int tid = threadIdx.x, nt = blockDim.x, dof = o.dof, n_links = o.n_links;
+  if (tid < kWave) {
+    int owner = -1, dir = 0;
+    for (int li = 0; li < n_links; ++li) {
+      int j = links[li].first_jacobian_index;
+      for (int d = 0; d < 6; ++d)
+        if (links[li].free_directions[d]) {
+          if (j == tid) { owner = li; dir = d; }
+          ++j;
+        }
+    }
+    w.lanes[TL_COL_OWNER * kWave + tid] = owner;
+    w.lanes[TL_COL_DIR * kWave + tid] = dir;
+    w.lanes[TL_PARENT * kWave + tid] = tid < n_links ? links[tid].parent : -1;
+    const int ql = tid >> 2;
+    int first = 0, mask = 0;
+    if (ql < n_links) {
+      first = links[ql].first_jacobian_index;
+      for (int d = 0; d < 6; ++d) mask |= links[ql].free_directions[d] ? (1 << d) : 0;
+    }
+    w.lanes[TL_QUAD_FIRST * kWave + tid] = first;
+    w.lanes[TL_QUAD_MASK * kWave + tid] = mask;
+  }
+  for (int e = tid; e < dof * dof; e += nt) {
+    const int c = e / dof, r = e - c * dof;
+    if (r >= c) w.lower[c * dof - c * (c - 1) / 2 + (r - c)] = r | (c << 8);
+  }
+}
+
+// Link::Adjoint (link.cpp:341-348) of one pose as its two blocks: [[R, 0], [skew(t) R, R]]
+struct TreeKin {
+  float R[9], TR[9];  // lane 2 li: adjoint(parent2body) of link li, lane 2 li + 1: adjoint(joint2body)
+  float own[6];       // lane c: Jacobian column c where its link sets it (link.cpp:176-180)
+};
+// Part 1 (one wave, before the Jacobians; depends on the joint poses only): the adjoints, the columns the links set
+// themselves, the Tikhonov vector (optimizer.cpp:252-271)
+__device__ __forceinline__ void tree_kin_adjoints(const TreeOptDev& o, const LinkDev* links, const TreeWork& w, TreeKin& kin,
+                                                  int tid) {
+  const int lane = tid & (kWave - 1), n_links = o.n_links;
+  const int li = lane >> 1, which = lane & 1;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { kin.R[i] = 0.0f; kin.TR[i] = 0.0f; }
+  if (li < n_links) {
+    const LinkDev& l = links[li];
+    const Affine b2j = load_pose(l.body2joint);
+    Affine m = b2j;
+    if (which == 0) m = mul_pose(load_pose(l.joint2parent), b2j);  // (a root's is never read)
+    const Affine p = inverse_pose(m);
+    float sk[9];
+    sk[0] = 0.0f;     sk[3] = -p.t[2]; sk[6] = p.t[1];
+    sk[1] = p.t[2];   sk[4] = 0.0f;    sk[7] = -p.t[0];
+    sk[2] = -p.t[1];  sk[5] = p.t[0];  sk[8] = 0.0f;
+    mul3(sk, p.l, kin.TR);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) kin.R[i] = p.l[i];
+    if (which == 1) {
+      float* ad = w.AD + (size_t)li * 72 + 36;  // R | skew(t) R of adjoint(joint2body)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { ad[i] = kin.R[i]; ad[9 + i] = kin.TR[i]; }
+    }
+  }
+  tree_wave_sync();
+  const int owner = w.lanes[TL_COL_OWNER * kWave + lane], dir = w.lanes[TL_COL_DIR * kWave + lane];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) kin.own[r] = 0.0f;
+  if (owner >= 0) {
+    // column `dir` of [[R, 0], [skew(t) R, R]]: rows 0..2 | rows 3..5
+    const float* ad = w.AD + (size_t)owner * 72 + 36;
+    const int cc = dir < 3 ? dir : dir - 3;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float top = ad[cc * 3 + r], low = ad[9 + cc * 3 + r];
+      kin.own[r] = dir < 3 ? top : 0.0f;
+      kin.own[3 + r] = dir < 3 ? low : top;
+    }
+    w.tikhonov[lane] = dir < 3 ? o.tikhonov_rotation : o.tikhonov_translation;
+  }
+}
+// Part 2: Link::CalculateJacobian (link.cpp:159-182), parents before children.  Lane c carries column c:
+// J_link[:, c] = adjoint(parent2body) J_parent[:, c] -- sum over k = 0..5 of ad(r, k) J(k, c) in that order; the upper
+// right block of the adjoint is zero, and adding a product with zero to a sum that started at +0 changes nothing -- or
+// what the link sets itself.  Ends without a barrier (the caller's workgroup barrier publishes w.J).
+__device__ __forceinline__ void tree_kin_jacobians(const TreeOptDev& o, const TreeWork& w, const TreeKin& kin, int tid) {
+  const int lane = tid & (kWave - 1), n_links = o.n_links, dof = o.dof;
+  const int parents = w.lanes[TL_PARENT * kWave + lane], owner = w.lanes[TL_COL_OWNER * kWave + lane];
+  float v[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) v[r] = 0.0f;
+  int held = -2;  // the link whose column is in v
+#pragma nounroll
+  for (int li = 0; li < n_links; ++li) {
+    const int p = __builtin_amdgcn_readlane(parents, li);
+    float nv[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) nv[r] = 0.0f;
+    if (p >= 0) {  // uniform
+      float in[6];
+      if (p == held) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) in[r] = v[r];
+      } else {  // (a branching tree: this lane's own store of the parent's column)
+        const float* Jp = w.J + (size_t)p * 6 * dof + (size_t)(lane < dof ? lane : 0) * 6;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) in[r] = Jp[r];
+      }
+      float R[9], T[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        R[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kin.R[i]), 2 * li));
+        T[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kin.TR[i]), 2 * li));
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float top = 0.0f, low = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) top += R[k * 3 + r] * in[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) low += T[k * 3 + r] * in[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) low += R[k * 3 + r] * in[3 + k];
+        nv[r] = top;
+        nv[3 + r] = low;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v[r] = owner == li ? kin.own[r] : nv[r];
+    held = li;
+    if (lane < dof) {
+      float* J = w.J + (size_t)li * 6 * dof + (size_t)lane * 6;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) J[r] = v[r];
+    }
+  }
+}
+
+// SoftConstraint::AddGradientsAndHessiansToLinks soft_constraint.cpp:113-131 (optimizer.cpp:283-284) onto a copy of
+// the link sums; thread 0, between two workgroup barriers
+__device__ __noinline__ void tree_soft_constraints(int n_soft, const SoftConstraintDev* soft, const LinkDev* links,
+                                                   float* GH) {
+  for (int si = 0; si < n_soft; ++si) {
+    const SoftConstraintDev& sc = soft[si];
+    Affine b12j1 = load_pose(sc.joint.body12joint1);
+    Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(load_pose(links[sc.joint.link1].link2world))),
+                                   load_pose(links[sc.joint.link2].link2world));
+    Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(sc.joint.body22joint2)));
+    for (int which = 0; which < 2; ++which) {
+      float g[6], h[36];
+      for (int i = 0; i < 6; ++i) g[i] = 0.0f;
+      for (int i = 0; i < 36; ++i) h[i] = 0.0f;
+      const Affine& body2joint1 = which == 0 ? b12j1 : body22joint1;
+      const float sign = which == 0 ? -1.0f : 1.0f;
+      soft_constraint_add_group(sc, true, joint22joint1, body2joint1, sign, g, h);
+      soft_constraint_add_group(sc, false, joint22joint1, body2joint1, sign, g, h);
+      float* gh = GH + (size_t)(which == 0 ? sc.joint.link1 : sc.joint.link2) * 42;
+      for (int i = 0; i < 6; ++i) gh[i] += g[i];
+      for (int i = 0; i < 36; ++i) gh[6 + i] += h[i];
+    }
+  }
+}
+
+// Optimizer::AddProjectedGradientsAndHessians (optimizer.cpp:309-321) + the Tikhonov diagonal, by the whole workgroup,
+// straight into the system of the solve (w.A lower triangle, w.b).  A wave per link: H J, then the link's terms
+// J^T g and J^T (H J) -- 6-term dots, the expressions of tree_project -- ; then one thread per element adds the links
+// one after the other.  Needs w.J (tree_kin_jacobians) and ends with a workgroup barrier.
+template <bool CONSTRAINED>
+__device__ __forceinline__ void tree_system_fast(const TreeOptDev& o, const LinkDev* links, const TreeWork& w,
+                                                 const float* gh_links, int tid) {
+  const int nt = blockDim.x, wave = tid >> 6, lane = tid & (kWave - 1), n_waves = nt >> 6;
+  const int dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
+  const int n_lower = dof * (dof + 1) / 2, stride = dof + n_lower;
+  const float* GH = gh_links;
+  if constexpr (CONSTRAINED) {
+    // (the pivoted in-place factorisation may run: everything below the diagonal is read, the constraint block too)
+    for (int e = tid; e < size * size; e += nt) w.A[e] = 0.0f;
+    for (int i = dof + tid; i < size; i += nt) w.b[i] = 0.0f;
+    if (o.n_soft > 0) {
+      GH = w.GH;
+      for (int e = tid; e < n_links * 42; e += nt) w.GH[e] = gh_links[e];
+      __syncthreads();
+      if (tid == 0) tree_soft_constraints(o.n_soft, o.soft, links, w.GH);
+      __syncthreads();
+    }
+  }
+  for (int li = wave; li < n_links; li += n_waves) {
+    const float* g = GH + (size_t)li * 42;
+    const float* H = g + 6;
+    const float* J = w.J + (size_t)li * 6 * dof;
+    float* HJ = w.HJ + (size_t)li * 6 * dof;
+    for (int e = lane; e < 6 * dof; e += kWave) {
+      const int c = e / 6, r = e - c * 6;
+      float sacc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sacc += H[k * 6 + r] * J[c * 6 + k];
+      HJ[e] = sacc;
+    }
+    tree_wave_sync();
+    for (int x = lane; x < stride; x += kWave) {
+      float sacc = 0.0f;
+      if (x < dof) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sacc += J[x * 6 + k] * g[k];
+      } else {
+        const int rc = w.lower[x - dof], r = rc & 255, c = rc >> 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sacc += J[r * 6 + k] * HJ[c * 6 + k];
+      }
+      w.terms[(size_t)li * stride + x] = sacc;
+    }
+  }
+  __syncthreads();
+  for (int x = tid; x < stride; x += nt) {
+    float acc = 0.0f;
+    if (x < dof) {
+      for (int li = 0; li < n_links; ++li) acc += w.terms[(size_t)li * stride + x];
+      w.b[x] = acc;
+    } else {
+      const int rc = w.lower[x - dof], r = rc & 255, c = rc >> 8;
+      for (int li = 0; li < n_links; ++li) acc -= w.terms[(size_t)li * stride + x];
+      if (r == c) acc += w.tikhonov[c];
+      w.A[(size_t)c * size + r] = acc;
+    }
+  }
+  __syncthreads();
+}
+
+// The rest of Optimizer::CalculateOptimization + Link::UpdatePoses (link.cpp:205-241) on the workgroup's FIRST wave:
+// constraint rows (CONSTRAINED), LDL^T, NaN guard, exp() with four lanes per link, the joints, link2world down the
+// tree.  w.A / w.b hold the assembled system.  False when the NaN guard skipped the update.
+template <bool CONSTRAINED>
+__device__ __forceinline__ bool tree_solve_fast(const TreeOptDev& o, LinkDev* links, const TreeWork& w, int tid) {
+  const int lane = tid & (kWave - 1), dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
+  PHASE_T0();
+  float* A = w.A;
+  float* b = w.b;
+  if constexpr (CONSTRAINED) {  // Constraint::CalculateResidualAndConstraintJacobian constraint.cpp:81-102
+    int idx = dof;
+    for (int ci = 0; ci < o.n_constraints; ++ci) {
+      const ConstraintDev& c = o.constraints[ci];
+      const int n_c = c.n;
+      if (lane == 0) {
+        Affine b12j1 = load_pose(c.body12joint1);
+        Affine body22joint1 = mul_pose(mul_pose(b12j1, inverse_pose(load_pose(links[c.link1].link2world))),
+                                       load_pose(links[c.link2].link2world));
+        Affine joint22joint1 = mul_pose(body22joint1, inverse_pose(load_pose(c.body22joint2)));
+        float angle, axis[3];
+        angle_axis(joint22joint1.l, &angle, axis);
+        float rv[3] = {angle * axis[0], angle * axis[1], angle * axis[2]};
+        int ri = 0;
+        for (int d = 0; d < 6; ++d)
+          if (c.directions[d]) w.cres[ri++] = d < 3 ? rv[d] : joint22joint1.t[d - 3];
+        constraint_unprojected_jacobian(c, joint22joint1, body22joint1, w.j2);
+        constraint_unprojected_jacobian(c, joint22joint1, b12j1, w.j1);
+      }
+      tree_wave_sync();
+      const float* J1 = w.J + (size_t)c.link1 * 6 * dof;
+      const float* J2 = w.J + (size_t)c.link2 * 6 * dof;
+      for (int e = lane; e < dof * n_c; e += kWave) {
+        const int col = e / n_c, r = e - col * n_c;
+        float s2 = 0.0f, s1 = 0.0f;
+        for (int k = 0; k < 6; ++k) {
+          s2 += w.j2[k * n_c + r] * J2[(size_t)col * 6 + k];
+          s1 += w.j1[k * n_c + r] * J1[(size_t)col * 6 + k];
+        }
+        A[(size_t)col * size + idx + r] = -(s2 - s1);  // AddResidualsAndConstraintJacobians optimizer.cpp:323-333
+      }
+      if (lane < n_c) b[idx + lane] = w.cres[lane];
+      tree_wave_sync();
+      idx += n_c;
+    }
+  }
+  PHASE_MARK(12);
+  ldlt_solve_any<true>(A, b, size, w.temp, w.trans, lane);
+  PHASE_MARK(13);
+  int has_nan = 0;
+  for (int i = lane; i < size; i += kWave) has_nan |= (b[i] != b[i]) ? 1 : 0;
+  if (__builtin_amdgcn_ballot_w64(has_nan != 0) != 0) return false;  // NaN guard optimizer.cpp:165
+  // the variations of all links: four lanes per link, lane c < 3 of the group works out column c of
+  // exp(skew(theta_r)) (colexpm3: the oracle's Expm3 operation for operation), lane 3 carries the translation
+  float* var_all = w.AD;  // [n_links][12]: l[9] | t[3]
+  {
+    const int li = lane >> 2, c = lane & 3;
+    if (li < n_links) {
+      const int first = w.lanes[TL_QUAD_FIRST * kWave + lane], mask = w.lanes[TL_QUAD_MASK * kWave + lane];
+      float th[6];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {
+        const int j = first + __builtin_popcount(mask & ((1 << d) - 1));
+        const float t = b[(mask >> d) & 1 ? j : 0];
+        th[d] = (mask >> d) & 1 ? t : 0.0f;
+      }
+      float K[9], col[3];
+      K[0] = 0.0f;   K[3] = -th[2]; K[6] = th[1];
+      K[1] = th[2];  K[4] = 0.0f;   K[7] = -th[0];
+      K[2] = -th[1]; K[5] = th[0];  K[8] = 0.0f;
+      colexpm3<true>(K, c, col);
+      float* v = var_all + (size_t)li * 12;
+      if (c == 3) { col[0] = th[3]; col[1] = th[4]; col[2] = th[5]; }
+      v[c * 3] = col[0]; v[c * 3 + 1] = col[1]; v[c * 3 + 2] = col[2];
+    }
+  }
+  tree_wave_sync();
+  PHASE_MARK(14);
+  // out(k, c) = (P(k,0) b0 + P(k,1) b1) + P(k,2) b2 [+ P(k,3) for the translation column], b = column c of the right
+  // factor: mul_pose's expression for element (k, c), the row's four values by DPP quad broadcasts
+  const int qc = lane & 3;
+  auto quadmul = [&](float P, float b0, float b1, float b2) {
+    const float p0 = quad_lane<0>(P), p1 = quad_lane<1>(P), p2 = quad_lane<2>(P), p3 = quad_lane<3>(P);
+    const float v = (p0 * b0 + p1 * b1) + p2 * b2;
+    return qc == 3 ? v + p3 : v;
+  };
+  // the joints: joint2parent <- joint2parent * variation (fixed body2joint), or body2joint <- variation * body2joint;
+  // twelve lanes per link (element (k, c) in lane 4 k + c of a row of sixteen), four links at a time
+  for (int base = 0; base < n_links; base += 4) {
+    const int li = base + (lane >> 4), q = lane & 15, k = q >> 2, kk = k < 3 ? k : 0;
+    if (li < n_links && links[li].parent >= 0) {  // (the same in all lanes of a row)
+      LinkDev& l = links[li];
+      const float* v = var_all + (size_t)li * 12;
+      const bool fixed = l.fixed_body2joint_pose != 0;
+      float* M = fixed ? l.joint2parent : l.body2joint;
+      const float m_own = M[qc * 4 + kk], m0 = M[qc * 4], m1 = M[qc * 4 + 1], m2 = M[qc * 4 + 2];
+      const float v_own = v[qc * 3 + kk], v0 = v[qc * 3], v1 = v[qc * 3 + 1], v2 = v[qc * 3 + 2];
+      const float r = fixed ? quadmul(m_own, v0, v1, v2) : quadmul(v_own, m0, m1, m2);
+      if (k < 3) M[qc * 4 + k] = r;
+      if (q < 4) M[q * 4 + 3] = q == 3 ? 1.0f : 0.0f;
+    }
+  }
+  tree_wave_sync();
+  // link2world, parents before children: (parent's link2world * joint2parent) * body2joint, left to right like the
+  // reference.  Twelve lanes hold a pose; a child whose parent was the previous link takes the parent's pose from the
+  // registers it was just formed in; the next link's joint poses are loaded before this link's pose is stored.
+  {
+    const int k = (lane >> 2) < 3 ? (lane >> 2) : 0, c = qc;
+    const bool holds = lane < 12;
+    // (volatile LDS loads + the scheduling barrier below: the compiler otherwise moves them to their use)
+    typedef const volatile __attribute__((address_space(3))) float* LdsVF;
+    typedef const volatile __attribute__((address_space(3))) int* LdsVI;
+    float d0, d1, d2, e0, e1, e2;
+    int parent;
+    auto fetch = [&](int li) {
+      LdsVF B1 = (LdsVF)links[li].joint2parent;
+      LdsVF B2 = (LdsVF)links[li].body2joint;
+      d0 = B1[c * 4]; d1 = B1[c * 4 + 1]; d2 = B1[c * 4 + 2];
+      e0 = B2[c * 4]; e1 = B2[c * 4 + 1]; e2 = B2[c * 4 + 2];
+      parent = *(LdsVI)&links[li].parent;
+    };
+    fetch(0);
+    float cur = 0.0f;
+    int cur_link = -2;
+#pragma nounroll
+    for (int li = 0; li < n_links; ++li) {
+      LinkDev& l = links[li];
+      const float f0 = d0, f1 = d1, f2 = d2, g0 = e0, g1 = e1, g2 = e2;
+      const int p = __builtin_amdgcn_readfirstlane(parent);
+      if (li + 1 < n_links) fetch(li + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      float result;
+      if (p >= 0) {
+        const float P = p == cur_link ? cur : links[p].link2world[c * 4 + k];
+        result = quadmul(quadmul(P, f0, f1, f2), g0, g1, g2);
+      } else {
+        // a root: link2world <- ((link2world * body2joint^-1) * variation) * body2joint (link.cpp:226-230)
+        const float* v = var_all + (size_t)li * 12;
+        const Affine inv = inverse_pose(load_pose(l.body2joint));
+        // (column c of the inverse by selects: an indexed private array would live in scratch memory)
+        const float i0 = c == 0 ? inv.l[0] : (c == 1 ? inv.l[3] : (c == 2 ? inv.l[6] : inv.t[0]));
+        const float i1 = c == 0 ? inv.l[1] : (c == 1 ? inv.l[4] : (c == 2 ? inv.l[7] : inv.t[1]));
+        const float i2 = c == 0 ? inv.l[2] : (c == 1 ? inv.l[5] : (c == 2 ? inv.l[8] : inv.t[2]));
+        const float T = l.link2world[c * 4 + k];
+        result = quadmul(quadmul(quadmul(T, i0, i1, i2), v[c * 3], v[c * 3 + 1], v[c * 3 + 2]), g0, g1, g2);
+      }
+      if (holds) l.link2world[c * 4 + k] = result;
+      if (lane < 4) l.link2world[lane * 4 + 3] = lane == 3 ? 1.0f : 0.0f;
+      cur = result;
+      cur_link = li;
+    }
+    tree_wave_sync();
+  }
+  PHASE_MARK(15);
+  return true;
+}
+
+// ---------------------------------------------------------------------------
 // Tracker::ExecuteTrackingStep (tracker.cpp:344-364) for kinematic structures in ONE launch: one workgroup per link
 // that carries modalities runs that body's correspondence searches, products and reference-order sums (the device
 // functions of tracking_step_kernel); per Newton step the workgroups of a structure hand each other their link's 42
@@ -1007,19 +1421,38 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
 // launches per frame (8-body chain, 7 x 2 iterations).  All workgroups of the grid must be resident (checked by the
 // host); a wait that runs out abandons the step and raises the context's abort word like the split kernel does.
 // ---------------------------------------------------------------------------
-extern "C" {
-
-__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
-tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
-                          const DepthModDev* dmods, const CameraDev* cams, float* body_poses, TrackLdsLayout layout,
-                          int off_points, int np, int off_tree, int iteration, int n_corr_iterations,
-                          int n_update_iterations, int fuse_histogram, TreeStepParams xp) {
+template <bool CONSTRAINED>
+__device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
+                                               const DepthModDev* dmods, const CameraDev* cams, float* body_poses,
+                                               TrackLdsLayout layout, int off_points, int np, int off_tree, int iteration,
+                                               int n_corr_iterations, int n_update_iterations, int fuse_histogram,
+                                               TreeStepParams xp) {
   extern __shared__ __attribute__((aligned(16))) float lds_tree[];
-  const TreeStepDev& st = steps[blockIdx.x];
-  const TreeOptDev& o = opts[st.opt];
+  // the workgroup's and the structure's parameters through the constant address space: scalar loads, the values in
+  // SGPRs for the whole launch (round 4 read them with per-lane loads: every field a VGPR alive across the search loop
+  // -- 119 spill stores in front of it)
+  typedef const __attribute__((address_space(4))) TreeStepDev CTreeStep;
+  typedef const __attribute__((address_space(4))) TreeOptDev CTreeOpt;
+  CTreeStep& stc = *(CTreeStep*)(steps + blockIdx.x);
+  TreeStepDev st;
+  st.opt = stc.opt; st.link = stc.link; st.tracked = stc.tracked;
+  st.region_modality = stc.region_modality; st.depth_modality = stc.depth_modality; st.region_first = stc.region_first;
+  CTreeOpt& oc = *(CTreeOpt*)(opts + st.opt);
+  TreeOptDev o;
+  o.n_links = oc.n_links; o.links = oc.links; o.dof = oc.dof;
+  o.n_constraints = oc.n_constraints; o.constraints = oc.constraints; o.n_rows = oc.n_rows;
+  o.n_soft = oc.n_soft; o.soft = oc.soft;
+  o.tikhonov_rotation = oc.tikhonov_rotation; o.tikhonov_translation = oc.tikhonov_translation;
+  o.work = oc.work; o.partial = oc.partial;
+  o.n_tracked = oc.n_tracked; o.tracked_links = oc.tracked_links; o.exchange = oc.exchange;
+  if constexpr (!CONSTRAINED) { o.n_constraints = 0; o.n_rows = 0; o.n_soft = 0; }
   CRegion* rm = st.region_modality >= 0 ? (CRegion*)(rmods + st.region_modality) : nullptr;
   CDepth* dm = st.depth_modality >= 0 ? (CDepth*)(dmods + st.depth_modality) : nullptr;
   const int tid = threadIdx.x, nt = blockDim.x, n_links = o.n_links, dof = o.dof;
+  // the last wave has no correspondence line to form products for (216 slots at most): it keeps the structure's
+  // kinematics; the first runs the chain and the solve
+  const int kin_first = nt - kWave;
+  const bool kin_wave = tid >= kin_first;
   Lds s = carve(lds_tree, layout);
   float* ps = lds_tree + off_points;
   float* rows_r = lds_tree + layout.off_rows_r;
@@ -1041,8 +1474,9 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
     const int li = i >> 4;
     if (links[li].body >= 0) links[li].link2world[i & 15] = body_poses[16 * links[li].body + (i & 15)];
   }
+  tree_tables(o, links, w);
   __syncthreads();
-  float* pose = links[st.link].link2world;  // this workgroup's body2world, kept current by its own tree_solve
+  float* pose = links[st.link].link2world;  // this workgroup's body2world, kept current by its own solve
   CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
   CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
   CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
@@ -1071,7 +1505,20 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
       }
     }
     for (int u = 0; u < n_update_iterations; ++u, ++round) {
+      PHASE_T0();
       const Affine b2w = load_pose(pose);
+      // The structure code addresses LDS by thread: left alone, the compiler works all those addresses out once, in
+      // front of the search loop, keeps them alive across it and spills them (round 4: 119 stores there, the reloads
+      // on the first wave's serial path).  An opaque copy of the thread index per Newton step keeps them where they
+      // are used.
+      int ltid = tid;
+      asm volatile("" : "+v"(ltid));
+      TreeKin kin;
+      if (kin_wave) {
+        // adjoints of the structure (they depend on the joint poses only) beside the other waves' products
+        tree_kin_adjoints(o, links, w, kin, ltid);
+        PHASE_MARK_BY(17, kin_first);
+      }
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         region_products(*rm, *cam, b2c, c, u, s, rows_r, layout.pitch_r);
@@ -1081,45 +1528,49 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
         depth_products(*dm, b2c, c, ps, np, rows_d, layout.pitch_d);
       }
       __syncthreads();
+      PHASE_MARK(5);
       const uint32_t tag = xp.seq * 64u + (uint32_t)round + 1u;
       auto* slot = granules + (size_t)(round & 1) * o.n_tracked * M3T_TREE_GRANULES;
-      if (tid >= kWave && tid < 2 * kWave) {
-        // the second wave: adjoints and Jacobians of the structure (they depend on the joint poses only) while the
-        // first wave runs down this link's sums and the other links' sums are on their way
-        tree_kinematics<1>(o, links, w);
-      }
-      if (tid < kWave) {  // one wave: the sums in the reference's order, the link's sum, publish
-        float sum_r = 0.0f, sum_d = 0.0f;
-        chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
-                   chain_slots(np), gh_lane_row(tid < 42 ? tid : 0), sum_r, sum_d);
-        float gh = 0.0f;  // Link::CalculateGradientAndHessian link.cpp:184-193, in the order of Link::modalities
-        if (rm && dm && !st.region_first) { gh += sum_d; gh += sum_r; }
-        else { if (rm) gh += sum_r; if (dm) gh += sum_d; }
-        if (tid < 42) {
-          gh_links[st.link * 42 + tid] = gh;
-          __hip_atomic_store(slot + (size_t)st.tracked * M3T_TREE_GRANULES + tid,
-                             (static_cast<unsigned long long>(tag) << 32) | (unsigned)__float_as_int(gh),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      // collect the other tracked links' sums (one granule per thread and trip, re-read until its tag matches)
       bool timed_out = false;
-      for (int idx = tid; idx < o.n_tracked * 42; idx += nt) {
-        const int t = idx / 42, i = idx - t * 42;
-        if (t == st.tracked) continue;
-        auto* g = slot + (size_t)t * M3T_TREE_GRANULES + i;
-        unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (static_cast<uint32_t>(v >> 32) != tag) {
-          if (++spins > (1u << 12) ||
-              ((spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xp.seq)) {
-            timed_out = true;
-            break;
+      if (kin_wave) {
+        // ... and the Jacobians, a column per lane, while the first wave runs down this link's sums and the other
+        // links' sums are on their way
+        tree_kin_jacobians(o, w, kin, ltid);
+        PHASE_MARK_BY(18, kin_first);
+      } else {
+        if (tid < kWave) {  // one wave: the sums in the reference's order, the link's sum, publish
+          float sum_r = 0.0f, sum_d = 0.0f;
+          chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
+                     chain_slots(np), gh_lane_row(ltid < 42 ? ltid : 0), sum_r, sum_d);
+          float gh = 0.0f;  // Link::CalculateGradientAndHessian link.cpp:184-193, in the order of Link::modalities
+          if (rm && dm && !st.region_first) { gh += sum_d; gh += sum_r; }
+          else { if (rm) gh += sum_r; if (dm) gh += sum_d; }
+          if (tid < 42) {
+            gh_links[st.link * 42 + ltid] = gh;
+            __hip_atomic_store(slot + (size_t)st.tracked * M3T_TREE_GRANULES + ltid,
+                               (static_cast<unsigned long long>(tag) << 32) | (unsigned)__float_as_int(gh),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          __builtin_amdgcn_s_sleep(1);
-          v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          PHASE_MARK(23);
         }
-        gh_links[o.tracked_links[t] * 42 + i] = __int_as_float(static_cast<int>(static_cast<uint32_t>(v)));
+        // collect the other tracked links' sums (one granule per thread and trip, re-read until its tag matches)
+        for (int idx = ltid; idx < o.n_tracked * 42; idx += kin_first) {
+          const int t = idx / 42, i = idx - t * 42;
+          if (t == st.tracked) continue;
+          auto* g = slot + (size_t)t * M3T_TREE_GRANULES + i;
+          unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned spins = 0;
+          while (static_cast<uint32_t>(v >> 32) != tag) {
+            if (++spins > (1u << 12) ||
+                ((spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xp.seq)) {
+              timed_out = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          gh_links[o.tracked_links[t] * 42 + i] = __int_as_float(static_cast<int>(static_cast<uint32_t>(v)));
+        }
       }
       if (__syncthreads_or(timed_out ? 1 : 0)) {
         if (tid == 0) {
@@ -1128,16 +1579,14 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
         }
         return;
       }
-      {  // Optimizer::CalculateOptimization + UpdatePoses on this workgroup's copy of the structure: the sums by all
-         // threads (the barrier above also says that the second wave's Jacobians are there), the solve and the pose
-         // updates -- short dependent stages -- by the first wave
-        PHASE_T0();
-        tree_system_block(o, links, w, gh_links);
-        PHASE_MARK(30);
-        if (tid < kWave) (void)tree_solve<1>(o, links, w, nullptr, nullptr, 0, true);
-        PHASE_MARK(31);
-      }
+      PHASE_MARK(22);
+      // Optimizer::CalculateOptimization + UpdatePoses on this workgroup's copy of the structure: the sums by all
+      // waves, the solve and the pose updates -- short dependent stages -- by the first
+      tree_system_fast<CONSTRAINED>(o, links, w, gh_links, ltid);
+      PHASE_MARK(30);
+      if (tid < kWave) (void)tree_solve_fast<CONSTRAINED>(o, links, w, ltid);
       __syncthreads();
+      PHASE_MARK(31);
     }
   }
   if (rm && tid == 0) *as_global_w(rm->last_view) = region_view;
@@ -1155,6 +1604,7 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
     }
   }
   if (fuse_histogram && rm) {  // RegionModality::CalculateResults :572-583 in the same launch
+    PHASE_T0();
     const Affine b2w = load_pose(pose);
     __syncthreads();
     const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
@@ -1164,7 +1614,30 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
     region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
                             (__attribute__((address_space(3))) uint32_t*)(lds_tree + M3T_MISC_FLOATS), lds_tree, 0, -1,
                             nullptr, 0, 0, region_view);
+    PHASE_MARK(26);
   }
+}
+
+extern "C" {
+
+// kinematic structures without Constraint / SoftConstraint objects (a chain, a tree): no constraint code in the kernel
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
+                          const DepthModDev* dmods, const CameraDev* cams, float* body_poses, TrackLdsLayout layout,
+                          int off_points, int np, int off_tree, int iteration, int n_corr_iterations,
+                          int n_update_iterations, int fuse_histogram, TreeStepParams xp) {
+  tree_step_body<false>(steps, opts, rmods, dmods, cams, body_poses, layout, off_points, np, off_tree, iteration,
+                        n_corr_iterations, n_update_iterations, fuse_histogram, xp);
+}
+// ... and with them (closed chains: constraint rows, an indefinite system; soft constraints onto the link sums)
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_tree_constrained_kernel(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
+                                      const DepthModDev* dmods, const CameraDev* cams, float* body_poses,
+                                      TrackLdsLayout layout, int off_points, int np, int off_tree, int iteration,
+                                      int n_corr_iterations, int n_update_iterations, int fuse_histogram,
+                                      TreeStepParams xp) {
+  tree_step_body<true>(steps, opts, rmods, dmods, cams, body_poses, layout, off_points, np, off_tree, iteration,
+                       n_corr_iterations, n_update_iterations, fuse_histogram, xp);
 }
 
 __global__ void __launch_bounds__(64)

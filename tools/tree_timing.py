@@ -26,6 +26,28 @@ n = 4
 for k in range(4, 8):
     ch.upload(inputs, k); ch.tracker.ExecuteTrackingStep(k)
 f(hip.ctx, buf, 1)
-for i in range(32):
+NAMES = {
+    0: "search: view", 1: "search: phase A (lines)", 2: "search: phase B (pixels)", 3: "search: phase C1 (distributions)",
+    4: "search: phase C2 (normalisation)",
+    7: "  B: addresses + pixel load issue", 8: "  B: pixel wait", 9: "  B: gather issue", 10: "  B: gather wait",
+    11: "  B: products",
+    5: "Newton: g/H products + barrier (all waves; last wave: adjoints)",
+    17: "  last wave: adjoints of all links", 18: "  last wave: Jacobians, a column per lane",
+    23: "Newton: g/H chain (42 lanes) + publish", 22: "Newton: collect the other links' sums + barrier",
+    30: "Newton: system -sum J^T H J | sum J^T g (wave per link)",
+    31: "Newton: solve + pose updates (first wave) + barrier",
+    12: "  solve: constraint rows", 13: "  solve: LDL^T", 14: "  solve: exp() of the variations",
+    15: "  solve: joints + link2world down the tree",
+    19: "  (round 4) H J", 20: "  (round 4) terms + sums",
+    26: "histogram update (tail)", 27: "  tail: view", 28: "  tail: occlusion windows", 29: "  tail: pixel walk",
+}
+ORDER = [0, 1, 2, 7, 8, 9, 10, 11, 3, 4, 5, 17, 18, 23, 22, 30, 19, 20, 31, 12, 13, 14, 15, 26, 27, 28, 29]
+print("tracking_step_tree_kernel, 8-body chain (13 dof), s_memtime ticks per frame of workgroup 0 (7 searches, 14 Newton steps)")
+top = 0
+for i in ORDER + [j for j in range(32) if j not in ORDER]:
     if buf[i]:
-        print("phase %2d: %9.0f cycles/frame" % (i, buf[i] / n))
+        name = NAMES.get(i, "phase %d" % i)
+        print("%-66s %9.0f" % (name, buf[i] / n))
+        if not name.startswith("  "):
+            top += buf[i] / n
+print("%-66s %9.0f" % ("sum of the top-level phases", top))
