@@ -11,7 +11,7 @@ The directory name starts with a digit, so import it with
 """
 import os
 
-from . import batch, config, evaluation, generator, host, sharding, synthetic  # noqa: F401
+from . import config, evaluation, generator, host, sharding, synthetic  # noqa: F401
 from ._capi import CApi, M3TError  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -306,6 +306,7 @@ _HIP_ONLY = {
     "comm_destroy": [],
     "calculate_optimization_allreduce": [],
     "comm_get_allreduce_count": [C.POINTER(C.c_longlong)],
+    "comm_get_rank_count": [C.POINTER(C.c_int)],
     "cameras_set_ring": [c_int_p, C.c_int, C.c_int],
     "cameras_upload_batch_async": [c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t],
     "set_roi_ingest": [C.c_int, C.c_float],
@@ -341,7 +342,7 @@ def pose_ret(buf):
     return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
 
 
-_NEWER_ENTRY_POINTS = ("get_step_kernel", "comm_get_allreduce_count", "debug_log_checksum", "set_roi_ingest",
+_NEWER_ENTRY_POINTS = ("get_step_kernel", "comm_get_allreduce_count", "comm_get_rank_count", "debug_log_checksum", "set_roi_ingest",
                        "cameras_upload_batch_roi_async", "roi_get_status", "reserve_ingest_cus", "camera_slot_sync")
 
 

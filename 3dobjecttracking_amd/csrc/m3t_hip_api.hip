@@ -308,6 +308,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
@@ -319,6 +320,7 @@ struct Rccl {
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(handle, "ncclCommCount"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce) { error = "librccl.so.1 lacks the nccl* entry points"; AllReduce = nullptr; return false; }
@@ -3833,6 +3835,18 @@ int m3t_hip_comm_get_allreduce_count(m3t_hip_context* ctx, long long* count) {
   CHECK_CTX();
   REQUIRE(count, M3T_ERR_INVALID_ARGUMENT, "null output");
   *count = ctx->allreduce_calls;
+  return M3T_OK;
+}
+int m3t_hip_comm_get_rank_count(m3t_hip_context* ctx, int* n_ranks) {
+  CHECK_CTX();
+  REQUIRE(n_ranks, M3T_ERR_INVALID_ARGUMENT, "null output");
+  *n_ranks = 0;
+  if (!ctx->comm) return M3T_OK;
+  REQUIRE(g_rccl.Load() && g_rccl.CommCount, M3T_ERR_UNSUPPORTED, "ncclCommCount is not available in the loaded librccl");
+  const ncclResult_t rc = g_rccl.CommCount(ctx->comm, n_ranks);
+  if (rc != ncclSuccess)
+    return Fail(ctx, M3T_ERR_DEVICE,
+                std::string("ncclCommCount: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
   return M3T_OK;
 }
 int m3t_hip_get_step_kernel(m3t_hip_context* ctx, char* name, size_t capacity) {

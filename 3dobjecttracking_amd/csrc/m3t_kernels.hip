@@ -234,9 +234,13 @@ __device__ __forceinline__ bool view_direction(const Affine& b2c, float& o0, flo
 // is the argmax over the row: the same dot products (same expression, same operands), the largest, the lowest index
 // among equals -- the result of the full scan, bit for bit.  Outside it: -1, the caller scans all views.  Every wave
 // works the row out for itself (19 lanes): no LDS, no barrier.
+// LEAN (tracking_step_tree_kernel, which has no register to spare): the lane goes through an empty asm, so that the row
+// offset is worked out here and not once in front of the caller's loops -- one VGPR pair less alive across them.  The
+// other kernels keep the plain form: with it the 64-object step measured 2.5 % slower (r05a, same process).
+template <bool LEAN = false>
 __device__ __forceinline__ int closest_view_local(G<v4f> neighbors, int prev, float o0, float o1, float o2) {
   int lane = threadIdx.x & (kWave - 1);
-  asm volatile("" : "+v"(lane));  // (the row offset is worked out here, not in front of the caller's loops: one VGPR pair less alive across them)
+  if constexpr (LEAN) asm volatile("" : "+v"(lane));
   const v4f e = neighbors[(uint32_t)prev * M3T_VIEW_ROW + (lane < M3T_VIEW_ROW ? lane : 0)];
   float d = (o0 * e.x + o1 * e.y) + o2 * e.z;
   const float d_prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 0));
@@ -759,7 +763,7 @@ constexpr int kExchangeFieldBits = 5;
 
 // RENDER = false: a launch shape that never runs with renderer-fed branches (the split kernel: m3t_hip_api.hip takes
 // the per-search launches of tracking_step_kernel as soon as a modality reads a rendering) leaves their code out
-template <bool HIST_LDS, int BMAX = 8, bool RENDER = true>
+template <bool HIST_LDS, int BMAX = 8, bool RENDER = true, bool LEAN = false>
 __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                        const Affine& b2dc, int iteration, int corr_iteration,
                                                        const Lds& s, int line_lo = 0, int line_hi = 1 << 30,
@@ -782,7 +786,7 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   int view = -1;
   if (prev_view >= 0 && m.view_neighbors != nullptr) {
     float o0, o1, o2;
-    if (view_direction(b2c, o0, o1, o2)) view = closest_view_local((G<v4f>)m.view_neighbors, prev_view, o0, o1, o2);
+    if (view_direction(b2c, o0, o1, o2)) view = closest_view_local<LEAN>((G<v4f>)m.view_neighbors, prev_view, o0, o1, o2);
   }
   if (view < 0) view = closest_view((G<v4f>)m.orientations4, m.n_views, b2c, s.misc);  // block-uniform; two barriers
   PHASE_MARK(0);
@@ -944,8 +948,14 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
     }
     __syncthreads();
     my_valid_occ = 0;  // counted from the flags now
+    // (LEAN: the loops over a thread's lines stay rolled -- at most one trip at 200 lines and 512 threads; unrolled by
+    // eight their trip-count bookkeeping sits in front of the caller's loops, a VGPR each)
+    if constexpr (LEAN) {
 #pragma nounroll
-    for (int line = tid; line < nl; line += nt) my_valid_occ += f2i_bits(s.state[LS_VALID * nl + line]) & 1;
+      for (int line = tid; line < nl; line += nt) my_valid_occ += f2i_bits(s.state[LS_VALID * nl + line]) & 1;
+    } else {
+      for (int line = tid; line < nl; line += nt) my_valid_occ += f2i_bits(s.state[LS_VALID * nl + line]) & 1;
+    }
   }
   // two-pass fallback :435-463: use the occlusion-handled set only if it has enough lines
   bool use_occ = false;
@@ -1080,12 +1090,18 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   }
   // the final flag (bit 0 = line is in data_lines_), for the lines of all parts: it follows from phase A, which every
   // workgroup ran in full.  (Threads above may still test `flags & valid_mask`: bit 0 only ever takes that test's value.)
-  if (!defer_vote)
-#pragma nounroll
-    for (int line = tid; line < nl; line += nt) {
+  if (!defer_vote) {
+    auto final_flag = [&](int line) {
       const int flags = f2i_bits(s.state[LS_VALID * nl + line]);
       s.state[LS_VALID * nl + line] = i2f_bits((flags & ~1) | ((flags & valid_mask) ? 1 : 0));
+    };
+    if constexpr (LEAN) {
+#pragma nounroll
+      for (int line = tid; line < nl; line += nt) final_flag(line);
+    } else {
+      for (int line = tid; line < nl; line += nt) final_flag(line);
     }
+  }
   __syncthreads();
   PHASE_MARK(4);
   return view;  // the closest view (a depth modality of the same body with the same view table and camera pose reuses it)
@@ -2203,10 +2219,10 @@ __device__ __forceinline__ void depth_correspondences_scan(CDepth& m, CCam& cam,
   __syncthreads();
 }
 
-template <bool RENDER = true>
+template <bool RENDER = true, bool LEAN = false>
 __device__ __forceinline__ void depth_correspondences_vote(CDepth& m, int iteration, float* ps, int np, float* misc) {
   int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));  // (the flag addresses are formed here, not once in front of the caller's loops)
+  if constexpr (LEAN) asm volatile("" : "+v"(tid));  // (the flag addresses are formed here, not once in front of the caller's loops)
   const int nt = blockDim.x;
   const bool handle_occlusions = (iteration - m.first_iteration) >= m.n_unoccluded_iterations;
   const bool measured_pass = m.measure_occlusions && handle_occlusions;
@@ -2215,8 +2231,12 @@ __device__ __forceinline__ void depth_correspondences_vote(CDepth& m, int iterat
   bool use_occ = false;
   if (measured_pass || modeled_pass) {
     int mine = 0;
+    if constexpr (LEAN) {
 #pragma nounroll
-    for (int i = tid; i < np; i += nt) mine += f2i_bits(ps[PS_VALID * np + i]) & 1;
+      for (int i = tid; i < np; i += nt) mine += f2i_bits(ps[PS_VALID * np + i]) & 1;
+    } else {
+      for (int i = tid; i < np; i += nt) mine += f2i_bits(ps[PS_VALID * np + i]) & 1;
+    }
     int cnt = wave_sum_i(mine);
     int* imisc = reinterpret_cast<int*>(misc);
     if (tid % kWave == 0) imisc[64 + tid / kWave] = cnt;
@@ -2226,10 +2246,15 @@ __device__ __forceinline__ void depth_correspondences_vote(CDepth& m, int iterat
     use_occ = total >= m.min_n_unoccluded_points;
   }
   const int valid_mask = use_occ ? 1 : 2;
-#pragma nounroll
-  for (int i = tid; i < np; i += nt) {
+  auto final_flag = [&](int i) {
     int flags = f2i_bits(ps[PS_VALID * np + i]);
     ps[PS_VALID * np + i] = i2f_bits((flags & ~1) | ((flags & valid_mask) ? 1 : 0));
+  };
+  if constexpr (LEAN) {
+#pragma nounroll
+    for (int i = tid; i < np; i += nt) final_flag(i);
+  } else {
+    for (int i = tid; i < np; i += nt) final_flag(i);
   }
   __syncthreads();
 }

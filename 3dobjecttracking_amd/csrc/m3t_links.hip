@@ -1491,15 +1491,15 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_view = region_correspondences<false>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, 0, 1 << 30, nullptr,
-                                                    region_view);
+        region_view = region_correspondences<false, 8, true, true>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, 0, 1 << 30,
+                                                                   nullptr, region_view);
         region_moments(*rm, s);
       }
       if (dm) {
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
         depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, 0, 1 << 30,
                                    (rm && dm->view_search_shared) ? region_view : -1);
-        depth_correspondences_vote(*dm, iteration, ps, np, s.misc);
+        depth_correspondences_vote<true, true>(*dm, iteration, ps, np, s.misc);
       } else {
         __syncthreads();
       }

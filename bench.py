@@ -88,6 +88,11 @@ def parse():
     p.add_argument("--no-buckets", action="store_true",
                    help="skip the one-launch-per-sub-step leg (profiling runs: only the timed kernels are launched)")
     p.add_argument("--sweep", type=str, default="", help="comma separated object counts for a batch sweep (extra)")
+    p.add_argument("--rank-share", type=str, default="",
+                   help="comma separated GPU counts N (e.g. 1,2,4,8): measure rank 0's share of the configuration -- the "
+                        "objects rank_plan() gives it at N ranks, or the chain's distributed path with the modalities "
+                        "of bodies i mod N == 0 -- ALONE on this one GPU and emit `projected_scaling` (a projection: "
+                        "no transport, no barrier skew; never `value`)")
     p.add_argument("--extras", action="store_true",
                    help="extra legs (never the headline): model generation without OpenGL and a tracking step with "
                         "all renderer-fed branches, on the reference's own test fixture")
@@ -166,6 +171,78 @@ def rank_plan(config, rank, world, objects=0, models=0):
             "model_of": [(i % n_streams) % n_models for i in range(n_obj)] if n_obj else []}
 
 
+def live_rccl_ranks(dist, hip=None):
+    """How many ranks RCCL really spans, asked of the live communicator -- never echoed from argv / WORLD_SIZE: the
+    library's own communicator (chain8: ncclCommCount through m3t_hip_comm_get_rank_count) when `hip` is given, else
+    torch.distributed's process group if its backend is nccl (= RCCL on ROCm); 0 under gloo or without a group."""
+    if hip is not None:
+        n = C.c_int(0)
+        hip.call("comm_get_rank_count", C.byref(n))
+        return int(n.value)
+    if dist is None or not dist.is_initialized():
+        return 0
+    return int(dist.get_world_size()) if str(dist.get_backend()).lower() == "nccl" else 0
+
+
+def rank_share_points(pkg, scenes, inputs_full, cfg, config, counts, objects, models, use_depth, K=10, W=3, regions=7):
+    """`--rank-share`: rank 0's share at N ranks (rank_plan: the objects it would own), run ALONE on this GPU.  The
+    projected whole-job rate is (objects of all ranks) x K / (rank 0's time): what N GPUs deliver if every rank takes
+    as long as rank 0 does alone -- no transport (the rigid configurations have none on the data path), no barrier
+    skew, no host contention between N processes.  A projection, labelled as such; the driver's N-GPU runs measure."""
+    n_frames = K + W + 1
+    points, base_rate = [], None
+    for n in counts:
+        plan = rank_plan(config, 0, n, objects, models)
+        if cfg["scaling"] == "weak":
+            ids = list(range(plan["n_obj"]))  # every rank holds the same number of objects
+        else:
+            ids = [i for i in plan["global_ids"]]  # object i -> GPU i mod N: rank 0's are 0, N, 2 N, ...
+        if not ids:
+            continue
+        hip = pkg.open_context(0)
+        sub = scenes.subset(inputs_full, ids)
+        inst = scenes.Instance(hip, sub, use_depth=use_depth)
+        scenes.stage_frames(hip, inst, sub, n_frames)
+        hip.call("cameras_select_slot", 0)
+        hip.call("start_modalities", 0)
+
+        def run(first, count):
+            for k in range(first, first + count):
+                hip.call("cameras_select_slot", k)
+                hip.call("execute_tracking_step", k)
+
+        run(1, W)
+        hip.call("sync")
+        restart = np.stack([np.ascontiguousarray(sub.gt[i][W].T, np.float32).reshape(16) for i in range(len(ids))])
+        times = []
+        for _ in range(regions):
+            hip.call("bodies_set_poses", restart.ctypes.data_as(C.POINTER(C.c_float)), len(ids))
+            hip.call("sync")
+            t = time.perf_counter()
+            run(1 + W, K)
+            hip.call("sync")
+            times.append(time.perf_counter() - t)
+        el = float(np.median(times))
+        shape = (C.c_int * 4)()
+        hip.call("get_step_shape", shape)
+        name = C.create_string_buffer(64)
+        hip.call("get_step_kernel", name, 64)
+        total = plan["total_objects"]
+        rate = total * K / el
+        if base_rate is None:
+            base_rate = rate / n
+        points.append({"n_gpus": n, "objects_on_rank_0": len(ids), "objects_in_all": total,
+                       "rank_0_ms_per_step": round(el / K * 1e3, 4), "kernel": name.value.decode(),
+                       "workgroups_per_object": int(shape[1]),
+                       "projected_pose_updates_per_s": round(rate, 1),
+                       "projected_efficiency_vs_n_times_the_first_point": round(rate / (base_rate * n), 4)})
+        del inst, hip
+    return {"what": "PROJECTION, not a measurement of N GPUs: rank 0's share (bench.rank_plan) timed alone on ONE GPU; "
+                    "projected rate = objects of all ranks x steps / rank 0's time; no transport (none on the data path "
+                    "of the rigid configurations), no barrier skew, no contention between N host processes",
+            "steps": K, "warmup": W, "regions": regions, "points": points}
+
+
 def flush_stdio():
     sys.stdout.flush()
     try:
@@ -209,7 +286,7 @@ def main():
         except Exception:  # noqa: BLE001 (a convenience, not a requirement)
             pass
 
-    # the synthetic inputs are generated on worker processes (3dobjecttracking_amd/batch.py: one task per model / per
+    # the synthetic inputs are generated on worker processes (bench_inputs.py: one task per model / per
     # object stream, the same bits as in one process, serial fallback; at N > 1 every rank keeps to its share of the cores)
     os.environ.setdefault("M3T_INPUT_WORKERS", "auto" if world == 1 else str(max(1, int(usable_cpus()["usable"]) // world)))
     pkg = importlib.import_module("3dobjecttracking_amd")
@@ -217,7 +294,8 @@ def main():
         import bench_chain
         out = bench_chain.run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_traffic)
     else:
-        out = run_objects(args, pkg, pkg.batch, rank, local_rank, world, dist, torch, dry_run)
+        import bench_inputs  # (beside this file: the synthetic batches, their worker processes and cache)
+        out = run_objects(args, pkg, bench_inputs, rank, local_rank, world, dist, torch, dry_run)
         if out is not None and dry_run:
             out["dry_run"] = "M3T_BENCH_SHARE_ONE_GPU=1: %d ranks on ONE GPU over gloo, one workgroup per object -- the N-rank code path, not a measurement" % world
             out["metric"] = "[DRY RUN, not a measurement] " + out["metric"]
@@ -462,7 +540,8 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch, dry_run
                    "parallelism": "objects sharded over %d GPU(s) (%s), no collective on the data path" %
                                   (world, "rank r owns objects [r n, (r + 1) n)" if cfg["scaling"] == "weak"
                                    else "object i on GPU i mod %d" % world),
-                   "ranks": world, "rccl_ranks": world if world > 1 else 0,
+                   "ranks": world, "rccl_ranks": live_rccl_ranks(dist),
+                   "process_group_backend": (str(dist.get_backend()) if dist is not None else None),
                    "tracked_within_5cm_5deg": "%d/%d" % (tracked, n_obj),
                    "mean_add_s_vs_ground_truth_m": round(float(np.mean(adds_gt)), 6), "setup_s": round(setup_s, 1)},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
@@ -477,6 +556,10 @@ def run_objects(args, pkg, scenes, rank, local_rank, world, dist, torch, dry_run
     }
     if sweep:
         out["batch_sweep"] = sweep
+    if args.rank_share and world == 1:
+        counts = [int(x) for x in args.rank_share.split(",") if x]
+        out["projected_scaling"] = rank_share_points(pkg, scenes, inputs, cfg, args.config, counts, args.objects,
+                                                     args.models, use_depth)
     if args.extras:
         out["extras"] = extras_point(pkg)
     return out

@@ -85,8 +85,62 @@ def optimization_time_structures(api, host, n_bodies, n_structures):
     return host.Tracker(api, 1, 1)
 
 
+def rank_share_chain(args, pkg, scenes, syn, host, inputs, joints, start_root, start_angles, n_bodies, local_rank,
+                     K=10, W=3, regions=7):
+    """`--rank-share`: what ONE rank of N pays per tracking step before the transport is added -- the whole link tree
+    but only the modalities of the bodies i mod N == 0 (sharding.place_bodies), through the distributed path (library
+    communicator at world size 1: link sums -> ncclAllReduce -> project + solve per Newton step).  The other ranks'
+    link sums are missing, so the poses are not the chain's: a timing of the code path, never a result."""
+    counts = [int(x) for x in args.rank_share.split(",") if x]
+    n_frames = K + W + 1
+    points = []
+    for n in counts:
+        owned = [i for i, r in enumerate(pkg.sharding.place_bodies(n_bodies, n)) if r == 0]
+        ctx = pkg.open_context(local_rank)
+        ch = Chain(ctx, host, syn, inputs, joints, start_root, start_angles, owned)
+        buf = C.create_string_buffer(128)
+        ctx.call("comm_get_unique_id", buf, 128)
+        ctx.call("comm_init_rank", buf, 128, 1, 0)
+        for i in owned:
+            ctx.call("camera_set_ring", ch.cams[i].id, n_frames)
+            for k in range(n_frames):
+                f = inputs.color[i][k]
+                ctx.call("camera_upload_slot", ch.cams[i].id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+
+        def steps(first, count):
+            for k in range(first, first + count):
+                ctx.call("cameras_select_slot", k)
+                ctx.call("execute_tracking_step", k)
+
+        ctx.call("cameras_select_slot", 0)
+        ctx.call("start_modalities", 0)
+        steps(1, W)
+        ctx.call("sync")
+        times = []
+        for _ in range(regions):
+            t = time.perf_counter()
+            steps(1 + W, K)
+            ctx.call("sync")
+            times.append(time.perf_counter() - t)
+        el = float(np.median(times))
+        calls = C.c_longlong(0)
+        ctx.call("comm_get_allreduce_count", C.byref(calls))
+        ranks = C.c_int(0)
+        ctx.call("comm_get_rank_count", C.byref(ranks))
+        points.append({"n_gpus": n, "bodies_with_modalities_on_rank_0": len(owned), "rank_0_ms_per_step": round(el / K * 1e3, 4),
+                       "projected_pose_updates_per_s_before_transport": round(n_bodies * K / el, 1),
+                       "allreduce_calls_per_step": round(calls.value / (W + regions * K), 2),
+                       "communicator_ranks_in_this_measurement": int(ranks.value)})
+        ctx.call("comm_destroy")
+        del ch, ctx
+    return {"what": "PROJECTION, not a measurement of N GPUs: the distributed path of rank 0 (modalities of the bodies "
+                    "i mod N == 0 only, whole link tree) timed alone on ONE GPU with the library's communicator at world "
+                    "size 1; the all-reduce's transport latency over xGMI (14 per step) is NOT in it",
+            "steps": K, "warmup": W, "regions": regions, "points": points}
+
+
 def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_traffic=None):
-    scenes = pkg.batch
+    import bench_inputs as scenes
     syn, host = pkg.synthetic, pkg.host
     n_bodies, K, W = args.objects or 8, args.steps, args.warmup
     n_frames = K + W + 1
@@ -235,6 +289,10 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
                       "gpu_us_per_structure": round(gpu_us / n_structures, 3), "cpu_port_us_per_structure": round(cpu_us, 2)})
     total = n_bodies * K
     rate = total / elapsed
+    import bench
+    rccl_ranks = bench.live_rccl_ranks(dist, hip)  # ncclCommCount of the library's communicator: 0 at N = 1 (none set)
+    projected = rank_share_chain(args, pkg, scenes, syn, host, inputs, joints, start_root, start_angles, n_bodies, local_rank) \
+        if (getattr(args, "rank_share", "") and world == 1) else None
     collectives = C.c_longlong(0)  # ncclAllReduce calls this rank's context issued (start to here: W + repeats x K steps)
     hip.call("comm_get_allreduce_count", C.byref(collectives))
     steps_run = W + max(1, args.repeats) * K
@@ -256,7 +314,7 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
                                 "first wave" if fused else "one launch per sub-step, link kernels: one wave per structure",
                                 world, 42 * n_bodies, "" if world > 1 else " when N > 1"),
                    "bodies": n_bodies, "parallelism": "bodies sharded over %d GPU(s)" % world,
-                   "rccl_ranks": world if world > 1 else 0,
+                   "rccl_ranks": rccl_ranks,
                    "allreduce_calls_per_step": round(collectives.value / steps_run, 3),
                    "max_rotation_error_vs_ground_truth_rad": round(float(max(e[0] for e in gt_err)), 5),
                    "setup_s": round(setup_s, 1)},
@@ -276,4 +334,5 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
                     "ms_per_step_median": round(elapsed / K * 1e3, 4)},
         "optimization_time_sweep": sweep,
         "distributed_path_world1": distributed,
+        "projected_scaling": projected,
     }

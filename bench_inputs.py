@@ -1,17 +1,26 @@
-"""Batches of independent single-body trackers on seeded synthetic inputs: what bench.py times, what the
-parity tests compare, what __graft_entry__.smoke() runs.  `Inputs` holds the rendered frames, sparse viewpoint models
-and start poses; `Instance` is the object graph of those inputs behind ONE C-ABI context (the HIP library -- or, in
-the tests and bench.py's checker legs, the CPU oracle bound through the same ctypes layer), driven through identical
-Tracker calls."""
+"""Bench / test infrastructure, NOT part of the product package: batches of independent single-body trackers on
+seeded synthetic inputs -- what bench.py times, what the parity tests compare, what
+__graft_entry__.smoke() runs -- with the worker processes and the on-disk cache that keep their generation out of
+the GPU minutes.  `Inputs` holds the rendered frames, sparse viewpoint models and start poses; `Instance` is the object
+graph of those inputs behind ONE C-ABI context (the HIP library -- or, in the tests and bench.py's checker legs, the
+CPU oracle bound through the same ctypes layer), driven through identical Tracker calls.  (Until round 5 this was
+3dobjecttracking_amd/batch.py.)"""
 import ctypes as C
 import hashlib
+import importlib
 import os
 import pickle
+import stat
+import sys
 
 import numpy as np
 
-from . import host
-from . import synthetic as syn
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+_pkg = importlib.import_module("3dobjecttracking_amd")
+host = _pkg.host
+syn = _pkg.synthetic
 
 
 def _cache_file(kind, key):
@@ -21,12 +30,27 @@ def _cache_file(kind, key):
     root = os.environ.get("M3T_INPUT_CACHE")
     if not root:
         return None
-    h = hashlib.sha1(repr(key).encode())
+    if not _cache_dir_is_ours(root):
+        return None
+    h = hashlib.sha1(repr((key, np.__version__, sys.byteorder)).encode())
     for path in (syn.__file__, __file__):
         with open(path, "rb") as f:
             h.update(f.read())
-    os.makedirs(root, exist_ok=True)
     return os.path.join(root, "%s_%s.pkl" % (kind, h.hexdigest()[:20]))
+
+
+def _cache_dir_is_ours(root):
+    """The cache holds pickles, and loading a pickle runs what is in it: the directory is created 0700 and used only if
+    it belongs to this user and nobody else can write to it (a directory somebody else made under /tmp is refused)."""
+    try:
+        os.makedirs(root, mode=0o700, exist_ok=True)
+        st = os.stat(root)
+    except OSError:
+        return False
+    if st.st_uid != os.getuid() or (st.st_mode & (stat.S_IWGRP | stat.S_IWOTH)):
+        sys.stderr.write("M3T_INPUT_CACHE=%s is not a private directory of this user: not used\n" % root)
+        return False
+    return True
 
 
 def _cache_load(path):

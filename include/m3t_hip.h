@@ -285,6 +285,9 @@ int m3t_hip_calculate_optimization_allreduce(m3t_hip_context*);
 /* number of ncclAllReduce calls the context has issued so far (one per Newton step of a tracking step while a
  * communicator is set: the observable a host or a test checks the distributed path with) */
 int m3t_hip_comm_get_allreduce_count(m3t_hip_context*, long long* count);
+/* ranks of the communicator the context holds, asked of RCCL itself (ncclCommCount); 0 without a communicator: what a
+ * benchmark line reports as the collective's width -- an observation, not an echo of the launcher's arguments */
+int m3t_hip_comm_get_rank_count(m3t_hip_context*, int* n_ranks);
 int m3t_hip_calculate_consistent_poses(m3t_hip_context*); /* tracker.cpp:423, optimizer.cpp:135 */
 int m3t_hip_calculate_results(m3t_hip_context*, int iteration);                    /* :503 */
 /* Tracker::ExecuteTrackingStep (M3T tracker.cpp:344) == Tracker::ExecuteTrackingCycle

@@ -526,6 +526,11 @@ class Tracker {
     c_->Check(m3t_hip_comm_get_allreduce_count(c_->get(), &n), "Tracker");
     return n;
   }
+  int CommRankCount() const {  // ncclCommCount of the live communicator, 0 without one
+    int n = 0;
+    c_->Check(m3t_hip_comm_get_rank_count(c_->get(), &n), "Tracker");
+    return n;
+  }
   // test hook: checksum and general-logarithm count of the device's logarithm over a range of float bit patterns
   std::array<unsigned long long, 3> DebugLogChecksum(unsigned first_bits, unsigned last_bits) const {
     std::array<unsigned long long, 3> out{};

@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
-    # seeded inputs with the same arguments are generated once per session (3dobjecttracking_amd/batch.py: every load
+    # seeded inputs with the same arguments are generated once per session (bench_inputs.py: every load
     # is a fresh copy, a test that edits its inputs does not reach another test's); minutes of numpy on a GPU box
     if "M3T_INPUT_CACHE" not in os.environ:
         import atexit

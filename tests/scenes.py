@@ -7,9 +7,14 @@ import util
 from util import host, syn
 
 
-# the batch builders live in the package (bench.py uses them without touching tests/)
-Inputs = util.pkg.batch.Inputs
-Instance = util.pkg.batch.Instance
+# the batch builders live beside bench.py (bench_inputs.py: bench.py uses them without touching tests/)
+import bench_inputs  # noqa: E402 (repo root: bench / test infrastructure, not in the product package)
+
+Inputs = bench_inputs.Inputs
+Instance = bench_inputs.Instance
+replicate = bench_inputs.replicate
+subset = bench_inputs.subset
+stage_frames = bench_inputs.stage_frames
 
 
 def compare_poses(pa, pb):

@@ -149,11 +149,11 @@ def test_synth512_batch_matches_the_oracle(env, kernel, shape):
     body2world after every frame and the histograms, bit for bit; and every object equals the other objects that look
     at the same stream (nothing leaks between the workgroups that share a CU)."""
     base = scenes.Inputs(64, 4, n_divides=4, n_models=16, with_depth=True)
-    inputs = util.pkg.batch.replicate(base, 512)  # how bench.py spreads its 64 rendered streams over the batch
+    inputs = scenes.replicate(base, 512)  # how bench.py spreads its 64 rendered streams over the batch
     got, hist, got_shape = hip_trajectory(inputs, use_depth=True, env=env, want_kernel=kernel)
     assert got_shape == shape
     sample = list(range(31)) + [511]
-    ref, ref_hist = oracle_trajectory(util.pkg.batch.subset(inputs, sample), use_depth=True)
+    ref, ref_hist = oracle_trajectory(scenes.subset(inputs, sample), use_depth=True)
     for k in range(inputs.n_frames):
         assert np.array_equal(got[k][sample], ref[k]), k
         for i in range(64, 512):
@@ -169,7 +169,7 @@ def test_compact_kernel_counts_saturated_background_pixels():
     0x7fff, which as a background sample must not be taken for the list's empty-slot word 0xffff (round-3 advisor).
     Frames with every 8th pixel of every 8th row saturated: foreground and background walks both meet bin 32767."""
     base = scenes.Inputs(8, 4, n_divides=2, n_models=4)
-    inputs = util.pkg.batch.subset(base, list(range(8)))
+    inputs = scenes.subset(base, list(range(8)))
     inputs.color = [[f.copy() for f in frames] for frames in base.color]
     for frames in inputs.color:
         for f in frames:

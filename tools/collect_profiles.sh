@@ -19,7 +19,7 @@ mkdir -p "$OUT"
 cd "$REPO"
 # every bench.py invocation below would regenerate its configuration's inputs (rbot64: 39 s of numpy on the box's CPU,
 # synth512: 66 s -- about 14 of the 23.5 minutes of round 4's collection): generate once per (configuration, frame count)
-export M3T_INPUT_CACHE=${M3T_INPUT_CACHE:-/tmp/m3t_inputs}
+export M3T_INPUT_CACHE=${M3T_INPUT_CACHE:-${XDG_CACHE_HOME:-$HOME/.cache}/m3t_inputs}  # (a private directory: the cache holds pickles, bench_inputs.py refuses one that others can write to)
 export M3T_INPUT_WORKERS=${M3T_INPUT_WORKERS:-auto}  # ... and the first generation on all cores (same bits: tests/test_input_cache.py)
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 args_of() {  # bench.py arguments of a profile configuration

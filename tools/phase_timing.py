@@ -2,7 +2,7 @@
 using a -DM3T_PHASE_TIMING build of the library (gpurun_out/libm3t_hip_timing.so)."""
 import ctypes as C, importlib, os, sys
 
-os.environ.setdefault("M3T_INPUT_WORKERS", "auto")  # inputs on worker processes (same bits; batch.py)
+os.environ.setdefault("M3T_INPUT_WORKERS", "auto")  # inputs on worker processes (same bits; bench_inputs.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

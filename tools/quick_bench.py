@@ -14,12 +14,12 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("M3T_INPUT_WORKERS", "auto")  # inputs on worker processes (same bits; batch.py)
+os.environ.setdefault("M3T_INPUT_WORKERS", "auto")  # inputs on worker processes (same bits; bench_inputs.py)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("3dobjecttracking_amd")
-scenes = pkg.batch
+import bench_inputs as scenes  # noqa: E402
 
 
 def main():

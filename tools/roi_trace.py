@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("M3T_INPUT_WORKERS", "auto")  # inputs on worker processes (same bits; batch.py)
+os.environ.setdefault("M3T_INPUT_WORKERS", "auto")  # inputs on worker processes (same bits; bench_inputs.py)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -39,7 +39,7 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--report":
         return report(sys.argv[2])
     pkg = importlib.import_module("3dobjecttracking_amd")
-    scenes = pkg.batch
+    import bench_inputs as scenes
     n_obj, n_frames = 64, 8
     margin = float(os.environ.get("ROI_MARGIN", "24"))
     hip = pkg.open_context(0)

@@ -8,7 +8,7 @@ import numpy as np
 pkg = importlib.import_module("3dobjecttracking_amd")
 import os
 import bench_chain
-scenes = pkg.batch
+import bench_inputs as scenes
 lib = sys.argv[1]
 hip = pkg.CApi(lib, "m3t_hip_")
 f = hip.lib.m3t_hip_debug_phase_cycles
