@@ -1197,6 +1197,7 @@ __device__ __noinline__ void tree_soft_constraints(int n_soft, const SoftConstra
 template <bool CONSTRAINED>
 __device__ __forceinline__ void tree_system_fast(const TreeOptDev& o, const LinkDev* links, const TreeWork& w,
                                                  const float* gh_links, int tid) {
+  PHASE_T0();
   const int nt = blockDim.x, wave = tid >> 6, lane = tid & (kWave - 1), n_waves = nt >> 6;
   const int dof = o.dof, n_links = o.n_links, size = o.dof + o.n_rows;
   const int n_lower = dof * (dof + 1) / 2, stride = dof + n_lower;
@@ -1239,7 +1240,9 @@ __device__ __forceinline__ void tree_system_fast(const TreeOptDev& o, const Link
       w.terms[(size_t)li * stride + x] = sacc;
     }
   }
+  PHASE_MARK(19);
   __syncthreads();
+  PHASE_MARK(20);
   for (int x = tid; x < stride; x += nt) {
     float acc = 0.0f;
     if (x < dof) {
@@ -1357,6 +1360,7 @@ __device__ __forceinline__ bool tree_solve_fast(const TreeOptDev& o, LinkDev* li
     }
   }
   tree_wave_sync();
+  PHASE_MARK(21);
   // link2world, parents before children: (parent's link2world * joint2parent) * body2joint, left to right like the
   // reference.  Twelve lanes hold a pose; a child whose parent was the previous link takes the parent's pose from the
   // registers it was just formed in; the next link's joint poses are loaded before this link's pose is stored.

@@ -37,11 +37,12 @@ NAMES = {
     30: "Newton: system -sum J^T H J | sum J^T g (wave per link)",
     31: "Newton: solve + pose updates (first wave) + barrier",
     12: "  solve: constraint rows", 13: "  solve: LDL^T", 14: "  solve: exp() of the variations",
-    15: "  solve: joints + link2world down the tree",
-    19: "  (round 4) H J", 20: "  (round 4) terms + sums",
+    15: "  solve: link2world down the tree",
+    19: "  system: H J + the link's terms (wave per link)", 20: "  system: barrier (the slowest wave)",
+    21: "  solve: joints (twelve lanes per link)",
     26: "histogram update (tail)", 27: "  tail: view", 28: "  tail: occlusion windows", 29: "  tail: pixel walk",
 }
-ORDER = [0, 1, 2, 7, 8, 9, 10, 11, 3, 4, 5, 17, 18, 23, 22, 30, 19, 20, 31, 12, 13, 14, 15, 26, 27, 28, 29]
+ORDER = [0, 1, 2, 7, 8, 9, 10, 11, 3, 4, 5, 17, 18, 23, 22, 30, 19, 20, 31, 12, 13, 14, 21, 15, 26, 27, 28, 29]
 print("tracking_step_tree_kernel, 8-body chain (13 dof), s_memtime ticks per frame of workgroup 0 (7 searches, 14 Newton steps)")
 top = 0
 for i in ORDER + [j for j in range(32) if j not in ORDER]:
