@@ -237,9 +237,6 @@ struct CompactLayout {
 #define M3T_BLOCK_THREADS 512
 #endif
 #define M3T_MISC_FLOATS 1024
-#ifndef M3T_SPLIT2_DEFAULT
-#define M3T_SPLIT2_DEFAULT 0  /* tracking_step_split2_kernel on by default? (M3T_HIP_SPLIT2 overrides) */
-#endif
 #define M3T_SPLIT_LANES 256   /* tracking_step_split_kernel: workgroups per object x padded elements per part */
 #define M3T_SPLIT_MAX_PARTS 16
 

@@ -539,7 +539,7 @@ int CheckSplitExchange(Ctx* ctx) {
     const bool tree = std::strncmp(ctx->last_step_kernel, "tracking_step_tree_", 19) == 0;
     const bool render = std::strcmp(ctx->last_step_kernel, "tracking_step_split_render_kernel") == 0;
     const std::string msg =
-        std::string(ctx->last_step_kernel[0] ? ctx->last_step_kernel : (render ? "tracking_step_split_render_kernel" : "tracking_step_split_kernel")) +
+        std::string(tree ? ctx->last_step_kernel : (render ? "tracking_step_split_render_kernel" : "tracking_step_split_kernel")) +
         ": a workgroup waited in vain for the other workgroups of its " + (tree ? "kinematic structure" : "object") +
         " (is another process or stream using this GPU?); the step was abandoned part-way: workgroups that had "
         "already finished may have written the new pose" + (tree ? "s and joints" : "") +
@@ -1355,8 +1355,6 @@ int UploadTables(Ctx* ctx) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_split_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_split_render_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_split2_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
@@ -3477,7 +3475,7 @@ int m3t_hip_calculate_results(m3t_hip_context* ctx, int iteration) {
 extern "C++" {
 template <typename K>
 int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_histogram, size_t* lds_out,
-                     int default_limit = 8, bool two_per_cu = false) {
+                     int default_limit = 8) {
   const size_t lds_tracking = size_t(ctx->layout.off_hist >= 0 ? ctx->layout.off_hist : ctx->layout.total_floats) * 4;
   // (each workgroup counts its share of the histogram bins: that share of the count table; the pair table is
   // read from L2, never staged)
@@ -3491,9 +3489,8 @@ int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_his
   if (const char* e = std::getenv("M3T_HIP_SPLIT_PARTS")) limit = std::atoi(e);  // developer override
   const int elements = std::max(ctx->layout.nl, ctx->depth_mods.empty() ? 1 : ctx->np_max);
   for (int p = M3T_SPLIT_MAX_PARTS; p >= 2; p >>= 1) {
-    // 256-thread workgroups (developer override) and tracking_step_split2_kernel (512 threads, 128 VGPRs): two are
-    // resident per CU if their LDS fits twice
-    const int per_cu = ((threads == M3T_SPLIT_LANES || two_per_cu) && lds_split_for(p) * 2 <= size_t(160) * 1024) ? 2 : 1;
+    // 256-thread workgroups (developer override): two are resident per CU if their LDS fits twice
+    const int per_cu = (threads == M3T_SPLIT_LANES && lds_split_for(p) * 2 <= size_t(160) * 1024) ? 2 : 1;
     const int padded = (n + 7) / 8 * 8;  // grid blocks / p: every XCD gets the blocks of the fullest one
     if (p > limit || padded * p > ctx->compute_cus * per_cu) continue;
     if ((elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;  // a part's elements fit its share of the lanes
@@ -3603,25 +3600,9 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // parts x padded elements per part = 256 (the collecting threads of split_exchange_state).
     int parts = 0;
     size_t lds_split = 0;
-    bool split2 = false;  // tracking_step_split2_kernel: the 128-VGPR form, two workgroups per CU
     if (ctx->split_possible && ctx->split_enabled && threads % M3T_SPLIT_LANES == 0 &&
-        ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT")) {
+        ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT"))
       parts = ChooseSplitParts(ctx, tracking_step_split_kernel, n, threads, want_fused_histogram, &lds_split);
-      // Twice the workgroups per object where the CUs hold only half of what the exchange allows (64 objects: 8
-      // instead of 4): worth the halved register file only if it really doubles them.  M3T_HIP_SPLIT2=0 / 1:
-      // developer override (never / whenever it gives more workgroups per object).
-      const char* e2 = std::getenv("M3T_HIP_SPLIT2");
-      const bool want2 = e2 ? std::atoi(e2) != 0 : M3T_SPLIT2_DEFAULT != 0;
-      if (want2 && threads == M3T_BLOCK_THREADS && ctx->fused_mode == 1) {
-        size_t lds2 = 0;
-        const int parts2 = ChooseSplitParts(ctx, tracking_step_split2_kernel, n, threads, want_fused_histogram, &lds2, 8, true);
-        if (parts2 >= 2 * std::max(parts, 1)) {
-          parts = parts2;
-          lds_split = lds2;
-          split2 = true;
-        }
-      }
-    }
     const bool split = parts >= 2;
     // More objects than CUs: the compact kernel (<= 47 KB of LDS, <= 128 VGPRs per object: 3-4 workgroups per CU;
     // measured crossover on 256 CUs: 256 objects 0.249 vs 0.225 ms with one 512-thread workgroup per CU, 384 objects
@@ -3629,7 +3610,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     bool compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && n > ctx->compute_cus;
     if (const char* e = std::getenv("M3T_HIP_COMPACT")) compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && std::atoi(e) != 0;
     if (std::getenv("M3T_HIP_THREADS")) compact = false;
-    ctx->last_step_kernel = split ? (split2 ? "tracking_step_split2_kernel" : "tracking_step_split_kernel")
+    ctx->last_step_kernel = split ? "tracking_step_split_kernel"
                                   : (compact ? "tracking_step_compact_kernel"
                                              : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_kernel" : "tracking_step_kernel"));
     if (compact) {
@@ -3643,8 +3624,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       SplitParams sp{};
       if ((r = PrepareSplit(ctx, n, parts, &sp))) return r;
       histogram_fused = want_fused_histogram;
-      hipLaunchKernelGGL(split2 ? tracking_step_split2_kernel : tracking_step_split_kernel,
-                         dim3((n + 7) / 8 * 8 * parts), dim3(threads), lds_split, ctx->stream,
+      hipLaunchKernelGGL(tracking_step_split_kernel, dim3((n + 7) / 8 * 8 * parts), dim3(threads), lds_split, ctx->stream,
                          ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                          ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                          ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,

@@ -566,12 +566,10 @@ __device__ __forceinline__ void chain_fill(float* chain, float x, float step, in
 // one or two items per thread, a batch of 8 would be mostly empty slots.
 template <int SCALE, int BMAX, typename HistPtr>
 __device__ __forceinline__ void region_segments(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist,
-                                                int n_lines, int valid_mask, const Lds& s, int line_lo,
-                                                int tid_ = -1) {
+                                                int n_lines, int valid_mask, const Lds& s, int line_lo) {
   constexpr int B0 = SCALE >= 8 ? 2 : (SCALE >= 6 ? 3 : (SCALE >= 4 ? 4 : (SCALE == 3 ? 6 : 8)));  // <= 20 pixels in flight
   constexpr int B = B0 < BMAX ? B0 : BMAX;
-  // tid_ >= 0: the caller's copy of the thread index (tracking_step_body, LEAN: an opaque one, see there)
-  const int tid = tid_ >= 0 ? tid_ : (int)threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
+  const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
   const int bin_bits = 8 - m.bitshift;  // n_bins == 1 << bin_bits
   const int bitshift = m.bitshift;
   const int n_items = (n_lines - line_lo) * n_seg;  // lines [line_lo, n_lines)
@@ -679,8 +677,8 @@ __device__ __forceinline__ void region_segments(CRegion& m, G<uint8_t> image, ui
 // any scale (not unrolled); same arithmetic
 template <typename HistPtr>
 __device__ void region_segments_generic(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist, int n_lines,
-                                        int valid_mask, int scale, const Lds& s, int line_lo, int tid_ = -1) {
-  const int tid = tid_ >= 0 ? tid_ : (int)threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
+                                        int valid_mask, int scale, const Lds& s, int line_lo) {
+  const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl, n_seg = m.n_seg;
   const int bitshift = m.bitshift, n_bins = m.n_bins, n_bins2 = m.n_bins * m.n_bins;
   const int n_items = (n_lines - line_lo) * n_seg;
   for (int item = tid; item < n_items; item += nt) {
@@ -723,18 +721,18 @@ __device__ void region_segments_generic(CRegion& m, G<uint8_t> image, uint32_t p
 template <int BMAX, typename HistPtr>
 __device__ __forceinline__ void region_segments_dispatch(CRegion& m, G<uint8_t> image, uint32_t pitch, HistPtr hist,
                                                          int scale, int n_lines, int valid_mask, const Lds& s,
-                                                         int line_lo, int tid_ = -1) {
+                                                         int line_lo) {
   switch (scale) {
-    case 1: region_segments<1, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo, tid_); break;
-    case 2: region_segments<2, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo, tid_); break;
-    case 3: region_segments<3, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo, tid_); break;
-    case 4: region_segments<4, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo, tid_); break;
-    case 5: region_segments<5, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo, tid_); break;
-    case 6: region_segments<6, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo, tid_); break;
-    case 7: region_segments<7, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo, tid_); break;
-    case 8: region_segments<8, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo, tid_); break;
-    case 9: region_segments<9, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo, tid_); break;
-    default: region_segments_generic(m, image, pitch, hist, n_lines, valid_mask, scale, s, line_lo, tid_); break;
+    case 1: region_segments<1, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 2: region_segments<2, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 3: region_segments<3, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 4: region_segments<4, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 5: region_segments<5, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 6: region_segments<6, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 7: region_segments<7, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 8: region_segments<8, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    case 9: region_segments<9, BMAX>(m, image, pitch, hist, n_lines, valid_mask, s, line_lo); break;
+    default: region_segments_generic(m, image, pitch, hist, n_lines, valid_mask, scale, s, line_lo); break;
   }
 }
 
@@ -774,9 +772,7 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   // early: the thread that normalises a distribution value (phase C2) also sends it to the object's other workgroups
   // (the granule split_exchange_publish would write after the phase: same slot, same tag, same value), unless the
   // occlusion vote is deferred -- then the rows travel with the flags after the phase
-  int tid = threadIdx.x;
-  if constexpr (LEAN) asm volatile("" : "+v"(tid));  // (an opaque copy: the per-thread addresses below are formed below)
-  const int nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
   const RegionIter it = region_iter(m, corr_iteration);
   const int nl = s.nl;
   PHASE_T0();
@@ -982,10 +978,9 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   const int n_lines_b = n_lines < line_hi ? n_lines : line_hi;
   const int nl_b = nl < line_hi ? nl : line_hi;
   if (HIST_LDS) {  // pair table staged in LDS (n_bins <= 16)
-    region_segments_dispatch<BMAX>(m, image, pitch, (LdsF)s.hist, it.scale, n_lines_b, valid_mask, s, line_lo, LEAN ? tid : -1);
+    region_segments_dispatch<BMAX>(m, image, pitch, (LdsF)s.hist, it.scale, n_lines_b, valid_mask, s, line_lo);
   } else {         // pair table gathered from L2 / HBM
-    region_segments_dispatch<BMAX>(m, image, pitch, (G<v2f>)m.histogram_norm, it.scale, n_lines_b, valid_mask, s, line_lo,
-                                   LEAN ? tid : -1);
+    region_segments_dispatch<BMAX>(m, image, pitch, (G<v2f>)m.histogram_norm, it.scale, n_lines_b, valid_mask, s, line_lo);
   }
   __syncthreads();
   PHASE_MARK(2);
@@ -1114,8 +1109,8 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
 
 // tracking_step_split_kernel, occlusion handling on: the two-pass vote :435-463 and the final flags once every
 // workgroup's occlusion results (bit 0 of the flags) are in.  Barriers inside; ends without one.
-__device__ __forceinline__ void region_finish_flags(CRegion& m, const Lds& s, int tid_ = -1) {
-  const int tid = tid_ >= 0 ? tid_ : (int)threadIdx.x, nt = blockDim.x, nl = s.nl;
+__device__ __forceinline__ void region_finish_flags(CRegion& m, const Lds& s) {
+  const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
   int mine = 0;
   for (int line = tid; line < nl; line += nt) mine += f2i_bits(s.state[LS_VALID * nl + line]) & 1;
   const int cnt = wave_sum_i(mine);
@@ -1136,10 +1131,9 @@ __device__ __forceinline__ void region_finish_flags(CRegion& m, const Lds& s, in
 // `inside`, for all other lines if not (tracking_step_split_kernel: the own part's lines while the other parts'
 // are still on their way, the received ones afterwards).  No barrier.
 template <int DL>
-__device__ __forceinline__ void region_moments_lines(CRegion& m, const Lds& s, int lo, int hi, bool inside, int dl,
-                                                     int tid_ = -1) {
+__device__ __forceinline__ void region_moments_lines(CRegion& m, const Lds& s, int lo, int hi, bool inside, int dl) {
   const int nl = s.nl;
-  for (int line = tid_ >= 0 ? tid_ : (int)threadIdx.x; line < nl; line += blockDim.x) {
+  for (int line = threadIdx.x; line < nl; line += blockDim.x) {
     if ((line >= lo && line < hi) != inside) continue;
     if (!(f2i_bits(s.state[LS_VALID * nl + line]) & 1)) continue;
     constexpr int N = DL > 0 ? DL : M3T_MAX_DISTRIBUTION_LENGTH;
@@ -1161,11 +1155,10 @@ __device__ __forceinline__ void region_moments_lines(CRegion& m, const Lds& s, i
     s.state[LS_VAR * nl + line] = fmaxf(var, m.min_expected_variance);
   }
 }
-__device__ __forceinline__ void region_moments(CRegion& m, const Lds& s, int lo = 0, int hi = 1 << 30, bool inside = true,
-                                               int tid_ = -1) {
+__device__ __forceinline__ void region_moments(CRegion& m, const Lds& s, int lo = 0, int hi = 1 << 30, bool inside = true) {
   const int dl = m.distribution_length;
-  if (dl == 12) region_moments_lines<12>(m, s, lo, hi, inside, dl, tid_);  // the default length: straight-line code
-  else region_moments_lines<0>(m, s, lo, hi, inside, dl, tid_);
+  if (dl == 12) region_moments_lines<12>(m, s, lo, hi, inside, dl);  // the default length: straight-line code
+  else region_moments_lines<0>(m, s, lo, hi, inside, dl);
 }
 
 // ---------------------------------------------------------------------------
@@ -1294,8 +1287,8 @@ __device__ __forceinline__ void chain_sums(const float* rows_a, int pitch_a, int
 // writes the line's 27 products to rows[row * pitch + line] (zeros for slots that do not contribute).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void region_products(CRegion& m, CCam& cam, const Affine& b2c, int corr_iteration, int opt_iteration,
-                                const Lds& s, float* rows, int pitch, int tid_ = -1) {
-  const int tid = tid_ >= 0 ? tid_ : (int)threadIdx.x, nt = blockDim.x, nl = s.nl;
+                                const Lds& s, float* rows, int pitch) {
+  const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
   const RegionIter it = region_iter(m, corr_iteration);
   const int slots = chain_slots(nl);
   for (int line = tid; line < slots; line += nt) {
@@ -1410,10 +1403,9 @@ __device__ __forceinline__ SplitExchangeView split_exchange_view(const SplitExch
   return v;
 }
 __device__ __forceinline__ void split_exchange_publish(const SplitExchange& x, int round, const Lds& s, bool with_region,
-                                                       float* ps, int np, bool with_depth, int first_field = 0,
-                                                       int tid_ = -1) {
+                                                       float* ps, int np, bool with_depth, int first_field = 0) {
   // first_field: the fields below it have been sent already (region_correspondences, early)
-  const int tid = tid_ >= 0 ? tid_ : (int)threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
   const SplitExchangeView v = split_exchange_view(x, round, s, with_region, ps, np, with_depth);
   const uint32_t tag = v.tag;
   const int lmask = v.lmask, nfr = v.nfr, nf = v.nf, region_row0 = v.region_row0, depth_row0 = v.depth_row0;
@@ -1433,8 +1425,8 @@ __device__ __forceinline__ void split_exchange_publish(const SplitExchange& x, i
 }
 // returns false when the exchange timed out (block-uniform); ends with a barrier
 __device__ __forceinline__ bool split_exchange_collect(const SplitExchange& x, int round, const Lds& s, bool with_region,
-                                                       float* ps, int np, bool with_depth, int tid_ = -1) {
-  const int tid = tid_ >= 0 ? tid_ : (int)threadIdx.x, nt = blockDim.x;
+                                                       float* ps, int np, bool with_depth) {
+  const int tid = threadIdx.x, nt = blockDim.x;
   const SplitExchangeView v = split_exchange_view(x, round, s, with_region, ps, np, with_depth);
   const uint32_t tag = v.tag;
   const int lmask = v.lmask, nfr = v.nfr, nf = v.nf, region_row0 = v.region_row0, depth_row0 = v.depth_row0;
@@ -2933,11 +2925,7 @@ struct SplitParams {               // tracking_step_split_kernel: n_parts workgr
 };
 
 extern "C++" {
-// LEAN (tracking_step_split2_kernel: two 512-thread workgroups per CU, 128 VGPRs): the LDS carve-up is formed anew,
-// from offsets that went through an empty asm, at the top of every correspondence iteration and every Newton step.
-// Left alone, the compiler works the per-thread LDS addresses of all phases out once, in front of the loops, and
-// keeps them alive across them: at 128 registers that was 99 spill stores and ~200 reloads inside the phases.
-template <bool HIST_LDS, bool SPLIT = false, bool RENDER = !SPLIT, bool LEAN = false>
+template <bool HIST_LDS, bool SPLIT = false, bool RENDER = !SPLIT>
 __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
@@ -2972,24 +2960,6 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   float* pose = s.misc + kMiscPose;           // 16 floats
   float* gh_region = s.misc + kMiscGhRegion;  // 42
   float* gh_depth = s.misc + kMiscGhDepth;    // 42
-  int ltid = -1;  // LEAN: an opaque copy of the thread index, renewed with the carve-up (-1: the callees read threadIdx.x)
-  auto recarve = [&]() {
-    if constexpr (LEAN) {
-      ltid = threadIdx.x;
-      asm volatile("" : "+v"(ltid));
-      TrackLdsLayout L = layout;
-      int op = off_points;
-      asm volatile("" : "+s"(L.off_state), "+s"(L.off_chain), "+s"(L.off_seg_f), "+s"(L.off_seg_b), "+s"(L.off_misc),
-                        "+s"(L.off_rows_r), "+s"(L.off_rows_d), "+s"(op));
-      s = carve(lds_t, L);
-      ps = lds_t + op;
-      rows_r = lds_t + L.off_rows_r;
-      rows_d = lds_t + L.off_rows_d;
-      pose = s.misc + kMiscPose;
-      gh_region = s.misc + kMiscGhRegion;
-      gh_depth = s.misc + kMiscGhDepth;
-    }
-  };
   if (threadIdx.x < 16) pose[threadIdx.x] = body_poses[16 * o.body + threadIdx.x];
   if (rm) stage_log_table(s.misc);
   if (HIST_LDS && rm) stage_histogram(*rm, lds_t + layout.off_hist);
@@ -3029,7 +2999,6 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   // the view of the modality's previous search (of the previous frame for the first one): closest_view_local
   int region_view = rm ? *as_global(rm->last_view) : -1;
   for (int c = first_corr_iteration; c < first_corr_iteration + n_corr_iterations; ++c) {
-    recarve();
     if (record_poses) search_poses[(c + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
     {
       const Affine b2w = load_pose(pose);
@@ -3038,7 +3007,7 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_view = region_correspondences<HIST_LDS, SPLIT ? 2 : 8, RENDER, LEAN>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s,
+        region_view = region_correspondences<HIST_LDS, SPLIT ? 2 : 8, RENDER>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s,
                                                                               line_lo, line_hi, &vote_deferred, region_view,
                                                                               SPLIT ? &exchange : nullptr);
       }
@@ -3063,35 +3032,34 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         EXCHANGE_STAMP(0, c, part, object);
         // (the distribution rows left with phase C2 unless the vote is deferred)
         split_exchange_publish(exchange, c, s, rm != nullptr, ps, np, dm != nullptr,
-                               (rm && !vote_deferred) ? rm->distribution_length : 0, ltid);
+                               (rm && !vote_deferred) ? rm->distribution_length : 0);
         EXCHANGE_STAMP(1, c, part, object);
-        if (rm && !vote_deferred) region_moments(*rm, s, line_lo, line_hi, true, ltid);
-        if (!split_exchange_collect(exchange, c, s, rm != nullptr, ps, np, dm != nullptr, ltid)) return;
+        if (rm && !vote_deferred) region_moments(*rm, s, line_lo, line_hi, true);
+        if (!split_exchange_collect(exchange, c, s, rm != nullptr, ps, np, dm != nullptr)) return;
         EXCHANGE_STAMP(2, c, part, object);
         PHASE_MARK(22);
         if (vote_deferred) {
-          region_finish_flags(*rm, s, ltid);
-          region_moments(*rm, s, 0, 1 << 30, true, ltid);
+          region_finish_flags(*rm, s);
+          region_moments(*rm, s);
         } else if (rm) {
-          region_moments(*rm, s, line_lo, line_hi, false, ltid);
+          region_moments(*rm, s, line_lo, line_hi, false);
         }
       } else {
         if (rm) region_moments(*rm, s);
       }
       {
         PHASE_T0();
-        if (dm) depth_correspondences_vote<RENDER, LEAN>(*dm, iteration, ps, np, s.misc);
+        if (dm) depth_correspondences_vote<RENDER>(*dm, iteration, ps, np, s.misc);
         else __syncthreads();
         PHASE_MARK(25);
       }
     }
     for (int u = 0; u < n_update_iterations; ++u) {
       PHASE_T0();
-      recarve();
       const Affine b2w = load_pose(pose);
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
-        region_products(*rm, *cam, b2c, c, u, s, rows_r, layout.pitch_r, ltid);
+        region_products(*rm, *cam, b2c, c, u, s, rows_r, layout.pitch_r);
       }
       if (dm) {
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
@@ -3101,10 +3069,38 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
 #ifdef M3T_PHASE_TIMING
       if (u == 0) { PHASE_MARK(5); } else { PHASE_MARK(24); }
 #endif
+#ifdef M3T_TREE_SUMS
+      // EXPERIMENT (tools/variants, never the product): the g/H sums as north_star literally
+      // prescribes them -- LDS + wavefront tree reductions -- instead of the reference-order chain: 16 lanes per
+      // product row add every sixteenth slot, a DPP row tree adds the sixteen partial sums.  Not the reference's
+      // order: the poses leave the oracle's bits (tools/tree_sums_deviation.py measures by how much;
+      // profiles/r05_headline_floor.txt has the result).
+      float* tree_r = s.misc + kMiscPartials;       // 27 sums per modality (the per-wave partials' scratch)
+      float* tree_d = s.misc + kMiscPartials + 32;
+      {
+        const int row = threadIdx.x >> 4, gl = threadIdx.x & 15;
+        if (row < 27) {
+          float acc_r = 0.0f, acc_d = 0.0f;
+          if (rm) for (int i = gl; i < chain_slots(s.nl); i += 16) acc_r -= rows_r[row * layout.pitch_r + i];
+          if (dm) for (int i = gl; i < chain_slots(np); i += 16) acc_d -= rows_d[row * layout.pitch_d + i];
+          acc_r += dpp_zero<0x111, 0xf>(acc_r); acc_r += dpp_zero<0x112, 0xf>(acc_r);
+          acc_r += dpp_zero<0x114, 0xf>(acc_r); acc_r += dpp_zero<0x118, 0xf>(acc_r);
+          acc_d += dpp_zero<0x111, 0xf>(acc_d); acc_d += dpp_zero<0x112, 0xf>(acc_d);
+          acc_d += dpp_zero<0x114, 0xf>(acc_d); acc_d += dpp_zero<0x118, 0xf>(acc_d);
+          if (gl == 15) { tree_r[row] = acc_r; tree_d[row] = acc_d; }
+        }
+      }
+      __syncthreads();
+#endif
       if (threadIdx.x < kWave) {  // one wave: the sums in the reference's order, Link sum, solve, pose update
         float sum_r = 0.0f, sum_d = 0.0f;
+#ifdef M3T_TREE_SUMS
+        sum_r = rm ? tree_r[gh_lane_row(threadIdx.x < 42 ? threadIdx.x : 0)] : 0.0f;
+        sum_d = dm ? tree_d[gh_lane_row(threadIdx.x < 42 ? threadIdx.x : 0)] : 0.0f;
+#else
         chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
                    chain_slots(np), gh_lane_row(threadIdx.x < 42 ? threadIdx.x : 0), sum_r, sum_d);
+#endif
         float gh = 0.0f;  // Link::CalculateGradientAndHessian link.cpp:184-193
         if (rm) gh += sum_r;
         if (dm) gh += sum_d;
@@ -3119,7 +3115,6 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       PHASE_MARK(6);
     }
   }
-  recarve();
   // (every workgroup of a split object holds the same pose: the first one writes it; no other workgroup can
   // still be waiting to read the old one, it had to publish its first results before this one got here)
   if (threadIdx.x < 16 && part == 0) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
@@ -3189,18 +3184,6 @@ tracking_step_split_kernel(const RigidOptDev* opts, const RegionModDev* rmods, c
                      int fuse_histogram, SplitParams split) {
   tracking_step_body<false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
                                   n_corr_iterations, n_update_iterations, write_state, fuse_histogram, &split);
-}
-
-// ... and two of them per CU (128 VGPRs each): 8 workgroups per object at 64 objects, where the 256 CUs hold 4 per
-// object of the kernel above.  Round 4's 128-register build of that kernel spilled 496 bytes per lane and ran at 0.23 ms;
-// this one re-forms its LDS addresses per phase (tracking_step_body, LEAN) and
-__global__ void __launch_bounds__(M3T_BLOCK_THREADS, 4)
-tracking_step_split2_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
-                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
-                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int fuse_histogram, SplitParams split) {
-  tracking_step_body<false, true, false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
-                                               n_corr_iterations, n_update_iterations, write_state, fuse_histogram, &split);
 }
 
 // the same with the renderer-fed branches compiled in, one correspondence search per launch (the host redraws the
