@@ -772,7 +772,9 @@ __device__ __forceinline__ int region_correspondences(CRegion& m, CCam& cam, CCa
   // early: the thread that normalises a distribution value (phase C2) also sends it to the object's other workgroups
   // (the granule split_exchange_publish would write after the phase: same slot, same tag, same value), unless the
   // occlusion vote is deferred -- then the rows travel with the flags after the phase
-  const int tid = threadIdx.x, nt = blockDim.x;
+  int tid = threadIdx.x;
+  if constexpr (LEAN) asm volatile("" : "+v"(tid));  // (an opaque copy: the per-thread addresses of the phases are formed in them)
+  const int nt = blockDim.x;
   const RegionIter it = region_iter(m, corr_iteration);
   const int nl = s.nl;
   PHASE_T0();

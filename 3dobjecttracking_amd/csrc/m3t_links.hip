@@ -400,6 +400,23 @@ __device__ __forceinline__ void ldlt_solve_wave(float* a, float* x, int n, float
 #undef A_
 }
 
+// Lane L (a constant after unrolling, L < 16) of the caller's ROW of sixteen lanes, by DPP row_newbcast: for the rows
+// of a system of at most sixteen unknowns (lanes 0..15) what v_readlane gives, without the trip through an SGPR (round 5:
+// v_readlane -> VALU costs ~23 cycles on the dependent path, DPP ~14, and the move folds into the consuming multiply).
+template <int L>
+__device__ __forceinline__ int row_lane_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + L, 0xf, 0xf, true); }
+__device__ __forceinline__ int row_lane(int v, int l) {
+  switch (l) {
+    case 0: return row_lane_i<0>(v);   case 1: return row_lane_i<1>(v);   case 2: return row_lane_i<2>(v);
+    case 3: return row_lane_i<3>(v);   case 4: return row_lane_i<4>(v);   case 5: return row_lane_i<5>(v);
+    case 6: return row_lane_i<6>(v);   case 7: return row_lane_i<7>(v);   case 8: return row_lane_i<8>(v);
+    case 9: return row_lane_i<9>(v);   case 10: return row_lane_i<10>(v); case 11: return row_lane_i<11>(v);
+    case 12: return row_lane_i<12>(v); case 13: return row_lane_i<13>(v); case 14: return row_lane_i<14>(v);
+    default: return row_lane_i<15>(v);
+  }
+}
+__device__ __forceinline__ float row_lane(float v, int l) { return __int_as_float(row_lane(__float_as_int(v), l)); }
+
 // The same solve for systems of at most N unknowns with the matrix in REGISTERS: lane = row, one register per column
 // (the scheme of rigid_solve_wave for any size).  Eigen's LDLT<Lower> is the bordered variant -- step k writes column
 // k only -- so its diagonal pivoting looks at input diagonal entries only and the whole transposition sequence can be
@@ -427,7 +444,7 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     if (j < n) {  // uniform
-      const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), j));
+      const float dj = row_lane(d, j);
       rank += dj > d ? 1 : 0;
       tie = tie || (dj == d && j != lane);
     }
@@ -436,7 +453,7 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
   if (distinct) {
 #pragma unroll
     for (int j = 0; j < N; ++j)
-      if (j < n && __builtin_amdgcn_readlane(rank, j) == lane) src = j;
+      if (j < n && row_lane(rank, j) == lane) src = j;
   }
 #pragma nounroll
   for (int k = 0; k < (distinct ? 0 : n); ++k) {
@@ -454,7 +471,7 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
   float b[N];
 #pragma unroll
   for (int c = 0; c < N; ++c) {
-    const int sc = __builtin_amdgcn_readlane(src, c);
+    const int sc = row_lane(src, c);
     const int hi = src > sc ? src : sc, lo = src > sc ? sc : src;
     b[c] = (row && c <= lane && c < n) ? a[(size_t)lo * n + hi] : 0.0f;
   }
@@ -470,7 +487,7 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
 #pragma unroll
   for (int c = 0; c < N; ++c) {
     b[c] -= acc[c];  // row c: the pivot D_c; rows below: A21 -= A20 * temp  (c = 0: minus +0)
-    const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[c]), c));
+    const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[c]), c));  // (kept: an SGPR, used by every lane below)
     D[c] = c < n ? dc : 1.0f;
     const bool pivot_valid = fabsf(D[c]) > 0.0f;
     const float q = b[c] / D[c];
@@ -478,14 +495,14 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
     const float tv = D[c] * b[c];  // lane k: temp_k[c] = D_c * L(k, c)
 #pragma unroll
     for (int k = c + 1; k < N; ++k) {
-      const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tv), k));
+      const float t = row_lane(tv, k);
       acc[k] += b[c] * t;
     }
   }
   // 4. L y = P b (column sweep), D z = y (pseudo-inverse), L^T w = z (ordered subtraction on broadcast values)
 #pragma unroll
   for (int c = 0; c < N - 1; ++c) {
-    const float xc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xp), c));
+    const float xc = row_lane(xp, c);
     xp = lane > c ? xp - b[c] * xc : xp;
   }
   float dself = 1.0f;
@@ -500,7 +517,7 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
     float sacc = X[i];
 #pragma unroll
     for (int r = i + 1; r < N; ++r)
-      sacc -= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[i]), r)) * X[r];  // L(r, i) * w_r
+      sacc -= row_lane(b[i], r) * X[r];  // L(r, i) * w_r
     X[i] = sacc;
   }
   // 5. un-permute: position p is input row src
@@ -1465,7 +1482,25 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
   LinkDev* links = reinterpret_cast<LinkDev*>(lds_tree + off_tree);
   float* gh_links = reinterpret_cast<float*>(links + n_links);
   float* partial = gh_links + n_links * 42;
-  const TreeWork w = tree_carve(partial + dof * dof + dof, n_links, dof, o.n_rows);
+  TreeWork w = tree_carve(partial + dof * dof + dof, n_links, dof, o.n_rows);
+  // The LDS carve-up is formed anew -- from offsets that went through an empty asm -- at the top of every
+  // correspondence iteration and every Newton step: left alone, the compiler works the per-thread LDS addresses of all
+  // phases out once, in front of the loops, keeps them alive across the loops and spills them (the same reason as for
+  // `ltid` below)
+  auto recarve = [&]() {
+    TrackLdsLayout L = layout;
+    int op = off_points, ot = off_tree;
+    asm volatile("" : "+s"(L.off_state), "+s"(L.off_chain), "+s"(L.off_seg_f), "+s"(L.off_seg_b), "+s"(L.off_misc),
+                      "+s"(L.off_rows_r), "+s"(L.off_rows_d), "+s"(op), "+s"(ot));
+    s = carve(lds_tree, L);
+    ps = lds_tree + op;
+    rows_r = lds_tree + L.off_rows_r;
+    rows_d = lds_tree + L.off_rows_d;
+    links = reinterpret_cast<LinkDev*>(lds_tree + ot);
+    gh_links = reinterpret_cast<float*>(links + n_links);
+    partial = gh_links + n_links * 42;
+    w = tree_carve(partial + dof * dof + dof, n_links, dof, o.n_rows);
+  };
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(o.links);
     uint32_t* dst = reinterpret_cast<uint32_t*>(links);
@@ -1480,7 +1515,7 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
   }
   tree_tables(o, links, w);
   __syncthreads();
-  float* pose = links[st.link].link2world;  // this workgroup's body2world, kept current by its own solve
+  float* pose = links[st.link].link2world;  // this workgroup's body2world, kept current by its own solve (re-formed by recarve)
   CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
   CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
   CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
@@ -1490,6 +1525,8 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
   int region_view = rm ? *as_global(rm->last_view) : -1;  // the view of the modality's previous search (closest_view_local)
   for (int c = 0; c < n_corr_iterations; ++c) {
     {
+      recarve();
+      pose = links[st.link].link2world;
       const Affine b2w = load_pose(pose);
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
@@ -1510,6 +1547,8 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
     }
     for (int u = 0; u < n_update_iterations; ++u, ++round) {
       PHASE_T0();
+      recarve();
+      pose = links[st.link].link2world;
       const Affine b2w = load_pose(pose);
       // The structure code addresses LDS by thread: left alone, the compiler works all those addresses out once, in
       // front of the search loop, keeps them alive across it and spills them (round 4: 119 stores there, the reloads
@@ -1593,6 +1632,8 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
       PHASE_MARK(31);
     }
   }
+  recarve();
+  pose = links[st.link].link2world;
   if (rm && tid == 0) *as_global_w(rm->last_view) = region_view;
   // every workgroup of a structure holds the same link table: the first one writes it (and the bodies) back
   if (st.tracked == 0) {

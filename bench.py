@@ -786,8 +786,9 @@ def cpu_all_cores(scenes, inputs, n_obj, n_frames, use_depth, seconds=8.0, nativ
 
 def measured_traffic(config, kernel, n_obj, fused_histogram=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_hbm_traffic_*.json:
-    FETCH_SIZE and WRITE_SIZE in separate runs of this same command, read side doubled as MI355X_MICROARCH.md §HBM
-    prescribes for gfx950).  The counters cannot be collected from inside this process; null when no profile of this
+    FETCH_SIZE and WRITE_SIZE in separate runs of this same command; the read side corrected by the factor measured on
+    this hardware in the kernels' own access pattern, profiles/rNN_counter_calibration.txt -- MI355X_MICROARCH.md §HBM
+    calibrates wide streams only).  The counters cannot be collected from inside this process; null when no profile of this
     configuration, batch size, kernel and launch structure exists."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic*.json")), reverse=True):
@@ -797,7 +798,12 @@ def measured_traffic(config, kernel, n_obj, fused_histogram=False):
                 continue
             if bool(d.get("histogram_update_fused", False)) != fused_histogram or kernel not in d["kernels"]:
                 continue
-            return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
+            src = os.path.relpath(path, ROOT)
+            if d.get("correction"):  # (round 5: the factor is measured, tools/ubench_counters.hip)
+                src += "; correction: FETCH_SIZE x %.3f (%s); bracket [raw, read side doubled] = %s" % (
+                    d["correction"]["FETCH_SIZE"], d["correction"]["how"],
+                    d["kernels"][kernel].get("hbm_bytes_per_launch_bracket"))
+            return d["kernels"][kernel]["hbm_bytes_per_launch_corrected"], src
         except Exception:
             continue
     return None, None

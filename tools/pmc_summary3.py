@@ -1,8 +1,14 @@
 """Per-launch means of the PMC passes of tools/collect_profiles.sh for every kernel of the timed batch, the ratios the
 counters were collected for, and the HBM traffic block bench.py quotes (profiles/rNN_hbm_traffic_<profile>.json).
 SQ_* cycle counters are per-SE sums of quad-cycles as rocprofv3 reports them; GRBM_GUI_ACTIVE comes out once per XCD
-(summed here, divided by 8 below); FETCH_SIZE / WRITE_SIZE are in KB, the read side is doubled per
-MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request of a wide stream: an upper estimate for scattered gathers).
+(summed here, divided by 8 below); FETCH_SIZE / WRITE_SIZE are in KB.  Corrections are MEASURED on this hardware in the
+tracking kernels' own access patterns (profiles/rNN_counter_calibration.txt from tools/ubench_counters.hip, lines
+`factor <pattern> <counter> <reported / bytes moved>`): the tracking kernels' HBM reads are first touches of frame rows
+by lanes on different rows (cal_read_pixels: FETCH_SIZE reports 0.62 of the bytes) plus tables and model rows read in
+order (cal_read_4B / cal_read_16B: 0.50); their writes are consecutive (cal_write_4B: 1.00).  The calibrated figure
+divides FETCH_SIZE by the pixel-walk factor and leaves WRITE_SIZE alone; the bracket [raw, read side doubled] is
+published beside it -- a sparse 4-byte gather is tallied at exactly 64 B per request (factor 1.00), a wide stream at
+half its bytes (MI355X_MICROARCH.md §HBM), and everything these kernels do lies between the two.
 
   python tools/pmc_summary3.py <dir with one sub-directory per pass> <out.json> <profile name> "<command>"
 """
@@ -14,6 +20,21 @@ import sys
 
 OBJECTS = {"rbot64": 64, "rbot4096": 4096, "ycb21": 21, "synth512": 512, "chain8": 8}
 CONFIG = {"rbot64": "rbot64", "rbot4096": "rbot64", "ycb21": "ycb21", "synth512": "synth512", "chain8": "chain8"}
+
+
+def calibration():
+    """(FETCH_SIZE factor of the pixel-walk pattern, WRITE_SIZE factor of consecutive stores, file) from the newest
+    profiles/r*_counter_calibration.txt; (0.5, 1.0, None) -- the guide's streaming-read figure -- without one"""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    for path in sorted(glob.glob(os.path.join(root, "r*_counter_calibration.txt")), reverse=True):
+        f = {}
+        for line in open(path):
+            p = line.split()
+            if len(p) == 4 and p[0] == "factor":
+                f[(p[1], p[2])] = float(p[3])
+        if ("cal_read_pixels", "FETCH_SIZE") in f:
+            return f[("cal_read_pixels", "FETCH_SIZE")], f.get(("cal_write_4B", "WRITE_SIZE"), 1.0), os.path.basename(path)
+    return 0.5, 1.0, None
 
 
 def per_kernel(folder):
@@ -75,17 +96,26 @@ def main(out_dir, target, profile, command):
             k = kernels.setdefault(key[0], {"workgroups": key[1], "threads": key[2], "vgprs": key[3],
                                             "lds_bytes": key[4], "scratch_bytes": key[5], "per_launch_means": {}})
             k["per_launch_means"].update({n: v for n, v in c.items()})
+    f_read, f_write, cal_file = calibration()
     traffic = {"command": command, "profile": profile, "config": CONFIG.get(profile, profile),
                "objects_per_launch": OBJECTS.get(profile), "kernels": {},
+               "correction": {"FETCH_SIZE": round(1.0 / f_read, 4), "WRITE_SIZE": round(1.0 / f_write, 4),
+                              "how": ("calibrated, profiles/%s: FETCH_SIZE reports %.3f of the bytes of the pixel-walk "
+                                      "pattern (a lane per image row), WRITE_SIZE %.3f of consecutive stores" %
+                                      (cal_file, f_read, f_write)) if cal_file else
+                                     "uncalibrated: the guide's streaming-read factor (FETCH_SIZE x 2)"},
                "note": "FETCH_SIZE and WRITE_SIZE (KB) in separate rocprofv3 --pmc passes, mean over the launches of the "
-                       "timed region; read side doubled per MI355X_MICROARCH.md HBM section"}
+                       "timed region; hbm_bytes_per_launch_corrected applies `correction`, the bracket is [raw, read "
+                       "side doubled] (sparse gathers are tallied at 1.00, wide streams at 0.50 of their bytes)"}
     for name, k in kernels.items():
         m = k["per_launch_means"]
         k["ratios"] = ratios_of(m)
         if m.get("FETCH_SIZE") is not None and m.get("WRITE_SIZE") is not None:
             k["hbm"] = {"FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
                         "hbm_bytes_per_launch_raw": int((m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024),
-                        "hbm_bytes_per_launch_corrected": int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)}
+                        "hbm_bytes_per_launch_corrected": int((m["FETCH_SIZE"] / f_read + m["WRITE_SIZE"] / f_write) * 1024),
+                        "hbm_bytes_per_launch_bracket": [int((m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024),
+                                                         int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)]}
             traffic["kernels"][name] = dict(k["hbm"])
     # fused = the histogram update rides in the tracking launch: then region_histogram_kernel only runs for
     # StartModalities (and in bench.py's unfused-buckets leg, which profiling runs skip: --no-buckets), i.e. far less
