@@ -193,6 +193,7 @@ struct m3t_hip_context {
   bool links_device_newer = false;  // joint poses on the device are ahead of the host mirror
   DevMem d_links, d_constraints, d_soft, d_treeopts, d_work, d_partial;
   DevMem d_link_sums, d_link_first;  // what a structure spread over processes exchanges (links_gather_kernel): [links][42], first link per structure
+  DevMem d_link_sums_alt, d_links_alt;  // tracking_step_tree_segment_kernel: the second copies (sums, link table) that take turns
   size_t link_sums_count = 0;
   // tracking_step_tree_kernel: one workgroup per link that carries modalities
   DevMem d_treesteps, d_tracked_links, d_tree_exchange;
@@ -229,6 +230,8 @@ struct m3t_hip_context {
   int compute_cus = 0;  // what the tracking launches may count on (set with the device properties)
   size_t tree_lds_attribute = 0;  // dynamic LDS limit last set on the one-launch tree kernel ...
   const void* tree_lds_kernel = nullptr;  // ... and which of the two it was
+  size_t tree_segment_lds_attribute = 0;  // the same for tracking_step_tree_segment_kernel
+  const void* tree_segment_lds_kernel = nullptr;
   DevMem d_split;            // [objects][2 slots][parts][32 fields][256 / parts] granules, then one abort word per object
   size_t split_objects = 0;  // capacity of d_split
   unsigned split_seq = 0;    // launch counter inside the granule tags
@@ -765,6 +768,7 @@ int UploadTreeTables(Ctx* ctx) {
     partial_total += size_t(dof) * dof + dof;
   }
   HIPCHK(ctx->d_links.alloc(std::max<size_t>(1, links.size()) * sizeof(LinkDev)));
+  HIPCHK(ctx->d_links_alt.alloc(std::max<size_t>(1, links.size()) * sizeof(LinkDev)));
   HIPCHK(ctx->d_constraints.alloc(std::max<size_t>(1, cons.size()) * sizeof(ConstraintDev)));
   HIPCHK(ctx->d_soft.alloc(std::max<size_t>(1, soft.size()) * sizeof(SoftConstraintDev)));
   HIPCHK(ctx->d_treeopts.alloc(std::max<size_t>(1, opts.size()) * sizeof(TreeOptDev)));
@@ -785,6 +789,8 @@ int UploadTreeTables(Ctx* ctx) {
     ctx->link_sums_count = links.size() * 42;
     HIPCHK(ctx->d_link_sums.alloc(std::max<size_t>(1, ctx->link_sums_count) * 4));
     HIPCHK(hipMemset(ctx->d_link_sums.p, 0, ctx->d_link_sums.bytes));
+    HIPCHK(ctx->d_link_sums_alt.alloc(std::max<size_t>(1, ctx->link_sums_count) * 4));
+    HIPCHK(hipMemset(ctx->d_link_sums_alt.p, 0, ctx->d_link_sums_alt.bytes));
   }
   HIPCHK(ctx->d_partial.alloc(std::max<size_t>(1, partial_total) * 4));
   HIPCHK(hipMemset(ctx->d_partial.p, 0, ctx->d_partial.bytes));
@@ -804,8 +810,13 @@ int UploadTreeTables(Ctx* ctx) {
     d.tikhonov_translation = o.tt;
     d.work = ctx->d_work.as<float>() + work_off[oi];
     d.partial = ctx->d_partial.as<float>() + o.partial_offset;
+    d.links_alt = ctx->d_links_alt.as<LinkDev>() + link_off[oi];
+    d.first_link = int(link_off[oi]);
   }
-  if (!links.empty()) HIPCHK(hipMemcpy(ctx->d_links.p, links.data(), links.size() * sizeof(LinkDev), hipMemcpyHostToDevice));
+  if (!links.empty()) {
+    HIPCHK(hipMemcpy(ctx->d_links.p, links.data(), links.size() * sizeof(LinkDev), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_links_alt.p, links.data(), links.size() * sizeof(LinkDev), hipMemcpyHostToDevice));
+  }
   if (!cons.empty()) HIPCHK(hipMemcpy(ctx->d_constraints.p, cons.data(), cons.size() * sizeof(ConstraintDev), hipMemcpyHostToDevice));
   if (!soft.empty()) HIPCHK(hipMemcpy(ctx->d_soft.p, soft.data(), soft.size() * sizeof(SoftConstraintDev), hipMemcpyHostToDevice));
   // tracking_step_tree_kernel: the links that carry modalities, one workgroup each (at most one region and one
@@ -1524,10 +1535,10 @@ int LaunchSolveSums(Ctx* ctx) {
 // sum of the stacked link sums ([links of all structures][6 + 36]) over the ranks of the communicator: ONE
 // ncclAllReduce on the context's stream, in place.  Exact: every link's modalities live on one rank, the others add
 // +0.0 (m3t_links.hip, links_gather_kernel)
-int AllReducePartial(Ctx* ctx) {
+int AllReducePartial(Ctx* ctx, float* buffer = nullptr) {
   REQUIRE(ctx->partial_ready, M3T_ERR_NOT_SET_UP, "calculate_optimization_begin has to be called first");
   REQUIRE(ctx->comm != nullptr, M3T_ERR_NOT_SET_UP, "no communicator: m3t_hip_comm_init_rank / m3t_hip_comm_set first");
-  float* buffer = ctx->d_link_sums.as<float>();
+  if (!buffer) buffer = ctx->d_link_sums.as<float>();
   const ncclResult_t rc =
       g_rccl.AllReduce(buffer, buffer, ctx->link_sums_count, ncclFloat, ncclSum, ctx->comm, ctx->stream);
   if (rc != ncclSuccess)
@@ -1601,6 +1612,30 @@ bool TreeStepFused(Ctx* ctx) {
   int resident = ResidentBlocks(ctx, kernel, M3T_BLOCK_THREADS, lds);
   resident = std::min(resident, int(size_t(160) * 1024 / lds));
   return resident >= 1 && ctx->n_treesteps <= ctx->compute_cus * resident;
+}
+
+// A structure spread over processes (a communicator is set): can the step run as ONE launch + ONE all-reduce per
+// Newton step (tracking_step_tree_segment_kernel)?  The conditions of the one-launch step, except that no workgroup
+// waits for another one inside a launch: no co-residency needed, any grid.
+bool TreeStepSegmented(Ctx* ctx) {
+  if (!(ctx->tree_mode && ctx->tree_fused_possible && ctx->fused_mode == 1 && ctx->comm && ctx->n_render_all == 0 &&
+        ctx->shared_histograms.empty() && ctx->n_treesteps > 0 && !std::getenv("M3T_HIP_NO_TREE_SEGMENTS")))
+    return false;
+  if (ctx->layout.off_hist >= 0) return false;
+  const bool fused_histogram = !ctx->region_mods.empty() && ctx->hist_counts_in_lds;
+  const size_t lds = TreeStepLds(ctx, fused_histogram);
+  if (lds > size_t(160) * 1024) return false;
+  auto kernel = ctx->tree_constrained ? tracking_step_tree_segment_constrained_kernel : tracking_step_tree_segment_kernel;
+  if (ctx->tree_segment_lds_attribute != lds || ctx->tree_segment_lds_kernel != reinterpret_cast<const void*>(kernel)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(lds)) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    ctx->tree_segment_lds_attribute = lds;
+    ctx->tree_segment_lds_kernel = reinterpret_cast<const void*>(kernel);
+  }
+  return true;
 }
 
 int Prepare(Ctx* ctx, bool need_images) {
@@ -2188,7 +2223,11 @@ int m3t_hip_camera_select_slot(m3t_hip_context* ctx, int id, int slot) {
 }
 int m3t_hip_cameras_select_slot(m3t_hip_context* ctx, int slot) {
   CHECK_CTX();
+  // every camera that has a ring: a camera without one keeps its only frame (the cameras of bodies whose modalities
+  // live on another rank -- a structure spread over processes -- hold no frames at all; round 5: before, the call
+  // failed on them with "bad frame slot", i.e. the N > 1 chain leg of bench.py could not have run)
   for (size_t i = 0; i < ctx->cameras.size(); ++i) {
+    if (ctx->cameras[i]->n_slots <= 1 && slot != 0) continue;
     int r = m3t_hip_camera_select_slot(ctx, int(i), slot);
     if (r) return r;
   }
@@ -3720,6 +3759,66 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     histogram_fused = want_fused_histogram;
     ctx->links_device_newer = true;
     ctx->last_step_kernel = ctx->tree_constrained ? "tracking_step_tree_constrained_kernel" : "tracking_step_tree_kernel";
+    ctx->last_step_shape[0] = ctx->n_treesteps;
+    ctx->last_step_shape[1] = 1;
+    ctx->last_step_shape[2] = M3T_BLOCK_THREADS;
+    ctx->last_step_shape[3] = histogram_fused ? 1 : 0;
+    ctx->state_valid = false;
+  } else if (TreeStepSegmented(ctx)) {
+    // kinematic structures spread over processes: one launch and one all-reduce (of the link sums) per Newton step,
+    // a last launch for the last solve, the bodies and the histogram update (m3t_links.hip, tree_segment_body)
+    ScopedKernelTimer timer(ctx, 0);
+    const bool want_fused_histogram = !ctx->region_mods.empty() && ctx->hist_counts_in_lds && ctx->shared_histograms.empty() &&
+                                      !std::getenv("M3T_HIP_NO_FUSED_HISTOGRAM");
+    const size_t lds = TreeStepLds(ctx, want_fused_histogram);
+    const int off_tree = int((lds / 4 - ctx->tree_block_floats));
+    auto kernel = ctx->tree_constrained ? tracking_step_tree_segment_constrained_kernel : tracking_step_tree_segment_kernel;
+    float* sums[2] = {ctx->d_link_sums.as<float>(), ctx->d_link_sums_alt.as<float>()};
+    const int n_newton = ctx->n_corr_iterations * ctx->n_update_iterations;
+    // launch k reads the link table launch k - 1 wrote: the primary table at k <= 1 (launch 0 solves nothing and writes
+    // nothing), then alternately; launch k >= 1 writes the other one.  The last launch (k = n_newton) must leave the
+    // joints in the primary table, the one the rest of the library reads: an odd n_newton ends in the second one and
+    // is copied over.
+    for (int k = 0; k <= n_newton; ++k) {
+      TreeSegmentParams sp{};
+      const int c = k / std::max(ctx->n_update_iterations, 1), u = k % std::max(ctx->n_update_iterations, 1);
+      const bool last = k == n_newton;
+      int flags = 0;
+      if (k <= 1) flags |= TSEG_FIRST;  // (nothing has written the bodies' link2world yet: launch 0 solves nothing)
+      if (k > 0) flags |= TSEG_SOLVE;
+      if (!last) {
+        flags |= TSEG_SUMS;
+        if (u == 0) flags |= TSEG_SEARCH | (ctx->n_update_iterations > 1 ? TSEG_STORE_STATE : 0);
+        else flags |= TSEG_LOAD_STATE;
+      } else {
+        flags |= TSEG_FINAL;
+      }
+      const bool read_alt = k >= 2 && (k % 2 == 0);
+      const bool write_alt = k >= 1 && (k % 2 == 1);
+      if (read_alt) flags |= TSEG_LINKS_FROM_ALT;
+      if (write_alt) flags |= TSEG_LINKS_TO_ALT;
+      sp.flags = flags;
+      sp.corr_iteration = last ? 0 : c;
+      sp.opt_iteration = last ? 0 : u;
+      sp.sums_in = sums[(k + 1) & 1];  // what launch k - 1 wrote and the all-reduce summed
+      sp.sums_out = sums[k & 1];
+      hipLaunchKernelGGL(kernel, dim3(ctx->n_treesteps), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
+                         ctx->d_treesteps.as<TreeStepDev>(), ctx->d_treeopts.as<TreeOptDev>(),
+                         ctx->d_region.as<RegionModDev>(), ctx->d_depth.as<DepthModDev>(), ctx->cams_active,
+                         ctx->d_poses.as<float>(), ctx->layout, ctx->off_points, ctx->np_max, off_tree, iteration,
+                         (last && want_fused_histogram) ? 1 : 0, sp);
+      HIPCHK(hipGetLastError());
+      if (!last) {
+        ctx->partial_ready = true;
+        if ((r = AllReducePartial(ctx, sums[k & 1]))) return r;
+        ctx->partial_ready = false;
+      }
+    }
+    if (n_newton >= 1 && (n_newton % 2 == 1))  // the last launch wrote the second table
+      HIPCHK(hipMemcpyAsync(ctx->d_links.p, ctx->d_links_alt.p, ctx->d_links.bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    histogram_fused = want_fused_histogram;
+    ctx->links_device_newer = true;
+    ctx->last_step_kernel = ctx->tree_constrained ? "tracking_step_tree_segment_constrained_kernel" : "tracking_step_tree_segment_kernel";
     ctx->last_step_shape[0] = ctx->n_treesteps;
     ctx->last_step_shape[1] = 1;
     ctx->last_step_shape[2] = M3T_BLOCK_THREADS;

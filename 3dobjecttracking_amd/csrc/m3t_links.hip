@@ -54,6 +54,11 @@ struct TreeOptDev {
   int n_tracked;
   const int* tracked_links;     // [n_tracked] link index inside the structure
   unsigned long long* exchange;
+  // tracking_step_tree_segment_kernel (a structure spread over processes): the second copy of the link table -- a launch
+  // reads one and writes the other, so that no workgroup can read joints another workgroup of the same launch has
+  // already moved -- and where this structure's links start in the stacked link sums
+  LinkDev* links_alt;
+  int first_link;
 };
 #define M3T_TREE_GRANULES 64  /* granules per tracked link and slot (42 used) */
 #define M3T_TREE_LANE_FIELDS 5 /* per-lane constants of a structure (tree_tables) */
@@ -75,6 +80,25 @@ struct TreeStepParams {
   unsigned seq;            // launch sequence number inside the granule tags
   unsigned abort_id;       // what a workgroup that waited in vain writes to *host_abort
   unsigned* host_abort;    // mapped host word
+};
+// one launch of tracking_step_tree_segment_kernel: [solve from the summed link sums of the previous Newton step] ->
+// [correspondence search | line state from the search's launch] -> [g/H products, the link's sums]
+enum {
+  TSEG_SOLVE = 1,        // apply the (all-reduced) link sums in `sums_in` first: project, solve, update the joints
+  TSEG_SEARCH = 2,       // run the correspondence search (the first Newton step of a correspondence iteration)
+  TSEG_STORE_STATE = 4,  // ... and leave its line / point state in global memory for the following launches
+  TSEG_LOAD_STATE = 8,   // a later Newton step of the same search: line / point state from global memory
+  TSEG_SUMS = 16,        // form this link's g/H sums and write them to `sums_out`
+  TSEG_FINAL = 32,       // the frame's last launch: bodies written back, histogram update
+  TSEG_FIRST = 64,       // no launch of this frame has moved the bodies yet: links with a body stand where the body stands
+  TSEG_LINKS_FROM_ALT = 128,  // read the link table from links_alt (else links) ...
+  TSEG_LINKS_TO_ALT = 256,    // ... and write the solved one to links_alt (else links)
+};
+struct TreeSegmentParams {
+  int flags;
+  int corr_iteration, opt_iteration;
+  const float* sums_in;  // [all links of all structures][42], summed over the ranks
+  float* sums_out;       // this rank's link sums of this Newton step (links without local modalities: zero)
 };
 
 namespace {
@@ -1663,6 +1687,192 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
   }
 }
 
+// ---------------------------------------------------------------------------
+// A structure spread over processes, round 5: ONE launch and ONE all-reduce per Newton step instead of
+// the per-sub-step launches (correspondences, g/H per modality, link sums, all-reduce, project + solve: 50 launches per
+// frame of the 8-body chain, 0.70 ms per step before any transport).  Launch k = [solve: every workgroup applies the
+// summed link sums of Newton step k - 1 to its own LDS copy of the structure, exactly what tracking_step_tree_kernel
+// does after its in-kernel exchange] -> [the search of a new correspondence iteration, or its line state from global
+// memory] -> [products, the link's sums in the reference's order -> sums_out]; the host all-reduces sums_out on the
+// stream and launches k + 1.  Links whose modalities live on another rank contribute zeros (written by the structure's
+// first workgroup), so the sum is exact and N ranks compute the poses of one process bit for bit, as before.
+// No workgroup waits for another one inside a launch: the grid needs no co-residency.  Two copies of the link table
+// and of the sums take turns, so that a workgroup that starts late never reads what a faster one of the same launch
+// has already written.
+// ---------------------------------------------------------------------------
+template <bool CONSTRAINED>
+__device__ __forceinline__ void tree_segment_body(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
+                                                  const DepthModDev* dmods, const CameraDev* cams, float* body_poses,
+                                                  TrackLdsLayout layout, int off_points, int np, int off_tree,
+                                                  int iteration, int fuse_histogram, TreeSegmentParams sp) {
+  extern __shared__ __attribute__((aligned(16))) float lds_tree[];
+  typedef const __attribute__((address_space(4))) TreeStepDev CTreeStep;
+  typedef const __attribute__((address_space(4))) TreeOptDev CTreeOpt;
+  CTreeStep& stc = *(CTreeStep*)(steps + blockIdx.x);
+  TreeStepDev st;
+  st.opt = stc.opt; st.link = stc.link; st.tracked = stc.tracked;
+  st.region_modality = stc.region_modality; st.depth_modality = stc.depth_modality; st.region_first = stc.region_first;
+  CTreeOpt& oc = *(CTreeOpt*)(opts + st.opt);
+  TreeOptDev o;
+  o.n_links = oc.n_links; o.links = oc.links; o.dof = oc.dof;
+  o.n_constraints = oc.n_constraints; o.constraints = oc.constraints; o.n_rows = oc.n_rows;
+  o.n_soft = oc.n_soft; o.soft = oc.soft;
+  o.tikhonov_rotation = oc.tikhonov_rotation; o.tikhonov_translation = oc.tikhonov_translation;
+  o.work = oc.work; o.partial = oc.partial;
+  o.n_tracked = oc.n_tracked; o.tracked_links = oc.tracked_links; o.exchange = oc.exchange;
+  o.links_alt = oc.links_alt; o.first_link = oc.first_link;
+  if constexpr (!CONSTRAINED) { o.n_constraints = 0; o.n_rows = 0; o.n_soft = 0; }
+  CRegion* rm = st.region_modality >= 0 ? (CRegion*)(rmods + st.region_modality) : nullptr;
+  CDepth* dm = st.depth_modality >= 0 ? (CDepth*)(dmods + st.depth_modality) : nullptr;
+  const int tid = threadIdx.x, nt = blockDim.x, n_links = o.n_links, dof = o.dof, flags = sp.flags;
+  const int c = sp.corr_iteration, u = sp.opt_iteration;
+  const bool kin_wave = tid >= nt - kWave;
+  Lds s = carve(lds_tree, layout);
+  float* ps = lds_tree + off_points;
+  float* rows_r = lds_tree + layout.off_rows_r;
+  float* rows_d = lds_tree + layout.off_rows_d;
+  LinkDev* links = reinterpret_cast<LinkDev*>(lds_tree + off_tree);
+  float* gh_links = reinterpret_cast<float*>(links + n_links);
+  float* partial = gh_links + n_links * 42;
+  const TreeWork w = tree_carve(partial + dof * dof + dof, n_links, dof, o.n_rows);
+  LinkDev* table_in = (flags & TSEG_LINKS_FROM_ALT) ? o.links_alt : o.links;
+  LinkDev* table_out = (flags & TSEG_LINKS_TO_ALT) ? o.links_alt : o.links;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(table_in);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(links);
+    for (int i = tid; i < n_links * (int)(sizeof(LinkDev) / 4); i += nt) dst[i] = src[i];
+    if (flags & TSEG_SOLVE) {
+      const float* sums = sp.sums_in + (size_t)o.first_link * 42;
+      for (int i = tid; i < n_links * 42; i += nt) gh_links[i] = sums[i];
+    }
+  }
+  if (rm) stage_log_table(s.misc);
+  __syncthreads();
+  if (flags & TSEG_FIRST) {
+    for (int i = tid; i < n_links * 16; i += nt) {  // a link with a body stands where its body stands (link.cpp:296-301)
+      const int li = i >> 4;
+      if (links[li].body >= 0) links[li].link2world[i & 15] = body_poses[16 * links[li].body + (i & 15)];
+    }
+  }
+  tree_tables(o, links, w);
+  __syncthreads();
+  if (flags & TSEG_SOLVE) {
+    // Optimizer::CalculateOptimization + UpdatePoses from the summed link sums, on this workgroup's copy
+    TreeKin kin;
+    if (kin_wave) {
+      tree_kin_adjoints(o, links, w, kin, tid);
+      tree_kin_jacobians(o, w, kin, tid);
+    }
+    __syncthreads();
+    tree_system_fast<CONSTRAINED>(o, links, w, gh_links, tid);
+    if (tid < kWave) (void)tree_solve_fast<CONSTRAINED>(o, links, w, tid);
+    __syncthreads();
+    if (st.tracked == 0) {  // every workgroup of the structure holds the same table: the first one writes it
+      for (int i = tid; i < n_links * 48; i += nt) {
+        const int li = i / 48, k = i - li * 48;
+        float* dst = k < 16 ? table_out[li].body2joint : (k < 32 ? table_out[li].joint2parent : table_out[li].link2world);
+        const float* src = k < 16 ? links[li].body2joint : (k < 32 ? links[li].joint2parent : links[li].link2world);
+        dst[k & 15] = src[k & 15];
+      }
+      if (flags & TSEG_FINAL)
+        for (int i = tid; i < n_links * 16; i += nt) {
+          const int li = i >> 4;
+          if (links[li].body >= 0) body_poses[16 * links[li].body + (i & 15)] = links[li].link2world[i & 15];
+        }
+    }
+  }
+  float* pose = links[st.link].link2world;
+  CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
+  CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
+  CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
+  int region_view = rm ? *as_global(rm->last_view) : -1;
+  if (flags & TSEG_SEARCH) {
+    const Affine b2w = load_pose(pose);
+    if (rm) {
+      const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+      Affine b2dc = b2c;
+      if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
+      region_view = region_correspondences<false, 8, true, true>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, 0, 1 << 30,
+                                                                 nullptr, region_view);
+      region_moments(*rm, s);
+    }
+    if (dm) {
+      const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
+      depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, 0, 1 << 30,
+                                 (rm && dm->view_search_shared) ? region_view : -1);
+      depth_correspondences_vote<true, true>(*dm, iteration, ps, np, s.misc);
+    } else {
+      __syncthreads();
+    }
+    if (rm && tid == 0) *as_global_w(rm->last_view) = region_view;
+    if (flags & TSEG_STORE_STATE) {  // (the layout of the unfused kernels' line / point state: compact stride)
+      if (rm)
+        for (int i = tid; i < LS_FIELDS * rm->n_lines_max; i += nt) {
+          const int f = i / rm->n_lines_max, l = i - f * rm->n_lines_max;
+          rm->line_state[i] = s.state[f * s.nl + l];
+        }
+      if (dm)
+        for (int i = tid; i < PS_FIELDS * dm->n_points_max; i += nt) {
+          const int f = i / dm->n_points_max, l = i - f * dm->n_points_max;
+          dm->point_state[i] = ps[f * np + l];
+        }
+    }
+  } else if (flags & TSEG_LOAD_STATE) {
+    if (rm) {
+      for (int i = tid; i < LS_FIELDS * rm->n_lines_max; i += nt) {
+        const int f = i / rm->n_lines_max, l = i - f * rm->n_lines_max;
+        s.state[f * s.nl + l] = rm->line_state[i];
+      }
+      for (int l = rm->n_lines_max + tid; l < s.nl; l += nt) s.state[LS_VALID * s.nl + l] = i2f_bits(0);
+    }
+    if (dm) {
+      for (int i = tid; i < PS_FIELDS * dm->n_points_max; i += nt) {
+        const int f = i / dm->n_points_max, l = i - f * dm->n_points_max;
+        ps[f * np + l] = dm->point_state[i];
+      }
+      for (int l = dm->n_points_max + tid; l < np; l += nt) ps[PS_VALID * np + l] = i2f_bits(0);
+    }
+    __syncthreads();
+  }
+  if (flags & TSEG_SUMS) {
+    const Affine b2w = load_pose(pose);
+    if (rm) {
+      const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+      region_products(*rm, *cam, b2c, c, u, s, rows_r, layout.pitch_r);
+    }
+    if (dm) {
+      const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
+      depth_products(*dm, b2c, c, ps, np, rows_d, layout.pitch_d);
+    }
+    __syncthreads();
+    float* out = sp.sums_out + (size_t)o.first_link * 42;
+    if (tid < kWave) {  // one wave: the sums in the reference's order, the link's sum
+      float sum_r = 0.0f, sum_d = 0.0f;
+      chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
+                 chain_slots(np), gh_lane_row(tid < 42 ? tid : 0), sum_r, sum_d);
+      float gh = 0.0f;  // Link::CalculateGradientAndHessian link.cpp:184-193, in the order of Link::modalities
+      if (rm && dm && !st.region_first) { gh += sum_d; gh += sum_r; }
+      else { if (rm) gh += sum_r; if (dm) gh += sum_d; }
+      if (tid < 42) out[st.link * 42 + tid] = gh;
+    } else if (st.tracked == 0) {
+      // links without modalities on this rank add nothing (x + 0 = x on every rank: the all-reduce is exact)
+      for (int i = tid - kWave; i < n_links * 42; i += nt - kWave)
+        if (links[i / 42].n_gh == 0) out[i] = 0.0f;
+    }
+  }
+  if ((flags & TSEG_FINAL) && fuse_histogram && rm) {  // RegionModality::CalculateResults :572-583 in the same launch
+    const Affine b2w = load_pose(pose);
+    __syncthreads();
+    const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+    Affine b2dc = b2c;
+    if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
+    const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
+    region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
+                            (__attribute__((address_space(3))) uint32_t*)(lds_tree + M3T_MISC_FLOATS), lds_tree, 0, -1,
+                            nullptr, 0, 0, region_view);
+  }
+}
+
 extern "C" {
 
 // kinematic structures without Constraint / SoftConstraint objects (a chain, a tree): no constraint code in the kernel
@@ -1683,6 +1893,24 @@ tracking_step_tree_constrained_kernel(const TreeStepDev* steps, const TreeOptDev
                                       TreeStepParams xp) {
   tree_step_body<true>(steps, opts, rmods, dmods, cams, body_poses, layout, off_points, np, off_tree, iteration,
                        n_corr_iterations, n_update_iterations, fuse_histogram, xp);
+}
+
+// (a structure spread over processes: one launch per Newton step, the all-reduce of the link sums between two launches)
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_tree_segment_kernel(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
+                                  const DepthModDev* dmods, const CameraDev* cams, float* body_poses, TrackLdsLayout layout,
+                                  int off_points, int np, int off_tree, int iteration, int fuse_histogram,
+                                  TreeSegmentParams sp) {
+  tree_segment_body<false>(steps, opts, rmods, dmods, cams, body_poses, layout, off_points, np, off_tree, iteration,
+                           fuse_histogram, sp);
+}
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_tree_segment_constrained_kernel(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
+                                              const DepthModDev* dmods, const CameraDev* cams, float* body_poses,
+                                              TrackLdsLayout layout, int off_points, int np, int off_tree, int iteration,
+                                              int fuse_histogram, TreeSegmentParams sp) {
+  tree_segment_body<true>(steps, opts, rmods, dmods, cams, body_poses, layout, off_points, np, off_tree, iteration,
+                          fuse_histogram, sp);
 }
 
 __global__ void __launch_bounds__(64)

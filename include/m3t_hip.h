@@ -95,7 +95,7 @@ int m3t_hip_camera_set_world2camera_pose(m3t_hip_context*, int camera_id, const 
 int m3t_hip_camera_set_ring(m3t_hip_context*, int camera_id, int n_slots);
 int m3t_hip_camera_upload_slot(m3t_hip_context*, int camera_id, int slot, const void* pixels, size_t row_step);
 int m3t_hip_camera_select_slot(m3t_hip_context*, int camera_id, int slot);
-int m3t_hip_cameras_select_slot(m3t_hip_context*, int slot); /* all cameras */
+int m3t_hip_cameras_select_slot(m3t_hip_context*, int slot); /* all cameras that have a ring (one without keeps its frame) */
 /* asynchronous ingest (replaces the blocking cv::Mat hand-over of Camera::UpdateImage,
  * camera.h:32-88, for callers that keep their frames in page-locked memory).  upload_slot_async enqueues
  * the copy on the context's copy stream and returns; `pixels` must stay valid until ingest_sync() or
