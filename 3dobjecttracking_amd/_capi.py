@@ -312,6 +312,7 @@ _HIP_ONLY = {
     "set_roi_ingest": [C.c_int, C.c_float],
     "cameras_upload_batch_roi_async": [c_int_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t],
     "roi_get_status": [c_int_p, C.c_int, c_int_p, C.POINTER(C.c_longlong)],
+    "roi_get_unrecovered": [c_int_p, C.c_int, c_int_p],
     "reserve_ingest_cus": [C.c_int],
     "camera_select_slot": [C.c_int, C.c_int],
     "cameras_select_slot": [C.c_int],
@@ -343,7 +344,7 @@ def pose_ret(buf):
 
 
 _NEWER_ENTRY_POINTS = ("get_step_kernel", "comm_get_allreduce_count", "comm_get_rank_count", "debug_log_checksum", "set_roi_ingest",
-                       "cameras_upload_batch_roi_async", "roi_get_status", "reserve_ingest_cus", "camera_slot_sync")
+                       "cameras_upload_batch_roi_async", "roi_get_status", "roi_get_unrecovered", "reserve_ingest_cus", "camera_slot_sync")
 
 
 class CApi:

@@ -438,95 +438,19 @@ __global__ void __launch_bounds__(M3T_COMPACT_THREADS, M3T_COMPACT_WAVES)
 tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                              const CameraDev* cams, float* body_poses, CompactLayout L, int iteration,
                              int n_corr_iterations, int n_update_iterations, int fuse_histogram) {
-  extern __shared__ __attribute__((aligned(16))) float lds_c[];
-  COpt& o = *(COpt*)(opts + blockIdx.x);
-  CRegion* rm = o.region_modality >= 0 ? (CRegion*)(rmods + o.region_modality) : nullptr;
-  CDepth* dm = o.depth_modality >= 0 ? (CDepth*)(dmods + o.depth_modality) : nullptr;
-  float* misc = lds_c;
-  float* state = lds_c + L.off_state;
-  float* rows_r = lds_c + L.off_rows_r;
-  float* ps = lds_c + L.off_points;
-  float* rows_d = lds_c + L.off_rows_d;
-  float* pose = misc + kCMiscPose;
-  const int nl = L.nl, np = L.np;
-  if (threadIdx.x < 16) pose[threadIdx.x] = body_poses[16 * o.body + threadIdx.x];
-  if (rm) {
-    stage_log_table(misc);
-    for (int i = threadIdx.x; i < L.pitch_r; i += blockDim.x) rows_r[8 * L.pitch_r + i] = -1.0f;
-  }
-  if (dm)
-    for (int i = threadIdx.x; i < L.pitch_d; i += blockDim.x) rows_d[8 * L.pitch_d + i] = 1.0f;
-  __syncthreads();
-  CCam* cam = rm ? (CCam*)(cams + rm->camera) : nullptr;
-  CCam* rdcam = (rm && rm->measure_occlusions) ? (CCam*)(cams + rm->depth_camera) : nullptr;
-  CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
-  // ROI ingest: the poses this step reads its frames at (m3t_ingest.hip checks them against what was uploaded)
-  GW<float> search_poses = as_global_w(o.search_poses);
-  const bool record_poses = o.search_poses != nullptr && threadIdx.x < 16;
-  if (record_poses) search_poses[threadIdx.x] = pose[threadIdx.x];
-  int region_view = rm ? *as_global(rm->last_view) : -1;  // the view of the modality's previous search
-  for (int c = 0; c < n_corr_iterations; ++c) {
-    if (record_poses) search_poses[(c + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
-    {
-      const Affine b2w = load_pose(pose);
-      if (rm) {
-        const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
-        Affine b2dc = b2c;
-        if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_view = compact_region_correspondences(*rm, *cam, rdcam, b2c, b2dc, iteration, c, misc, state, nl, region_view);
-      }
-      if (dm) {
-        const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
-        depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, misc, 0, 1 << 30,
-                                   (rm && dm->view_search_shared) ? region_view : -1);
-        depth_correspondences_vote(*dm, iteration, ps, np, misc);
-      }
-    }
-    for (int u = 0; u < n_update_iterations; ++u) {
-      const Affine b2w = load_pose(pose);
-      if (rm) {
-        const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
-        compact_region_products(*rm, *cam, b2c, c, u, misc, state, nl, rows_r, L.pitch_r);
-      }
-      if (dm) {
-        const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
-        compact_depth_products(*dm, b2c, c, ps, np, rows_d, L.pitch_d);
-      }
-      __syncthreads();
-      if (threadIdx.x < kWave) {  // one wave: the sums, Link::CalculateGradientAndHessian link.cpp:184-193, solve, pose
-        float sum_r = 0.0f, sum_d = 0.0f;
-        compact_chain(rm ? rows_r : nullptr, L.pitch_r, chain_slots(nl), dm ? rows_d : nullptr, L.pitch_d,
-                      chain_slots(np), threadIdx.x, sum_r, sum_d);
-        float gh = 0.0f;
-        if (rm) gh += sum_r;
-        if (dm) gh += sum_d;
-        rigid_solve_wave(gh, o.tikhonov_rotation, o.tikhonov_translation, (LdsW)pose, (LdsW)(misc + kMiscSolve));
-      }
-      __syncthreads();
-    }
-  }
-  if (threadIdx.x < 16) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
-  if (rm && threadIdx.x == 0) *as_global_w(rm->last_view) = region_view;
-  if (record_poses) search_poses[(n_corr_iterations + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
-  if (fuse_histogram && rm) {
-    // RegionModality::CalculateResults :572-583 in the same launch: the carve-up is free now (first 1024 floats =
-    // the scratch block of region_histogram_update).  While this workgroup streams its histograms through the blend,
-    // the CU's other workgroups walk their lines: HBM streaming beside L1-gather-bound work.
-    const Affine b2w = load_pose(pose);
-    __syncthreads();
-    const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
-    Affine b2dc = b2c;
-    if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-    const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
-    auto* counts = (__attribute__((address_space(3))) uint32_t*)(lds_c + L.off_tail_counts);
-    if (L.tail_pass_bins > 0)
-      region_histogram_update<false, true, false>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false, counts, lds_c, 0, -1,
-                                           reinterpret_cast<uint16_t*>(lds_c + L.off_tail_list), L.tail_list_row,
-                                           L.tail_pass_bins, region_view);
-    else
-      region_histogram_update<false, false, false>(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false, counts, lds_c, 0, -1,
-                                                   nullptr, 0, 0, region_view);
-  }
+  const RoiGuardArgs guard{};  // (unused)
+#define M3T_COMPACT_GUARD false
+#include "m3t_compact_step.inc"
+#undef M3T_COMPACT_GUARD
+}
+// ... reading frame slots that hold the trackers' rectangles only (ROI ingest)
+__global__ void __launch_bounds__(M3T_COMPACT_THREADS, M3T_COMPACT_WAVES)
+tracking_step_compact_guard_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                                   const CameraDev* cams, float* body_poses, CompactLayout L, int iteration,
+                                   int n_corr_iterations, int n_update_iterations, int fuse_histogram, RoiGuardArgs guard) {
+#define M3T_COMPACT_GUARD true
+#include "m3t_compact_step.inc"
+#undef M3T_COMPACT_GUARD
 }
 
 }  // extern "C"

@@ -189,6 +189,28 @@ struct RoiItemDev {
   float reach_px, reach_m;       // the modality's reach (m3t_roi.h), without the caller's margin
 };
 
+// ROI guard (tracking_step_*_guard_kernel): appended to an object's search-pose block, at search_poses + 16 * n_poses.
+// flag: the object's last guarded step needed pixels outside its rectangle and was NOT committed (pose, histograms and
+// modality state are those before the step); the repeat launch (mode 2) runs the flagged objects only and clears it.
+#define M3T_ROI_GUARD_ITEMS 3 /* readers per object: region (colour), region (depth: measured occlusions), depth */
+struct RoiGuardDev {
+  int flag;
+  int n_items;
+  int item[M3T_ROI_GUARD_ITEMS];  // rows of the RoiItemDev table
+  int reserved[3];
+};
+struct m3t_roi_rect;
+struct RoiGuardArgs {
+  const RoiItemDev* items;
+  const m3t_roi_rect* rects;  // [slot][camera id]
+  int n_cams, n_rect_slots;
+  int n_poses;                // floats of an object's search-pose block in front of its RoiGuardDev: 16 * n_poses
+  int mode;                   // 1: every object, flag the ones that leave their rectangles; 2: the flagged ones only
+  int* misses;                // mapped host memory: [0] count, [1 ..] body ids (mode 1)
+  int miss_capacity;
+  int* unrecovered;           // the same for objects that miss again in mode 2 (no whole frame could be fetched)
+};
+
 // LDS carve-up of the tracking kernels, computed on the host from the maxima
 // over all objects of one launch.
 struct TrackLdsLayout {

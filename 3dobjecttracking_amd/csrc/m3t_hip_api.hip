@@ -251,24 +251,43 @@ struct m3t_hip_context {
   const char* last_step_kernel = "";   // m3t_hip_get_step_kernel
   // ROI ingest (m3t_ingest.hip): rectangles instead of whole frames
   bool roi_enabled = false;        // m3t_hip_set_roi_ingest
+  bool roi_adaptive = false;       // ... with enable = 2: per-body margins from the motion over the last step
   float roi_margin_px = 0.0f;
-  bool roi_recorded = false;       // the last step left its search poses (a fused rigid launch): the next pull may use them
+  bool roi_recorded = false;       // the last step was a fused rigid launch with the ROI tables in place: the next pull may go as rectangles
   int roi_n_poses = 0;             // n_corr_iterations + 2
   int n_roi_items = 0;
   long long roi_pulls = 0;         // batch-frames uploaded as rectangles so far
-  DevMem d_search_poses, d_roi_items, d_roi_item_first, d_roi_cam_ids, d_roi_rects, d_roi_pose_snapshot;
-  std::vector<int> roi_cam_ids;    // what d_roi_cam_ids holds
+  long long roi_repeated = 0;      // bodies whose step was repeated on whole frames so far (read with roi_get_status)
+  DevMem d_search_poses, d_roi_items, d_roi_item_first, d_roi_cam_ids, d_roi_all_cam_ids, d_roi_rects, d_roi_pose_snapshot,
+         d_roi_motion_peak;  // [reader]: adaptive margins (roi_rect_kernel)
+  std::vector<int> roi_cam_ids;    // what d_roi_cam_ids holds (a batch whose ids are not consecutive)
   int roi_rect_slots = 0;          // d_roi_rects: [slot][camera id]
-  // two snapshots of the bodies' poses, alternating: taken at the END of every fused rigid step (= the poses the next
+  // Where the whole frames behind the rectangles of a slot are (the repair after a guarded step reads them): one entry
+  // per batch upload into the slot, replaced by the next upload of the same cameras.  The host block has to stay what
+  // it is until the step that reads the slot is done -- the lifetime rule of every asynchronous upload.
+  struct RoiSource {
+    std::vector<int> ids;          // the batch's cameras (ring order)
+    const int* d_ids = nullptr;    // the same on the device
+    const uint8_t* src = nullptr;  // device address of the mapped host block
+    size_t camera_stride = 0;
+    uint32_t row_step = 0;
+  };
+  std::vector<std::vector<RoiSource>> roi_sources;  // [slot]
+  // three snapshots of the bodies' poses, in turn: taken at the END of every fused rigid step (= the poses the next
   // step starts from, available a whole pull earlier than a snapshot at that step's start), or at a step's start when
-  // the previous step's end does not vouch for them (first step, poses set by the host, other launches in between)
-  hipEvent_t roi_snapshot_done[2] = {nullptr, nullptr};
+  // the previous step's end does not vouch for them (first step, poses set by the host, other launches in between).
+  // A rectangle upload reads the newest one and, for adaptive margins, the one before it.
+  static constexpr int kRoiSnapshots = 3;
+  hipEvent_t roi_snapshot_done[kRoiSnapshots] = {nullptr, nullptr, nullptr};
   bool roi_snapshot_valid = false;
   int roi_use = 0;              // the snapshot the next rectangle upload reads: the poses at the start of the step enqueued last
+  int roi_prev = -1;            // the snapshot one step before roi_use (-1: none)
   int roi_end_index = 0;        // where the last step's end-of-step snapshot went
   bool roi_end_valid = false;   // ... and whether it still describes the device poses
-  int* roi_miss_host = nullptr;             // mapped: [0] count, [1 ..] body ids
+  int* roi_miss_host = nullptr;             // mapped: [0] count, [1 ..] body ids: steps that left their rectangles (and were repeated)
   int* roi_miss_dev = nullptr;
+  int* roi_unrecovered_host = nullptr;      // the same for bodies whose repeat missed again (no whole frame within reach)
+  int* roi_unrecovered_dev = nullptr;
   static constexpr int kRoiMissCapacity = 255;
   int np_max = 0, off_points = 0;
   size_t lds_track = 0, lds_corr = 0, lds_hist = 0, lds_depth = 0;
@@ -498,6 +517,7 @@ int CreateCamera(Ctx* ctx, const m3t_intrinsics* intr, const float* w2c, bool de
 }
 
 void RoiMarkWholeFrame(Ctx* ctx, int camera, int slot, hipStream_t stream);  // (ROI ingest, below)
+void RoiMarkWholeFrames(Ctx* ctx, const int* ids, int n, int slot, hipStream_t stream);
 
 int UploadFrame(Ctx* ctx, int id, int slot, const void* pixels, size_t row_step) {
   REQUIRE(id >= 0 && id < int(ctx->cameras.size()) && pixels, M3T_ERR_INVALID_ARGUMENT, "bad camera id");
@@ -1095,9 +1115,12 @@ int BuildRoiTables(Ctx* ctx) {
   for (auto& od : ctx->opt_table) od.search_poses = nullptr;
   if (!ctx->roi_enabled || ctx->tree_mode || ctx->opt_table.empty()) return M3T_OK;
   ctx->roi_n_poses = ctx->n_corr_iterations + 2;
-  const size_t per_object = size_t(ctx->roi_n_poses) * 16;
+  // per object: the poses, then the guard's header (RoiGuardDev: which rows of the reader table are this object's)
+  static_assert(sizeof(RoiGuardDev) % 4 == 0, "RoiGuardDev is addressed in floats");
+  const size_t per_object = size_t(ctx->roi_n_poses) * 16 + sizeof(RoiGuardDev) / 4;
   HIPCHK(ctx->d_search_poses.alloc(ctx->opt_table.size() * per_object * 4));
   HIPCHK(hipMemset(ctx->d_search_poses.p, 0, ctx->opt_table.size() * per_object * 4));
+  ctx->roi_prev = -1;
   std::vector<RoiItemDev> items;
   auto add = [&](int camera, int body, int opt, const Model& model, float reach_px, float reach_m) {
     RoiItemDev it{};
@@ -1145,11 +1168,31 @@ int BuildRoiTables(Ctx* ctx) {
     HIPCHK(hipMemcpy(ctx->d_roi_items.p, items.data(), items.size() * sizeof(RoiItemDev), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(ctx->d_roi_item_first.p, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
   ctx->n_roi_items = int(items.size());
+  HIPCHK(ctx->d_roi_motion_peak.alloc(std::max<size_t>(1, items.size()) * sizeof(float)));
+  {  // (until a body's motion is known its margin is the caller's)
+    std::vector<float> peaks(std::max<size_t>(1, items.size()), -1.0f);
+    HIPCHK(hipMemcpy(ctx->d_roi_motion_peak.p, peaks.data(), peaks.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  {  // the guard's headers: every object's readers by their rows in the sorted table
+    std::vector<float> blocks(ctx->opt_table.size() * per_object, 0.0f);
+    for (size_t j = 0; j < items.size(); ++j) {
+      RoiGuardDev* g = reinterpret_cast<RoiGuardDev*>(blocks.data() + size_t(items[j].opt) * per_object + size_t(ctx->roi_n_poses) * 16);
+      if (g->n_items < M3T_ROI_GUARD_ITEMS) g->item[g->n_items++] = int(j);
+    }
+    HIPCHK(hipMemcpy(ctx->d_search_poses.p, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice));
+  }
+  {  // the camera ids in order: a batch of consecutive ids needs no list of its own
+    std::vector<int> all(std::max<size_t>(1, n_cams));
+    for (size_t c = 0; c < n_cams; ++c) all[c] = int(c);
+    HIPCHK(ctx->d_roi_all_cam_ids.alloc(all.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(ctx->d_roi_all_cam_ids.p, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   int slots = 1;
   for (auto& c : ctx->cameras) slots = std::max(slots, c->n_slots);
   ctx->roi_rect_slots = slots;
   HIPCHK(ctx->d_roi_rects.alloc(size_t(slots) * n_cams * sizeof(m3t_roi_rect)));
-  HIPCHK(ctx->d_roi_pose_snapshot.alloc(2 * std::max<size_t>(64, ctx->body_poses.size() * 4)));  // two snapshots
+  ctx->roi_sources.assign(size_t(slots), {});
+  HIPCHK(ctx->d_roi_pose_snapshot.alloc(Ctx::kRoiSnapshots * std::max<size_t>(64, ctx->body_poses.size() * 4)));
   for (auto& e : ctx->roi_snapshot_done)
     if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   {  // what every slot holds now: a whole frame, or (a rectangle from before the rebuild) nothing that can be vouched for
@@ -1160,26 +1203,47 @@ int BuildRoiTables(Ctx* ctx) {
           rects[size_t(sl) * n_cams + c] = m3t_roi_rect{0, 0, ctx->cameras[c]->intr.width - 1, ctx->cameras[c]->intr.height - 1};
     HIPCHK(hipMemcpy(ctx->d_roi_rects.p, rects.data(), rects.size() * sizeof(m3t_roi_rect), hipMemcpyHostToDevice));
   }
-  if (!ctx->roi_miss_host) {
+  if (!ctx->roi_miss_host) {  // two lists in one mapped block: misses (repeated), misses of the repeat
     void *host = nullptr, *dev = nullptr;
-    HIPCHK(hipHostMalloc(&host, (Ctx::kRoiMissCapacity + 1) * sizeof(int), hipHostMallocMapped));
-    std::memset(host, 0, (Ctx::kRoiMissCapacity + 1) * sizeof(int));
+    const size_t list = Ctx::kRoiMissCapacity + 1;
+    HIPCHK(hipHostMalloc(&host, 2 * list * sizeof(int), hipHostMallocMapped));
+    std::memset(host, 0, 2 * list * sizeof(int));
     HIPCHK(hipHostGetDevicePointer(&dev, host, 0));
     ctx->roi_miss_host = static_cast<int*>(host);
     ctx->roi_miss_dev = static_cast<int*>(dev);
+    ctx->roi_unrecovered_host = ctx->roi_miss_host + list;
+    ctx->roi_unrecovered_dev = ctx->roi_miss_dev + list;
   }
   return M3T_OK;
 }
 
-// a whole frame was (or is being, on `stream`) written into (camera, slot)
-void RoiMarkWholeFrame(Ctx* ctx, int camera, int slot, hipStream_t stream) {
-  Camera& c = *ctx->cameras[camera];
-  c.slot_is_roi[slot] = false;
+// whole frames were (or are being, on `stream`) written into the slot of the cameras ids[0 .. n): ONE launch notes
+// that in the rectangle table (round 4 launched one single-thread kernel per camera: 64 per batch-frame)
+void RoiMarkWholeFrames(Ctx* ctx, const int* ids, int n, int slot, hipStream_t stream) {
+  bool consecutive = true;
+  for (int i = 0; i < n; ++i) {
+    ctx->cameras[ids[i]]->slot_is_roi[slot] = false;
+    consecutive = consecutive && ids[i] == ids[0] + i;
+  }
+  if (slot < int(ctx->roi_sources.size())) {  // the whole frames replace what the rectangles of these cameras came from
+    auto& sources = ctx->roi_sources[size_t(slot)];
+    for (size_t k = 0; k < sources.size();) {
+      bool overlaps = false;
+      for (int i = 0; i < n && !overlaps; ++i)
+        overlaps = std::find(sources[k].ids.begin(), sources[k].ids.end(), ids[i]) != sources[k].ids.end();
+      if (overlaps) sources.erase(sources.begin() + long(k)); else ++k;
+    }
+  }
   if (!ctx->roi_enabled || ctx->n_roi_items == 0 || slot >= ctx->roi_rect_slots || ctx->tables_dirty) return;
-  hipLaunchKernelGGL(roi_set_rect_kernel, dim3(1), dim3(1), 0, stream,
-                     ctx->d_roi_rects.as<m3t_roi_rect>() + size_t(slot) * ctx->cameras.size() + camera, 0, 0,
-                     c.intr.width - 1, c.intr.height - 1);
+  m3t_roi_rect* rects = ctx->d_roi_rects.as<m3t_roi_rect>() + size_t(slot) * ctx->cameras.size();
+  // (a batch is a group of cameras of equal geometry: m3t_hip_cameras_set_ring)
+  for (int i = 0; i < n; i += consecutive ? n : 1) {
+    const Camera& c = *ctx->cameras[ids[i]];
+    hipLaunchKernelGGL(roi_set_rects_kernel, dim3(((consecutive ? n : 1) + 63) / 64), dim3(64), 0, stream, rects, ids[i],
+                       consecutive ? n : 1, c.intr.width, c.intr.height);
+  }
 }
+void RoiMarkWholeFrame(Ctx* ctx, int camera, int slot, hipStream_t stream) { RoiMarkWholeFrames(ctx, &camera, 1, slot, stream); }
 
 int UploadTables(Ctx* ctx) {
   if (ctx->copies_pending) {
@@ -1954,8 +2018,18 @@ int m3t_hip_camera_slot_sync(m3t_hip_context* ctx, int id, int slot) {
   REQUIRE(id >= 0 && id < int(ctx->cameras.size()), M3T_ERR_INVALID_ARGUMENT, "bad camera id");
   Camera& c = *ctx->cameras[id];
   REQUIRE(slot >= 0 && slot < c.n_slots, M3T_ERR_INVALID_ARGUMENT, "bad frame slot");
-  if (size_t(slot) >= c.slot_copied.size() || !c.slot_copied[slot]) return M3T_OK;  // nothing was enqueued
   HIPCHK(hipSetDevice(ctx->device));
+  if (c.slot_is_roi[slot]) {
+    // a rectangle went into the slot (m3t_hip_cameras_upload_batch_roi_async): the host block is read by the pull and,
+    // should a body outrun its rectangle, again by the repair of the step that reads the slot -- both must be over
+    if (ctx->async_ingest && ctx->copy_stream[0]) HIPCHK(hipStreamSynchronize(ctx->copy_stream[0]));
+    if (c.last_read_step[slot] >= 0 && c.last_read_step[slot] + Ctx::kStepEvents > ctx->step_counter)
+      HIPCHK(hipEventSynchronize(ctx->step_done[c.last_read_step[slot] % Ctx::kStepEvents]));
+    else if (c.last_read_step[slot] >= 0)
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    return M3T_OK;
+  }
+  if (size_t(slot) >= c.slot_copied.size() || !c.slot_copied[slot]) return M3T_OK;  // nothing was enqueued
   HIPCHK(hipEventSynchronize(c.slot_copied[slot]));
   return M3T_OK;
 }
@@ -2052,10 +2126,8 @@ int m3t_hip_cameras_upload_batch_async(m3t_hip_context* ctx, const int* ids, int
   else
     HIPCHK(hipMemcpy2DAsync(dst, c0.pitch, base, row_step, row, size_t(c0.intr.height) * size_t(n), hipMemcpyHostToDevice,
                             ctx->copy_stream[cs]));
-  for (int i = 0; i < n; ++i) {
-    ctx->cameras[ids[i]]->has_image[slot] = true;
-    RoiMarkWholeFrame(ctx, ids[i], slot, ctx->copy_stream[cs]);
-  }
+  for (int i = 0; i < n; ++i) ctx->cameras[ids[i]]->has_image[slot] = true;
+  RoiMarkWholeFrames(ctx, ids, n, slot, ctx->copy_stream[cs]);
   ctx->copies_pending |= 1u << cs;
   return M3T_OK;
 }
@@ -2066,8 +2138,10 @@ int m3t_hip_cameras_upload_batch_async(m3t_hip_context* ctx, const int* ids, int
 int m3t_hip_set_roi_ingest(m3t_hip_context* ctx, int enable, float margin_px) {
   CHECK_CTX();
   REQUIRE(margin_px >= 0.0f && margin_px < 1.0e6f, M3T_ERR_INVALID_ARGUMENT, "bad margin");
+  REQUIRE(enable >= 0 && enable <= 2, M3T_ERR_INVALID_ARGUMENT, "enable: 0 (off), 1 (one margin for all bodies) or 2 (adaptive margins)");
   if ((enable != 0) != ctx->roi_enabled) ctx->tables_dirty = true;
   ctx->roi_enabled = enable != 0;
+  ctx->roi_adaptive = enable == 2;
   ctx->roi_margin_px = margin_px;
   return M3T_OK;
 }
@@ -2088,28 +2162,44 @@ int m3t_hip_reserve_ingest_cus(m3t_hip_context* ctx, int n_cus) {
   // need all of theirs resident at once
   REQUIRE(n_cus % 32 == 0, M3T_ERR_INVALID_ARGUMENT,
           "n_cus must be a multiple of 32 (one CU from each of the 4 shader engines of each of the 8 XCDs)");
+  // the mask layout above (bit i -> XCD i mod 8, the highest bits of an XCD = the last CU of each shader engine) and the
+  // multiple-of-32 rule were probed on MI355X in SPX mode (tools/ubench_cumask.hip): on another part or partition mode
+  // the split / tree launches, which need all their workgroups resident, could be planned wrong
+  REQUIRE(n_cus == 0 || (ctx->prop.multiProcessorCount == 256 && std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) == 0),
+          M3T_ERR_UNSUPPORTED, "CU reservation is laid out for MI355X (gfx950, 256 CUs in one partition)");
   if (n_cus == ctx->ingest_cus) return M3T_OK;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (auto& cs : ctx->copy_stream)
     if (cs) HIPCHK(hipStreamSynchronize(cs));
+  // all new streams first, then the swap: a failure leaves the context as it was.  (hipExtStreamCreateWithCUMask makes
+  // BLOCKING streams: while CUs are reserved, work on the legacy NULL stream -- a plain hipMemcpy, torch's default
+  // stream -- synchronises with the compute stream and copy stream 0; keep such work off the device meanwhile, or
+  // the pull / step overlap is lost.)
   const int before = ctx->ingest_cus;
   ctx->ingest_cus = n_cus;
   hipStream_t compute = nullptr;
-  if (CreateMaskedStream(ctx, &compute, false) != hipSuccess) {
+  hipStream_t copies_old[Ctx::kCopyStreams];
+  for (int i = 0; i < Ctx::kCopyStreams; ++i) {
+    copies_old[i] = ctx->copy_stream[i];
+    ctx->copy_stream[i] = nullptr;
+  }
+  hipError_t e = CreateMaskedStream(ctx, &compute, false);
+  if (e == hipSuccess && ctx->async_ingest) e = CreateCopyStreams(ctx);
+  if (e != hipSuccess) {
     (void)hipGetLastError();
+    if (compute) (void)hipStreamDestroy(compute);
+    for (int i = 0; i < Ctx::kCopyStreams; ++i) {
+      if (ctx->copy_stream[i]) (void)hipStreamDestroy(ctx->copy_stream[i]);
+      ctx->copy_stream[i] = copies_old[i];
+    }
     ctx->ingest_cus = before;
     return Fail(ctx, M3T_ERR_UNSUPPORTED, "this device / runtime does not create CU-masked streams");
   }
-  HIPCHK(hipStreamDestroy(ctx->stream));
+  (void)hipStreamDestroy(ctx->stream);
   ctx->stream = compute;
-  if (ctx->async_ingest) {
-    for (auto& cs : ctx->copy_stream) {
-      if (cs) HIPCHK(hipStreamDestroy(cs));
-      cs = nullptr;
-    }
-    HIPCHK(CreateCopyStreams(ctx));
-  }
+  for (auto& cs : copies_old)
+    if (cs) (void)hipStreamDestroy(cs);
   ctx->compute_cus = ctx->prop.multiProcessorCount - n_cus;
   ctx->copies_pending = 0;
   return M3T_OK;
@@ -2151,11 +2241,19 @@ int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context* ctx, const int* ids,
   if (!pull) return m3t_hip_cameras_upload_batch_async(ctx, ids, n, slot, base, camera_stride, row_step);
   HIPCHK(hipSetDevice(ctx->device));
   const int cs = 0;
-  if (ctx->roi_cam_ids != std::vector<int>(ids, ids + n)) {  // (rare: the batch's camera list changed)
-    HIPCHK(hipStreamSynchronize(ctx->copy_stream[cs]));
-    ctx->roi_cam_ids.assign(ids, ids + n);
-    HIPCHK(ctx->d_roi_cam_ids.alloc(size_t(n) * sizeof(int)));
-    HIPCHK(hipMemcpy(ctx->d_roi_cam_ids.p, ids, size_t(n) * sizeof(int), hipMemcpyHostToDevice));
+  bool consecutive = true;
+  for (int i = 0; i < n; ++i) consecutive = consecutive && ids[i] == ids[0] + i;
+  const int* d_ids = ctx->d_roi_all_cam_ids.as<int>() + ids[0];
+  if (!consecutive) {
+    if (ctx->roi_cam_ids != std::vector<int>(ids, ids + n)) {  // (rare: a scattered batch whose camera list changed)
+      HIPCHK(hipStreamSynchronize(ctx->copy_stream[cs]));
+      HIPCHK(hipStreamSynchronize(ctx->stream));  // (a repair may still read the old list)
+      for (auto& sources : ctx->roi_sources) sources.clear();
+      ctx->roi_cam_ids.assign(ids, ids + n);
+      HIPCHK(ctx->d_roi_cam_ids.alloc(size_t(n) * sizeof(int)));
+      HIPCHK(hipMemcpy(ctx->d_roi_cam_ids.p, ids, size_t(n) * sizeof(int), hipMemcpyHostToDevice));
+    }
+    d_ids = ctx->d_roi_cam_ids.as<int>();
   }
   long last_read = -1;
   for (int i = 0; i < n; ++i) last_read = std::max(last_read, ctx->cameras[ids[i]]->last_read_step[slot]);
@@ -2167,16 +2265,22 @@ int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context* ctx, const int* ids,
     ctx->copy_waited_step[cs] = last_read;
   }
   HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->roi_snapshot_done[ctx->roi_use], 0));  // the poses the rectangles come from
+  const bool adaptive = ctx->roi_adaptive && ctx->roi_prev >= 0;
+  if (adaptive) HIPCHK(hipStreamWaitEvent(ctx->copy_stream[cs], ctx->roi_snapshot_done[ctx->roi_prev], 0));
   const Camera& c0 = *ctx->cameras[ids[0]];
   // the camera table is only read for intrinsics and world2camera here: any slot version will do (the first one)
   m3t_roi_rect* rects = ctx->d_roi_rects.as<m3t_roi_rect>() + size_t(slot) * ctx->cameras.size();
+  const size_t snapshot_floats = ctx->d_roi_pose_snapshot.bytes / (4 * Ctx::kRoiSnapshots);
+  const float* snapshots = ctx->d_roi_pose_snapshot.as<float>();
+  // (without a second snapshot an adaptive upload takes the whole margin)
   hipLaunchKernelGGL(roi_rect_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->copy_stream[cs],
-                     ctx->d_roi_items.as<RoiItemDev>(), ctx->d_roi_item_first.as<int>(), ctx->d_roi_cam_ids.as<int>(), n,
-                     ctx->d_cams.as<CameraDev>(),
-                     ctx->d_roi_pose_snapshot.as<float>() + size_t(ctx->roi_use) * (ctx->d_roi_pose_snapshot.bytes / 8),
-                     ctx->roi_margin_px, rects);
+                     ctx->d_roi_items.as<RoiItemDev>(), ctx->d_roi_item_first.as<int>(), d_ids, n,
+                     ctx->d_cams.as<CameraDev>(), snapshots + size_t(ctx->roi_use) * snapshot_floats,
+                     adaptive ? snapshots + size_t(ctx->roi_prev) * snapshot_floats : (const float*)nullptr,
+                     adaptive ? ctx->d_roi_motion_peak.as<float>() : (float*)nullptr, ctx->roi_margin_px,
+                     std::min(ctx->roi_margin_px, 4.0f), rects);
   hipLaunchKernelGGL(roi_pull_kernel, dim3((c0.intr.height + 7) / 8, n), dim3(256), 0, ctx->copy_stream[cs],
-                     ctx->d_roi_cam_ids.as<int>(), rects, src, camera_stride, uint32_t(row_step), c0.frame(slot),
+                     d_ids, rects, src, camera_stride, uint32_t(row_step), c0.frame(slot),
                      c0.frame_bytes, c0.pitch, c0.is_depth ? 2 : 3);
   HIPCHK(hipGetLastError());
   ++ctx->roi_pulls;
@@ -2184,11 +2288,29 @@ int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context* ctx, const int* ids,
     ctx->cameras[ids[i]]->has_image[slot] = true;
     ctx->cameras[ids[i]]->slot_is_roi[slot] = true;
   }
+  {  // where the whole frames are, should a body outrun its rectangle (the repair of the step that reads this slot)
+    auto& sources = ctx->roi_sources[size_t(slot)];
+    for (size_t k = 0; k < sources.size();) {
+      bool overlaps = false;
+      for (int i = 0; i < n && !overlaps; ++i)
+        overlaps = std::find(sources[k].ids.begin(), sources[k].ids.end(), ids[i]) != sources[k].ids.end();
+      if (overlaps) sources.erase(sources.begin() + long(k)); else ++k;
+    }
+    Ctx::RoiSource source;
+    source.ids.assign(ids, ids + n);
+    source.d_ids = d_ids;
+    source.src = src;
+    source.camera_stride = camera_stride;
+    source.row_step = uint32_t(row_step);
+    sources.push_back(std::move(source));
+  }
   ctx->copies_pending |= 1u << cs;
   return M3T_OK;
 }
-// Bodies whose last checked steps needed pixels outside the rectangle that had been uploaded (their poses since then
-// are not the whole-frame poses): up to `capacity` body ids, *n = how many there were; the list is cleared.
+// Bodies whose steps since the last call needed pixels outside the rectangle that had been uploaded: up to `capacity`
+// body ids, *n = how many there were; the list is cleared.  Such a step is not committed; the library fetched the whole
+// frames and repeated it (m3t_hip_execute_tracking_step), so the poses ARE the whole-frame poses -- the list says how
+// often the margin was too small.  m3t_hip_roi_get_unrecovered names the ones for which that was not possible.
 int m3t_hip_roi_get_status(m3t_hip_context* ctx, int* bodies, int capacity, int* n, long long* n_rectangle_uploads) {
   CHECK_CTX();
   REQUIRE(n && capacity >= 0 && (bodies || capacity == 0), M3T_ERR_INVALID_ARGUMENT, "null output");
@@ -2201,6 +2323,24 @@ int m3t_hip_roi_get_status(m3t_hip_context* ctx, int* bodies, int capacity, int*
   *n = count;
   for (int i = 0; i < std::min(std::min(count, capacity), int(Ctx::kRoiMissCapacity)); ++i) bodies[i] = ctx->roi_miss_host[1 + i];
   std::memset(ctx->roi_miss_host, 0, (Ctx::kRoiMissCapacity + 1) * sizeof(int));
+  return M3T_OK;
+}
+// Bodies whose step left its rectangle AND whose repeat did too (the whole frames were not within reach: the host
+// block of the upload was not recorded for the slot, e.g. after the tables were rebuilt).  Their step was not
+// committed: pose, histograms and modality state are those before it.  Re-upload the frame in full
+// (m3t_hip_cameras_upload_batch_async) and call m3t_hip_execute_tracking_step again -- the bodies that were committed
+// are then stepped a second time, so set their poses back first or accept the extra step.  Cleared by the call.
+int m3t_hip_roi_get_unrecovered(m3t_hip_context* ctx, int* bodies, int capacity, int* n) {
+  CHECK_CTX();
+  REQUIRE(n && capacity >= 0 && (bodies || capacity == 0), M3T_ERR_INVALID_ARGUMENT, "null output");
+  *n = 0;
+  if (!ctx->roi_unrecovered_host) return M3T_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int count = __atomic_load_n(&ctx->roi_unrecovered_host[0], __ATOMIC_ACQUIRE);
+  *n = count;
+  for (int i = 0; i < std::min(std::min(count, capacity), int(Ctx::kRoiMissCapacity)); ++i) bodies[i] = ctx->roi_unrecovered_host[1 + i];
+  std::memset(ctx->roi_unrecovered_host, 0, (Ctx::kRoiMissCapacity + 1) * sizeof(int));
   return M3T_OK;
 }
 int m3t_hip_ingest_sync(m3t_hip_context* ctx) {
@@ -3513,7 +3653,7 @@ int m3t_hip_calculate_results(m3t_hip_context* ctx, int iteration) {
 // with every workgroup resident at once (their in-kernel exchange needs that).
 extern "C++" {
 template <typename K>
-int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_histogram, size_t* lds_out,
+static int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_histogram, size_t* lds_out,
                      int default_limit = 8) {
   const size_t lds_tracking = size_t(ctx->layout.off_hist >= 0 ? ctx->layout.off_hist : ctx->layout.total_floats) * 4;
   // (each workgroup counts its share of the histogram bins: that share of the count table; the pair table is
@@ -3545,7 +3685,7 @@ int ChooseSplitParts(Ctx* ctx, K kernel, int n, int threads, bool want_fused_his
 }
 }  // extern "C++"
 // the exchange buffers and the per-launch descriptor of a split launch
-int PrepareSplit(Ctx* ctx, int n, int parts, SplitParams* out) {
+static int PrepareSplit(Ctx* ctx, int n, int parts, SplitParams* out) {
   const size_t per_object = size_t(2) * M3T_SPLIT_LANES * 32;  // granules
   if (!ctx->split_abort_host) {
     void* host = nullptr;
@@ -3600,15 +3740,18 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
           "a frame slot holds the trackers' rectangle only (ROI ingest): that needs the fused step of rigid objects");
   const bool roi_active = ctx->roi_enabled && ctx->n_roi_items > 0 && rigid_fused;
   float* const roi_snapshots = ctx->d_roi_pose_snapshot.as<float>();
-  const size_t roi_snapshot_floats = ctx->d_roi_pose_snapshot.bytes / 8;
+  const size_t roi_snapshot_floats = ctx->d_roi_pose_snapshot.bytes / (4 * Ctx::kRoiSnapshots);
   if (roi_active) {
     // the poses the NEXT frame's rectangles are computed from (m3t_hip_cameras_upload_batch_roi_async, copy stream):
     // the poses this step starts from.  The previous step's end-of-step snapshot holds exactly those -- and was ready
     // before this step had to wait for its own frame, so the next pull can follow the current one at once -- unless
-    // something else touched the poses in between
+    // something else touched the poses in between.  The snapshot before that one (adaptive margins) is the start of
+    // the previous step.
     if (ctx->roi_end_valid && !host_poses_before && !untracked_before) {
+      ctx->roi_prev = ctx->roi_use;
       ctx->roi_use = ctx->roi_end_index;
     } else {
+      ctx->roi_prev = -1;
       ctx->roi_use = 0;
       HIPCHK(hipMemcpyAsync(roi_snapshots, ctx->d_poses.p, ctx->body_poses.size() * 4, hipMemcpyDeviceToDevice, ctx->stream));
       HIPCHK(hipEventRecord(ctx->roi_snapshot_done[0], ctx->stream));
@@ -3617,6 +3760,21 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   }
   ctx->roi_end_valid = false;
   ctx->roi_recorded = roi_active;
+  // a step that reads rectangles runs the guarded kernels (m3t_kernels.hip, roi_guard_outside): an object whose poses
+  // leave what was uploaded is not committed but flagged; roi_repair_kernel then fetches the whole frames of the
+  // flagged objects' cameras and the step is launched again for the flagged objects alone
+  RoiGuardArgs guard{};
+  if (roi_frames) {
+    guard.items = ctx->d_roi_items.as<RoiItemDev>();
+    guard.rects = ctx->d_roi_rects.as<m3t_roi_rect>();
+    guard.n_cams = int(ctx->cameras.size());
+    guard.n_rect_slots = ctx->roi_rect_slots;
+    guard.n_poses = ctx->roi_n_poses;
+    guard.mode = 1;
+    guard.misses = ctx->roi_miss_dev;
+    guard.miss_capacity = int(Ctx::kRoiMissCapacity);
+    guard.unrecovered = ctx->roi_unrecovered_dev;
+  }
   if (rigid_fused) {  // (a communicator: the structures span GPUs)
     int n = int(ctx->opt_table.size());
     ScopedKernelTimer timer(ctx, 0);
@@ -3641,7 +3799,8 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     size_t lds_split = 0;
     if (ctx->split_possible && ctx->split_enabled && threads % M3T_SPLIT_LANES == 0 &&
         ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT"))
-      parts = ChooseSplitParts(ctx, tracking_step_split_kernel, n, threads, want_fused_histogram, &lds_split);
+      parts = roi_frames ? ChooseSplitParts(ctx, tracking_step_split_guard_kernel, n, threads, want_fused_histogram, &lds_split)
+                         : ChooseSplitParts(ctx, tracking_step_split_kernel, n, threads, want_fused_histogram, &lds_split);
     const bool split = parts >= 2;
     // More objects than CUs: the compact kernel (<= 47 KB of LDS, <= 128 VGPRs per object: 3-4 workgroups per CU;
     // measured crossover on 256 CUs: 256 objects 0.249 vs 0.225 ms with one 512-thread workgroup per CU, 384 objects
@@ -3649,32 +3808,79 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     bool compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && n > ctx->compute_cus;
     if (const char* e = std::getenv("M3T_HIP_COMPACT")) compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && std::atoi(e) != 0;
     if (std::getenv("M3T_HIP_THREADS")) compact = false;
+    if (roi_frames)
+      ctx->last_step_kernel = split ? "tracking_step_split_guard_kernel"
+                                    : (compact ? "tracking_step_compact_guard_kernel"
+                                               : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_guard_kernel" : "tracking_step_guard_kernel"));
+    else
     ctx->last_step_kernel = split ? "tracking_step_split_kernel"
                                   : (compact ? "tracking_step_compact_kernel"
                                              : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_kernel" : "tracking_step_kernel"));
     if (compact) {
       threads = M3T_COMPACT_THREADS;
       histogram_fused = want_fused_histogram && ctx->compact_fuses_histogram;
-      hipLaunchKernelGGL(tracking_step_compact_kernel, dim3(n), dim3(threads), ctx->lds_compact, ctx->stream,
-                         ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
-                         ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->compact,
-                         iteration, ctx->n_corr_iterations, ctx->n_update_iterations, histogram_fused ? 1 : 0);
     } else if (split) {
-      SplitParams sp{};
-      if ((r = PrepareSplit(ctx, n, parts, &sp))) return r;
       histogram_fused = want_fused_histogram;
-      hipLaunchKernelGGL(tracking_step_split_kernel, dim3((n + 7) / 8 * 8 * parts), dim3(threads), lds_split, ctx->stream,
-                         ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
-                         ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
-                         ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
-                         ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, sp);
-    } else
-    hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), lds, ctx->stream,
-                       ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
-                       ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
-                       ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
-                       ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, 0);
-    HIPCHK(hipGetLastError());
+    }
+    // pass 0: the step; passes 1 (repair) and 2 (the flagged objects again, on whole frames) only behind rectangles
+    for (int pass = 0; pass < (roi_frames ? 2 : 1); ++pass) {
+      if (pass == 1) {
+        for (size_t sl = 0; sl < ctx->roi_sources.size(); ++sl)
+          for (const Ctx::RoiSource& source : ctx->roi_sources[sl]) {
+            const Camera& c0 = *ctx->cameras[source.ids[0]];
+            if (c0.current != int(sl) || !c0.slot_is_roi[sl]) continue;  // (this step reads another slot of these cameras)
+            m3t_roi_rect* rects = ctx->d_roi_rects.as<m3t_roi_rect>() + sl * ctx->cameras.size();
+            hipLaunchKernelGGL(roi_repair_kernel, dim3((c0.intr.height + 7) / 8, unsigned(source.ids.size())), dim3(256), 0,
+                               ctx->stream, source.d_ids, ctx->d_roi_items.as<RoiItemDev>(), ctx->d_roi_item_first.as<int>(),
+                               ctx->d_opts.as<RigidOptDev>(), ctx->roi_n_poses, rects, source.src, source.camera_stride,
+                               source.row_step, c0.frame(int(sl)), c0.frame_bytes, c0.pitch, c0.intr.width, c0.intr.height,
+                               c0.is_depth ? 2 : 3);
+          }
+        guard.mode = 2;
+      }
+      if (compact) {
+        if (roi_frames)
+          hipLaunchKernelGGL(tracking_step_compact_guard_kernel, dim3(n), dim3(threads), ctx->lds_compact, ctx->stream,
+                             ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                             ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->compact,
+                             iteration, ctx->n_corr_iterations, ctx->n_update_iterations, histogram_fused ? 1 : 0, guard);
+        else
+          hipLaunchKernelGGL(tracking_step_compact_kernel, dim3(n), dim3(threads), ctx->lds_compact, ctx->stream,
+                             ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                             ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->compact,
+                             iteration, ctx->n_corr_iterations, ctx->n_update_iterations, histogram_fused ? 1 : 0);
+      } else if (split) {
+        SplitParams sp{};
+        if ((r = PrepareSplit(ctx, n, parts, &sp))) return r;
+        if (roi_frames)
+          hipLaunchKernelGGL(tracking_step_split_guard_kernel, dim3((n + 7) / 8 * 8 * parts), dim3(threads), lds_split,
+                             ctx->stream, ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                             ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
+                             ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
+                             ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, sp, guard);
+        else
+          hipLaunchKernelGGL(tracking_step_split_kernel, dim3((n + 7) / 8 * 8 * parts), dim3(threads), lds_split, ctx->stream,
+                             ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                             ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
+                             ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
+                             ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, sp);
+      } else if (roi_frames) {
+        hipLaunchKernelGGL(ctx->layout.off_hist >= 0 ? tracking_step_lds_guard_kernel : tracking_step_guard_kernel, dim3(n),
+                           dim3(threads), lds, ctx->stream, ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                           ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
+                           ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
+                           ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, guard);
+      } else {
+        hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), lds, ctx->stream,
+                           ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                           ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
+                           ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
+                           ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, 0);
+      }
+      HIPCHK(hipGetLastError());
+    }
+    // (where the repair fetched a whole frame only the device's rectangle table knows it: for the host the slot keeps
+    // counting as a rectangle slot -- conservative -- until the next upload into it)
     ctx->last_step_shape[0] = n;
     ctx->last_step_shape[1] = split ? parts : 1;
     ctx->last_step_shape[2] = threads;
@@ -3842,18 +4048,13 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     if ((r = LaunchHistogram(ctx, iteration, false))) return r;
   }
   if (roi_active) {  // the poses the step ends on = the poses the next one starts from
-    ctx->roi_end_index = 1 - ctx->roi_use;
+    // (the third buffer: a rectangle upload that is still to run on the copy stream reads roi_use and roi_prev)
+    ctx->roi_end_index = 0;
+    while (ctx->roi_end_index == ctx->roi_use || ctx->roi_end_index == ctx->roi_prev) ++ctx->roi_end_index;
     HIPCHK(hipMemcpyAsync(roi_snapshots + size_t(ctx->roi_end_index) * roi_snapshot_floats, ctx->d_poses.p,
                           ctx->body_poses.size() * 4, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipEventRecord(ctx->roi_snapshot_done[ctx->roi_end_index], ctx->stream));
     ctx->roi_end_valid = true;
-  }
-  if (roi_frames) {  // did the step stay inside the rectangles it was given?
-    hipLaunchKernelGGL(roi_check_kernel, dim3((ctx->n_roi_items + 63) / 64), dim3(64), 0, ctx->stream,
-                       ctx->d_roi_items.as<RoiItemDev>(), ctx->n_roi_items, ctx->cams_active, int(ctx->cameras.size()),
-                       ctx->d_opts.as<RigidOptDev>(), ctx->roi_n_poses, ctx->d_roi_rects.as<m3t_roi_rect>(),
-                       ctx->roi_rect_slots, ctx->roi_miss_dev, int(Ctx::kRoiMissCapacity));
-    HIPCHK(hipGetLastError());
   }
   if (ctx->async_ingest) {
     // remember which frame slots this step reads, so that a later asynchronous upload into one of

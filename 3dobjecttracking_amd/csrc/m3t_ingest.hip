@@ -1,47 +1,34 @@
 // m3t_ingest.hip — ROI ingest: instead of whole frames, only the rectangle of every
 // camera frame that the trackers can read crosses PCIe.
-//   roi_rect_kernel   every camera's rectangle from the bodies' poses (m3t_roi.h: projected box around the model's
-//                     points + the modality's reach + the caller's margin for the motion until the frame is used)
-//   roi_pull_kernel   ONE launch per batch-frame on the copy stream: the rectangles' rows straight from the mapped,
-//                     page-locked host block into the ring slot, 16 bytes per thread and trip (measured: 33-51 GB/s,
-//                     against 2.8-6.4 GB/s for one 2-D DMA per camera: tools/ubench_ingest.hip)
-//   roi_check_kernel  after a tracking step: the rectangle the step really needed -- the union over the poses its
-//                     searches ran at (the tracking kernels store them) -- against the rectangle that was in the
-//                     slot; a body whose needs stick out is reported (m3t_hip_roi_get_status), its pose of this step
-//                     is not to be trusted
-// Included by m3t_hip_api.hip after m3t_kernels.hip.
+//   roi_rect_kernel    every camera's rectangle from the bodies' poses (m3t_roi.h: projected box around the model's
+//                      points + the modality's reach + a margin for the motion until the frame is used: the caller's,
+//                      or -- adaptive -- from what the body's rectangle moved over the last steps, at most the caller's)
+//   roi_pull_kernel    ONE launch per batch-frame on the copy stream: the rectangles' rows straight from the mapped,
+//                      page-locked host block into the ring slot, 16 bytes per thread and trip (measured: 33-51 GB/s,
+//                      against 2.8-6.4 GB/s for one 2-D DMA per camera: tools/ubench_ingest.hip)
+//   roi_repair_kernel  after a guarded tracking step (tracking_step_*_guard_kernel, m3t_kernels.hip: a step that needs
+//                      pixels outside its rectangles is not committed, its object is flagged): the WHOLE frames of the
+//                      cameras the flagged objects read, from the same host block; the step is then repeated for the
+//                      flagged objects.  Nothing to do, and next to no time, when no object is flagged
+// Included by m3t_hip_api.hip after m3t_kernels.hip (roi_body2camera, roi_intrinsics and the guard live there).
 #ifndef M3T_INGEST_HIP_
 #define M3T_INGEST_HIP_
 
 #include "m3t_roi.h"
 
-namespace {
-
-// body2camera (column-major 4 x 4) = world2camera * body2world
-__device__ __forceinline__ void roi_body2camera(const float* w2c, const float* b2w, float* out) {
-  for (int c = 0; c < 4; ++c)
-    for (int r = 0; r < 3; ++r)
-      out[c * 4 + r] = ((w2c[r] * b2w[c * 4] + w2c[4 + r] * b2w[c * 4 + 1]) + w2c[8 + r] * b2w[c * 4 + 2]) +
-                       (c == 3 ? w2c[12 + r] : 0.0f);
-  out[3] = out[7] = out[11] = 0.0f;
-  out[15] = 1.0f;
-}
-__device__ __forceinline__ m3t_intrinsics roi_intrinsics(const CameraDev& cam) {
-  m3t_intrinsics k;
-  k.fu = cam.fu; k.fv = cam.fv; k.ppu = cam.ppu; k.ppv = cam.ppv;
-  k.width = cam.width; k.height = cam.height;
-  return k;
-}
-
-}  // namespace
-
 extern "C" {
 
 // one thread per camera of the batch: cam_ids[i] = camera id; item_first[camera id .. + 1] = its readers in `items`;
-// rects: the rectangle table of the slot, by camera id
+// rects: the rectangle table of the slot, by camera id.  Adaptive margins (prev_poses and motion_peak not null): the
+// frame is read two steps after body_poses, so a reader's rectangle has to hold two steps of the body's motion.  With
+// m = what the rectangle's edges moved between prev_poses (one step earlier) and body_poses, and peak = the largest m
+// of the recent past (motion_peak[reader], decaying by a tenth per step), the margin is max(2 m, peak) + 3 pixels --
+// twice the last step for a body that keeps its velocity, the recent extreme for one that jitters -- at least
+// min_margin_px, at most margin_px.  A body that outruns that is caught by the tracking kernels' guard and repeated.
 __global__ void __launch_bounds__(64)
 roi_rect_kernel(const RoiItemDev* items, const int* item_first, const int* cam_ids, int n_batch, const CameraDev* cams,
-                const float* body_poses, float margin_px, m3t_roi_rect* rects) {
+                const float* body_poses, const float* prev_poses, float* motion_peak, float margin_px, float min_margin_px,
+                m3t_roi_rect* rects) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_batch) return;
   const int cam_id = cam_ids[i];
@@ -52,7 +39,20 @@ roi_rect_kernel(const RoiItemDev* items, const int* item_first, const int* cam_i
     const RoiItemDev& it = items[j];
     float b2c[16];
     roi_body2camera(cam.world2camera, body_poses + 16 * it.body, b2c);
-    r = m3t_roi_union(r, m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px + margin_px, it.reach_m));
+    float margin = margin_px;
+    if (prev_poses && motion_peak) {
+      const m3t_roi_rect now = m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px, it.reach_m);
+      float b2c_prev[16];
+      roi_body2camera(cam.world2camera, prev_poses + 16 * it.body, b2c_prev);
+      const m3t_roi_rect before = m3t_roi_body(b2c_prev, it.box_min, it.box_max, &k, it.reach_px, it.reach_m);
+      const float moved = (float)max(max(abs(now.x0 - before.x0), abs(now.x1 - before.x1)),
+                                     max(abs(now.y0 - before.y0), abs(now.y1 - before.y1)));
+      const float known = motion_peak[j];  // < 0: no motion seen yet -- the first rectangle takes the whole margin
+      const float peak = known < 0.0f ? moved : fmaxf(moved, 0.9f * known);
+      motion_peak[j] = peak;  // (this camera's thread is the only one that touches reader j)
+      if (!(known < 0.0f)) margin = fminf(margin_px, fmaxf(min_margin_px, fmaxf(2.0f * moved, peak) + 3.0f));
+    }
+    r = m3t_roi_union(r, m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px + margin, it.reach_m));
   }
   rects[cam_id] = r;
 }
@@ -61,7 +61,7 @@ roi_rect_kernel(const RoiItemDev* items, const int* item_first, const int* cam_i
 // (one host block, one slab).  At most 32 VGPRs: a wave of this kernel fits next to the two 240-VGPR waves per SIMD of
 // tracking_step_split_kernel, so the rectangles of frame k + 1 CAN cross PCIe while step k runs on all CUs -- measured
 // (profiles/r04_roi_trace.txt): the step kernel then runs 2.3-3 x longer (the CUs' memory pipelines hold the ~2 us PCIe
-// reads), and the loop takes what step + pull take one after the other.
+// reads), and the loop takes what step + pull take one after the other (hence m3t_hip_reserve_ingest_cus).
 __global__ void __launch_bounds__(256)
 roi_pull_kernel(const int* cam_ids, const m3t_roi_rect* rects /* of this slot, by camera id */, const uint8_t* src0,
                 size_t src_camera_stride, uint32_t src_row_step, uint8_t* dst0, size_t dst_camera_stride,
@@ -88,38 +88,42 @@ roi_pull_kernel(const int* cam_ids, const m3t_roi_rect* rects /* of this slot, b
   }
 }
 
-// one thread per reader: n_poses poses per object ([0] the pose at the start of the step, [1 .. n_corr] the poses of
-// the searches, [n_corr + 1] the final pose: the histogram lines); rects: [slot][camera id], the camera table says
-// which slot the step read; misses[0] = count, misses[1 ..] = body ids
-__global__ void __launch_bounds__(64)
-roi_check_kernel(const RoiItemDev* items, int n_items, const CameraDev* cams, int n_cams, const RigidOptDev* opts,
-                 int n_poses, const m3t_roi_rect* rects, int n_rect_slots, int* misses, int capacity) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_items) return;
-  const RoiItemDev& it = items[i];
-  if (it.opt < 0) return;
-  const float* poses = opts[it.opt].search_poses;
-  if (!poses) return;
-  const CameraDev& cam = cams[it.camera];
-  if (cam.slot >= n_rect_slots) return;  // (a ring slot added since the tables were built: whole frames only)
-  const m3t_roi_rect have = rects[(size_t)cam.slot * n_cams + it.camera];
-  if (have.x0 <= 0 && have.y0 <= 0 && have.x1 >= cam.width - 1 && have.y1 >= cam.height - 1) return;  // a whole frame
-  const m3t_intrinsics k = roi_intrinsics(cam);
-  m3t_roi_rect need = m3t_roi_empty();
-  for (int j = 0; j < n_poses; ++j) {
-    float b2c[16];
-    roi_body2camera(cam.world2camera, poses + 16 * j, b2c);
-    need = m3t_roi_union(need, m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px, it.reach_m));
+// The repair after a guarded step, same grid and same source / destination as the pull of the batch: a camera one of
+// whose readers is flagged (RoiGuardDev::flag of the reader's optimizer, behind its search poses) gets its whole frame;
+// the first workgroup of the camera notes that in the rectangle table.  (The rectangle is read by the repeated step
+// only, which is launched after this kernel.)
+__global__ void __launch_bounds__(256)
+roi_repair_kernel(const int* cam_ids, const RoiItemDev* items, const int* item_first, const RigidOptDev* opts, int n_poses,
+                  m3t_roi_rect* rects, const uint8_t* src0, size_t src_camera_stride, uint32_t src_row_step, uint8_t* dst0,
+                  size_t dst_camera_stride, uint32_t dst_pitch, int width, int height, int bytes_per_pixel) {
+  const int cam_id = cam_ids[blockIdx.y];
+  bool flagged = false;
+  for (int j = item_first[cam_id]; j < item_first[cam_id + 1] && !flagged; ++j) {
+    const int opt = items[j].opt;
+    if (opt >= 0 && opts[opt].search_poses)
+      flagged = reinterpret_cast<const RoiGuardDev*>(opts[opt].search_poses + 16 * n_poses)->flag != 0;
   }
-  if (!m3t_roi_contains(have, need)) {
-    const int at = atomicAdd(&misses[0], 1);
-    if (at < capacity) misses[1 + at] = it.body;
+  if (!flagged) return;
+  const int row0 = (int)blockIdx.x * 8;
+  if (row0 >= height) return;
+  const int chunks = (width * bytes_per_pixel + 15) >> 4;
+  const uint8_t* src = src0 + (size_t)blockIdx.y * src_camera_stride;
+  uint8_t* dst = dst0 + (size_t)blockIdx.y * dst_camera_stride;
+  const int rows = min(8, height - row0), total = rows * chunks;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int dr = i / chunks, c = i - dr * chunks;
+    *reinterpret_cast<uint4*>(dst + (size_t)(row0 + dr) * dst_pitch + ((size_t)c << 4)) =
+        *reinterpret_cast<const uint4*>(src + (size_t)(row0 + dr) * src_row_step + ((size_t)c << 4));
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) rects[cam_id] = m3t_roi_rect{0, 0, width - 1, height - 1};
 }
 
-// a whole frame went into (slot, camera): its rectangle is the frame
-__global__ void roi_set_rect_kernel(m3t_roi_rect* rect, int x0, int y0, int x1, int y1) {
-  rect->x0 = x0; rect->y0 = y0; rect->x1 = x1; rect->y1 = y1;
+// whole frames went into the slot of the cameras first_id .. first_id + n - 1 (equal geometry): their rectangles are
+// the frames
+__global__ void __launch_bounds__(64)
+roi_set_rects_kernel(m3t_roi_rect* rects /* of the slot, by camera id */, int first_id, int n, int width, int height) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rects[first_id + i] = m3t_roi_rect{0, 0, width - 1, height - 1};
 }
 
 }  // extern "C"

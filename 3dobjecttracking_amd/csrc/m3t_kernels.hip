@@ -29,6 +29,7 @@
 #include "m3t_device.h"
 #include "m3t_log.h"
 #include "m3t_renderer_read.h"
+#include "m3t_roi.h"
 
 #ifdef M3T_PHASE_TIMING
 // developer instrumentation: accumulated s_memtime cycles per phase, block 0 thread 0
@@ -211,6 +212,73 @@ __device__ __forceinline__ int wave_min_i(int v) {  // broadcast result
   v = min(v, dpp_self_i<0x142, 0xa>(v));
   v = min(v, dpp_self_i<0x143, 0xc>(v));
   return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---------------------------------------------------------------------------
+// ROI guard (tracking_step_*_guard_kernel): a step that reads frame slots holding only
+// the trackers' rectangles checks, at every pose its searches (and its histogram lines) run at, that what a reader can
+// touch there lies inside the rectangle that was uploaded.  A step that does not is not committed -- pose, modality
+// state and histograms stay those before the step -- and the object is flagged: the library fetches its cameras' whole
+// frames and repeats the step for the flagged objects (m3t_hip_execute_tracking_step).  No reference counterpart
+// (the step either side of the path: loader_camera.cpp:76-98 hands over whole frames).
+// ---------------------------------------------------------------------------
+// body2camera (column-major 4 x 4) = world2camera * body2world
+__device__ __forceinline__ void roi_body2camera(const float* w2c, const float* b2w, float* out) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 3; ++r)
+      out[c * 4 + r] = ((w2c[r] * b2w[c * 4] + w2c[4 + r] * b2w[c * 4 + 1]) + w2c[8 + r] * b2w[c * 4 + 2]) +
+                       (c == 3 ? w2c[12 + r] : 0.0f);
+  out[3] = out[7] = out[11] = 0.0f;
+  out[15] = 1.0f;
+}
+__device__ __forceinline__ m3t_intrinsics roi_intrinsics(const CameraDev& cam) {
+  m3t_intrinsics k;
+  k.fu = cam.fu; k.fv = cam.fv; k.ppu = cam.ppu; k.ppv = cam.ppv;
+  k.width = cam.width; k.height = cam.height;
+  return k;
+}
+// All 64 lanes of one wave: does a reader of the object (hdr: its readers) need pixels outside the rectangle in its
+// camera's slot at the pose b2w (16 floats)?  Eight lanes per reader, one corner of the model's box each
+// (m3t_roi_corner), joined by lane exchanges, widened as m3t_roi_body widens it.  The same answer in every lane.
+__device__ __noinline__ int roi_guard_outside(const RoiItemDev* items, const m3t_roi_rect* rects, int n_cams, int n_rect_slots,
+                                              const RoiGuardDev* hdr, const CameraDev* cams, const float* b2w) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int g = lane >> 3, corner = lane & 7;
+  const bool active = g < hdr->n_items && g < M3T_ROI_GUARD_ITEMS;
+  const RoiItemDev& it = items[hdr->item[active ? g : 0]];
+  const CameraDev& cam = cams[it.camera];
+  const m3t_intrinsics k = roi_intrinsics(cam);
+  float b2c[16];
+  roi_body2camera(cam.world2camera, b2w, b2c);
+  float u = 0.0f, v = 0.0f, z = 0.0f;
+  int front = m3t_roi_corner(b2c, it.box_min, it.box_max, corner, &k, &u, &v, &z);
+  float u_min = u, u_max = u, v_min = v, v_max = v, z_min = z;
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+    front &= __shfl_xor(front, m);
+    float o;
+    o = __shfl_xor(u_min, m); u_min = o < u_min ? o : u_min;
+    o = __shfl_xor(u_max, m); u_max = o > u_max ? o : u_max;
+    o = __shfl_xor(v_min, m); v_min = o < v_min ? o : v_min;
+    o = __shfl_xor(v_max, m); v_max = o > v_max ? o : v_max;
+    o = __shfl_xor(z_min, m); z_min = o < z_min ? o : z_min;
+  }
+  m3t_roi_rect need = {0, 0, k.width - 1, k.height - 1};  // a box that reaches the camera plane: the whole frame
+  if (front) need = m3t_roi_widen(u_min, u_max, v_min, v_max, z_min, &k, it.reach_px, it.reach_m);
+  bool outside = false;
+  if (active && cam.slot < n_rect_slots)  // (a ring slot added since the tables were built holds whole frames only)
+    outside = !m3t_roi_contains(rects[(size_t)cam.slot * n_cams + it.camera], need);
+  return __builtin_amdgcn_ballot_w64(outside) != 0ull ? 1 : 0;
+}
+// what a workgroup does with the guard's verdict (one thread per object): mode 1 flags a miss and reports the body,
+// mode 2 (the repeat over whole frames) clears the flag and reports a body that still misses
+__device__ __forceinline__ void roi_guard_report(const RoiGuardArgs& a, RoiGuardDev* hdr, int body, bool miss) {
+  hdr->flag = (a.mode == 1 && miss) ? 1 : 0;
+  if (miss) {
+    int* list = a.mode == 1 ? a.misses : a.unrecovered;
+    const int at = atomicAdd(&list[0], 1);
+    if (at < a.miss_capacity) list[1 + at] = body;
+  }
 }
 
 // The viewing direction of RegionModel::GetClosestView (region_model.cpp:113-119): o = R^-1 t / |t|; false when t = 0
@@ -2927,11 +2995,12 @@ struct SplitParams {               // tracking_step_split_kernel: n_parts workgr
 };
 
 extern "C++" {
-template <bool HIST_LDS, bool SPLIT = false, bool RENDER = !SPLIT>
+template <bool HIST_LDS, bool SPLIT = false, bool RENDER = !SPLIT, bool GUARD = false>
 __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
-                     int fuse_histogram, const SplitParams* split = nullptr, int first_corr_iteration = 0) {
+                     int fuse_histogram, const SplitParams* split = nullptr, int first_corr_iteration = 0,
+                     const RoiGuardArgs* guard = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds_t[];
   // SPLIT: n_parts workgroups share one object.  Each runs the whole step, but walks the pixels (and scans the depth
   // windows) of its own part of the lines (points) only; the line results are exchanged once per correspondence
@@ -2953,6 +3022,14 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     if ((int)gridDim.x / n_parts != split->n_objects && object >= split->n_objects) return;
   }
   COpt& o = *(COpt*)(opts + object);
+  // GUARD (ROI ingest, roi_guard_outside above): the last wave checks every pose the step reads its frames at
+  RoiGuardDev* guard_hdr = nullptr;
+  int guard_miss = 0;
+  if constexpr (GUARD) {
+    guard_hdr = reinterpret_cast<RoiGuardDev*>(o.search_poses + 16 * guard->n_poses);
+    if (guard->mode == 2 && guard_hdr->flag == 0) return;  // the repeat: flagged objects only (all parts read the same flag)
+  }
+  const bool guard_wave = GUARD && threadIdx.x >= blockDim.x - kWave;
   CRegion* rm = o.region_modality >= 0 ? (CRegion*)(rmods + o.region_modality) : nullptr;
   CDepth* dm = o.depth_modality >= 0 ? (CDepth*)(dmods + o.depth_modality) : nullptr;
   Lds s = carve(lds_t, layout);
@@ -3002,6 +3079,10 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
   int region_view = rm ? *as_global(rm->last_view) : -1;
   for (int c = first_corr_iteration; c < first_corr_iteration + n_corr_iterations; ++c) {
     if (record_poses) search_poses[(c + 1) * 16 + threadIdx.x] = pose[threadIdx.x];
+    if constexpr (GUARD) {
+      if (guard_wave)  // (the pose in LDS stands until the solve of this search's first Newton step, barriers away)
+        guard_miss |= roi_guard_outside(guard->items, guard->rects, guard->n_cams, guard->n_rect_slots, guard_hdr, cams, pose);
+    }
     {
       const Affine b2w = load_pose(pose);
       bool vote_deferred = false;  // decided by region_correspondences (the one predicate for both sides)
@@ -3117,6 +3198,19 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
       PHASE_MARK(6);
     }
   }
+  if constexpr (GUARD) {
+    // the final pose (the histogram lines run there), then the verdict for the whole workgroup: a step that left its
+    // rectangles is dropped before anything of it reaches memory
+    int* verdict = reinterpret_cast<int*>(s.misc) + 96;
+    if (guard_wave) {
+      guard_miss |= roi_guard_outside(guard->items, guard->rects, guard->n_cams, guard->n_rect_slots, guard_hdr, cams, pose);
+      if ((threadIdx.x & (kWave - 1)) == 0) *verdict = guard_miss;
+    }
+    __syncthreads();
+    const bool miss = *verdict != 0;
+    if (part == 0 && threadIdx.x == 0) roi_guard_report(*guard, guard_hdr, o.body, miss);
+    if (miss) return;
+  }
   // (every workgroup of a split object holds the same pose: the first one writes it; no other workgroup can
   // still be waiting to read the old one, it had to publish its first results before this one got here)
   if (threadIdx.x < 16 && part == 0) body_poses[16 * o.body + threadIdx.x] = pose[threadIdx.x];
@@ -3186,6 +3280,36 @@ tracking_step_split_kernel(const RigidOptDev* opts, const RegionModDev* rmods, c
                      int fuse_histogram, SplitParams split) {
   tracking_step_body<false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
                                   n_corr_iterations, n_update_iterations, write_state, fuse_histogram, &split);
+}
+
+// ROI ingest: the same three kernels with the guard compiled in (frame slots that hold the trackers' rectangles only;
+// the kernels above stay what they are for whole frames)
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_guard_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int fuse_histogram, RoiGuardArgs guard) {
+  tracking_step_body<false, false, false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
+                                                n_corr_iterations, n_update_iterations, write_state, fuse_histogram,
+                                                nullptr, 0, &guard);
+}
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_lds_guard_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int fuse_histogram, RoiGuardArgs guard) {
+  tracking_step_body<true, false, false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
+                                               n_corr_iterations, n_update_iterations, write_state, fuse_histogram,
+                                               nullptr, 0, &guard);
+}
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_split_guard_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int fuse_histogram, SplitParams split, RoiGuardArgs guard) {
+  tracking_step_body<false, true, false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
+                                               n_corr_iterations, n_update_iterations, write_state, fuse_histogram, &split,
+                                               0, &guard);
 }
 
 // the same with the renderer-fed branches compiled in, one correspondence search per launch (the host redraws the

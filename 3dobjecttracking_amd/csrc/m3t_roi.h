@@ -84,25 +84,27 @@ M3T_ROI_FN void m3t_roi_depth_reach(const m3t_depth_modality_params* p, float fu
 // projection maps the box into the convex hull of its projected corners as long as the box lies in front of the
 // camera; a box that reaches the camera plane gives the whole frame.  reach_px + reach_m (metres, taken at the box's
 // nearest depth) widen the hull's bounding rectangle.
-M3T_ROI_FN m3t_roi_rect m3t_roi_body(const float* body2camera, const float* box_min, const float* box_max,
-                                     const m3t_intrinsics* intr, float reach_px, float reach_m) {
+// (the two halves of m3t_roi_body: the tracking kernels' ROI guard takes one corner per lane and joins the eight with
+// lane exchanges -- min / max are exact whatever their order, so both ways give the same rectangle)
+// One corner of the box in the image: returns 0 when it does not lie in front of the camera.
+M3T_ROI_FN int m3t_roi_corner(const float* body2camera, const float* box_min, const float* box_max, int corner,
+                              const m3t_intrinsics* intr, float* u, float* v, float* z_out) {
+  const float bx = (corner & 1) ? box_max[0] : box_min[0];
+  const float by = (corner & 2) ? box_max[1] : box_min[1];
+  const float bz = (corner & 4) ? box_max[2] : box_min[2];
+  const float x = body2camera[0] * bx + body2camera[4] * by + body2camera[8] * bz + body2camera[12];
+  const float y = body2camera[1] * bx + body2camera[5] * by + body2camera[9] * bz + body2camera[13];
+  const float z = body2camera[2] * bx + body2camera[6] * by + body2camera[10] * bz + body2camera[14];
+  *z_out = z;
+  if (!(z > 1e-3f)) return 0;
+  *u = x * intr->fu / z + intr->ppu;
+  *v = y * intr->fv / z + intr->ppv;
+  return 1;
+}
+// The bounding rectangle of the projected corners, widened by the reach and cut to the frame.
+M3T_ROI_FN m3t_roi_rect m3t_roi_widen(float u_min, float u_max, float v_min, float v_max, float z_min,
+                                      const m3t_intrinsics* intr, float reach_px, float reach_m) {
   m3t_roi_rect full = {0, 0, intr->width - 1, intr->height - 1};
-  float u_min = 3.0e38f, u_max = -3.0e38f, v_min = 3.0e38f, v_max = -3.0e38f, z_min = 3.0e38f;
-  for (int corner = 0; corner < 8; ++corner) {
-    const float bx = (corner & 1) ? box_max[0] : box_min[0];
-    const float by = (corner & 2) ? box_max[1] : box_min[1];
-    const float bz = (corner & 4) ? box_max[2] : box_min[2];
-    const float x = body2camera[0] * bx + body2camera[4] * by + body2camera[8] * bz + body2camera[12];
-    const float y = body2camera[1] * bx + body2camera[5] * by + body2camera[9] * bz + body2camera[13];
-    const float z = body2camera[2] * bx + body2camera[6] * by + body2camera[10] * bz + body2camera[14];
-    if (!(z > 1e-3f)) return full;
-    const float u = x * intr->fu / z + intr->ppu, v = y * intr->fv / z + intr->ppv;
-    u_min = u < u_min ? u : u_min;
-    u_max = u > u_max ? u : u_max;
-    v_min = v < v_min ? v : v_min;
-    v_max = v > v_max ? v : v_max;
-    z_min = z < z_min ? z : z_min;
-  }
   const float f = intr->fu > intr->fv ? intr->fu : intr->fv;
   const float reach = reach_px + reach_m * f / z_min + 1.0f;
   if (!(u_min > -1.0e7f && u_max < 1.0e7f && v_min > -1.0e7f && v_max < 1.0e7f && reach < 1.0e7f)) return full;
@@ -116,4 +118,19 @@ M3T_ROI_FN m3t_roi_rect m3t_roi_body(const float* body2camera, const float* box_
   if (r.x1 > intr->width - 1) r.x1 = intr->width - 1;
   if (r.y1 > intr->height - 1) r.y1 = intr->height - 1;
   return r;
+}
+M3T_ROI_FN m3t_roi_rect m3t_roi_body(const float* body2camera, const float* box_min, const float* box_max,
+                                     const m3t_intrinsics* intr, float reach_px, float reach_m) {
+  m3t_roi_rect full = {0, 0, intr->width - 1, intr->height - 1};
+  float u_min = 3.0e38f, u_max = -3.0e38f, v_min = 3.0e38f, v_max = -3.0e38f, z_min = 3.0e38f;
+  for (int corner = 0; corner < 8; ++corner) {
+    float u, v, z;
+    if (!m3t_roi_corner(body2camera, box_min, box_max, corner, intr, &u, &v, &z)) return full;
+    u_min = u < u_min ? u : u_min;
+    u_max = u > u_max ? u : u_max;
+    v_min = v < v_min ? v : v_min;
+    v_max = v > v_max ? v : v_max;
+    z_min = z < z_min ? z : z_min;
+  }
+  return m3t_roi_widen(u_min, u_max, v_min, v_max, z_min, intr, reach_px, reach_m);
 }

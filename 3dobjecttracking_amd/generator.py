@@ -12,6 +12,7 @@ cameras) are refused with the class name in the message.
 Errors follow the reference: a missing required parameter or an unknown referenced name raises ValueError with
 the reference's message text (generator.h:65-157) where the reference prints it and returns false.
 """
+import ctypes as C
 import os
 import sys
 
@@ -76,6 +77,21 @@ class _LoaderCamera:
         self._prefetch = bool(enable) and getattr(self.api, "is_hip", False)
         self._drop_pipeline()
 
+    def enable_roi_ingest(self, enable=True, margin_px=24.0, adaptive=True, reserve_cus=0):
+        """ROI ingest for this camera's pipeline (m3t_hip_set_roi_ingest: a setting of the whole context, every
+        loader camera of a tracker should be given the same one): of frame k + 1 only the rectangle the trackers can
+        read crosses PCIe, pulled by a kernel out of the page-locked slab while frame k is tracked; a body that
+        outruns its rectangle has its step repeated on the whole frame by the library, so the poses are those of
+        whole frames bit for bit.  adaptive: per-body margins from the motion over the last step (at most margin_px).
+        reserve_cus (a multiple of 32): compute units kept free of the tracking kernels for the pull
+        (m3t_hip_reserve_ingest_cus).  HIP contexts with prefetch on; otherwise ignored."""
+        self._roi = bool(enable) and getattr(self.api, "is_hip", False)
+        self._drop_pipeline()
+        if getattr(self.api, "is_hip", False):
+            self.api.call("set_roi_ingest", (2 if adaptive else 1) if enable else 0, C.c_float(margin_px))
+            if reserve_cus or not enable:
+                self.api.call("reserve_ingest_cus", int(reserve_cus) if enable else 0)
+
     def _drop_pipeline(self):
         for job in getattr(self, "_jobs", {}).values():
             job["thread"].join()
@@ -109,7 +125,8 @@ class _LoaderCamera:
                            for _ in range(self._PIPELINE_SLOTS)]
             for a in self._slabs:
                 self.api.call("host_register", a.ctypes.data_as(C.c_void_p), a.nbytes)
-            self.set_ring(self._PIPELINE_SLOTS)
+            # (a ring of the batch kind, with this camera as its only member: what the rectangle upload needs)
+            self.api.call("cameras_set_ring", (C.c_int * 1)(self.id), 1, self._PIPELINE_SLOTS)
         return self._slabs[slot]
 
     def _start_decode(self, index):
@@ -118,6 +135,9 @@ class _LoaderCamera:
         if index in self._jobs or index in self._uploaded:
             return
         slab = self._slab(index % self._PIPELINE_SLOTS)
+        # the copy that last read this slab must have left it (a no-op in steady state: UpdateImage has waited for it;
+        # after set_load_index / enable_prefetch a popped upload may still be in flight)
+        self.slot_sync(index % self._PIPELINE_SLOTS)
         saved, self.load_index = self.load_index, index
         path = self.image_path()
         self.load_index = saved
@@ -149,7 +169,14 @@ class _LoaderCamera:
             self._failed = (job["path"], job["error"])
             return False
         slot = index % self._PIPELINE_SLOTS
-        self.upload_slot(slot, self._slabs[slot], asynchronous=True)
+        slab = self._slabs[slot]
+        if getattr(self, "_roi", False):
+            # the trackers' rectangle only (whole frames until a fused step has run, and whenever rectangles are not
+            # possible: the library decides); the slab stays untouched until slot_sync
+            self.api.call("cameras_upload_batch_roi_async", (C.c_int * 1)(self.id), 1, slot,
+                          slab.ctypes.data_as(C.c_void_p), slab.nbytes, slab.strides[0])
+        else:
+            self.upload_slot(slot, slab, asynchronous=True)
         self._uploaded[index] = slot
         return True
 
@@ -383,6 +410,14 @@ class GeneratedTracker(host.Tracker):
                 return False
         self.set_up = True
         return True
+
+    def enable_roi_ingest(self, enable=True, margin_px=24.0, adaptive=True, reserve_cus=0):
+        """ROI ingest for every loader camera of the tracker (_LoaderCamera.enable_roi_ingest): of each frame only
+        the trackers' rectangle crosses PCIe; poses equal those of whole frames bit for bit (a body that outruns its
+        rectangle is repeated on the whole frame inside ExecuteTrackingStep)"""
+        for cam in self.cameras:
+            if hasattr(cam, "enable_roi_ingest"):
+                cam.enable_roi_ingest(enable, margin_px, adaptive, reserve_cus)
 
     def body_ptrs(self):
         return list(self.bodies)

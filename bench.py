@@ -655,7 +655,8 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
 
         def timed(roi_on):
             # both runs from the same state: poses of frame W, histograms initialised on frame W (whole frames)
-            hip.call("set_roi_ingest", 1 if roi_on else 0, C.c_float(margin))
+            # (roi_on = 2: adaptive margins -- three times what a body's rectangle moved over the last step, at most `margin`)
+            hip.call("set_roi_ingest", int(roi_on), C.c_float(margin))
             hip.call("bodies_set_poses", restart.ctypes.data_as(C.POINTER(C.c_float)), n_obj)
             upload(1, start_block)
             hip.call("ingest_sync")
@@ -693,7 +694,9 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
                "rectangle_uploads": int(pulls.value), "bodies_outside_their_rectangle": int(n_miss.value),
                "bit_identical_to_whole_frames": bool(np.array_equal(poses_roi, poses_full)), "margin_px": margin,
                "timed": "median of 5 runs of %d steps" % n_up,
-               "note": "m3t_hip_cameras_upload_batch_roi_async: one pull kernel per batch-frame over the mapped slab"}
+               "note": "m3t_hip_cameras_upload_batch_roi_async: one pull kernel per batch-frame over the mapped slab; the "
+                       "steps run the guarded kernels (a body that leaves its rectangle is repeated on the whole frame inside "
+                       "the step: counted in bodies_outside_their_rectangle)"}
         # ... and with CUs of its own for the pull kernel (m3t_hip_reserve_ingest_cus: CU-masked streams): frame k + 1
         # crosses PCIe WHILE step k runs on the other CUs
         if "reserve_ingest_cus" in hip._fn:
@@ -704,11 +707,18 @@ def pcie_legs(hip, inst, inputs, n_obj, W, K):
                 shape = (C.c_int * 4)()
                 hip.call("get_step_shape", shape)
                 hip.call("roi_get_status", bodies, 64, C.byref(n_miss), C.byref(pulls))
-                roi["reserved_cus"].append(
-                    {"cus_for_the_pull": n_cus, "pose_updates_per_s": round(n_obj * n_up / dt_res, 1),
-                     "ms_per_step": round(dt_res / n_up * 1e3, 3), "workgroups_per_object": int(shape[1]),
-                     "bodies_outside_their_rectangle": int(n_miss.value),
-                     "bit_identical_to_whole_frames": bool(np.array_equal(poses_res, poses_full))})
+                entry = {"cus_for_the_pull": n_cus, "pose_updates_per_s": round(n_obj * n_up / dt_res, 1),
+                         "ms_per_step": round(dt_res / n_up * 1e3, 3), "workgroups_per_object": int(shape[1]),
+                         "bodies_outside_their_rectangle": int(n_miss.value),
+                         "bit_identical_to_whole_frames": bool(np.array_equal(poses_res, poses_full))}
+                # ... and with per-body margins from the motion over the last step (fewer bytes)
+                dt_ad, poses_ad = median_of(2)
+                hip.call("roi_get_status", bodies, 64, C.byref(n_miss), C.byref(pulls))
+                entry["adaptive_margins"] = {"pose_updates_per_s": round(n_obj * n_up / dt_ad, 1),
+                                             "ms_per_step": round(dt_ad / n_up * 1e3, 3),
+                                             "bodies_repeated_on_whole_frames": int(n_miss.value),
+                                             "bit_identical_to_whole_frames": bool(np.array_equal(poses_ad, poses_full))}
+                roi["reserved_cus"].append(entry)
             hip.call("reserve_ingest_cus", 0)
         hip.call("set_roi_ingest", 0, C.c_float(0.0))
     for b in blocks:

@@ -120,24 +120,33 @@ int m3t_hip_ingest_sync(m3t_hip_context*); /* wait until all enqueued frame copi
 /* wait until the last camera_upload_slot_async into (camera, slot) has left its host buffer, and for nothing else: a
  * loader that recycles one camera's page-locked buffers does not hold up the copies of the other cameras */
 int m3t_hip_camera_slot_sync(m3t_hip_context*, int camera_id, int slot);
-/* ROI ingest: only the part of a frame the trackers can read crosses PCIe.  set_roi_ingest(enable, margin_px) makes
- * the fused step of rigid objects record the poses its searches run at; cameras_upload_batch_roi_async is
- * cameras_upload_batch_async for rectangles: one kernel on the copy stream computes every camera's rectangle -- the
- * projected box around the model points of the bodies tracked through it, widened by the modalities' reach
- * (region_modality.cpp:1433-1508, 1640-1780, 1343-1389; depth_modality.cpp:736-776, 826-884) and by margin_px for the
- * motion until the frame has been used (two frames: the rectangle comes from the pose at the start of the step
- * enqueued last) -- and pulls its rows out of the host block, which has to be page-locked and mapped
- * (host_register).  Where that is not possible (ROI ingest off, no step recorded yet, cameras not in one ring in this
- * order, strides that are not multiples of 16 bytes) the whole frames are uploaded.  After every step that read a
- * rectangle the library checks, on the device, that the poses the step went through stayed inside it;
- * roi_get_status returns (and clears) the bodies for which they did not -- their poses since then are not the
- * whole-frame poses: re-upload the frame in full, set the pose again and repeat the step.  Results of steps without
- * misses equal the whole-frame results bit for bit. */
+/* ROI ingest: only the part of a frame the trackers can read crosses PCIe.  set_roi_ingest(enable, margin_px) switches
+ * it on for the fused step of rigid objects; cameras_upload_batch_roi_async is cameras_upload_batch_async for
+ * rectangles: one kernel on the copy stream computes every camera's rectangle -- the projected box around the model
+ * points of the bodies tracked through it, widened by the modalities' reach (region_modality.cpp:1433-1508, 1640-1780,
+ * 1343-1389; depth_modality.cpp:736-776, 826-884) and by a margin for the motion until the frame has been used (two
+ * steps: the rectangle comes from the poses the step enqueued last starts from) -- and pulls its rows out of the host
+ * block, which has to be page-locked and mapped (host_register).  enable = 1: margin_px for every body; enable = 2:
+ * per body from the motion of its rectangle -- max(twice the last step, the largest step of the recent past) + 3
+ * pixels, at least 4, at most margin_px: fewer bytes where bodies move little, and nothing lost where one does not
+ * (next paragraph).  Where
+ * rectangles are not possible (ROI ingest off, no fused step yet, cameras not in one ring in this order, strides that are
+ * not multiples of 16 bytes) the whole frames are uploaded.
+ * A step that reads rectangles checks on the device, at every pose its searches and histogram lines run at, that what
+ * it can touch lies inside them.  A body whose step does not is NOT committed (pose, histograms, modality state stay
+ * those before the step); the library then fetches the whole frames of that body's cameras from the same host block
+ * -- which therefore has to stay what it is until the step is done, the lifetime rule of every asynchronous upload --
+ * and repeats the step for those bodies, inside the same execute_tracking_step call.  Results equal the whole-frame
+ * results bit for bit either way.  roi_get_status returns (and clears) the bodies that were repeated since the last
+ * call -- a count of how often the margin was too small; roi_get_unrecovered the ones whose repeat could not see a
+ * whole frame either (the host block of the slot was not known any more, e.g. tables rebuilt in between): their step
+ * is still uncommitted -- upload the frame in full and execute the step again. */
 int m3t_hip_set_roi_ingest(m3t_hip_context*, int enable, float margin_px);
 int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context*, const int* camera_ids, int n_cameras, int slot, const void* base,
                                            size_t camera_stride, size_t row_step);
 int m3t_hip_roi_get_status(m3t_hip_context*, int* body_ids, int capacity, int* n_misses,
                             long long* n_rectangle_uploads /* batch-frames that went as rectangles so far; may be NULL */);
+int m3t_hip_roi_get_unrecovered(m3t_hip_context*, int* body_ids, int capacity, int* n_bodies);
 /* Keep n_cus compute units free of the tracking kernels and run the ROI pull kernel on them (CU-masked streams), so
  * that the rectangles of frame k + 1 cross PCIe WHILE step k runs: on shared CUs the pull's PCIe reads hold the CUs'
  * memory pipelines and the step takes 2.3-3 x longer, on CUs of its own the pull costs the step little.  n_cus has to

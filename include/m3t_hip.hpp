@@ -481,8 +481,9 @@ class Tracker {
                                                        camera_stride, row_step));
   }
   // ROI ingest: rectangles instead of frames (m3t_hip.h)
-  void SetRoiIngest(bool enable, float margin_px) {
-    c_->Check(m3t_hip_set_roi_ingest(c_->get(), enable ? 1 : 0, margin_px), "Tracker");
+  // adaptive: per-body margins from the motion over the last step, at most margin_px
+  void SetRoiIngest(bool enable, float margin_px, bool adaptive = false) {
+    c_->Check(m3t_hip_set_roi_ingest(c_->get(), enable ? (adaptive ? 2 : 1) : 0, margin_px), "Tracker");
   }
   // ... pulled by a kernel on CUs of its own while the step runs on the others (replaces the streams: stream() again)
   void ReserveIngestCus(int n_cus) { c_->Check(m3t_hip_reserve_ingest_cus(c_->get(), n_cus), "Tracker"); }
@@ -491,10 +492,19 @@ class Tracker {
     return c_->Step(m3t_hip_cameras_upload_batch_roi_async(c_->get(), camera_ids.data(), int(camera_ids.size()), slot,
                                                            base, camera_stride, row_step));
   }
-  std::vector<int> RoiMisses() {  // bodies whose last checked steps left their rectangle (cleared by the call)
+  // bodies whose steps left their rectangle since the last call (they were repeated on whole frames: the poses are
+  // the whole-frame poses; the list counts how often the margin was too small)
+  std::vector<int> RoiMisses() {
     std::vector<int> bodies(256);
     int n = 0;
     c_->Check(m3t_hip_roi_get_status(c_->get(), bodies.data(), int(bodies.size()), &n, nullptr), "Tracker");
+    bodies.resize(size_t(n < int(bodies.size()) ? n : int(bodies.size())));
+    return bodies;
+  }
+  std::vector<int> RoiUnrecovered() {  // ... and the ones whose repeat could not see a whole frame either (m3t_hip.h)
+    std::vector<int> bodies(256);
+    int n = 0;
+    c_->Check(m3t_hip_roi_get_unrecovered(c_->get(), bodies.data(), int(bodies.size()), &n), "Tracker");
     bodies.resize(size_t(n < int(bodies.size()) ? n : int(bodies.size())));
     return bodies;
   }

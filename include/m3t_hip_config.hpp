@@ -636,11 +636,24 @@ class FramePipeline {
   using Check = std::function<std::string(const Image&)>;  // "" or why the image does not fit the camera
   ~FramePipeline() { Drop(nullptr); }
   bool enabled = true;
+  // ROI ingest (m3t_hip.h: m3t_hip_set_roi_ingest is a setting of the whole context -- give every loader camera of a
+  // tracker the same one): of frame k + 1 only the rectangle the trackers can read is pulled out of the slab while
+  // frame k is tracked; a body that outruns its rectangle is repeated on the whole frame by the library, so the poses
+  // are those of whole frames bit for bit.  reserve_cus (a multiple of 32): CUs kept free for the pull kernel.
+  bool roi = false;
+  bool EnableRoi(m3t_hip_context* ctx, bool enable, float margin_px = 24.0f, bool adaptive = true, int reserve_cus = 0) {
+    Drop(ctx);
+    if (m3t_hip_set_roi_ingest(ctx, enable ? (adaptive ? 2 : 1) : 0, margin_px) < 0) return false;
+    if ((reserve_cus || !enable) && m3t_hip_reserve_ingest_cus(ctx, enable ? reserve_cus : 0) < 0) return false;
+    roi = enable;
+    return true;
+  }
   // returns false (and leaves `enabled` false) when the library has no asynchronous ingest
   bool Prepare(m3t_hip_context* ctx, int camera_id, size_t frame_bytes) {
     if (!enabled || ready_) return enabled;
     for (auto& slab : slabs_) slab.assign(frame_bytes, 0);
-    if (m3t_hip_camera_set_ring(ctx, camera_id, kSlots) < 0) { enabled = false; return false; }
+    // (a ring of the batch kind with this camera as its only member: what the rectangle upload needs)
+    if (m3t_hip_cameras_set_ring(ctx, &camera_id, 1, kSlots) < 0) { enabled = false; return false; }
     for (auto& slab : slabs_)
       if (m3t_hip_host_register(ctx, slab.data(), slab.size()) < 0) { enabled = false; return false; }
     ready_ = true;
@@ -695,7 +708,10 @@ class FramePipeline {
     jobs_.erase(it);
     if (!ok) return false;
     const int slot = index % kSlots;
-    if (m3t_hip_camera_upload_slot_async(ctx, camera_id, slot, slabs_[size_t(slot)].data(), row_step) < 0) {
+    const int rc = roi ? m3t_hip_cameras_upload_batch_roi_async(ctx, &camera_id, 1, slot, slabs_[size_t(slot)].data(),
+                                                                slabs_[size_t(slot)].size(), row_step)
+                       : m3t_hip_camera_upload_slot_async(ctx, camera_id, slot, slabs_[size_t(slot)].data(), row_step);
+    if (rc < 0) {
       if (error) *error = m3t_hip_last_error(ctx);
       return false;
     }
@@ -729,7 +745,9 @@ class FramePipeline {
     }
     const int slot = TakeUploaded(k);
     // every copy issued so far has left its slab: the slab frame k + 2 is decoded into (frame k - 1's) is free
-    if (m3t_hip_ingest_sync(ctx) < 0 || m3t_hip_camera_select_slot(ctx, camera_id, slot) < 0) {
+    // (a slab a rectangle was pulled from is read again if a body outruns it: also wait for the step that read it)
+    if (m3t_hip_ingest_sync(ctx) < 0 || (roi && m3t_hip_camera_slot_sync(ctx, camera_id, (k + 2) % kSlots) < 0) ||
+        m3t_hip_camera_select_slot(ctx, camera_id, slot) < 0) {
       std::cerr << m3t_hip_last_error(ctx) << std::endl;
       return false;
     }

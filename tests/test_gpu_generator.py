@@ -3,6 +3,8 @@ metafiles read, both sparse viewpoint models generated on the GPU and saved, pos
 step — against the golden pose of TrackerTest.OptimizePoseMatrixGeneratorSetUp (test/tracker_test.cpp:182-195)."""
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -38,12 +40,16 @@ def test_generated_tracker_with_generated_models(tmp_path):
     assert np.array_equal(tracker2.body_ptrs()[0].body2world_pose(), pose)
 
 
-def test_tracker_process_over_the_fixture_sequence(tmp_path):
+@pytest.mark.parametrize("roi", [False, True])
+def test_tracker_process_over_the_fixture_sequence(tmp_path, roi):
     """RunTrackerProcess-style loop: detect, start, then one step per loaded frame until the images run out
-    (frames 200 and 201 exist); the object does not move between them, so the pose stays at the first step's"""
+    (frames 200 and 201 exist); the object does not move between them, so the pose stays at the first step's.
+    roi: the loader cameras hand their frames over as rectangles (enable_roi_ingest) -- the same poses"""
     root = reference_tree(tmp_path)
     api = util.open_hip()
     tracker = util.pkg.generator.GenerateConfiguredTracker(api, str(root / "tracker_test" / "tracker_config.yaml"))
+    if roi:
+        tracker.enable_roi_ingest(True, margin_px=16.0)
     assert tracker.RunTrackerProcess(5) is False  # not set up
     assert tracker.SetUp()
     assert tracker.RunTrackerProcess(5) == 2      # image 202 is missing: the process stops there
@@ -66,12 +72,17 @@ def test_loader_camera_overlapped_ingest(tmp_path):
         Image.fromarray(np.ascontiguousarray(inputs.color[0][k][:, :, ::-1])).save(str(tmp_path / ("color_%04d.png" % k)))
     intr = inputs.intr
     results = {}
-    for prefetch in (False, True, "no read-back"):  # (the last: nothing waits for a step until the sequence ends, the
-        api = util.open_hip()                        #  slabs are recycled on the strength of camera_slot_sync alone)
+    # ("no read-back": nothing waits for a step until the sequence ends, the slabs are recycled on the strength of
+    # camera_slot_sync alone; "roi": the frames go as the tracker's rectangle, m3t_hip_cameras_upload_batch_roi_async,
+    # with adaptive margins -- "roi tight": with a margin of 1 pixel, so that steps are repeated on whole frames)
+    for prefetch in (False, True, "no read-back", "roi", "roi tight", "roi no read-back"):
+        api = util.open_hip()
         cam = util.pkg.generator.LoaderColorCamera(
             api, str(tmp_path), (intr["fu"], intr["fv"], intr["ppu"], intr["ppv"], intr["width"], intr["height"]),
             "color_", 0, 4, "")
         cam.enable_prefetch(bool(prefetch))
+        if str(prefetch).startswith("roi"):
+            cam.enable_roi_ingest(True, margin_px=1.0 if prefetch == "roi tight" else 24.0, adaptive=prefetch != "roi tight")
         body = host.Body(api, inputs.start[0])
         m = inputs.region_models[0]
         model = host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2])
@@ -87,12 +98,21 @@ def test_loader_camera_overlapped_ingest(tmp_path):
             assert cam.UpdateImage(True)
             assert np.array_equal(cam.image, inputs.color[0][k])
             assert tracker.ExecuteTrackingStep(k)
-            if prefetch != "no read-back":
+            if not str(prefetch).endswith("no read-back"):
                 poses.append(body.body2world_pose())
         assert not cam.UpdateImage(True)  # frame 9 does not exist
         results[prefetch] = poses or [body.body2world_pose()]
-    for a, b in zip(results[False], results[True]):
-        assert np.array_equal(a, b)
+        if str(prefetch).startswith("roi"):
+            bodies, n, pulls = (C.c_int * 8)(), C.c_int(0), C.c_longlong(0)
+            api.call("roi_get_status", bodies, 8, C.byref(n), C.byref(pulls))
+            assert pulls.value >= n_frames - 3, pulls.value  # rectangles, not whole frames
+            print(prefetch, "steps repeated on whole frames:", n.value)
+            api.call("roi_get_unrecovered", bodies, 8, C.byref(n))
+            assert n.value == 0
+    for key in (True, "roi", "roi tight"):
+        for a, b in zip(results[False], results[key]):
+            assert np.array_equal(a, b), key
     assert np.array_equal(results["no read-back"][-1], results[True][-1])
+    assert np.array_equal(results["roi no read-back"][-1], results[True][-1])
     e = syn.pose_errors(results[True][-1], inputs.gt[0][-1])
     assert e[0] < np.deg2rad(5) and e[1] < 0.05

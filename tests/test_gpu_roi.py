@@ -1,7 +1,8 @@
 """ROI ingest (m3t_hip_set_roi_ingest, m3t_hip_cameras_upload_batch_roi_async): only the rectangle of
 every frame that the trackers can read is pulled out of the page-locked host block, overlapped with the previous
-tracking step; the poses of the sequence equal those of the blocking whole-frame hand-over bit for bit, the device-side
-check reports no body that left its rectangle -- and does report it when the margin is too small for the motion."""
+tracking step; the poses of the sequence equal those of the blocking whole-frame hand-over bit for bit.  The guarded
+kernels report no body that left its rectangle -- and when the margin is too small for the motion, the step of that
+body is repeated on the whole frame inside the same call: still the whole-frame poses, bit for bit."""
 import ctypes as C
 
 import numpy as np
@@ -21,14 +22,21 @@ def status(hip):
     return n.value, list(bodies[:min(n.value, 64)]), pulls.value
 
 
-def run(inputs, mode, margin=24.0, n_frames=None, with_depth=False, reserve_cus=0):
+def unrecovered(hip):
+    bodies = (C.c_int * 64)()
+    n = C.c_int(0)
+    hip.call("roi_get_unrecovered", bodies, 64, C.byref(n))
+    return n.value
+
+
+def run(inputs, mode, margin=24.0, n_frames=None, with_depth=False, reserve_cus=0, adaptive=False):
     n_frames = n_frames or inputs.n_frames
     hip = util.open_hip()
     if reserve_cus:
         hip.call("reserve_ingest_cus", reserve_cus)
     inst = scenes.Instance(hip, inputs, use_depth=with_depth)
     if mode != "blocking":
-        hip.call("set_roi_ingest", 1, C.c_float(margin))
+        hip.call("set_roi_ingest", 2 if adaptive else 1, C.c_float(margin))
     inst.upload_frame(0)
     assert inst.tracker.StartModalities(0)
     out = []
@@ -69,6 +77,10 @@ def run(inputs, mode, margin=24.0, n_frames=None, with_depth=False, reserve_cus=
             upload((k + 1) % 2, k + 1)
         out.append(np.stack(inst.poses()))  # (synchronises: the next upload is not overlapped here, the path is the same)
     inst.tracker.ingest_sync()
+    assert unrecovered(hip) == 0
+    kernel = C.create_string_buffer(128)
+    hip.call("get_step_kernel", kernel, 128)
+    assert b"_guard_kernel" in kernel.value, kernel.value  # the last step read rectangles
     return out, status(hip)
 
 
@@ -91,10 +103,8 @@ def test_rectangles_region_and_depth():
         assert np.array_equal(a, b), k
 
 
-def test_a_body_that_outruns_its_rectangle_is_reported():
-    """object 1 runs away sideways by 2 cm (~24 pixels) per frame from frame 3 on -- which the tracker follows: its
-    rectangle (computed from the pose two frames back, with the margin that is enough for the ordinary motion of the
-    other two bodies) does not hold what the step needs: roi_get_status names that body, and only that one"""
+def runaway_inputs():
+    """object 1 runs away sideways by 2 cm (~24 pixels) per frame from frame 3 on -- which the tracker follows"""
     inputs = scenes.Inputs(3, 7, n_divides=2)
     runner = inputs.scenes[1]
     for k in range(3, inputs.n_frames):
@@ -102,10 +112,37 @@ def test_a_body_that_outruns_its_rectangle_is_reported():
         pose[0, 3] -= 0.02 * (k - 2)
         inputs.gt[1][k] = pose
         inputs.color[1][k] = runner.render(pose)
-    _, (misses, bodies, pulls) = run(inputs, "roi", margin=24.0)
+    return inputs
+
+
+def test_a_body_that_outruns_its_rectangle_is_repeated_on_the_whole_frame():
+    """the runaway's rectangle (computed from the pose two frames back, with the margin that is enough for the ordinary
+    motion of the other two bodies) does not hold what its step needs.  The guarded kernel drops that step, the
+    library fetches the body's whole frame from the host block and repeats the step for that body alone: the poses
+    of ALL bodies are those of the blocking whole-frame hand-over, bit for bit, and roi_get_status names the runaway,
+    and only the runaway, as repeated"""
+    inputs = runaway_inputs()
+    ref, _ = run(inputs, "blocking")
+    got, (misses, bodies, pulls) = run(inputs, "roi", margin=24.0)
     assert pulls > 0 and misses >= 1
-    # body ids are creation order: object 1 is body 1
-    assert set(bodies) == {1}, bodies
+    assert set(bodies) == {1}, bodies  # body ids are creation order: object 1 is body 1
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(a, b), k
+    # the runaway was tracked (the repeated steps saw the frames)
+    e = util.syn.pose_errors(got[-1][1], inputs.gt[1][-1])
+    assert e[1] < 0.02, e
+
+
+def test_adaptive_margins_track_like_whole_frames():
+    """set_roi_ingest(2, cap): every body's margin follows what its rectangle moved over the last step (three times
+    that, at least 4 pixels, at most the cap) -- fewer bytes per frame; a body that accelerates past it is repeated.
+    Poses bit for bit those of whole frames, with and without the runaway"""
+    for inputs in (scenes.Inputs(6, 8, n_divides=2), runaway_inputs()):
+        ref, _ = run(inputs, "blocking")
+        got, (misses, bodies, pulls) = run(inputs, "roi", margin=48.0, adaptive=True)
+        assert pulls >= inputs.n_frames - 3
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert np.array_equal(a, b), (k, misses, bodies)
 
 
 def test_pull_kernel_on_reserved_cus():

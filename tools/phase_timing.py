@@ -15,7 +15,7 @@ ycb = len(sys.argv) > 3 and sys.argv[3] == "ycb"
 hip = pkg.CApi(lib, "m3t_hip_")
 f = hip.lib.m3t_hip_debug_phase_cycles
 f.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-inputs = scenes.Inputs(n_obj, 8, n_divides=4, n_models=8, with_depth=ycb)
+inputs = scenes.Inputs(n_obj, 8, n_divides=4, n_models=min(8, n_obj), with_depth=ycb)
 inst = scenes.Instance(hip, inputs, use_depth=ycb)
 inst.upload_frame(0)
 inst.tracker.StartModalities(0)
