@@ -1056,7 +1056,11 @@ int LaunchRenderers(Ctx* ctx, const int* which, int n_which, const int* pairs, i
   // rows, at least two rows each) per launch, whatever the number of renderings (measured on the reference's test
   // scene, two pairs of twins, renderer-fed step: 32 bands 0.633 ms, 64: 0.624, 100: 0.611; 64 -> 128 slices: no
   // change, 256: slower)
-  int slices = std::min(128, std::max(32, 128 / std::max(1, n_pairs)));
+  // (round 5: at 128 pairs -- the renderer-fed step of 64 objects -- 32 slices per pair were 4096 workgroups of 149
+  // VGPRs, one per CU at a time, each paying the projection and the matrix chain for two trips over its triangles:
+  // 131 us per set-up launch; 2 slices per pair = one workgroup per CU: 2.33 -> 1.64 ms per step,
+  // profiles/r05_render64_knobs.txt)
+  int slices = std::min(128, std::max(2, 128 / std::max(1, n_pairs)));
   int bands = std::min(std::max(8, largest_image_size / 2), std::max(8, 256 / std::max(1, n_pairs)));
   if (const char* e = std::getenv("M3T_HIP_RASTER_BANDS")) bands = std::max(1, std::atoi(e));    // developer overrides
   if (const char* e = std::getenv("M3T_HIP_RASTER_SLICES")) slices = std::max(1, std::atoi(e));
@@ -1074,7 +1078,7 @@ int LaunchRenderers(Ctx* ctx, const int* which, int n_which, const int* pairs, i
   if (ctx->lds_raster == 1 && largest_image_size > 0 && lds <= size_t(160) * 1024) {
     hipLaunchKernelGGL(focused_setup_kernel, dim3(slices, n_pairs), dim3(M3T_BLOCK_THREADS), 0, ctx->stream,
                        ctx->d_renderers.as<RendererDev>(), pairs, ctx->cams_active, ctx->d_poses.as<float>());
-    hipLaunchKernelGGL(focused_resolve_kernel, dim3(bands, n_pairs), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
+    hipLaunchKernelGGL(focused_resolve_kernel, dim3(n_pairs, bands), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
                        ctx->d_renderers.as<RendererDev>(), pairs);
     HIPCHK(hipGetLastError());
     return M3T_OK;

@@ -22,7 +22,7 @@ extern "C" {
 // rects: the rectangle table of the slot, by camera id.  Adaptive margins (prev_poses and motion_peak not null): the
 // frame is read two steps after body_poses, so a reader's rectangle has to hold two steps of the body's motion.  With
 // m = what the rectangle's edges moved between prev_poses (one step earlier) and body_poses, and peak = the largest m
-// of the recent past (motion_peak[reader], decaying by a tenth per step), the margin is max(2 m, peak) + 3 pixels --
+// of the recent past (motion_peak[reader], decaying by 2 % per step), the margin is max(2 m, 1.25 peak) + 3 pixels --
 // twice the last step for a body that keeps its velocity, the recent extreme for one that jitters -- at least
 // min_margin_px, at most margin_px.  A body that outruns that is caught by the tracking kernels' guard and repeated.
 __global__ void __launch_bounds__(64)
@@ -48,9 +48,9 @@ roi_rect_kernel(const RoiItemDev* items, const int* item_first, const int* cam_i
       const float moved = (float)max(max(abs(now.x0 - before.x0), abs(now.x1 - before.x1)),
                                      max(abs(now.y0 - before.y0), abs(now.y1 - before.y1)));
       const float known = motion_peak[j];  // < 0: no motion seen yet -- the first rectangle takes the whole margin
-      const float peak = known < 0.0f ? moved : fmaxf(moved, 0.9f * known);
+      const float peak = known < 0.0f ? moved : fmaxf(moved, 0.98f * known);
       motion_peak[j] = peak;  // (this camera's thread is the only one that touches reader j)
-      if (!(known < 0.0f)) margin = fminf(margin_px, fmaxf(min_margin_px, fmaxf(2.0f * moved, peak) + 3.0f));
+      if (!(known < 0.0f)) margin = fminf(margin_px, fmaxf(min_margin_px, fmaxf(2.0f * moved, 1.25f * peak) + 3.0f));
     }
     r = m3t_roi_union(r, m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px + margin, it.reach_m));
   }

@@ -33,30 +33,26 @@ struct RasterTriangle {
   int x0, x1, y0, y1;
 };
 
-M3T_RASTER_FN bool raster_setup(const RasterM44& trans, const float* vertices, const int* triangles, int t, bool culling,
-                                int S, RasterTriangle& o) {
+// A vertex after projection and snapping: window coordinates in 1/256 pixel (integers, exact in f64 and -- inside the
+// range the set-up accepts -- in int32) and the window depth.  false: the vertex lies behind the eye or so far off the
+// image that the exact-integer range would be left; a triangle with such a vertex is dropped (no near-plane clipping).
+M3T_RASTER_FN bool raster_vertex(const RasterM44& trans, const float* p, int S, double* sx, double* sy, float* wz) {
   const float half_s = 0.5f * (float)S;
-  double sx[3], sy[3];
-  float wz[3];
-  bool behind = false;
-  for (int k = 0; k < 3; ++k) {
-    const float* p = vertices + (size_t)triangles[t * 3 + k] * 3;
-    float cx = ((trans(0, 0) * p[0] + trans(0, 1) * p[1]) + trans(0, 2) * p[2]) + trans(0, 3);
-    float cy = ((trans(1, 0) * p[0] + trans(1, 1) * p[1]) + trans(1, 2) * p[2]) + trans(1, 3);
-    float cz = ((trans(2, 0) * p[0] + trans(2, 1) * p[1]) + trans(2, 2) * p[2]) + trans(2, 3);
-    float cw = ((trans(3, 0) * p[0] + trans(3, 1) * p[1]) + trans(3, 2) * p[2]) + trans(3, 3);
-    if (!(cw > 0.0f)) behind = true;  // no near-plane clipping: such triangles are dropped
-    float wx = (cx / cw + 1.0f) * half_s;
-    float wy = (cy / cw + 1.0f) * half_s;
-    wz[k] = (cz / cw + 1.0f) * 0.5f;
-    sx[k] = floor((double)wx * 256.0 + 0.5);
-    sy[k] = floor((double)wy * 256.0 + 0.5);
-  }
-  if (behind) return false;
-  // anything this far off the image cannot touch it and would leave the exact-integer range
-  if (!(fabs(sx[0]) < 3.0e7 && fabs(sx[1]) < 3.0e7 && fabs(sx[2]) < 3.0e7 && fabs(sy[0]) < 3.0e7 &&
-        fabs(sy[1]) < 3.0e7 && fabs(sy[2]) < 3.0e7))
-    return false;
+  float cx = ((trans(0, 0) * p[0] + trans(0, 1) * p[1]) + trans(0, 2) * p[2]) + trans(0, 3);
+  float cy = ((trans(1, 0) * p[0] + trans(1, 1) * p[1]) + trans(1, 2) * p[2]) + trans(1, 3);
+  float cz = ((trans(2, 0) * p[0] + trans(2, 1) * p[1]) + trans(2, 2) * p[2]) + trans(2, 3);
+  float cw = ((trans(3, 0) * p[0] + trans(3, 1) * p[1]) + trans(3, 2) * p[2]) + trans(3, 3);
+  float wx = (cx / cw + 1.0f) * half_s;
+  float wy = (cy / cw + 1.0f) * half_s;
+  *wz = (cz / cw + 1.0f) * 0.5f;
+  *sx = floor((double)wx * 256.0 + 0.5);
+  *sy = floor((double)wy * 256.0 + 0.5);
+  // behind the eye | anything this far off the image cannot touch it and would leave the exact-integer range
+  return cw > 0.0f && fabs(*sx) < 3.0e7 && fabs(*sy) < 3.0e7;
+}
+// The triangle of three such vertices (all of them accepted by raster_vertex): culling, orientation, bounding box.
+M3T_RASTER_FN bool raster_setup_snapped(const double (&sx)[3], const double (&sy)[3], const float (&wz)[3], bool culling,
+                                        int S, RasterTriangle& o) {
   double area = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sy[1] - sy[0]) * (sx[2] - sx[0]);
   if (area == 0.0) return false;
   // counter-clockwise meshes seen from outside have negative area in the y-down image
@@ -76,6 +72,25 @@ M3T_RASTER_FN bool raster_setup(const RasterM44& trans, const float* vertices, c
   o.y0 = (int)fmax(ceil((min_y - 128.0) / 256.0), 0.0);
   o.y1 = (int)fmin(floor((max_y - 128.0) / 256.0), (double)(S - 1));
   return o.x1 >= o.x0 && o.y1 >= o.y0;
+}
+// (the triangle by the coordinates of its three vertices, xyz xyz xyz: a caller that walks a triangle list can have the
+// next triangles' indices and vertices on their way while this one is set up)
+M3T_RASTER_FN bool raster_setup_vertices(const RasterM44& trans, const float (&xyz)[9], bool culling, int S,
+                                         RasterTriangle& o) {
+  double sx[3], sy[3];
+  float wz[3];
+  bool ok = true;
+  for (int k = 0; k < 3; ++k) ok = raster_vertex(trans, xyz + 3 * k, S, &sx[k], &sy[k], &wz[k]) && ok;
+  return ok && raster_setup_snapped(sx, sy, wz, culling, S, o);
+}
+M3T_RASTER_FN bool raster_setup(const RasterM44& trans, const float* vertices, const int* triangles, int t, bool culling,
+                                int S, RasterTriangle& o) {
+  float xyz[9];
+  for (int k = 0; k < 3; ++k) {
+    const float* p = vertices + (size_t)triangles[t * 3 + k] * 3;
+    xyz[3 * k] = p[0]; xyz[3 * k + 1] = p[1]; xyz[3 * k + 2] = p[2];
+  }
+  return raster_setup_vertices(trans, xyz, culling, S, o);
 }
 
 // the packed z-buffer word of a covered pixel from its three edge-function values, or 0xffffffff when the depth

@@ -224,10 +224,47 @@ focused_setup_kernel(const RendererDev* renderers, const int* which, const Camer
     const int per_slice = (r.n_triangles[order] + gridDim.x - 1) / gridDim.x;
     const int t_begin = blockIdx.x * per_slice;
     const int t_end = min(t_begin + per_slice, r.n_triangles[order]);
+    // A slice is tens of trips long at 128 pairs and a trip is two dependent loads (indices, then the vertices they
+    // name -- the meshes of 64 objects do not stay in L2) in front of ~400 instructions, at two waves per SIMD: the
+    // loads run two trips ahead -- the indices of trip i + 2 and the vertices of trip i + 1 are on their way while
+    // trip i is set up (round 5, 128 pairs x 2 slices: 49.5 -> 45 us with the indices alone -> 41.4 us).  Measured
+    // and not kept, all with identical images: the body's vertices snapped once into an LDS table and the triangles
+    // set up from it (a third of the instructions, 41.9 us: the trips are chains of dependent f64 operations at two
+    // waves per SIMD, not instruction issue), two triangles per thread and trip on top of that (41.8), the list
+    // append's atomic answered one trip later (57: registers), a 128-VGPR build with two workgroups per CU (46.9)
+    int idx1[3] = {0, 0, 0}, idx2[3] = {0, 0, 0};
+    float xyz1[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) xyz1[k] = 0.0f;
+    auto load_indices = [&](int t, int (&index)[3]) {
+      if (t < t_end) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) index[k] = triangles[t * 3 + k];
+      }
+    };
+    auto load_vertices = [&](int t, const int (&index)[3], float (&xyz)[9]) {
+      if (t < t_end) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float* p = vertices + (size_t)index[k] * 3;
+          xyz[3 * k] = p[0]; xyz[3 * k + 1] = p[1]; xyz[3 * k + 2] = p[2];
+        }
+      }
+    };
+    load_indices(t_begin + tid, idx1);
+    load_indices(t_begin + nt + tid, idx2);
+    load_vertices(t_begin + tid, idx1, xyz1);
     for (int base = t_begin; base < t_end; base += nt) {
       const int t = base + tid;
+      float xyz[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xyz[k] = xyz1[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) idx1[k] = idx2[k];
+      load_vertices(t + nt, idx1, xyz1);
+      load_indices(t + 2 * nt, idx2);
       RasterSurvivor sv;
-      const bool ok = t < t_end && raster_setup(trans, vertices, triangles, t, culling, S, sv.tri);
+      const bool ok = t < t_end && raster_setup_vertices(trans, xyz, culling, S, sv.tri);
       // one atomic per wave: the lanes with a survivor take consecutive entries
       const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
       if (mask == 0) continue;  // wave-uniform
@@ -256,11 +293,15 @@ focused_resolve_kernel(const RendererDev* renderers, const int* which) {
   // are numbered through (block-wide prefix sum) and dealt out evenly: a covered pixel costs ~30 f64 operations, and a
   // thread that finished a 100-pixel box by itself kept its whole wave waiting (measured: 54 us per resolve).
   constexpr int kPiece = 8, kPer = 4;  // survivors a thread looks at per trip: one trip up to 2048 survivors
-  const RendererDev& r = renderers[which[2 * blockIdx.y]];
-  const int twin = which[2 * blockIdx.y + 1];  // a renderer whose rendering is this one (focused_setup_kernel), or -1
+  // grid: (renderer pairs, bands) -- workgroup b runs on XCD b mod 8, so with the pair as the fast index the bands of a
+  // pair share an XCD (whenever the number of pairs is a multiple of 8) and its survivor list is fetched into ONE L2:
+  // round 5, 128 pairs x 8 bands -- with the band as the fast index each of the eight L2s read all 12 MB of lists
+  const RendererDev& r = renderers[which[2 * blockIdx.x]];
+  const int twin = which[2 * blockIdx.x + 1];  // a renderer whose rendering is this one (focused_setup_kernel), or -1
   const int S = r.image_size;
-  const int band_rows = (S + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int row_lo = (int)blockIdx.x * band_rows, row_hi = min(row_lo + band_rows, S) - 1;  // inclusive
+  const int n_bands = (int)gridDim.y;
+  const int band_rows = (S + n_bands - 1) / n_bands;
+  const int row_lo = (int)blockIdx.y * band_rows, row_hi = min(row_lo + band_rows, S) - 1;  // inclusive
   const int n_px = band_rows * S;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & (kWave - 1), wave = tid / kWave;
   int* first_item = reinterpret_cast<int*>(lds_z + n_px);  // [nt + 1]: pieces before thread t's survivors
@@ -319,23 +360,41 @@ focused_resolve_kernel(const RendererDev* renderers, const int* which) {
   }
   __syncthreads();
   const int n_out = (row_hi - row_lo + 1) * S;
-  for (int i = tid; i < n_out; i += nt) {
-    const uint32_t v = lds_z[i];
-    r.depth_image[row_lo * S + i] = v == 0xffffffffu ? (uint16_t)65535 : (uint16_t)(v >> 16);
-    r.silhouette_image[row_lo * S + i] = v == 0xffffffffu ? (uint8_t)0 : (uint8_t)(v & 0xffu);
-  }
-  if (twin >= 0) {  // the same rendering with the twin's id byte: the winner's draw order sits in bits 8..15
-    const RendererDev& t = renderers[twin];
+  // four pixels per thread and store where the band allows it (its first pixel and its length multiples of four: the
+  // images come from hipMalloc): one 8-byte and one 4-byte store instead of four 2-byte and four 1-byte ones -- the
+  // output of 128 pairs cost 10.7 of the launch's 69 us (round 5, probe builds)
+  const RendererDev* t = twin >= 0 ? &renderers[twin] : nullptr;  // the same rendering with the twin's id byte: the
+  const size_t first = (size_t)row_lo * S;                        // winner's draw order sits in bits 8..15
+  auto depth_of = [](uint32_t v) { return v == 0xffffffffu ? (uint32_t)65535 : v >> 16; };
+  auto id_of = [](uint32_t v) { return v == 0xffffffffu ? 0u : (v & 0xffu); };
+  auto twin_id_of = [t](uint32_t v) { return (v == 0xffffffffu || !t->silhouette) ? 0u : (uint32_t)(uint8_t)t->id[(v >> 8) & 0xffu]; };
+  if ((first & 3) == 0 && (n_out & 3) == 0) {
+    for (int i = tid * 4; i < n_out; i += nt * 4) {
+      const uint32_t v0 = lds_z[i], v1 = lds_z[i + 1], v2 = lds_z[i + 2], v3 = lds_z[i + 3];
+      const uint2 d = make_uint2(depth_of(v0) | depth_of(v1) << 16, depth_of(v2) | depth_of(v3) << 16);
+      *reinterpret_cast<uint2*>(r.depth_image + first + i) = d;
+      *reinterpret_cast<uint32_t*>(r.silhouette_image + first + i) =
+          id_of(v0) | id_of(v1) << 8 | id_of(v2) << 16 | id_of(v3) << 24;
+      if (t) {
+        *reinterpret_cast<uint2*>(t->depth_image + first + i) = d;
+        *reinterpret_cast<uint32_t*>(t->silhouette_image + first + i) =
+            twin_id_of(v0) | twin_id_of(v1) << 8 | twin_id_of(v2) << 16 | twin_id_of(v3) << 24;
+      }
+    }
+  } else {
     for (int i = tid; i < n_out; i += nt) {
       const uint32_t v = lds_z[i];
-      t.depth_image[row_lo * S + i] = v == 0xffffffffu ? (uint16_t)65535 : (uint16_t)(v >> 16);
-      t.silhouette_image[row_lo * S + i] =
-          (v == 0xffffffffu || !t.silhouette) ? (uint8_t)0 : (uint8_t)t.id[(v >> 8) & 0xffu];
+      r.depth_image[first + i] = (uint16_t)depth_of(v);
+      r.silhouette_image[first + i] = (uint8_t)id_of(v);
+      if (t) {
+        t->depth_image[first + i] = (uint16_t)depth_of(v);
+        t->silhouette_image[first + i] = (uint8_t)twin_id_of(v);
+      }
     }
   }
   // every band has read the count by now once it says it is done: the last one clears the list for the next rendering
   if (tid == 0) {
-    if (atomicAdd(r.n_survivors + 1, 1) == (int)gridDim.x - 1) {
+    if (atomicAdd(r.n_survivors + 1, 1) == n_bands - 1) {
       __hip_atomic_store(r.n_survivors, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(r.n_survivors + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -127,7 +127,7 @@ int m3t_hip_camera_slot_sync(m3t_hip_context*, int camera_id, int slot);
  * 1343-1389; depth_modality.cpp:736-776, 826-884) and by a margin for the motion until the frame has been used (two
  * steps: the rectangle comes from the poses the step enqueued last starts from) -- and pulls its rows out of the host
  * block, which has to be page-locked and mapped (host_register).  enable = 1: margin_px for every body; enable = 2:
- * per body from the motion of its rectangle -- max(twice the last step, the largest step of the recent past) + 3
+ * per body from the motion of its rectangle -- max(twice the last step, 1.25 x the largest step of the recent past) + 3
  * pixels, at least 4, at most margin_px: fewer bytes where bodies move little, and nothing lost where one does not
  * (next paragraph).  Where
  * rectangles are not possible (ROI ingest off, no fused step yet, cameras not in one ring in this order, strides that are

@@ -15,7 +15,7 @@ from util import host
 
 n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-api = pkg.open_context(0)
+api = pkg.CApi(os.environ["M3T_LIB"], "m3t_hip_") if os.environ.get("M3T_LIB") else pkg.open_context(0)  # (M3T_LIB: a variant build)
 fixtures = []
 for _ in range(n_obj):
     g = gs.TrackerFixture(api, measure_occlusions=False, region_params=dict(n_unoccluded_iterations=0),
@@ -34,14 +34,16 @@ for _ in range(n_obj):
     fixtures.append((g, rs))
 start = fixtures[0][0].body.body2world_pose()
 tracker = fixtures[0][0].tracker
+import ctypes as C
+start_all = (C.c_float * (16 * 2 * n_obj))()  # every fixture made two bodies: the tracked triangle and the bottle
+api.call("bodies_get_poses", start_all, 2 * n_obj)
 tracker.StartModalities(0)
 tracker.ExecuteTrackingStep(0)
 api.call("sync")
 poses = np.stack([g.body.body2world_pose() for g, _ in fixtures])
 t0 = time.perf_counter()
 for _ in range(steps):
-    for g, _ in fixtures:
-        g.body.set_body2world_pose(start)
+    api.call("bodies_set_poses", start_all, 2 * n_obj)  # (one call: 2 n set_body2world_pose calls are not the tracker's time)
     tracker.ExecuteTrackingStep(0)
 api.call("sync")
 dt = (time.perf_counter() - t0) / steps
