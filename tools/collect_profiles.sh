@@ -9,11 +9,14 @@
 #   * per-phase cycles of the developer build (tools/phase_timing.py)
 # Order: the PMC passes first -- their HBM traffic blocks go into profiles/ on the box, so the bench lines taken after
 # them quote this run's traffic (roofline.traffic_source).
-# usage: tools/collect_profiles.sh [what ...]   what = tests pmc bench extras stats phases sweep (default: all)
+#   * (round 5) counter calibration (FETCH_SIZE / WRITE_SIZE against known byte counts, before the PMC passes that use it),
+#     rank-share projections (one rank's share at 1 / 2 / 4 / 8 ranks, alone on this GPU), per-kernel statistics of the
+#     64-object renderer-fed step
+# usage: tools/collect_profiles.sh [what ...]   what = tests cal pmc bench extras stats phases rankshare render sweep (default: all)
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 OUT=$REPO/gpurun_out/$ROUND
-WHAT=${@:-tests pmc bench extras stats phases sweep}
+WHAT=${@:-tests cal pmc bench extras stats phases rankshare render sweep}
 CONFIGS=${CONFIGS:-rbot64 rbot4096 ycb21 synth512 chain8}
 mkdir -p "$OUT"
 cd "$REPO"
@@ -35,6 +38,15 @@ if has tests; then
   tail -2 "$OUT/gpu_tests.log"
 fi
 PROF="--steps 10 --warmup 2 --no-cpu-baseline --no-pcie --no-buckets --repeats 1"
+if has cal; then  # what FETCH_SIZE / WRITE_SIZE report for known byte counts in the tracking kernels' access patterns
+  mkdir -p "$OUT/cal" tools/bin
+  [ -x tools/bin/ubench_counters ] || hipcc --offload-arch=gfx950 -O3 -o tools/bin/ubench_counters tools/ubench_counters.hip > "$OUT/cal/build.log" 2>&1
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/cal/fetch" -- "$REPO/tools/bin/ubench_counters" > "$OUT/cal/known.txt" 2> "$OUT/cal/fetch.log"
+   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/cal/write" -- "$REPO/tools/bin/ubench_counters" > "$OUT/cal/known_w.txt" 2> "$OUT/cal/write.log")
+  python tools/counter_calibration.py "$OUT/cal" "$OUT/cal/known.txt" "$OUT/counter_calibration.txt" | tail -10
+  [ -s "$OUT/counter_calibration.txt" ] && grep -q "^factor" "$OUT/counter_calibration.txt" && cp "$OUT/counter_calibration.txt" "$REPO/profiles/${ROUND}_counter_calibration.txt"
+  rm -rf "$OUT/cal"
+fi
 if has pmc; then
   declare -A PASS
   PASS[sq1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
@@ -48,7 +60,7 @@ if has pmc; then
     # all passes for the configurations in PMC_FULL (default: the headline), FETCH_SIZE / WRITE_SIZE only for the
     # others (every bench line gets its roofline.traffic; a pass is one more run of the bench command)
     passes="fetch write"
-    [[ " ${PMC_FULL:-rbot64} " == *" $c "* ]] && passes="sq1 sq2 ta tcc fetch write"
+    [[ " ${PMC_FULL:-rbot64 rbot4096 chain8} " == *" $c "* ]] && passes="sq1 sq2 ta tcc fetch write"
     for p in ${PMC_PASSES:-$passes}; do
       (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --pmc ${PASS[$p]} --output-format csv -d "$OUT/pmc_$c/$p" -- python "$REPO/bench.py" $(args_of $c) $PROF > "$OUT/pmc_$c/$p.log" 2>&1)
     done
@@ -83,12 +95,36 @@ if has stats; then
   done
 fi
 if has phases; then
-  for v in "rbot64:64:" "ycb21:21:ycb"; do
+  for v in "rbot64:64:" "rbot1:1:" "ycb21:21:ycb"; do
     IFS=: read name n ycb <<< "$v"
     (timeout 300 python tools/phase_timing.py tools/libm3t_hip_timing.so $n $ycb 2>&1 | grep -v amdgpu) > "$OUT/phase_timing_$name.txt" 2>&1
   done
   (timeout 300 python tools/tree_timing.py tools/libm3t_hip_timing.so 2>&1 | grep -v amdgpu) > "$OUT/phase_timing_chain8.txt" 2>&1
   head -12 "$OUT/phase_timing_rbot64.txt"
+fi
+if has rankshare; then  # what one GPU can say about N: rank 0's share at N = 1, 2, 4, 8 ranks, alone on this GPU (a projection)
+  for c in rbot64 synth512 ycb21 chain8; do
+    (timeout 900 python bench.py --config $c --rank-share 1,2,4,8 --no-cpu-baseline --no-pcie --no-buckets --busy-seconds 1 > "$OUT/rank_share_$c.json" 2> "$OUT/rank_share_$c.err")
+    python - "$OUT/rank_share_$c.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(d["metric"], d["ms_per_step"], "rccl_ranks", d["config"].get("rccl_ranks"))
+    for p in (d.get("projected_scaling") or {}).get("points", []):
+        print("  ", {k: v for k, v in p.items() if k in ("n_gpus", "objects_on_rank_0", "bodies_with_modalities_on_rank_0", "rank_0_ms_per_step", "projected_pose_updates_per_s", "projected_pose_updates_per_s_before_transport")})
+except Exception as e:
+    print("rank-share:", e)
+PY
+  done
+fi
+if has render; then  # the renderer-fed step of the reference's test scene, 64 times in one context and once: per-kernel times
+  for n in 64 1; do
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/render$n" -- python "$REPO/tools/render64_trace.py" $n 10 > "$OUT/render$n.log" 2>&1)
+    cp "$OUT"/render$n/*/*kernel_stats.csv "$OUT/render${n}_kernel_stats.csv" 2>/dev/null
+    rm -rf "$OUT/render$n"
+    (grep objects "$OUT/render$n.log"; echo "without the profiler: $(timeout 300 python tools/render64_trace.py $n 20 2>&1 | grep objects)") | tee "$OUT/render$n.txt"
+    rm -f "$OUT/render$n.log"
+  done
 fi
 if has sweep; then
   (timeout 1200 python bench.py --no-pcie --no-cpu-baseline --no-buckets --repeats 3 --sweep 1,8,32,256,512,1024,4096 > "$OUT/bench_sweep.json" 2> "$OUT/bench_sweep.err")
