@@ -224,6 +224,7 @@ struct m3t_hip_context {
   bool fuse_histogram_possible = false;  // ... and the histogram update can ride in the same launch
   // several workgroups per object (tracking_step_split_kernel) for batches that leave most CUs idle
   bool split_possible = false;
+  size_t tree_split_lds_attribute = 0;  // the dynamic LDS limit tracking_step_tree_split_kernel was given last
   bool split_enabled = true;  // m3t_hip_set_object_split
   std::map<std::tuple<const void*, int, size_t>, int> occupancy_cache;  // ResidentBlocks
   int ingest_cus = 0;   // m3t_hip_reserve_ingest_cus: CUs kept free of the tracking kernels for the ROI pull kernel
@@ -3959,6 +3960,40 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     xp.abort_id = ctx->split_launches;
     xp.host_abort = ctx->split_abort_dev;
     const int off_tree = int((lds / 4 - ctx->tree_block_floats));
+    // Structures that leave CUs idle (the 8-body chain: 8 workgroups on 256 CUs): several workgroups per tracked link
+    // (tracking_step_tree_split_kernel; open structures only -- the constrained kernel keeps one).  The parts of a link
+    // exchange their lines' results, so all workgroups must be resident: checked like the split kernel's launch.
+    int tree_parts = 0;
+    if (!ctx->tree_constrained && ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_TREE_SPLIT")) {
+      bool can = true;
+      for (auto& m : ctx->region_mods) can = can && m->shared_histograms < 0 && m->p.n_histogram_bins >= 4;
+      const int elements = std::max(ctx->layout.nl, ctx->depth_mods.empty() ? 1 : ctx->np_max);
+      int limit = 4;  // (measured on the 8-body chain: 2 parts .. ms, 4 .. ms, 8 .. ms per step)
+      if (const char* e = std::getenv("M3T_HIP_TREE_PARTS")) limit = std::atoi(e);  // developer override
+      for (int p = M3T_SPLIT_MAX_PARTS; can && p >= 2; p >>= 1) {
+        if (p > limit || (elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;
+        if (ctx->tree_split_lds_attribute != lds) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_tree_split_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+          }
+          ctx->tree_split_lds_attribute = lds;
+        }
+        int resident = ResidentBlocks(ctx, tracking_step_tree_split_kernel, M3T_BLOCK_THREADS, lds);
+        resident = std::min(resident, int(size_t(160) * 1024 / lds));
+        if (resident >= 1 && ctx->n_treesteps * p <= ctx->compute_cus * resident) { tree_parts = p; break; }
+      }
+    }
+    if (tree_parts >= 2) {
+      SplitParams sp{};
+      if ((r = PrepareSplit(ctx, ctx->n_treesteps, tree_parts, &sp))) return r;
+      hipLaunchKernelGGL(tracking_step_tree_split_kernel, dim3(ctx->n_treesteps * tree_parts), dim3(M3T_BLOCK_THREADS), lds,
+                         ctx->stream, ctx->d_treesteps.as<TreeStepDev>(), ctx->d_treeopts.as<TreeOptDev>(),
+                         ctx->d_region.as<RegionModDev>(), ctx->d_depth.as<DepthModDev>(), ctx->cams_active,
+                         ctx->d_poses.as<float>(), ctx->layout, ctx->off_points, ctx->np_max, off_tree, iteration,
+                         ctx->n_corr_iterations, ctx->n_update_iterations, want_fused_histogram ? 1 : 0, xp, sp);
+    } else
     hipLaunchKernelGGL(ctx->tree_constrained ? tracking_step_tree_constrained_kernel : tracking_step_tree_kernel,
                        dim3(ctx->n_treesteps), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
                        ctx->d_treesteps.as<TreeStepDev>(), ctx->d_treeopts.as<TreeOptDev>(),
@@ -3968,9 +4003,10 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     HIPCHK(hipGetLastError());
     histogram_fused = want_fused_histogram;
     ctx->links_device_newer = true;
-    ctx->last_step_kernel = ctx->tree_constrained ? "tracking_step_tree_constrained_kernel" : "tracking_step_tree_kernel";
+    ctx->last_step_kernel = tree_parts >= 2 ? "tracking_step_tree_split_kernel"
+                                            : (ctx->tree_constrained ? "tracking_step_tree_constrained_kernel" : "tracking_step_tree_kernel");
     ctx->last_step_shape[0] = ctx->n_treesteps;
-    ctx->last_step_shape[1] = 1;
+    ctx->last_step_shape[1] = tree_parts >= 2 ? tree_parts : 1;
     ctx->last_step_shape[2] = M3T_BLOCK_THREADS;
     ctx->last_step_shape[3] = histogram_fused ? 1 : 0;
     ctx->state_valid = false;

@@ -1466,19 +1466,33 @@ __device__ __forceinline__ bool tree_solve_fast(const TreeOptDev& o, LinkDev* li
 // launches per frame (8-body chain, 7 x 2 iterations).  All workgroups of the grid must be resident (checked by the
 // host); a wait that runs out abandons the step and raises the context's abort word like the split kernel does.
 // ---------------------------------------------------------------------------
-template <bool CONSTRAINED>
+// SPLIT (round 5; tracking_step_tree_split_kernel): the bodies of a structure get the split kernel's treatment -- n_parts
+// workgroups per tracked link, each walks the pixels and builds the distributions of its part of the link's lines
+// (scans the depth windows of its part of the points), the parts hand each other their results once per
+// correspondence iteration (split_exchange_publish / _collect, m3t_kernels.hip), after which every part holds the whole
+// link state, forms the same sums in the same order and -- with the other links' sums, which the link's first part
+// publishes for everybody -- solves the same system.  Workgroup b works for tracked link b mod n_steps, part
+// b / n_steps: with eight tracked links a link's parts share an XCD.
+template <bool CONSTRAINED, bool SPLIT = false>
 __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
                                                const DepthModDev* dmods, const CameraDev* cams, float* body_poses,
                                                TrackLdsLayout layout, int off_points, int np, int off_tree, int iteration,
                                                int n_corr_iterations, int n_update_iterations, int fuse_histogram,
-                                               TreeStepParams xp) {
+                                               TreeStepParams xp, const SplitParams* split = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds_tree[];
   // the workgroup's and the structure's parameters through the constant address space: scalar loads, the values in
   // SGPRs for the whole launch (round 4 read them with per-lane loads: every field a VGPR alive across the search loop
   // -- 119 spill stores in front of it)
   typedef const __attribute__((address_space(4))) TreeStepDev CTreeStep;
   typedef const __attribute__((address_space(4))) TreeOptDev CTreeOpt;
-  CTreeStep& stc = *(CTreeStep*)(steps + blockIdx.x);
+  int step_index = blockIdx.x, part = 0, n_parts = 1;
+  if constexpr (SPLIT) {
+    n_parts = split->n_parts;
+    const int n_steps = (int)gridDim.x / n_parts;
+    part = (int)blockIdx.x / n_steps;
+    step_index = (int)blockIdx.x - part * n_steps;
+  }
+  CTreeStep& stc = *(CTreeStep*)(steps + step_index);
   TreeStepDev st;
   st.opt = stc.opt; st.link = stc.link; st.tracked = stc.tracked;
   st.region_modality = stc.region_modality; st.depth_modality = stc.depth_modality; st.region_first = stc.region_first;
@@ -1545,6 +1559,29 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
   CCam* dcam = dm ? (CCam*)(cams + dm->camera) : nullptr;
   auto* granules = (__attribute__((address_space(1))) unsigned long long*)o.exchange;
   auto* abort_word = (__attribute__((address_space(1))) unsigned*)(o.exchange + 2 * (size_t)o.n_tracked * M3T_TREE_GRANULES);
+  int line_lo = 0, line_hi = 1 << 30, pt_lo = 0, pt_hi = 1 << 30;
+  SplitExchange exchange{};
+  if constexpr (SPLIT) {  // (as in tracking_step_body: the link's step index is the "object" of the granule buffer)
+    line_lo = part * split->per_part_lines;
+    line_hi = line_lo + split->per_part_lines;
+    pt_lo = part * split->per_part_points;
+    pt_hi = pt_lo + split->per_part_points;
+    exchange.granules = (__attribute__((address_space(1))) unsigned long long*)split->granules +
+                        ((size_t)step_index * 2 * n_parts << (kExchangeFieldBits + split->lshift));
+    exchange.object_abort = (__attribute__((address_space(1))) unsigned*)split->object_abort + step_index;
+    exchange.host_abort = split->host_abort;
+    exchange.seq = split->seq;
+    exchange.abort_id = split->abort_id;
+    exchange.part = part;
+    exchange.n_parts = n_parts;
+    exchange.lshift = split->lshift;
+    exchange.per_part_lines = split->per_part_lines;
+    exchange.per_part_points = split->per_part_points;
+    exchange.n_region_fields = rm ? rm->distribution_length : 0;
+    exchange.first_region_row = LS_DIST0;
+    exchange.n_depth_fields = PS_VALID + 1 - PS_CORR_X;
+    exchange.first_depth_row = PS_CORR_X;
+  }
   int round = 0;
   int region_view = rm ? *as_global(rm->last_view) : -1;  // the view of the modality's previous search (closest_view_local)
   for (int c = 0; c < n_corr_iterations; ++c) {
@@ -1552,18 +1589,40 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
       recarve();
       pose = links[st.link].link2world;
       const Affine b2w = load_pose(pose);
+      bool vote_deferred = false;  // decided by region_correspondences (the one predicate for all parts)
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         Affine b2dc = b2c;
         if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
-        region_view = region_correspondences<false, 8, true, true>(*rm, *cam, rdcam, b2c, b2dc, iteration, c, s, 0, 1 << 30,
-                                                                   nullptr, region_view);
-        region_moments(*rm, s);
+        region_view = region_correspondences<false, SPLIT ? 2 : 8, true, true>(
+            *rm, *cam, rdcam, b2c, b2dc, iteration, c, s, line_lo, line_hi, SPLIT ? &vote_deferred : nullptr, region_view,
+            SPLIT ? &exchange : nullptr);
+        if constexpr (!SPLIT) region_moments(*rm, s);
       }
       if (dm) {
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
-        depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, 0, 1 << 30,
+        depth_correspondences_scan(*dm, *dcam, b2c, iteration, c, ps, np, s.misc, pt_lo, pt_hi,
                                    (rm && dm->view_search_shared) ? region_view : -1);
+      }
+      if constexpr (SPLIT) {
+        // publish the own part's results, take the moments of the own lines while the other parts' results are on
+        // their way, collect them, then the moments of the received lines (tracking_step_body, SPLIT)
+        if (rm) {
+          exchange.n_region_fields = rm->distribution_length + (vote_deferred ? 1 : 0);
+          exchange.first_region_row = vote_deferred ? LS_VALID : LS_DIST0;
+        }
+        split_exchange_publish(exchange, c, s, rm != nullptr, ps, np, dm != nullptr,
+                               (rm && !vote_deferred) ? rm->distribution_length : 0);
+        if (rm && !vote_deferred) region_moments(*rm, s, line_lo, line_hi, true);
+        if (!split_exchange_collect(exchange, c, s, rm != nullptr, ps, np, dm != nullptr)) return;
+        if (vote_deferred) {
+          region_finish_flags(*rm, s);
+          region_moments(*rm, s);
+        } else if (rm) {
+          region_moments(*rm, s, line_lo, line_hi, false);
+        }
+      }
+      if (dm) {
         depth_correspondences_vote<true, true>(*dm, iteration, ps, np, s.misc);
       } else {
         __syncthreads();
@@ -1614,9 +1673,10 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
           else { if (rm) gh += sum_r; if (dm) gh += sum_d; }
           if (tid < 42) {
             gh_links[st.link * 42 + ltid] = gh;
-            __hip_atomic_store(slot + (size_t)st.tracked * M3T_TREE_GRANULES + ltid,
-                               (static_cast<unsigned long long>(tag) << 32) | (unsigned)__float_as_int(gh),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (part == 0)  // (every part of the link holds these sums: the first one hands them to the other links)
+              __hip_atomic_store(slot + (size_t)st.tracked * M3T_TREE_GRANULES + ltid,
+                                 (static_cast<unsigned long long>(tag) << 32) | (unsigned)__float_as_int(gh),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           PHASE_MARK(23);
         }
@@ -1658,9 +1718,9 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
   }
   recarve();
   pose = links[st.link].link2world;
-  if (rm && tid == 0) *as_global_w(rm->last_view) = region_view;
+  if (rm && tid == 0 && part == 0) *as_global_w(rm->last_view) = region_view;
   // every workgroup of a structure holds the same link table: the first one writes it (and the bodies) back
-  if (st.tracked == 0) {
+  if (st.tracked == 0 && part == 0) {
     for (int i = tid; i < n_links * 48; i += nt) {
       const int li = i / 48, k = i - li * 48;
       float* dst = k < 16 ? o.links[li].body2joint : (k < 32 ? o.links[li].joint2parent : o.links[li].link2world);
@@ -1680,8 +1740,12 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
     Affine b2dc = b2c;
     if (rdcam) b2dc = mul_pose(load_pose(rdcam->world2camera), b2w);
     const bool handle_occlusions = (iteration - rm->first_iteration) >= rm->n_unoccluded_iterations;
+    // (the parts of a split link take an equal share of the bins each: n_bins^3 is a multiple of 64)
+    const int n_bins3 = rm->n_bins * rm->n_bins * rm->n_bins;
+    const int bin_lo = SPLIT ? part * (n_bins3 / n_parts) : 0;
+    const int bin_hi = SPLIT ? bin_lo + n_bins3 / n_parts : -1;
     region_histogram_update(*rm, *cam, rdcam, b2c, b2dc, handle_occlusions, false,
-                            (__attribute__((address_space(3))) uint32_t*)(lds_tree + M3T_MISC_FLOATS), lds_tree, 0, -1,
+                            (__attribute__((address_space(3))) uint32_t*)(lds_tree + M3T_MISC_FLOATS), lds_tree, bin_lo, bin_hi,
                             nullptr, 0, 0, region_view);
     PHASE_MARK(26);
   }
@@ -1883,6 +1947,15 @@ tracking_step_tree_kernel(const TreeStepDev* steps, const TreeOptDev* opts, cons
                           int n_update_iterations, int fuse_histogram, TreeStepParams xp) {
   tree_step_body<false>(steps, opts, rmods, dmods, cams, body_poses, layout, off_points, np, off_tree, iteration,
                         n_corr_iterations, n_update_iterations, fuse_histogram, xp);
+}
+// ... with several workgroups per tracked link (open structures that leave CUs idle: SPLIT above)
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_tree_split_kernel(const TreeStepDev* steps, const TreeOptDev* opts, const RegionModDev* rmods,
+                                const DepthModDev* dmods, const CameraDev* cams, float* body_poses, TrackLdsLayout layout,
+                                int off_points, int np, int off_tree, int iteration, int n_corr_iterations,
+                                int n_update_iterations, int fuse_histogram, TreeStepParams xp, SplitParams split) {
+  tree_step_body<false, true>(steps, opts, rmods, dmods, cams, body_poses, layout, off_points, np, off_tree, iteration,
+                              n_corr_iterations, n_update_iterations, fuse_histogram, xp, &split);
 }
 // ... and with them (closed chains: constraint rows, an indefinite system; soft constraints onto the link sums)
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)

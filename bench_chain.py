@@ -299,7 +299,7 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
     name = C.create_string_buffer(64)
     hip.call("get_step_kernel", name, 64)
     kernel = name.value.decode()
-    fused = kernel == "tracking_step_tree_kernel"
+    fused = kernel in ("tracking_step_tree_kernel", "tracking_step_tree_split_kernel")
     traffic, traffic_src = (measured_traffic("chain8", kernel, n_bodies, True) if (measured_traffic and fused) else (None, None))
     return {
         "metric": "pose-updates/sec (Mb-ICG kinematic chain, %d bodies, %d dof)" % (n_bodies, 6 + n_bodies - 1),

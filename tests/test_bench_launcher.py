@@ -87,3 +87,31 @@ def test_chain_bodies_round_robin():
     for world in (1, 2, 4, 8):
         ranks = pkg.sharding.place_bodies(8, world)
         assert ranks == [i % world for i in range(8)]
+
+
+def test_rccl_ranks_come_from_the_live_process_group():
+    """config.rccl_ranks answers "how many ranks did RCCL span" from the communicator, never from argv: 0 without a
+    process group and 0 under gloo (the one-GPU dry run of the N-rank path runs over gloo), the group's size under nccl"""
+    import torch.distributed as dist
+    assert bench.live_rccl_ranks(None) == 0
+    assert bench.live_rccl_ranks(dist) == 0  # no group yet
+    port = util.free_port() if hasattr(util, "free_port") else 29631
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        assert dist.get_world_size() == 1 and bench.live_rccl_ranks(dist) == 0
+    finally:
+        dist.destroy_process_group()
+
+    class FakeNccl:  # (no RCCL without a GPU: the rule itself)
+        @staticmethod
+        def is_initialized():
+            return True
+
+        @staticmethod
+        def get_backend():
+            return "nccl"
+
+        @staticmethod
+        def get_world_size():
+            return 8
+    assert bench.live_rccl_ranks(FakeNccl) == 8

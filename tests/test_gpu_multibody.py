@@ -443,10 +443,13 @@ def test_eight_body_chain_matches_the_oracle():
             assert ch.tracker.ExecuteTrackingStep(k)
             out.append(chain_state(ch))
         states[name] = out
-        if name == "hip":  # the whole loop nest of the structure in one launch, one workgroup per body
+        if name == "hip":  # the whole loop nest of the structure in one launch, four workgroups per body (round 5)
             kernel = C.create_string_buffer(64)
             api.call("get_step_kernel", kernel, 64)
-            assert kernel.value.decode() == "tracking_step_tree_kernel"
+            assert kernel.value.decode() == "tracking_step_tree_split_kernel"
+            shape = (C.c_int * 4)()
+            api.call("get_step_shape", shape)
+            assert list(shape)[:3] == [8, 4, 512], list(shape)
     for k, (sh, so) in enumerate(zip(states["hip"], states["oracle"])):
         assert len(sh) == 15
         for x, y in zip(sh, so):
@@ -455,6 +458,97 @@ def test_eight_body_chain_matches_the_oracle():
     for i in range(8):
         e = syn.pose_errors(states["hip"][-1][i], gt[-1][0][i])
         assert e[0] < np.deg2rad(5) and e[1] < 0.05
+
+
+class DepthChain:
+    """body A (free root) -- revolute joint -- body B, a RegionModality (measured occlusions) and a DepthModality on
+    each link, YCB parameters, a colour and a depth camera per body"""
+
+    def __init__(self, api, inputs, joint2parent, start_a, start_angle):
+        rp, dp = dict(syn.YCB_REGION_PARAMS), dict(syn.YCB_DEPTH_PARAMS)
+        self.bodies = [host.Body(api, np.eye(4)), host.Body(api, np.eye(4))]
+        self.cams = [host.ColorCamera(api, **inputs.intr) for _ in range(2)]
+        self.dcams = [host.DepthCamera(api, depth_scale=inputs.depth_scale, **inputs.intr) for _ in range(2)]
+        rmodels = [host.RegionModel(api, data_points=m[0], orientations=m[1], contour_lengths=m[2]) for m in inputs.region_models]
+        dmodels = [host.DepthModel(api, data_points=m[0], orientations=m[1], surface_areas=m[2]) for m in inputs.depth_models]
+        self.link_a = host.Link(api, body=self.bodies[0])
+        self.link_b = host.Link(api, body=self.bodies[1], parent=self.link_a,
+                                joint2parent_pose=joint2parent @ syn.make_pose(syn.rot_vec([0, 0, start_angle]), [0, 0, 0]),
+                                free_directions=(0, 0, 1, 0, 0, 0))
+        for i, link in enumerate((self.link_a, self.link_b)):
+            link.AddModality(host.RegionModality(api, self.bodies[i], self.cams[i], rmodels[i], depth_camera=self.dcams[i], **rp))
+            link.AddModality(host.DepthModality(api, self.bodies[i], self.dcams[i], dmodels[i], **dp))
+        self.opt = host.Optimizer(api, root_link=self.link_a)
+        self.tracker = host.Tracker(api, 4, 2)
+        self.bodies[0].set_body2world_pose(start_a)
+        assert self.tracker.CalculateConsistentPoses()
+
+    def upload(self, frames, k):
+        for i in range(2):
+            self.cams[i].UpdateImage(frames[i][k][0])
+            self.dcams[i].UpdateImage(frames[i][k][1])
+
+    def state(self):
+        return [b.body2world_pose() for b in self.bodies] + [self.link_b.joint2parent_pose()]
+
+
+@gpu
+@pytest.mark.parametrize("with_depth", [False, True])
+def test_bodies_of_a_structure_split_over_workgroups(with_depth, monkeypatch):
+    """tracking_step_tree_split_kernel (round 5): 2, 4 and 8 workgroups per tracked link -- the parts of a link exchange
+    their lines' distributions (with measured occlusions: the lines' flags too; their points' correspondences) once per
+    correspondence iteration, the link sums travel between the links as before -- against one workgroup per link and
+    against the oracle: the same bits after every frame, Region links and Region + Depth links"""
+    import bench_chain
+    start_rng = np.random.default_rng(5)
+    if with_depth:
+        inputs = scenes.Inputs(2, 1, n_divides=2, with_depth=True)
+        rng = np.random.default_rng(11)
+        joint2parent = syn.make_pose(syn.rot_vec([0.3, -0.2, 0.1]), [0.16, 0.02, 0.0])
+        pose_a, angle, frames, first = inputs.gt[0][0].copy(), 0.2, [[], []], None
+        for k in range(3):
+            pose_a = syn.perturb_pose(pose_a, rng, rot_deg=0.7, trans=0.002)
+            angle += rng.uniform(-0.03, 0.03)
+            pose_b = pose_a @ joint2parent @ syn.make_pose(syn.rot_vec([0, 0, angle]), [0, 0, 0])
+            first = first or (pose_a.copy(), angle)
+            frames[0].append(inputs.scenes[0].render(pose_a))
+            frames[1].append(inputs.scenes[1].render(pose_b))
+        start_a = syn.perturb_pose(first[0], start_rng, rot_deg=0.5, trans=0.001)
+        build = lambda api: DepthChain(api, inputs, joint2parent, start_a, first[1] + 0.01)
+        n, n_frames, feed = 2, 3, frames
+    else:
+        n = 4
+        inputs, joints, gt = bench_chain.chain_inputs(scenes, syn, n, 4, 2)
+        start_root = syn.perturb_pose(gt[0][0][0], start_rng, rot_deg=0.5, trans=0.001)
+        build = lambda api: bench_chain.Chain(api, host, syn, inputs, joints, start_root, gt[0][1] + 0.01, range(n))
+        n_frames, feed = len(gt), inputs
+    states = {}
+    for parts in ("oracle", 1, 2, 4, 8):
+        if parts == "oracle":
+            api = util.open_oracle()
+        else:
+            monkeypatch.setenv("M3T_HIP_TREE_PARTS", str(parts))
+            api = util.open_hip()
+        ch = build(api)
+        ch.upload(feed, 0)
+        assert ch.tracker.StartModalities(0)
+        out = []
+        for k in range(n_frames):
+            ch.upload(feed, k)
+            assert ch.tracker.ExecuteTrackingStep(k)
+            out.append(ch.state() if with_depth else chain_state(ch))
+        states[parts] = out
+        if parts != "oracle":
+            shape = (C.c_int * 4)()
+            api.call("get_step_shape", shape)
+            kernel = C.create_string_buffer(64)
+            api.call("get_step_kernel", kernel, 64)
+            assert list(shape)[:2] == [n, parts], (parts, list(shape))
+            assert kernel.value.decode() == ("tracking_step_tree_kernel" if parts == 1 else "tracking_step_tree_split_kernel")
+    for parts in (1, 2, 4, 8):
+        for sa, sb in zip(states["oracle"], states[parts]):
+            for x, y in zip(sa, sb):
+                assert np.array_equal(x, y), parts
 
 
 @gpu
@@ -480,7 +574,7 @@ def test_object_split_off_keeps_the_tree_kernel_out():
         states[name] = out
         kernel = C.create_string_buffer(64)
         api.call("get_step_kernel", kernel, 64)
-        assert (kernel.value.decode() == "tracking_step_tree_kernel") == (name == "tree")
+        assert kernel.value.decode().startswith("tracking_step_tree") == (name == "tree")
     for sa, sb in zip(states["tree"], states["unfused"]):
         for x, y in zip(sa, sb):
             assert np.array_equal(x, y)
