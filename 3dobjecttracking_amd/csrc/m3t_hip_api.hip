@@ -3968,7 +3968,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       bool can = true;
       for (auto& m : ctx->region_mods) can = can && m->shared_histograms < 0 && m->p.n_histogram_bins >= 4;
       const int elements = std::max(ctx->layout.nl, ctx->depth_mods.empty() ? 1 : ctx->np_max);
-      int limit = 4;  // (measured on the 8-body chain: 2 parts .. ms, 4 .. ms, 8 .. ms per step)
+      int limit = 8;  // (the 8-body chain, ms per step: 1 part 0.3046, 2: 0.2939, 4: 0.2756, 8: 0.2649; profiles/r05_chain8_parts.txt)
       if (const char* e = std::getenv("M3T_HIP_TREE_PARTS")) limit = std::atoi(e);  // developer override
       for (int p = M3T_SPLIT_MAX_PARTS; can && p >= 2; p >>= 1) {
         if (p > limit || (elements + p - 1) / p > M3T_SPLIT_LANES / p) continue;

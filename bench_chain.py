@@ -259,8 +259,10 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
             distributed = {"ms_per_step": round(dt / K * 1e3, 4), "allreduce_calls_per_step": round(calls.value / (W + K), 2),
                            "floats_per_allreduce": 42 * n_bodies,
                            "bit_identical_to_the_one_launch_step": bool(np.array_equal(ch2.poses(), first_poses)),
-                           "note": "library communicator at world size 1: links_gather_kernel -> ncclAllReduce -> "
-                                   "links_solve_sums_kernel per Newton step, sub-step launches around them"}
+                           "kernel": (lambda b: (ctx2.call("get_step_kernel", b, 64), b.value.decode())[1])(C.create_string_buffer(64)),
+                           "note": "library communicator at world size 1: one launch of tracking_step_tree_segment_kernel "
+                                   "(solve from the summed link sums | search or line state | products, link sums) and one "
+                                   "ncclAllReduce per Newton step"}
             ctx2.call("comm_destroy")
         except Exception as e:  # (no RCCL on the box: the leg is reported as missing, the bench line stands)
             distributed = {"error": str(e)[:200]}

@@ -443,13 +443,13 @@ def test_eight_body_chain_matches_the_oracle():
             assert ch.tracker.ExecuteTrackingStep(k)
             out.append(chain_state(ch))
         states[name] = out
-        if name == "hip":  # the whole loop nest of the structure in one launch, four workgroups per body (round 5)
+        if name == "hip":  # the whole loop nest of the structure in one launch, eight workgroups per body (round 5)
             kernel = C.create_string_buffer(64)
             api.call("get_step_kernel", kernel, 64)
             assert kernel.value.decode() == "tracking_step_tree_split_kernel"
             shape = (C.c_int * 4)()
             api.call("get_step_shape", shape)
-            assert list(shape)[:3] == [8, 4, 512], list(shape)
+            assert list(shape)[:3] == [8, 8, 512], list(shape)
     for k, (sh, so) in enumerate(zip(states["hip"], states["oracle"])):
         assert len(sh) == 15
         for x, y in zip(sh, so):
@@ -465,7 +465,8 @@ class DepthChain:
     each link, YCB parameters, a colour and a depth camera per body"""
 
     def __init__(self, api, inputs, joint2parent, start_a, start_angle):
-        rp, dp = dict(syn.YCB_REGION_PARAMS), dict(syn.YCB_DEPTH_PARAMS)
+        # (32 bins: with 16 the pair table is staged in LDS and the structure takes the per-sub-step launches)
+        rp, dp = dict(syn.YCB_REGION_PARAMS, n_histogram_bins=32), dict(syn.YCB_DEPTH_PARAMS)
         self.bodies = [host.Body(api, np.eye(4)), host.Body(api, np.eye(4))]
         self.cams = [host.ColorCamera(api, **inputs.intr) for _ in range(2)]
         self.dcams = [host.DepthCamera(api, depth_scale=inputs.depth_scale, **inputs.intr) for _ in range(2)]

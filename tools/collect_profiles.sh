@@ -103,7 +103,7 @@ if has phases; then
   head -12 "$OUT/phase_timing_rbot64.txt"
 fi
 if has rankshare; then  # what one GPU can say about N: rank 0's share at N = 1, 2, 4, 8 ranks, alone on this GPU (a projection)
-  for c in rbot64 synth512 ycb21 chain8; do
+  for c in ${RANKSHARE_CONFIGS:-rbot64 synth512 ycb21 chain8}; do
     (timeout 900 python bench.py --config $c --rank-share 1,2,4,8 --no-cpu-baseline --no-pcie --no-buckets --busy-seconds 1 > "$OUT/rank_share_$c.json" 2> "$OUT/rank_share_$c.err")
     python - "$OUT/rank_share_$c.json" <<'PY'
 import json, sys

@@ -43,7 +43,10 @@ NAMES = {
     26: "histogram update (tail)", 27: "  tail: view", 28: "  tail: occlusion windows", 29: "  tail: pixel walk",
 }
 ORDER = [0, 1, 2, 7, 8, 9, 10, 11, 3, 4, 5, 17, 18, 23, 22, 30, 19, 20, 31, 12, 13, 14, 21, 15, 26, 27, 28, 29]
-print("tracking_step_tree_kernel, 8-body chain (13 dof), s_memtime ticks per frame of workgroup 0 (7 searches, 14 Newton steps)")
+name, shape = C.create_string_buffer(64), (C.c_int * 4)()
+hip.call("get_step_kernel", name, 64)
+hip.call("get_step_shape", shape)
+print("%s %s, 8-body chain (13 dof), s_memtime ticks per frame of workgroup 0 (7 searches, 14 Newton steps)" % (name.value.decode(), list(shape)))
 top = 0
 for i in ORDER + [j for j in range(32) if j not in ORDER]:
     if buf[i]:
