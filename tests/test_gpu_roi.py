@@ -29,12 +29,13 @@ def unrecovered(hip):
     return n.value
 
 
-def run(inputs, mode, margin=24.0, n_frames=None, with_depth=False, reserve_cus=0, adaptive=False):
+def run(inputs, mode, margin=24.0, n_frames=None, with_depth=False, reserve_cus=0, adaptive=False, expect_kernel=None,
+        region_params=None):
     n_frames = n_frames or inputs.n_frames
     hip = util.open_hip()
     if reserve_cus:
         hip.call("reserve_ingest_cus", reserve_cus)
-    inst = scenes.Instance(hip, inputs, use_depth=with_depth)
+    inst = scenes.Instance(hip, inputs, use_depth=with_depth, region_params=region_params)
     if mode != "blocking":
         hip.call("set_roi_ingest", 2 if adaptive else 1, C.c_float(margin))
     inst.upload_frame(0)
@@ -81,6 +82,7 @@ def run(inputs, mode, margin=24.0, n_frames=None, with_depth=False, reserve_cus=
     kernel = C.create_string_buffer(128)
     hip.call("get_step_kernel", kernel, 128)
     assert b"_guard_kernel" in kernel.value, kernel.value  # the last step read rectangles
+    assert expect_kernel is None or kernel.value.decode() == expect_kernel, kernel.value
     return out, status(hip)
 
 
@@ -115,15 +117,27 @@ def runaway_inputs():
     return inputs
 
 
-def test_a_body_that_outruns_its_rectangle_is_repeated_on_the_whole_frame():
-    """the runaway's rectangle (computed from the pose two frames back, with the margin that is enough for the ordinary
+@pytest.mark.parametrize("shape", ["split", "one workgroup", "one workgroup, pair table in LDS", "compact"])
+def test_a_body_that_outruns_its_rectangle_is_repeated_on_the_whole_frame(shape, monkeypatch):
+    """(every guarded kernel: the split one the planner picks for three objects, tracking_step_guard_kernel with the
+    split switched off, tracking_step_compact_guard_kernel with the compact kernel forced)
+    the runaway's rectangle (computed from the pose two frames back, with the margin that is enough for the ordinary
     motion of the other two bodies) does not hold what its step needs.  The guarded kernel drops that step, the
     library fetches the body's whole frame from the host block and repeats the step for that body alone: the poses
     of ALL bodies are those of the blocking whole-frame hand-over, bit for bit, and roi_get_status names the runaway,
     and only the runaway, as repeated"""
+    if shape != "split":
+        monkeypatch.setenv("M3T_HIP_NO_SPLIT", "1")
+    if shape == "compact":
+        monkeypatch.setenv("M3T_HIP_COMPACT", "1")
     inputs = runaway_inputs()
-    ref, _ = run(inputs, "blocking")
-    got, (misses, bodies, pulls) = run(inputs, "roi", margin=24.0)
+    params = dict(util.syn.RBOT_REGION_PARAMS, n_histogram_bins=16) if "LDS" in shape else None
+    ref, _ = run(inputs, "blocking", region_params=params)
+    got, (misses, bodies, pulls) = run(inputs, "roi", margin=24.0, region_params=params,
+                                       expect_kernel={"split": "tracking_step_split_guard_kernel",
+                                                      "one workgroup": "tracking_step_guard_kernel",
+                                                      "one workgroup, pair table in LDS": "tracking_step_lds_guard_kernel",
+                                                      "compact": "tracking_step_compact_guard_kernel"}[shape])
     assert pulls > 0 and misses >= 1
     assert set(bodies) == {1}, bodies  # body ids are creation order: object 1 is body 1
     for k, (a, b) in enumerate(zip(got, ref)):
