@@ -1515,7 +1515,12 @@ __device__ __forceinline__ bool split_exchange_collect(const SplitExchange& x, i
     const bool ok_d = q != x.part && l < x.per_part_points && e_d < np;
     auto* theirs = slot + ((size_t)q << (kExchangeFieldBits + x.lshift)) + l;
     // batches of 8 granules per thread: all loads of a batch are issued before the first tag is looked at
-    // (straight-line code on named registers: an indexed private array would live in scratch memory)
+    // (straight-line code on named registers: an indexed private array would live in scratch memory).
+    // Round 5, tools/exchange_waits.py (the stamps without the phase marks): every part waits 4.4-5.3 k cycles between
+    // its publish and its last granule, all parts alike -- no laggard.  Two other ways of polling were measured and are
+    // slower at 64 objects (0.148 ms): re-reading all stale granules of a batch per poll (0.156: eight times the
+    // polling traffic on the L2 the partners' stores have to get through) and waiting for the batch's first granule
+    // alone before asking for the other seven (0.155: one more round trip in front of every batch).
     for (int f0 = group; f0 < nf; f0 += 8 * n_groups) {
       unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0;
 #define M3T_EXCHANGE_LOAD(J, G)                                                                                      \
