@@ -1027,6 +1027,15 @@ class GeneratedTracker {
     set_up_ = true;
     return true;
   }
+  // ROI ingest for every loader camera (FramePipeline::EnableRoi): of each frame only the trackers' rectangle crosses
+  // PCIe; poses equal those of whole frames bit for bit (a body that outruns its rectangle is repeated on the whole
+  // frame inside ExecuteTrackingStep)
+  bool EnableRoiIngest(bool enable, float margin_px = 24.0f, bool adaptive = true, int reserve_cus = 0) {
+    bool ok = true;
+    for (auto& c : color_cameras) ok = c.second->pipeline.EnableRoi(context->get(), enable, margin_px, adaptive, reserve_cus) && ok;
+    for (auto& c : depth_cameras) ok = c.second->pipeline.EnableRoi(context->get(), enable, margin_px, adaptive, reserve_cus) && ok;
+    return ok;
+  }
   bool UpdateCameras() {
     if (!CheckSetUp()) return false;
     bool ok = true;

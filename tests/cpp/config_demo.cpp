@@ -194,7 +194,36 @@ int main(int argc, char** argv) {
       for (auto& mp : tracker->model_paths) std::printf("model %s %s\n", mp.first.c_str(), mp.second.c_str());
       return 0;
     }
-    std::fprintf(stderr, "usage: config_demo yaml|obj|png|bin|track ...\n");
+    // RunTrackerProcess-style loop over the loaded sequence (tracker.cpp:209-330): detect, start, then a step per frame
+    // until the images run out; `roi` != 0: the loader cameras hand their frames over as rectangles (margin_px = roi)
+    if (mode == "process" && argc >= 4) {
+      auto context = std::make_shared<Context>(0);
+      auto tracker = cfg::GenerateConfiguredTracker(context, argv[2]);
+      const float roi = float(std::atof(argv[3]));
+      if (roi != 0.0f && !tracker->EnableRoiIngest(true, roi, false)) return 6;
+      std::set<std::string> names;
+      for (auto& o : tracker->optimizers) names.insert(o.first);
+      if (!tracker->SetUp() || !tracker->DetectPoses(names) || !tracker->StartModalities(0)) return 5;
+      int steps = 0;
+      for (int k = 0; k < 8; ++k) {
+        if (k > 0 && !tracker->UpdateCameras()) break;
+        if (!tracker->ExecuteTrackingStep(k)) return 7;
+        ++steps;
+        for (auto& b : tracker->bodies) {
+          Pose p = b.second->body2world_pose();
+          std::printf("%d %s", k, b.first.c_str());
+          for (float v : p) std::printf(" %a", double(v));
+          std::printf("\n");
+        }
+      }
+      int n = 0;
+      long long pulls = 0;
+      std::vector<int> bodies(16);
+      m3t_hip_roi_get_status(context->get(), bodies.data(), 16, &n, &pulls);
+      std::printf("steps %d rectangle_uploads %lld repeated %d\n", steps, pulls, n);
+      return 0;
+    }
+    std::fprintf(stderr, "usage: config_demo yaml|obj|png|bin|track|process ...\n");
     return 1;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

@@ -110,6 +110,28 @@ def test_cpp_generated_tracker_reproduces_the_reference_pose(demo, tmp_path):
     assert np.array_equal(tracker.body_ptrs()[0].body2world_pose(), pose)
 
 
+@pytest.mark.gpu
+def test_cpp_loader_pipeline_through_roi_rectangles(demo, tmp_path):
+    """FramePipeline::EnableRoi (GeneratedTracker::EnableRoiIngest): the C++ loader cameras hand the frames of the
+    reference's test sequence over as rectangles -- the same poses after every step as with whole frames, bit for bit;
+    with a margin of one pixel too (steps repeated on whole frames inside the library where the rectangle was too
+    small)"""
+    import glob
+    import shutil
+    root = reference_tree(tmp_path)
+    config = root / "tracker_test" / "tracker_config.yaml"
+    # frames 200 and 201 exist (the object does not move between them): 202 .. 205 = the two again, so that the
+    # sequence is long enough for rectangles (the first uploads precede the first fused step and go as whole frames)
+    for path in glob.glob(str(root / "**" / "*_image_20[01].png"), recursive=True):
+        for k in (2, 4):
+            shutil.copyfile(path, path[:-5] + str(int(path[-5]) + k) + ".png")
+    runs = {margin: demo("process", config, margin).splitlines() for margin in (0, 24, 1)}
+    for margin, out in runs.items():
+        assert out[-1].split()[:2] == ["steps", "6"], out[-1]
+        assert out[:-1] == runs[0][:-1], margin
+    assert int(runs[24][-1].split()[3]) >= 2, runs[24][-1]  # frames went as rectangles
+
+
 def test_cpp_evaluators_agree_with_the_python_evaluators(demo, tmp_path):
     """include/m3t_hip_evaluation.hpp against 3dobjecttracking_amd/evaluation.py on the same files and poses"""
     ev = util.pkg.evaluation
