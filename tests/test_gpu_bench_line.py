@@ -43,6 +43,9 @@ def test_two_rank_code_path_dry_run_on_one_gpu():
     assert line["n_gpus"] == 2 and "dry_run" in line and line["metric"].startswith("[DRY RUN")
     assert line["scaling"] == "weak" and line["config"]["objects_per_gpu"] == 8 and line["config"]["ranks"] == 2
     assert line["parity"]["bit_identical"] is True
+    # the ranks of this run talked over gloo: RCCL spanned none of them (the field is asked of the live process group,
+    # not echoed from --gpus)
+    assert line["config"]["rccl_ranks"] == 0
     assert line["roofline"]["workgroups_per_object"] == 1
     # weak scaling: value = the objects of both ranks over the slower rank's time
     assert abs(line["value"] - 2 * 8 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 0.01
