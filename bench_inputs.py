@@ -96,6 +96,11 @@ def _workers(n_tasks, heavy):
             n = min(n, max(1, int(float(quota) / float(period))))
     except (OSError, ValueError):
         pass
+    # the ranks of one node generate their inputs at the same time: they share the cores
+    try:
+        n = max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
+    except ValueError:
+        pass
     return max(1, min(n, n_tasks))
 
 
