@@ -96,10 +96,20 @@ def test_rectangles_track_like_whole_frames():
         assert np.array_equal(a, b), k
 
 
-def test_rectangles_region_and_depth():
+@pytest.mark.parametrize("shape", ["split", "one workgroup", "compact"])
+def test_rectangles_region_and_depth(shape, monkeypatch):
+    """Region + Depth objects (YCB parameters: measured occlusions, two cameras per object) through every guarded
+    kernel: rectangles of the colour AND the depth frames, the poses of whole frames, nobody repeated"""
+    if shape != "split":
+        monkeypatch.setenv("M3T_HIP_NO_SPLIT", "1")
+    if shape == "compact":
+        monkeypatch.setenv("M3T_HIP_COMPACT", "1")
     inputs = scenes.Inputs(3, 6, n_divides=2, with_depth=True)
     ref, _ = run(inputs, "blocking", with_depth=True)
-    got, (misses, bodies, pulls) = run(inputs, "roi", with_depth=True)
+    got, (misses, bodies, pulls) = run(inputs, "roi", with_depth=True,
+                                       expect_kernel={"split": "tracking_step_split_guard_kernel",
+                                                      "one workgroup": "tracking_step_lds_guard_kernel",
+                                                      "compact": "tracking_step_compact_guard_kernel"}[shape])
     assert pulls >= 2 * (inputs.n_frames - 3) and misses == 0, (pulls, bodies)
     for k, (a, b) in enumerate(zip(got, ref)):
         assert np.array_equal(a, b), k
