@@ -153,7 +153,11 @@ int m3t_hip_roi_get_unrecovered(m3t_hip_context*, int* body_ids, int capacity, i
  * take the same number of CUs from every shader engine: a multiple of 32 on MI355X (8 XCDs x 4 engines; anything else
  * is refused); 32 and 64 were measured (tools/ubench_cumask.hip, bench.py's ROI leg).  The tracking launches plan with the remaining CUs (fewer workgroups per object
  * where the batch no longer fits).  0 = off (default).  The call synchronises and REPLACES the context's streams:
- * fetch m3t_hip_get_stream again afterwards.  Results do not depend on it. */
+ * fetch m3t_hip_get_stream again afterwards.  Results do not depend on it.  The layout is MI355X's (gfx950, 256 CUs in
+ * one partition): other devices are refused (M3T_ERR_UNSUPPORTED).  CU-masked streams are BLOCKING streams (the runtime
+ * offers no other kind): while CUs are reserved, work on the legacy NULL stream -- a plain hipMemcpy, torch's default
+ * stream -- synchronises with the context's compute stream and its first copy stream; keep such work off the device
+ * meanwhile or the pull / step overlap is lost. */
 int m3t_hip_reserve_ingest_cus(m3t_hip_context*, int n_cus);
 
 /* ---- Bodies (body.h:46: only body2world_pose crosses the boundary) ------------ */
