@@ -187,6 +187,7 @@ struct RoiItemDev {
   int opt;                       // the rigid optimizer whose search poses apply (-1: none recorded)
   float box_min[3], box_max[3];  // around the data points of the modality's model, body frame
   float reach_px, reach_m;       // the modality's reach (m3t_roi.h), without the caller's margin
+  float rho;                     // the points also lie in the ellipsoid of rho x the box's half extents (0: not used)
 };
 
 // ROI guard (tracking_step_*_guard_kernel): appended to an object's search-pose block, at search_poses + 16 * n_poses.

@@ -65,6 +65,7 @@ struct Model {
   DevMem view_neighbors;          // [n_views][M3T_VIEW_ROW] float4 (closest_view_local), empty for tiny view sets
   std::vector<float> h_orientations;  // host copy: modalities whose models share their view table share the view search
   float box_min[3] = {0, 0, 0}, box_max[3] = {0, 0, 0};  // around the centres of all data points (ROI ingest, m3t_roi.h)
+  float box_rho = 0.0f;  // ... which also lie in the ellipsoid of box_rho x the box's half extents (0: a flat box, not used)
 };
 
 struct Camera {
@@ -457,6 +458,24 @@ int CreateModel(Ctx* ctx, bool region, int n_views, int n_points, const float* p
       m->box_min[k] = std::min(m->box_min[k], pts[i * m->point_floats + k]);
       m->box_max[k] = std::max(m->box_max[k], pts[i * m->point_floats + k]);
     }
+  {  // the largest normalised radius of a point about the box's centre (m3t_roi_ellipsoid)
+    double mid[3], half[3], worst = 0.0;
+    bool flat = false;
+    for (int k = 0; k < 3; ++k) {
+      mid[k] = 0.5 * (double(m->box_min[k]) + double(m->box_max[k]));
+      half[k] = 0.5 * (double(m->box_max[k]) - double(m->box_min[k]));
+      flat = flat || !(half[k] > 1e-9);
+    }
+    for (size_t i = 0; !flat && i < size_t(n_views) * n_points; ++i) {
+      double r2 = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        const double q = (double(pts[i * m->point_floats + k]) - mid[k]) / half[k];
+        r2 += q * q;
+      }
+      worst = std::max(worst, r2);
+    }
+    m->box_rho = flat ? 0.0f : float(std::sqrt(worst) * (1.0 + 1e-4));
+  }
   size_t pb = size_t(n_views) * n_points * m->point_floats * 4;
   HIPCHK(m->points.alloc(pb));
   HIPCHK(m->orientations.alloc(size_t(n_views) * 12));
@@ -1138,6 +1157,7 @@ int BuildRoiTables(Ctx* ctx) {
     }
     it.reach_px = reach_px;
     it.reach_m = reach_m;
+    it.rho = model.box_rho;
     items.push_back(it);
   };
   for (size_t oi = 0; oi < ctx->opt_table.size(); ++oi) {

@@ -41,10 +41,10 @@ roi_rect_kernel(const RoiItemDev* items, const int* item_first, const int* cam_i
     roi_body2camera(cam.world2camera, body_poses + 16 * it.body, b2c);
     float margin = margin_px;
     if (prev_poses && motion_peak) {
-      const m3t_roi_rect now = m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px, it.reach_m);
+      const m3t_roi_rect now = m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px, it.reach_m, it.rho);
       float b2c_prev[16];
       roi_body2camera(cam.world2camera, prev_poses + 16 * it.body, b2c_prev);
-      const m3t_roi_rect before = m3t_roi_body(b2c_prev, it.box_min, it.box_max, &k, it.reach_px, it.reach_m);
+      const m3t_roi_rect before = m3t_roi_body(b2c_prev, it.box_min, it.box_max, &k, it.reach_px, it.reach_m, it.rho);
       const float moved = (float)max(max(abs(now.x0 - before.x0), abs(now.x1 - before.x1)),
                                      max(abs(now.y0 - before.y0), abs(now.y1 - before.y1)));
       const float known = motion_peak[j];  // < 0: no motion seen yet -- the first rectangle takes the whole margin
@@ -52,7 +52,7 @@ roi_rect_kernel(const RoiItemDev* items, const int* item_first, const int* cam_i
       motion_peak[j] = peak;  // (this camera's thread is the only one that touches reader j)
       if (!(known < 0.0f)) margin = fminf(margin_px, fmaxf(min_margin_px, fmaxf(2.0f * moved, 1.25f * peak) + 3.0f));
     }
-    r = m3t_roi_union(r, m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px + margin, it.reach_m));
+    r = m3t_roi_union(r, m3t_roi_body(b2c, it.box_min, it.box_max, &k, it.reach_px + margin, it.reach_m, it.rho));
   }
   rects[cam_id] = r;
 }

@@ -264,7 +264,10 @@ __device__ __noinline__ int roi_guard_outside(const RoiItemDev* items, const m3t
     o = __shfl_xor(z_min, m); z_min = o < z_min ? o : z_min;
   }
   m3t_roi_rect need = {0, 0, k.width - 1, k.height - 1};  // a box that reaches the camera plane: the whole frame
-  if (front) need = m3t_roi_widen(u_min, u_max, v_min, v_max, z_min, &k, it.reach_px, it.reach_m);
+  if (front) {
+    m3t_roi_tighten(b2c, it.box_min, it.box_max, it.rho, &k, &u_min, &u_max, &v_min, &v_max, &z_min);
+    need = m3t_roi_widen(u_min, u_max, v_min, v_max, z_min, &k, it.reach_px, it.reach_m);
+  }
   bool outside = false;
   if (active && cam.slot < n_rect_slots)  // (a ring slot added since the tables were built holds whole frames only)
     outside = !m3t_roi_contains(rects[(size_t)cam.slot * n_cams + it.camera], need);

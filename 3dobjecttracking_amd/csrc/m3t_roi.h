@@ -10,9 +10,9 @@
 //                                  (x z with depth scaling; depth_modality.cpp:826-884), and the measured-occlusion
 //                                  window (:736-776)
 // and those points are data points of the modality's sparse viewpoint model moved by the pose: the rectangle is the
-// bounding rectangle of the projected box around the model's points, widened by a reach in pixels plus a reach in
-// metres at the box's near side.
-// Host and device code (plain C functions); tests/test_roi_bound.py checks the rectangles against the oracle: frames
+// bounding rectangle of the projected box around the model's points -- cut down to the outline of the ellipsoid that
+// holds them where that is tighter (round 5) --, widened by a reach in pixels plus a reach in metres at the near side.
+// Host and device code (plain functions, C++ only for a default argument); tests/test_roi_bound.py checks the rectangles against the oracle: frames
 // scrambled outside them leave every pose and histogram of a tracked sequence unchanged.
 #pragma once
 #include <math.h>
@@ -101,6 +101,65 @@ M3T_ROI_FN int m3t_roi_corner(const float* body2camera, const float* box_min, co
   *v = y * intr->fv / z + intr->ppv;
   return 1;
 }
+// A second, independent bound (round 5): the points also lie inside the ellipsoid around the box's centre whose
+// semi-axes are rho x the box's half extents (rho: the largest normalised radius of a point, computed where the model is
+// loaded; 1 for points on the inscribed ellipsoid -- a convex body seen from all sides --, sqrt(3) at worst).  Its
+// outline in the image is a conic whose axis-parallel tangents have a closed form: with c the centre and S = R D R^T
+// the shape matrix in the camera frame (D = diag(semi-axes^2)), the dual conic in normalised image coordinates is
+// C* = S - c c^T and the tangents u = const are the roots of C*22 u^2 - 2 C*02 u + C*00 = 0 (v alike, index 1).  The box's
+// projected corners over-estimate an ellipsoidal body by the corners' overhang (~ 30 % of the radius); the
+// intersection of the two bounds is still a bound.  Returns 0 (and leaves the limits alone) when rho <= 0 or the
+// ellipsoid does not lie in front of the camera.
+M3T_ROI_FN int m3t_roi_ellipsoid(const float* body2camera, const float* box_min, const float* box_max, float rho,
+                                 const m3t_intrinsics* intr, float* u_min, float* u_max, float* v_min, float* v_max,
+                                 float* z_min) {
+  if (!(rho > 0.0f)) return 0;
+  float m[3], d[3];
+  for (int k = 0; k < 3; ++k) {
+    m[k] = 0.5f * (box_min[k] + box_max[k]);
+    const float e = rho * 0.5f * (box_max[k] - box_min[k]);
+    d[k] = e * e;
+  }
+  const float* B = body2camera;
+  const float cx = B[0] * m[0] + B[4] * m[1] + B[8] * m[2] + B[12];
+  const float cy = B[1] * m[0] + B[5] * m[1] + B[9] * m[2] + B[13];
+  const float cz = B[2] * m[0] + B[6] * m[1] + B[10] * m[2] + B[14];
+  // S_ij = sum_k B(i, k) B(j, k) d_k (rows 0, 1, 2 of the rotation)
+  const float s00 = B[0] * B[0] * d[0] + B[4] * B[4] * d[1] + B[8] * B[8] * d[2];
+  const float s11 = B[1] * B[1] * d[0] + B[5] * B[5] * d[1] + B[9] * B[9] * d[2];
+  const float s22 = B[2] * B[2] * d[0] + B[6] * B[6] * d[1] + B[10] * B[10] * d[2];
+  const float s02 = B[0] * B[2] * d[0] + B[4] * B[6] * d[1] + B[8] * B[10] * d[2];
+  const float s12 = B[1] * B[2] * d[0] + B[5] * B[6] * d[1] + B[9] * B[10] * d[2];
+  const float depth = sqrtf(s22);         // the ellipsoid's half extent along the optical axis
+  if (!(cz - depth > 1e-3f)) return 0;    // it has to lie in front of the camera as a whole
+  const float c22 = s22 - cz * cz;        // < 0
+  const float c00 = s00 - cx * cx, c02 = s02 - cx * cz;
+  const float c11 = s11 - cy * cy, c12 = s12 - cy * cz;
+  const float du = c02 * c02 - c00 * c22, dv = c12 * c12 - c11 * c22;
+  if (!(du >= 0.0f && dv >= 0.0f && c22 < 0.0f)) return 0;
+  const float ru = sqrtf(du), rv = sqrtf(dv);
+  // (c22 < 0: the root with + ru is the smaller one)
+  *u_min = (c02 + ru) / c22 * intr->fu + intr->ppu;
+  *u_max = (c02 - ru) / c22 * intr->fu + intr->ppu;
+  *v_min = (c12 + rv) / c22 * intr->fv + intr->ppv;
+  *v_max = (c12 - rv) / c22 * intr->fv + intr->ppv;
+  *z_min = cz - depth;
+  return 1;
+}
+// ... intersected with the limits of the projected corners (both hold, so the tighter one of each holds)
+M3T_ROI_FN void m3t_roi_tighten(const float* body2camera, const float* box_min, const float* box_max, float rho,
+                                const m3t_intrinsics* intr, float* u_min, float* u_max, float* v_min, float* v_max,
+                                float* z_min) {
+  float eu0, eu1, ev0, ev1, ez;
+  if (!m3t_roi_ellipsoid(body2camera, box_min, box_max, rho, intr, &eu0, &eu1, &ev0, &ev1, &ez)) return;
+  // (half a pixel of slack for the f32 evaluation of the roots: their cancellation error is ~1e-3 pixel)
+  eu0 -= 0.5f; ev0 -= 0.5f; eu1 += 0.5f; ev1 += 0.5f;
+  *u_min = eu0 > *u_min ? eu0 : *u_min;
+  *u_max = eu1 < *u_max ? eu1 : *u_max;
+  *v_min = ev0 > *v_min ? ev0 : *v_min;
+  *v_max = ev1 < *v_max ? ev1 : *v_max;
+  *z_min = ez > *z_min ? ez : *z_min;
+}
 // The bounding rectangle of the projected corners, widened by the reach and cut to the frame.
 M3T_ROI_FN m3t_roi_rect m3t_roi_widen(float u_min, float u_max, float v_min, float v_max, float z_min,
                                       const m3t_intrinsics* intr, float reach_px, float reach_m) {
@@ -120,7 +179,7 @@ M3T_ROI_FN m3t_roi_rect m3t_roi_widen(float u_min, float u_max, float v_min, flo
   return r;
 }
 M3T_ROI_FN m3t_roi_rect m3t_roi_body(const float* body2camera, const float* box_min, const float* box_max,
-                                     const m3t_intrinsics* intr, float reach_px, float reach_m) {
+                                     const m3t_intrinsics* intr, float reach_px, float reach_m, float rho = 0.0f) {
   m3t_roi_rect full = {0, 0, intr->width - 1, intr->height - 1};
   float u_min = 3.0e38f, u_max = -3.0e38f, v_min = 3.0e38f, v_max = -3.0e38f, z_min = 3.0e38f;
   for (int corner = 0; corner < 8; ++corner) {
@@ -132,5 +191,6 @@ M3T_ROI_FN m3t_roi_rect m3t_roi_body(const float* body2camera, const float* box_
     v_max = v > v_max ? v : v_max;
     z_min = z < z_min ? z : z_min;
   }
+  m3t_roi_tighten(body2camera, box_min, box_max, rho, intr, &u_min, &u_max, &v_min, &v_max, &z_min);
   return m3t_roi_widen(u_min, u_max, v_min, v_max, z_min, intr, reach_px, reach_m);
 }

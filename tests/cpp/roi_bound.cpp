@@ -6,20 +6,20 @@ static void put(const m3t_roi_rect& r, int* out) { out[0] = r.x0; out[1] = r.y0;
 extern "C" {
 // corr_iteration < 0: the histogram lines (StartModality / CalculateResults)
 void roi_region_color(const float* body2camera, const float* box_min, const float* box_max, const m3t_intrinsics* intr,
-                      const m3t_region_modality_params* p, int corr_iteration, int* out) {
+                      const m3t_region_modality_params* p, int corr_iteration, float rho, int* out) {
   const float reach = corr_iteration < 0 ? m3t_roi_region_histogram_reach(p) : m3t_roi_region_line_reach(p, corr_iteration);
-  put(m3t_roi_body(body2camera, box_min, box_max, intr, reach, 0.0f), out);
+  put(m3t_roi_body(body2camera, box_min, box_max, intr, reach, 0.0f, rho), out);
 }
 void roi_region_depth(const float* body2camera, const float* box_min, const float* box_max, const m3t_intrinsics* intr,
-                      const m3t_region_modality_params* p, int* out) {
+                      const m3t_region_modality_params* p, float rho, int* out) {
   float reach_m, reach_px;
   m3t_roi_region_depth_reach(p, &reach_m, &reach_px);
-  put(m3t_roi_body(body2camera, box_min, box_max, intr, reach_px, reach_m), out);
+  put(m3t_roi_body(body2camera, box_min, box_max, intr, reach_px, reach_m, rho), out);
 }
 void roi_depth(const float* body2camera, const float* box_min, const float* box_max, const m3t_intrinsics* intr,
-               const m3t_depth_modality_params* p, int* out) {
+               const m3t_depth_modality_params* p, float rho, int* out) {
   float reach_m, reach_px;
   m3t_roi_depth_reach(p, intr->fu, &reach_m, &reach_px);
-  put(m3t_roi_body(body2camera, box_min, box_max, intr, reach_px, reach_m), out);
+  put(m3t_roi_body(body2camera, box_min, box_max, intr, reach_px, reach_m, rho), out);
 }
 }

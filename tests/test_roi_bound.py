@@ -28,16 +28,25 @@ def roi_lib(tmp_path):
 def rect(fn, pose, box, intr, params, *extra):
     out = (C.c_int * 4)()
     p = np.ascontiguousarray(np.asarray(pose, np.float32).T).reshape(16)  # column-major
-    lo, hi = (np.ascontiguousarray(b, np.float32) for b in box)
+    lo, hi = (np.ascontiguousarray(b, np.float32) for b in box[:2])
     f = C.POINTER(C.c_float)
-    fn(p.ctypes.data_as(f), lo.ctypes.data_as(f), hi.ctypes.data_as(f), C.byref(intr), C.byref(params), *extra, out)
+    fn(p.ctypes.data_as(f), lo.ctypes.data_as(f), hi.ctypes.data_as(f), C.byref(intr), C.byref(params), *extra,
+       C.c_float(box[2] if TIGHT else 0.0), out)
     return list(out)
 
 
+TIGHT = not os.environ.get("M3T_ROI_BOX_ONLY")  # the ellipsoid bound on (what the library does); False: the projected box alone (round 4)
+
+
 def box_of(points):
-    """box around the centres of a sparse viewpoint model's data points ([views][points][>= 3])"""
+    """box around the centres of a sparse viewpoint model's data points ([views][points][>= 3]), and rho: the points
+    also lie in the ellipsoid of rho x the box's half extents about its centre (m3t_roi_ellipsoid; computed as the
+    library computes it where a model is loaded)"""
     c = np.asarray(points, np.float32)[..., :3].reshape(-1, 3)
-    return c.min(axis=0), c.max(axis=0)
+    lo, hi = c.min(axis=0), c.max(axis=0)
+    mid, half = 0.5 * (lo.astype(np.float64) + hi), 0.5 * (hi.astype(np.float64) - lo)
+    rho = 0.0 if np.any(half <= 1e-9) else float(np.sqrt(np.max(np.sum(((c - mid) / half) ** 2, axis=1))) * (1.0 + 1e-4))
+    return lo, hi, rho
 
 
 def union(a, b):
@@ -130,7 +139,7 @@ def test_frames_scrambled_outside_the_rectangles_track_identically(tmp_path, wit
     for (fa, ba), (fb, bb) in zip([r.histograms() for r in c.region], ref_hist):
         assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
     # the rectangles are a fraction of the frame (and a frame of noise does change the result: the check has teeth)
-    print("colour rectangles: %.3f .. %.3f of the frame" % (min(fractions), max(fractions)))
+    print("colour rectangles: %.3f .. %.3f of the frame, mean %.3f" % (min(fractions), max(fractions), float(np.mean(fractions))))
     assert max(fractions) < limit, fractions
     noise = scenes.Inputs.__new__(scenes.Inputs)
     noise.__dict__.update(scrambled.__dict__)
