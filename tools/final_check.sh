@@ -8,5 +8,5 @@ export M3T_INPUT_CACHE=${M3T_INPUT_CACHE:-${XDG_CACHE_HOME:-$HOME/.cache}/m3t_in
 (timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) | tee "$OUT/smoke.log"
 t0=$(date +%s.%N)
 timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-echo "python bench.py: $(echo "$(date +%s.%N) - $t0" | bc) s wall" | tee -a "$OUT/smoke.log"
+echo "python bench.py: $(echo "$(date +%s.%N) - $t0" | bc 2>/dev/null) s wall" | tee -a "$OUT/smoke.log"
 tail -1 "$OUT/bench_default.json" | cut -c1-400
