@@ -304,6 +304,7 @@ _HIP_ONLY = {
     "comm_init_rank": [C.c_void_p, C.c_size_t, C.c_int, C.c_int],
     "comm_set": [C.c_void_p],
     "comm_destroy": [],
+    "comm_set_reduce_callback": [C.c_void_p, C.c_void_p],
     "calculate_optimization_allreduce": [],
     "comm_get_allreduce_count": [C.POINTER(C.c_longlong)],
     "comm_get_rank_count": [C.POINTER(C.c_int)],
@@ -325,6 +326,10 @@ _HIP_ONLY = {
 }
 
 
+# int fn(void* user, float* device_buffer, size_t count, void* hip_stream): m3t_hip_comm_set_reduce_callback
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
 def fptr(a):
     return a.ctypes.data_as(c_float_p)
 
@@ -343,7 +348,7 @@ def pose_ret(buf):
     return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
 
 
-_NEWER_ENTRY_POINTS = ("get_step_kernel", "comm_get_allreduce_count", "comm_get_rank_count", "debug_log_checksum", "set_roi_ingest",
+_NEWER_ENTRY_POINTS = ("comm_set_reduce_callback", "get_step_kernel", "comm_get_allreduce_count", "comm_get_rank_count", "debug_log_checksum", "set_roi_ingest",
                        "cameras_upload_batch_roi_async", "roi_get_status", "roi_get_unrecovered", "reserve_ingest_cus", "camera_slot_sync")
 
 

@@ -7,11 +7,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libm3t_hip.so")
 # m3t_hip_api.hip is the one translation unit; it includes the other .hip files and m3t_device.h
-SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc", ".map")))
 HEADERS = [os.path.join(HERE, "..", "include", "m3t_hip.h"), os.path.join(HERE, "..", "include", "m3t_types.h")]
 # -ffp-contract=off: the kernels follow the reference's f32 expression trees op by op
+# -fvisibility=hidden: only what include/m3t_hip.h declares (default visibility pushed there) is a dynamic symbol
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden",
+         "-Wl,--version-script=" + os.path.join(CSRC, "libm3t_hip.map")]
 
 
 def needs_build():

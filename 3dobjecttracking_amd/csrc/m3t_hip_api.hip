@@ -195,6 +195,8 @@ struct m3t_hip_context {
   DevMem d_links, d_constraints, d_soft, d_treeopts, d_work, d_partial;
   DevMem d_link_sums, d_link_first;  // what a structure spread over processes exchanges (links_gather_kernel): [links][42], first link per structure
   DevMem d_link_sums_alt, d_links_alt;  // tracking_step_tree_segment_kernel: the second copies (sums, link table) that take turns
+  DevMem d_poses_first;  // ... and the bodies' start poses for a frame of one Newton step
+  bool tree_untracked_structure = false;  // some structure has no modality in this context (its bodies live on other ranks)
   size_t link_sums_count = 0;
   // tracking_step_tree_kernel: one workgroup per link that carries modalities
   DevMem d_treesteps, d_tracked_links, d_tree_exchange;
@@ -210,6 +212,10 @@ struct m3t_hip_context {
   ncclComm_t comm = nullptr;
   long long allreduce_calls = 0;  // ncclAllReduce calls issued since the context was created (m3t_hip_comm_get_allreduce_count)
   bool comm_owned = false;
+  // ... or the host's own transport in the collective's place (m3t_hip_comm_set_reduce_callback): MPI, gloo, threads
+  m3t_hip_reduce_fn reduce_fn = nullptr;
+  void* reduce_user = nullptr;
+  bool Distributed() const { return comm != nullptr || reduce_fn != nullptr; }
   int n_corr_iterations = 5, n_update_iterations = 2;
   int fused_mode = 1;
   // device tables
@@ -868,6 +874,7 @@ int UploadTreeTables(Ctx* ctx) {
     size_t exchange_total = 0, attached = 0;
     bool possible = true;
     ctx->tree_block_floats = 0;
+    ctx->tree_untracked_structure = false;
     for (size_t oi = 0; oi < opts.size(); ++oi) {
       const Optimizer& o = ctx->optimizers[oi];
       tracked_off[oi] = tracked.size();
@@ -893,6 +900,7 @@ int UploadTreeTables(Ctx* ctx) {
         tracked.push_back(int(k));
       }
       opts[oi].n_tracked = n_tracked;
+      if (n_tracked == 0) ctx->tree_untracked_structure = true;
       exchange_off[oi] = exchange_total;
       exchange_total += size_t(2) * n_tracked * M3T_TREE_GRANULES + 1;  // + the structure's abort word
       const size_t block = (o.order.size() * sizeof(LinkDev) + 3) / 4 + o.order.size() * 42 + size_t(o.dof) * o.dof + o.dof +
@@ -1202,7 +1210,10 @@ int BuildRoiTables(Ctx* ctx) {
     std::vector<float> blocks(ctx->opt_table.size() * per_object, 0.0f);
     for (size_t j = 0; j < items.size(); ++j) {
       RoiGuardDev* g = reinterpret_cast<RoiGuardDev*>(blocks.data() + size_t(items[j].opt) * per_object + size_t(ctx->roi_n_poses) * 16);
-      if (g->n_items < M3T_ROI_GUARD_ITEMS) g->item[g->n_items++] = int(j);
+      // (a reader beyond the header's capacity would shrink its camera's upload without any kernel checking it)
+      REQUIRE(g->n_items < M3T_ROI_GUARD_ITEMS, M3T_ERR_UNSUPPORTED,
+              "ROI ingest: an optimizer has more frame readers than the guard header holds (M3T_ROI_GUARD_ITEMS)");
+      g->item[g->n_items++] = int(j);
     }
     HIPCHK(hipMemcpy(ctx->d_search_poses.p, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice));
   }
@@ -1626,8 +1637,15 @@ int LaunchSolveSums(Ctx* ctx) {
 // +0.0 (m3t_links.hip, links_gather_kernel)
 int AllReducePartial(Ctx* ctx, float* buffer = nullptr) {
   REQUIRE(ctx->partial_ready, M3T_ERR_NOT_SET_UP, "calculate_optimization_begin has to be called first");
-  REQUIRE(ctx->comm != nullptr, M3T_ERR_NOT_SET_UP, "no communicator: m3t_hip_comm_init_rank / m3t_hip_comm_set first");
+  REQUIRE(ctx->Distributed(), M3T_ERR_NOT_SET_UP,
+          "no communicator: m3t_hip_comm_init_rank / m3t_hip_comm_set / m3t_hip_comm_set_reduce_callback first");
   if (!buffer) buffer = ctx->d_link_sums.as<float>();
+  if (ctx->reduce_fn) {  // the host's transport: leaves the sum over its ranks in the buffer, in stream order
+    const int rc = ctx->reduce_fn(ctx->reduce_user, buffer, ctx->link_sums_count, static_cast<void*>(ctx->stream));
+    if (rc != 0) return Fail(ctx, M3T_ERR_DEVICE, "the reduce callback failed with code " + std::to_string(rc));
+    ++ctx->allreduce_calls;
+    return M3T_OK;
+  }
   const ncclResult_t rc =
       g_rccl.AllReduce(buffer, buffer, ctx->link_sums_count, ncclFloat, ncclSum, ctx->comm, ctx->stream);
   if (rc != ncclSuccess)
@@ -1641,7 +1659,7 @@ int AllReducePartial(Ctx* ctx, float* buffer = nullptr) {
 // (SURVEY 8e): link sums -> ONE all-reduce of them -> project + solve, on every path that reaches this function
 // (m3t_hip_calculate_optimization and the sub-step loop of m3t_hip_execute_tracking_step alike).
 int LaunchOptimization(Ctx* ctx) {
-  if (ctx->comm) {
+  if (ctx->Distributed()) {
     if (!ctx->tree_mode) {  // rigid bodies only: force the general path so that the sums exist
       ctx->tree_mode = true;
       ctx->fused_possible = false;
@@ -1679,7 +1697,7 @@ size_t TreeStepLds(Ctx* ctx, bool fused_histogram) {
 // structure copy next to the tracking carve-up in LDS, and every workgroup of the grid resident at once.
 bool TreeStepFused(Ctx* ctx) {
   // (m3t_hip_set_object_split(ctx, 0) = "this context shares its GPU": no launch whose workgroups wait for each other)
-  if (!(ctx->tree_mode && ctx->tree_fused_possible && ctx->fused_mode == 1 && !ctx->comm && ctx->n_render_all == 0 &&
+  if (!(ctx->tree_mode && ctx->tree_fused_possible && ctx->fused_mode == 1 && !ctx->Distributed() && ctx->n_render_all == 0 &&
         ctx->shared_histograms.empty() && ctx->n_treesteps > 0 && ctx->split_enabled &&
         !std::getenv("M3T_HIP_NO_TREE_FUSION")))
     return false;
@@ -1707,9 +1725,12 @@ bool TreeStepFused(Ctx* ctx) {
 // Newton step (tracking_step_tree_segment_kernel)?  The conditions of the one-launch step, except that no workgroup
 // waits for another one inside a launch: no co-residency needed, any grid.
 bool TreeStepSegmented(Ctx* ctx) {
-  if (!(ctx->tree_mode && ctx->tree_fused_possible && ctx->fused_mode == 1 && ctx->comm && ctx->n_render_all == 0 &&
+  if (!(ctx->tree_mode && ctx->tree_fused_possible && ctx->fused_mode == 1 && ctx->Distributed() && ctx->n_render_all == 0 &&
         ctx->shared_histograms.empty() && ctx->n_treesteps > 0 && !std::getenv("M3T_HIP_NO_TREE_SEGMENTS")))
     return false;
+  // a structure's solve is done by the workgroups of its tracked links: one whose modalities all live on other ranks
+  // has none here, and still has to be solved from the summed link sums -> the per-sub-step launches (grid = structures)
+  if (ctx->tree_untracked_structure) return false;
   if (ctx->layout.off_hist >= 0) return false;
   const bool fused_histogram = !ctx->region_mods.empty() && ctx->hist_counts_in_lds;
   const size_t lds = TreeStepLds(ctx, fused_histogram);
@@ -2036,8 +2057,10 @@ int m3t_hip_camera_upload_slot_async(m3t_hip_context* ctx, int id, int slot, con
   ctx->copies_pending |= 1u << cs;
   return M3T_OK;
 }
-// Wait until the last camera_upload_slot_async into (camera, slot) has left its host buffer -- and for nothing else:
-// the copies of other cameras and of this camera's other slots stay in flight (m3t_hip_ingest_sync waits for all).
+// Wait until the last upload into (camera, slot) -- camera_upload_slot_async, a batch upload, a rectangle pull -- has
+// left its host buffer, and for nothing else: the copies of other cameras and of this camera's other slots stay in
+// flight (m3t_hip_ingest_sync waits for all).  A rectangle slot also waits for the step that read it (its repair
+// reads the host block once more).
 int m3t_hip_camera_slot_sync(m3t_hip_context* ctx, int id, int slot) {
   CHECK_CTX();
   REQUIRE(id >= 0 && id < int(ctx->cameras.size()), M3T_ERR_INVALID_ARGUMENT, "bad camera id");
@@ -2047,7 +2070,8 @@ int m3t_hip_camera_slot_sync(m3t_hip_context* ctx, int id, int slot) {
   if (c.slot_is_roi[slot]) {
     // a rectangle went into the slot (m3t_hip_cameras_upload_batch_roi_async): the host block is read by the pull and,
     // should a body outrun its rectangle, again by the repair of the step that reads the slot -- both must be over
-    if (ctx->async_ingest && ctx->copy_stream[0]) HIPCHK(hipStreamSynchronize(ctx->copy_stream[0]));
+    if (size_t(slot) < c.slot_copied.size() && c.slot_copied[slot]) HIPCHK(hipEventSynchronize(c.slot_copied[slot]));
+    else if (ctx->async_ingest && ctx->copy_stream[0]) HIPCHK(hipStreamSynchronize(ctx->copy_stream[0]));
     if (c.last_read_step[slot] >= 0 && c.last_read_step[slot] + Ctx::kStepEvents > ctx->step_counter)
       HIPCHK(hipEventSynchronize(ctx->step_done[c.last_read_step[slot] % Ctx::kStepEvents]));
     else if (c.last_read_step[slot] >= 0)
@@ -2153,6 +2177,14 @@ int m3t_hip_cameras_upload_batch_async(m3t_hip_context* ctx, const int* ids, int
                             ctx->copy_stream[cs]));
   for (int i = 0; i < n; ++i) ctx->cameras[ids[i]]->has_image[slot] = true;
   RoiMarkWholeFrames(ctx, ids, n, slot, ctx->copy_stream[cs]);
+  // m3t_hip_camera_slot_sync: every camera of the batch waits for this transfer before its host block is written again
+  // (also reached from cameras_upload_batch_roi_async whenever rectangles are not possible)
+  for (int i = 0; i < n; ++i) {
+    Camera& c = *ctx->cameras[ids[i]];
+    if (c.slot_copied.size() < size_t(c.n_slots)) c.slot_copied.resize(size_t(c.n_slots), nullptr);
+    if (!c.slot_copied[slot]) HIPCHK(hipEventCreateWithFlags(&c.slot_copied[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c.slot_copied[slot], ctx->copy_stream[cs]));
+  }
   ctx->copies_pending |= 1u << cs;
   return M3T_OK;
 }
@@ -2310,8 +2342,13 @@ int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context* ctx, const int* ids,
   HIPCHK(hipGetLastError());
   ++ctx->roi_pulls;
   for (int i = 0; i < n; ++i) {
-    ctx->cameras[ids[i]]->has_image[slot] = true;
-    ctx->cameras[ids[i]]->slot_is_roi[slot] = true;
+    Camera& c = *ctx->cameras[ids[i]];
+    c.has_image[slot] = true;
+    c.slot_is_roi[slot] = true;
+    // m3t_hip_camera_slot_sync waits for THIS pull, not for whatever else the copy stream carries by then
+    if (c.slot_copied.size() < size_t(c.n_slots)) c.slot_copied.resize(size_t(c.n_slots), nullptr);
+    if (!c.slot_copied[slot]) HIPCHK(hipEventCreateWithFlags(&c.slot_copied[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c.slot_copied[slot], ctx->copy_stream[cs]));
   }
   {  // where the whole frames are, should a body outrun its rectangle (the repair of the step that reads this slot)
     auto& sources = ctx->roi_sources[size_t(slot)];
@@ -3648,6 +3685,16 @@ int m3t_hip_comm_destroy(m3t_hip_context* ctx) {
   ctx->comm_owned = false;
   return M3T_OK;
 }
+// The host's own transport in the collective's place: fn(user, device buffer, count, hipStream_t) is called wherever
+// ncclAllReduce would be, and has to leave the sum over the host's ranks in the buffer, ordered on that stream (it may
+// synchronise the stream and do the sum on the host).  While it is set the context takes the distributed paths exactly
+// as with a communicator.  NULL takes it out again.
+int m3t_hip_comm_set_reduce_callback(m3t_hip_context* ctx, m3t_hip_reduce_fn fn, void* user) {
+  CHECK_CTX();
+  ctx->reduce_fn = fn;
+  ctx->reduce_user = fn ? user : nullptr;
+  return M3T_OK;
+}
 // sum of the stacked link sums of all structures over the ranks of the communicator: ONE ncclAllReduce on the
 // context's stream, in place (Link::CalculateGradientAndHessian link.cpp:184-193 is the sum being distributed)
 int m3t_hip_calculate_optimization_allreduce(m3t_hip_context* ctx) {
@@ -3758,7 +3805,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   ctx->untracked_launches = untracked_before;  // a whole step is tracked by its step_done event below
   if ((r = CheckSplitExchange(ctx))) return r;  // an earlier step that was abandoned on the device
   bool histogram_fused = false;
-  const bool rigid_fused = ctx->fused_mode >= 1 && ctx->fused_possible && !ctx->comm;
+  const bool rigid_fused = ctx->fused_mode >= 1 && ctx->fused_possible && !ctx->Distributed();
   bool roi_frames = false;  // does this step read a slot that holds a rectangle only
   for (auto& cam : ctx->cameras) roi_frames = roi_frames || cam->slot_is_roi[cam->current];
   REQUIRE(!roi_frames || (rigid_fused && ctx->n_roi_items > 0), M3T_ERR_UNSUPPORTED,
@@ -3911,7 +3958,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     ctx->last_step_shape[2] = threads;
     ctx->last_step_shape[3] = histogram_fused ? 1 : 0;
     ctx->state_valid = ctx->fused_mode == 2;
-  } else if (ctx->fused_mode >= 1 && ctx->fused_per_search_possible && !ctx->comm && !ctx->tree_mode &&
+  } else if (ctx->fused_mode >= 1 && ctx->fused_per_search_possible && !ctx->Distributed() && !ctx->tree_mode &&
              !std::getenv("M3T_HIP_NO_SEARCH_FUSION")) {
     // Renderer-fed branches (modelled occlusions, region / silhouette checking): the focused renderings are redrawn
     // before every correspondence search from the bodies' current poses (correspondence_renderer_ptrs,
@@ -4045,6 +4092,16 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // nothing), then alternately; launch k >= 1 writes the other one.  The last launch (k = n_newton) must leave the
     // joints in the primary table, the one the rest of the library reads: an odd n_newton ends in the second one and
     // is copied over.
+    // FIRST (the links take their bodies' poses) and FINAL (the bodies take their links') meet in one launch only when
+    // the frame has a single Newton step: a workgroup that starts late would then seed from poses a faster one has
+    // already written back, so that launch seeds from a snapshot taken in front of the loop
+    const float* first_poses = ctx->d_poses.as<float>();
+    if (n_newton == 1) {
+      if (ctx->d_poses_first.bytes < ctx->d_poses.bytes) HIPCHK(ctx->d_poses_first.alloc(ctx->d_poses.bytes));
+      HIPCHK(hipMemcpyAsync(ctx->d_poses_first.p, ctx->d_poses.p, ctx->body_poses.size() * 4, hipMemcpyDeviceToDevice,
+                            ctx->stream));
+      first_poses = ctx->d_poses_first.as<float>();
+    }
     for (int k = 0; k <= n_newton; ++k) {
       TreeSegmentParams sp{};
       const int c = k / std::max(ctx->n_update_iterations, 1), u = k % std::max(ctx->n_update_iterations, 1);
@@ -4068,6 +4125,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       sp.opt_iteration = last ? 0 : u;
       sp.sums_in = sums[(k + 1) & 1];  // what launch k - 1 wrote and the all-reduce summed
       sp.sums_out = sums[k & 1];
+      sp.first_poses = first_poses;
       hipLaunchKernelGGL(kernel, dim3(ctx->n_treesteps), dim3(M3T_BLOCK_THREADS), lds, ctx->stream,
                          ctx->d_treesteps.as<TreeStepDev>(), ctx->d_treeopts.as<TreeOptDev>(),
                          ctx->d_region.as<RegionModDev>(), ctx->d_depth.as<DepthModDev>(), ctx->cams_active,

@@ -99,6 +99,8 @@ struct TreeSegmentParams {
   int corr_iteration, opt_iteration;
   const float* sums_in;  // [all links of all structures][42], summed over the ranks
   float* sums_out;       // this rank's link sums of this Newton step (links without local modalities: zero)
+  const float* first_poses;  // TSEG_FIRST: the bodies' poses the frame starts from -- body_poses itself, or (a frame of ONE
+                             // Newton step: FIRST and FINAL in the same launch) a snapshot that launch does not write
 };
 
 namespace {
@@ -1815,7 +1817,7 @@ __device__ __forceinline__ void tree_segment_body(const TreeStepDev* steps, cons
   if (flags & TSEG_FIRST) {
     for (int i = tid; i < n_links * 16; i += nt) {  // a link with a body stands where its body stands (link.cpp:296-301)
       const int li = i >> 4;
-      if (links[li].body >= 0) links[li].link2world[i & 15] = body_poses[16 * links[li].body + (i & 15)];
+      if (links[li].body >= 0) links[li].link2world[i & 15] = sp.first_poses[16 * links[li].body + (i & 15)];
     }
   }
   tree_tables(o, links, w);

@@ -67,3 +67,86 @@ def place_bodies(n_bodies, world_size, shared_histograms=()):
         if g is not None:
             group_rank[g] = rank_of[b]
     return rank_of
+
+
+class ThreadRanks:
+    """N contexts of ONE process playing the ranks of a kinematic structure spread over GPUs, one host
+    thread per context, the collective supplied through m3t_hip_comm_set_reduce_callback: where a rank would call
+    ncclAllReduce, its thread synchronises its stream, copies its link sums to the host, meets the others at a barrier,
+    adds all of them in `order` (any order: every link's modalities live on one rank, the others add +0.0, the sum is
+    exact) and writes the total back to its device buffer.  The contexts may sit on one GPU (tests, the `--rank-share`
+    measurements of bench_chain.py -- the distributed step has no launch whose workgroups wait for each other) or on
+    one GPU each (a one-process multi-GPU host without RCCL).  Plain HIP runtime calls through ctypes: no torch."""
+
+    def __init__(self, contexts, order=None):
+        import ctypes as C
+        import threading
+        from ._capi import REDUCE_FN
+        self.C = C
+        self.contexts = list(contexts)
+        self.n = len(self.contexts)
+        self.order = list(order) if order is not None else list(reversed(range(self.n)))
+        assert sorted(self.order) == list(range(self.n))
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.barrier = threading.Barrier(self.n)
+        self.parts = [None] * self.n
+        self.calls = [0] * self.n
+        self.errors = []
+        self._keep = []
+        for rank, ctx in enumerate(self.contexts):
+            fn = REDUCE_FN(self._make(rank))
+            self._keep.append(fn)
+            ctx.call("comm_set_reduce_callback", C.cast(fn, C.c_void_p), None)
+
+    def _make(self, rank):
+        C, hip = self.C, self.hip
+
+        def reduce(user, buffer, count, stream):
+            try:
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return 1
+                part = np.empty(count, np.float32)
+                if hip.hipMemcpy(part.ctypes.data_as(C.c_void_p), buffer, count * 4, 2) != 0:  # hipMemcpyDeviceToHost
+                    return 2
+                self.parts[rank] = part
+                self.barrier.wait(timeout=60)
+                total = self.parts[self.order[0]].copy()
+                for r in self.order[1:]:
+                    total += self.parts[r]
+                self.barrier.wait(timeout=60)  # (everybody has read the parts before anybody's next call replaces one)
+                if hip.hipMemcpy(buffer, total.ctypes.data_as(C.c_void_p), count * 4, 1) != 0:  # hipMemcpyHostToDevice
+                    return 3
+                self.calls[rank] += 1
+                return 0
+            except Exception as e:  # (a broken barrier, ...: the step fails with M3T_ERR_DEVICE)
+                self.errors.append((rank, repr(e)))
+                return 4
+        return reduce
+
+    def run(self, fn):
+        """fn(rank, context) on one thread per rank, in lock-step wherever the contexts reduce; returns the results"""
+        import threading
+        out, failures = [None] * self.n, []
+
+        def work(rank):
+            try:
+                out[rank] = fn(rank, self.contexts[rank])
+            except BaseException as e:
+                failures.append((rank, e))
+                self.barrier.abort()
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(self.n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if failures:
+            self.barrier.reset()
+            raise failures[0][1]
+        return out
+
+    def close(self):
+        for ctx in self.contexts:
+            ctx.call("comm_set_reduce_callback", None, None)
+        self._keep = []

@@ -33,6 +33,15 @@
 extern "C" {
 #endif
 
+/* The entry points below are the ONLY dynamic symbols of libm3t_hip.so: the library is built with -fvisibility=hidden
+ * and everything declared between this push and the pop at the end of the header has default visibility (the
+ * library's own C++ -- std:: instantiations, kernel launch stubs -- stays private, so that two libraries carrying the
+ * same inline C++ in one process cannot interpose each other; tests/test_abi_symbols.py checks `nm -D`). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#define M3T_HIP_VISIBILITY_PUSHED 1
+#endif
+
 typedef struct m3t_hip_context m3t_hip_context;
 
 /* ---- context ------------------------------------------------------------- */
@@ -117,8 +126,10 @@ int m3t_hip_cameras_set_ring(m3t_hip_context*, const int* camera_ids, int n_came
 int m3t_hip_cameras_upload_batch_async(m3t_hip_context*, const int* camera_ids, int n_cameras, int slot, const void* base,
                                        size_t camera_stride, size_t row_step);
 int m3t_hip_ingest_sync(m3t_hip_context*); /* wait until all enqueued frame copies have landed */
-/* wait until the last camera_upload_slot_async into (camera, slot) has left its host buffer, and for nothing else: a
- * loader that recycles one camera's page-locked buffers does not hold up the copies of the other cameras */
+/* wait until the last upload into (camera, slot) -- camera_upload_slot_async, a batch upload this camera was part of,
+ * a rectangle pull -- has left its host buffer, and for nothing else: a loader that recycles one camera's page-locked
+ * buffers does not hold up the copies of the other cameras.  A slot that holds a rectangle also waits for the step
+ * that read it: should a body have outrun its rectangle, that step's repair reads the host block once more. */
 int m3t_hip_camera_slot_sync(m3t_hip_context*, int camera_id, int slot);
 /* ROI ingest: only the part of a frame the trackers can read crosses PCIe.  set_roi_ingest(enable, margin_px) switches
  * it on for the fused step of rigid objects; cameras_upload_batch_roi_async is cameras_upload_batch_async for
@@ -295,6 +306,16 @@ int m3t_hip_comm_init_rank(m3t_hip_context*, const void* id, size_t id_bytes, in
 int m3t_hip_comm_set(m3t_hip_context*, void* nccl_comm /* ncclComm_t or NULL */);
 int m3t_hip_comm_destroy(m3t_hip_context*);
 int m3t_hip_calculate_optimization_allreduce(m3t_hip_context*);
+/* The host's own transport in the collective's place (MPI, gloo, shared memory between threads, a test harness that
+ * plays several ranks on one GPU): fn is called wherever the library would call ncclAllReduce -- once per Newton step,
+ * with the DEVICE buffer of begin() / of the fused distributed step, its length in floats and the context's
+ * hipStream_t -- and has to leave the sum over the host's ranks in that buffer, ordered on that stream (it may
+ * synchronise the stream and add on the host).  Non-zero return = failure: the step returns M3T_ERR_DEVICE.  While a
+ * callback is set the context takes the distributed paths exactly as with a communicator (comm_get_allreduce_count
+ * counts the calls; comm_get_rank_count stays 0: the library does not know the host's world).  NULL removes it.
+ * Replaces nothing in the reference (optimizer.cpp:309-321 sums in one process); the seam next to comm_set. */
+typedef int (*m3t_hip_reduce_fn)(void* user, float* device_buffer, size_t count, void* hip_stream);
+int m3t_hip_comm_set_reduce_callback(m3t_hip_context*, m3t_hip_reduce_fn fn, void* user);
 /* number of ncclAllReduce calls the context has issued so far (one per Newton step of a tracking step while a
  * communicator is set: the observable a host or a test checks the distributed path with) */
 int m3t_hip_comm_get_allreduce_count(m3t_hip_context*, long long* count);
@@ -353,6 +374,11 @@ int m3t_hip_get_kernel_timing(m3t_hip_context*, float total_ms[2], int launches[
  * tracking_step_split_kernel when the batch leaves CUs idle), [2] threads per workgroup,
  * [3] 1 if the histogram update ran inside the same launch; zeros before the first fused step */
 int m3t_hip_get_step_shape(m3t_hip_context*, int shape[4]);
+
+#ifdef M3T_HIP_VISIBILITY_PUSHED
+#pragma GCC visibility pop
+#undef M3T_HIP_VISIBILITY_PUSHED
+#endif
 
 #ifdef __cplusplus
 }

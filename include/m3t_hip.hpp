@@ -525,6 +525,11 @@ class Tracker {
   }
   void CommSet(void* nccl_comm) { c_->Check(m3t_hip_comm_set(c_->get(), nccl_comm), "Tracker"); }
   void CommDestroy() { c_->Check(m3t_hip_comm_destroy(c_->get()), "Tracker"); }
+  // the host's own transport in ncclAllReduce's place (MPI, gloo, threads that play ranks): fn sums the device buffer
+  // over the host's ranks, in stream order; nullptr removes it
+  void CommSetReduceCallback(m3t_hip_reduce_fn fn, void* user) {
+    c_->Check(m3t_hip_comm_set_reduce_callback(c_->get(), fn, user), "Tracker");
+  }
   bool CalculateOptimizationAllReduce() { return c_->Step(m3t_hip_calculate_optimization_allreduce(c_->get())); }
   void* stream() const {
     void* s = nullptr;

@@ -28,6 +28,15 @@ def test_hip_library_exports_every_declared_symbol():
     assert "m3t_hip_execute_tracking_step" in names and "m3t_hip_execute_tracking_cycle" in names
 
 
+def test_hip_library_exports_nothing_but_the_declared_symbols():
+    """the dynamic symbol table of libm3t_hip.so is the C-ABI and nothing else (-fvisibility=hidden + the version script
+    csrc/libm3t_hip.map): no kernel launch stubs, no std:: instantiations that another library's copy could interpose"""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", util.pkg.LIB_PATH], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _declared("include/m3t_hip.h", "m3t_hip_"), sorted(set(exported) ^ set(_declared("include/m3t_hip.h", "m3t_hip_")))
+
+
 def test_oracle_library_exports_every_declared_symbol():
     names = _declared("oracle/m3t_oracle.h", "m3t_oracle_")
     lib = ctypes.CDLL(util.build_oracle())
