@@ -1,8 +1,8 @@
 // m3t_renderer_read.h -- what the modalities read from a focused rendering (region_modality.cpp:1157-1229, 1293-1341,
 // 1391-1431; depth_modality.cpp:778-824), free of device-only constructs so that tests/cpp/renderer_read_check.cpp
-// can run both forms on the host:
-//   *_reference  the loops as the reference writes them: one sample, one decision, next sample
-//   (no suffix)  what the kernels call: all samples a loop can touch are requested first (independent, predicated
+// can run them on the host beside the loops as the reference writes them (one sample, one decision, next sample:
+// tests/cpp/renderer_read_reference.h, test infrastructure):
+//   what the kernels call: all samples a loop can touch are requested first (independent, predicated
 //                loads: one memory round trip instead of up to 36 in a row), then the reference's decisions are taken
 //                in the reference's order on the loaded values.  Same samples, same comparisons, same result.
 // Pointer types are template parameters (the kernels pass address-space-1 pointers).
@@ -49,18 +49,6 @@ M3T_READ_FN ModeledWindow modeled_window(const FocusedCrop& c, float center_u, f
   w.u_max = w.u_max < size_minus_1 ? w.u_max : size_minus_1;
   w.v_max = w.v_max < size_minus_1 ? w.v_max : size_minus_1;
   return w;
-}
-template <typename DepthPtr>
-M3T_READ_FN unsigned short modeled_window_min_reference(DepthPtr depth_image, const FocusedCrop& c, float center_u,
-                                                        float center_v, float diameter) {
-  const ModeledWindow w = modeled_window(c, center_u, center_v, diameter);
-  unsigned short min_value = 65535;
-  for (int v = w.v_min; v <= w.v_max; v += w.stride)
-    for (int u = w.u_min; u <= w.u_max; u += w.stride) {
-      unsigned short d = depth_image[(size_t)v * c.image_size + u];
-      min_value = d < min_value ? d : min_value;
-    }
-  return min_value;
 }
 // the window spans at most M3T_MAX_N_OCCLUSION_STRIDES strides (stride > diameter / 5, so diameter / stride + 0.5
 // truncates to at most 5): at most 6 samples per row and column, before and after the clamps
@@ -114,37 +102,6 @@ M3T_READ_FN void silhouette_run(IdPtr silhouette_image, int image_size, float u,
 // ---- IsDynamicLineRegionSufficient :1293-1341 (an off-image coordinate in the foreground loop, which the reference
 // reads unchecked, counts as another region)
 template <typename IdPtr>
-M3T_READ_FN bool dynamic_line_region_sufficient_reference(IdPtr silhouette_image, const FocusedCrop& c, int region_id,
-                                                          float min_continuous_distance, float fscale, float center_u,
-                                                          float center_v, float normal_u, float normal_v) {
-  const float scale = c.scale;
-  float focused_min_continuous_distance = min_continuous_distance * fscale * scale;
-  float focused_stride = fmaxf((focused_min_continuous_distance - M3T_REGION_OFFSET) / (float)M3T_N_REGION_STRIDE, 0.0f);
-  float stride_u = focused_stride * normal_u;
-  float stride_v = focused_stride * normal_v;
-  float offset_u = M3T_REGION_OFFSET * normal_u;
-  float offset_v = M3T_REGION_OFFSET * normal_v;
-  float focused_center_u = 0.5f + (center_u - c.corner_u) * scale;
-  float focused_center_v = 0.5f + (center_v - c.corner_v) * scale;
-  float u = focused_center_u - offset_u;
-  float v = focused_center_v - offset_v;
-  for (int i = 0; i <= M3T_N_REGION_STRIDE; ++i) {
-    if (silhouette_at(silhouette_image, c.image_size, u, v) != region_id) return false;
-    u -= stride_u;
-    v -= stride_v;
-  }
-  u = focused_center_u + offset_u;
-  v = focused_center_v + offset_v;
-  for (int i = 0; i <= M3T_N_REGION_STRIDE; ++i) {
-    int id = silhouette_at(silhouette_image, c.image_size, u, v);
-    if (id < 0) break;
-    if (id == region_id) return false;
-    u += stride_u;
-    v += stride_v;
-  }
-  return true;
-}
-template <typename IdPtr>
 M3T_READ_FN bool dynamic_line_region_sufficient(IdPtr silhouette_image, const FocusedCrop& c, int region_id,
                                                 float min_continuous_distance, float fscale, float center_u,
                                                 float center_v, float normal_u, float normal_v) {
@@ -176,57 +133,6 @@ M3T_READ_FN bool dynamic_line_region_sufficient(IdPtr silhouette_image, const Fo
 }
 
 // ---- DynamicRegionDistance :1157-1229 (with the assignment to the *foreground* distance in the background loop)
-template <typename IdPtr>
-M3T_READ_FN void dynamic_region_distance_reference(IdPtr silhouette_image, const FocusedCrop& c, int region_id,
-                                                   float max_considered_line_length, float unconsidered_line_length,
-                                                   float center_u, float center_v, float normal_u, float normal_v,
-                                                   float* foreground, float* background) {
-  const float scale = c.scale;
-  float stride = max_considered_line_length / (float)M3T_N_REGION_STRIDE;
-  float focused_stride = stride * scale;
-  float focused_stride_u = focused_stride * normal_u;
-  float focused_stride_v = focused_stride * normal_v;
-  float delta_start = M3T_REGION_OFFSET / scale - unconsidered_line_length;
-  int i_start = m3t_read_f2i(delta_start / stride + 1.0f);
-  i_start = i_start > 0 ? i_start : 0;
-  float offset = unconsidered_line_length + (float)i_start * stride;
-  float focused_offset = offset * scale;
-  float focused_offset_u = focused_offset * normal_u;
-  float focused_offset_v = focused_offset * normal_v;
-  float focused_center_u = 0.5f + (center_u - c.corner_u) * scale;
-  float focused_center_v = 0.5f + (center_v - c.corner_v) * scale;
-  float u = focused_center_u - focused_offset_u;
-  float v = focused_center_v - focused_offset_v;
-  for (int i = i_start; i <= M3T_N_REGION_STRIDE; ++i) {
-    int id = silhouette_at(silhouette_image, c.image_size, u, v);
-    if (id < 0) {
-      *foreground = stride * (float)i;
-      break;
-    }
-    if (id != region_id) {
-      *foreground = i == i_start ? 0.0f : stride * (float)i;
-      break;
-    }
-    u -= focused_stride_u;
-    v -= focused_stride_v;
-  }
-  u = focused_center_u + focused_offset_u;
-  v = focused_center_v + focused_offset_v;
-  for (int i = i_start; i <= M3T_N_REGION_STRIDE; ++i) {
-    int id = silhouette_at(silhouette_image, c.image_size, u, v);
-    if (id < 0) {
-      *background = max_considered_line_length;
-      break;
-    }
-    if (id == region_id) {
-      if (i == i_start) *background = 0.0f;
-      else *foreground = stride * (float)i;
-      break;
-    }
-    u += focused_stride_u;
-    v += focused_stride_v;
-  }
-}
 template <typename IdPtr>
 M3T_READ_FN void dynamic_region_distance(IdPtr silhouette_image, const FocusedCrop& c, int region_id,
                                          float max_considered_line_length, float unconsidered_line_length, float center_u,

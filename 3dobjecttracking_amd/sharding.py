@@ -150,3 +150,42 @@ class ThreadRanks:
         for ctx in self.contexts:
             ctx.call("comm_set_reduce_callback", None, None)
         self._keep = []
+
+
+class HostReduce:
+    """m3t_hip_comm_set_reduce_callback with torch.distributed as the transport: the link sums of a rank go to the host,
+    `dist.all_reduce(SUM)` adds them over the process group (gloo: works between processes that share one GPU, where
+    RCCL refuses a second rank on the same device; MPI-style hosts do the same with their own call) and the total goes
+    back to the device buffer.  What the library's own ncclAllReduce does in one call on the stream, done the slow way:
+    for dry runs and for hosts without RCCL, not for speed."""
+
+    def __init__(self, ctx, dist):
+        import ctypes as C
+        import torch
+        from ._capi import REDUCE_FN
+        self.ctx, self.calls = ctx, 0
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.error = None
+
+        def reduce(user, buffer, count, stream):
+            try:
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return 1
+                part = torch.empty(count, dtype=torch.float32)
+                if hip.hipMemcpy(part.data_ptr(), buffer, count * 4, 2) != 0:  # hipMemcpyDeviceToHost
+                    return 2
+                dist.all_reduce(part, op=dist.ReduceOp.SUM)
+                if hip.hipMemcpy(buffer, part.data_ptr(), count * 4, 1) != 0:  # hipMemcpyHostToDevice
+                    return 3
+                self.calls += 1
+                return 0
+            except Exception as e:  # noqa: BLE001 (reported through the step's error code)
+                self.error = repr(e)
+                return 4
+        self._fn = REDUCE_FN(reduce)
+        ctx.call("comm_set_reduce_callback", C.cast(self._fn, C.c_void_p), None)
+
+    def close(self):
+        self.ctx.call("comm_set_reduce_callback", None, None)

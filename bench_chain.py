@@ -136,10 +136,78 @@ def rank_share_chain(args, pkg, scenes, syn, host, inputs, joints, start_root, s
     return {"what": "PROJECTION, not a measurement of N GPUs: the distributed path of rank 0 (modalities of the bodies "
                     "i mod N == 0 only, whole link tree) timed alone on ONE GPU with the library's communicator at world "
                     "size 1; the all-reduce's transport latency over xGMI (14 per step) is NOT in it",
-            "steps": K, "warmup": W, "regions": regions, "points": points}
+            "steps": K, "warmup": W, "regions": regions, "points": points,
+            "thread_ranks": thread_ranks_chain(pkg, syn, host, inputs, joints, start_root, start_angles, n_bodies, local_rank,
+                                               [n for n in counts if n > 1], K, W)}
 
 
-def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_traffic=None):
+def thread_ranks_chain(pkg, syn, host, inputs, joints, start_root, start_angles, n_bodies, device, counts, K, W):
+    """The N-rank step with REAL partial sums on one GPU: N contexts, one host thread each, body i's modality in context
+    i mod N, the link sums added through m3t_hip_comm_set_reduce_callback (sharding.ThreadRanks).  Every context takes
+    tracking_step_tree_segment_kernel with its own bodies only and must end on the poses of one context that owns the
+    whole chain (the one-launch step), bit for bit.  The time is N contexts sharing ONE GPU plus a host-side sum per
+    Newton step (stream sync, two copies, two thread barriers): an upper bound of the code path, not of N GPUs."""
+    n_frames = K + W + 1
+
+    def stage(ctx, ch):
+        for i in ch.owned:
+            ctx.call("camera_set_ring", ch.cams[i].id, n_frames)
+            for k in range(n_frames):
+                f = inputs.color[i][k]
+                ctx.call("camera_upload_slot", ch.cams[i].id, k, f.ctypes.data_as(C.c_void_p), f.strides[0])
+
+    def steps(ctx, first, count):
+        for k in range(first, first + count):
+            ctx.call("cameras_select_slot", k)
+            ctx.call("execute_tracking_step", k)
+
+    one = pkg.open_context(device)
+    ch1 = Chain(one, host, syn, inputs, joints, start_root, start_angles, range(n_bodies))
+    stage(one, ch1)
+    one.call("cameras_select_slot", 0)
+    one.call("start_modalities", 0)
+    steps(one, 1, W + K)
+    expected = ch1.poses()
+    del ch1, one
+    out = []
+    for n in counts:
+        placed = pkg.sharding.place_bodies(n_bodies, n)
+        ctxs = [pkg.open_context(device) for _ in range(n)]
+        chains = [Chain(ctxs[r], host, syn, inputs, joints, start_root, start_angles, [i for i, p in enumerate(placed) if p == r])
+                  for r in range(n)]
+        ranks = pkg.sharding.ThreadRanks(ctxs)
+        elapsed = [0.0] * n
+
+        def work(rank, ctx):
+            stage(ctx, chains[rank])
+            ctx.call("cameras_select_slot", 0)
+            ctx.call("start_modalities", 0)
+            steps(ctx, 1, W)
+            ctx.call("sync")
+            t = time.perf_counter()
+            steps(ctx, 1 + W, K)
+            ctx.call("sync")
+            elapsed[rank] = time.perf_counter() - t
+            return chains[rank].poses()
+
+        poses = ranks.run(work)
+        kernels, calls = [], []
+        for ctx in ctxs:
+            name, c = C.create_string_buffer(96), C.c_longlong(0)
+            ctx.call("get_step_kernel", name, 96)
+            ctx.call("comm_get_allreduce_count", C.byref(c))
+            kernels.append(name.value.decode())
+            calls.append(round(c.value / (W + K), 2))
+        ranks.close()
+        out.append({"n_ranks": n, "bodies_per_rank": [len(ch.owned) for ch in chains],
+                    "kernel": sorted(set(kernels)), "reductions_per_step": sorted(set(calls)),
+                    "bit_identical_to_one_context_owning_the_chain": bool(all(np.array_equal(p, expected) for p in poses)),
+                    "ms_per_step_all_ranks_sharing_one_gpu_host_summed": round(max(elapsed) / K * 1e3, 4)})
+        del chains, ctxs
+    return out
+
+
+def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_traffic=None, dry_run=False):
     import bench_inputs as scenes
     syn, host = pkg.synthetic, pkg.host
     n_bodies, K, W = args.objects or 8, args.steps, args.warmup
@@ -152,7 +220,10 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
     hip = pkg.open_context(local_rank)
     owned = [i for i, r in enumerate(pkg.sharding.place_bodies(n_bodies, world)) if r == rank]
     ch = Chain(hip, host, syn, inputs, joints, start_root, start_angles, owned)
-    if world > 1:  # the library's own RCCL communicator: rank 0 creates the id, torch.distributed carries it
+    host_reduce = None
+    if world > 1 and dry_run:  # all ranks on one GPU: the collective through the reduce seam, gloo as the transport
+        host_reduce = pkg.sharding.HostReduce(hip, dist)
+    elif world > 1:  # the library's own RCCL communicator: rank 0 creates the id, torch.distributed carries it
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             buf = C.create_string_buffer(128)
@@ -301,6 +372,8 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
     name = C.create_string_buffer(64)
     hip.call("get_step_kernel", name, 64)
     kernel = name.value.decode()
+    shape = (C.c_int * 4)()
+    hip.call("get_step_shape", shape)
     fused = kernel in ("tracking_step_tree_kernel", "tracking_step_tree_split_kernel")
     traffic, traffic_src = (measured_traffic("chain8", kernel, n_bodies, True) if (measured_traffic and fused) else (None, None))
     return {
@@ -312,11 +385,13 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
                                "RegionModality per body (RBOT parameters, 200 lines x 7 x 2); %s; body i on GPU i mod %d, "
                                "ONE ncclAllReduce of %d floats (the link sums) per Newton step%s" %
                                (n_bodies, n_bodies - 1,
-                                "one launch per frame, one workgroup per body, the structure solved by every workgroup's "
-                                "first wave" if fused else "one launch per sub-step, link kernels: one wave per structure",
+                                "one launch per frame, %d workgroup(s) of %d threads per body, the structure solved by every "
+                                "workgroup's first wave" % (shape[1], shape[2]) if fused else
+                                ("one launch of tracking_step_tree_segment_kernel and one reduction of the link sums per Newton "
+                                 "step" if "segment" in kernel else "one launch per sub-step, link kernels: one wave per structure"),
                                 world, 42 * n_bodies, "" if world > 1 else " when N > 1"),
                    "bodies": n_bodies, "parallelism": "bodies sharded over %d GPU(s)" % world,
-                   "rccl_ranks": rccl_ranks,
+                   "rccl_ranks": rccl_ranks, "step_kernel": kernel,
                    "allreduce_calls_per_step": round(collectives.value / steps_run, 3),
                    "max_rotation_error_vs_ground_truth_rad": round(float(max(e[0] for e in gt_err)), 5),
                    "setup_s": round(setup_s, 1)},

@@ -7,7 +7,7 @@
 #include <random>
 #include <vector>
 
-#include "../../3dobjecttracking_amd/csrc/m3t_renderer_read.h"
+#include "renderer_read_reference.h"
 
 int main(int argc, char** argv) {
   const int n = argc > 1 ? std::atoi(argv[1]) : 2000000;

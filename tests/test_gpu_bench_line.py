@@ -49,3 +49,24 @@ def test_two_rank_code_path_dry_run_on_one_gpu():
     assert line["roofline"]["workgroups_per_object"] == 1
     # weak scaling: value = the objects of both ranks over the slower rank's time
     assert abs(line["value"] - 2 * 8 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 0.01
+
+
+def test_chain_two_rank_code_path_dry_run_on_one_gpu():
+    """`bench.py --config chain8 --gpus 2` on a one-GPU box: both ranks on device 0, body i's modality on rank i mod 2,
+    the link sums summed over gloo through m3t_hip_comm_set_reduce_callback (RCCL refuses two ranks on one device).
+    Launcher, placement, the segment kernel with partial ownership, 14 reductions per step, rank 0's parity check
+    against the oracle's single process: everything of the 8-GPU chain leg but the transport."""
+    env = dict(os.environ, M3T_BENCH_SHARE_ONE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--config", "chain8", "--gpus", "2",
+                          "--steps", "3", "--warmup", "1", "--repeats", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=util.ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "dry_run" in line and line["metric"].startswith("[DRY RUN")
+    assert line["parity"]["bit_identical"] is True and line["parity"]["n"] == 8
+    assert line["config"]["rccl_ranks"] == 0  # (no RCCL communicator: the host's transport)
+    assert line["config"]["allreduce_calls_per_step"] == 14.0
+    assert line["roofline"]["kernel"].startswith("whole step")  # not the one-launch kernel
+    assert line["config"]["step_kernel"] == "tracking_step_tree_segment_kernel"

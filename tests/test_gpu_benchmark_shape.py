@@ -24,7 +24,9 @@ def shape_of(api):
 
 @pytest.fixture(scope="module")
 def rbot64():
-    return scenes.Inputs(64, 6, n_divides=4, n_models=8)  # bench.py: scenes.Inputs(n_obj, n_frames, 4, n_models=8)
+    # bench.py --config rbot64: scenes.Inputs(64, n_frames, n_divides=4, n_models=CONFIGS["rbot64"]["models"]) -- 18 models
+    import bench
+    return scenes.Inputs(64, 6, n_divides=4, n_models=bench.CONFIGS["rbot64"]["models"])
 
 
 def oracle_trajectory(inputs, use_depth=False):
