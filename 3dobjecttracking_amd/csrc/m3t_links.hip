@@ -13,6 +13,8 @@
 //   links_solve_kernel   : constraint rows, Tikhonov, pivoted LDL^T, NaN guard, pose update
 // Arithmetic mirrors the CPU restatement operation for operation.
 
+#include "m3t_exact_math.h"  // atan2f / tanf / tan of the constraint code, the implementation the oracle includes too
+
 #define M3T_MAX_LINK_MODALITIES 4
 
 struct LinkDev {
@@ -166,7 +168,7 @@ __device__ void angle_axis(const float* m /*3x3 col-major*/, float* angle, float
   }
   float n = sqrtf((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
   if (n != 0.0f) {
-    *angle = 2.0f * atan2f(n, fabsf(q[3]));
+    *angle = 2.0f * m3t_atan2f_pos(n, fabsf(q[3]));  // (the f32 nearest to the f64 value: m3t_exact_math.h, shared with the oracle)
     if (q[3] < 0.0f) n = -n;
     for (int c = 0; c < 3; ++c) axis[c] = q[c] / n;
   } else {
@@ -175,11 +177,7 @@ __device__ void angle_axis(const float* m /*3x3 col-major*/, float* angle, float
   }
 }
 
-__device__ float xcotx_dev(float x) {  // common.h:73-77
-  if (tanf(x) <= 1.17549435e-38f) return 1.0f;
-  if (tanf(x) >= 3.40282347e+38f) return 0.0f;
-  return (float)((double)x / tan((double)x));
-}
+__device__ float xcotx_dev(float x) { return m3t_xcotx(x); }  // common.h:73-77 (m3t_exact_math.h)
 
 // Constraint::UnprojectedConstraintJacobian constraint.cpp:211-274 -> jac [n x 6] column-major
 __device__ void constraint_unprojected_jacobian(const ConstraintDev& c, const Affine& joint22joint1,

@@ -273,7 +273,8 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if dry_run:
-            dist.init_process_group("gloo")
+            import datetime
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))  # (a mismatched collective fails, not hangs)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         # N ranks build their inputs (rendering, model sampling: numpy) side by side on one host: every rank keeps to

@@ -265,14 +265,17 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
         if first_poses is None:
             first_poses = ch.poses()
     elapsed = float(np.median(times))
-    if rank != 0:
-        return None
-    # roofline leg: ONE HIP event pair on the context's stream around the K launches of one more region
+    # roofline leg: ONE HIP event pair on the context's stream around the K launches of one more region.  EVERY rank
+    # runs these steps: at N > 1 each of them reduces 14 times per step, and a rank that had already left for the final
+    # barrier would leave rank 0 waiting in its first all-reduce for ever (found by the two-rank dry run of round 6)
     ms, cnt = (C.c_float * 2)(), (C.c_int * 2)()
     hip.call("set_kernel_timing", 2)
     run_steps(1 + W, K)
     hip.call("get_kernel_timing", ms, cnt)
     hip.call("set_kernel_timing", 0)
+    barrier()
+    if rank != 0:
+        return None
     kernel_ms = float(ms[0]) / max(int(cnt[0]), 1) if cnt[0] else None
     # ---- CPU restatement of the same chain (all bodies in one process) + parity of the first timed trajectory ----
     cpu, parity = None, None
@@ -368,7 +371,7 @@ def run(args, pkg, rank, local_rank, world, dist, torch, open_oracle, measured_t
         if (getattr(args, "rank_share", "") and world == 1) else None
     collectives = C.c_longlong(0)  # ncclAllReduce calls this rank's context issued (start to here: W + repeats x K steps)
     hip.call("comm_get_allreduce_count", C.byref(collectives))
-    steps_run = W + max(1, args.repeats) * K
+    steps_run = W + max(1, args.repeats) * K + K  # (+ the roofline leg's region)
     name = C.create_string_buffer(64)
     hip.call("get_step_kernel", name, 64)
     kernel = name.value.decode()

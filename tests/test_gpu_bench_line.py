@@ -59,7 +59,7 @@ def test_chain_two_rank_code_path_dry_run_on_one_gpu():
     env = dict(os.environ, M3T_BENCH_SHARE_ONE_GPU="1")
     out = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--config", "chain8", "--gpus", "2",
                           "--steps", "3", "--warmup", "1", "--repeats", "1"],
-                         capture_output=True, text=True, timeout=900, cwd=util.ROOT, env=env)
+                         capture_output=True, text=True, timeout=600, cwd=util.ROOT, env=env)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1

@@ -21,9 +21,9 @@ def test_constraint_convergence_on_device(seed):
     errs_h, poses_h = run_convergence(util.open_hip(), seed)
     errs_o, poses_o = run_convergence(util.open_oracle(), seed)
     assert errs_h[-1][0] < 2e-5 and errs_h[-1][1] < 2e-5
-    for ph, po in zip(poses_h, poses_o):  # atan2f / tan differ in the last bit between libm and ocml
+    for ph, po in zip(poses_h, poses_o):  # atan2f / tanf / tan through csrc/m3t_exact_math.h on both sides (round 6)
         for a, b in zip(ph, po):
-            assert np.max(np.abs(a - b)) < 2e-5
+            assert np.array_equal(a, b)
 
 
 @gpu
@@ -37,7 +37,7 @@ def test_soft_constraints_on_device(kw):
     assert errs_h[-1][0] < errs_h[0][0]
     for ph, po in zip(poses_h, poses_o):
         for a, b in zip(ph, po):
-            assert np.max(np.abs(a - b)) < 2e-5
+            assert np.array_equal(a, b)
 
 
 class Chain:
@@ -585,8 +585,8 @@ def test_object_split_off_keeps_the_tree_kernel_out():
 def test_closed_chain_with_a_hard_constraint_matches_the_oracle():
     """A -- revolute -- B -- revolute -- C with a Constraint (constraint.cpp:81-102, translation directions) that ties
     a point of C back to A: a closed kinematic loop, three RegionModalities.  The constraint rows make the system an
-    indefinite KKT matrix; atan2f / tan of the constraint Jacobians differ in the last bit between ocml and glibc, so
-    the stated tolerance is 2e-5 (everywhere else it is zero)."""
+    indefinite KKT matrix.  atan2f / tanf / tan of the constraint Jacobians are one IEEE-only implementation on both
+    sides since round 6 (csrc/m3t_exact_math.h; rounds 2-5 stated 2e-5 here): the tolerance is zero, as everywhere."""
     inputs = scenes.Inputs(3, 1, n_divides=2)
     rng = np.random.default_rng(3)
     j1 = syn.make_pose(syn.rot_vec([0.2, -0.1, 0.3]), [0.05, 0.01, 0.0])
@@ -649,9 +649,9 @@ def test_closed_chain_with_a_hard_constraint_matches_the_oracle():
         assert np.max(np.abs(gap)) < 1e-4
         if name == "hip_comm":
             api.call("comm_destroy")
-    for sh, so in zip(states["hip"], states["oracle"]):
+    for sh, so in zip(states["hip"], states["oracle"]):  # no tolerance (round 6: atan2f / tan shared with the oracle)
         for x, y in zip(sh, so):
-            assert np.max(np.abs(x - y)) < 2e-5
-    for sh, sc in zip(states["hip"], states["hip_comm"]):  # same device arithmetic on both paths: no tolerance
+            assert np.array_equal(x, y)
+    for sh, sc in zip(states["hip"], states["hip_comm"]):  # same device arithmetic on both paths
         for x, y in zip(sh, sc):
             assert np.array_equal(x, y)
