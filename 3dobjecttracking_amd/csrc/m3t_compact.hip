@@ -26,15 +26,41 @@ static_assert(kCMiscGhD + 42 <= M3T_COMPACT_MISC_FLOATS, "misc block too small")
 
 // One correspondence line, walked by one thread.  dist0 = &state[CS_DIST0 * nl + line]: receives the 12 raw
 // distribution products (CalculateDistribution before its normalisation).
-template <int SCALE>
+// The pair table of a 32-bin histogram is 256 KB: every sample of the walk is a dependent 8-byte gather from L2
+// (98.8 k requests per object-frame: with the pixel loads they keep the texture-address units 66 % busy,
+// profiles/r05_pmc_rbot4096.json).  But a pair takes one of three constants for almost every bin -- (0.5, 0.5) for a
+// bin neither histogram holds (region_modality.cpp:1594-1597), (1, 0) / (0, 1) for a bin only one of them holds
+// (x / (x + 0) == 1 exactly) -- and only the bins BOTH hold (a few hundred of 32 768) need their two floats.  So the
+// table is kept in LDS as two bits per bin plus the pairs of the mixed bins in bin order:
+//   word w: a = bits of the bins whose pair is not (0.5, 0.5) / (0, 1), b = ... not (0.5, 0.5) / (1, 0); a & b = mixed
+//   rank[w] = number of mixed bins in front of word w;  pairs[rank] = the pair as the blend stored it
+// classified from the stored PAIR (not from the histograms), so the value a lookup returns is the table's value bit for
+// bit whatever produced it.  A mixed bin whose rank does not fit the LDS budget is read from the global table.
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+struct CompactTable {  // (address-space-3 pointers: ds_read, not flat loads)
+  const __attribute__((address_space(3))) v2u* ab;
+  const __attribute__((address_space(3))) uint16_t* rank;  // 3 + the number of mixed bins in front of the word
+  const __attribute__((address_space(3))) v2f* pairs;
+  int cap;
+};
+
+template <int SCALE, bool TABLE = false>
 __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G<v2f> hist, int bitshift, int bin_bits,
                                              int start, float step, float x0, bool horiz, bool reversed,
-                                             const float (&lf)[8], const float (&lb)[8], float* dist0, int nl) {
+                                             const float (&lf)[8], const float (&lb)[8], float* dist0, int nl,
+                                             const CompactTable* table = nullptr) {
   // segments per batch: all pixel loads of a batch are issued before the first histogram gather
   // 8 - 20 pixel loads in flight per lane: measured best.  (Smaller batches, and smaller batches with the next
   // batch's pixels requested before the current one is worked on, were both slower: 2.02 / 1.99 vs 1.95 ms per
   // 4096-object step -- with 16 waves per CU the other waves are the prefetch.)
-  constexpr int GS = SCALE <= 2 ? 8 : (SCALE <= 5 ? 4 : 2);
+#ifndef M3T_TABLE_GS_SHIFT
+#define M3T_TABLE_GS_SHIFT 1  /* the table walk's batches: half the plain walk's (4096 objects: 1.88 / 1.78 / 1.85 ms for 0 / 1 / 2) */
+#endif
+#ifndef M3T_TABLE_WAVES
+#define M3T_TABLE_WAVES 3     /* experiment knob: waves per SIMD the table kernel's register budget is held to */
+#endif
+  constexpr int GS0 = SCALE <= 2 ? 8 : (SCALE <= 5 ? 4 : 2);
+  constexpr int GS = TABLE ? ((GS0 >> M3T_TABLE_GS_SHIFT) > 0 ? (GS0 >> M3T_TABLE_GS_SHIFT) : 1) : GS0;
   float wf[8], wb[8];  // ring: segment t of the walk sits in slot t & 7
 #pragma unroll
   for (int i = 0; i < 8; ++i) { wf[i] = 0.0f; wb[i] = 0.0f; }
@@ -69,6 +95,7 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
       uint32_t px[GS][SCALE];
       load_batch(px, t0 + g0);
       v2f h[GS][SCALE];
+      if constexpr (!TABLE) {
 #pragma unroll
       for (int g = 0; g < GS; ++g)
 #pragma unroll
@@ -79,6 +106,46 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
                                (((v >> 16) & 0xffu) >> bitshift);
           h[g][j] = hist[idx];
         }
+      } else {
+        // all words of the batch first, then ONE pair read per sample -- slot 0 / 1 / 2 of the pair array hold the three
+        // constants, a mixed bin's pair sits at 3 + its rank: the slot is a select, not the value --; the rare mixed bin
+        // beyond the LDS budget takes the global table behind a wave vote
+        v2u ab[GS][SCALE];
+        uint32_t rk[GS][SCALE];
+#pragma unroll
+        for (int g = 0; g < GS; ++g)
+#pragma unroll
+          for (int j = 0; j < SCALE; ++j) {
+            const uint32_t v = px[g][j];
+            const uint32_t idx = ((((v & 0xffu) >> bitshift) << bin_bits | ((v >> 8) & 0xffu) >> bitshift) << bin_bits) |
+                                 (((v >> 16) & 0xffu) >> bitshift);
+            px[g][j] = idx;
+            ab[g][j] = table->ab[idx >> 5];
+            rk[g][j] = table->rank[idx >> 5];  // 3 + the mixed bins in front of the word
+          }
+        bool overflow = false;
+        const uint32_t last_slot = (uint32_t)table->cap + 2u;
+#pragma unroll
+        for (int g = 0; g < GS; ++g)
+#pragma unroll
+          for (int j = 0; j < SCALE; ++j) {
+            const uint32_t bit = px[g][j] & 31u, a = (ab[g][j].x >> bit) & 1u, b = (ab[g][j].y >> bit) & 1u;
+            const uint32_t r = rk[g][j] + (uint32_t)__builtin_popcount((ab[g][j].x & ab[g][j].y) & ((1u << bit) - 1u));
+            const uint32_t state = a + 2u * b;  // 0: (0.5, 0.5), 1: (1, 0), 2: (0, 1), 3: mixed
+            const uint32_t slot = state == 3u ? r : state;
+            const bool far = slot > last_slot;
+            overflow = overflow || far;
+            h[g][j] = table->pairs[far ? 0u : slot];
+            rk[g][j] = far ? 1u : 0u;
+          }
+        if (__builtin_amdgcn_ballot_w64(overflow) != 0) {
+#pragma unroll
+          for (int g = 0; g < GS; ++g)
+#pragma unroll
+            for (int j = 0; j < SCALE; ++j)
+              if (rk[g][j]) h[g][j] = hist[px[g][j]];
+        }
+      }
 #pragma unroll
       for (int g = 0; g < GS; ++g) {
         const int t = t0 + g0 + g;
@@ -127,12 +194,94 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
   }
 }
 
+// Builds the LDS table above from the modality's pair table (histogram_norm) and its occupancy bytes (one per group of
+// four bins, 0 = all four pairs are (0.5, 0.5)); 256 threads, thread t takes the words 4 t .. 4 t + 3 of 1024 (32 bins
+// each), so that the ranks follow from a scan over the threads.  Ends with a barrier.
+__device__ __forceinline__ void compact_stage_table(CRegion& m, float* lds_table, int n_words, int cap, float* misc,
+                                                    unsigned* overflow_word) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  v2u* ab = reinterpret_cast<v2u*>(lds_table);
+  v2f* pairs = reinterpret_cast<v2f*>(lds_table + 2 * n_words);                     // [3 + cap]
+  uint16_t* rank = reinterpret_cast<uint16_t*>(lds_table + 2 * n_words + 2 * (3 + cap));  // [n_words]
+  if (tid < 3) {
+    v2f c;
+    c.x = tid == 0 ? 0.5f : (tid == 1 ? 1.0f : 0.0f);
+    c.y = tid == 0 ? 0.5f : (tid == 1 ? 0.0f : 1.0f);
+    pairs[tid] = c;
+  }
+  G<v4f> norm4 = (G<v4f>)m.histogram_norm;          // two pairs per v4f
+  G<uint8_t> occupancy = as_global(m.occupancy);    // [n_bins3 / 4]
+  const int per_thread = (n_words + nt - 1) / nt;   // 4 for 32 bins, 1 (half the threads idle) for 16
+  const int w0 = tid * per_thread;
+  int my_mixed = 0;
+  for (int k = 0; k < per_thread; ++k) {
+    const int w = w0 + k;
+    if (w >= n_words) break;
+    uint32_t a = 0u, b = 0u;
+    const v2u occ = *(G<v2u>)(occupancy + 8 * w);  // the word's eight groups
+    const unsigned long long occ64 = ((unsigned long long)occ.y << 32) | occ.x;
+    if (occ64 != 0ull) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if ((occ64 >> (8 * g)) & 0xffull) {
+          const v4f n0 = norm4[(32 * w + 4 * g) / 2], n1 = norm4[(32 * w + 4 * g) / 2 + 1];
+          const float px[4] = {n0.x, n0.z, n1.x, n1.z}, py[4] = {n0.y, n0.w, n1.y, n1.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool empty = px[i] == 0.5f && py[i] == 0.5f;
+            const bool f_only = px[i] == 1.0f && py[i] == 0.0f, b_only = px[i] == 0.0f && py[i] == 1.0f;
+            if (!empty && !b_only) a |= 1u << (4 * g + i);
+            if (!empty && !f_only) b |= 1u << (4 * g + i);
+          }
+        }
+      }
+    }
+    v2u e_ab;
+    e_ab.x = a;
+    e_ab.y = b;
+    ab[w] = e_ab;
+    my_mixed += __builtin_popcount(a & b);
+  }
+  // exclusive scan of my_mixed over the threads: inside the wave by shuffles, across the waves through `misc`
+  int incl = my_mixed;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int up = __shfl_up(incl, d, kWave);
+    if ((tid & (kWave - 1)) >= d) incl += up;
+  }
+  int* wsum = reinterpret_cast<int*>(misc) + 64;
+  if ((tid & (kWave - 1)) == kWave - 1) wsum[tid / kWave] = incl;
+  __syncthreads();
+  int base = incl - my_mixed;
+  for (int wv = 0; wv < tid / kWave; ++wv) base += wsum[wv];
+  for (int k = 0; k < per_thread; ++k) {
+    const int w = w0 + k;
+    if (w >= n_words) break;
+    rank[w] = (uint16_t)(base + 3);
+    const v2u e = ab[w];
+    uint32_t mixed = e.x & e.y;
+    while (mixed) {
+      const int bit = __builtin_ctz(mixed);
+      mixed &= mixed - 1u;
+      if (base < cap) pairs[3 + base] = ((G<v2f>)m.histogram_norm)[32 * w + bit];
+      ++base;
+    }
+  }
+  // histograms whose mixed bins outgrow the table (long sequences): those lookups take the global table, and the host is
+  // told by how much, so that it can go back to the kernel without the table (no traffic while everything fits)
+  if (tid == nt - 1 && base > cap && overflow_word)
+    __hip_atomic_fetch_max(overflow_word, (unsigned)(base - cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+}
+
 // RegionModality::CalculateCorrespondences (:390-465) for one object by one 256-thread workgroup, thread = line.
 // Line set-up as in region_correspondences (phase A), then the walk above, normalisation and moments; everything a
 // line needs in between stays in the thread's registers.  Ends with a barrier.  Returns the closest view.
+template <bool TABLE = false>
 __device__ __forceinline__ int compact_region_correspondences(CRegion& m, CCam& cam, CCam* dcam, const Affine& b2c,
                                                               const Affine& b2dc, int iteration, int corr_iteration,
-                                                              float* misc, float* state, int nl, int prev_view = -1) {
+                                                              float* misc, float* state, int nl, int prev_view = -1,
+                                                              const CompactTable* table = nullptr) {
   const int tid = threadIdx.x;
   const RegionIter it = region_iter(m, corr_iteration);
   // the view of the previous search first (closest_view_local: 20 loads, no barrier), else the scan over all views
@@ -237,6 +386,16 @@ __device__ __forceinline__ int compact_region_correspondences(CRegion& m, CCam& 
     float* dist0 = state + CS_DIST0 * nl + line;
     const int bitshift = m.bitshift, bin_bits = 8 - m.bitshift;
     G<v2f> hist = (G<v2f>)m.histogram_norm;
+    if constexpr (TABLE) {
+    switch (it.scale) {
+#define M3T_COMPACT_WALK(S) \
+  case S: compact_walk<S, true>(image, pitch, hist, bitshift, bin_bits, start, step, x0, horiz, reversed, lf, lb, dist0, nl, table); break;
+      M3T_COMPACT_WALK(1) M3T_COMPACT_WALK(2) M3T_COMPACT_WALK(3) M3T_COMPACT_WALK(4) M3T_COMPACT_WALK(5)
+      M3T_COMPACT_WALK(6) M3T_COMPACT_WALK(7) M3T_COMPACT_WALK(8) M3T_COMPACT_WALK(9)
+#undef M3T_COMPACT_WALK
+      default: break;
+    }
+    } else {
     switch (it.scale) {
 #define M3T_COMPACT_WALK(S) \
   case S: compact_walk<S>(image, pitch, hist, bitshift, bin_bits, start, step, x0, horiz, reversed, lf, lb, dist0, nl); break;
@@ -244,6 +403,7 @@ __device__ __forceinline__ int compact_region_correspondences(CRegion& m, CCam& 
       M3T_COMPACT_WALK(6) M3T_COMPACT_WALK(7) M3T_COMPACT_WALK(8) M3T_COMPACT_WALK(9)
 #undef M3T_COMPACT_WALK
       default: break;  // (the host does not choose this kernel for larger scales)
+    }
     }
     // normalisation :1628-1636 and CalculateDistributionMoments :1639-1658 (the thread reads back its own stores)
     float raw[12];
@@ -440,7 +600,9 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
                              int n_corr_iterations, int n_update_iterations, int fuse_histogram) {
   const RoiGuardArgs guard{};  // (unused)
 #define M3T_COMPACT_GUARD false
+#define M3T_COMPACT_TABLE false
 #include "m3t_compact_step.inc"
+#undef M3T_COMPACT_TABLE
 #undef M3T_COMPACT_GUARD
 }
 // ... reading frame slots that hold the trackers' rectangles only (ROI ingest)
@@ -449,7 +611,22 @@ tracking_step_compact_guard_kernel(const RigidOptDev* opts, const RegionModDev* 
                                    const CameraDev* cams, float* body_poses, CompactLayout L, int iteration,
                                    int n_corr_iterations, int n_update_iterations, int fuse_histogram, RoiGuardArgs guard) {
 #define M3T_COMPACT_GUARD true
+#define M3T_COMPACT_TABLE false
 #include "m3t_compact_step.inc"
+#undef M3T_COMPACT_TABLE
+#undef M3T_COMPACT_GUARD
+}
+
+// ... with the pair table compacted in LDS (three workgroups per CU: the table costs the fourth one its room)
+__global__ void __launch_bounds__(M3T_COMPACT_THREADS, M3T_TABLE_WAVES)
+tracking_step_compact_table_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                                   const CameraDev* cams, float* body_poses, CompactLayout L, int iteration,
+                                   int n_corr_iterations, int n_update_iterations, int fuse_histogram) {
+  const RoiGuardArgs guard{};  // (unused)
+#define M3T_COMPACT_GUARD false
+#define M3T_COMPACT_TABLE true
+#include "m3t_compact_step.inc"
+#undef M3T_COMPACT_TABLE
 #undef M3T_COMPACT_GUARD
 }
 

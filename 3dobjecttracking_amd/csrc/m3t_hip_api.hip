@@ -254,6 +254,10 @@ struct m3t_hip_context {
   // tracking_step_compact_kernel (m3t_compact.hip): the launch shape of batches with two objects per CU and more
   CompactLayout compact{};
   size_t lds_compact = 0;
+  CompactLayout compact_table{};  // ... with the pair table compacted in LDS (tracking_step_compact_table_kernel)
+  size_t lds_compact_table = 0;   // 0: not available for this context's modalities
+  unsigned* table_overflow_host = nullptr;  // mapped: mixed bins that did not fit the LDS table, largest over the workgroups
+  unsigned* table_overflow_dev = nullptr;
   bool compact_possible = false;       // every modality fits the kernel's assumptions (UploadTables)
   bool compact_fuses_histogram = false;  // ... and the count table fits next to the scratch block (<= 16 bins)
   const char* last_step_kernel = "";   // m3t_hip_get_step_kernel
@@ -702,6 +706,30 @@ void ComputeLayout(Ctx* ctx) {
   }
   ctx->compact = C;
   ctx->lds_compact = size_t(C.total_floats) * 4;
+  // tracking_step_compact_table_kernel: the same carve-up with the compacted pair table behind the search's part (the
+  // tail's lists and counts lie over it: the table is dead by then).  Region-only batches with histograms of at least
+  // 1024 bins; the budget is a third of the CU's LDS (three workgroups per CU instead of four).
+  ctx->compact_table = C;
+  ctx->compact_table.off_table = 0;
+  ctx->lds_compact_table = 0;
+  if (bins3 >= 1024 && bins3 % 32 == 0 && bins3 <= 32768 && !ctx->region_mods.empty()) {
+    CompactLayout T = C;
+    T.off_table = (o + 3) / 4 * 4;  // (o: the end of the search's carve-up)
+    T.table_words = bins3 / 32;
+    // 50 KB: three workgroups per CU with room for the allocation granule (a third of 160 KB does not fit three times)
+    int budget_floats = 50 * 256;
+    if (const char* e = std::getenv("M3T_HIP_COMPACT_TABLE_KB")) budget_floats = std::atoi(e) * 256;  // developer override
+    const int index_floats = 2 * T.table_words + (T.table_words + 1) / 2;  // bit words, 16-bit ranks
+    int cap = (budget_floats - T.off_table - index_floats - 8) / 2 - 3;
+    if (const char* e = std::getenv("M3T_HIP_COMPACT_TABLE_CAP")) cap = std::min(cap, std::atoi(e));  // (tests: force the overflow path)
+    if (cap >= 64) {
+      T.table_cap = std::min(std::min(cap, bins3), 65000);
+      T.total_floats = std::max(C.total_floats, (T.off_table + index_floats + 2 * (3 + T.table_cap) + 3) / 4 * 4);
+      T.table_overflow = nullptr;  // (set where the kernel is launched: a mapped host word)
+      ctx->compact_table = T;
+      ctx->lds_compact_table = size_t(T.total_floats) * 4;
+    }
+  }
 }
 
 void DfsOrder(Ctx* ctx, int link, std::vector<int>* order) {
@@ -1456,9 +1484,15 @@ int UploadTables(Ctx* ctx) {
         ctx->compact_possible = false;
       for (int i = 0; i < m->p.n_scales; ++i)
         if (m->p.scales[i] < 1 || m->p.scales[i] > 9) ctx->compact_possible = false;
+      // (the LDS pair table is laid out for ONE histogram size, each modality's own table, no shared ColorHistograms)
+      if (m->p.n_histogram_bins != ctx->region_mods[0]->p.n_histogram_bins || m->shared_histograms >= 0)
+        ctx->lds_compact_table = 0;
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_compact_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_compact)));
+    if (ctx->lds_compact_table)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_compact_table_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_compact_table)));
     // the split kernel: free rigid bodies with their own histograms (the pair table is read from L2)
     ctx->split_possible = ctx->fused_possible;
     for (auto& m : ctx->region_mods)
@@ -1843,6 +1877,7 @@ void m3t_hip_destroy(m3t_hip_context* ctx) {
     for (auto& e : c->slot_copied)
       if (e) (void)hipEventDestroy(e);
   if (ctx->split_abort_host) (void)hipHostFree(ctx->split_abort_host);
+  if (ctx->table_overflow_host) (void)hipHostFree(ctx->table_overflow_host);
   if (ctx->roi_miss_host) (void)hipHostFree(ctx->roi_miss_host);
   for (auto& e : ctx->roi_snapshot_done)
     if (e) (void)hipEventDestroy(e);
@@ -3578,6 +3613,10 @@ int m3t_hip_start_modalities(m3t_hip_context* ctx, int iteration) {
   }
   int r = Prepare(ctx, true);
   if (r) return r;
+  if (ctx->table_overflow_host) {  // new histograms: the LDS pair table gets its chance again
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *static_cast<volatile unsigned*>(ctx->table_overflow_host) = 0u;
+  }
   if ((r = RenderForModalities(ctx, true))) return r;  // start_modality_renderer_ptrs tracker.cpp:430-436
   return LaunchHistogram(ctx, iteration, true);
 }
@@ -3880,13 +3919,34 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     bool compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && n > ctx->compute_cus;
     if (const char* e = std::getenv("M3T_HIP_COMPACT")) compact = !split && ctx->compact_possible && ctx->fused_mode == 1 && std::atoi(e) != 0;
     if (std::getenv("M3T_HIP_THREADS")) compact = false;
+    // Region-only batches with >= 1024-bin histograms: the pair table compacted in LDS (round 6; 4096 objects 1.96 ->
+    // 1.78 ms).  While the mixed bins of every object fit the table, that is; histograms that outgrow it by more than
+    // half its size (the kernels report it through a mapped word) go back to the kernel that gathers from L2.
+    // M3T_HIP_COMPACT_TABLE=0 / 1: developer override.
+    bool compact_table = compact && !roi_frames && ctx->lds_compact_table > 0 && ctx->depth_mods.empty();
+    // (three workgroups per CU instead of four: a batch that is ONE round of the plain kernel but not of this one keeps
+    // the plain kernel -- 1024 objects on 256 CUs: 0.556 vs 0.583 ms; 384: 0.314 / 0.290, 512: 0.325 / 0.298, 2048:
+    // 1.041 / 0.935, 4096: 1.964 / 1.769)
+    if (n > 3 * ctx->compute_cus && n <= 4 * ctx->compute_cus) compact_table = false;
+    if (compact_table && !ctx->table_overflow_host) {
+      void *host = nullptr, *dev = nullptr;
+      HIPCHK(hipHostMalloc(&host, 64, hipHostMallocMapped));
+      std::memset(host, 0, 64);
+      HIPCHK(hipHostGetDevicePointer(&dev, host, 0));
+      ctx->table_overflow_host = static_cast<unsigned*>(host);
+      ctx->table_overflow_dev = static_cast<unsigned*>(dev);
+    }
+    if (compact_table && *static_cast<volatile unsigned*>(ctx->table_overflow_host) > unsigned(ctx->compact_table.table_cap) / 2)
+      compact_table = false;
+    if (const char* e = std::getenv("M3T_HIP_COMPACT_TABLE")) compact_table = compact_table && std::atoi(e) != 0;
+    if (compact_table) ctx->compact_table.table_overflow = ctx->table_overflow_dev;
     if (roi_frames)
       ctx->last_step_kernel = split ? "tracking_step_split_guard_kernel"
                                     : (compact ? "tracking_step_compact_guard_kernel"
                                                : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_guard_kernel" : "tracking_step_guard_kernel"));
     else
     ctx->last_step_kernel = split ? "tracking_step_split_kernel"
-                                  : (compact ? "tracking_step_compact_kernel"
+                                  : (compact ? (compact_table ? "tracking_step_compact_table_kernel" : "tracking_step_compact_kernel")
                                              : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_kernel" : "tracking_step_kernel"));
     if (compact) {
       threads = M3T_COMPACT_THREADS;
@@ -3916,6 +3976,11 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
                              ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                              ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->compact,
                              iteration, ctx->n_corr_iterations, ctx->n_update_iterations, histogram_fused ? 1 : 0, guard);
+        else if (compact_table)
+          hipLaunchKernelGGL(tracking_step_compact_table_kernel, dim3(n), dim3(threads), ctx->lds_compact_table, ctx->stream,
+                             ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                             ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->compact_table,
+                             iteration, ctx->n_corr_iterations, ctx->n_update_iterations, histogram_fused ? 1 : 0);
         else
           hipLaunchKernelGGL(tracking_step_compact_kernel, dim3(n), dim3(threads), ctx->lds_compact, ctx->stream,
                              ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),

@@ -49,7 +49,8 @@ def kernel_of(api):
 
 
 def hip_trajectory(inputs, use_depth=False, env=None, want_kernel=None):
-    for k in ("M3T_HIP_NO_SPLIT", "M3T_HIP_SPLIT_PARTS", "M3T_HIP_THREADS", "M3T_HIP_COMPACT"):
+    for k in ("M3T_HIP_NO_SPLIT", "M3T_HIP_SPLIT_PARTS", "M3T_HIP_THREADS", "M3T_HIP_COMPACT", "M3T_HIP_COMPACT_TABLE",
+              "M3T_HIP_COMPACT_TABLE_KB"):
         os.environ.pop(k, None)
     os.environ.update(env or {})
     try:
@@ -118,13 +119,62 @@ def test_compact_kernel_is_bit_identical_to_the_oracle(rbot64):
     workgroups, a thread per correspondence line, factor rows instead of product rows), forced onto the headline
     inputs: poses after every frame and histograms equal the oracle's"""
     ref, ref_hist = oracle_trajectory(rbot64)
-    got, hist, shape = hip_trajectory(rbot64, env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1"},
+    got, hist, shape = hip_trajectory(rbot64, env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1", "M3T_HIP_COMPACT_TABLE": "0"},
                                       want_kernel="tracking_step_compact_kernel")
     assert shape[:3] == [64, 1, 256]
     for k in range(rbot64.n_frames):
         assert np.array_equal(got[k], ref[k]), k
     for (fa, ba), (fb, bb) in zip(hist, ref_hist):
         assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+
+
+def test_compact_table_kernel_is_bit_identical_to_the_oracle(rbot64):
+    """tracking_step_compact_table_kernel (round 6; the default for Region-only batches of more objects than CUs): the
+    32-bin pair table compacted in LDS -- two bits per bin for the three constant pairs (0.5, 0.5) / (1, 0) / (0, 1), the
+    pairs of the bins both histograms hold in bin order -- in place of the 8-byte gather per sample
+    (region_modality.cpp:1575-1598).  Saturated pixels put bin 32767 -- the table's last bit -- into both histograms."""
+    base = scenes.subset(rbot64, list(range(16)))
+    base.color = [[f.copy() for f in frames] for frames in base.color]
+    for frames in base.color:
+        for f in frames:
+            f[::8, ::8, :] = 255
+    ref, ref_hist = oracle_trajectory(base)
+    got, hist, shape = hip_trajectory(base, env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1"},
+                                      want_kernel="tracking_step_compact_table_kernel")
+    assert shape[:3] == [16, 1, 256]
+    for k in range(base.n_frames):
+        assert np.array_equal(got[k], ref[k]), k
+    for (fa, ba), (fb, bb) in zip(hist, ref_hist):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+
+
+def test_compact_table_overflow_takes_the_global_table_and_tells_the_host(rbot64):
+    """a table with room for 64 mixed bins only: the bins beyond it are read from the global pair table inside the same
+    walk (same poses, bit for bit), the kernels report by how much they overflowed, and the host goes back to the
+    kernel without the table from the next step on -- until StartModalities brings new histograms"""
+    base = scenes.subset(rbot64, list(range(8)))
+    ref, _ = oracle_trajectory(base)
+    for k in ("M3T_HIP_NO_SPLIT", "M3T_HIP_SPLIT_PARTS", "M3T_HIP_THREADS", "M3T_HIP_COMPACT", "M3T_HIP_COMPACT_TABLE"):
+        os.environ.pop(k, None)
+    os.environ.update({"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1", "M3T_HIP_COMPACT_TABLE_CAP": "64"})
+    try:
+        api = util.open_hip()
+        a = scenes.Instance(api, base)
+        a.upload_frame(0)
+        assert a.tracker.StartModalities(0)
+        kernels = []
+        for k in range(base.n_frames):
+            a.upload_frame(k)
+            assert a.tracker.ExecuteTrackingStep(k)
+            assert np.array_equal(np.stack(a.poses()), ref[k]), k  # (the read-back also waits for the step)
+            kernels.append(kernel_of(api))
+        assert kernels[0] == "tracking_step_compact_table_kernel" and kernels[-1] == "tracking_step_compact_kernel", kernels
+        assert a.tracker.StartModalities(base.n_frames - 1)
+        assert a.tracker.ExecuteTrackingStep(base.n_frames - 1)
+        assert kernel_of(api) == "tracking_step_compact_table_kernel"
+    finally:
+        for k in ("M3T_HIP_COMPACT", "M3T_HIP_NO_SPLIT", "M3T_HIP_COMPACT_TABLE_CAP"):
+            os.environ.pop(k, None)
 
 
 def test_compact_kernel_region_and_depth():
@@ -178,7 +228,7 @@ def test_compact_kernel_counts_saturated_background_pixels():
             f[::8, ::8, :] = 255
     ref, ref_hist = oracle_trajectory(inputs)
     assert all(fb[1].reshape(-1)[32767] > 0 and fb[0].reshape(-1)[32767] > 0 for fb in ref_hist)
-    got, hist, shape = hip_trajectory(inputs, env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1"},
+    got, hist, shape = hip_trajectory(inputs, env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1", "M3T_HIP_COMPACT_TABLE": "0"},
                                       want_kernel="tracking_step_compact_kernel")
     assert shape == [8, 1, 256, 1]
     for (fa, ba), (fb, bb) in zip(hist, ref_hist):
