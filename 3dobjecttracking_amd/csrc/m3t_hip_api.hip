@@ -89,6 +89,13 @@ struct Camera {
 struct FrameSlab {  // the frame rings of a group of cameras of equal geometry in one allocation
   DevMem mem;
   std::vector<int> cameras;
+  // per ring slot: behind the last batch upload / rectangle pull into it (m3t_hip_camera_slot_sync of any of its
+  // cameras).  ONE event per batch-frame: an event per camera cost a 64-camera upload 0.3 ms of host time.
+  std::vector<hipEvent_t> slot_copied;
+  ~FrameSlab() {
+    for (auto& e : slot_copied)
+      if (e) (void)hipEventDestroy(e);
+  }
 };
 
 struct BodyGeometryH {  // body.h:46-60 on the device
@@ -271,7 +278,8 @@ struct m3t_hip_context {
   long long roi_pulls = 0;         // batch-frames uploaded as rectangles so far
   long long roi_repeated = 0;      // bodies whose step was repeated on whole frames so far (read with roi_get_status)
   DevMem d_search_poses, d_roi_items, d_roi_item_first, d_roi_cam_ids, d_roi_all_cam_ids, d_roi_rects, d_roi_pose_snapshot,
-         d_roi_motion_peak;  // [reader]: adaptive margins (roi_rect_kernel)
+         d_roi_motion_peak,  // [reader]: adaptive margins (roi_rect_kernel)
+         d_roi_opt_of_region;  // [region modality]: its optimizer's row (region_histogram_kernel behind a guarded step)
   std::vector<int> roi_cam_ids;    // what d_roi_cam_ids holds (a batch whose ids are not consecutive)
   int roi_rect_slots = 0;          // d_roi_rects: [slot][camera id]
   // Where the whole frames behind the rectangles of a slot are (the repair after a guarded step reads them): one entry
@@ -1224,6 +1232,13 @@ int BuildRoiTables(Ctx* ctx) {
   for (auto& it : items) ++first[size_t(it.camera) + 1];
   for (size_t c = 0; c < n_cams; ++c) first[c + 1] += first[c];
   HIPCHK(ctx->d_roi_items.alloc(std::max<size_t>(1, items.size()) * sizeof(RoiItemDev)));
+  {  // region modality -> its optimizer (region_histogram_kernel behind a guarded step)
+    std::vector<int> opt_of(std::max<size_t>(1, ctx->region_mods.size()), -1);
+    for (size_t oi = 0; oi < ctx->opt_table.size(); ++oi)
+      if (ctx->opt_table[oi].region_modality >= 0) opt_of[size_t(ctx->opt_table[oi].region_modality)] = int(oi);
+    HIPCHK(ctx->d_roi_opt_of_region.alloc(opt_of.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(ctx->d_roi_opt_of_region.p, opt_of.data(), opt_of.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   HIPCHK(ctx->d_roi_item_first.alloc(first.size() * sizeof(int)));
   if (!items.empty())
     HIPCHK(hipMemcpy(ctx->d_roi_items.p, items.data(), items.size() * sizeof(RoiItemDev), hipMemcpyHostToDevice));
@@ -1572,13 +1587,16 @@ struct ScopedKernelTimer {
   }
 };
 
-int LaunchHistogram(Ctx* ctx, int iteration, bool initialize) {
+int LaunchHistogram(Ctx* ctx, int iteration, bool initialize, bool behind_guarded_step = false) {
   int n = int(ctx->region_mods.size());
   if (n == 0) return M3T_OK;
   ScopedKernelTimer timer(ctx, 1);
+  const bool guarded = behind_guarded_step && ctx->d_roi_opt_of_region.p != nullptr && !ctx->opt_table.empty();
   hipLaunchKernelGGL(region_histogram_kernel, dim3(n), dim3(M3T_BLOCK_THREADS), ctx->lds_hist, ctx->stream,
                      ctx->d_region.as<RegionModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), iteration,
-                     initialize ? 1 : 0, ctx->hist_counts_in_lds ? 1 : 0);
+                     initialize ? 1 : 0, ctx->hist_counts_in_lds ? 1 : 0,
+                     guarded ? ctx->d_opts.as<RigidOptDev>() : (const RigidOptDev*)nullptr,
+                     guarded ? ctx->d_roi_opt_of_region.as<int>() : (const int*)nullptr, ctx->roi_n_poses);
   if (!ctx->shared_histograms.empty())  // Initialize / UpdateHistograms of the shared objects, tracker.cpp:441-443,513-515
     hipLaunchKernelGGL(shared_histogram_finish_kernel, dim3(unsigned(ctx->shared_histograms.size())),
                        dim3(M3T_BLOCK_THREADS), 0, ctx->stream, ctx->d_shared_histograms.as<SharedHistogramsDev>(),
@@ -2105,7 +2123,10 @@ int m3t_hip_camera_slot_sync(m3t_hip_context* ctx, int id, int slot) {
   if (c.slot_is_roi[slot]) {
     // a rectangle went into the slot (m3t_hip_cameras_upload_batch_roi_async): the host block is read by the pull and,
     // should a body outrun its rectangle, again by the repair of the step that reads the slot -- both must be over
-    if (size_t(slot) < c.slot_copied.size() && c.slot_copied[slot]) HIPCHK(hipEventSynchronize(c.slot_copied[slot]));
+    hipEvent_t pulled = nullptr;
+    if (c.slab >= 0 && size_t(slot) < ctx->slabs[size_t(c.slab)]->slot_copied.size())
+      pulled = ctx->slabs[size_t(c.slab)]->slot_copied[slot];
+    if (pulled) HIPCHK(hipEventSynchronize(pulled));
     else if (ctx->async_ingest && ctx->copy_stream[0]) HIPCHK(hipStreamSynchronize(ctx->copy_stream[0]));
     if (c.last_read_step[slot] >= 0 && c.last_read_step[slot] + Ctx::kStepEvents > ctx->step_counter)
       HIPCHK(hipEventSynchronize(ctx->step_done[c.last_read_step[slot] % Ctx::kStepEvents]));
@@ -2113,7 +2134,12 @@ int m3t_hip_camera_slot_sync(m3t_hip_context* ctx, int id, int slot) {
       HIPCHK(hipStreamSynchronize(ctx->stream));
     return M3T_OK;
   }
-  if (size_t(slot) >= c.slot_copied.size() || !c.slot_copied[slot]) return M3T_OK;  // nothing was enqueued
+  // (a camera may have been fed both ways: its own uploads and batch uploads of its slab; an event that has long
+  // completed costs nothing to wait for)
+  if (c.slab >= 0 && size_t(slot) < ctx->slabs[size_t(c.slab)]->slot_copied.size() &&
+      ctx->slabs[size_t(c.slab)]->slot_copied[slot])
+    HIPCHK(hipEventSynchronize(ctx->slabs[size_t(c.slab)]->slot_copied[slot]));
+  if (size_t(slot) >= c.slot_copied.size() || !c.slot_copied[slot]) return M3T_OK;  // nothing (else) was enqueued
   HIPCHK(hipEventSynchronize(c.slot_copied[slot]));
   return M3T_OK;
 }
@@ -2214,11 +2240,11 @@ int m3t_hip_cameras_upload_batch_async(m3t_hip_context* ctx, const int* ids, int
   RoiMarkWholeFrames(ctx, ids, n, slot, ctx->copy_stream[cs]);
   // m3t_hip_camera_slot_sync: every camera of the batch waits for this transfer before its host block is written again
   // (also reached from cameras_upload_batch_roi_async whenever rectangles are not possible)
-  for (int i = 0; i < n; ++i) {
-    Camera& c = *ctx->cameras[ids[i]];
-    if (c.slot_copied.size() < size_t(c.n_slots)) c.slot_copied.resize(size_t(c.n_slots), nullptr);
-    if (!c.slot_copied[slot]) HIPCHK(hipEventCreateWithFlags(&c.slot_copied[slot], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(c.slot_copied[slot], ctx->copy_stream[cs]));
+  {
+    FrameSlab& slab = *ctx->slabs[size_t(c0.slab)];
+    if (slab.slot_copied.size() < size_t(c0.n_slots)) slab.slot_copied.resize(size_t(c0.n_slots), nullptr);
+    if (!slab.slot_copied[slot]) HIPCHK(hipEventCreateWithFlags(&slab.slot_copied[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(slab.slot_copied[slot], ctx->copy_stream[cs]));
   }
   ctx->copies_pending |= 1u << cs;
   return M3T_OK;
@@ -2380,10 +2406,12 @@ int m3t_hip_cameras_upload_batch_roi_async(m3t_hip_context* ctx, const int* ids,
     Camera& c = *ctx->cameras[ids[i]];
     c.has_image[slot] = true;
     c.slot_is_roi[slot] = true;
-    // m3t_hip_camera_slot_sync waits for THIS pull, not for whatever else the copy stream carries by then
-    if (c.slot_copied.size() < size_t(c.n_slots)) c.slot_copied.resize(size_t(c.n_slots), nullptr);
-    if (!c.slot_copied[slot]) HIPCHK(hipEventCreateWithFlags(&c.slot_copied[slot], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(c.slot_copied[slot], ctx->copy_stream[cs]));
+  }
+  {  // m3t_hip_camera_slot_sync waits for THIS pull, not for whatever else the copy stream carries by then
+    FrameSlab& slab = *ctx->slabs[size_t(c0.slab)];
+    if (slab.slot_copied.size() < size_t(c0.n_slots)) slab.slot_copied.resize(size_t(c0.n_slots), nullptr);
+    if (!slab.slot_copied[slot]) HIPCHK(hipEventCreateWithFlags(&slab.slot_copied[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(slab.slot_copied[slot], ctx->copy_stream[cs]));
   }
   {  // where the whole frames are, should a body outrun its rectangle (the repair of the step that reads this slot)
     auto& sources = ctx->roi_sources[size_t(slot)];
@@ -4228,7 +4256,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
   }
   if (!histogram_fused) {
     if ((r = RenderForModalities(ctx, true))) return r;
-    if ((r = LaunchHistogram(ctx, iteration, false))) return r;
+    if ((r = LaunchHistogram(ctx, iteration, false, roi_frames))) return r;
   }
   if (roi_active) {  // the poses the step ends on = the poses the next one starts from
     // (the third buffer: a rectangle upload that is still to run on the copy stream reads roi_use and roi_prev)

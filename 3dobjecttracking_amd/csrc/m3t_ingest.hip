@@ -62,6 +62,10 @@ roi_rect_kernel(const RoiItemDev* items, const int* item_first, const int* cam_i
 // tracking_step_split_kernel, so the rectangles of frame k + 1 CAN cross PCIe while step k runs on all CUs -- measured
 // (profiles/r04_roi_trace.txt): the step kernel then runs 2.3-3 x longer (the CUs' memory pipelines hold the ~2 us PCIe
 // reads), and the loop takes what step + pull take one after the other (hence m3t_hip_reserve_ingest_cus).
+// Round 6 (tools/ubench_ingest.hip, profiles/r06_ubench_ingest.txt): a kernel that streams the whole host block reaches
+// the link's 57 GB/s (as the DMA engines do); rectangles of the tracked size come at 43 GB/s in this shape and at 47 GB/s
+// with 32 rows per workgroup, four loads in flight and 64-byte-aligned spans ON AN IDLE GPU -- but beside the step, on
+// 32 / 64 reserved CUs, that shape gave 168 k / 150 k pose-updates/s against this one's 180 k / 185 k: not taken.
 __global__ void __launch_bounds__(256)
 roi_pull_kernel(const int* cam_ids, const m3t_roi_rect* rects /* of this slot, by camera id */, const uint8_t* src0,
                 size_t src_camera_stride, uint32_t src_row_step, uint8_t* dst0, size_t dst_camera_stride,

@@ -276,7 +276,9 @@ __device__ __noinline__ int roi_guard_outside(const RoiItemDev* items, const m3t
 // what a workgroup does with the guard's verdict (one thread per object): mode 1 flags a miss and reports the body,
 // mode 2 (the repeat over whole frames) clears the flag and reports a body that still misses
 __device__ __forceinline__ void roi_guard_report(const RoiGuardArgs& a, RoiGuardDev* hdr, int body, bool miss) {
-  hdr->flag = (a.mode == 1 && miss) ? 1 : 0;
+  // (2: still outside after the repeat on whole frames -- the step's separate histogram launch leaves such a body alone;
+  // the next step's first pass writes the flag afresh)
+  hdr->flag = miss ? (a.mode == 1 ? 1 : 2) : 0;
   if (miss) {
     int* list = a.mode == 1 ? a.misses : a.unrecovered;
     const int at = atomicAdd(&list[0], 1);
@@ -2826,8 +2828,16 @@ extern "C" {
 // One block per region modality.  initialize != 0: StartModality (:375-388), else CalculateResults (:572-583).
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
 region_histogram_kernel(const RegionModDev* mods, const CameraDev* cams, const float* body_poses, int iteration,
-                        int initialize, int counts_in_lds) {
+                        int initialize, int counts_in_lds, const RigidOptDev* guarded_opts, const int* opt_of_region,
+                        int guard_poses) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // behind a guarded step (ROI ingest): a body whose step was not committed keeps its histograms as well
+  if (guarded_opts && opt_of_region) {
+    const int oi = opt_of_region[blockIdx.x];
+    if (oi >= 0 && guarded_opts[oi].search_poses &&
+        reinterpret_cast<const RoiGuardDev*>(guarded_opts[oi].search_poses + 16 * guard_poses)->flag != 0)
+      return;
+  }
   CRegion& m = *(CRegion*)(mods + blockIdx.x);
   CCam& cam = *(CCam*)(cams + m.camera);
   CCam* dcam = m.measure_occlusions ? (CCam*)(cams + m.depth_camera) : nullptr;

@@ -77,7 +77,7 @@ class _LoaderCamera:
         self._prefetch = bool(enable) and getattr(self.api, "is_hip", False)
         self._drop_pipeline()
 
-    def enable_roi_ingest(self, enable=True, margin_px=24.0, adaptive=True, reserve_cus=0):
+    def enable_roi_ingest(self, enable=True, margin_px=24.0, adaptive=False, reserve_cus=0):
         """ROI ingest for this camera's pipeline (m3t_hip_set_roi_ingest: a setting of the whole context, every
         loader camera of a tracker should be given the same one): of frame k + 1 only the rectangle the trackers can
         read crosses PCIe, pulled by a kernel out of the page-locked slab while frame k is tracked; a body that
@@ -411,7 +411,7 @@ class GeneratedTracker(host.Tracker):
         self.set_up = True
         return True
 
-    def enable_roi_ingest(self, enable=True, margin_px=24.0, adaptive=True, reserve_cus=0):
+    def enable_roi_ingest(self, enable=True, margin_px=24.0, adaptive=False, reserve_cus=0):
         """ROI ingest for every loader camera of the tracker (_LoaderCamera.enable_roi_ingest): of each frame only
         the trackers' rectangle crosses PCIe; poses equal those of whole frames bit for bit (a body that outruns its
         rectangle is repeated on the whole frame inside ExecuteTrackingStep)"""

@@ -641,7 +641,7 @@ class FramePipeline {
   // frame k is tracked; a body that outruns its rectangle is repeated on the whole frame by the library, so the poses
   // are those of whole frames bit for bit.  reserve_cus (a multiple of 32): CUs kept free for the pull kernel.
   bool roi = false;
-  bool EnableRoi(m3t_hip_context* ctx, bool enable, float margin_px = 24.0f, bool adaptive = true, int reserve_cus = 0) {
+  bool EnableRoi(m3t_hip_context* ctx, bool enable, float margin_px = 24.0f, bool adaptive = false, int reserve_cus = 0) {
     Drop(ctx);
     if (m3t_hip_set_roi_ingest(ctx, enable ? (adaptive ? 2 : 1) : 0, margin_px) < 0) return false;
     if ((reserve_cus || !enable) && m3t_hip_reserve_ingest_cus(ctx, enable ? reserve_cus : 0) < 0) return false;
@@ -1030,7 +1030,7 @@ class GeneratedTracker {
   // ROI ingest for every loader camera (FramePipeline::EnableRoi): of each frame only the trackers' rectangle crosses
   // PCIe; poses equal those of whole frames bit for bit (a body that outruns its rectangle is repeated on the whole
   // frame inside ExecuteTrackingStep)
-  bool EnableRoiIngest(bool enable, float margin_px = 24.0f, bool adaptive = true, int reserve_cus = 0) {
+  bool EnableRoiIngest(bool enable, float margin_px = 24.0f, bool adaptive = false, int reserve_cus = 0) {
     bool ok = true;
     for (auto& c : color_cameras) ok = c.second->pipeline.EnableRoi(context->get(), enable, margin_px, adaptive, reserve_cus) && ok;
     for (auto& c : depth_cameras) ok = c.second->pipeline.EnableRoi(context->get(), enable, margin_px, adaptive, reserve_cus) && ok;

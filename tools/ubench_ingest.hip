@@ -37,6 +37,53 @@ pull_kernel(const unsigned char* __restrict__ host_block, unsigned char* __restr
   }
 }
 
+// pull variants (round 6): ROWS rows per workgroup, K 16-byte loads in flight per thread, spans widened to ALIGN bytes
+template <int ROWS, int K, int ALIGN>
+__global__ void __launch_bounds__(256)
+pull_variant(const unsigned char* __restrict__ host_block, unsigned char* __restrict__ ring, const Rect* rects) {
+  const int cam = blockIdx.y;
+  const Rect r = rects[cam];
+  const int row0 = r.y0 + blockIdx.x * ROWS;
+  if (row0 >= r.y1) return;
+  const int b0 = (r.x0 * BPP) & ~(ALIGN - 1);
+  int b1 = (r.x1 * BPP + ALIGN - 1) & ~(ALIGN - 1);
+  if (b1 > PITCH) b1 = PITCH;
+  const int chunks = (b1 - b0) >> 4;
+  const int rows = (r.y1 - row0) < ROWS ? (r.y1 - row0) : ROWS;
+  const int total = rows * chunks;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * K) {
+    uint4 v[K];
+    size_t at[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = i0 + k * 256;
+      const int row = i / chunks, c = i - row * chunks;
+      at[k] = (size_t)cam * FRAME + (size_t)(row0 + row) * PITCH + b0 + ((size_t)c << 4);
+      if (i < total) v[k] = *reinterpret_cast<const uint4*>(host_block + at[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (i0 + k * 256 < total) *reinterpret_cast<uint4*>(ring + at[k]) = v[k];
+  }
+}
+
+// The ceiling of a kernel's reads from mapped host memory (round 6): the whole block streamed by `wgs` workgroups, every
+// thread K 16-byte loads in flight (a wave asks for K x 1 KB of consecutive host memory at a time), consecutive or with
+// the loads of a thread 128 bytes apart (WIDE: two 64-byte halves of a 128-byte line per pair of loads)
+template <int K>
+__global__ void __launch_bounds__(256)
+stream_kernel(const uint4* __restrict__ host_block, uint4* __restrict__ ring, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256 * K;
+  for (size_t base = (size_t)blockIdx.x * 256 * K + threadIdx.x; base < n16; base += stride) {
+    uint4 v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = base + (size_t)k * 256 < n16 ? host_block[base + (size_t)k * 256] : uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (base + (size_t)k * 256 < n16) ring[base + (size_t)k * 256] = v[k];
+  }
+}
+
 int main() {
   unsigned char *host, *host_dev, *ring;
   Rect* d_rects;
@@ -61,6 +108,27 @@ int main() {
     const double ms = ms_since(t) / reps;
     printf("full frames             %7.3f ms per batch-frame  %6.1f GB/s  -> %8.0f pose-updates/s\n", ms, N * FRAME / ms * 1e-6,
            N / ms * 1e3);
+  }
+  {  // what the link gives a KERNEL: the same 62.9 MB streamed from the mapped block, by workgroups x loads in flight
+    const size_t n16 = N * FRAME / 16;
+    for (int wgs : {64, 256, 1024, 4096}) {
+      double ms[4];
+      int col = 0;
+#define STREAM(K)                                                                                                   \
+      {                                                                                                             \
+        hipLaunchKernelGGL(stream_kernel<K>, dim3(wgs), dim3(256), 0, s, (const uint4*)host_dev, (uint4*)ring, n16); \
+        CHECK(hipStreamSynchronize(s));                                                                             \
+        auto t = now();                                                                                             \
+        for (int k = 0; k < reps; ++k)                                                                              \
+          hipLaunchKernelGGL(stream_kernel<K>, dim3(wgs), dim3(256), 0, s, (const uint4*)host_dev, (uint4*)ring, n16); \
+        CHECK(hipStreamSynchronize(s));                                                                             \
+        ms[col++] = ms_since(t) / reps;                                                                             \
+      }
+      STREAM(1) STREAM(2) STREAM(4) STREAM(8)
+#undef STREAM
+      printf("kernel stream, %4d workgroups x 256 threads: 16 B x {1, 2, 4, 8} loads in flight per thread: %5.1f / %5.1f / %5.1f / %5.1f GB/s\n",
+             wgs, N * FRAME / ms[0] * 1e-6, N * FRAME / ms[1] * 1e-6, N * FRAME / ms[2] * 1e-6, N * FRAME / ms[3] * 1e-6);
+    }
   }
   for (int side : {128, 192, 256, 320, 384, 512}) {
     Rect rects[N];
@@ -142,6 +210,27 @@ int main() {
       for (int k = 0; k < reps; ++k) run();
       CHECK(hipStreamSynchronize(s));
       mspull = ms_since(t) / reps;
+    }
+    {
+      const int rows = rects[0].y1 - rects[0].y0;
+      double v[6];
+      int col = 0;
+#define VARIANT(ROWS, K, ALIGN)                                                                                        \
+      {                                                                                                                \
+        auto run = [&] {                                                                                               \
+          hipLaunchKernelGGL((pull_variant<ROWS, K, ALIGN>), dim3((rows + ROWS - 1) / ROWS, N), dim3(256), 0, s, host_dev, ring, d_rects); \
+        };                                                                                                             \
+        run();                                                                                                         \
+        CHECK(hipStreamSynchronize(s));                                                                                \
+        auto t = now();                                                                                                \
+        for (int k = 0; k < reps; ++k) run();                                                                          \
+        CHECK(hipStreamSynchronize(s));                                                                                \
+        v[col++] = bytes / (ms_since(t) / reps) * 1e-6;                                                                \
+      }
+      VARIANT(8, 2, 16) VARIANT(8, 2, 64) VARIANT(16, 4, 64) VARIANT(32, 4, 64) VARIANT(32, 8, 64) VARIANT(64, 8, 128)
+#undef VARIANT
+      printf("               pull variants (rows per workgroup, loads in flight, span alignment), GB/s of rectangle bytes: "
+             "8/2/16 %5.1f  8/2/64 %5.1f  16/4/64 %5.1f  32/4/64 %5.1f  32/8/64 %5.1f  64/8/128 %5.1f\n", v[0], v[1], v[2], v[3], v[4], v[5]);
     }
     printf("rect %3d^2 (%5.1f %% of the frames)  2d x 64: %7.3f ms (%5.1f GB/s, %8.0f pose-updates/s)   pull kernel: %7.3f ms (%5.1f GB/s, "
            "%8.0f pose-updates/s)\n", side, 100.0 * bytes / (N * FRAME), ms2d, bytes / ms2d * 1e-6, N / ms2d * 1e3, mspull,
