@@ -3951,6 +3951,8 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     // 1.78 ms).  While the mixed bins of every object fit the table, that is; histograms that outgrow it by more than
     // half its size (the kernels report it through a mapped word) go back to the kernel that gathers from L2.
     // M3T_HIP_COMPACT_TABLE=0 / 1: developer override.
+    // (Region + Depth batches keep the plain kernel: measured with the table, synth512 0.769 / 0.784 vs 0.778 ms -- their
+    // 16-bin pair table is 32 KB and sits in the L1 / L2 anyway, and the depth scan is most of their step)
     bool compact_table = compact && !roi_frames && ctx->lds_compact_table > 0 && ctx->depth_mods.empty();
     // (three workgroups per CU instead of four: a batch that is ONE round of the plain kernel but not of this one keeps
     // the plain kernel -- 1024 objects on 256 CUs: 0.556 vs 0.583 ms; 384: 0.314 / 0.290, 512: 0.325 / 0.298, 2048:

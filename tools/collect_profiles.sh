@@ -14,7 +14,7 @@
 #     64-object renderer-fed step
 # usage: tools/collect_profiles.sh [what ...]   what = tests cal pmc bench extras stats phases rankshare render sweep (default: all)
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=$REPO/gpurun_out/$ROUND
 WHAT=${@:-tests cal pmc bench extras stats phases rankshare render sweep}
 CONFIGS=${CONFIGS:-rbot64 rbot4096 ycb21 synth512 chain8}
@@ -78,6 +78,9 @@ if has bench; then
     (timeout 900 python bench.py $(args_of $c) $extra > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err")
     head -c 400 "$OUT/bench_$c.json"; echo
   done
+  # (round 6) the 4096-object line again with the kernel that gathers its pairs from L2: the LDS table's before / after
+  (M3T_HIP_COMPACT_TABLE=0 timeout 900 python bench.py --config rbot64 --objects 4096 --no-pcie --no-cpu-baseline --no-buckets > "$OUT/bench_rbot4096_plain_kernel.json" 2> "$OUT/bench_rbot4096_plain_kernel.err")
+  head -c 300 "$OUT/bench_rbot4096_plain_kernel.json"; echo
 fi
 if has extras; then
   (timeout 900 python bench.py --extras --no-pcie --no-cpu-baseline --no-buckets --busy-seconds 1 > "$OUT/bench_extras.json" 2> "$OUT/bench_extras.err")
