@@ -37,12 +37,27 @@ static_assert(kCMiscGhD + 42 <= M3T_COMPACT_MISC_FLOATS, "misc block too small")
 // classified from the stored PAIR (not from the histograms), so the value a lookup returns is the table's value bit for
 // bit whatever produced it.  A mixed bin whose rank does not fit the LDS budget is read from the global table.
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+// A stored pair takes FIVE bytes, not eight: the smaller of its two floats as it is, and the larger one as its distance in
+// units in the last place from 1.0f - smaller (x + y = 1 up to roundings: the distance is -2 .. 2), with a bit that says
+// which of the two the smaller one is.  larger = as_float(as_int(1.0f - smaller) + k) is the stored float bit for bit --
+// k is the difference of the two bit patterns, nothing is assumed about the roundings; a pair whose k does not fit four
+// bits (never seen) is marked and read from the global table.  1.6 x the pairs in the same LDS: the bench's steady state
+// (2 000 mixed bins after a few hundred frames of the same scene) fits where 1 400 eight-byte pairs did not.
 struct CompactTable {  // (address-space-3 pointers: ds_read, not flat loads)
   const __attribute__((address_space(3))) v2u* ab;
   const __attribute__((address_space(3))) uint16_t* rank;  // 3 + the number of mixed bins in front of the word
-  const __attribute__((address_space(3))) v2f* pairs;
+  const __attribute__((address_space(3))) float* small;    // [3 + cap]: the smaller float of the pair in slot i
+  const __attribute__((address_space(3))) uint8_t* meta;   // [3 + cap]: bit 7 = y is the smaller one, bits 0-3 = k + 8; 0xff = read the global table
   int cap;
 };
+__device__ __forceinline__ uint8_t compact_pair_meta(float x, float y, float* smaller) {
+  const bool y_small = y < x;
+  const float s = y_small ? y : x, l = y_small ? x : y;
+  const int k = __float_as_int(l) - __float_as_int(1.0f - s);
+  *smaller = s;
+  if (k < -8 || k > 7) return 0xffu;
+  return (uint8_t)((y_small ? 0x80 : 0) | (k + 8));
+}
 
 template <int SCALE, bool TABLE = false>
 __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G<v2f> hist, int bitshift, int bin_bits,
@@ -125,6 +140,7 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
           }
         bool overflow = false;
         const uint32_t last_slot = (uint32_t)table->cap + 2u;
+        // the slot of every sample (its bit words and rank are dead after that) ...
 #pragma unroll
         for (int g = 0; g < GS; ++g)
 #pragma unroll
@@ -133,9 +149,33 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
             const uint32_t r = rk[g][j] + (uint32_t)__builtin_popcount((ab[g][j].x & ab[g][j].y) & ((1u << bit) - 1u));
             const uint32_t state = a + 2u * b;  // 0: (0.5, 0.5), 1: (1, 0), 2: (0, 1), 3: mixed
             const uint32_t slot = state == 3u ? r : state;
-            const bool far = slot > last_slot;
+            const bool beyond = slot > last_slot;
+            overflow = overflow || beyond;
+            rk[g][j] = beyond ? 0x80000000u : slot;
+          }
+        // ... the stored halves of all pairs of the batch ...
+#pragma unroll
+        for (int g = 0; g < GS; ++g)
+#pragma unroll
+          for (int j = 0; j < SCALE; ++j) {
+            const uint32_t at = rk[g][j] & 0x7fffffffu;
+            ab[g][j].x = __float_as_uint(table->small[at]);
+            ab[g][j].y = table->meta[at];
+          }
+        // ... and the pairs
+#pragma unroll
+        for (int g = 0; g < GS; ++g)
+#pragma unroll
+          for (int j = 0; j < SCALE; ++j) {
+            const float sm = __uint_as_float(ab[g][j].x);
+            const uint32_t meta = ab[g][j].y;
+            const bool far = (rk[g][j] >> 31) != 0u || meta == 0xffu;
             overflow = overflow || far;
-            h[g][j] = table->pairs[far ? 0u : slot];
+            const float lg = __int_as_float(__float_as_int(1.0f - sm) + (int)(meta & 15u) - 8);
+            v2f p;
+            p.x = (meta & 0x80u) ? lg : sm;
+            p.y = (meta & 0x80u) ? sm : lg;
+            h[g][j] = p;
             rk[g][j] = far ? 1u : 0u;
           }
         if (__builtin_amdgcn_ballot_w64(overflow) != 0) {
@@ -201,13 +241,13 @@ __device__ __forceinline__ void compact_stage_table(CRegion& m, float* lds_table
                                                     unsigned* overflow_word) {
   const int tid = threadIdx.x, nt = blockDim.x;
   v2u* ab = reinterpret_cast<v2u*>(lds_table);
-  v2f* pairs = reinterpret_cast<v2f*>(lds_table + 2 * n_words);                     // [3 + cap]
-  uint16_t* rank = reinterpret_cast<uint16_t*>(lds_table + 2 * n_words + 2 * (3 + cap));  // [n_words]
-  if (tid < 3) {
-    v2f c;
-    c.x = tid == 0 ? 0.5f : (tid == 1 ? 1.0f : 0.0f);
-    c.y = tid == 0 ? 0.5f : (tid == 1 ? 0.0f : 1.0f);
-    pairs[tid] = c;
+  float* small = lds_table + 2 * n_words;                                                  // [3 + cap]
+  uint8_t* meta = reinterpret_cast<uint8_t*>(small + 3 + cap);                             // [3 + cap]
+  uint16_t* rank = reinterpret_cast<uint16_t*>(small + 3 + cap + (3 + cap + 3) / 4);       // [n_words]
+  if (tid < 3) {  // slot 0: (0.5, 0.5), 1: (1, 0), 2: (0, 1)
+    float sm;
+    meta[tid] = compact_pair_meta(tid == 0 ? 0.5f : (tid == 1 ? 1.0f : 0.0f), tid == 0 ? 0.5f : (tid == 1 ? 0.0f : 1.0f), &sm);
+    small[tid] = sm;
   }
   G<v4f> norm4 = (G<v4f>)m.histogram_norm;          // two pairs per v4f
   G<uint8_t> occupancy = as_global(m.occupancy);    // [n_bins3 / 4]
@@ -221,18 +261,27 @@ __device__ __forceinline__ void compact_stage_table(CRegion& m, float* lds_table
     const v2u occ = *(G<v2u>)(occupancy + 8 * w);  // the word's eight groups
     const unsigned long long occ64 = ((unsigned long long)occ.y << 32) | occ.x;
     if (occ64 != 0ull) {
+      // the pairs of all occupied groups are requested before the first is looked at: one round trip per word
+      v4f n[8][2];
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         if ((occ64 >> (8 * g)) & 0xffull) {
-          const v4f n0 = norm4[(32 * w + 4 * g) / 2], n1 = norm4[(32 * w + 4 * g) / 2 + 1];
-          const float px[4] = {n0.x, n0.z, n1.x, n1.z}, py[4] = {n0.y, n0.w, n1.y, n1.w};
+          n[g][0] = norm4[(32 * w + 4 * g) / 2];
+          n[g][1] = norm4[(32 * w + 4 * g) / 2 + 1];
+        } else {
+          n[g][0] = v4f{0.5f, 0.5f, 0.5f, 0.5f};
+          n[g][1] = v4f{0.5f, 0.5f, 0.5f, 0.5f};
+        }
+      }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const bool empty = px[i] == 0.5f && py[i] == 0.5f;
-            const bool f_only = px[i] == 1.0f && py[i] == 0.0f, b_only = px[i] == 0.0f && py[i] == 1.0f;
-            if (!empty && !b_only) a |= 1u << (4 * g + i);
-            if (!empty && !f_only) b |= 1u << (4 * g + i);
-          }
+      for (int g = 0; g < 8; ++g) {
+        const float px[4] = {n[g][0].x, n[g][0].z, n[g][1].x, n[g][1].z}, py[4] = {n[g][0].y, n[g][0].w, n[g][1].y, n[g][1].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool empty = px[i] == 0.5f && py[i] == 0.5f;
+          const bool f_only = px[i] == 1.0f && py[i] == 0.0f, b_only = px[i] == 0.0f && py[i] == 1.0f;
+          if (!empty && !b_only) a |= 1u << (4 * g + i);
+          if (!empty && !f_only) b |= 1u << (4 * g + i);
         }
       }
     }
@@ -254,6 +303,9 @@ __device__ __forceinline__ void compact_stage_table(CRegion& m, float* lds_table
   __syncthreads();
   int base = incl - my_mixed;
   for (int wv = 0; wv < tid / kWave; ++wv) base += wsum[wv];
+  // the mixed bins' numbers into their slots first (LDS only: a colour cluster puts a hundred of them into one thread's
+  // words) ...
+  uint32_t* slot_bin = reinterpret_cast<uint32_t*>(small);
   for (int k = 0; k < per_thread; ++k) {
     const int w = w0 + k;
     if (w >= n_words) break;
@@ -263,8 +315,28 @@ __device__ __forceinline__ void compact_stage_table(CRegion& m, float* lds_table
     while (mixed) {
       const int bit = __builtin_ctz(mixed);
       mixed &= mixed - 1u;
-      if (base < cap) pairs[3 + base] = ((G<v2f>)m.histogram_norm)[32 * w + bit];
+      if (base < cap) slot_bin[3 + base] = (uint32_t)(32 * w + bit);
       ++base;
+    }
+  }
+  if (tid == nt - 1) wsum[8] = base;  // all mixed bins of the table
+  __syncthreads();
+  // ... then the pairs themselves, dealt out over all threads, four requests in flight each
+  {
+    const int n_stored = min(wsum[8], cap);
+    G<v2f> norm = (G<v2f>)m.histogram_norm;
+    for (int e0 = tid; e0 < n_stored; e0 += 4 * nt) {
+      v2f pr[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (e0 + q * nt < n_stored) pr[q] = norm[slot_bin[3 + e0 + q * nt]];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (e0 + q * nt < n_stored) {
+          float sm;
+          meta[3 + e0 + q * nt] = compact_pair_meta(pr[q].x, pr[q].y, &sm);
+          small[3 + e0 + q * nt] = sm;
+        }
     }
   }
   // histograms whose mixed bins outgrow the table (long sequences): those lookups take the global table, and the host is

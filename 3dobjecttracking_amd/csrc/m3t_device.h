@@ -255,8 +255,9 @@ struct CompactLayout {
   int off_tail_list, off_tail_counts;
   int total_floats;
   // tracking_step_compact_table_kernel (round 6): the region modality's pair table compacted in LDS behind the search's
-  // carve-up -- [table_words] x {bits a, bits b} | [3 + table_cap] pairs (the three constants first) | [table_words] u16: 3 +
-  // the rank of the word's first mixed bin
+  // carve-up -- [table_words] x {bits a, bits b} | [3 + table_cap] f32: the smaller float of a pair (the three constants
+  // first) | [3 + table_cap] u8: which one it is and the larger one's distance from 1 - smaller | [table_words] u16: 3 + the
+  // rank of the word's first mixed bin
   int off_table, table_words, table_cap;
   unsigned* table_overflow;  // mapped host word: the largest number of mixed bins a workgroup could not place (atomic max)
 };

@@ -724,15 +724,18 @@ void ComputeLayout(Ctx* ctx) {
     CompactLayout T = C;
     T.off_table = (o + 3) / 4 * 4;  // (o: the end of the search's carve-up)
     T.table_words = bins3 / 32;
-    // 50 KB: three workgroups per CU with room for the allocation granule (a third of 160 KB does not fit three times)
-    int budget_floats = 50 * 256;
+    // 52 KB: three workgroups per CU with room for the allocation granule (a third of 160 KB, 54 356 B, does not fit three
+    // times: measured, the kernel ran at two workgroups per CU)
+    int budget_floats = 52 * 256;
     if (const char* e = std::getenv("M3T_HIP_COMPACT_TABLE_KB")) budget_floats = std::atoi(e) * 256;  // developer override
     const int index_floats = 2 * T.table_words + (T.table_words + 1) / 2;  // bit words, 16-bit ranks
-    int cap = (budget_floats - T.off_table - index_floats - 8) / 2 - 3;
+    // (a stored pair takes five bytes: m3t_compact.hip, CompactTable)
+    int cap = int((long(budget_floats - T.off_table - index_floats - 12) * 4) / 5) - 3;
     if (const char* e = std::getenv("M3T_HIP_COMPACT_TABLE_CAP")) cap = std::min(cap, std::atoi(e));  // (tests: force the overflow path)
     if (cap >= 64) {
       T.table_cap = std::min(std::min(cap, bins3), 65000);
-      T.total_floats = std::max(C.total_floats, (T.off_table + index_floats + 2 * (3 + T.table_cap) + 3) / 4 * 4);
+      T.total_floats = std::max(C.total_floats,
+                                (T.off_table + index_floats + (3 + T.table_cap) + (3 + T.table_cap + 3) / 4 + 3) / 4 * 4);
       T.table_overflow = nullptr;  // (set where the kernel is launched: a mapped host word)
       ctx->compact_table = T;
       ctx->lds_compact_table = size_t(T.total_floats) * 4;
