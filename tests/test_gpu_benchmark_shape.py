@@ -148,6 +148,41 @@ def test_compact_table_kernel_is_bit_identical_to_the_oracle(rbot64):
         assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
 
 
+@pytest.mark.parametrize("n_bins,kernel", [(16, "tracking_step_compact_table_kernel"), (8, "tracking_step_compact_kernel"),
+                                           (64, "tracking_step_compact_kernel")])
+def test_compact_table_kernel_histogram_sizes(n_bins, kernel):
+    """16 bins per channel: a table of 128 words (half the staging threads idle); 8 bins (512 bins in all: below the
+    table's lower limit) and 64 bins (262 144: above what 16-bit ranks and slots hold) keep the kernel that gathers
+    from the global table.  All three against the oracle, bit for bit."""
+    inputs = scenes.Inputs(6, 4, n_divides=2, n_models=2)
+    rp = dict(syn.RBOT_REGION_PARAMS, n_histogram_bins=n_bins, measure_occlusions=0)
+
+    def trajectory(api):
+        a = scenes.Instance(api, inputs, region_params=rp)
+        a.upload_frame(0)
+        assert a.tracker.StartModalities(0)
+        out = []
+        for k in range(inputs.n_frames):
+            a.upload_frame(k)
+            assert a.tracker.ExecuteTrackingStep(k)
+            out.append(np.stack(a.poses()))
+        return out, [r.histograms() for r in a.region]
+
+    ref, ref_hist = trajectory(util.open_oracle())
+    os.environ.update({"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1"})
+    try:
+        api = util.open_hip()
+        got, hist = trajectory(api)
+        assert kernel_of(api) == kernel
+    finally:
+        for k in ("M3T_HIP_COMPACT", "M3T_HIP_NO_SPLIT"):
+            os.environ.pop(k, None)
+    for k in range(inputs.n_frames):
+        assert np.array_equal(got[k], ref[k]), k
+    for (fa, ba), (fb, bb) in zip(hist, ref_hist):
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+
+
 def test_compact_table_overflow_takes_the_global_table_and_tells_the_host(rbot64):
     """a table with room for 64 mixed bins only: the bins beyond it are read from the global pair table inside the same
     walk (same poses, bit for bit), the kernels report by how much they overflowed, and the host goes back to the
