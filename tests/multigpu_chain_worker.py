@@ -18,8 +18,17 @@ def main():
     import torch
     import torch.distributed as dist
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    # M3T_TEST_SHARE_ONE_GPU=1: every rank on device 0, the link sums over gloo through m3t_hip_comm_set_reduce_callback
+    # (RCCL refuses two ranks on one device) -- the same worker, placement and checks on a one-GPU box
+    share = os.environ.get("M3T_TEST_SHARE_ONE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if share:
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=240))
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     pkg = importlib.import_module("3dobjecttracking_amd")
     import bench_chain as bc
     import scenes
@@ -32,22 +41,38 @@ def main():
     hip = pkg.open_context(local)
     owned = [i for i, r in enumerate(pkg.sharding.place_bodies(n_bodies, world)) if r == rank]
     ch = bc.Chain(hip, host, syn, inputs, joints, start_root, start_angles, owned)
-    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-    if rank == 0:
-        buf = C.create_string_buffer(128)
-        hip.call("comm_get_unique_id", buf, 128)
-        uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device="cuda")
-    dist.broadcast(uid, 0)
-    hip.call("comm_init_rank", C.create_string_buffer(bytes(uid.cpu().tolist()), 128), 128, world, rank)
+    reduce = None
+    if share:
+        reduce = pkg.sharding.HostReduce(hip, dist)
+    else:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            hip.call("comm_get_unique_id", buf, 128)
+            uid = torch.tensor(list(buf.raw), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        hip.call("comm_init_rank", C.create_string_buffer(bytes(uid.cpu().tolist()), 128), 128, world, rank)
     ch.upload(inputs, 0)
     assert ch.tracker.StartModalities(0)
     for k in range(n_frames):
         ch.upload(inputs, k)
         assert ch.tracker.ExecuteTrackingStep(k)
-    poses = torch.from_numpy(ch.poses()).cuda()
+    name = C.create_string_buffer(96)
+    hip.call("get_step_kernel", name, 96)
+    assert name.value.decode() == "tracking_step_tree_segment_kernel", name.value  # one launch + one reduction per Newton step
+    calls = C.c_longlong(0)
+    hip.call("comm_get_allreduce_count", C.byref(calls))
+    assert calls.value == 14 * n_frames, calls.value
+    poses = torch.from_numpy(ch.poses())
+    if not share:
+        poses = poses.cuda()
     gathered = [torch.zeros_like(poses) for _ in range(world)]
     dist.all_gather(gathered, poses)
-    hip.call("comm_destroy")
+    if reduce is not None:
+        assert reduce.error is None and reduce.calls == 14 * n_frames, (reduce.error, reduce.calls)
+        reduce.close()
+    else:
+        hip.call("comm_destroy")
     if rank == 0:
         for r in range(1, world):
             assert torch.equal(gathered[0], gathered[r]), "replicas differ on rank %d" % r
