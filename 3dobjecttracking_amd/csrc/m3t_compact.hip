@@ -47,8 +47,9 @@ struct CompactTable {  // (address-space-3 pointers: ds_read, not flat loads)
   const __attribute__((address_space(3))) v2u* ab;
   const __attribute__((address_space(3))) uint16_t* rank;  // 3 + the number of mixed bins in front of the word
   const __attribute__((address_space(3))) float* small;    // [3 + cap]: the smaller float of the pair in slot i
-  const __attribute__((address_space(3))) uint8_t* meta;   // [3 + cap]: bit 7 = y is the smaller one, bits 0-3 = k + 8; 0xff = read the global table
+  const __attribute__((address_space(3))) uint8_t* meta;   // [3 + cap]: bit 7 = y is the smaller one, bits 0-3 = k + 8
   int cap;
+  bool fits;  // every mixed bin of this object has its slot (else the workgroup walks with the global table)
 };
 __device__ __forceinline__ uint8_t compact_pair_meta(float x, float y, float* smaller) {
   const bool y_small = y < x;
@@ -122,9 +123,9 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
           h[g][j] = hist[idx];
         }
       } else {
-        // all words of the batch first, then ONE pair read per sample -- slot 0 / 1 / 2 of the pair array hold the three
-        // constants, a mixed bin's pair sits at 3 + its rank: the slot is a select, not the value --; the rare mixed bin
-        // beyond the LDS budget takes the global table behind a wave vote
+        // all words of the batch first, then ONE pair per sample -- slot 0 / 1 / 2 of the pair array hold the three
+        // constants, a mixed bin's pair sits at 3 + its rank: the slot is a select, not the value.  (Every mixed bin of
+        // this object has its slot: a workgroup whose table does not hold them all walks with the global table.)
         v2u ab[GS][SCALE];
         uint32_t rk[GS][SCALE];
 #pragma unroll
@@ -138,8 +139,6 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
             ab[g][j] = table->ab[idx >> 5];
             rk[g][j] = table->rank[idx >> 5];  // 3 + the mixed bins in front of the word
           }
-        bool overflow = false;
-        const uint32_t last_slot = (uint32_t)table->cap + 2u;
         // the slot of every sample (its bit words and rank are dead after that) ...
 #pragma unroll
         for (int g = 0; g < GS; ++g)
@@ -148,19 +147,15 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
             const uint32_t bit = px[g][j] & 31u, a = (ab[g][j].x >> bit) & 1u, b = (ab[g][j].y >> bit) & 1u;
             const uint32_t r = rk[g][j] + (uint32_t)__builtin_popcount((ab[g][j].x & ab[g][j].y) & ((1u << bit) - 1u));
             const uint32_t state = a + 2u * b;  // 0: (0.5, 0.5), 1: (1, 0), 2: (0, 1), 3: mixed
-            const uint32_t slot = state == 3u ? r : state;
-            const bool beyond = slot > last_slot;
-            overflow = overflow || beyond;
-            rk[g][j] = beyond ? 0x80000000u : slot;
+            rk[g][j] = state == 3u ? r : state;
           }
         // ... the stored halves of all pairs of the batch ...
 #pragma unroll
         for (int g = 0; g < GS; ++g)
 #pragma unroll
           for (int j = 0; j < SCALE; ++j) {
-            const uint32_t at = rk[g][j] & 0x7fffffffu;
-            ab[g][j].x = __float_as_uint(table->small[at]);
-            ab[g][j].y = table->meta[at];
+            ab[g][j].x = __float_as_uint(table->small[rk[g][j]]);
+            ab[g][j].y = table->meta[rk[g][j]];
           }
         // ... and the pairs
 #pragma unroll
@@ -169,22 +164,12 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
           for (int j = 0; j < SCALE; ++j) {
             const float sm = __uint_as_float(ab[g][j].x);
             const uint32_t meta = ab[g][j].y;
-            const bool far = (rk[g][j] >> 31) != 0u || meta == 0xffu;
-            overflow = overflow || far;
             const float lg = __int_as_float(__float_as_int(1.0f - sm) + (int)(meta & 15u) - 8);
             v2f p;
             p.x = (meta & 0x80u) ? lg : sm;
             p.y = (meta & 0x80u) ? sm : lg;
             h[g][j] = p;
-            rk[g][j] = far ? 1u : 0u;
           }
-        if (__builtin_amdgcn_ballot_w64(overflow) != 0) {
-#pragma unroll
-          for (int g = 0; g < GS; ++g)
-#pragma unroll
-            for (int j = 0; j < SCALE; ++j)
-              if (rk[g][j]) h[g][j] = hist[px[g][j]];
-        }
       }
 #pragma unroll
       for (int g = 0; g < GS; ++g) {
@@ -237,7 +222,7 @@ __device__ __forceinline__ void compact_walk(G<uint8_t> image, uint32_t pitch, G
 // Builds the LDS table above from the modality's pair table (histogram_norm) and its occupancy bytes (one per group of
 // four bins, 0 = all four pairs are (0.5, 0.5)); 256 threads, thread t takes the words 4 t .. 4 t + 3 of 1024 (32 bins
 // each), so that the ranks follow from a scan over the threads.  Ends with a barrier.
-__device__ __forceinline__ void compact_stage_table(CRegion& m, float* lds_table, int n_words, int cap, float* misc,
+__device__ __forceinline__ bool compact_stage_table(CRegion& m, float* lds_table, int n_words, int cap, float* misc,
                                                     unsigned* overflow_word) {
   const int tid = threadIdx.x, nt = blockDim.x;
   v2u* ab = reinterpret_cast<v2u*>(lds_table);
@@ -322,11 +307,13 @@ __device__ __forceinline__ void compact_stage_table(CRegion& m, float* lds_table
   if (tid == nt - 1) wsum[8] = base;  // all mixed bins of the table
   __syncthreads();
   // ... then the pairs themselves, dealt out over all threads, four requests in flight each
+  bool bad_k = false;
   {
     const int n_stored = min(wsum[8], cap);
     G<v2f> norm = (G<v2f>)m.histogram_norm;
     for (int e0 = tid; e0 < n_stored; e0 += 4 * nt) {
       v2f pr[4];
+      // (bad_k below: a pair whose larger float is further than the four bits of k reach from 1 - smaller -- never seen)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (e0 + q * nt < n_stored) pr[q] = norm[slot_bin[3 + e0 + q * nt]];
@@ -334,16 +321,20 @@ __device__ __forceinline__ void compact_stage_table(CRegion& m, float* lds_table
       for (int q = 0; q < 4; ++q)
         if (e0 + q * nt < n_stored) {
           float sm;
-          meta[3 + e0 + q * nt] = compact_pair_meta(pr[q].x, pr[q].y, &sm);
+          const uint8_t mt = compact_pair_meta(pr[q].x, pr[q].y, &sm);
+          bad_k = bad_k || mt == 0xffu;
+          meta[3 + e0 + q * nt] = mt;
           small[3 + e0 + q * nt] = sm;
         }
     }
   }
-  // histograms whose mixed bins outgrow the table (long sequences): those lookups take the global table, and the host is
-  // told by how much, so that it can go back to the kernel without the table (no traffic while everything fits)
-  if (tid == nt - 1 && base > cap && overflow_word)
-    __hip_atomic_fetch_max(overflow_word, (unsigned)(base - cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __syncthreads();
+  // histograms whose mixed bins outgrow the table (long sequences): this workgroup walks with the global table, and the
+  // host is told by how much, so that it can go back to the kernel without the table (no traffic while everything fits)
+  const int total_mixed = wsum[8];
+  if (tid == nt - 1 && total_mixed > cap && overflow_word)
+    __hip_atomic_fetch_max(overflow_word, (unsigned)(total_mixed - cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool any_bad = __syncthreads_or(bad_k ? 1 : 0) != 0;
+  return total_mixed <= cap && !any_bad;
 }
 
 // RegionModality::CalculateCorrespondences (:390-465) for one object by one 256-thread workgroup, thread = line.
@@ -458,25 +449,25 @@ __device__ __forceinline__ int compact_region_correspondences(CRegion& m, CCam& 
     float* dist0 = state + CS_DIST0 * nl + line;
     const int bitshift = m.bitshift, bin_bits = 8 - m.bitshift;
     G<v2f> hist = (G<v2f>)m.histogram_norm;
+#define M3T_COMPACT_WALK(S, T) \
+  case S: compact_walk<S, T>(image, pitch, hist, bitshift, bin_bits, start, step, x0, horiz, reversed, lf, lb, dist0, nl, table); break;
+#define M3T_COMPACT_WALKS(T)                                                                                  \
+    switch (it.scale) {                                                                                       \
+      M3T_COMPACT_WALK(1, T) M3T_COMPACT_WALK(2, T) M3T_COMPACT_WALK(3, T) M3T_COMPACT_WALK(4, T) M3T_COMPACT_WALK(5, T) \
+      M3T_COMPACT_WALK(6, T) M3T_COMPACT_WALK(7, T) M3T_COMPACT_WALK(8, T) M3T_COMPACT_WALK(9, T)                 \
+      default: break; /* (the host does not choose this kernel for larger scales) */                          \
+    }
     if constexpr (TABLE) {
-    switch (it.scale) {
-#define M3T_COMPACT_WALK(S) \
-  case S: compact_walk<S, true>(image, pitch, hist, bitshift, bin_bits, start, step, x0, horiz, reversed, lf, lb, dist0, nl, table); break;
-      M3T_COMPACT_WALK(1) M3T_COMPACT_WALK(2) M3T_COMPACT_WALK(3) M3T_COMPACT_WALK(4) M3T_COMPACT_WALK(5)
-      M3T_COMPACT_WALK(6) M3T_COMPACT_WALK(7) M3T_COMPACT_WALK(8) M3T_COMPACT_WALK(9)
-#undef M3T_COMPACT_WALK
-      default: break;
-    }
+      if (table->fits) {  // (block-uniform: every mixed bin of this object has its slot in LDS)
+        M3T_COMPACT_WALKS(true)
+      } else {
+        M3T_COMPACT_WALKS(false)
+      }
     } else {
-    switch (it.scale) {
-#define M3T_COMPACT_WALK(S) \
-  case S: compact_walk<S>(image, pitch, hist, bitshift, bin_bits, start, step, x0, horiz, reversed, lf, lb, dist0, nl); break;
-      M3T_COMPACT_WALK(1) M3T_COMPACT_WALK(2) M3T_COMPACT_WALK(3) M3T_COMPACT_WALK(4) M3T_COMPACT_WALK(5)
-      M3T_COMPACT_WALK(6) M3T_COMPACT_WALK(7) M3T_COMPACT_WALK(8) M3T_COMPACT_WALK(9)
+      M3T_COMPACT_WALKS(false)
+    }
+#undef M3T_COMPACT_WALKS
 #undef M3T_COMPACT_WALK
-      default: break;  // (the host does not choose this kernel for larger scales)
-    }
-    }
     // normalisation :1628-1636 and CalculateDistributionMoments :1639-1658 (the thread reads back its own stores)
     float raw[12];
 #pragma unroll
