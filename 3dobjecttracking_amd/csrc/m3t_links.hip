@@ -63,7 +63,7 @@ struct TreeOptDev {
   int first_link;
 };
 #define M3T_TREE_GRANULES 64  /* granules per tracked link and slot (42 used) */
-#define M3T_TREE_LANE_FIELDS 5 /* per-lane constants of a structure (tree_tables) */
+#define M3T_TREE_LANE_FIELDS 9 /* per-lane constants of a structure (tree_tables) */
 // what the one-launch step's structure code (tracking_step_tree_kernel) is laid out for: a link per wave in the
 // system assembly, two lanes per link for the adjoints, four per link for exp(), a Jacobian column per lane
 #define M3T_TREE_FUSED_MAX_LINKS 16
@@ -111,7 +111,8 @@ __host__ __device__ inline size_t tree_work_floats(int n_links, int dof, int n_r
   size_t size = size_t(dof) + n_rows;
   return size_t(n_links) * (12 * dof + 42 + 72) + size * size + 4 * size + size_t(n_rows) * (dof + 1) + 2 * 6 * 6 + 64 +
          size_t(n_links) * (size_t(dof) * dof + dof) + dof +  // tree_system_block: per-link terms of A and b, Tikhonov vector
-         size_t(dof) * (dof + 1) / 2 + M3T_TREE_LANE_FIELDS * 64;  // tree_tables: (row, column) of the lower triangle's elements, per-lane constants
+         size_t(dof) * (dof + 1) / 2 + M3T_TREE_LANE_FIELDS * 64 +  // tree_tables: (row, column) of the lower triangle's elements, per-lane constants
+         size_t(n_links) * 12;  // ... and the inverse of a root's body2joint
 }
 
 __device__ inline void affine_to_array(const Affine& a, float* p) {
@@ -293,6 +294,7 @@ struct TreeWork {
   float *terms, *tikhonov;  // [n_links][dof * dof + dof], [dof] (tree_system_block)
   int* trans;
   int *lower, *lanes;       // [dof (dof + 1) / 2], [M3T_TREE_LANE_FIELDS][64] (tree_tables)
+  float* root_inverse;      // [n_links][12]: body2joint^-1 of a root, columns 0..2 | translation (tree_tables)
 };
 __device__ __forceinline__ TreeWork tree_carve(float* w, int n_links, int dof, int n_rows) {
   const int size = dof + n_rows;
@@ -312,6 +314,7 @@ __device__ __forceinline__ TreeWork tree_carve(float* w, int n_links, int dof, i
   t.tikhonov = t.terms + (size_t)n_links * ((size_t)dof * dof + dof);
   t.lower = reinterpret_cast<int*>(t.tikhonov + dof);
   t.lanes = t.lower + (size_t)dof * (dof + 1) / 2;
+  t.root_inverse = reinterpret_cast<float*>(t.lanes + M3T_TREE_LANE_FIELDS * 64);
   return t;
 }
 
@@ -449,10 +452,12 @@ __device__ __forceinline__ float row_lane(float v, int l) { return __int_as_floa
 // the swaps would have carried them.  A zero or NaN diagonal (first pivot invalid, or a NaN that the reference's
 // comparisons treat specially) takes the general routine.  ~8 k cycles instead of ~50 k for the 13 x 13 system of an
 // 8-body chain, where every step of the general routine pays several LDS round trips and barriers.
-template <int N, bool WAVE>
+// FULL: the caller stored BOTH triangles of the (symmetric) matrix -- the gather of P A P^T then needs no (larger, smaller)
+// index pair per element.
+template <int N, bool WAVE, bool FULL = false>
 __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float* temp, int* trans, int lane) {
   const bool row = lane < n;
-  float d = row ? fabsf(a[(size_t)lane * n + lane]) : 0.0f;
+  float d = row ? fabsf(a[(size_t)lane * n + lane]) : -1.0f;  // (a padded lane: below every |A(i,i)|)
   const bool bad = (d != d) || (__builtin_amdgcn_ballot_w64(row && d > 0.0f) == 0);
   if (__builtin_amdgcn_ballot_w64(row && bad) != 0) {  // uniform
     ldlt_solve_wave<WAVE>(a, x, n, temp, trans, lane);
@@ -461,24 +466,18 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
   // 1. the transposition sequence: position p holds input row src.  Eigen's selection (the first largest of the
   // rest, swapped to the front) leaves DISTINCT values in descending order whatever the swaps were: position p holds
   // the row of rank p, and the ranks take N broadcasts instead of n dependent wave-wide maxima.  Equal values are
-  // reordered by the swaps themselves: those take the selection step by step.
-  int src = lane;
+  // reordered by the swaps themselves: those take the selection step by step.  (Two rows with the same value have the
+  // same rank, so some position finds no row: that is the test for equal values.  Padded lanes rank behind all rows.)
   int rank = 0;
-  bool tie = false;
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    if (j < n) {  // uniform
-      const float dj = row_lane(d, j);
-      rank += dj > d ? 1 : 0;
-      tie = tie || (dj == d && j != lane);
-    }
-  }
-  const bool distinct = __builtin_amdgcn_ballot_w64(row && tie) == 0;
-  if (distinct) {
+  for (int j = 0; j < N; ++j) rank += row_lane(d, j) > d ? 1 : 0;
+  int src = -1;
 #pragma unroll
-    for (int j = 0; j < N; ++j)
-      if (j < n && row_lane(rank, j) == lane) src = j;
-  }
+  for (int j = 0; j < N; ++j)
+    if (row_lane(rank, j) == lane) src = j;
+  const bool distinct = __builtin_amdgcn_ballot_w64(row && src < 0) == 0;
+  if (!distinct) src = lane;
+  if (!row) src = 0;
 #pragma nounroll
   for (int k = 0; k < (distinct ? 0 : n); ++k) {
     const float key = (lane >= k && row) ? d : -1.0f;
@@ -493,11 +492,21 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
   }
   // 2. row `lane` of P A P^T (lower triangle; the input holds its lower triangle) and the permuted right-hand side
   float b[N];
+  if constexpr (FULL) {
+    // (the elements above the diagonal come along: they stay in their lane's registers and only ever feed each other)
+    const int srcn = src * n;
 #pragma unroll
-  for (int c = 0; c < N; ++c) {
-    const int sc = row_lane(src, c);
-    const int hi = src > sc ? src : sc, lo = src > sc ? sc : src;
-    b[c] = (row && c <= lane && c < n) ? a[(size_t)lo * n + hi] : 0.0f;
+    for (int c = 0; c < N; ++c) {
+      const float v = a[row_lane(srcn, c) + src];
+      b[c] = (row && c < n) ? v : 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      const int sc = row_lane(src, c);
+      const int hi = src > sc ? src : sc, lo = src > sc ? sc : src;
+      b[c] = (row && c <= lane && c < n) ? a[(size_t)lo * n + hi] : 0.0f;
+    }
   }
   float xp = row ? x[src] : 0.0f;
   // 3. factorisation, right-looking: as soon as column c is final, its term enters the running sums acc[k] of all
@@ -551,13 +560,13 @@ __device__ __forceinline__ void ldlt_solve_rows(float* a, float* x, int n, float
   if (row) x[src] = mine;
   tree_sync<WAVE>();
 }
-template <bool WAVE>
+template <bool WAVE, bool FULL = false>
 __device__ __forceinline__ void ldlt_solve_any(float* a, float* x, int n, float* temp, int* trans, int lane) {
   // lane: the caller's lane inside the wave that runs the solve (a parameter so that a caller can keep the compiler
   // from working its addresses out far ahead: tree_step_body)
-  if (n <= 8) ldlt_solve_rows<8, WAVE>(a, x, n, temp, trans, lane);
-  else if (n <= 13) ldlt_solve_rows<13, WAVE>(a, x, n, temp, trans, lane);  // (13: a free root and seven one-dof joints)
-  else if (n <= 16) ldlt_solve_rows<16, WAVE>(a, x, n, temp, trans, lane);
+  if (n <= 8) ldlt_solve_rows<8, WAVE, FULL>(a, x, n, temp, trans, lane);
+  else if (n <= 13) ldlt_solve_rows<13, WAVE, FULL>(a, x, n, temp, trans, lane);  // (13: a free root and seven one-dof joints)
+  else if (n <= 16) ldlt_solve_rows<16, WAVE, FULL>(a, x, n, temp, trans, lane);
   else ldlt_solve_wave<WAVE>(a, x, n, temp, trans, lane);
 }
 
@@ -1062,7 +1071,8 @@ __device__ __forceinline__ bool tree_solve(const TreeOptDev& o, LinkDev* links, 
 // CONSTRAINED = false leaves Constraint / SoftConstraint code out of the kernel altogether (a chain never runs it; in
 // round 4 its private arrays were 40 % of the kernel's scratch instructions).
 // ---------------------------------------------------------------------------
-enum { TL_COL_OWNER = 0, TL_COL_DIR = 1, TL_PARENT = 2, TL_QUAD_FIRST = 3, TL_QUAD_MASK = 4 };
+enum { TL_COL_OWNER = 0, TL_COL_DIR = 1, TL_PARENT = 2, TL_QUAD_FIRST = 3, TL_QUAD_MASK = 4, TL_JOINT = 5 /* .. 8 */ };
+static_assert(M3T_TREE_LANE_FIELDS == TL_JOINT + M3T_TREE_FUSED_MAX_LINKS / 4, "lane table: a joint row per four links");
 
 __device__ __forceinline__ void tree_wave_sync() { tree_sync_mode<1>(); }
 
@@ -1093,6 +1103,25 @@ __device__ __forceinline__ void tree_tables(const TreeOptDev& o, const LinkDev* 
     }
     w.lanes[TL_QUAD_FIRST * kWave + tid] = first;
     w.lanes[TL_QUAD_MASK * kWave + tid] = mask;
+    // a root's body2joint does not move while a kernel runs (Link::UpdatePoses link.cpp:226-230 moves link2world): its
+    // inverse once per launch, not once per Newton step
+    if (tid < n_links && links[tid].parent < 0) {
+      const Affine inv = inverse_pose(load_pose(links[tid].body2joint));
+      float* ri = w.root_inverse + (size_t)tid * 12;
+      for (int i = 0; i < 9; ++i) ri[i] = inv.l[i];
+      for (int i = 0; i < 3; ++i) ri[9 + i] = inv.t[i];
+    }
+    // the joint update (tree_solve_fast): link 4 pass + tid / 16 moves joint2parent (a fixed body2joint) or body2joint
+    for (int pass = 0; pass < M3T_TREE_FUSED_MAX_LINKS / 4; ++pass) {
+      const int li = pass * 4 + (tid >> 4);
+      int code = -1;
+      if (li < n_links && links[li].parent >= 0) {
+        const bool fixed = links[li].fixed_body2joint_pose != 0;
+        const float* M = fixed ? links[li].joint2parent : links[li].body2joint;
+        code = (int)(M - reinterpret_cast<const float*>(links)) * 2 + (fixed ? 1 : 0);
+      }
+      w.lanes[(TL_JOINT + pass) * kWave + tid] = code;
+    }
   }
   for (int e = tid; e < dof * dof; e += nt) {
     const int c = e / dof, r = e - c * dof;
@@ -1255,6 +1284,13 @@ __device__ __forceinline__ void tree_system_fast(const TreeOptDev& o, const Link
       __syncthreads();
     }
   }
+  // (row | column << 8 of the lane's first two terms: asked for in front of the H J products, not between them and the dots)
+  int rc_first[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int x = lane + q * kWave;
+    rc_first[q] = (x >= dof && x < stride) ? w.lower[x - dof] : x;
+  }
   for (int li = wave; li < n_links; li += n_waves) {
     const float* g = GH + (size_t)li * 42;
     const float* H = g + 6;
@@ -1268,32 +1304,62 @@ __device__ __forceinline__ void tree_system_fast(const TreeOptDev& o, const Link
       HJ[e] = sacc;
     }
     tree_wave_sync();
-    for (int x = lane; x < stride; x += kWave) {
+    // J^T g (x < dof: row x of J^T with g) and J^T (H J) (row r with column c of H J): ONE six-term dot for both kinds
+    for (int x = lane, q = 0; x < stride; x += kWave, ++q) {
+      const int rc = q < 2 ? (q == 0 ? rc_first[0] : rc_first[1]) : (x >= dof ? w.lower[x - dof] : x);
+      const int r = rc & 255, c = rc >> 8;
+      const float* pa = J + r * 6;
+      const float* pb = x < dof ? g : HJ + c * 6;
       float sacc = 0.0f;
-      if (x < dof) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) sacc += J[x * 6 + k] * g[k];
-      } else {
-        const int rc = w.lower[x - dof], r = rc & 255, c = rc >> 8;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sacc += J[r * 6 + k] * HJ[c * 6 + k];
-      }
+      for (int k = 0; k < 6; ++k) sacc += pa[k] * pb[k];
       w.terms[(size_t)li * stride + x] = sacc;
     }
   }
   PHASE_MARK(19);
+  // one thread per element adds the links' terms one after the other: b = sum, A = 0 - term - term ... (x - t is
+  // x + (-t) bit for bit, so both kinds of element run ONE loop), four terms asked for at a time; where the element
+  // goes and its Tikhonov value do not depend on the terms: fetched in front of the barrier
+  const int x0 = tid < stride ? tid : 0;
+  const bool is_b = x0 < dof;
+  int r0 = 0, c0 = 0;
+  float tikhonov = 0.0f;
+  if (!is_b) {
+    const int rc = w.lower[x0 - dof];
+    r0 = rc & 255; c0 = rc >> 8;
+    if (r0 == c0) tikhonov = w.tikhonov[c0];
+  }
   __syncthreads();
   PHASE_MARK(20);
   for (int x = tid; x < stride; x += nt) {
+    int r = r0, c = c0;
+    float tik = tikhonov;
+    if (x != x0) {  // (more elements than threads: not the fused kernels' shapes)
+      r = c = 0; tik = 0.0f;
+      if (x >= dof) {
+        const int rc = w.lower[x - dof];
+        r = rc & 255; c = rc >> 8;
+        if (r == c) tik = w.tikhonov[c];
+      }
+    }
+    const bool to_b = x < dof;
     float acc = 0.0f;
-    if (x < dof) {
-      for (int li = 0; li < n_links; ++li) acc += w.terms[(size_t)li * stride + x];
+    const int last = n_links - 1;
+#pragma nounroll
+    for (int l0 = 0; l0 < n_links; l0 += 4) {
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = w.terms[(size_t)(l0 + j < last ? l0 + j : last) * stride + x];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (l0 + j < n_links) acc += to_b ? t[j] : -t[j];  // uniform
+    }
+    if (to_b) {
       w.b[x] = acc;
     } else {
-      const int rc = w.lower[x - dof], r = rc & 255, c = rc >> 8;
-      for (int li = 0; li < n_links; ++li) acc -= w.terms[(size_t)li * stride + x];
-      if (r == c) acc += w.tikhonov[c];
+      if (r == c) acc += tik;
       w.A[(size_t)c * size + r] = acc;
+      if constexpr (!CONSTRAINED) w.A[(size_t)r * size + c] = acc;  // (ldlt_solve_rows<FULL> gathers from either triangle)
     }
   }
   __syncthreads();
@@ -1345,7 +1411,7 @@ __device__ __forceinline__ bool tree_solve_fast(const TreeOptDev& o, LinkDev* li
     }
   }
   PHASE_MARK(12);
-  ldlt_solve_any<true>(A, b, size, w.temp, w.trans, lane);
+  ldlt_solve_any<true, !CONSTRAINED>(A, b, size, w.temp, w.trans, lane);  // (tree_system_fast: both triangles)
   PHASE_MARK(13);
   int has_nan = 0;
   for (int i = lane; i < size; i += kWave) has_nan |= (b[i] != b[i]) ? 1 : 0;
@@ -1386,69 +1452,98 @@ __device__ __forceinline__ bool tree_solve_fast(const TreeOptDev& o, LinkDev* li
   };
   // the joints: joint2parent <- joint2parent * variation (fixed body2joint), or body2joint <- variation * body2joint;
   // twelve lanes per link (element (k, c) in lane 4 k + c of a row of sixteen), four links at a time
-  for (int base = 0; base < n_links; base += 4) {
-    const int li = base + (lane >> 4), q = lane & 15, k = q >> 2, kk = k < 3 ? k : 0;
-    if (li < n_links && links[li].parent >= 0) {  // (the same in all lanes of a row)
-      LinkDev& l = links[li];
+  // (which matrix a row of lanes updates comes from the lane table: no trip to the link's parent / fixed fields first)
+  for (int pass = 0; pass * 4 < n_links; ++pass) {
+    const int code = w.lanes[(TL_JOINT + pass) * kWave + lane];  // (offset of the matrix) * 2 + fixed, or -1
+    if (code >= 0) {  // (the same in all lanes of a row)
+      const int li = pass * 4 + (lane >> 4), k = (lane >> 2) & 3, kk = k < 3 ? k : 0;
       const float* v = var_all + (size_t)li * 12;
-      const bool fixed = l.fixed_body2joint_pose != 0;
-      float* M = fixed ? l.joint2parent : l.body2joint;
+      const bool fixed = (code & 1) != 0;
+      float* M = reinterpret_cast<float*>(links) + (code >> 1);
       const float m_own = M[qc * 4 + kk], m0 = M[qc * 4], m1 = M[qc * 4 + 1], m2 = M[qc * 4 + 2];
       const float v_own = v[qc * 3 + kk], v0 = v[qc * 3], v1 = v[qc * 3 + 1], v2 = v[qc * 3 + 2];
       const float r = fixed ? quadmul(m_own, v0, v1, v2) : quadmul(v_own, m0, m1, m2);
-      if (k < 3) M[qc * 4 + k] = r;
-      if (q < 4) M[q * 4 + 3] = q == 3 ? 1.0f : 0.0f;
+      M[qc * 4 + k] = k < 3 ? r : (qc == 3 ? 1.0f : 0.0f);
     }
   }
   tree_wave_sync();
   PHASE_MARK(21);
   // link2world, parents before children: (parent's link2world * joint2parent) * body2joint, left to right like the
-  // reference.  Twelve lanes hold a pose; a child whose parent was the previous link takes the parent's pose from the
-  // registers it was just formed in; the next link's joint poses are loaded before this link's pose is stored.
+  // reference.  Sixteen lanes hold a pose (element (k, c) in lane 4 k + c; the fourth group of four stores the constant
+  // bottom row); a child whose parent was the previous link takes the parent's pose from the registers it was just
+  // formed in.  The roots first (they depend on nothing but themselves), then ONE loop over the other links without a
+  // divergent branch: parents from the lane table, the next link's joint poses loaded before this link's products, one
+  // store per link.
   {
-    const int k = (lane >> 2) < 3 ? (lane >> 2) : 0, c = qc;
-    const bool holds = lane < 12;
-    // (volatile LDS loads + the scheduling barrier below: the compiler otherwise moves them to their use)
-    typedef const volatile __attribute__((address_space(3))) float* LdsVF;
-    typedef const volatile __attribute__((address_space(3))) int* LdsVI;
-    float d0, d1, d2, e0, e1, e2;
-    int parent;
-    auto fetch = [&](int li) {
-      LdsVF B1 = (LdsVF)links[li].joint2parent;
-      LdsVF B2 = (LdsVF)links[li].body2joint;
-      d0 = B1[c * 4]; d1 = B1[c * 4 + 1]; d2 = B1[c * 4 + 2];
-      e0 = B2[c * 4]; e1 = B2[c * 4 + 1]; e2 = B2[c * 4 + 2];
-      parent = *(LdsVI)&links[li].parent;
-    };
-    fetch(0);
+    const int k3 = lane >> 2, k = k3 < 3 ? k3 : 0, c = qc;
+    const int parents = w.lanes[TL_PARENT * kWave + lane];  // lane li: the parent of link li
     float cur = 0.0f;
     int cur_link = -2;
+    const float bottom = c == 3 ? 1.0f : 0.0f;
 #pragma nounroll
     for (int li = 0; li < n_links; ++li) {
+      if (__builtin_amdgcn_readlane(parents, li) >= 0) continue;  // uniform
+      // a root: link2world <- ((link2world * body2joint^-1) * variation) * body2joint (link.cpp:226-230)
       LinkDev& l = links[li];
-      const float f0 = d0, f1 = d1, f2 = d2, g0 = e0, g1 = e1, g2 = e2;
-      const int p = __builtin_amdgcn_readfirstlane(parent);
-      if (li + 1 < n_links) fetch(li + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      float result;
-      if (p >= 0) {
-        const float P = p == cur_link ? cur : links[p].link2world[c * 4 + k];
-        result = quadmul(quadmul(P, f0, f1, f2), g0, g1, g2);
-      } else {
-        // a root: link2world <- ((link2world * body2joint^-1) * variation) * body2joint (link.cpp:226-230)
-        const float* v = var_all + (size_t)li * 12;
-        const Affine inv = inverse_pose(load_pose(l.body2joint));
-        // (column c of the inverse by selects: an indexed private array would live in scratch memory)
-        const float i0 = c == 0 ? inv.l[0] : (c == 1 ? inv.l[3] : (c == 2 ? inv.l[6] : inv.t[0]));
-        const float i1 = c == 0 ? inv.l[1] : (c == 1 ? inv.l[4] : (c == 2 ? inv.l[7] : inv.t[1]));
-        const float i2 = c == 0 ? inv.l[2] : (c == 1 ? inv.l[5] : (c == 2 ? inv.l[8] : inv.t[2]));
-        const float T = l.link2world[c * 4 + k];
-        result = quadmul(quadmul(quadmul(T, i0, i1, i2), v[c * 3], v[c * 3 + 1], v[c * 3 + 2]), g0, g1, g2);
-      }
-      if (holds) l.link2world[c * 4 + k] = result;
-      if (lane < 4) l.link2world[lane * 4 + 3] = lane == 3 ? 1.0f : 0.0f;
+      const float* v = var_all + (size_t)li * 12;
+      const float* ri = w.root_inverse + (size_t)li * 12 + c * 3;  // column c of body2joint^-1 (tree_tables)
+      const float i0 = ri[0], i1 = ri[1], i2 = ri[2];
+      const float T = l.link2world[c * 4 + k];
+      const float g0 = l.body2joint[c * 4], g1 = l.body2joint[c * 4 + 1], g2 = l.body2joint[c * 4 + 2];
+      const float result = quadmul(quadmul(quadmul(T, i0, i1, i2), v[c * 3], v[c * 3 + 1], v[c * 3 + 2]), g0, g1, g2);
+      if (lane < 16) l.link2world[c * 4 + k3] = k3 < 3 ? result : bottom;
       cur = result;
       cur_link = li;
+    }
+    if (lane < 16) {
+      // Four links at a time: their joint poses are all asked for first, then four products in straight-line code (the
+      // LDS answers in order: the compiler's wait in front of a product is a count that leaves the later links' loads
+      // in flight; behind the uniform branches of a rolled, software-pipelined loop it drained the queue per link).
+      typedef const volatile __attribute__((address_space(3))) float* LdsVF;
+      const int last = n_links - 1;
+#pragma nounroll
+      for (int base = 0; base < n_links; base += 4) {
+        float J[4][3], B[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int li = base + j < last ? base + j : last;
+          LdsVF B1 = (LdsVF)links[li].joint2parent;
+          LdsVF B2 = (LdsVF)links[li].body2joint;
+          J[j][0] = B1[c * 4]; J[j][1] = B1[c * 4 + 1]; J[j][2] = B1[c * 4 + 2];
+          B[j][0] = B2[c * 4]; B[j][1] = B2[c * 4 + 1]; B[j][2] = B2[c * 4 + 2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (the four poses stay in registers until all four are formed -- a store in front of the next product would be
+        // waited for with it; a parent formed in this group that is not the previous link comes from those registers)
+        float res[4];
+        int formed = 0;  // bit j: res[j] holds link base + j
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int li = base + j;
+          const int p = li < n_links ? __builtin_amdgcn_readlane(parents, li) : -1;
+          res[j] = 0.0f;
+          if (p >= 0) {  // uniform
+            float P = cur;
+            if (p != cur_link) {
+              if (p >= base && ((formed >> (p - base)) & 1)) {
+                P = res[0];
+#pragma unroll
+                for (int i = 1; i < j; ++i) P = p == base + i ? res[i] : P;
+              } else {
+                P = links[p].link2world[c * 4 + k];
+              }
+            }
+            const float result = quadmul(quadmul(P, J[j][0], J[j][1], J[j][2]), B[j][0], B[j][1], B[j][2]);
+            res[j] = result;
+            formed |= 1 << j;
+            cur = result;
+            cur_link = li;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((formed >> j) & 1) links[base + j].link2world[c * 4 + k3] = k3 < 3 ? res[j] : bottom;
+      }
     }
     tree_wave_sync();
   }
@@ -1685,6 +1780,7 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
           const int t = idx / 42, i = idx - t * 42;
           if (t == st.tracked) continue;
           auto* g = slot + (size_t)t * M3T_TREE_GRANULES + i;
+          const int dst_link = o.tracked_links[t];  // (a global load: on its way while the granule is awaited, not after)
           unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           unsigned spins = 0;
           while (static_cast<uint32_t>(v >> 32) != tag) {
@@ -1696,7 +1792,7 @@ __device__ __forceinline__ void tree_step_body(const TreeStepDev* steps, const T
             __builtin_amdgcn_s_sleep(1);
             v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          gh_links[o.tracked_links[t] * 42 + i] = __int_as_float(static_cast<int>(static_cast<uint32_t>(v)));
+          gh_links[dst_link * 42 + i] = __int_as_float(static_cast<int>(static_cast<uint32_t>(v)));
         }
       }
       if (__syncthreads_or(timed_out ? 1 : 0)) {
