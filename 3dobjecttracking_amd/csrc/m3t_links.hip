@@ -1413,9 +1413,10 @@ __device__ __forceinline__ bool tree_solve_fast(const TreeOptDev& o, LinkDev* li
   PHASE_MARK(12);
   ldlt_solve_any<true, !CONSTRAINED>(A, b, size, w.temp, w.trans, lane);  // (tree_system_fast: both triangles)
   PHASE_MARK(13);
-  int has_nan = 0;
-  for (int i = lane; i < size; i += kWave) has_nan |= (b[i] != b[i]) ? 1 : 0;
-  if (__builtin_amdgcn_ballot_w64(has_nan != 0) != 0) return false;  // NaN guard optimizer.cpp:165
+  {  // NaN guard optimizer.cpp:165 (size <= M3T_TREE_FUSED_MAX_SIZE = the wave: one element per lane)
+    const float bl = b[lane < size ? lane : 0];
+    if (__builtin_amdgcn_ballot_w64(bl != bl) != 0) return false;
+  }
   // the variations of all links: four lanes per link, lane c < 3 of the group works out column c of
   // exp(skew(theta_r)) (colexpm3: the oracle's Expm3 operation for operation), lane 3 carries the translation
   float* var_all = w.AD;  // [n_links][12]: l[9] | t[3]
@@ -1499,7 +1500,11 @@ __device__ __forceinline__ bool tree_solve_fast(const TreeOptDev& o, LinkDev* li
       // Four links at a time: their joint poses are all asked for first, then four products in straight-line code (the
       // LDS answers in order: the compiler's wait in front of a product is a count that leaves the later links' loads
       // in flight; behind the uniform branches of a rolled, software-pipelined loop it drained the queue per link).
-      typedef const volatile __attribute__((address_space(3))) float* LdsVF;
+      // (a column of a pose is sixteen bytes at an eight-byte boundary of the link table: one ds_read2_b64)
+      typedef float Column __attribute__((ext_vector_type(4), aligned(8)));
+      typedef const volatile __attribute__((address_space(3))) Column* LdsVC;
+      static_assert(offsetof(LinkDev, joint2parent) % 8 == 0 && offsetof(LinkDev, body2joint) % 8 == 0 && sizeof(LinkDev) % 8 == 0,
+                    "pose columns of the link table at eight-byte boundaries");
       const int last = n_links - 1;
 #pragma nounroll
       for (int base = 0; base < n_links; base += 4) {
@@ -1507,10 +1512,10 @@ __device__ __forceinline__ bool tree_solve_fast(const TreeOptDev& o, LinkDev* li
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int li = base + j < last ? base + j : last;
-          LdsVF B1 = (LdsVF)links[li].joint2parent;
-          LdsVF B2 = (LdsVF)links[li].body2joint;
-          J[j][0] = B1[c * 4]; J[j][1] = B1[c * 4 + 1]; J[j][2] = B1[c * 4 + 2];
-          B[j][0] = B2[c * 4]; B[j][1] = B2[c * 4 + 1]; B[j][2] = B2[c * 4 + 2];
+          const Column cj = *(LdsVC)(links[li].joint2parent + c * 4);
+          const Column cb = *(LdsVC)(links[li].body2joint + c * 4);
+          J[j][0] = cj.x; J[j][1] = cj.y; J[j][2] = cj.z;
+          B[j][0] = cb.x; B[j][1] = cb.y; B[j][2] = cb.z;
         }
         __builtin_amdgcn_sched_barrier(0);
         // (the four poses stay in registers until all four are formed -- a store in front of the next product would be
