@@ -668,6 +668,19 @@ tracking_step_compact_kernel(const RigidOptDev* opts, const RegionModDev* rmods,
 #undef M3T_COMPACT_TABLE
 #undef M3T_COMPACT_GUARD
 }
+// ... with 512-thread workgroups, two per CU (the same registers and LDS per object): batches of at most two objects per CU
+// whose step is the depth scan -- sixteen lanes per point, 200 points: 12.5 rounds of a 256-thread workgroup, half of that here
+__global__ void __launch_bounds__(2 * M3T_COMPACT_THREADS, M3T_COMPACT_WAVES)
+tracking_step_compact_wide_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                                  const CameraDev* cams, float* body_poses, CompactLayout L, int iteration,
+                                  int n_corr_iterations, int n_update_iterations, int fuse_histogram) {
+  const RoiGuardArgs guard{};  // (unused)
+#define M3T_COMPACT_GUARD false
+#define M3T_COMPACT_TABLE false
+#include "m3t_compact_step.inc"
+#undef M3T_COMPACT_TABLE
+#undef M3T_COMPACT_GUARD
+}
 // ... reading frame slots that hold the trackers' rectangles only (ROI ingest)
 __global__ void __launch_bounds__(M3T_COMPACT_THREADS, M3T_COMPACT_WAVES)
 tracking_step_compact_guard_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,

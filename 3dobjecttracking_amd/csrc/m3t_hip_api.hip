@@ -1508,6 +1508,8 @@ int UploadTables(Ctx* ctx) {
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_compact_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_compact)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_compact_wide_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_compact)));
     if (ctx->lds_compact_table)
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_compact_table_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(ctx->lds_compact_table)));
@@ -3973,16 +3975,29 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
       compact_table = false;
     if (const char* e = std::getenv("M3T_HIP_COMPACT_TABLE")) compact_table = compact_table && std::atoi(e) != 0;
     if (compact_table) ctx->compact_table.table_overflow = ctx->table_overflow_dev;
+    // Batches with depth modalities: 512-thread workgroups, two per CU (round 6).  Their step is the depth scan -- sixteen
+    // lanes per point, 200 points: 12.5 rounds of a 256-thread workgroup, half of that here --, the registers and the LDS
+    // per object stay, 16 waves per CU instead of 12.  Measured (Region + Depth, YCB parameters, ms per step, 256 / 512
+    // threads): 257 objects 0.732 / 0.577, 512: 0.790 / 0.635, 640: 0.970 / 0.949, 700: 0.986 / 1.058, 768: 0.996 / 1.083,
+    // 900: 1.473 / 1.168, 1024: 1.567 / 1.216, 2048: 2.640 / 2.410, 4096: 5.097 / 4.736 -- the 256-thread kernel keeps the
+    // batches that are ONE round of its three workgroups per CU but not of two.  Region-only batches: 384 / 512 objects
+    // 0.314 / 0.295 and 0.324 / 0.306 ms, behind the LDS pair table's 0.286 / 0.292 -- not taken.
+    // M3T_HIP_COMPACT_WIDE=0 / 1: developer override.
+    bool compact_wide = compact && !roi_frames && !compact_table && !ctx->depth_mods.empty() &&
+                        !(2 * n > 5 * ctx->compute_cus && n <= 3 * ctx->compute_cus);
+    if (const char* e = std::getenv("M3T_HIP_COMPACT_WIDE"))
+      compact_wide = compact && !roi_frames && !compact_table && std::atoi(e) != 0;
     if (roi_frames)
       ctx->last_step_kernel = split ? "tracking_step_split_guard_kernel"
                                     : (compact ? "tracking_step_compact_guard_kernel"
                                                : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_guard_kernel" : "tracking_step_guard_kernel"));
     else
     ctx->last_step_kernel = split ? "tracking_step_split_kernel"
-                                  : (compact ? (compact_table ? "tracking_step_compact_table_kernel" : "tracking_step_compact_kernel")
+                                  : (compact ? (compact_table ? "tracking_step_compact_table_kernel"
+                                                              : (compact_wide ? "tracking_step_compact_wide_kernel" : "tracking_step_compact_kernel"))
                                              : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_kernel" : "tracking_step_kernel"));
     if (compact) {
-      threads = M3T_COMPACT_THREADS;
+      threads = compact_wide ? 2 * M3T_COMPACT_THREADS : M3T_COMPACT_THREADS;
       histogram_fused = want_fused_histogram && ctx->compact_fuses_histogram;
     } else if (split) {
       histogram_fused = want_fused_histogram;
@@ -4013,6 +4028,11 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
           hipLaunchKernelGGL(tracking_step_compact_table_kernel, dim3(n), dim3(threads), ctx->lds_compact_table, ctx->stream,
                              ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                              ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->compact_table,
+                             iteration, ctx->n_corr_iterations, ctx->n_update_iterations, histogram_fused ? 1 : 0);
+        else if (compact_wide)
+          hipLaunchKernelGGL(tracking_step_compact_wide_kernel, dim3(n), dim3(threads), ctx->lds_compact, ctx->stream,
+                             ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
+                             ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(), ctx->compact,
                              iteration, ctx->n_corr_iterations, ctx->n_update_iterations, histogram_fused ? 1 : 0);
         else
           hipLaunchKernelGGL(tracking_step_compact_kernel, dim3(n), dim3(threads), ctx->lds_compact, ctx->stream,

@@ -212,14 +212,17 @@ def test_compact_table_overflow_takes_the_global_table_and_tells_the_host(rbot64
             os.environ.pop(k, None)
 
 
-def test_compact_kernel_region_and_depth():
+@pytest.mark.parametrize("wide,kernel,threads", [("0", "tracking_step_compact_kernel", 256),
+                                                 ("1", "tracking_step_compact_wide_kernel", 512)])
+def test_compact_kernel_region_and_depth(wide, kernel, threads):
     """the same for Region + Depth objects with measured occlusions (YCB parameters, 16 bins: the histogram update
-    rides in the launch)"""
+    rides in the launch), with 256-thread workgroups and with the 512-thread ones batches with depth modalities take"""
     inputs = scenes.Inputs(21, 5, n_divides=4, n_models=6, with_depth=True)
     ref, ref_hist = oracle_trajectory(inputs, use_depth=True)
-    got, hist, shape = hip_trajectory(inputs, use_depth=True, env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1"},
-                                      want_kernel="tracking_step_compact_kernel")
-    assert shape == [21, 1, 256, 1]
+    got, hist, shape = hip_trajectory(inputs, use_depth=True,
+                                      env={"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1", "M3T_HIP_COMPACT_WIDE": wide},
+                                      want_kernel=kernel)
+    assert shape == [21, 1, threads, 1]
     for k in range(inputs.n_frames):
         assert np.array_equal(got[k], ref[k]), k
     for (fa, ba), (fb, bb) in zip(hist, ref_hist):
@@ -227,7 +230,8 @@ def test_compact_kernel_region_and_depth():
 
 
 @pytest.mark.parametrize("env,kernel,shape", [
-    ({}, "tracking_step_compact_kernel", [512, 1, 256, 1]),
+    ({}, "tracking_step_compact_wide_kernel", [512, 1, 512, 1]),
+    ({"M3T_HIP_COMPACT_WIDE": "0"}, "tracking_step_compact_kernel", [512, 1, 256, 1]),
     ({"M3T_HIP_COMPACT": "0"}, "tracking_step_lds_kernel", [512, 1, 512, 1])])
 def test_synth512_batch_matches_the_oracle(env, kernel, shape):
     """BASELINE configs[3] at its stated size on one GPU: bench.py --config synth512's own inputs (64 rendered Region +
