@@ -39,7 +39,7 @@ NAMES = {
     12: "  solve: constraint rows", 13: "  solve: LDL^T", 14: "  solve: exp() of the variations",
     15: "  solve: link2world down the tree",
     19: "  system: H J + the link's terms (wave per link)", 20: "  system: barrier (the slowest wave)",
-    21: "  solve: joints (twelve lanes per link)",
+    21: "  solve: joints (sixteen lanes per link)",
     26: "histogram update (tail)", 27: "  tail: view", 28: "  tail: occlusion windows", 29: "  tail: pixel walk",
 }
 ORDER = [0, 1, 2, 7, 8, 9, 10, 11, 3, 4, 5, 17, 18, 23, 22, 30, 19, 20, 31, 12, 13, 14, 21, 15, 26, 27, 28, 29]
