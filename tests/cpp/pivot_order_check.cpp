@@ -58,6 +58,34 @@ int main() {
     std::stable_sort(b.begin(), b.end(), [&](int x, int y) { return d[x] > d[y]; });
     ties_that_differ += a != b;
   }
+  // round 6: the kernel's test for equal values -- two rows with the same value share a rank, so some position finds no
+  // row -- and its padding (lanes behind the n rows hold -1: they rank behind every row and take no position below n)
+  long long detection_errors = 0;
+  for (int it = 0; it < 200000; ++it) {
+    const int n = 1 + (int)(rng() % 16), N = 16;
+    std::vector<float> d(N, -1.0f);
+    const bool coarse = (rng() & 1) != 0;
+    for (int i = 0; i < n; ++i) d[i] = coarse ? (float)(rng() % 5) : uni(rng);
+    bool ties = false;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < i; ++j) ties = ties || d[i] == d[j];
+    std::vector<int> src(N, -1);
+    for (int lane = 0; lane < N; ++lane) {
+      int rank = 0;
+      for (int j = 0; j < N; ++j) rank += d[j] > d[lane] ? 1 : 0;
+      for (int p = 0; p < N; ++p)  // "if (row_lane(rank, j) == lane) src = j", seen from position p
+        if (rank == p) src[p] = lane;
+    }
+    bool unfilled = false;
+    for (int p = 0; p < n; ++p) unfilled = unfilled || src[p] < 0;
+    detection_errors += unfilled != ties;
+    if (!ties) {
+      std::vector<float> rows(d.begin(), d.begin() + n);
+      std::vector<int> want = by_selection(rows);
+      for (int p = 0; p < n; ++p) detection_errors += src[p] != want[p];
+    }
+  }
   std::printf("cases %lld mismatches %lld ties_that_differ %lld\n", cases, mismatches, ties_that_differ);
-  return mismatches == 0 ? 0 : 1;
+  if (detection_errors) std::printf("tie detection errors %lld\n", detection_errors);
+  return mismatches == 0 && detection_errors == 0 ? 0 : 1;
 }
