@@ -50,7 +50,7 @@ def kernel_of(api):
 
 def hip_trajectory(inputs, use_depth=False, env=None, want_kernel=None):
     for k in ("M3T_HIP_NO_SPLIT", "M3T_HIP_SPLIT_PARTS", "M3T_HIP_THREADS", "M3T_HIP_COMPACT", "M3T_HIP_COMPACT_TABLE",
-              "M3T_HIP_COMPACT_TABLE_KB"):
+              "M3T_HIP_COMPACT_TABLE_KB", "M3T_HIP_COMPACT_WIDE"):
         os.environ.pop(k, None)
     os.environ.update(env or {})
     try:
@@ -227,6 +227,31 @@ def test_compact_kernel_region_and_depth(wide, kernel, threads):
         assert np.array_equal(got[k], ref[k]), k
     for (fa, ba), (fb, bb) in zip(hist, ref_hist):
         assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+
+
+@pytest.mark.parametrize("wide,kernel,threads", [("0", "tracking_step_compact_kernel", 256),
+                                                 ("1", "tracking_step_compact_wide_kernel", 512)])
+def test_compact_kernels_depth_only(wide, kernel, threads):
+    """objects that carry a DepthModality alone (no lines: every thread of either workgroup size scans points)"""
+    inputs = scenes.Inputs(9, 4, n_divides=4, n_models=3, with_depth=True)
+    ora, api_env = util.open_oracle(), {"M3T_HIP_COMPACT": "1", "M3T_HIP_NO_SPLIT": "1", "M3T_HIP_COMPACT_WIDE": wide}
+    b = scenes.Instance(ora, inputs, use_region=False, use_depth=True)
+    os.environ.update(api_env)
+    try:
+        api = util.open_hip()
+        a = scenes.Instance(api, inputs, use_region=False, use_depth=True)
+        for inst in (a, b):
+            inst.upload_frame(0)
+            assert inst.tracker.StartModalities(0)
+        for k in range(inputs.n_frames):
+            for inst in (a, b):
+                inst.upload_frame(k)
+                assert inst.tracker.ExecuteTrackingStep(k)
+            assert np.array_equal(np.stack(a.poses()), np.stack(b.poses())), k
+        assert kernel_of(api) == kernel and shape_of(api)[:3] == [9, 1, threads], (kernel_of(api), shape_of(api))
+    finally:
+        for k in api_env:
+            os.environ.pop(k, None)
 
 
 @pytest.mark.parametrize("env,kernel,shape", [
