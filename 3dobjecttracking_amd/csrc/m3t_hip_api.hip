@@ -1521,6 +1521,11 @@ int UploadTables(Ctx* ctx) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_split_render_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
+    for (const void* pair_kernel : {reinterpret_cast<const void*>(tracking_step_split_pair_kernel),
+                                    reinterpret_cast<const void*>(tracking_step_pair_kernel),
+                                    reinterpret_cast<const void*>(tracking_step_lds_pair_kernel)})
+      HIPCHK(hipFuncSetAttribute(pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, int(std::max(ctx->lds_track, ctx->lds_hist))));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(tracking_step_lds_kernel),
@@ -3929,7 +3934,12 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     int threads = M3T_BLOCK_THREADS;
     if (n >= 2 * ctx->compute_cus && ctx->lds_track * 2 <= 160 * 1024) threads = M3T_BLOCK_THREADS / 2;
     if (const char* e = std::getenv("M3T_HIP_THREADS")) threads = std::atoi(e);  // developer override
-    auto kernel = ctx->layout.off_hist >= 0 ? tracking_step_lds_kernel : tracking_step_kernel;
+    // Batches with region AND depth modalities: the _pair_ kernels (m3t_kernels.hip, PAIR: the two modalities' products
+    // side by side, their sums on two waves).  M3T_HIP_NO_PAIR: developer override.
+    const bool pair = !roi_frames && !ctx->region_mods.empty() && !ctx->depth_mods.empty() && !std::getenv("M3T_HIP_NO_PAIR");
+    auto split_kernel = pair ? tracking_step_split_pair_kernel : tracking_step_split_kernel;
+    auto kernel = pair ? (ctx->layout.off_hist >= 0 ? tracking_step_lds_pair_kernel : tracking_step_pair_kernel)
+                       : (ctx->layout.off_hist >= 0 ? tracking_step_lds_kernel : tracking_step_kernel);
     // One workgroup per CU: the histogram update (CalculateResults) runs at the end of the same launch, its
     // count table taking over the line buffers' LDS.  With two workgroups per CU that table (128 KB at 32 bins)
     // would not fit twice, so large batches keep the separate region_histogram_kernel.
@@ -3944,7 +3954,8 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
     if (ctx->split_possible && ctx->split_enabled && threads % M3T_SPLIT_LANES == 0 &&
         ctx->n_corr_iterations < 64 && !std::getenv("M3T_HIP_NO_SPLIT"))
       parts = roi_frames ? ChooseSplitParts(ctx, tracking_step_split_guard_kernel, n, threads, want_fused_histogram, &lds_split)
-                         : ChooseSplitParts(ctx, tracking_step_split_kernel, n, threads, want_fused_histogram, &lds_split);
+                         : ChooseSplitParts(ctx, split_kernel, n, threads,
+                                            want_fused_histogram, &lds_split);
     const bool split = parts >= 2;
     // More objects than CUs: the compact kernel (<= 47 KB of LDS, <= 128 VGPRs per object: 3-4 workgroups per CU;
     // measured crossover on 256 CUs: 256 objects 0.249 vs 0.225 ms with one 512-thread workgroup per CU, 384 objects
@@ -3992,10 +4003,11 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
                                     : (compact ? "tracking_step_compact_guard_kernel"
                                                : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_guard_kernel" : "tracking_step_guard_kernel"));
     else
-    ctx->last_step_kernel = split ? "tracking_step_split_kernel"
+    ctx->last_step_kernel = split ? (pair ? "tracking_step_split_pair_kernel" : "tracking_step_split_kernel")
                                   : (compact ? (compact_table ? "tracking_step_compact_table_kernel"
                                                               : (compact_wide ? "tracking_step_compact_wide_kernel" : "tracking_step_compact_kernel"))
-                                             : (ctx->layout.off_hist >= 0 ? "tracking_step_lds_kernel" : "tracking_step_kernel"));
+                                             : (ctx->layout.off_hist >= 0 ? (pair ? "tracking_step_lds_pair_kernel" : "tracking_step_lds_kernel")
+                                                                          : (pair ? "tracking_step_pair_kernel" : "tracking_step_kernel")));
     if (compact) {
       threads = compact_wide ? 2 * M3T_COMPACT_THREADS : M3T_COMPACT_THREADS;
       histogram_fused = want_fused_histogram && ctx->compact_fuses_histogram;
@@ -4049,7 +4061,7 @@ int m3t_hip_execute_tracking_step(m3t_hip_context* ctx, int iteration) {
                              ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,
                              ctx->n_update_iterations, ctx->fused_mode == 2 ? 1 : 0, histogram_fused ? 1 : 0, sp, guard);
         else
-          hipLaunchKernelGGL(tracking_step_split_kernel, dim3((n + 7) / 8 * 8 * parts), dim3(threads), lds_split, ctx->stream,
+          hipLaunchKernelGGL(split_kernel, dim3((n + 7) / 8 * 8 * parts), dim3(threads), lds_split, ctx->stream,
                              ctx->d_opts.as<RigidOptDev>(), ctx->d_region.as<RegionModDev>(),
                              ctx->d_depth.as<DepthModDev>(), ctx->cams_active, ctx->d_poses.as<float>(),
                              ctx->layout, ctx->off_points, ctx->np_max, iteration, ctx->n_corr_iterations,

@@ -1361,9 +1361,10 @@ __device__ __forceinline__ void chain_sums(const float* rows_a, int pitch_a, int
 // RegionModality::CalculateGradientAndHessian (:485-558), the per-line part: one thread per line slot
 // writes the line's 27 products to rows[row * pitch + line] (zeros for slots that do not contribute).
 // ---------------------------------------------------------------------------
+// (tid0 / nt0: the threads that take part -- all of the workgroup, or the half that works beside depth_products' half)
 __device__ __forceinline__ void region_products(CRegion& m, CCam& cam, const Affine& b2c, int corr_iteration, int opt_iteration,
-                                const Lds& s, float* rows, int pitch) {
-  const int tid = threadIdx.x, nt = blockDim.x, nl = s.nl;
+                                const Lds& s, float* rows, int pitch, int tid0 = -1, int nt0 = 0) {
+  const int tid = tid0 >= 0 ? tid0 : (int)threadIdx.x, nt = tid0 >= 0 ? nt0 : (int)blockDim.x, nl = s.nl;
   const RegionIter it = region_iter(m, corr_iteration);
   const int slots = chain_slots(nl);
   for (int line = tid; line < slots; line += nt) {
@@ -2347,8 +2348,8 @@ __device__ __forceinline__ void depth_correspondences(CDepth& m, CCam& cam, cons
 // DepthModality::CalculateGradientAndHessian (depth_modality.cpp:333-381), the per-point part: one thread per
 // point slot writes the point's 27 products to rows[row * pitch + point] (see chain_sums above).
 __device__ __forceinline__ void depth_products(CDepth& m, const Affine& b2c, int corr_iteration, const float* ps, int np, float* rows,
-                               int pitch) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+                               int pitch, int tid0 = -1, int nt0 = 0) {
+  const int tid = tid0 >= 0 ? tid0 : (int)threadIdx.x, nt = tid0 >= 0 ? nt0 : (int)blockDim.x;
   const Affine c2b = inverse_pose(b2c);
   const float standard_deviation = last_valid(m.standard_deviations, m.n_standard_deviations, corr_iteration);
   const int slots = chain_slots(np);
@@ -3013,7 +3014,13 @@ struct SplitParams {               // tracking_step_split_kernel: n_parts workgr
 };
 
 extern "C++" {
-template <bool HIST_LDS, bool SPLIT = false, bool RENDER = !SPLIT, bool GUARD = false>
+// PAIR (round 6; the _pair_ kernels, for batches whose bodies carry a RegionModality AND a DepthModality): per Newton step
+// the lines' products by the first half of the workgroup BESIDE the points' products by the second (one round instead of
+// two: 200 lines and 200 points never fill 512 threads one after the other), and the two modalities' sums on two waves --
+// each in the reference's order, added like Link::CalculateGradientAndHessian adds them.  A template parameter, not a
+// run-time choice: the Region-only step keeps its machine code (with the choice inside, tracking_step_split_kernel went
+// from 234 to 241 VGPRs and the 64-object headline from 0.149 to 0.151 ms).
+template <bool HIST_LDS, bool SPLIT = false, bool RENDER = !SPLIT, bool GUARD = false, bool PAIR = false>
 __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
@@ -3158,6 +3165,22 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
     for (int u = 0; u < n_update_iterations; ++u) {
       PHASE_T0();
       const Affine b2w = load_pose(pose);
+      bool side_by_side = false;
+      float sum_early = 0.0f;
+      if constexpr (PAIR) {
+        const int half = (int)blockDim.x >> 1;
+        side_by_side = rm && dm && (half & (kWave - 1)) == 0 && chain_slots(s.nl) <= half && chain_slots(np) <= half;
+        if (side_by_side) {
+          if ((int)threadIdx.x < half) {
+            const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
+            region_products(*rm, *cam, b2c, c, u, s, rows_r, layout.pitch_r, (int)threadIdx.x, half);
+          } else {
+            const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
+            depth_products(*dm, b2c, c, ps, np, rows_d, layout.pitch_d, (int)threadIdx.x - half, half);
+          }
+        }
+      }
+      if (!side_by_side) {
       if (rm) {
         const Affine b2c = mul_pose(load_pose(cam->world2camera), b2w);
         region_products(*rm, *cam, b2c, c, u, s, rows_r, layout.pitch_r);
@@ -3166,10 +3189,24 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         const Affine b2c = mul_pose(load_pose(dcam->world2camera), b2w);
         depth_products(*dm, b2c, c, ps, np, rows_d, layout.pitch_d);
       }
+      }
       __syncthreads();
 #ifdef M3T_PHASE_TIMING
       if (u == 0) { PHASE_MARK(5); } else { PHASE_MARK(24); }
 #endif
+      if constexpr (PAIR) {
+        if (side_by_side) {  // the lines' sums by the first wave, the points' by the second (handed over in LDS)
+          if (threadIdx.x < 2 * kWave) {
+            const bool second = threadIdx.x >= kWave;
+            const int lane = (int)threadIdx.x & (kWave - 1);
+            float unused = 0.0f;
+            chain_sums(second ? rows_d : rows_r, second ? layout.pitch_d : layout.pitch_r, chain_slots(second ? np : s.nl),
+                       nullptr, 0, 0, gh_lane_row(lane < 42 ? lane : 0), sum_early, unused);
+            if (second && lane < 42) gh_depth[lane] = sum_early;
+          }
+          __syncthreads();
+        }
+      }
 #ifdef M3T_TREE_SUMS
       // EXPERIMENT (tools/variants, never the product): the g/H sums as north_star literally
       // prescribes them -- LDS + wavefront tree reductions -- instead of the reference-order chain: 16 lanes per
@@ -3199,8 +3236,13 @@ __device__ __forceinline__ void tracking_step_body(const RigidOptDev* opts, cons
         sum_r = rm ? tree_r[gh_lane_row(threadIdx.x < 42 ? threadIdx.x : 0)] : 0.0f;
         sum_d = dm ? tree_d[gh_lane_row(threadIdx.x < 42 ? threadIdx.x : 0)] : 0.0f;
 #else
-        chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
-                   chain_slots(np), gh_lane_row(threadIdx.x < 42 ? threadIdx.x : 0), sum_r, sum_d);
+        if (PAIR && side_by_side) {
+          sum_r = sum_early;
+          sum_d = gh_depth[threadIdx.x < 42 ? threadIdx.x : 0];
+        } else {
+          chain_sums(rm ? rows_r : nullptr, layout.pitch_r, chain_slots(s.nl), dm ? rows_d : nullptr, layout.pitch_d,
+                     chain_slots(np), gh_lane_row(threadIdx.x < 42 ? threadIdx.x : 0), sum_r, sum_d);
+        }
 #endif
         float gh = 0.0f;  // Link::CalculateGradientAndHessian link.cpp:184-193
         if (rm) gh += sum_r;
@@ -3298,6 +3340,35 @@ tracking_step_split_kernel(const RigidOptDev* opts, const RegionModDev* rmods, c
                      int fuse_histogram, SplitParams split) {
   tracking_step_body<false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
                                   n_corr_iterations, n_update_iterations, write_state, fuse_histogram, &split);
+}
+
+// Bodies with a RegionModality and a DepthModality: the same three kernels with PAIR (tracking_step_body): ycb21 0.157 ->
+// 0.143 ms per step, 64 / 128 / 256 Region + Depth objects 0.207 / 0.295 / 0.429 -> 0.193 / 0.281 / 0.415
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_pair_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int fuse_histogram, int first_corr_iteration) {
+  tracking_step_body<false, false, false, false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
+                                                       n_corr_iterations, n_update_iterations, write_state, fuse_histogram,
+                                                       nullptr, first_corr_iteration);
+}
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_lds_pair_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int fuse_histogram, int first_corr_iteration) {
+  tracking_step_body<true, false, false, false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
+                                                      n_corr_iterations, n_update_iterations, write_state, fuse_histogram,
+                                                      nullptr, first_corr_iteration);
+}
+__global__ void __launch_bounds__(M3T_BLOCK_THREADS)
+tracking_step_split_pair_kernel(const RigidOptDev* opts, const RegionModDev* rmods, const DepthModDev* dmods,
+                     const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
+                     int iteration, int n_corr_iterations, int n_update_iterations, int write_state,
+                     int fuse_histogram, SplitParams split) {
+  tracking_step_body<false, true, false, false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration,
+                                                      n_corr_iterations, n_update_iterations, write_state, fuse_histogram, &split);
 }
 
 // ROI ingest: the same three kernels with the guard compiled in (frame slots that hold the trackers' rectangles only;

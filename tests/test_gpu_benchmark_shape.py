@@ -50,7 +50,7 @@ def kernel_of(api):
 
 def hip_trajectory(inputs, use_depth=False, env=None, want_kernel=None):
     for k in ("M3T_HIP_NO_SPLIT", "M3T_HIP_SPLIT_PARTS", "M3T_HIP_THREADS", "M3T_HIP_COMPACT", "M3T_HIP_COMPACT_TABLE",
-              "M3T_HIP_COMPACT_TABLE_KB", "M3T_HIP_COMPACT_WIDE"):
+              "M3T_HIP_COMPACT_TABLE_KB", "M3T_HIP_COMPACT_WIDE", "M3T_HIP_NO_PAIR"):
         os.environ.pop(k, None)
     os.environ.update(env or {})
     try:
@@ -99,12 +99,15 @@ def test_headline_batch_in_the_other_launch_shapes(rbot64):
             assert np.array_equal(got[k], ref[k]), (env, k)
 
 
-def test_ycb_batch_is_bit_identical_to_the_oracle():
+@pytest.mark.parametrize("env,kernel", [({}, "tracking_step_split_pair_kernel"),
+                                        ({"M3T_HIP_NO_PAIR": "1"}, "tracking_step_split_kernel")])
+def test_ycb_batch_is_bit_identical_to_the_oracle(env, kernel):
     """BASELINE configs[2]: 21 objects, Region + Depth fused modalities, YCB parameters (evaluate_ycb_dataset.cpp:46-76,
-    108-133), 2562-view models; 8 workgroups per object (168 CUs)"""
+    108-133), 2562-view models; 8 workgroups per object (168 CUs).  Through the _pair_ kernel bodies with both modalities
+    take (the lines' and the points' products side by side, their sums on two waves) and through the plain one."""
     inputs = scenes.Inputs(21, 5, n_divides=4, n_models=6, with_depth=True)
     ref, ref_hist = oracle_trajectory(inputs, use_depth=True)
-    got, hist, shape = hip_trajectory(inputs, use_depth=True)
+    got, hist, shape = hip_trajectory(inputs, use_depth=True, env=env, want_kernel=kernel)
     assert shape[:3] == [21, 8, 512]
     for k in range(inputs.n_frames):
         assert np.array_equal(got[k], ref[k]), k
@@ -257,7 +260,8 @@ def test_compact_kernels_depth_only(wide, kernel, threads):
 @pytest.mark.parametrize("env,kernel,shape", [
     ({}, "tracking_step_compact_wide_kernel", [512, 1, 512, 1]),
     ({"M3T_HIP_COMPACT_WIDE": "0"}, "tracking_step_compact_kernel", [512, 1, 256, 1]),
-    ({"M3T_HIP_COMPACT": "0"}, "tracking_step_lds_kernel", [512, 1, 512, 1])])
+    ({"M3T_HIP_COMPACT": "0"}, "tracking_step_lds_pair_kernel", [512, 1, 512, 1]),
+    ({"M3T_HIP_COMPACT": "0", "M3T_HIP_NO_PAIR": "1"}, "tracking_step_lds_kernel", [512, 1, 512, 1])])
 def test_synth512_batch_matches_the_oracle(env, kernel, shape):
     """BASELINE configs[3] at its stated size on one GPU: bench.py --config synth512's own inputs (64 rendered Region +
     Depth streams of 16 distinct 2562-view models, spread over 512 objects with their own cameras, frames and
