@@ -3401,7 +3401,7 @@ tracking_step_split_guard_kernel(const RigidOptDev* opts, const RegionModDev* rm
                                                0, &guard);
 }
 
-// the same with the renderer-fed branches compiled in, one correspondence search per launch (the host redraws the
+// the same with the renderer-fed branches compiled in (and PAIR: 1 object 0.570 -> 0.545 ms per step, 64 objects 1.209 -> 1.181), one correspondence search per launch (the host redraws the
 // focused renderings between the searches): round 4 -- the renderer-fed step of a small batch was ONE workgroup per
 // object (87 us per search for the reference's test scene)
 __global__ void __launch_bounds__(M3T_BLOCK_THREADS)
@@ -3409,8 +3409,8 @@ tracking_step_split_render_kernel(const RigidOptDev* opts, const RegionModDev* r
                      const CameraDev* cams, float* body_poses, TrackLdsLayout layout, int off_points, int np,
                      int iteration, int n_update_iterations, int write_state, int first_corr_iteration,
                      SplitParams split) {
-  tracking_step_body<false, true, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, 1,
-                                        n_update_iterations, write_state, 0, &split, first_corr_iteration);
+  tracking_step_body<false, true, true, false, true>(opts, rmods, dmods, cams, body_poses, layout, off_points, np, iteration, 1,
+                                                     n_update_iterations, write_state, 0, &split, first_corr_iteration);
 }
 
 // Test hook (m3t_hip_debug_log_checksum): the logarithm exactly as region_products takes it -- m3t_log_fast on the
