@@ -1472,9 +1472,9 @@ __device__ __forceinline__ bool tree_solve_fast(const TreeOptDev& o, LinkDev* li
   // link2world, parents before children: (parent's link2world * joint2parent) * body2joint, left to right like the
   // reference.  Sixteen lanes hold a pose (element (k, c) in lane 4 k + c; the fourth group of four stores the constant
   // bottom row); a child whose parent was the previous link takes the parent's pose from the registers it was just
-  // formed in.  The roots first (they depend on nothing but themselves), then ONE loop over the other links without a
-  // divergent branch: parents from the lane table, the next link's joint poses loaded before this link's products, one
-  // store per link.
+  // formed in.  The roots first (they depend on nothing but themselves), then the other links four at a time without a
+  // divergent branch: parents from the lane table, the four links' joint poses loaded before the first product, the four
+  // stores behind the last.
   {
     const int k3 = lane >> 2, k = k3 < 3 ? k3 : 0, c = qc;
     const int parents = w.lanes[TL_PARENT * kWave + lane];  // lane li: the parent of link li
