@@ -214,7 +214,11 @@ class Instance:
     """The object graph of `inputs` behind one C-ABI context (HIP or oracle)."""
 
     def __init__(self, api, inputs, region_params=None, depth_params=None, tracker_params=None, use_region=True,
-                 use_depth=False):
+                 use_depth=False, kinds=None):
+        # kinds (optional): per object "rd" | "r" | "d" -- which modalities the body carries (default: use_region / use_depth
+        # for all of them)
+        if kinds is not None:
+            use_region, use_depth = any("r" in k for k in kinds), any("d" in k for k in kinds)
         self.api = api
         self.inputs = inputs
         rp = dict(region_params or (syn.YCB_REGION_PARAMS if inputs.with_depth else syn.RBOT_REGION_PARAMS))
@@ -241,11 +245,11 @@ class Instance:
                 if camera_of is not None:
                     shared[camera_of[i]] = (cam, dcam)
             mods = []
-            if use_region:
+            if use_region and (kinds is None or "r" in kinds[i]):
                 r = host.RegionModality(api, body, cam, self.region_models[inputs.model_of[i]], depth_camera=dcam, **rp)
                 self.region.append(r)
                 mods.append(r)
-            if use_depth:
+            if use_depth and (kinds is None or "d" in kinds[i]):
                 d = host.DepthModality(api, body, dcam, self.depth_models[inputs.model_of[i]], **dp)
                 self.depth.append(d)
                 mods.append(d)

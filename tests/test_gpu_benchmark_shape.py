@@ -257,6 +257,37 @@ def test_compact_kernels_depth_only(wide, kernel, threads):
             os.environ.pop(k, None)
 
 
+@pytest.mark.parametrize("env,kernel", [({}, "tracking_step_split_pair_kernel"),
+                                        ({"M3T_HIP_NO_SPLIT": "1"}, "tracking_step_lds_pair_kernel"),
+                                        ({"M3T_HIP_NO_PAIR": "1"}, "tracking_step_split_kernel")])
+def test_mixed_batch_through_the_pair_kernels(env, kernel):
+    """bodies with both modalities, with a RegionModality alone and with a DepthModality alone in ONE context: the _pair_
+    kernels decide per body (side by side only where there are two modalities to put side by side)"""
+    inputs = scenes.Inputs(9, 4, n_divides=4, n_models=3, with_depth=True)
+    kinds = ["rd", "r", "d"] * 3
+    ora = util.open_oracle()
+    b = scenes.Instance(ora, inputs, kinds=kinds)
+    os.environ.update(env)
+    try:
+        api = util.open_hip()
+        a = scenes.Instance(api, inputs, kinds=kinds)
+        for inst in (a, b):
+            inst.upload_frame(0)
+            assert inst.tracker.StartModalities(0)
+        for k in range(inputs.n_frames):
+            for inst in (a, b):
+                inst.upload_frame(k)
+                assert inst.tracker.ExecuteTrackingStep(k)
+            assert np.array_equal(np.stack(a.poses()), np.stack(b.poses())), k
+        assert kernel_of(api) == kernel, kernel_of(api)
+        for ra, rb in zip(a.region, b.region):
+            (fa, ba), (fb, bb) = ra.histograms(), rb.histograms()
+            assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
 @pytest.mark.parametrize("env,kernel,shape", [
     ({}, "tracking_step_compact_wide_kernel", [512, 1, 512, 1]),
     ({"M3T_HIP_COMPACT_WIDE": "0"}, "tracking_step_compact_kernel", [512, 1, 256, 1]),
